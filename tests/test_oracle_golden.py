@@ -1,0 +1,139 @@
+"""Pin the CPU oracle to the golden vectors produced by the real reference (tests/golden/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import case_dict
+from oracle import iou_oracle, sola_oracle
+from sola_amd import synth
+
+POS_W, TEMP, ALIGN_W = 1.5, 0.07, 0.3
+
+
+def _run(cfg, sd, B, N, T, L, seed, dtype=torch.float32, taps=None):
+    inp = synth.make_inputs(cfg, B, N, T, L, seed)
+    sm, st = sola_oracle.forward(sd, cfg, inp["object_tokens"], inp["lang_tokens"], dtype=dtype, taps=taps)
+    neg = np.broadcast_to(sd["negative_token.weight"][None], (B,) + sd["negative_token.weight"].shape)
+    ls = sola_oracle.losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W, dtype=dtype)
+    return sm, st, ls
+
+
+@pytest.fixture(scope="module")
+def small_sd():
+    return synth.make_state_dict(synth.SMALL_MODEL_CFG, 42)
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return synth.make_state_dict(synth.DEFAULT_MODEL_CFG, 42)
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_small_forward_taps_losses(small_golden, small_sd, ci):
+    B, N, T, L = [int(v) for v in small_golden["cases"][ci]]
+    g = case_dict(small_golden, ci)
+    taps = {}
+    sm, st, ls = _run(synth.SMALL_MODEL_CFG, small_sd, B, N, T, L, 100 + ci, taps=taps)
+    assert sum(("tap." + k) in g for k in taps) >= 13
+    for k, v in taps.items():
+        if "tap." + k not in g:  # "encoder" duplicates conv5
+            continue
+        ref = g["tap." + k]
+        np.testing.assert_allclose(v.numpy(), ref, rtol=0, atol=2e-4 * max(1.0, np.abs(ref).max()), err_msg=k)
+    np.testing.assert_allclose(sm.numpy(), g["score_map"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(st.numpy(), g["score_tokens"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose([float(ls["total"]), float(ls["bce"]), float(ls["align"])], g["loss"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(ls["neg_argmax"].numpy(), g["neg_argmax"])
+    np.testing.assert_array_equal(sola_oracle.select(sm).numpy(), g["selected"])
+    np.testing.assert_array_equal(sm.argmax(dim=1).numpy(), g["argmax_track"])
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_full_forward_losses(full_golden, full_sd, ci):
+    B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
+    g = case_dict(full_golden, ci)
+    taps = {} if ci in (0, 1) else None
+    sm, st, ls = _run(synth.DEFAULT_MODEL_CFG, full_sd, B, N, T, L, 200 + ci, taps=taps)
+    # 1e-3 is the north-star tolerance.  fp32 evaluation-order noise of this network is ~1e-4 at NS and
+    # ~4e-4 at (T=128,N=128): the reference itself sits that far from a float64 evaluation.
+    np.testing.assert_allclose(sm.numpy(), g["score_map"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(st.numpy(), g["score_tokens"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose([float(ls["total"]), float(ls["bce"]), float(ls["align"])], g["loss"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(ls["neg_argmax"].numpy(), g["neg_argmax"])
+    np.testing.assert_array_equal(sola_oracle.select(sm).numpy(), g["selected"])
+    np.testing.assert_array_equal(sm.argmax(dim=1).numpy(), g["argmax_track"])
+    if taps is not None:
+        for k, v in taps.items():
+            if "tap." + k not in g:
+                continue
+            ref = g["tap." + k]
+            v = v.numpy()
+            if v.ndim == 4:
+                v = v[:, :2]
+            np.testing.assert_allclose(v, ref, rtol=0, atol=2e-4 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+def test_float64_oracle_agrees(full_golden, full_sd):
+    """The float64 evaluation of the same restatement stays within the north-star tolerance of the fp32 reference."""
+    B, N, T, L = [int(v) for v in full_golden["cases"][0]]
+    g = case_dict(full_golden, 0)
+    sm, st, _ = _run(synth.DEFAULT_MODEL_CFG, full_sd, B, N, T, L, 200, dtype=torch.float64)
+    np.testing.assert_allclose(sm.numpy(), g["score_map"], rtol=0, atol=1e-4)
+
+
+def test_grad_norm_dict_restatement(small_golden):
+    g = case_dict(small_golden, 0)
+    grads = {k[len("grad."):]: g[k] for k in g if k.startswith("grad.")}
+    out = sola_oracle.grad_norm_dict(grads, 2)
+    ref = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))
+    assert set(out) == set(ref)
+    for k in ref:
+        assert out[k] == pytest.approx(ref[k], rel=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- IoU
+def test_iou_pairs(iou_golden):
+    A = np.unpackbits(iou_golden["pair_A"], axis=-1)[..., :960]
+    B = np.unpackbits(iou_golden["pair_B"], axis=-1)[..., :960]
+    ref = iou_golden["pair_iou"]
+    inter, union = iou_oracle.iou_matrix(A, B)
+    got = np.array([[iou_oracle.iou_from_counts(int(inter[p, r]), int(union[p, r])) for r in range(B.shape[0])]
+                    for p in range(A.shape[0])])
+    np.testing.assert_array_equal(got, ref)  # bit-exact doubles
+    assert got[3, 5] == 1.0  # empty/empty
+    np.testing.assert_array_equal(got > 0.7, ref > 0.7)
+
+
+def test_iou_tie(iou_golden):
+    a = np.zeros((10, 10), np.uint8)
+    b = np.zeros((10, 10), np.uint8)
+    a[0, :10] = 1
+    b[0, :7] = 1
+    v = iou_oracle.compute_mask_iou(a, b)
+    assert v == float(iou_golden["tie_iou"]) == 0.7
+    assert not (v > 0.7)
+
+
+def test_nearest_resize_index(iou_golden):
+    for i, (h, w, Ho, Wo) in enumerate(iou_golden["resize_sizes"]):
+        np.testing.assert_array_equal(iou_oracle.nearest_index(int(Ho), int(h)), iou_golden[f"resize{i}_row"])
+        np.testing.assert_array_equal(iou_oracle.nearest_index(int(Wo), int(w)), iou_golden[f"resize{i}_col"])
+
+
+def test_masklet_iou(iou_golden):
+    v = iou_oracle.compute_masklet_iou(iou_golden["masklet_A"], iou_golden["masklet_B"])
+    assert v == float(iou_golden["masklet_iou"])
+
+
+def test_dedup_loop(iou_golden):
+    tracks = np.unpackbits(iou_golden["dedup_tracks"], axis=-1)[..., :960]
+    segs = np.unpackbits(iou_golden["dedup_segs"], axis=-1)[..., :640]
+    ids = [int(v) for v in iou_golden["dedup_ids"]]
+    masklets = {pid: tracks[i] for i, pid in enumerate(ids)}
+    prompts = [{"status": int(s), "frame_idx": int(f), "segmentation": segs[r]}
+               for r, (s, f) in enumerate(zip(iou_golden["dedup_status_in"], iou_golden["dedup_frame_idx"]))]
+    n = iou_oracle.dedup_batch(masklets, ids, prompts, 0.7)
+    assert n == int(iou_golden["dedup_n_filtered"])
+    np.testing.assert_array_equal([p["status"] for p in prompts], iou_golden["dedup_status_out"])
+    np.testing.assert_array_equal([p.get("filtered_by", -1) for p in prompts], iou_golden["dedup_filtered_by"])
+    np.testing.assert_array_equal([p.get("filtered_iou", -1.0) for p in prompts], iou_golden["dedup_filtered_iou"])
