@@ -1,0 +1,170 @@
+/*
+ * sola_hip.h — C ABI of libsola_hip.so: the MI355X (gfx950) implementation of SOLA's track-selection hot path.
+ *
+ * The reference (cvlab-kaist/SOLA) has no FFI layer: its boundary is the Python object interface used by
+ * train.py / inference.py / evaluator.py.  The entry points below are what a binding for that
+ * path binds; each cites the reference interface it replaces (paths relative to the reference root).
+ * sola_amd/module.py, sola_amd/loss.py and sola_amd/seg_utils.py are the ctypes bindings that present the
+ * reference's own Python interface on top of this ABI (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *dev* is a device (HBM) pointer owned by the caller;
+ *   - every function returns 0 on success or a negative SolaStatus; sola_last_error() gives the message of the
+ *     last failure on the calling thread; nothing throws across the ABI;
+ *   - all work is enqueued asynchronously on the given hipStream_t (passed as void*; NULL = default stream);
+ *   - a context is re-entrant across contexts but not thread-safe on one context;
+ *   - fp32 row-major tensors; activations are channels-last: object tokens [B,N,T,d], text tokens [B,L,D].
+ */
+#ifndef SOLA_HIP_H
+#define SOLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum SolaStatus {
+    SOLA_OK = 0,
+    SOLA_ERR_ARG = -1,       /* invalid argument / unsupported shape */
+    SOLA_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SOLA_ERR_WEIGHT = -3,    /* unknown weight name, wrong size, or weights missing at forward time */
+    SOLA_ERR_WORKSPACE = -4, /* workspace too small */
+    SOLA_ERR_STATE = -5      /* call sequence error (e.g. backward without a saved forward) */
+} SolaStatus;
+
+/* configs["model"] of the reference (configs/mevis/default.yaml:3-13; consumed at module/module.py:59-63,76,19).
+ * num_heads is hard-coded to 8 in the reference (module/module.py:13-15). */
+typedef struct SolaConfig {
+    int32_t object_token_dim;
+    int32_t lang_token_dim;
+    int32_t n_layers;
+    int32_t max_temporal_length;
+    int32_t n_negative;
+    int32_t n_groups;        /* encoder GroupNorm groups */
+    int32_t n_groups_module; /* alignment-layer GroupNorm groups */
+    int32_t num_heads;
+} SolaConfig;
+
+typedef struct SolaCtx SolaCtx;
+
+const char* sola_last_error(void);
+const char* sola_version(void);
+
+/* ---- context: replaces LanguageAlignedTrackSelectionModule.__init__ / .to(device) (module/module.py:55-110) ---- */
+int sola_ctx_create(const SolaConfig* cfg, int device, SolaCtx** out);
+int sola_ctx_destroy(SolaCtx* ctx);
+
+/* Number of state_dict tensors and their names/sizes, in the reference's state_dict order
+ * (84 entries for the default config: 83 parameters + the Fourier buffer: module/module.py:74-110, tools/attention.py:26-29). */
+int sola_num_weights(const SolaCtx* ctx);
+int sola_weight_info(const SolaCtx* ctx, int index, const char** name, int64_t* numel);
+
+/* Borrow a device pointer for one state_dict tensor (fp32, contiguous).  Replaces load_state_dict / parameter
+ * access (inference.py:33, train.py:46).  The pointer must stay valid until replaced or the ctx is destroyed. */
+int sola_set_weight(SolaCtx* ctx, const char* name, const void* dev_ptr, int64_t numel);
+
+/* Tell the context that weight VALUES changed in place (optimizer step): the standardised conv weights
+ * (module/ws.py:9-13) are recomputed at the next forward.  recompute_every_forward=1 mirrors the reference,
+ * which re-standardises on every call. */
+int sola_weights_changed(SolaCtx* ctx);
+int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
+
+/* ---- forward: replaces LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162) ------------------ */
+size_t sola_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
+int sola_forward(SolaCtx* ctx,
+                 const float* dev_object_tokens, /* [B,N,T,object_token_dim] */
+                 const float* dev_lang_tokens,   /* [B,L,lang_token_dim]     */
+                 int B, int N, int T, int L,
+                 float* dev_score_map,           /* [B,N]                    */
+                 float* dev_score_tokens,        /* [B,N,lang_token_dim]     */
+                 void* dev_workspace, size_t workspace_bytes, void* stream);
+
+/* Location of a named intermediate of the LAST forward inside the workspace (parity tests / debugging).
+ * Names: conv0..conv5 (pre-norm encoder conv outputs [B*N*T_l, C_l]), pe [T',D], lang [B*W,D],
+ * l<i>_obj, l<i>_motion, l<i>_o2l (post-GroupNorm activations [B*N*T', D]). */
+int sola_workspace_tap(const SolaCtx* ctx, const char* name, size_t* byte_offset, int64_t* rows, int64_t* cols);
+
+/* ---- losses: replaces train.py:98-113 (weighted BCE + AlignmentLoss.forward, tools/loss.py:14-58) --------------
+ * dev_neg_tokens is [B,n_neg,D] with neg_batch_stride = n_neg*D, or one [n_neg,D] table shared by every sample with
+ * neg_batch_stride = 0 (train.py:92 repeats negative_token.weight over the batch).
+ * dev_loss3 receives {total, bce, alignment}; dev_neg_argmax (optional, int32 [B,N]) the hardest-negative index.
+ * Scratch: 3*B*N floats. */
+int sola_loss(const float* dev_score_map, const float* dev_score_tokens,
+              const float* dev_labels,     /* [B,N] {0,1} */
+              const float* dev_pos_tokens, /* [B,1,D]     */
+              const float* dev_neg_tokens, int64_t neg_batch_stride,
+              int B, int N, int D, int n_neg,
+              float positive_weight, float temperature, float alignment_weight,
+              float* dev_loss3, int32_t* dev_neg_argmax,
+              void* dev_scratch, size_t scratch_bytes, void* stream);
+
+/* ---- selection: replaces inference.py:59-60 (sigmoid, strict > threshold) ------------------------------------- */
+int sola_select(const float* dev_score_map, int64_t n, float threshold, float* dev_prob, float* dev_pred, void* stream);
+
+/* ---- per-stage entry points (each is one kernel family; used by the parity tests and by sola_forward) ---------- */
+/* module/ws.py:9-13: w [cout,cin,k] -> standardised, re-laid-out [cout, k*cin] (k-major) */
+int sola_ws_standardize(const float* dev_w, int cout, int cin, int k, float* dev_out, void* stream);
+/* C[M,N] = A[M,K] * W[N,K]^T + bias[N] (+ R[M,N]); F.linear (tools/attention.py:63-65,73). K % 4 == 0. */
+int sola_gemm_nt(const float* dev_a, int lda, const float* dev_w, const float* dev_bias, const float* dev_r, int ldr,
+                 float* dev_c, int ldc, int M, int N, int K, void* stream);
+/* channels-last conv1d along T (module/ws.py:14-22): x [R,T_in,cin], w_std [cout,k*cin] -> y [R,T_out,cout] */
+int sola_conv1d_cl(const float* dev_x, const float* dev_wstd, const float* dev_bias, float* dev_y,
+                   int R, int T_in, int cin, int cout, int k, int stride, int pad, void* stream);
+/* GroupNorm over token sets (nn.GroupNorm; module/module.py:76,34,43,49): for instance i the tokens are rows
+ * (i / inner) * outer_stride + (i % inner) * inner_stride + j * tok_stride, j < ntok, of an [*, C] matrix.
+ * y = gn(x) (optionally LeakyReLU(slope)); if dev_pe != NULL also y2 = y + pe[(i % inner)] (module.py:38). */
+int sola_group_norm(const float* dev_x, float* dev_y, float* dev_y2, const float* dev_pe,
+                    const float* dev_gamma, const float* dev_beta,
+                    int n_inst, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tok_stride,
+                    int ntok, int C, int groups, float eps, float leaky_slope, int apply_leaky, void* stream);
+/* softmax(q k^T * scale) v for G groups x H heads (tools/attention.py:66-72).  Row r of group g lives at matrix row
+ * (g / inner) * outer + (g % inner) * inner_stride + r * row_stride (q and o share addressing; k and v share). */
+int sola_attention(const float* dev_q, int ldq, const float* dev_k, int ldk, const float* dev_v, int ldv,
+                   float* dev_o, int ldo, int G, int H, int head_dim, int Sq, int Sk, int inner,
+                   int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
+                   int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, void* stream);
+/* module/module.py:112-128: pe [t_len, D] */
+int sola_pos_encoding(const float* dev_gauss, int D, int t_len, int max_temporal_length, float* dev_pe, void* stream);
+
+/* ---- mask IoU: replaces track_generation/seg_utils.py:128-142 (compute_mask_iou), :109-125 (compute_masklet_iou)
+ * and the prompt-mask nearest resize of generate_tokens_grid.py:269-272 ------------------------------------------
+ * Masks are packed to 1 bit/pixel (words of 32 pixels, row-major over the H*W comparison grid).
+ * elem_type: 0 = uint8, 1 = float32; a pixel is set when its value != 0.  If (h,w) != (H,W) the source is
+ * resampled with ATen's nearest rule while packing.  dev_area receives the per-mask popcount (int64). */
+int64_t sola_mask_words(int H, int W);
+int sola_mask_pack(const void* dev_masks, int elem_type, int n, int h, int w, int H, int W,
+                   uint32_t* dev_bits, int64_t* dev_area, void* stream);
+/* inter[p,r] = popcount(A[a_index(p,r)] & B[r]), union = area_A + area_B - inter.
+ * dev_a_frame (optional, int32 [R]): A holds P masklets of T frames (A index = p*T + frame[r]), which is the
+ * "pred masklet at the prompt's frame" gather of generate_tokens_grid.py:269.  T=1, NULL = plain P x R matrix. */
+int sola_mask_pair_counts(const uint32_t* dev_a_bits, const int64_t* dev_a_area, int P, int T,
+                          const uint32_t* dev_b_bits, const int64_t* dev_b_area, int R,
+                          const int32_t* dev_a_frame, int64_t words,
+                          int64_t* dev_inter, int64_t* dev_union, void* stream);
+/* One call for the common case: A [P,H,W], B [R,h,w] -> inter/union [P,R] (scratch: (P+R)*(words*4+8) bytes). */
+size_t sola_mask_iou_scratch_bytes(int P, int R, int H, int W);
+int sola_mask_iou_matrix(const void* dev_a, const void* dev_b, int elem_type, int P, int R, int H, int W, int h, int w,
+                         int64_t* dev_inter, int64_t* dev_union, void* dev_scratch, size_t scratch_bytes, void* stream);
+
+/* ---- in-library kernel timing (HIP events on the launch stream; used by bench.py's roofline object) ------------ */
+enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
+       SOLA_PROF_ATTN = 1,      /* attn_fwd_f32_kernel */
+       SOLA_PROF_NORM = 2,      /* group_norm_kernel */
+       SOLA_PROF_WS = 3,        /* ws_standardize_kernel */
+       SOLA_PROF_HEAD = 4,      /* score head / loss / select */
+       SOLA_PROF_MISC = 5,      /* pos-encoding, lang concat */
+       SOLA_PROF_IOU_PACK = 6,  /* mask_pack_kernel */
+       SOLA_PROF_IOU_PAIR = 7,  /* mask_pair_kernel */
+       SOLA_PROF_GEMM_SMALL = 8, /* gemm_nt_f32_kernel<64,64> (small grids) */
+       SOLA_PROF_NCAT = 9 };
+int sola_profile_enable(int enable);
+/* Synchronises the recorded events and returns, per category: launches, total milliseconds, algorithmic flops,
+ * algorithmic bytes accumulated since the last reset. Arrays have SOLA_PROF_NCAT entries. */
+int sola_profile_read(int64_t* launches, double* ms, double* flops, double* bytes, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLA_HIP_H */

@@ -1,0 +1,133 @@
+"""ctypes binding of libsola_hip.so (include/sola_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to load, importing a
+compute entry point raises ``SolaLibraryError`` with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsola_hip.so")
+
+
+class SolaLibraryError(RuntimeError):
+    pass
+
+
+class SolaError(RuntimeError):
+    """A libsola_hip call returned a negative status."""
+
+
+class SolaConfig(C.Structure):
+    _fields_ = [
+        ("object_token_dim", C.c_int32),
+        ("lang_token_dim", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("max_temporal_length", C.c_int32),
+        ("n_negative", C.c_int32),
+        ("n_groups", C.c_int32),
+        ("n_groups_module", C.c_int32),
+        ("num_heads", C.c_int32),
+    ]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/sola_hip.h declares
+SIGNATURES = {
+    "sola_last_error": (C.c_char_p, []),
+    "sola_version": (C.c_char_p, []),
+    "sola_ctx_create": (_i, [C.POINTER(SolaConfig), _i, C.POINTER(_vp)]),
+    "sola_ctx_destroy": (_i, [_vp]),
+    "sola_num_weights": (_i, [_vp]),
+    "sola_weight_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64)]),
+    "sola_set_weight": (_i, [_vp, C.c_char_p, _vp, _i64]),
+    "sola_weights_changed": (_i, [_vp]),
+    "sola_set_ws_policy": (_i, [_vp, _i]),
+    "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "sola_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sola_workspace_tap": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_i64)]),
+    "sola_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "sola_select": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
+    "sola_ws_standardize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "sola_gemm_nt": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sola_conv1d_cl": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sola_group_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp]),
+    "sola_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
+    "sola_pos_encoding": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "sola_mask_words": (_i64, [_i, _i]),
+    "sola_mask_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sola_mask_pair_counts": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "sola_mask_iou_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "sola_mask_iou_matrix": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sola_profile_enable": (_i, [_i]),
+    "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
+}
+
+PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64"]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises SolaLibraryError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SolaLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sola_amd/csrc`). sola_amd has no CPU or PyTorch fallback.")
+    try:
+        h = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SolaLibraryError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise SolaLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return h
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().sola_last_error()
+        raise SolaError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SolaError("sola_amd runs on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+
+
+def profile_enable(on=True):
+    check(lib().sola_profile_enable(1 if on else 0), "sola_profile_enable")
+
+
+def profile_read(reset=True):
+    n = len(PROF_CATEGORIES)
+    launches = (_i64 * n)()
+    ms = (C.c_double * n)()
+    flops = (C.c_double * n)()
+    nbytes = (C.c_double * n)()
+    check(lib().sola_profile_read(launches, ms, flops, nbytes, 1 if reset else 0), "sola_profile_read")
+    return {PROF_CATEGORIES[i]: {"launches": int(launches[i]), "ms": float(ms[i]), "flops": float(flops[i]),
+                                 "bytes": float(nbytes[i])} for i in range(n)}

@@ -1,0 +1,248 @@
+// Attention core softmax(q k^T * scale) v in f32 for the three attentions of an alignment layer
+// (tools/attention.py:66-72 called from module/module.py:32,41,47): inter-object (sequence = the N tracks of one
+// (b,t')), motion (sequence = the T' steps of one track) and object->language (all N*T' tokens against W text tokens).
+//
+// The activations stay in ONE layout, [B, N, T', D] token-major; each attention only changes how a (group, row) pair
+// maps to a matrix row (outer/inner/row strides), so no permuted copy is ever materialised.  Heads are column slices.
+//
+// HBM-bound kernel: q, k, v are read once and o written once per (group, head).  One wave (64 lanes) owns a
+// 16-query tile and walks the keys 16 at a time with v_mfma_f32_16x16x4_f32 (exact f32):
+//   S^T = K Q^T   : A = K rows (ds_read_b128 from LDS), B = Q rows (held in registers for the whole kernel).
+//                   Lane l then holds the scores of query (l & 15) against keys 4*(l >> 4)+{0..3}: a softmax row
+//                   lives in one 16-lane column, so max/sum are 3 in-lane ops + 2 xor-shuffles (16, 32).
+//   O^T = V^T P^T : A = V^T (ds_read_b32 from LDS), B = P straight from the score registers (same lane, same
+//                   key slots - no cross-lane movement).  Lane l ends with o[q = l & 15][16*dt + 4*(l >> 4) + {0..3}],
+//                   i.e. one float4 store per 16-wide head-dim tile.
+// Online softmax across 64-key LDS tiles handles any Sk.  Two staging modes:
+//   shared : 4 waves = 4 query tiles of one (group, head); K/V tile staged once per block (obj / obj->lang attention)
+//   private: every wave owns its own (group, head) with Sq, Sk <= 16 (motion attention over T' <= 16 steps)
+#include "kernels.h"
+
+namespace {
+
+struct AttnArgs {
+    const float *q, *k, *v;
+    float* o;
+    int ldq, ldk, ldv, ldo;
+    int G, H, Sq, Sk, inner, nqb;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+};
+
+template <int DH, bool PRIVATE>
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
+    constexpr int NC = DH / 16;   // 16-wide head-dim chunks
+    constexpr int LDK = DH + 8;   // K pitch: ds_read_b128 by 16-lane groups lands on 16 distinct 16-B slots
+    constexpr int LDV = DH + 4;   // V pitch: ds_read_b32, the two 16-lane halves of a 32-lane group are 16 banks apart
+    constexpr int F4 = DH / 4;    // float4 per row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;               // [64][LDK]
+    float* Vs = smem + 64 * LDK;    // [64][LDV]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+
+    int grp, h, qi;
+    bool unit_ok = true;
+    if constexpr (PRIVATE) {
+        const long long unit = (long long)blockIdx.x * 4 + wave;
+        unit_ok = unit < (long long)a.G * a.H;
+        grp = unit_ok ? (int)(unit / a.H) : 0;
+        h = unit_ok ? (int)(unit % a.H) : 0;
+        qi = c16;
+    } else {
+        int b = blockIdx.x;
+        const int qb = b % a.nqb;
+        b /= a.nqb;
+        h = b % a.H;
+        grp = b / a.H;
+        qi = qb * 64 + wave * 16 + c16;
+    }
+    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const bool q_ok = unit_ok && qi < a.Sq;
+
+    // Q fragment (B operand of S^T = K Q^T): lane holds q[qi][16c + 4*g4 + {0..3}], pre-scaled
+    float4 qf[NC];
+    {
+        const float* qp = a.q + (qrow0 + (long long)qi * a.q_rs) * a.ldq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float4 v = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[c] = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+        }
+    }
+
+    f32x4 oacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    constexpr int KT = PRIVATE ? 16 : 64;
+    const int row_base = PRIVATE ? wave * 16 : 0;
+    for (int kt0 = 0; kt0 < a.Sk; kt0 += KT) {
+        const int nrows = min(KT, a.Sk - kt0);
+        const int nrows16 = (nrows + 15) & ~15;
+        __syncthreads();  // the previous tile has been consumed by every wave
+        if constexpr (PRIVATE) {
+            if (unit_ok) {
+                for (int idx = lane; idx < 16 * F4; idx += 64) {
+                    const int r = idx / F4, c4 = idx - r * F4;
+                    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                    if (r < nrows) {
+                        const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
+                        kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+                        vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+                    }
+                    *reinterpret_cast<float4*>(&Ks[(row_base + r) * LDK + c4 * 4]) = kv;
+                    *reinterpret_cast<float4*>(&Vs[(row_base + r) * LDV + c4 * 4]) = vv;
+                }
+            }
+        } else {
+            for (int idx = tid; idx < nrows16 * F4; idx += 256) {
+                const int r = idx / F4, c4 = idx - r * F4;
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                if (r < nrows) {
+                    const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
+                    kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+                    vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+                }
+                *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = kv;
+                *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
+            }
+        }
+        __syncthreads();
+
+        constexpr int NT = KT / 16;
+        const int ntile = nrows16 >> 4;
+        // ---- scores: s[t][r] = q(c16) . k(kt0 + 16t + 4*g4 + r)
+        f32x4 sc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < ntile) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const float* kp = &Ks[(row_base + t * 16 + c16) * LDK + 4 * g4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
+                    if (c & 1) {
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a1, 0, 0, 0);
+                    } else {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a0, 0, 0, 0);
+                    }
+                }
+                const int key0 = kt0 + t * 16 + 4 * g4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < a.Sk) ? (a0[r] + a1[r]) : -INFINITY;
+            } else {
+                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        // ---- online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[t][r] = __expf(sc[t][r] - m_new);
+                rs += sc[t][r];
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* vp = &Vs[(row_base + t * 16 + 4 * g4 + r) * LDV + c16];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[c * 16], sc[t][r], oacc[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (q_ok) {
+        const float inv = 1.f / l_run;
+        float* op = a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(op + c * 16) =
+                make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+    }
+}
+
+template <int DH>
+int launch_dh(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+    constexpr size_t lds = (size_t)64 * ((DH + 8) + (DH + 4)) * sizeof(float);
+    const bool priv = a.Sq <= 16 && a.Sk <= 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (priv) {
+        const long long units = (long long)a.G * a.H;
+        a.nqb = 1;
+        dim3 grid((unsigned)((units + 3) / 4));
+        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true>), grid, dim3(256), lds, s, a);
+    } else {
+        a.nqb = (a.Sq + 63) / 64;
+        const long long blocks = (long long)a.G * a.H * a.nqb;
+        SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+        dim3 grid((unsigned)blocks);
+        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false>), grid, dim3(256), lds, s, a);
+    }
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+}  // namespace
+
+int launch_attention(const AttnDesc& d, hipStream_t s) {
+    SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
+    SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
+    AttnArgs a;
+    a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale;
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    switch (d.DH) {
+        case 128: return launch_dh<128>(a, s);
+        case 64: return launch_dh<64>(a, s);
+        case 32: return launch_dh<32>(a, s);
+        case 16: return launch_dh<16>(a, s);
+        default: sola_set_error("attention: head_dim %d unsupported (16/32/64/128)", d.DH); return SOLA_ERR_ARG;
+    }
+}

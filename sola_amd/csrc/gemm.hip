@@ -1,0 +1,231 @@
+// f32 "NT" GEMM on the gfx950 matrix cores: C[M,N] = A[M,K] * W[N,K]^T + bias (+ residual).
+//
+// Replaces F.linear at tools/attention.py:63-65,73 and, through an implicit im2col gather of the channels-last
+// activations, F.conv1d at module/ws.py:14-22 (k=3 window = 3*Cin contiguous floats per output row, zero-filled at
+// the sequence edges).  Exact f32 arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; there is no
+// xf32/TF32 on gfx950), so results are an fmaf chain per output element.
+//
+// Tiling (wave64): 256 threads = 4 waves in a 2x2 grid; block tile BM x BN x 32, each wave owns (BM/2) x (BN/2) as
+// 32x32 MFMA tiles (16 accumulator registers each).  Operands are staged global -> VGPR -> LDS with 16-byte
+// accesses; the LDS row pitch of 36 floats makes the per-lane ds_read_b128 fragment reads conflict-free
+// (16-lane groups hit 16 distinct 16-byte slots).  One ds_read_b128 per lane feeds four MFMAs: lanes 0-31 take
+// k = 8s+{0..3}, lanes 32-63 take k = 8s+{4..7}; operands A and B use the same k permutation so the sum is unchanged.
+// Double-buffered LDS, one barrier per 32-deep k-tile; the next tile's global loads are in flight during the MFMAs.
+// Up to three problems that share all dimensions run in one launch (q/k/v projections) via blockIdx.z.
+#include "kernels.h"
+
+namespace {
+
+struct GemmArgs {
+    GemmProblem p[3];
+    int M, N, K, lda, ldr, ldc;
+    int conv, T_in, T_out, stride, pad, Cin;
+    int tiles_m, tiles_n, xcd_remap;
+};
+
+constexpr int BK = 32;
+constexpr int LDP = 36;  // LDS row pitch in floats (144 B: 16-byte aligned, conflict-free for b128 fragment reads)
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
+    constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte loads per thread per operand per k-tile
+    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BM][LDP]
+    float* Ws = smem + 2 * BM * LDP;   // [2][BN][LDP]
+
+    const GemmProblem pr = a.p[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // block -> tile.  With 8 XCDs (block b runs on XCD b % 8) keep all column tiles of one row panel on one XCD so
+    // the A panel is fetched into a single L2.
+    int rt, ct;
+    {
+        const int bid = blockIdx.x;
+        if (a.xcd_remap) {
+            const int x = bid & 7, j = bid >> 3;
+            rt = x + 8 * (j / a.tiles_n);
+            ct = j % a.tiles_n;
+        } else {
+            rt = bid / a.tiles_n;
+            ct = bid % a.tiles_n;
+        }
+    }
+    const int m0 = rt * BM, n0 = ct * BN;
+
+    // ---- per-thread load coordinates: 8 lanes cover one 32-float (128 B) row segment
+    const int lr = tid >> 3;
+    const int lk = (tid & 7) << 2;
+    long long a_off[RA];
+    int a_t0[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + lr + 32 * i;
+        a_ok[i] = m < a.M;
+        if (a.conv) {
+            const int r = m / a.T_out;
+            const int to = m - r * a.T_out;
+            a_t0[i] = to * a.stride - a.pad;
+            a_off[i] = (long long)r * a.T_in * a.Cin;
+        } else {
+            a_t0[i] = 0;
+            a_off[i] = (long long)m * a.lda;
+        }
+    }
+    long long w_off[RW];
+    bool w_ok[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int n = n0 + lr + 32 * j;
+        w_ok[j] = n < a.N;
+        w_off[j] = (long long)n * a.K;
+    }
+
+    float4 ra[RA], rw[RW];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + lk;
+        const bool kok = k < a.K;
+        int kk = 0, ci = k;
+        if (a.conv) {
+            kk = k / a.Cin;
+            ci = k - kk * a.Cin;
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            bool ok = a_ok[i] && kok;
+            const float* src;
+            if (a.conv) {
+                const int ti = a_t0[i] + kk;
+                ok = ok && ti >= 0 && ti < a.T_in;
+                src = pr.A + a_off[i] + (long long)ti * a.Cin + ci;
+            } else {
+                src = pr.A + a_off[i] + k;
+            }
+            ra[i] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const bool ok = w_ok[j] && kok;
+            rw[j] = ok ? *reinterpret_cast<const float4*>(pr.W + w_off[j] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<float4*>(&As[(buf * BM + lr + 32 * i) * LDP + lk]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+            *reinterpret_cast<float4*>(&Ws[(buf * BN + lr + 32 * j) * LDP + lk]) = rw[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) << 2;
+    const int nk = (a.K + BK - 1) / BK;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const float* Ab = &As[(buf * BM + wr * (BM / 2) + frag_row) * LDP + frag_k];
+        const float* Wb = &Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP + frag_k];
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDP + ks * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * LDP + ks * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int col_l = lane & 31;
+    const int row_l = (lane >> 5) << 2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * (BN / 2) + j * 32 + col_l;
+        if (n >= a.N) continue;
+        const float bv = pr.bias ? pr.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (m < a.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (pr.R) v += pr.R[(long long)m * a.ldr + n];
+                    pr.C[(long long)m * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
+    GemmArgs a = base;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
+    constexpr size_t lds = (size_t)(BM + BN) * 2 * LDP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, 1, nprob);
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN>), grid, dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+}  // namespace
+
+int launch_gemm(const GemmDesc& d, hipStream_t s) {
+    SOLA_ARG(d.nprob >= 1 && d.nprob <= 3, "gemm: nprob %d", d.nprob);
+    SOLA_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.K % 4 == 0, "gemm: bad dims M=%d N=%d K=%d (K %% 4 == 0 required)", d.M, d.N, d.K);
+    if (d.conv) {
+        SOLA_ARG(d.Cin % 4 == 0 && d.K % d.Cin == 0, "conv gemm: Cin=%d K=%d", d.Cin, d.K);
+    } else {
+        SOLA_ARG(d.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", d.lda);
+    }
+    GemmArgs a;
+    for (int i = 0; i < 3; ++i) a.p[i] = d.p[i < d.nprob ? i : 0];
+    a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
+    a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
+    a.tiles_m = a.tiles_n = a.xcd_remap = 0;
+    const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
+    const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
+    SolaProfScope prof(big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
+                       4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
+    if (big) return launch_tile<128, 128>(a, d.nprob, s);
+    return launch_tile<64, 64>(a, d.nprob, s);
+}

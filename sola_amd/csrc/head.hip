@@ -1,0 +1,191 @@
+// Score head (module/module.py:152-160), training losses (train.py:98-113 with tools/loss.py:29-56) and the
+// inference-time selection (inference.py:59-60).  Everything here is [N, T']-sized after one [T',D].[D] matvec per
+// track, so one 256-thread block per (sample, track) with wave-shuffle reductions is enough; the mean over B*N is
+// a second single-block kernel with a fixed summation order (deterministic, no atomics).
+#include "kernels.h"
+
+namespace {
+
+struct HeadArgs {
+    const float* x;
+    const float* lbar;
+    float* score_map;
+    float* score_tokens;
+    int N, Tp, D;
+};
+
+// score_logits[t] = x[t,:] . mean_w(lang)   (== mean_w(x . lang_w), module.py:152-153)
+// a = softmax_t(score_logits); score_tokens = sum_t a_t x[t,:]; score_map = score_tokens . mean_w(lang)
+__global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
+    extern __shared__ float sh[];
+    float* logits = sh;               // [Tp]
+    float* red = sh + ((a.Tp + 3) & ~3);
+    const int bn = blockIdx.x;
+    const int b = bn / a.N;
+    const int d4n = a.D >> 2;
+    const float4* xb = reinterpret_cast<const float4*>(a.x + (long long)bn * a.Tp * a.D);
+    const float4* lb = reinterpret_cast<const float4*>(a.lbar + (long long)b * a.D);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < a.Tp; t += 4) {
+        float s = 0.f;
+        for (int i = lane; i < d4n; i += 64) {
+            const float4 xv = xb[(long long)t * d4n + i], lv = lb[i];
+            s += (xv.x * lv.x + xv.y * lv.y) + (xv.z * lv.z + xv.w * lv.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) logits[t] = s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = 0; t < a.Tp; ++t) mx = fmaxf(mx, logits[t]);
+    float den = 0.f;
+    for (int t = 0; t < a.Tp; ++t) den += expf(logits[t] - mx);
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.Tp; t += 256) logits[t] = expf(logits[t] - mx) / den;
+    __syncthreads();
+    float part = 0.f;
+    float4* out = reinterpret_cast<float4*>(a.score_tokens + (long long)bn * a.D);
+    for (int i = threadIdx.x; i < d4n; i += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < a.Tp; ++t) {
+            const float w = logits[t];
+            const float4 xv = xb[(long long)t * d4n + i];
+            acc.x += xv.x * w; acc.y += xv.y * w; acc.z += xv.z * w; acc.w += xv.w * w;
+        }
+        out[i] = acc;
+        const float4 lv = lb[i];
+        part += (acc.x * lv.x + acc.y * lv.y) + (acc.z * lv.z + acc.w * lv.w);
+    }
+    const float score = block_sum_256(part, red);
+    if (threadIdx.x == 0) a.score_map[bn] = score;
+}
+
+struct LossArgs {
+    const float *score_map, *score_tokens, *labels, *pos, *neg;
+    long long neg_batch_stride;
+    int N, D, n_neg;
+    float pos_w, temp_scale;
+    float* terms;
+    int32_t* neg_argmax;
+};
+
+__device__ __forceinline__ float bce_logits(float x, float y) {
+    // F.binary_cross_entropy_with_logits: max(x,0) - x*y + log(1 + exp(-|x|))
+    return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a) {
+    extern __shared__ float sh[];
+    float* negl = sh;  // [n_neg]
+    float* red = sh + ((a.n_neg + 3) & ~3);
+    const int bn = blockIdx.x;
+    const int b = bn / a.N;
+    const int d4n = a.D >> 2;
+    const float4* tok = reinterpret_cast<const float4*>(a.score_tokens + (long long)bn * a.D);
+    const float4* pos = reinterpret_cast<const float4*>(a.pos + (long long)b * a.D);
+    const float* negb = a.neg + (long long)b * a.neg_batch_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float p = 0.f;
+    for (int i = threadIdx.x; i < d4n; i += 256) {
+        const float4 tv = tok[i], pv = pos[i];
+        p += (tv.x * pv.x + tv.y * pv.y) + (tv.z * pv.z + tv.w * pv.w);
+    }
+    const float pos_logit = block_sum_256(p, red) * a.temp_scale;  // tools/loss.py:29-32
+    for (int m = wave; m < a.n_neg; m += 4) {
+        const float4* nv = reinterpret_cast<const float4*>(negb + (long long)m * a.D);
+        float s = 0.f;
+        for (int i = lane; i < d4n; i += 64) {
+            const float4 tv = tok[i], v = nv[i];
+            s += (tv.x * v.x + tv.y * v.y) + (tv.z * v.z + tv.w * v.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) negl[m] = s * a.temp_scale;  // tools/loss.py:33-36
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float y = a.labels[bn];
+        const float x = a.score_map[bn];
+        const float w = y > 0.f ? a.pos_w : 1.f;  // train.py:98-99
+        int arg = 0;
+        float best = negl[0];
+        for (int m = 1; m < a.n_neg; ++m)  // torch.argmax: first maximum (tools/loss.py:40)
+            if (negl[m] > best) { best = negl[m]; arg = m; }
+        float neg_sum = 0.f;
+        for (int m = 0; m < a.n_neg; ++m) neg_sum += bce_logits(negl[m], m == arg ? (1.f - y) : 0.f);
+        a.terms[(long long)bn * 3 + 0] = w * bce_logits(x, y);
+        a.terms[(long long)bn * 3 + 1] = bce_logits(pos_logit, y);
+        a.terms[(long long)bn * 3 + 2] = neg_sum;
+        if (a.neg_argmax) a.neg_argmax[bn] = arg;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* terms, int n, int n_neg, float pos_w,
+                                                          float align_w, float* loss3) {
+    __shared__ float red[4];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        s0 += terms[(long long)i * 3 + 0];
+        s1 += terms[(long long)i * 3 + 1];
+        s2 += terms[(long long)i * 3 + 2];
+    }
+    s0 = block_sum_256(s0, red);
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+        const float bce = s0 / (float)n;                                               // mean over B*N (train.py:100)
+        const float align = pos_w * (s1 / (float)n) + s2 / ((float)n * (float)n_neg);  // tools/loss.py:45-56
+        loss3[0] = bce + align_w * align;                                              // train.py:113
+        loss3[1] = bce;
+        loss3[2] = align;
+    }
+}
+
+__global__ void select_kernel(const float* score, long long n, float thr, float* prob, float* pred) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p = 1.f / (1.f + expf(-score[i]));
+    if (prob) prob[i] = p;
+    if (pred) pred[i] = p > thr ? 1.f : 0.f;  // strict > (inference.py:60)
+}
+
+}  // namespace
+
+int launch_score_head(const HeadDesc& d, hipStream_t s) {
+    SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.Tp > 0, "score_head: bad sizes");
+    HeadArgs a{d.x, d.lbar, d.score_map, d.score_tokens, d.N, d.Tp, d.D};
+    const size_t lds = (((size_t)d.Tp + 3) & ~(size_t)3) * 4 + 16;
+    SOLA_ARG(lds <= 60000, "score_head: T'=%d too long", d.Tp);
+    const double elems = (double)d.B * d.N * d.Tp * d.D;
+    SolaProfScope prof(SOLA_PROF_HEAD, s, 4.0 * elems, 4.0 * elems + 4.0 * d.B * d.N * d.D);
+    hipLaunchKernelGGL(score_head_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_loss(const LossDesc& d, hipStream_t s) {
+    SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.n_neg > 0 && d.n_neg < 8192, "loss: bad sizes");
+    LossArgs a{d.score_map, d.score_tokens, d.labels, d.pos, d.neg, d.neg_batch_stride, d.N, d.D, d.n_neg,
+               d.pos_w, d.temp_scale, d.terms, d.neg_argmax};
+    const size_t lds = (((size_t)d.n_neg + 3) & ~(size_t)3) * 4 + 16;
+    {
+        SolaProfScope prof(SOLA_PROF_HEAD, s, 2.0 * d.B * d.N * (double)d.D * (d.n_neg + 1),
+                           4.0 * d.B * d.N * (double)d.D);
+        hipLaunchKernelGGL(loss_terms_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
+        SOLA_LAUNCH_CHECK();
+    }
+    {
+        SolaProfScope prof(SOLA_PROF_HEAD, s, 0, 12.0 * d.B * d.N);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, d.terms, d.B * d.N, d.n_neg, d.pos_w,
+                           d.align_w, d.loss3);
+        SOLA_LAUNCH_CHECK();
+    }
+    return SOLA_OK;
+}
+
+int launch_select(const float* score, long long n, float thr, float* prob, float* pred, hipStream_t s) {
+    SOLA_ARG(n > 0, "select: n=%lld", n);
+    SolaProfScope prof(SOLA_PROF_HEAD, s, 0, 12.0 * n);
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, score, n, thr, prob, pred);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}

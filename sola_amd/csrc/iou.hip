@@ -1,0 +1,182 @@
+// Pairwise mask IoU for the track de-duplication predicate (track_generation/seg_utils.py:128-142 compute_mask_iou,
+// :109-125 compute_masklet_iou; call sites generate_tokens_grid.py:266-278, generate_tokens_gdino.py:288-300).
+//
+// The reference evaluates sum(A*B) and sum(A+B) on float {0,1} images, one pair per call, with two host syncs per
+// pair.  Those sums are exact integers (< 2^24), so the predicate is integer popcount arithmetic:
+//   1. mask_pack : every mask is read ONCE from HBM (the only large traffic: (P+R)*H*W bytes), thresholded (!= 0),
+//                  optionally resampled with ATen's nearest rule (generate_tokens_grid.py:271-272), and written as
+//                  1 bit/pixel together with its area (popcount).  Pure HBM-bound byte streaming.
+//   2. mask_pair : inter[p,r] = popcount(Abits & Bbits) over 1/8-size L2-resident bit rows; union = |A|+|B|-inter.
+// Counts are int64 and order-independent (integer adds), so results are bit-exact and deterministic.
+#include "kernels.h"
+
+namespace {
+
+struct PackArgs {
+    const void* src;
+    uint32_t* bits;
+    unsigned long long* area;
+    int h, w, H, W;
+    long long hw_src, HW, words;
+    float sy, sx;
+    int identity;
+};
+
+template <typename T>
+__device__ __forceinline__ bool is_set(T v) { return v != (T)0; }
+
+// One lane packs 16 consecutive destination pixels; lane pairs are OR-combined into one 32-bit word.
+template <typename T>
+__global__ __launch_bounds__(256) void mask_pack_kernel(const PackArgs a) {
+    __shared__ int red[4];
+    const int n = blockIdx.y;
+    const long long run = (long long)blockIdx.x * 256 + threadIdx.x;  // 16-pixel run index inside this mask
+    const long long p0 = run * 16;
+    const T* src = reinterpret_cast<const T*>(a.src) + (long long)n * a.hw_src;
+    unsigned bits = 0;
+    if (p0 < a.HW) {
+        if (a.identity && p0 + 16 <= a.HW && (a.hw_src * (long long)sizeof(T)) % 16 == 0 &&
+            (reinterpret_cast<uintptr_t>(a.src) & 15) == 0) {
+            if constexpr (sizeof(T) == 1) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + p0);
+                const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bits |= (((wv[j] >> (8 * i)) & 0xffu) != 0u ? 1u : 0u) << (4 * j + i);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + p0 + 4 * j);
+                    bits |= (v.x != 0.f ? 1u : 0u) << (4 * j) | (v.y != 0.f ? 1u : 0u) << (4 * j + 1) |
+                            (v.z != 0.f ? 1u : 0u) << (4 * j + 2) | (v.w != 0.f ? 1u : 0u) << (4 * j + 3);
+                }
+            }
+        } else {
+            int y = (int)(p0 / a.W);
+            int x = (int)(p0 - (long long)y * a.W);
+            for (int i = 0; i < 16; ++i) {
+                if (p0 + i >= a.HW) break;
+                int sy = y, sx = x;
+                if (!a.identity) {
+                    // ATen nearest: min(floor(dst * float(in/out)), in - 1), product in fp32
+                    sy = a.h == a.H ? y : min((int)floorf((float)y * a.sy), a.h - 1);
+                    sx = a.w == a.W ? x : min((int)floorf((float)x * a.sx), a.w - 1);
+                }
+                bits |= (is_set(src[(long long)sy * a.w + sx]) ? 1u : 0u) << i;
+                if (++x == a.W) { x = 0; ++y; }
+            }
+        }
+    }
+    const unsigned other = __shfl_xor(bits, 1, 64);
+    if ((threadIdx.x & 1) == 0) {
+        const long long word = run >> 1;
+        if (word < a.words) a.bits[(long long)n * a.words + word] = bits | (other << 16);
+    }
+    int cnt = __popc(bits);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = red[0] + red[1] + red[2] + red[3];
+        if (tot) atomicAdd(&a.area[n], (unsigned long long)tot);
+    }
+}
+
+struct PairArgs {
+    const uint32_t *a_bits, *b_bits;
+    const long long *a_area, *b_area;
+    const int32_t* a_frame;
+    long long words;
+    int P, T, R;
+    long long *inter, *uni;
+};
+
+constexpr int PB = 4;  // A masks per block (share the B words)
+
+__global__ __launch_bounds__(256) void mask_pair_kernel(const PairArgs a) {
+    __shared__ int red[4][PB];
+    const int r = blockIdx.x;
+    const int pbase = blockIdx.y * PB;
+    const int frame = a.a_frame ? a.a_frame[r] : 0;
+    const uint32_t* bw = a.b_bits + (long long)r * a.words;
+    const uint32_t* aw[PB];
+    int np = 0;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int p = min(pbase + j, a.P - 1);
+        aw[j] = a.a_bits + ((long long)p * a.T + frame) * a.words;
+        if (pbase + j < a.P) np = j + 1;
+    }
+    int cnt[PB] = {0, 0, 0, 0};
+    const long long w4 = a.words >> 2;
+    const bool vec_ok = (a.words & 3) == 0;  // rows stay 16-byte aligned
+    if (vec_ok) {
+        for (long long i = threadIdx.x; i < w4; i += 256) {
+            const uint4 b = reinterpret_cast<const uint4*>(bw)[i];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const uint4 v = reinterpret_cast<const uint4*>(aw[j])[i];
+                cnt[j] += __popc(v.x & b.x) + __popc(v.y & b.y) + __popc(v.z & b.z) + __popc(v.w & b.w);
+            }
+        }
+    } else {
+        for (long long i = threadIdx.x; i < a.words; i += 256) {
+            const uint32_t b = bw[i];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) cnt[j] += __popc(aw[j][i] & b);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        int c = cnt[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+        const int j = threadIdx.x, p = pbase + j;
+        const long long in = (long long)red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        a.inter[(long long)p * a.R + r] = in;
+        a.uni[(long long)p * a.R + r] = a.a_area[(long long)p * a.T + frame] + a.b_area[r] - in;  // sum(A+B) - inter
+    }
+}
+
+}  // namespace
+
+int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
+                     long long* area, hipStream_t s) {
+    SOLA_ARG(n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "mask_pack: bad sizes");
+    SOLA_ARG(elem_type == 0 || elem_type == 1, "mask_pack: elem_type %d (0=u8, 1=f32)", elem_type);
+    SOLA_ARG(n <= 65535, "mask_pack: n=%d exceeds 65535 masks per call", n);
+    PackArgs a;
+    a.src = masks; a.bits = bits; a.area = reinterpret_cast<unsigned long long*>(area);
+    a.h = h; a.w = w; a.H = H; a.W = W;
+    a.hw_src = (long long)h * w; a.HW = (long long)H * W; a.words = (a.HW + 31) / 32;
+    a.sy = (float)h / (float)H; a.sx = (float)w / (float)W;
+    a.identity = (h == H && w == W) ? 1 : 0;
+    SOLA_HIP(hipMemsetAsync(area, 0, sizeof(long long) * n, s));
+    const long long runs = (a.HW + 15) / 16;
+    const unsigned blocks = (unsigned)((runs + 255) / 256);
+    const double src_bytes = (double)n * h * w * (elem_type ? 4 : 1);
+    SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, src_bytes + (double)n * a.words * 4);
+    if (elem_type == 0)
+        hipLaunchKernelGGL(mask_pack_kernel<uint8_t>, dim3(blocks, n), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(mask_pack_kernel<float>, dim3(blocks, n), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_mask_pair(const uint32_t* a_bits, const long long* a_area, int P, int T, const uint32_t* b_bits,
+                     const long long* b_area, int R, const int32_t* a_frame, long long words, long long* inter,
+                     long long* uni, hipStream_t s) {
+    SOLA_ARG(P > 0 && R > 0 && T > 0 && words > 0, "mask_pair: bad sizes");
+    PairArgs a{a_bits, b_bits, a_area, b_area, a_frame, words, P, T, R, inter, uni};
+    SolaProfScope prof(SOLA_PROF_IOU_PAIR, s, 0, 4.0 * words * ((double)R + (double)R * P));
+    hipLaunchKernelGGL(mask_pair_kernel, dim3(R, (P + PB - 1) / PB), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}

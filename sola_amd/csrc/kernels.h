@@ -1,0 +1,88 @@
+// Internal launcher interface shared by api.cpp and the kernel translation units.
+#pragma once
+#include "common.h"
+
+// ---- GEMM (gemm.hip): C = A * W^T + bias (+R), f32 MFMA ------------------------------------------------------
+struct GemmProblem {
+    const float* A;     // [M, K] rows (plain) or the conv source x [R*T_in, Cin]
+    const float* W;     // [N, K]
+    const float* bias;  // [N] or null
+    const float* R;     // [M, N] residual or null
+    float* C;           // [M, N]
+};
+struct GemmDesc {
+    GemmProblem p[3];
+    int nprob;  // 1..3 problems sharing every dimension (blockIdx.z selects)
+    int M, N, K;
+    int lda, ldr, ldc;  // ldw == K
+    // implicit im2col for the k=3 channels-last conv: row m = (r, t_out); k = kk*Cin + ci
+    int conv;  // 0: plain; 1: gather window
+    int T_in, T_out, stride, pad, Cin;
+};
+int launch_gemm(const GemmDesc& d, hipStream_t s);
+
+// ---- attention core (attn.hip) ---------------------------------------------------------------------------------
+struct AttnDesc {
+    const float *q, *k, *v;
+    float* o;
+    int ldq, ldk, ldv, ldo;
+    int G, H, DH, Sq, Sk, inner;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+};
+int launch_attention(const AttnDesc& d, hipStream_t s);
+
+// ---- normalisation / elementwise (norm.hip) --------------------------------------------------------------------
+struct WsLayer {
+    const float* w;  // [cout, cin, k]
+    float* out;      // [cout, k*cin]
+    int cout, cin, k;
+};
+int launch_ws_standardize(const WsLayer* layers, int n_layers, hipStream_t s);
+
+struct GroupNormDesc {
+    const float* x;
+    float* y;
+    float* y2;        // optional y + pe
+    const float* pe;  // [inner, C] when y2 != null
+    const float *gamma, *beta;
+    int n_inst, inner;
+    long long outer_stride, inner_stride, tok_stride;
+    int ntok, C, groups;
+    float eps, slope;
+    int leaky;
+};
+int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
+int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);
+// lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
+int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,
+                       hipStream_t s);
+
+// ---- score head + losses (head.hip) ----------------------------------------------------------------------------
+struct HeadDesc {
+    const float* x;     // [B, N, Tp, D]
+    const float* lbar;  // [B, D]
+    float* score_map;   // [B, N]
+    float* score_tokens;  // [B, N, D]
+    int B, N, Tp, D;
+};
+int launch_score_head(const HeadDesc& d, hipStream_t s);
+struct LossDesc {
+    const float *score_map, *score_tokens, *labels, *pos, *neg;
+    long long neg_batch_stride;  // 0 when the same negatives serve every sample
+    int B, N, D, n_neg;
+    float pos_w, temp_scale, align_w;
+    float* terms;  // [B*N, 3] scratch
+    float* loss3;
+    int32_t* neg_argmax;  // optional
+};
+int launch_loss(const LossDesc& d, hipStream_t s);
+int launch_select(const float* score, long long n, float thr, float* prob, float* pred, hipStream_t s);
+
+// ---- mask IoU (iou.hip) ----------------------------------------------------------------------------------------
+int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
+                     long long* area, hipStream_t s);
+int launch_mask_pair(const uint32_t* a_bits, const long long* a_area, int P, int T, const uint32_t* b_bits,
+                     const long long* b_area, int R, const int32_t* a_frame, long long words, long long* inter,
+                     long long* uni, hipStream_t s);

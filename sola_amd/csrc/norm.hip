@@ -1,0 +1,217 @@
+// HBM-bound elementwise / reduction kernels of the track-selection path:
+//   ws_standardize  : module/ws.py:9-13   per-out-channel weight standardisation (+ re-layout to [cout][k][cin])
+//   group_norm      : nn.GroupNorm at module/module.py:76-92 (encoder, + LeakyReLU) and :34,43,49 (alignment layer)
+//   pos_encoding    : module/module.py:112-128
+//   lang_concat     : module/module.py:146-147 (text tokens ++ negative tokens) and the mean over W of :152-153
+// All reductions are wave-shuffle + LDS trees with a fixed order (deterministic, no atomics).
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight standardisation: one 256-thread block per output channel, the channel's cin*k weights stay in registers
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WS_MAX_LAYERS = 8;
+constexpr int WS_MAX_PER_THREAD = 16;  // cin*k <= 4096
+struct WsArgs {
+    WsLayer layer[WS_MAX_LAYERS];
+    int first_block[WS_MAX_LAYERS + 1];
+    int n_layers;
+};
+
+__global__ __launch_bounds__(256) void ws_standardize_kernel(const WsArgs a) {
+    __shared__ float red[4];
+    int li = 0;
+    while (li + 1 < a.n_layers && (int)blockIdx.x >= a.first_block[li + 1]) ++li;
+    const WsLayer L = a.layer[li];
+    const int co = blockIdx.x - a.first_block[li];
+    const int n = L.cin * L.k;
+    const float* w = L.w + (long long)co * n;
+    float v[WS_MAX_PER_THREAD];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < WS_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        v[i] = idx < n ? w[idx] : 0.f;
+        s += v[i];
+    }
+    const float mean = block_sum_256(s, red) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < WS_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const float c = idx < n ? v[i] - mean : 0.f;
+        v[i] = c;
+        q += c * c;
+    }
+    const float var = block_sum_256(q, red) / (float)(n - 1);  // torch.std: unbiased
+    const float denom = sqrtf(var) + 1e-5f;                    // eps is added to the std (ws.py:11)
+    float* out = L.out + (long long)co * n;
+#pragma unroll
+    for (int i = 0; i < WS_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < n) {
+            const int ci = idx / L.k, kk = idx - ci * L.k;  // source layout [cin][k]
+            out[kk * L.cin + ci] = v[i] / denom;            // GEMM layout   [k][cin]
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm over (tokens x channels-of-group): one block per (instance, group); three passes over an L2-resident set
+// ---------------------------------------------------------------------------------------------------------------
+struct GnArgs {
+    const float* x;
+    float* y;
+    float* y2;
+    const float* pe;
+    const float *gamma, *beta;
+    int inner;
+    long long outer_stride, inner_stride, tok_stride;
+    int ntok, C, cg, groups;
+    float eps, slope;
+    int leaky;
+};
+
+__global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
+    __shared__ float red[4];
+    const int g = blockIdx.y;
+    const int inst = blockIdx.x;
+    const int f4 = a.cg >> 2;                 // float4 per token slice
+    const int lpt = f4;                       // lanes per token
+    const int tpp = 256 / lpt;                // tokens per pass
+    const int tl = threadIdx.x / lpt;         // token slot of this thread
+    const int c4 = threadIdx.x - tl * lpt;    // float4 index inside the slice
+    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const int ch = g * a.cg + c4 * 4;
+    const bool active = tl < tpp;
+    const float cnt = (float)a.ntok * (float)a.cg;
+
+    float s = 0.f;
+    if (active)
+        for (int t = tl; t < a.ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    const float mean = block_sum_256(s, red) / cnt;
+    float q = 0.f;
+    if (active)
+        for (int t = tl; t < a.ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float var = block_sum_256(q, red) / cnt;  // biased, as nn.GroupNorm
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    if (!active) return;
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)(inst % a.inner) * a.C + ch);
+    for (int t = tl; t < a.ntok; t += tpp) {
+        const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+        const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+        float4 o;
+        o.x = (v.x - mean) * rstd * ga.x + be.x;
+        o.y = (v.y - mean) * rstd * ga.y + be.y;
+        o.z = (v.z - mean) * rstd * ga.z + be.z;
+        o.w = (v.w - mean) * rstd * ga.w + be.w;
+        if (a.leaky) {
+            o.x = o.x >= 0.f ? o.x : o.x * a.slope;
+            o.y = o.y >= 0.f ? o.y : o.y * a.slope;
+            o.z = o.z >= 0.f ? o.z : o.z * a.slope;
+            o.w = o.w >= 0.f ? o.w : o.w * a.slope;
+        }
+        *reinterpret_cast<float4*>(a.y + off) = o;
+        if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pos_encoding_kernel(const float* __restrict__ gauss, int half, int t_len, float max_len, float* pe) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t_len * half) return;
+    const int t = i / half, j = i - t * half;
+    // module.py:123-127: (t / max_len) @ G, then * 2*pi (the python double is applied as an fp32 scalar), sin | cos
+    const float arg = ((float)t / max_len) * gauss[j] * 6.283185307179586f;
+    pe[(long long)t * 2 * half + j] = sinf(arg);
+    pe[(long long)t * 2 * half + half + j] = cosf(arg);
+}
+
+// lang_cat[b, w, :] and lbar[b, :] = mean_w lang_cat[b, w, :]; one thread per (b, float4 column)
+__global__ void lang_concat_kernel(const float* __restrict__ lang, const float* __restrict__ neg, float* out,
+                                   float* lbar, int B, int L, int n_neg, int D) {
+    const int d4 = D >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d4) return;
+    const int b = i / d4, c = (i - b * d4) * 4;
+    const int W = L + n_neg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < W; ++w) {
+        const float4 v = w < L ? *reinterpret_cast<const float4*>(lang + ((long long)b * L + w) * D + c)
+                               : *reinterpret_cast<const float4*>(neg + (long long)(w - L) * D + c);
+        *reinterpret_cast<float4*>(out + ((long long)b * W + w) * D + c) = v;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float inv = 1.f / (float)W;
+    *reinterpret_cast<float4*>(lbar + (long long)b * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+}  // namespace
+
+int launch_ws_standardize(const WsLayer* layers, int n_layers, hipStream_t s) {
+    SOLA_ARG(n_layers >= 1 && n_layers <= WS_MAX_LAYERS, "ws: %d layers", n_layers);
+    WsArgs a;
+    a.n_layers = n_layers;
+    int blocks = 0;
+    double elems = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        SOLA_ARG(layers[i].cin * layers[i].k <= 256 * WS_MAX_PER_THREAD && layers[i].cin * layers[i].k >= 2,
+                 "ws: cin*k = %d unsupported (2..%d)", layers[i].cin * layers[i].k, 256 * WS_MAX_PER_THREAD);
+        a.layer[i] = layers[i];
+        a.first_block[i] = blocks;
+        blocks += layers[i].cout;
+        elems += (double)layers[i].cout * layers[i].cin * layers[i].k;
+    }
+    a.first_block[n_layers] = blocks;
+    SolaProfScope prof(SOLA_PROF_WS, s, 6.0 * elems, 8.0 * elems);
+    hipLaunchKernelGGL(ws_standardize_kernel, dim3(blocks), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
+    SOLA_ARG(d.groups > 0 && d.C % d.groups == 0, "group_norm: C=%d groups=%d", d.C, d.groups);
+    const int cg = d.C / d.groups;
+    SOLA_ARG(cg % 4 == 0 && cg / 4 <= 256, "group_norm: channels per group %d must be a multiple of 4 and <= 1024", cg);
+    SOLA_ARG(d.n_inst > 0 && d.ntok > 0 && d.inner > 0 && d.groups <= 65535, "group_norm: bad sizes");
+    SOLA_ARG(d.y2 == nullptr || d.pe != nullptr, "group_norm: y2 needs pe");
+    GnArgs a;
+    a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
+    a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky;
+    const double elems = (double)d.n_inst * d.ntok * d.C;
+    SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);
+    hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s) {
+    SOLA_ARG(D % 2 == 0 && t_len > 0, "pos_encoding: D=%d t_len=%d", D, t_len);
+    const int half = D / 2, n = t_len * half;
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (n * 2 + half));
+    hipLaunchKernelGGL(pos_encoding_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gauss, half, t_len, (float)max_len, pe);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,
+                       hipStream_t s) {
+    SOLA_ARG(D % 4 == 0 && B > 0 && L >= 0 && n_neg >= 0 && L + n_neg > 0, "lang_concat: bad sizes");
+    const int n = B * (D / 4);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * B * (L + n_neg) * D);
+    hipLaunchKernelGGL(lang_concat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, lang, neg, out, lbar, B, L, n_neg, D);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}

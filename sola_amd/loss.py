@@ -1,0 +1,57 @@
+"""Drop-in for ``tools/loss.py`` (AlignmentLoss) and the loss assembly of ``train.py:98-113`` on libsola_hip.so."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ._lib import SolaError, check, current_stream, lib, ptr, require_cuda
+
+
+def track_selection_losses(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight=1.5,
+                           temperature=0.07, alignment_weight=0.3, return_argmax=False):
+    """One fused evaluation of train.py:98-113: weighted BCE on the logits, AlignmentLoss, and their sum.
+
+    score_map [B,N], score_tokens [B,N,D], labels [B,N], pos_tokens [B,1,D]; neg_tokens [B,n_neg,D] or a
+    shared [n_neg,D] table (what train.py:92 builds by repeating ``negative_token.weight``).
+    Returns a float32 tensor ``[total, bce, alignment]`` on the device (no host sync)."""
+    require_cuda(score_map, score_tokens, labels, pos_tokens, neg_tokens)
+    if torch.is_grad_enabled() and (score_map.requires_grad or score_tokens.requires_grad or neg_tokens.requires_grad):
+        raise SolaError("sola_amd: differentiable losses are not built yet; use torch.no_grad(). No PyTorch fallback.")
+    B, N = score_map.shape
+    D = score_tokens.shape[-1]
+    f = lambda t: t.detach().to(torch.float32).contiguous()
+    sm, st, lb, ps, ng = f(score_map), f(score_tokens), f(labels), f(pos_tokens), f(neg_tokens)
+    if ps.numel() != B * D:
+        raise SolaError("pos_tokens must be [B,1,D] (n_pos must be 1, tools/loss.py:24)")
+    if ng.dim() == 2:
+        n_neg, stride = ng.shape[0], 0
+    else:
+        if ng.shape[0] != B:
+            raise SolaError("neg_tokens batch dimension mismatch")
+        n_neg, stride = ng.shape[1], ng.shape[1] * D
+    dev = sm.device
+    loss3 = torch.empty(3, device=dev, dtype=torch.float32)
+    argmax = torch.empty((B, N), device=dev, dtype=torch.int32) if return_argmax else None
+    scratch = torch.empty(B * N * 3, device=dev, dtype=torch.float32)
+    check(lib().sola_loss(ptr(sm), ptr(st), ptr(lb), ptr(ps), ptr(ng), stride, B, N, D, n_neg, float(positive_weight),
+                          float(temperature), float(alignment_weight), ptr(loss3), ptr(argmax), ptr(scratch),
+                          scratch.numel() * 4, current_stream(dev)), "sola_loss")
+    return (loss3, argmax) if return_argmax else loss3
+
+
+class AlignmentLoss(nn.Module):
+    """tools/loss.py:4-58.  ``temperature`` stays a Parameter for interface parity; the reference never
+    optimises it (train.py:44-49), so its value is read on the host at call time."""
+
+    def __init__(self, positive_weight: float = 1.0, temperature: float = 0.07) -> None:
+        super().__init__()
+        self.positive_weight = positive_weight
+        self.temperature = nn.Parameter(torch.tensor(temperature))
+
+    def forward(self, object_tokens, labels, pos_tokens, neg_tokens):
+        assert pos_tokens.shape[1] == 1, "n_pos must be 1"
+        zeros = torch.zeros(labels.shape, device=object_tokens.device, dtype=torch.float32)
+        loss3 = track_selection_losses(zeros, object_tokens, labels, pos_tokens, neg_tokens,
+                                       positive_weight=self.positive_weight, temperature=float(self.temperature.detach()),
+                                       alignment_weight=0.0)
+        return loss3[2]

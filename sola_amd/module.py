@@ -1,0 +1,193 @@
+"""Drop-in for the reference's ``module/module.py``: same class name, constructor dict, forward signature,
+attributes and state_dict keys, with the numerics running in libsola_hip.so on the MI355X.
+
+``torch`` is used for parameter storage, device memory and the current stream only.  The standard
+``nn.Conv1d`` / ``nn.GroupNorm`` / ``nn.Linear`` / ``nn.Embedding`` objects below are parameter HOLDERS
+(their ``forward`` is never called); constructing them in the reference's order gives the reference's
+state_dict keys and - under the same ``torch.manual_seed`` - the reference's initial weights
+(module/module.py:74-110, tools/attention.py:26-29).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import SolaConfig, SolaError, check, current_stream, lib, ptr, require_cuda
+
+NUM_HEADS = 8  # module/module.py:13-15
+
+
+class _AttentionParams(nn.Module):
+    """Parameter holder with the key layout of tools/attention.py:26-29 (attention dropout 0.1, :12)."""
+
+    def __init__(self, embed_dim, num_heads, dropout_p=0.1):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout_p = embed_dim, num_heads, dropout_p
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise SolaError("parameter holder: the attention runs inside libsola_hip (sola_forward)")
+
+
+class ObjectLanguageAlignmentLayer(nn.Module):
+    """Parameter holder for one alignment layer (module/module.py:8-20)."""
+
+    def __init__(self, configs):
+        super().__init__()
+        D = configs["lang_token_dim"]
+        self.obj_attn = _AttentionParams(D, NUM_HEADS)
+        self.motion_attn = _AttentionParams(D, NUM_HEADS)
+        self.object2lang_attn = _AttentionParams(D, NUM_HEADS)
+        self.norm = nn.ModuleList([nn.GroupNorm(configs["n_groups_module"], D) for _ in range(3)])
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise SolaError("parameter holder: the layer runs inside libsola_hip (sola_forward)")
+
+
+class LanguageAlignedTrackSelectionModule(nn.Module):
+    """``m(object_tokens [B,N,T,d], lang_tokens [B,L,D]) -> (score_map [B,N], score_tokens [B,N,D])``
+    (module/module.py:54-162)."""
+
+    def __init__(self, configs) -> None:
+        super().__init__()
+        self.object_token_dim = configs["object_token_dim"]
+        self.lang_token_dim = configs["lang_token_dim"]
+        self.n_layers = configs["n_layers"]
+        self.max_temporal_length = configs["max_temporal_length"]
+        self.n_negative = configs["n_negative"]
+        self.n_groups = configs["n_groups"]
+        self.n_groups_module = configs["n_groups_module"]
+        self.dropout_p = configs.get("dropout_p", 0.2)
+        assert configs["norm_type"] == "group", "Weight standardization is only supported with group normalization."
+        d, h, D = self.object_token_dim, self.object_token_dim * 2, self.lang_token_dim
+        p = self.dropout_p
+        geo = [(d, h, 3, 2, 1), (h, h, 3, 2, 1), (h, h, 3, 2, 1), (h, D, 3, 1, 1), (D, D, 3, 1, 1)]
+        mods = []
+        for cin, cout, k, s, pad in geo:
+            mods += [nn.Conv1d(cin, cout, kernel_size=k, stride=s, padding=pad),
+                     nn.GroupNorm(self.n_groups, cout), nn.LeakyReLU(), nn.Dropout(p=p)]
+        mods.append(nn.Conv1d(D, D, kernel_size=1, stride=1, padding=0))
+        self.short_motion_encoder = nn.Sequential(*mods)  # indices 0..20 as in module/module.py:74-96
+        self.object_lang_align_layers = nn.ModuleList([ObjectLanguageAlignmentLayer(configs) for _ in range(self.n_layers)])
+        self.register_buffer("positional_encoding_gaussian_matrix", torch.randn((1, D // 2)).float())
+        self.negative_token = nn.Embedding(self.n_negative, D)
+        # library state (not part of the state_dict)
+        self._ctx = None
+        self._ctx_device = None
+        self._bound = {}      # key -> (data_ptr, version)
+        self._workspace = None
+        self._last_shape = None
+
+    # ------------------------------------------------------------------------------------------ library binding
+    def _config_struct(self):
+        return SolaConfig(self.object_token_dim, self.lang_token_dim, self.n_layers, self.max_temporal_length,
+                          self.n_negative, self.n_groups, self.n_groups_module, NUM_HEADS)
+
+    def _ensure_ctx(self, device):
+        if self._ctx is not None and self._ctx_device == device:
+            return
+        self._release_ctx()
+        handle = C.c_void_p()
+        cfg = self._config_struct()
+        check(lib().sola_ctx_create(C.byref(cfg), device.index if device.index is not None else torch.cuda.current_device(),
+                                    C.byref(handle)), "sola_ctx_create")
+        self._ctx, self._ctx_device, self._bound = handle, device, {}
+
+    def _release_ctx(self):
+        if getattr(self, "_ctx", None) is not None:
+            try:
+                lib().sola_ctx_destroy(self._ctx)
+            finally:
+                self._ctx = None
+
+    def __del__(self):
+        try:
+            self._release_ctx()
+        except Exception:
+            pass
+
+    def _bind_weights(self):
+        """Hand the library the current device pointer of every state_dict tensor; flag in-place updates."""
+        changed = False
+        for key, t in self.state_dict(keep_vars=True).items():
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise SolaError(f"{key}: expected a contiguous float32 tensor")
+            rec = (t.data_ptr(), t._version)
+            old = self._bound.get(key)
+            if old is None or old[0] != rec[0]:
+                check(lib().sola_set_weight(self._ctx, key.encode(), ptr(t), t.numel()), f"sola_set_weight({key})")
+                changed = True
+            elif old[1] != rec[1]:
+                changed = True
+            self._bound[key] = rec
+        if changed:
+            check(lib().sola_weights_changed(self._ctx), "sola_weights_changed")
+        # training re-standardises the conv weights every call like module/ws.py; eval caches them until a change
+        check(lib().sola_set_ws_policy(self._ctx, 1 if self.training else 0), "sola_set_ws_policy")
+
+    def _get_workspace(self, nbytes, device):
+        if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
+            self._workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._workspace
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, object_tokens, lang_tokens):
+        require_cuda(object_tokens, lang_tokens)
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            from .autograd import track_selection_forward  # backward kernels
+            return track_selection_forward(self, object_tokens, lang_tokens)
+        return self._forward_impl(object_tokens, lang_tokens)
+
+    def _forward_impl(self, object_tokens, lang_tokens):
+        if object_tokens.dim() != 4 or lang_tokens.dim() != 3:
+            raise SolaError("object_tokens must be [B,N,T,d] and lang_tokens [B,L,D]")
+        B, N, T, d = object_tokens.shape
+        Bl, L, D = lang_tokens.shape
+        if d != self.object_token_dim or D != self.lang_token_dim or Bl != B:
+            raise SolaError(f"shape mismatch: object_tokens {tuple(object_tokens.shape)}, lang_tokens {tuple(lang_tokens.shape)}")
+        dev = object_tokens.device
+        obj = object_tokens.to(torch.float32).contiguous()
+        lang = lang_tokens.to(torch.float32).contiguous()
+        self._ensure_ctx(dev)
+        self._bind_weights()
+        nbytes = lib().sola_workspace_bytes(self._ctx, B, N, T, L)
+        ws = self._get_workspace(nbytes, dev)
+        score_map = torch.empty((B, N), device=dev, dtype=torch.float32)
+        score_tokens = torch.empty((B, N, D), device=dev, dtype=torch.float32)
+        check(lib().sola_forward(self._ctx, ptr(obj), ptr(lang), B, N, T, L, ptr(score_map), ptr(score_tokens),
+                                 ptr(ws), ws.numel(), current_stream(dev)), "sola_forward")
+        self._last_shape = (B, N, T, L)
+        return score_map, score_tokens
+
+    def workspace_tap(self, name):
+        """Copy of a named intermediate of the last forward (see sola_workspace_tap); for parity tests."""
+        off, rows, cols = C.c_size_t(), C.c_int64(), C.c_int64()
+        check(lib().sola_workspace_tap(self._ctx, name.encode(), C.byref(off), C.byref(rows), C.byref(cols)), "sola_workspace_tap")
+        n = rows.value * cols.value
+        flat = self._workspace[off.value: off.value + 4 * n].view(torch.float32)
+        return flat.reshape(rows.value, cols.value).clone()
+
+    # ------------------------------------------------------------------------------------------ a7
+    def get_grad_norm_dict(self):
+        """module/module.py:164-199 with one device reduction per group and a single host sync."""
+        groups = [("short_motion_encoder", list(self.short_motion_encoder.parameters()))]
+        groups += [(f"scmola_layer_{i}", list(layer.parameters())) for i, layer in enumerate(self.object_lang_align_layers)]
+        groups.append(("negative_token", list(self.negative_token.parameters())))
+        sq = []
+        for _name, params in groups:
+            gs = [p.grad for p in params if p.grad is not None]
+            if gs:
+                sq.append(torch.stack([g.detach().double().pow(2).sum() for g in gs]).sum())
+            else:
+                sq.append(torch.zeros((), dtype=torch.float64, device=self.negative_token.weight.device))
+        vals = torch.stack(sq).cpu().tolist()
+        out = {"total_grad_norm": sum(vals) ** 0.5}
+        for (name, _), v in zip(groups, vals):
+            out[name] = v ** 0.5
+        return out

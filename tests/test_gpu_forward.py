@@ -1,0 +1,172 @@
+"""Whole-path parity on the MI355X: LanguageAlignedTrackSelectionModule + losses through the C ABI against
+(a) the committed golden vectors of the real reference and (b) the CPU oracle evaluated on the spot.
+
+Tolerance: the north star asks for per-track logits within 1e-3 (fp32) and bit-exact selections.  The fp32
+evaluation-order noise of this network is ~1e-4 at (T=32,N=64) and ~4e-4 at (T=128,N=128) (the reference itself
+sits that far from a float64 evaluation, tests/test_oracle_golden.py), so 1e-3 is asserted against the golden
+vectors and 5e-4 against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import case_dict  # noqa: E402
+from oracle import sola_oracle  # noqa: E402
+from sola_amd import synth  # noqa: E402
+from sola_amd.loss import AlignmentLoss, track_selection_losses  # noqa: E402
+from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
+
+POS_W, TEMP, ALIGN_W = 1.5, 0.07, 0.3
+TOL = 1e-3
+
+
+def build(cfg, seed=42):
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    sd = synth.make_state_dict(cfg, seed)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval(), sd
+
+
+@pytest.fixture(scope="module")
+def small_model():
+    return build(synth.SMALL_MODEL_CFG)
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    return build(synth.DEFAULT_MODEL_CFG)
+
+
+def run(m, cfg, B, N, T, L, seed):
+    inp = synth.make_inputs(cfg, B, N, T, L, seed)
+    c = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    with torch.no_grad():
+        sm, st = m(c["object_tokens"], c["lang_tokens"])
+        loss3, argmax = track_selection_losses(sm, st, c["labels"], c["pos_tokens"], m.negative_token.weight,
+                                               POS_W, TEMP, ALIGN_W, return_argmax=True)
+    torch.cuda.synchronize()
+    return inp, sm, st, loss3, argmax
+
+
+def check_outputs(g, sm, st, loss3, argmax, tol=TOL):
+    sm_c, st_c = sm.cpu().numpy(), st.cpu().numpy()
+    assert np.abs(sm_c - g["score_map"]).max() <= tol, np.abs(sm_c - g["score_map"]).max()
+    assert np.abs(st_c - g["score_tokens"]).max() <= tol, np.abs(st_c - g["score_tokens"]).max()
+    np.testing.assert_allclose(loss3.cpu().numpy().astype(np.float64), g["loss"], rtol=2e-4, atol=2e-4)
+    # bit-exact decisions: thresholded selection (inference.py:59-60), arg-max track, hardest negative (loss.py:40)
+    sel = (torch.sigmoid(sm) > 0.5).float().cpu().numpy()
+    np.testing.assert_array_equal(sel, g["selected"])
+    np.testing.assert_array_equal(sm.argmax(dim=1).cpu().numpy(), g["argmax_track"])
+    np.testing.assert_array_equal(argmax.cpu().numpy(), g["neg_argmax"])
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_small_cases_with_taps(small_golden, small_model, ci):
+    m, _sd = small_model
+    cfg = synth.SMALL_MODEL_CFG
+    B, N, T, L = [int(v) for v in small_golden["cases"][ci]]
+    g = case_dict(small_golden, ci)
+    _inp, sm, st, loss3, argmax = run(m, cfg, B, N, T, L, 100 + ci)
+    # stage-by-stage bisection aid: every intermediate the reference exposes through hooks
+    worst = {}
+    for name in [f"conv{i}" for i in range(6)] + ["pe"] + [f"l{l}_{s}" for l in range(2) for s in ("obj", "motion", "o2l")]:
+        ref = g["tap." + name]
+        got = m.workspace_tap(name).cpu().numpy().reshape(ref.shape)
+        worst[name] = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    assert not bad, f"intermediate mismatch: {bad} (all: {worst})"
+    check_outputs(g, sm, st, loss3, argmax)
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_full_cases_vs_golden(full_golden, full_model, ci):
+    m, _sd = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
+    g = case_dict(full_golden, ci)
+    _inp, sm, st, loss3, argmax = run(m, cfg, B, N, T, L, 200 + ci)
+    if ci in (0, 1):
+        for name in [f"conv{i}" for i in range(6)] + [f"l{l}_{s}" for l in range(2) for s in ("obj", "motion", "o2l")]:
+            ref = g["tap." + name]  # first two tracks only
+            got = m.workspace_tap(name).cpu().numpy().reshape(B, N, ref.shape[2], ref.shape[3])[:, :2]
+            err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+            assert err <= 3e-4, (name, err)
+    check_outputs(g, sm, st, loss3, argmax)
+
+
+def test_full_ns_vs_float64_oracle(full_model):
+    """North-star shape against a float64 evaluation of the oracle computed here (no fixture involved)."""
+    m, sd = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp, sm, st, loss3, _ = run(m, cfg, 1, 64, 32, 16, 777)
+    rsm, rst = sola_oracle.forward(sd, cfg, inp["object_tokens"], inp["lang_tokens"], dtype=torch.float64)
+    assert np.abs(sm.cpu().numpy() - rsm.numpy()).max() <= 5e-4
+    assert np.abs(st.cpu().numpy() - rst.numpy()).max() <= 5e-4
+    neg = np.broadcast_to(sd["negative_token.weight"][None], (1,) + sd["negative_token.weight"].shape)
+    ls = sola_oracle.losses(rsm, rst, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W, dtype=torch.float64)
+    np.testing.assert_allclose(loss3.cpu().numpy(), [float(ls["total"]), float(ls["bce"]), float(ls["align"])], rtol=2e-4, atol=2e-4)
+
+
+def test_batch_independence_and_track_permutation(full_model):
+    """Size-independent properties at the north-star shape: samples of a batch do not interact (GroupNorm statistics
+    never cross samples) and the network is permutation-equivariant over tracks."""
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp = synth.make_inputs(cfg, 3, 64, 32, 16, 31)
+    obj, lang = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
+    with torch.no_grad():
+        sm, st = m(obj, lang)
+        for b in range(3):
+            sm1, st1 = m(obj[b:b + 1], lang[b:b + 1])
+            assert (sm1[0] - sm[b]).abs().max().item() <= 2e-4
+            assert (st1[0] - st[b]).abs().max().item() <= 2e-4
+        perm = torch.randperm(64, generator=torch.Generator().manual_seed(0)).cuda()
+        smp, stp = m(obj[:, perm], lang)
+    assert (smp - sm[:, perm]).abs().max().item() <= 2e-4
+    assert (stp - st[:, perm]).abs().max().item() <= 2e-4
+
+
+def test_determinism(full_model):
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    _, sm1, st1, l1, _ = run(m, cfg, 2, 64, 32, 16, 5)
+    _, sm2, st2, l2, _ = run(m, cfg, 2, 64, 32, 16, 5)
+    assert torch.equal(sm1, sm2) and torch.equal(st1, st2) and torch.equal(l1, l2)
+
+
+def test_weight_update_invalidates_cached_standardisation(small_model):
+    m, _ = small_model
+    cfg = synth.SMALL_MODEL_CFG
+    _, sm1, _, _, _ = run(m, cfg, 1, 8, 8, 5, 1)
+    with torch.no_grad():
+        m.short_motion_encoder[0].weight.mul_(1.0).add_(0.05 * torch.randn_like(m.short_motion_encoder[0].weight))
+    _, sm2, _, _, _ = run(m, cfg, 1, 8, 8, 5, 1)
+    assert (sm1 - sm2).abs().max().item() > 1e-4  # eval mode caches w_std; an in-place update must refresh it
+    sd = synth.make_state_dict(cfg, 42)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    _, sm3, _, _, _ = run(m, cfg, 1, 8, 8, 5, 1)
+    assert torch.equal(sm1, sm3)
+
+
+def test_alignment_loss_module(small_golden, small_model):
+    """tools/loss.py interface: AlignmentLoss(pw, temp)(object_tokens=, labels=, pos_tokens=, neg_tokens=)."""
+    m, _ = small_model
+    cfg = synth.SMALL_MODEL_CFG
+    B, N, T, L = [int(v) for v in small_golden["cases"][1]]
+    g = case_dict(small_golden, 1)
+    inp, _sm, st, _l, _ = run(m, cfg, B, N, T, L, 101)
+    fn = AlignmentLoss(positive_weight=POS_W, temperature=TEMP).cuda()
+    neg = m.negative_token.weight.detach().clone().unsqueeze(0).repeat(B, 1, 1)  # train.py:92
+    with torch.no_grad():
+        v = fn(object_tokens=st, labels=torch.from_numpy(inp["labels"]).cuda(),
+               pos_tokens=torch.from_numpy(inp["pos_tokens"]).cuda(), neg_tokens=neg)
+    assert v.dim() == 0
+    assert abs(v.item() - g["loss"][2]) <= 2e-4 * max(1.0, abs(g["loss"][2]))
+
+
+def test_cpu_tensors_fail_loudly(small_model):
+    m, _ = small_model
+    from sola_amd import SolaError
+    with pytest.raises(SolaError):
+        m(torch.zeros(1, 2, 8, 32), torch.zeros(1, 3, 128))
