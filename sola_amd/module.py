@@ -83,6 +83,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._bound = {}      # key -> (data_ptr, version)
         self._workspace = None
         self._last_shape = None
+        self.ws_policy = "auto"
 
     # ------------------------------------------------------------------------------------------ library binding
     def _config_struct(self):
@@ -128,8 +129,10 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             self._bound[key] = rec
         if changed:
             check(lib().sola_weights_changed(self._ctx), "sola_weights_changed")
-        # training re-standardises the conv weights every call like module/ws.py; eval caches them until a change
-        check(lib().sola_set_ws_policy(self._ctx, 1 if self.training else 0), "sola_set_ws_policy")
+        # "auto": training re-standardises the conv weights every call like module/ws.py, eval caches them until a
+        # weight changes; "always" / "cached" force either behaviour (bench.py uses "always")
+        every = self.training if self.ws_policy == "auto" else self.ws_policy == "always"
+        check(lib().sola_set_ws_policy(self._ctx, 1 if every else 0), "sola_set_ws_policy")
 
     def _get_workspace(self, nbytes, device):
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
