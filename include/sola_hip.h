@@ -124,9 +124,53 @@ int sola_group_norm(const float* dev_x, float* dev_y, float* dev_y2, const float
 int sola_attention(const float* dev_q, int ldq, const float* dev_k, int ldk, const float* dev_v, int ldv,
                    float* dev_o, int ldo, int G, int H, int head_dim, int Sq, int Sk, int inner,
                    int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
-                   int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, void* stream);
+                   int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale,
+                   float* dev_lse /* optional [q rows, H]: log-sum-exp, needed by the backward */, void* stream);
 /* module/module.py:112-128: pe [t_len, D] */
 int sola_pos_encoding(const float* dev_gauss, int D, int t_len, int max_temporal_length, float* dev_pe, void* stream);
+
+/* ---- training: what loss.backward() does to this path under autograd (train.py:116-117) ----------------------------
+ * sola_forward_train = sola_forward that keeps every attention's q/k/v/output/residual and the softmax log-sum-exp in
+ * the workspace (sola_train_workspace_bytes); the workspace and dev_object_tokens must stay untouched until
+ * sola_backward has run.  sola_backward consumes d(score_map), d(score_tokens) and OVERWRITES the gradient buffer
+ * registered with sola_set_grad for each of the 83 parameters (same names and sizes as sola_set_weight; the Fourier
+ * buffer has no gradient).  Gradients flowing into negative_token.weight through the loss's neg_tokens argument come
+ * from sola_loss_backward (d_neg) and are added by the caller, exactly as autograd does for train.py:92. */
+size_t sola_train_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
+size_t sola_backward_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
+int sola_set_grad(SolaCtx* ctx, const char* name, void* dev_ptr, int64_t numel);
+int sola_forward_train(SolaCtx* ctx, const float* dev_object_tokens, const float* dev_lang_tokens,
+                       int B, int N, int T, int L, float* dev_score_map, float* dev_score_tokens,
+                       void* dev_workspace, size_t workspace_bytes, void* stream);
+int sola_backward(SolaCtx* ctx, const float* dev_d_score_map, const float* dev_d_score_tokens,
+                  const void* dev_forward_workspace, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* Backward of sola_loss.  dev_g3 = upstream gradients of {total, bce, alignment} (3 floats on the device).
+ * Writes d(score_map) [B,N], d(score_tokens) [B,N,D] and (optional) d(neg_tokens) [B,n_neg,D].  Scratch: B*N*n_neg floats. */
+int sola_loss_backward(const float* dev_score_map, const float* dev_score_tokens, const float* dev_labels,
+                       const float* dev_pos_tokens, const float* dev_neg_tokens, int64_t neg_batch_stride,
+                       int B, int N, int D, int n_neg, float positive_weight, float temperature, float alignment_weight,
+                       const float* dev_g3, float* dev_d_score_map, float* dev_d_score_tokens, float* dev_d_neg,
+                       void* dev_scratch, size_t scratch_bytes, void* stream);
+/* per-stage backward entry points (parity tests) */
+int sola_ws_backward(const float* dev_w, const float* dev_dwstd, int cout, int cin, int k, float* dev_dw, void* stream);
+/* C[N,K] = A[M,N]^T * B[M,K] (weight gradient), optional bias_grad[N] = column sums of A */
+size_t sola_gemm_tn_scratch_bytes(int M, int N, int K);
+int sola_gemm_tn(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, float* dev_bias_grad,
+                 int M, int N, int K, void* dev_scratch, size_t scratch_bytes, void* stream);
+int sola_conv1d_cl_backward(const float* dev_x, const float* dev_wstd, const float* dev_dy, float* dev_dx,
+                            float* dev_dwstd, float* dev_dbias, int R, int T_in, int cin, int cout, int k, int stride,
+                            int pad, void* dev_scratch, size_t scratch_bytes, void* stream);
+int sola_group_norm_backward(const float* dev_x, const float* dev_dy, const float* dev_dy2, const float* dev_gamma,
+                             const float* dev_beta, float* dev_dx, float* dev_dgamma, float* dev_dbeta,
+                             int n_inst, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tok_stride,
+                             int ntok, int C, int groups, float eps, float leaky_slope, int apply_leaky,
+                             void* dev_scratch, size_t scratch_bytes, void* stream);
+int sola_attention_backward(const float* dev_q, int ldq, const float* dev_k, int ldk, const float* dev_v, int ldv,
+                            const float* dev_o, const float* dev_dout, int ldo, const float* dev_lse,
+                            float* dev_dq, float* dev_dk, float* dev_dv, float* dev_dvec /* [q rows, H] scratch */,
+                            int G, int H, int head_dim, int Sq, int Sk, int inner,
+                            int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
+                            int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, void* stream);
 
 /* ---- mask IoU: replaces track_generation/seg_utils.py:128-142 (compute_mask_iou), :109-125 (compute_masklet_iou)
  * and the prompt-mask nearest resize of generate_tokens_grid.py:269-272 ------------------------------------------
@@ -158,7 +202,9 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_IOU_PACK = 6,  /* mask_pack_kernel */
        SOLA_PROF_IOU_PAIR = 7,  /* mask_pair_kernel */
        SOLA_PROF_GEMM_SMALL = 8, /* gemm_nt_f32_kernel<64,64> (small grids) */
-       SOLA_PROF_NCAT = 9 };
+       SOLA_PROF_GEMM_TN = 9,   /* gemm_tn_f32_kernel (weight gradients) */
+       SOLA_PROF_ATTN_BWD = 10, /* attn_bwd_* kernels */
+       SOLA_PROF_NCAT = 11 };
 int sola_profile_enable(int enable);
 /* Synchronises the recorded events and returns, per category: launches, total milliseconds, algorithmic flops,
  * algorithmic bytes accumulated since the last reset. Arrays have SOLA_PROF_NCAT entries. */

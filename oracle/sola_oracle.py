@@ -36,6 +36,8 @@ WS_EPS = 1e-5  # module/ws.py:11
 def _t(x, dtype):
     if isinstance(x, np.ndarray):
         x = torch.tensor(x)
+    if x.requires_grad:  # tests differentiate through the oracle with torch autograd
+        return x.to(device="cpu", dtype=dtype)
     return x.detach().to(device="cpu", dtype=dtype)
 
 

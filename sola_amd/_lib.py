@@ -55,7 +55,20 @@ SIGNATURES = {
     "sola_gemm_nt": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "sola_conv1d_cl": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sola_group_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp]),
-    "sola_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
+    "sola_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp, _vp]),
+    "sola_train_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "sola_backward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "sola_set_grad": (_i, [_vp, C.c_char_p, _vp, _i64]),
+    "sola_forward_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sola_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sola_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sola_ws_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sola_gemm_tn_scratch_bytes": (_sz, [_i, _i, _i]),
+    "sola_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sola_conv1d_cl_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sola_group_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
+    "sola_attention_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                     _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "sola_pos_encoding": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sola_mask_words": (_i64, [_i, _i]),
     "sola_mask_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -66,7 +79,7 @@ SIGNATURES = {
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
 }
 
-PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64"]
+PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64", "gemm_tn", "attn_bwd"]
 
 _lib = None
 

@@ -1,9 +1,69 @@
-"""Training path (forward that saves activations + HIP backward).  Not available yet in this build:
-the call fails loudly rather than falling back to PyTorch autograd."""
-from ._lib import SolaError
+"""Differentiable (training) path: ``torch.autograd.Function`` shells around sola_forward_train / sola_backward and
+sola_loss / sola_loss_backward.  PyTorch only carries the tensors and the graph edges; every gradient is computed by
+the HIP kernels of libsola_hip.so (backward.hip).  This is what ``loss.backward()`` at train.py:116-117 runs."""
+from __future__ import annotations
+
+import torch
+
+from ._lib import SolaError, check, current_stream, lib, ptr
+
+
+class _TrackSelection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, object_tokens, lang_tokens, *params):
+        score_map, score_tokens = module._forward_train_impl(object_tokens, lang_tokens)
+        ctx.module = module
+        ctx.n_params = len(params)
+        ctx.gen = module._train_generation
+        return score_map, score_tokens
+
+    @staticmethod
+    def backward(ctx, d_score_map, d_score_tokens):
+        m = ctx.module
+        if ctx.gen != m._train_generation:
+            raise SolaError("sola_amd: backward through a stale forward (the module ran another training forward since)")
+        grads = m._backward_impl(d_score_map, d_score_tokens)
+        return (None, None, None, *grads)
 
 
 def track_selection_forward(module, object_tokens, lang_tokens):
-    raise SolaError(
-        "sola_amd: the differentiable (training) forward is not built yet; call the module under torch.no_grad() "
-        "with module.eval() for the forward+loss path. There is no PyTorch fallback.")
+    if module.training and (module.dropout_p > 0 or module.attention_dropout_p > 0):
+        raise SolaError(
+            "sola_amd: dropout is not implemented in the HIP training path yet; build the module with dropout_p=0 and "
+            "set module.attention_dropout_p=0 (or call module.eval()) - there is no PyTorch fallback")
+    params = [p for p in module.parameters()]
+    return _TrackSelection.apply(module, object_tokens, lang_tokens, *params)
+
+
+class _Losses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight, temperature, alignment_weight):
+        from .loss import _loss_forward
+
+        loss3, _ = _loss_forward(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight, temperature,
+                                 alignment_weight, False)
+        ctx.save_for_backward(score_map, score_tokens, labels, pos_tokens, neg_tokens)
+        ctx.hyper = (float(positive_weight), float(temperature), float(alignment_weight))
+        return loss3
+
+    @staticmethod
+    def backward(ctx, g3):
+        score_map, score_tokens, labels, pos_tokens, neg_tokens = ctx.saved_tensors
+        pw, temp, aw = ctx.hyper
+        B, N = score_map.shape
+        D = score_tokens.shape[-1]
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        sm, st, lb, ps, ng, g = f(score_map), f(score_tokens), f(labels), f(pos_tokens), f(neg_tokens), f(g3)
+        shared = ng.dim() == 2
+        n_neg = ng.shape[0] if shared else ng.shape[1]
+        stride = 0 if shared else n_neg * D
+        dev = sm.device
+        d_sm = torch.empty_like(sm)
+        d_st = torch.empty_like(st)
+        d_neg = torch.empty_like(ng) if ctx.needs_input_grad[4] else None
+        n_scratch = ((B * N * n_neg + 63) // 64) * 64 + (B * n_neg * D if (shared and d_neg is not None) else 0)
+        scratch = torch.empty(n_scratch, device=dev, dtype=torch.float32)
+        check(lib().sola_loss_backward(ptr(sm), ptr(st), ptr(lb), ptr(ps), ptr(ng), stride, B, N, D, n_neg, pw, temp, aw,
+                                       ptr(g), ptr(d_sm), ptr(d_st), ptr(d_neg), ptr(scratch), scratch.numel() * 4,
+                                       current_stream(dev)), "sola_loss_backward")
+        return d_sm, d_st, None, None, d_neg, None, None, None

@@ -1,15 +1,12 @@
-// C ABI of libsola_hip.so (see include/sola_hip.h): context, weight registry, forward orchestration, event profiler.
-// Host orchestration only - every numeric step is a HIP kernel in gemm.hip / attn.hip / norm.hip / head.hip / iou.hip.
+// C ABI of libsola_hip.so (see include/sola_hip.h): context + weight registry, thin wrappers over the orchestration in
+// forward.hip / backward.hip and over the kernel launchers, and the HIP-event profiler.
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
 #include <mutex>
-#include <string>
-#include <unordered_map>
-#include <vector>
 
-#include "kernels.h"
+#include "ctx.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // errors
@@ -22,7 +19,7 @@ void sola_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sola_last_error(void) { return g_err; }
-extern "C" const char* sola_version(void) { return "sola_hip 0.1 (gfx950, f32 MFMA)"; }
+extern "C" const char* sola_version(void) { return "sola_hip 0.2 (gfx950, f32 MFMA, forward+backward)"; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // event profiler: start/stop HIP events on the launch stream around every kernel launch while enabled
@@ -109,97 +106,10 @@ extern "C" int sola_profile_read(int64_t* launches, double* ms, double* flops, d
 // ---------------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------------
-namespace {
-struct ConvGeom {
-    int cin, cout, k, stride, pad;
-};
-struct Weight {
-    std::string name;
-    int64_t numel;
-    const float* ptr;
-};
-struct Buf {
-    size_t off;
-    int64_t rows, cols;
-};
-struct Plan {
-    int B = 0, N = 0, T = 0, L = 0, W = 0, Tp = 0, M = 0;
-    int Tl[6] = {0};
-    std::unordered_map<std::string, Buf> bufs;
-    size_t total = 0;
-    size_t add(const std::string& name, int64_t rows, int64_t cols) {
-        const size_t off = total;
-        bufs[name] = Buf{off, rows, cols};
-        total += (((size_t)rows * (size_t)cols * sizeof(float)) + 255) & ~(size_t)255;
-        return off;
-    }
-};
-}  // namespace
-
-struct SolaCtx {
-    SolaConfig cfg;
-    int device;
-    ConvGeom conv[6];
-    std::vector<Weight> weights;
-    std::unordered_map<std::string, int> index;
-    float* ws_buf = nullptr;  // standardised conv weights [cout][k*cin], all six layers, ctx-owned
-    size_t ws_off[6];
-    bool ws_dirty = true;
-    bool ws_every_forward = true;
-    Plan last;
-};
-
-namespace {
-const int kConvIdx[6] = {0, 4, 8, 12, 16, 20};
-const int kNormIdx[5] = {1, 5, 9, 13, 17};
-
-void add_weight(SolaCtx* c, const std::string& name, int64_t numel) {
+static void add_weight(SolaCtx* c, const std::string& name, int64_t numel) {
     c->index[name] = (int)c->weights.size();
-    c->weights.push_back(Weight{name, numel, nullptr});
+    c->weights.push_back(Weight{name, numel, nullptr, nullptr});
 }
-
-const float* W(const SolaCtx* c, const std::string& name) {
-    auto it = c->index.find(name);
-    return it == c->index.end() ? nullptr : c->weights[it->second].ptr;
-}
-
-Plan make_plan(const SolaCtx* c, int B, int N, int T, int L) {
-    Plan p;
-    p.B = B; p.N = N; p.T = T; p.L = L;
-    p.W = L + c->cfg.n_negative;
-    int t = T;
-    for (int i = 0; i < 6; ++i) {
-        t = (t + 2 * c->conv[i].pad - c->conv[i].k) / c->conv[i].stride + 1;
-        p.Tl[i] = t;
-    }
-    p.Tp = p.Tl[5];
-    p.M = B * N * p.Tp;
-    const int D = c->cfg.lang_token_dim;
-    const int64_t R = (int64_t)B * N;
-    for (int i = 0; i < 6; ++i) {
-        p.add("conv" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
-        if (i < 5) p.add("act" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
-    }
-    p.add("pe", p.Tp, D);
-    p.add("lang", (int64_t)B * p.W, D);
-    p.add("lbar", B, D);
-    p.add("q", p.M, D);
-    p.add("k", p.M, D);
-    p.add("v", p.M, D);
-    p.add("lk", (int64_t)B * p.W, D);
-    p.add("lv", (int64_t)B * p.W, D);
-    p.add("attn", p.M, D);
-    p.add("res", p.M, D);
-    p.add("xpe", p.M, D);
-    for (int l = 0; l < c->cfg.n_layers; ++l) {
-        p.add("l" + std::to_string(l) + "_obj", p.M, D);
-        p.add("l" + std::to_string(l) + "_motion", p.M, D);
-        p.add("l" + std::to_string(l) + "_o2l", p.M, D);
-    }
-    p.add("loss_terms", (int64_t)B * N, 4);
-    return p;
-}
-}  // namespace
 
 extern "C" int sola_ctx_create(const SolaConfig* cfg, int device, SolaCtx** out) {
     SOLA_ARG(cfg && out, "ctx_create: null argument");
@@ -233,14 +143,13 @@ extern "C" int sola_ctx_create(const SolaConfig* cfg, int device, SolaCtx** out)
         c->ws_off[i] = ws_total;
         ws_total += (size_t)geo[i].cout * geo[i].cin * geo[i].k;
     }
-    static const char* attn_names[3] = {"obj_attn", "motion_attn", "object2lang_attn"};
     static const char* proj_names[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
     for (int l = 0; l < cfg->n_layers; ++l) {
         const std::string p = "object_lang_align_layers." + std::to_string(l) + ".";
         for (int a = 0; a < 3; ++a)
             for (int j = 0; j < 4; ++j) {
-                add_weight(c, p + attn_names[a] + "." + proj_names[j] + ".weight", (int64_t)D * D);
-                add_weight(c, p + attn_names[a] + "." + proj_names[j] + ".bias", D);
+                add_weight(c, p + kAttnLong[a] + "." + proj_names[j] + ".weight", (int64_t)D * D);
+                add_weight(c, p + kAttnLong[a] + "." + proj_names[j] + ".bias", D);
             }
         for (int j = 0; j < 3; ++j) {
             add_weight(c, p + "norm." + std::to_string(j) + ".weight", D);
@@ -274,24 +183,38 @@ extern "C" int sola_weight_info(const SolaCtx* c, int index, const char** name, 
     return SOLA_OK;
 }
 
-extern "C" int sola_set_weight(SolaCtx* c, const char* name, const void* dev_ptr, int64_t numel) {
-    SOLA_ARG(c && name && dev_ptr, "set_weight: null argument");
+static int find_weight(SolaCtx* c, const char* what, const char* name, const void* ptr, int64_t numel, Weight** out) {
+    SOLA_ARG(c && name && ptr, "%s: null argument", what);
     auto it = c->index.find(name);
     if (it == c->index.end()) {
-        sola_set_error("set_weight: unknown state_dict key '%s'", name);
+        sola_set_error("%s: unknown state_dict key '%s'", what, name);
         return SOLA_ERR_WEIGHT;
     }
     Weight& w = c->weights[it->second];
     if (w.numel != numel) {
-        sola_set_error("set_weight: '%s' has %lld elements, expected %lld", name, (long long)numel, (long long)w.numel);
+        sola_set_error("%s: '%s' has %lld elements, expected %lld", what, name, (long long)numel, (long long)w.numel);
         return SOLA_ERR_WEIGHT;
     }
-    if ((reinterpret_cast<uintptr_t>(dev_ptr) & 15) != 0) {
-        sola_set_error("set_weight: '%s' must be 16-byte aligned", name);
+    if ((reinterpret_cast<uintptr_t>(ptr) & 15) != 0) {
+        sola_set_error("%s: '%s' must be 16-byte aligned", what, name);
         return SOLA_ERR_WEIGHT;
     }
-    w.ptr = static_cast<const float*>(dev_ptr);
+    *out = &w;
+    return SOLA_OK;
+}
+
+extern "C" int sola_set_weight(SolaCtx* c, const char* name, const void* dev_ptr, int64_t numel) {
+    Weight* w = nullptr;
+    SOLA_TRY(find_weight(c, "set_weight", name, dev_ptr, numel, &w));
+    w->ptr = static_cast<const float*>(dev_ptr);
     c->ws_dirty = true;
+    return SOLA_OK;
+}
+
+extern "C" int sola_set_grad(SolaCtx* c, const char* name, void* dev_ptr, int64_t numel) {
+    Weight* w = nullptr;
+    SOLA_TRY(find_weight(c, "set_grad", name, dev_ptr, numel, &w));
+    w->grad = static_cast<float*>(dev_ptr);
     return SOLA_OK;
 }
 
@@ -309,7 +232,12 @@ extern "C" int sola_set_ws_policy(SolaCtx* c, int every) {
 
 extern "C" size_t sola_workspace_bytes(const SolaCtx* c, int B, int N, int T, int L) {
     if (!c || B <= 0 || N <= 0 || T <= 0 || L < 0) return 0;
-    return make_plan(c, B, N, T, L).total;
+    return make_plan(c, B, N, T, L, false).total;
+}
+
+extern "C" size_t sola_train_workspace_bytes(const SolaCtx* c, int B, int N, int T, int L) {
+    if (!c || B <= 0 || N <= 0 || T <= 0 || L < 0) return 0;
+    return make_plan(c, B, N, T, L, true).total;
 }
 
 extern "C" int sola_workspace_tap(const SolaCtx* c, const char* name, size_t* off, int64_t* rows, int64_t* cols) {
@@ -322,149 +250,14 @@ extern "C" int sola_workspace_tap(const SolaCtx* c, const char* name, size_t* of
     return SOLA_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------------------------------
-extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L,
-                            float* score_map, float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
-    SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
-    SOLA_ARG(B > 0 && N > 0 && T > 0 && L >= 1, "forward: bad sizes B=%d N=%d T=%d L=%d", B, N, T, L);
-    for (const Weight& w : c->weights)
-        if (!w.ptr) {
-            sola_set_error("forward: weight '%s' has not been set", w.name.c_str());
-            return SOLA_ERR_WEIGHT;
-        }
-    hipStream_t s = as_stream(stream_);
-    Plan p = make_plan(c, B, N, T, L);
-    if (ws_bytes < p.total) {
-        sola_set_error("forward: workspace %zu bytes < required %zu", ws_bytes, p.total);
-        return SOLA_ERR_WORKSPACE;
-    }
-    SOLA_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "forward: workspace must be 256-byte aligned");
-    char* base = static_cast<char*>(workspace);
-    auto buf = [&](const std::string& name) { return reinterpret_cast<float*>(base + p.bufs.at(name).off); };
-    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
-    const int Tp = p.Tp, M = p.M, Wn = p.W;
-    const int R = B * N;
+extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
+                            float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
+    return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_), false);
+}
 
-    // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
-    if (c->ws_dirty || c->ws_every_forward) {
-        WsLayer layers[6];
-        for (int i = 0; i < 6; ++i) {
-            const std::string nm = "short_motion_encoder." + std::to_string(kConvIdx[i]) + ".weight";
-            layers[i] = WsLayer{W(c, nm), c->ws_buf + c->ws_off[i], c->conv[i].cout, c->conv[i].cin, c->conv[i].k};
-        }
-        SOLA_TRY(launch_ws_standardize(layers, 6, s));
-        c->ws_dirty = false;
-    }
-
-    // a2: encoder (module/module.py:74-96,137-140)
-    const float* x = obj;
-    int t_in = T;
-    for (int i = 0; i < 6; ++i) {
-        const ConvGeom& g = c->conv[i];
-        const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
-        GemmDesc gd{};
-        gd.nprob = 1;
-        gd.p[0] = GemmProblem{x, c->ws_buf + c->ws_off[i], W(c, cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
-        gd.M = R * p.Tl[i]; gd.N = g.cout; gd.K = g.k * g.cin;
-        gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
-        gd.conv = g.k > 1 ? 1 : 0;
-        gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
-        SOLA_TRY(launch_gemm(gd, s));
-        if (i < 5) {
-            const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
-            GroupNormDesc nd{};
-            nd.x = buf("conv" + std::to_string(i)); nd.y = buf("act" + std::to_string(i)); nd.y2 = nullptr; nd.pe = nullptr;
-            nd.gamma = W(c, np + ".weight"); nd.beta = W(c, np + ".bias");
-            nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
-            nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
-            SOLA_TRY(launch_group_norm(nd, s));
-            x = buf("act" + std::to_string(i));
-        } else {
-            x = buf("conv5");
-        }
-        t_in = p.Tl[i];
-    }
-
-    // a3: positional table; text tokens ++ negative tokens and their mean (module/module.py:143-147)
-    SOLA_TRY(launch_pos_encoding(W(c, "positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
-    SOLA_TRY(launch_lang_concat(lang, W(c, "negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
-
-    // a5: alignment layers (module/module.py:22-52)
-    const float scale = 1.0f / sqrtf((float)DH);
-    auto linear3 = [&](const float* a0, const float* a1, const float* a2, const std::string& attn, int nprob, int rows,
-                       float* o0, float* o1, float* o2, int first_proj) -> int {
-        static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
-        const float* as[3] = {a0, a1, a2};
-        float* os[3] = {o0, o1, o2};
-        GemmDesc gd{};
-        gd.nprob = nprob;
-        for (int j = 0; j < nprob; ++j)
-            gd.p[j] = GemmProblem{as[j], W(c, attn + "." + pn[first_proj + j] + ".weight"),
-                                  W(c, attn + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
-        gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
-        return launch_gemm(gd, s);
-    };
-    auto out_proj = [&](const std::string& attn, const float* resid) -> int {
-        GemmDesc gd{};
-        gd.nprob = 1;
-        gd.p[0] = GemmProblem{buf("attn"), W(c, attn + ".out_proj.weight"), W(c, attn + ".out_proj.bias"), resid, buf("res")};
-        gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
-        return launch_gemm(gd, s);
-    };
-    auto gn = [&](const std::string& lp, int idx, float* y, float* y2, int n_inst, int inner, long long outer,
-                  long long inner_stride, long long tok_stride, int ntok) -> int {
-        GroupNormDesc nd{};
-        nd.x = buf("res"); nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
-        nd.gamma = W(c, lp + "norm." + std::to_string(idx) + ".weight");
-        nd.beta = W(c, lp + "norm." + std::to_string(idx) + ".bias");
-        nd.n_inst = n_inst; nd.inner = inner; nd.outer_stride = outer; nd.inner_stride = inner_stride;
-        nd.tok_stride = tok_stride; nd.ntok = ntok; nd.C = D; nd.groups = c->cfg.n_groups_module;
-        nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0;
-        return launch_group_norm(nd, s);
-    };
-    const float* xin = buf("conv5");
-    for (int l = 0; l < c->cfg.n_layers; ++l) {
-        const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
-        const std::string ls = "l" + std::to_string(l);
-        float *q = buf("q"), *k = buf("k"), *v = buf("v");
-        // (i) inter-object attention over the N tracks of each (b, t'): module.py:31-35
-        SOLA_TRY(linear3(xin, xin, xin, lp + "obj_attn", 3, M, q, k, v, 0));
-        {
-            AttnDesc ad{q, k, v, buf("attn"), D, D, D, D, B * Tp, H, DH, N, N, Tp,
-                        (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
-            SOLA_TRY(launch_attention(ad, s));
-        }
-        SOLA_TRY(out_proj(lp + "obj_attn", xin));
-        SOLA_TRY(gn(lp, 0, buf(ls + "_obj"), buf("xpe"), B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
-        // (ii) motion attention over T' per track, PE on q and k only: module.py:38-43
-        SOLA_TRY(linear3(buf("xpe"), buf("xpe"), buf(ls + "_obj"), lp + "motion_attn", 3, M, q, k, v, 0));
-        {
-            AttnDesc ad{q, k, v, buf("attn"), D, D, D, D, B * N, H, DH, Tp, Tp, 1,
-                        (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
-            SOLA_TRY(launch_attention(ad, s));
-        }
-        SOLA_TRY(out_proj(lp + "motion_attn", buf(ls + "_obj")));
-        SOLA_TRY(gn(lp, 1, buf(ls + "_motion"), nullptr, B * N, 1, Tp, 0, 1, Tp));
-        // (iii) object -> language cross attention: module.py:46-50
-        SOLA_TRY(linear3(buf(ls + "_motion"), nullptr, nullptr, lp + "object2lang_attn", 1, M, q, nullptr, nullptr, 0));
-        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1));
-        {
-            AttnDesc ad{q, buf("lk"), buf("lv"), buf("attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
-                        (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
-            SOLA_TRY(launch_attention(ad, s));
-        }
-        SOLA_TRY(out_proj(lp + "object2lang_attn", buf(ls + "_motion")));
-        SOLA_TRY(gn(lp, 2, buf(ls + "_o2l"), nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp));
-        xin = buf(ls + "_o2l");
-    }
-
-    // a6: score head (module/module.py:152-160)
-    HeadDesc hd{xin, buf("lbar"), score_map, score_tokens, B, N, Tp, D};
-    SOLA_TRY(launch_score_head(hd, s));
-    c->last = p;
-    return SOLA_OK;
+extern "C" int sola_forward_train(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L,
+                                  float* score_map, float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
+    return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_), true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -490,6 +283,33 @@ extern "C" int sola_loss(const float* score_map, const float* score_tokens, cons
     return launch_loss(d, as_stream(stream_));
 }
 
+extern "C" int sola_loss_backward(const float* score_map, const float* score_tokens, const float* labels, const float* pos,
+                                  const float* neg, int64_t neg_batch_stride, int B, int N, int D, int n_neg, float pw,
+                                  float temperature, float aw, const float* g3, float* d_score_map, float* d_score_tokens,
+                                  float* d_neg, void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(score_map && score_tokens && labels && pos && neg && g3 && d_score_map && d_score_tokens && scratch,
+             "loss_backward: null argument");
+    SOLA_ARG(B > 0 && N > 0 && D > 0 && n_neg > 0, "loss_backward: bad sizes");
+    // shared negatives (stride 0): the per-sample gradients are staged in the scratch and summed over b into d_neg [n_neg,D]
+    const bool shared = neg_batch_stride == 0 && d_neg != nullptr;
+    const size_t coef_floats = ((size_t)B * N * n_neg + 63) & ~(size_t)63;
+    const size_t need = (coef_floats + (shared ? (size_t)B * n_neg * D : 0)) * sizeof(float);
+    if (scratch_bytes < need) {
+        sola_set_error("loss_backward: scratch %zu bytes < required %zu", scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    float* stage = static_cast<float*>(scratch) + coef_floats;
+    LossBwdDesc d{};
+    d.score_map = score_map; d.score_tokens = score_tokens; d.labels = labels; d.pos = pos; d.neg = neg;
+    d.neg_batch_stride = neg_batch_stride; d.B = B; d.N = N; d.D = D; d.n_neg = n_neg;
+    d.pos_w = pw; d.temp_scale = expf(temperature); d.align_w = aw; d.g3 = g3;
+    d.d_score = d_score_map; d.d_tok = d_score_tokens; d.coef = static_cast<float*>(scratch);
+    d.d_neg = shared ? stage : d_neg;
+    SOLA_TRY(launch_loss_bwd(d, as_stream(stream_)));
+    if (shared) return launch_neg_token_grad(nullptr, nullptr, stage, d_neg, B, 0, n_neg, D, as_stream(stream_));
+    return SOLA_OK;
+}
+
 extern "C" int sola_select(const float* score, int64_t n, float thr, float* prob, float* pred, void* stream_) {
     SOLA_ARG(score && (prob || pred), "select: null argument");
     return launch_select(score, n, thr, prob, pred, as_stream(stream_));
@@ -504,6 +324,12 @@ extern "C" int sola_ws_standardize(const float* w, int cout, int cin, int k, flo
     return launch_ws_standardize(&l, 1, as_stream(stream_));
 }
 
+extern "C" int sola_ws_backward(const float* w, const float* dwstd, int cout, int cin, int k, float* dw, void* stream_) {
+    SOLA_ARG(w && dwstd && dw && cout > 0, "ws_backward: bad argument");
+    WsBwdLayer l{w, dwstd, dw, cout, cin, k};
+    return launch_ws_backward(&l, 1, as_stream(stream_));
+}
+
 extern "C" int sola_gemm_nt(const float* a, int lda, const float* w, const float* bias, const float* r, int ldr,
                             float* cmat, int ldc, int M, int N, int K, void* stream_) {
     SOLA_ARG(a && w && cmat, "gemm_nt: null argument");
@@ -512,6 +338,17 @@ extern "C" int sola_gemm_nt(const float* a, int lda, const float* w, const float
     gd.p[0] = GemmProblem{a, w, bias, r, cmat};
     gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
     return launch_gemm(gd, as_stream(stream_));
+}
+
+extern "C" size_t sola_gemm_tn_scratch_bytes(int M, int N, int K) { return gemm_tn_scratch_bytes(M, N, K); }
+
+extern "C" int sola_gemm_tn(const float* a, int lda, const float* b, int ldb, float* cmat, float* bias_grad, int M, int N,
+                            int K, void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(a && b && cmat && scratch, "gemm_tn: null argument");
+    GemmTnDesc d{};
+    d.A = a; d.B = b; d.C = cmat; d.bias_grad = bias_grad; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb;
+    d.scratch = static_cast<float*>(scratch); d.scratch_bytes = scratch_bytes;
+    return launch_gemm_tn(d, as_stream(stream_));
 }
 
 extern "C" int sola_conv1d_cl(const float* x, const float* wstd, const float* bias, float* y, int R, int T_in, int cin,
@@ -528,6 +365,37 @@ extern "C" int sola_conv1d_cl(const float* x, const float* wstd, const float* bi
     return launch_gemm(gd, as_stream(stream_));
 }
 
+// Backward of sola_conv1d_cl: dx [R,T_in,cin] (optional), dwstd [cout,k*cin], dbias [cout].
+// Scratch: max(sola_gemm_tn_scratch_bytes(R*T_out, cout, k*cin), 4*cout*k*cin) bytes.
+extern "C" int sola_conv1d_cl_backward(const float* x, const float* wstd, const float* dy, float* dx, float* dwstd,
+                                       float* dbias, int R, int T_in, int cin, int cout, int k, int stride, int pad,
+                                       void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(x && wstd && dy && dwstd && scratch && R > 0 && T_in > 0 && k >= 1 && stride >= 1, "conv1d_cl_backward: bad argument");
+    const int T_out = (T_in + 2 * pad - k) / stride + 1;
+    hipStream_t s = as_stream(stream_);
+    const bool gather = (k > 1 || stride > 1 || pad > 0);
+    GemmTnDesc d{};
+    d.A = dy; d.B = x; d.C = dwstd; d.bias_grad = dbias; d.M = R * T_out; d.N = cout; d.K = k * cin; d.lda = cout; d.ldb = cin;
+    d.conv = gather ? 1 : 0; d.T_in = T_in; d.T_out = T_out; d.stride = stride; d.pad = pad; d.Cin = cin;
+    d.scratch = static_cast<float*>(scratch); d.scratch_bytes = scratch_bytes;
+    SOLA_TRY(launch_gemm_tn(d, s));
+    if (!dx) return SOLA_OK;
+    const size_t need = (size_t)cout * k * cin * sizeof(float);
+    if (scratch_bytes < need) {
+        sola_set_error("conv1d_cl_backward: scratch %zu < %zu", scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    float* wt = static_cast<float*>(scratch);  // [cin][kk*cout + co]
+    for (int kk = 0; kk < k; ++kk)
+        SOLA_TRY(launch_transpose(wstd + (size_t)kk * cin, wt, cout, cin, k * cin, k * cout, kk * cout, s));
+    GemmDesc gd{};
+    gd.nprob = 1;
+    gd.p[0] = GemmProblem{dy, wt, nullptr, nullptr, dx};
+    gd.M = R * T_in; gd.N = cin; gd.K = k * cout; gd.lda = cout; gd.ldc = cin;
+    gd.conv = gather ? 2 : 0; gd.T_in = T_out; gd.T_out = T_in; gd.stride = stride; gd.pad = pad; gd.Cin = cout;
+    return launch_gemm(gd, s);
+}
+
 extern "C" int sola_group_norm(const float* x, float* y, float* y2, const float* pe, const float* gamma,
                                const float* beta, int n_inst, int inner, int64_t outer_stride, int64_t inner_stride,
                                int64_t tok_stride, int ntok, int C, int groups, float eps, float slope, int leaky,
@@ -537,12 +405,46 @@ extern "C" int sola_group_norm(const float* x, float* y, float* y2, const float*
     return launch_group_norm(d, as_stream(stream_));
 }
 
+// dgamma / dbeta [C]; scratch: 2 * n_inst * C floats
+extern "C" int sola_group_norm_backward(const float* x, const float* dy, const float* dy2, const float* gamma,
+                                        const float* beta, float* dx, float* dgamma, float* dbeta, int n_inst, int inner,
+                                        int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int ntok, int C,
+                                        int groups, float eps, float slope, int leaky, void* scratch, size_t scratch_bytes,
+                                        void* stream_) {
+    SOLA_ARG(x && dy && gamma && beta && dx && dgamma && dbeta && scratch, "group_norm_backward: null argument");
+    const size_t need = (size_t)2 * n_inst * C * sizeof(float);
+    if (scratch_bytes < need) {
+        sola_set_error("group_norm_backward: scratch %zu < %zu", scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    float* gp = static_cast<float*>(scratch);
+    float* bp = gp + (size_t)n_inst * C;
+    GroupNormBwdDesc d{x, dy, dy2, gamma, beta, dx, gp, bp, n_inst, inner, outer_stride, inner_stride, tok_stride, ntok, C, groups, eps, slope, leaky};
+    hipStream_t s = as_stream(stream_);
+    SOLA_TRY(launch_group_norm_bwd(d, s));
+    SOLA_TRY(launch_colsum(gp, dgamma, 1, n_inst, C, C, 1.f, 0, nullptr, 0, s));
+    return launch_colsum(bp, dbeta, 1, n_inst, C, C, 1.f, 0, nullptr, 0, s);
+}
+
 extern "C" int sola_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                               int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner,
-                              int64_t q_rs, int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, void* stream_) {
+                              int64_t q_rs, int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, float* lse,
+                              void* stream_) {
     SOLA_ARG(q && k && v && o, "attention: null argument");
-    AttnDesc d{q, k, v, o, ldq, ldk, ldv, ldo, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale};
+    AttnDesc d{q, k, v, o, ldq, ldk, ldv, ldo, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, lse};
     return launch_attention(d, as_stream(stream_));
+}
+
+// dq/dk/dv share the pitches of q/k/v; dvec scratch: (q rows) * H floats
+extern "C" int sola_attention_backward(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                       const float* o, const float* dout, int ldo, const float* lse, float* dq, float* dk,
+                                       float* dv, float* dvec, int G, int H, int head_dim, int Sq, int Sk, int inner,
+                                       int64_t q_outer, int64_t q_inner, int64_t q_rs, int64_t k_outer, int64_t k_inner,
+                                       int64_t k_rs, float scale, void* stream_) {
+    SOLA_ARG(q && k && v && o && dout && lse && dq && dk && dv && dvec, "attention_backward: null argument");
+    AttnBwdDesc d{q, k, v, o, dout, lse, dq, dk, dv, dvec, ldq, ldk, ldv, ldo, ldq, ldk, ldv, G, H, head_dim, Sq, Sk, inner,
+                  q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale};
+    return launch_attention_bwd(d, as_stream(stream_));
 }
 
 extern "C" int sola_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, void* stream_) {

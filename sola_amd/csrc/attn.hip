@@ -23,6 +23,7 @@ namespace {
 struct AttnArgs {
     const float *q, *k, *v;
     float* o;
+    float* lse;  // optional [q rows][H]: log-sum-exp of the scaled scores (saved for the backward)
     int ldq, ldk, ldv, ldo;
     int G, H, Sq, Sk, inner, nqb;
     long long q_outer, q_inner, q_rs;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
     }
 
     if (q_ok) {
+        if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * a.q_rs) * a.H + h] = m_run + logf(l_run);
         const float inv = 1.f / l_run;
         float* op = a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH + 4 * g4;
 #pragma unroll
@@ -236,6 +238,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale;
+    a.lse = d.lse;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     switch (d.DH) {

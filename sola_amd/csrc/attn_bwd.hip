@@ -1,0 +1,307 @@
+// Backward of the attention core (tools/attention.py:66-72 under autograd), exact f32 on v_mfma_f32_16x16x4_f32.
+// Two passes that each recompute the probabilities from the saved log-sum-exp (no S x S matrix is ever stored):
+//   attn_bwd_dq_kernel  : one wave per 16-query tile walks the keys.   P^T = exp(K Q^T - lse); dP^T = V dO^T;
+//                         dS^T = P^T o (dP^T - D); dQ^T += K^T dS^T.   Also writes D[q] = dO[q] . O[q].
+//   attn_bwd_dkv_kernel : one wave per 16-key tile walks the queries.  P = exp(Q K^T - lse); dP = dO V^T;
+//                         dS = P o (dP - D); dV^T += dO^T P; dK^T += Q^T dS.
+// In both passes the reduction index of every MFMA sits in the (lane>>4, register) slots and the row that owns the
+// softmax statistics sits in the 16-lane column (pass 1) or is fetched per register slot (pass 2), so - as in the
+// forward kernel - probabilities never move across lanes.  Every wave stages the streamed side through its own LDS
+// slice (16 rows at a time); all waves of a launch run the same trip count, so block barriers are uniform.
+// Addressing is the forward kernel's (outer / inner / row strides), so no permuted copies exist in the backward either.
+#include "kernels.h"
+
+namespace {
+
+struct AttnBwdArgs {
+    const float *q, *k, *v, *o, *dout, *lse;
+    float *dq, *dk, *dv, *dvec;  // dvec [q rows][H]
+    int ldq, ldk, ldv, ldo;      // ldo: row pitch of o / dout
+    int ld_dq, ld_dk, ld_dv;     // row pitches of the gradient outputs (they may be column slices of one matrix)
+    int G, H, Sq, Sk, inner, ntile;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    constexpr int NC = DH / 16, LD = DH + 4, F4 = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    float* Ks = smem + wave * 2 * 16 * LD;
+    float* Vs = Ks + 16 * LD;
+
+    const long long unit = (long long)blockIdx.x * 4 + wave;
+    const bool unit_ok = unit < (long long)a.G * a.H * a.ntile;
+    const int qt = unit_ok ? (int)(unit % a.ntile) : 0;
+    const long long gh = unit_ok ? unit / a.ntile : 0;
+    const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
+    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const int qi = qt * 16 + c16;
+    const bool q_ok = unit_ok && qi < a.Sq;
+    const long long qrow = qrow0 + (long long)qi * a.q_rs;
+
+    float4 qf[NC], dof[NC];
+    float dsum = 0.f;
+    {
+        const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
+        const float* op = a.o + qrow * a.ldo + h * DH + 4 * g4;
+        const float* gp = a.dout + qrow * a.ldo + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 qv = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : z;
+            const float4 ov = q_ok ? *reinterpret_cast<const float4*>(op + c * 16) : z;
+            const float4 gv = q_ok ? *reinterpret_cast<const float4*>(gp + c * 16) : z;
+            qf[c] = make_float4(qv.x * a.scale, qv.y * a.scale, qv.z * a.scale, qv.w * a.scale);
+            dof[c] = gv;
+            dsum += (ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w);
+        }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);  // D[q] for the lane's column
+    const float lse_q = q_ok ? a.lse[qrow * a.H + h] : 0.f;
+    if (q_ok && g4 == 0) a.dvec[qrow * a.H + h] = dsum;
+
+    f32x4 dqacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dqacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt0 = 0; kt0 < a.Sk; kt0 += 16) {
+        const int nrows = min(16, a.Sk - kt0);
+        __syncthreads();
+        if (unit_ok) {
+            for (int idx = lane; idx < 16 * F4; idx += 64) {
+                const int r = idx / F4, c4 = idx - r * F4;
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                if (r < nrows) {
+                    const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
+                    kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+                    vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+                }
+                *reinterpret_cast<float4*>(&Ks[r * LD + c4 * 4]) = kv;
+                *reinterpret_cast<float4*>(&Vs[r * LD + c4 * 4]) = vv;
+            }
+        }
+        __syncthreads();
+        // S^T[key][q] and dP^T[key][q]: A = K / V rows (b128), B = q / dO fragments
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+        const float* kp = &Ks[c16 * LD + 4 * g4];
+        const float* vp = &Vs[c16 * LD + 4 * g4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
+            const float4 vf = *reinterpret_cast<const float4*>(vp + c * 16);
+            if (c & 1) {
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, dof[c].x, p1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, dof[c].y, p1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, dof[c].z, p1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, dof[c].w, p1, 0, 0, 0);
+            } else {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, dof[c].x, p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, dof[c].y, p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, dof[c].z, p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, dof[c].w, p0, 0, 0, 0);
+            }
+        }
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool kok = kt0 + 4 * g4 + r < a.Sk;
+            const float p = (kok && q_ok) ? __expf((s0[r] + s1[r]) - lse_q) : 0.f;
+            ds[r] = p * ((p0[r] + p1[r]) - dsum);
+        }
+        // dQ^T[d][q] += sum_key K[key][d] * dS^T[key][q]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* kr = &Ks[(4 * g4 + r) * LD + c16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dqacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[c * 16], ds[r], dqacc[c], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        float* dp = a.dq + qrow * a.ld_dq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(dp + c * 16) = make_float4(dqacc[c][0] * a.scale, dqacc[c][1] * a.scale,
+                                                                  dqacc[c][2] * a.scale, dqacc[c][3] * a.scale);
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+    constexpr int NC = DH / 16, LD = DH + 4, F4 = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    float* Qs = smem + wave * 2 * 16 * LD;
+    float* Gs = Qs + 16 * LD;  // dO rows
+
+    const long long unit = (long long)blockIdx.x * 4 + wave;
+    const bool unit_ok = unit < (long long)a.G * a.H * a.ntile;
+    const int kt = unit_ok ? (int)(unit % a.ntile) : 0;
+    const long long gh = unit_ok ? unit / a.ntile : 0;
+    const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
+    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const int kj = kt * 16 + c16;
+    const bool k_ok = unit_ok && kj < a.Sk;
+    const long long krow = krow0 + (long long)kj * a.k_rs;
+
+    float4 kf[NC], vf[NC];
+    {
+        const float* kp = a.k + krow * a.ldk + h * DH + 4 * g4;
+        const float* vp = a.v + krow * a.ldv + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 kv = k_ok ? *reinterpret_cast<const float4*>(kp + c * 16) : z;
+            kf[c] = make_float4(kv.x * a.scale, kv.y * a.scale, kv.z * a.scale, kv.w * a.scale);
+            vf[c] = k_ok ? *reinterpret_cast<const float4*>(vp + c * 16) : z;
+        }
+    }
+    f32x4 dkacc[NC], dvacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int qt0 = 0; qt0 < a.Sq; qt0 += 16) {
+        const int nrows = min(16, a.Sq - qt0);
+        __syncthreads();
+        if (unit_ok) {
+            for (int idx = lane; idx < 16 * F4; idx += 64) {
+                const int r = idx / F4, c4 = idx - r * F4;
+                float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
+                if (r < nrows) {
+                    const long long row = qrow0 + (long long)(qt0 + r) * a.q_rs;
+                    qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
+                    gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
+                }
+                *reinterpret_cast<float4*>(&Qs[r * LD + c4 * 4]) = qv;
+                *reinterpret_cast<float4*>(&Gs[r * LD + c4 * 4]) = gv;
+            }
+        }
+        __syncthreads();
+        // S[q][key] and dP[q][key]: A = Q / dO rows (b128), B = k / v fragments; lane gets q = 4*g4 + r, key = c16
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+        const float* qp = &Qs[c16 * LD + 4 * g4];
+        const float* gp = &Gs[c16 * LD + 4 * g4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 qv = *reinterpret_cast<const float4*>(qp + c * 16);
+            const float4 gv = *reinterpret_cast<const float4*>(gp + c * 16);
+            if (c & 1) {
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, p1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[c].y, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, vf[c].y, p1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kf[c].z, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.z, vf[c].z, p1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kf[c].w, s1, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, p1, 0, 0, 0);
+            } else {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[c].y, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, vf[c].y, p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kf[c].z, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.z, vf[c].z, p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kf[c].w, s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, p0, 0, 0, 0);
+            }
+        }
+        float pr[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt0 + 4 * g4 + r;
+            const bool ok = k_ok && q < a.Sq;
+            float lse = 0.f, dv = 0.f;
+            if (ok) {
+                const long long row = qrow0 + (long long)q * a.q_rs;
+                lse = a.lse[row * a.H + h];
+                dv = a.dvec[row * a.H + h];
+            }
+            pr[r] = ok ? __expf((s0[r] + s1[r]) - lse) : 0.f;
+            ds[r] = pr[r] * ((p0[r] + p1[r]) - dv);
+        }
+        // dV^T[d][key] += sum_q dO[q][d] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* gr = &Gs[(4 * g4 + r) * LD + c16];
+            const float* qr = &Qs[(4 * g4 + r) * LD + c16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                dvacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[c * 16], pr[r], dvacc[c], 0, 0, 0);
+                dkacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[c * 16], ds[r], dkacc[c], 0, 0, 0);
+            }
+        }
+    }
+    if (k_ok) {
+        float* dkp = a.dk + krow * a.ld_dk + h * DH + 4 * g4;
+        float* dvp = a.dv + krow * a.ld_dv + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            *reinterpret_cast<float4*>(dkp + c * 16) = make_float4(dkacc[c][0] * a.scale, dkacc[c][1] * a.scale,
+                                                                   dkacc[c][2] * a.scale, dkacc[c][3] * a.scale);
+            *reinterpret_cast<float4*>(dvp + c * 16) = make_float4(dvacc[c][0], dvacc[c][1], dvacc[c][2], dvacc[c][3]);
+        }
+    }
+}
+
+template <int DH>
+int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * 2 * 16 * (DH + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    AttnBwdArgs a = a0;
+    a.ntile = (a.Sq + 15) / 16;
+    long long units = (long long)a.G * a.H * a.ntile;
+    SOLA_ARG((units + 3) / 4 < (1ll << 31), "attention backward: grid too large");
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    a.ntile = (a.Sk + 15) / 16;
+    units = (long long)a.G * a.H * a.ntile;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+}  // namespace
+
+int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
+    SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");
+    AttnBwdArgs a;
+    a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o; a.dout = d.dout; a.lse = d.lse;
+    a.dq = d.dq; a.dk = d.dk; a.dv = d.dv; a.dvec = d.dvec;
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.ld_dq = d.ld_dq; a.ld_dk = d.ld_dk; a.ld_dv = d.ld_dv;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.ntile = 1;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale;
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
+    switch (d.DH) {
+        case 128: return launch_bwd_dh<128>(a, s);
+        case 64: return launch_bwd_dh<64>(a, s);
+        case 32: return launch_bwd_dh<32>(a, s);
+        case 16: return launch_bwd_dh<16>(a, s);
+        default: sola_set_error("attention backward: head_dim %d unsupported", d.DH); return SOLA_ERR_ARG;
+    }
+}

@@ -1,0 +1,300 @@
+// Backward orchestration of the track-selection network (autograd of module/module.py:130-162): host code sequencing
+// gemm.hip (dX via the NT kernel on transposed weights / the transposed-conv gather), gemm_tn.hip (dW, db),
+// attn_bwd.hip, bwd.hip over the activations saved by sola_forward_impl(train = true).  Gradients of all 83
+// parameters are written to the borrowed buffers registered with sola_set_grad (overwrite semantics).
+#include <math.h>
+
+#include <algorithm>
+
+#include "ctx.h"
+
+namespace {
+
+struct Arena {
+    char* base;
+    size_t total = 0;
+    std::unordered_map<std::string, size_t> off;
+    size_t add(const std::string& name, size_t floats) {
+        off[name] = total;
+        total += (floats * sizeof(float) + 255) & ~(size_t)255;
+        return off[name];
+    }
+    float* get(const std::string& name) const { return reinterpret_cast<float*>(base + off.at(name)); }
+};
+
+Arena make_arena(const SolaCtx* c, const Plan& p) {
+    Arena a;
+    a.base = nullptr;
+    const size_t D = c->cfg.lang_token_dim, H = c->cfg.num_heads, M = p.M, BW = (size_t)p.B * p.W;
+    const size_t R = (size_t)p.B * p.N;
+    a.add("g0", M * D);
+    a.add("g1", M * D);
+    a.add("e", M * D);       // d(x + pe)
+    a.add("dres", M * D);
+    a.add("dattn", M * D);
+    a.add("dqkv", M * 3 * D);
+    a.add("dlkv", BW * 2 * D);
+    a.add("dlang", BW * D);
+    a.add("dvec", M * H);
+    a.add("dlbar_part", R * D);
+    a.add("dlbar", (size_t)p.B * D);
+    // GroupNorm partials are [n_inst][C]; n_inst is B*N (per track), B*T' (per time step) or B
+    size_t enc_max = 0, ws_total = 0, wt_max = 3 * D * D, tn_max = 0, inst_c_max = std::max(R, (size_t)p.B * p.Tp) * D;
+    int t_in = p.T;
+    for (int i = 0; i < 6; ++i) {
+        const ConvGeom& g = c->conv[i];
+        enc_max = std::max(enc_max, R * p.Tl[i] * (size_t)g.cout);
+        enc_max = std::max(enc_max, R * (size_t)t_in * g.cin);
+        ws_total += (size_t)g.cout * g.cin * g.k;
+        wt_max = std::max(wt_max, (size_t)g.cout * g.cin * g.k);
+        tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)(R * p.Tl[i]), g.cout, g.k * g.cin));
+        inst_c_max = std::max(inst_c_max, R * (size_t)g.cout);
+        t_in = p.Tl[i];
+    }
+    tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)M, (int)D, (int)D));
+    tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)BW, (int)D, (int)D));
+    a.add("enc0", enc_max);
+    a.add("enc1", enc_max);
+    a.add("dwstd", ws_total);
+    a.add("wt", wt_max);
+    a.add("tn", tn_max / sizeof(float) + 64);
+    a.add("gpart", inst_c_max);
+    a.add("bpart", inst_c_max);
+    a.add("colsum", colsum_scratch_bytes(1, (int)std::max(R, (size_t)p.B * p.Tp), (int)D) / sizeof(float) + 64);
+    return a;
+}
+
+}  // namespace
+
+size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p) { return make_arena(c, p).total; }
+
+extern "C" size_t sola_backward_workspace_bytes(const SolaCtx* c, int B, int N, int T, int L) {
+    if (!c || B <= 0 || N <= 0 || T <= 0 || L < 1) return 0;
+    return sola_backward_scratch_bytes(c, make_plan(c, B, N, T, L, true));
+}
+
+extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* d_score_tokens, const void* fwd_workspace,
+                             void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(c && d_score_map && d_score_tokens && fwd_workspace && scratch, "backward: null argument");
+    const Plan& p = c->last;
+    if (!p.train || p.M == 0) {
+        sola_set_error("backward: the last forward on this context was not sola_forward_train");
+        return SOLA_ERR_STATE;
+    }
+    for (const Weight& w : c->weights)
+        if (!w.grad && w.name != "positional_encoding_gaussian_matrix") {
+            sola_set_error("backward: no gradient buffer registered for '%s'", w.name.c_str());
+            return SOLA_ERR_WEIGHT;
+        }
+    Arena ar = make_arena(c, p);
+    if (scratch_bytes < ar.total) {
+        sola_set_error("backward: scratch %zu bytes < required %zu", scratch_bytes, ar.total);
+        return SOLA_ERR_WORKSPACE;
+    }
+    SOLA_ARG((reinterpret_cast<uintptr_t>(scratch) & 255) == 0, "backward: scratch must be 256-byte aligned");
+    ar.base = static_cast<char*>(scratch);
+    hipStream_t s = as_stream(stream_);
+    const char* fbase = static_cast<const char*>(fwd_workspace);
+    auto fb = [&](const std::string& name) { return reinterpret_cast<const float*>(fbase + p.bufs.at(name).off); };
+    auto W = [&](const std::string& name) { return ctx_weight(c, name); };
+    auto G = [&](const std::string& name) { return ctx_grad(c, name); };
+    const int B = p.B, N = p.N, Tp = p.Tp, M = p.M, Wn = p.W, L = p.L;
+    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
+    const int R = B * N;
+    const float scale = 1.0f / sqrtf((float)DH);
+    float* tn = ar.get("tn");
+    const size_t tn_bytes = ar.total - ar.off.at("tn");  // upper bound; launch_gemm_tn checks its own need
+    float* wt = ar.get("wt");
+
+    // ---- helpers ----------------------------------------------------------------------------------------------
+    // dW[N_out, K_in] = dY^T X, db = colsum(dY)
+    auto grad_w = [&](const float* dY, int ldy, const float* X, int ldx, int rows, int n_out, int k_in, float* dW, float* db) -> int {
+        GemmTnDesc d{};
+        d.A = dY; d.B = X; d.C = dW; d.bias_grad = db; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
+        d.scratch = tn; d.scratch_bytes = tn_bytes;
+        return launch_gemm_tn(d, s);
+    };
+    // dX[rows, k_in] = dY[rows, n_cat] * Wcat (+ R), where wt holds Wcat^T as [k_in][n_cat]
+    auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX) -> int {
+        GemmDesc d{};
+        d.nprob = 1;
+        d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
+        d.M = rows; d.N = k_in; d.K = n_cat; d.lda = ldy; d.ldr = k_in; d.ldc = k_in;
+        return launch_gemm(d, s);
+    };
+    auto transpose_into = [&](const float* w, int n_out, int k_in, int n_cat, int col_off) -> int {
+        return launch_transpose(w, wt, n_out, k_in, k_in, n_cat, col_off, s);  // wt[k][col_off + n] = w[n][k]
+    };
+    auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
+                      int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
+                      int leaky) -> int {
+        GroupNormBwdDesc d{};
+        d.x = xpre; d.dy = dy; d.dy2 = dy2; d.gamma = W(wname + ".weight"); d.beta = W(wname + ".bias"); d.dx = dx;
+        d.dgamma_part = ar.get("gpart"); d.dbeta_part = ar.get("bpart");
+        d.n_inst = n_inst; d.inner = inner; d.outer_stride = outer; d.inner_stride = inner_stride; d.tok_stride = tok_stride;
+        d.ntok = ntok; d.C = C; d.groups = groups; d.eps = 1e-5f; d.slope = 0.01f; d.leaky = leaky;
+        SOLA_TRY(launch_group_norm_bwd(d, s));
+        float* cs = ar.get("colsum");
+        const size_t csb = ar.total - ar.off.at("colsum");
+        SOLA_TRY(launch_colsum(ar.get("gpart"), G(wname + ".weight"), 1, n_inst, C, C, 1.f, 0, cs, csb, s));
+        return launch_colsum(ar.get("bpart"), G(wname + ".bias"), 1, n_inst, C, C, 1.f, 0, cs, csb, s);
+    };
+
+    // ---- score head -------------------------------------------------------------------------------------------
+    const std::string last = "l" + std::to_string(c->cfg.n_layers - 1) + "_o2l";
+    float* gbuf[2] = {ar.get("g0"), ar.get("g1")};
+    int cur = 0;
+    {
+        HeadBwdDesc d{fb(last), fb("lbar"), d_score_map, d_score_tokens, gbuf[cur], ar.get("dlbar_part"), B, N, Tp, D};
+        SOLA_TRY(launch_score_head_bwd(d, s));
+        SOLA_TRY(launch_colsum(ar.get("dlbar_part"), ar.get("dlbar"), B, N, D, D, 1.f, 0, nullptr, 0, s));
+    }
+    float* dres = ar.get("dres");
+    float* dattn = ar.get("dattn");
+    float* dqkv = ar.get("dqkv");
+    float* dlkv = ar.get("dlkv");
+    float* dlang = ar.get("dlang");
+    float* dvec = ar.get("dvec");
+    float* egrad = ar.get("e");
+    bool dlang_init = false;
+
+    for (int l = c->cfg.n_layers - 1; l >= 0; --l) {
+        const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
+        const std::string ls = "l" + std::to_string(l);
+        auto ab = [&](int a, const char* what) { return fb(abuf(true, l, kAttnShort[a], what)); };
+        const float* xin = l == 0 ? fb("conv5") : fb("l" + std::to_string(l - 1) + "_o2l");
+        // common tail of every sub-block: out_proj backward  (res = resid + attn * Wo^T + bo)
+        auto out_proj_bwd = [&](int a) -> int {
+            const std::string an = lp + kAttnLong[a];
+            SOLA_TRY(grad_w(dres, D, ab(a, "attn"), D, M, D, D, G(an + ".out_proj.weight"), G(an + ".out_proj.bias")));
+            SOLA_TRY(transpose_into(W(an + ".out_proj.weight"), D, D, D, 0));
+            return grad_x(dres, D, M, D, D, nullptr, dattn);
+        };
+
+        // (iii) object -> language: x_o2l = GN2(x_mot + attn(q(x_mot), k(lang), v(lang)) Wo)
+        {
+            const std::string an = lp + "object2lang_attn";
+            SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, N * Tp, D,
+                            c->cfg.n_groups_module, 0));
+            SOLA_TRY(out_proj_bwd(2));
+            AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
+                           dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
+                           B, H, DH, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
+            SOLA_TRY(launch_attention_bwd(ad, s));
+            const float* x_mot = fb(ls + "_motion");
+            SOLA_TRY(grad_w(dqkv, 3 * D, x_mot, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
+            SOLA_TRY(grad_w(dlkv, 2 * D, fb("lang"), D, B * Wn, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
+            SOLA_TRY(grad_w(dlkv + D, 2 * D, fb("lang"), D, B * Wn, D, D, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")));
+            SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, D, 0));
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur]));  // d x_mot = dres + dq Wq
+            SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
+            SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 2 * D, D));
+            SOLA_TRY(grad_x(dlkv, 2 * D, B * Wn, 2 * D, D, dlang_init ? dlang : nullptr, dlang));  // accumulate over layers
+            dlang_init = true;
+            cur = 1 - cur;
+        }
+        // (ii) motion: x_mot = GN1(x_obj + attn(q(x_obj+pe), k(x_obj+pe), v(x_obj)) Wo)
+        {
+            const std::string an = lp + "motion_attn";
+            SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, B * N, 1, Tp, 0, 1, Tp, D,
+                            c->cfg.n_groups_module, 0));
+            SOLA_TRY(out_proj_bwd(1));
+            AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
+                           dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
+                           B * N, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
+            SOLA_TRY(launch_attention_bwd(ad, s));
+            const float* x_pe = fb(ls + "_xpe");
+            const float* x_obj = fb(ls + "_obj");
+            SOLA_TRY(grad_w(dqkv, 3 * D, x_pe, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
+            SOLA_TRY(grad_w(dqkv + D, 3 * D, x_pe, D, M, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
+            SOLA_TRY(grad_w(dqkv + 2 * D, 3 * D, x_obj, D, M, D, D, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")));
+            SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 2 * D, 0));
+            SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, D));
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad));  // d(x_obj + pe) = dq Wq + dk Wk
+            SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, D, 0));
+            SOLA_TRY(grad_x(dqkv + 2 * D, 3 * D, M, D, D, dres, gbuf[1 - cur]));  // d x_obj (direct) = dres + dv Wv
+            cur = 1 - cur;
+        }
+        // (i) inter-object: x_obj = GN0(xin + attn(q,k,v(xin)) Wo); x_obj also feeds x_obj + pe
+        {
+            const std::string an = lp + "obj_attn";
+            SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, D,
+                            c->cfg.n_groups_module, 0));
+            SOLA_TRY(out_proj_bwd(0));
+            AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
+                           dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
+                           B * Tp, H, DH, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
+            SOLA_TRY(launch_attention_bwd(ad, s));
+            SOLA_TRY(grad_w(dqkv, 3 * D, xin, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
+            SOLA_TRY(grad_w(dqkv + D, 3 * D, xin, D, M, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
+            SOLA_TRY(grad_w(dqkv + 2 * D, 3 * D, xin, D, M, D, D, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")));
+            SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 3 * D, 0));
+            SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 3 * D, D));
+            SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 3 * D, 2 * D));
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur]));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
+            cur = 1 - cur;
+        }
+    }
+
+    // ---- negative tokens: rows L.. of d(lang ++ neg) from the k/v projections + the mean-over-W of the score head
+    SOLA_TRY(launch_neg_token_grad(dlang, ar.get("dlbar"), nullptr, G("negative_token.weight"), B, L, c->cfg.n_negative, D, s));
+
+    // ---- encoder ----------------------------------------------------------------------------------------------
+    const float* dy = gbuf[cur];  // gradient wrt conv5 output [R*T', D]
+    float* enc[2] = {ar.get("enc0"), ar.get("enc1")};
+    float* dwstd = ar.get("dwstd");
+    size_t ws_off[6];
+    {
+        size_t o = 0;
+        for (int i = 0; i < 6; ++i) {
+            ws_off[i] = o;
+            o += (size_t)c->conv[i].cout * c->conv[i].cin * c->conv[i].k;
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        const ConvGeom& g = c->conv[i];
+        const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
+        const int t_in = i == 0 ? p.T : p.Tl[i - 1];
+        const int rows = R * p.Tl[i];
+        const float* x_in = i == 0 ? nullptr : fb("act" + std::to_string(i - 1));
+        // dW_std[cout][k*cin] = dY^T im2col(x_in), db
+        {
+            GemmTnDesc d{};
+            d.A = dy; d.B = i == 0 ? c->last_obj : x_in; d.C = dwstd + ws_off[i]; d.bias_grad = G(cp + ".bias");
+            d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
+            d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
+            d.scratch = tn; d.scratch_bytes = tn_bytes;
+            SOLA_TRY(launch_gemm_tn(d, s));
+        }
+        if (i == 0) break;
+        // d act_{i-1}[(r, ti)][ci] = sum_{kk, co} dY[(r, to)][co] w_std[co][kk][ci]: the NT kernel with the transposed-conv
+        // gather over dY and the weights re-laid-out to [cin][kk*cout + co]
+        float* dact = enc[0];
+        for (int kk = 0; kk < g.k; ++kk)
+            SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, wt, g.cout, g.cin, g.k * g.cin,
+                                      g.k * g.cout, kk * g.cout, s));
+        {
+            GemmDesc d{};
+            d.nprob = 1;
+            d.p[0] = GemmProblem{dy, wt, nullptr, nullptr, dact};
+            d.M = R * t_in; d.N = g.cin; d.K = g.k * g.cout; d.lda = g.cout; d.ldc = g.cin;
+            d.conv = g.k > 1 ? 2 : 0; d.T_in = p.Tl[i]; d.T_out = t_in; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cout;
+            SOLA_TRY(launch_gemm(d, s));
+        }
+        // GroupNorm + LeakyReLU backward of stage i-1
+        const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i - 1]);
+        SOLA_TRY(gn_bwd(fb("conv" + std::to_string(i - 1)), dact, nullptr, np, enc[1], R, 1, t_in, 0, 1, t_in, g.cin,
+                        c->cfg.n_groups, 1));
+        dy = enc[1];  // dact (enc[0]) is consumed; the next stage's dX may overwrite it, its GN backward overwrites enc[1]
+    }
+    // weight-standardisation backward for all six convs
+    {
+        WsBwdLayer layers[6];
+        for (int i = 0; i < 6; ++i) {
+            const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
+            layers[i] = WsBwdLayer{W(cp + ".weight"), dwstd + ws_off[i], G(cp + ".weight"), c->conv[i].cout, c->conv[i].cin, c->conv[i].k};
+        }
+        SOLA_TRY(launch_ws_backward(layers, 6, s));
+    }
+    return SOLA_OK;
+}

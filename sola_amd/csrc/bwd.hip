@@ -1,0 +1,442 @@
+// Backward of the HBM-bound stages (autograd of module/module.py:76-92,34-49,152-160, module/ws.py:9-13,
+// train.py:98-113, tools/loss.py:29-56).  Same decomposition and deterministic reductions as the forward kernels.
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm backward: one block per (instance, group).  Statistics are recomputed exactly as in the forward.
+//   g = dy * lrelu'(y) * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));
+//   per-instance partial dgamma[c] = sum_tokens dy' * xhat, dbeta[c] = sum_tokens dy'   (reduced later by colsum)
+// ---------------------------------------------------------------------------------------------------------------
+struct GnBwdArgs {
+    const float *x, *dy, *dy2, *gamma, *beta;
+    float *dx, *dgp, *dbp;
+    int inner;
+    long long outer_stride, inner_stride, tok_stride;
+    int ntok, C, cg;
+    float eps, slope;
+    int leaky;
+};
+
+__global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) {
+    __shared__ float red[4];
+    __shared__ float part[256 * 8];
+    const int g = blockIdx.y, inst = blockIdx.x;
+    const int lpt = a.cg >> 2;
+    const int tpp = 256 / lpt;
+    const int tl = threadIdx.x / lpt;
+    const int c4 = threadIdx.x - tl * lpt;
+    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const int ch = g * a.cg + c4 * 4;
+    const bool active = tl < tpp;
+    const float cnt = (float)a.ntok * (float)a.cg;
+
+    float s = 0.f;
+    if (active)
+        for (int t = tl; t < a.ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    const float mean = block_sum_256(s, red) / cnt;
+    float q = 0.f;
+    if (active)
+        for (int t = tl; t < a.ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float var = block_sum_256(q, red) / cnt;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+
+    float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), be = ga;
+    if (active) {
+        ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+        be = *reinterpret_cast<const float4*>(a.beta + ch);
+    }
+    auto grad_in = [&](long long off, const float4& xh) {
+        float4 d = *reinterpret_cast<const float4*>(a.dy + off);
+        if (a.dy2) {
+            const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
+            d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+        }
+        if (a.leaky) {
+            if (xh.x * ga.x + be.x < 0.f) d.x *= a.slope;
+            if (xh.y * ga.y + be.y < 0.f) d.y *= a.slope;
+            if (xh.z * ga.z + be.z < 0.f) d.z *= a.slope;
+            if (xh.w * ga.w + be.w < 0.f) d.w *= a.slope;
+        }
+        return d;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+    if (active)
+        for (int t = tl; t < a.ntok; t += tpp) {
+            const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+            const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+            const float4 d = grad_in(off, xh);
+            dgam.x += d.x * xh.x; dgam.y += d.y * xh.y; dgam.z += d.z * xh.z; dgam.w += d.w * xh.w;
+            dbet.x += d.x; dbet.y += d.y; dbet.z += d.z; dbet.w += d.w;
+            const float g0 = d.x * ga.x, g1 = d.y * ga.y, g2 = d.z * ga.z, g3 = d.w * ga.w;
+            s1 += (g0 + g1) + (g2 + g3);
+            s2 += (g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w);
+        }
+    const float m1 = block_sum_256(s1, red) / cnt;
+    const float m2 = block_sum_256(s2, red) / cnt;
+    // per-channel partials: reduce the token slots that share a channel quad
+    float* pp = &part[threadIdx.x * 8];
+    pp[0] = dgam.x; pp[1] = dgam.y; pp[2] = dgam.z; pp[3] = dgam.w;
+    pp[4] = dbet.x; pp[5] = dbet.y; pp[6] = dbet.z; pp[7] = dbet.w;
+    __syncthreads();
+    if (threadIdx.x < lpt) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < tpp; ++sl) {
+            const float* src = &part[(sl * lpt + threadIdx.x) * 8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += src[j];
+        }
+        const long long o = (long long)inst * a.C + g * a.cg + threadIdx.x * 4;
+        *reinterpret_cast<float4*>(a.dgp + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(a.dbp + o) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    if (!active) return;
+    for (int t = tl; t < a.ntok; t += tpp) {
+        const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+        const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+        const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+        const float4 d = grad_in(off, xh);
+        float4 o;
+        o.x = rstd * (d.x * ga.x - m1 - xh.x * m2);
+        o.y = rstd * (d.y * ga.y - m1 - xh.y * m2);
+        o.z = rstd * (d.z * ga.z - m1 - xh.z * m2);
+        o.w = rstd * (d.w * ga.w - m1 - xh.w * m2);
+        *reinterpret_cast<float4*>(a.dx + off) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight-standardisation backward (module/ws.py:9-13): w_hat = c / (sigma + eps), c = w - mean(w),
+// sigma = sqrt(sum c^2 / (n-1)).  dc = g / s - (sum g w_hat) c / (s (n-1) sigma);  dw = dc - mean(dc)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WSB_MAX_LAYERS = 8, WSB_MAX_PER_THREAD = 16;
+struct WsBwdArgs {
+    WsBwdLayer layer[WSB_MAX_LAYERS];
+    int first_block[WSB_MAX_LAYERS + 1];
+    int n_layers;
+};
+
+__global__ __launch_bounds__(256) void ws_backward_kernel(const WsBwdArgs a) {
+    __shared__ float red[4];
+    int li = 0;
+    while (li + 1 < a.n_layers && (int)blockIdx.x >= a.first_block[li + 1]) ++li;
+    const WsBwdLayer L = a.layer[li];
+    const int co = blockIdx.x - a.first_block[li];
+    const int n = L.cin * L.k;
+    const float* w = L.w + (long long)co * n;
+    const float* gsrc = L.dwstd + (long long)co * n;
+    float c[WSB_MAX_PER_THREAD], g[WSB_MAX_PER_THREAD];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < WSB_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        c[i] = idx < n ? w[idx] : 0.f;
+        if (idx < n) {
+            const int ci = idx / L.k, kk = idx - ci * L.k;
+            g[i] = gsrc[kk * L.cin + ci];
+        } else {
+            g[i] = 0.f;
+        }
+        s += c[i];
+    }
+    const float mean = block_sum_256(s, red) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < WSB_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        c[i] = idx < n ? c[i] - mean : 0.f;
+        q += c[i] * c[i];
+    }
+    const float var = block_sum_256(q, red) / (float)(n - 1);
+    const float sigma = sqrtf(var);
+    const float sden = sigma + 1e-5f;
+    float gw = 0.f;
+#pragma unroll
+    for (int i = 0; i < WSB_MAX_PER_THREAD; ++i) gw += g[i] * (c[i] / sden);
+    const float A = block_sum_256(gw, red);
+    const float k2 = sigma > 0.f ? A / (sden * (float)(n - 1) * sigma) : 0.f;
+    float ds = 0.f;
+#pragma unroll
+    for (int i = 0; i < WSB_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        g[i] = idx < n ? g[i] / sden - k2 * c[i] : 0.f;  // dc
+        ds += g[i];
+    }
+    const float dmean = block_sum_256(ds, red) / (float)n;
+    float* out = L.dw + (long long)co * n;
+#pragma unroll
+    for (int i = 0; i < WSB_MAX_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < n) out[idx] = g[i] - dmean;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// score head backward (module/module.py:152-160)
+// ---------------------------------------------------------------------------------------------------------------
+struct HeadBwdArgs {
+    const float *x, *lbar, *d_score, *d_tok;
+    float *dx, *dlbar_part;
+    int N, Tp, D;
+};
+
+__global__ __launch_bounds__(256) void score_head_bwd_kernel(const HeadBwdArgs a) {
+    extern __shared__ float sh[];
+    const int tp4 = (a.Tp + 3) & ~3;
+    float* aw = sh;             // softmax weights a_t
+    float* da = sh + tp4;       // da_t, then dlogit_t
+    float* red = sh + 2 * tp4;  // 4
+    const int bn = blockIdx.x, b = bn / a.N;
+    const int d4n = a.D >> 2;
+    const float4* xb = reinterpret_cast<const float4*>(a.x + (long long)bn * a.Tp * a.D);
+    const float4* lb = reinterpret_cast<const float4*>(a.lbar + (long long)b * a.D);
+    const float4* dt = reinterpret_cast<const float4*>(a.d_tok + (long long)bn * a.D);
+    const float ds = a.d_score[bn];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // logits_t = x_t . lbar ; da_t = dtok . x_t with dtok = d_tok + ds * lbar
+    for (int t = wave; t < a.Tp; t += 4) {
+        float s = 0.f, u = 0.f;
+        for (int i = lane; i < d4n; i += 64) {
+            const float4 xv = xb[(long long)t * d4n + i], lv = lb[i], gv = dt[i];
+            s += (xv.x * lv.x + xv.y * lv.y) + (xv.z * lv.z + xv.w * lv.w);
+            u += (xv.x * (gv.x + ds * lv.x) + xv.y * (gv.y + ds * lv.y)) + (xv.z * (gv.z + ds * lv.z) + xv.w * (gv.w + ds * lv.w));
+        }
+        s = wave_sum(s);
+        u = wave_sum(u);
+        if (lane == 0) { aw[t] = s; da[t] = u; }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = 0; t < a.Tp; ++t) mx = fmaxf(mx, aw[t]);
+    float den = 0.f;
+    for (int t = 0; t < a.Tp; ++t) den += expf(aw[t] - mx);
+    float sada = 0.f;
+    for (int t = 0; t < a.Tp; ++t) sada += (expf(aw[t] - mx) / den) * da[t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.Tp; t += 256) {
+        const float w = expf(aw[t] - mx) / den;
+        aw[t] = w;
+        da[t] = w * (da[t] - sada);  // dlogit_t
+    }
+    __syncthreads();
+    float4* dxo = reinterpret_cast<float4*>(a.dx + (long long)bn * a.Tp * a.D);
+    float4* dlb = reinterpret_cast<float4*>(a.dlbar_part + (long long)bn * a.D);
+    for (int i = threadIdx.x; i < d4n; i += 256) {
+        const float4 lv = lb[i], gv = dt[i];
+        const float4 dtok = make_float4(gv.x + ds * lv.x, gv.y + ds * lv.y, gv.z + ds * lv.z, gv.w + ds * lv.w);
+        float4 tok = make_float4(0.f, 0.f, 0.f, 0.f), acc = tok;
+        for (int t = 0; t < a.Tp; ++t) {
+            const float w = aw[t], dl = da[t];
+            const float4 xv = xb[(long long)t * d4n + i];
+            tok.x += w * xv.x; tok.y += w * xv.y; tok.z += w * xv.z; tok.w += w * xv.w;
+            acc.x += dl * xv.x; acc.y += dl * xv.y; acc.z += dl * xv.z; acc.w += dl * xv.w;
+            dxo[(long long)t * d4n + i] = make_float4(w * dtok.x + dl * lv.x, w * dtok.y + dl * lv.y,
+                                                      w * dtok.z + dl * lv.z, w * dtok.w + dl * lv.w);
+        }
+        dlb[i] = make_float4(ds * tok.x + acc.x, ds * tok.y + acc.y, ds * tok.z + acc.z, ds * tok.w + acc.w);
+    }
+    (void)red;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// loss backward (train.py:98-113, tools/loss.py:29-56)
+// ---------------------------------------------------------------------------------------------------------------
+struct LossBwdArgs {
+    const float *score_map, *score_tokens, *labels, *pos, *neg;
+    long long neg_batch_stride;
+    int B, N, D, n_neg;
+    float pos_w, temp_scale, align_w;
+    const float* g3;
+    float *d_score, *d_tok, *coef;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const LossBwdArgs a) {
+    extern __shared__ float sh[];
+    float* negl = sh;  // [n_neg] logits, then coefficients
+    float* red = sh + ((a.n_neg + 3) & ~3);
+    float* sc = red + 4;  // [2]: dpos coefficient
+    const int bn = blockIdx.x, b = bn / a.N;
+    const int d4n = a.D >> 2;
+    const float4* tok = reinterpret_cast<const float4*>(a.score_tokens + (long long)bn * a.D);
+    const float4* pos = reinterpret_cast<const float4*>(a.pos + (long long)b * a.D);
+    const float* negb = a.neg + (long long)b * a.neg_batch_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float p = 0.f;
+    for (int i = threadIdx.x; i < d4n; i += 256) {
+        const float4 tv = tok[i], pv = pos[i];
+        p += (tv.x * pv.x + tv.y * pv.y) + (tv.z * pv.z + tv.w * pv.w);
+    }
+    const float pos_logit = block_sum_256(p, red) * a.temp_scale;
+    for (int m = wave; m < a.n_neg; m += 4) {
+        const float4* nv = reinterpret_cast<const float4*>(negb + (long long)m * a.D);
+        float s = 0.f;
+        for (int i = lane; i < d4n; i += 64) {
+            const float4 tv = tok[i], v = nv[i];
+            s += (tv.x * v.x + tv.y * v.y) + (tv.z * v.z + tv.w * v.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) negl[m] = s * a.temp_scale;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float bn_count = (float)a.B * (float)a.N;
+        const float y = a.labels[bn], x = a.score_map[bn];
+        const float w = y > 0.f ? a.pos_w : 1.f;
+        const float cb = a.g3[0] + a.g3[1];               // d total / d bce
+        const float ca = a.g3[0] * a.align_w + a.g3[2];   // d total / d align
+        a.d_score[bn] = cb * w * (sigmoidf_(x) - y) / bn_count;
+        int arg = 0;
+        float best = negl[0];
+        for (int m = 1; m < a.n_neg; ++m)
+            if (negl[m] > best) { best = negl[m]; arg = m; }
+        sc[0] = a.temp_scale * ca * a.pos_w * (sigmoidf_(pos_logit) - y) / bn_count;
+        for (int m = 0; m < a.n_neg; ++m) {
+            const float target = m == arg ? (1.f - y) : 0.f;
+            const float cf = a.temp_scale * ca * (sigmoidf_(negl[m]) - target) / (bn_count * (float)a.n_neg);
+            negl[m] = cf;
+            a.coef[(long long)bn * a.n_neg + m] = cf;
+        }
+    }
+    __syncthreads();
+    const float dpos = sc[0];
+    float4* out = reinterpret_cast<float4*>(a.d_tok + (long long)bn * a.D);
+    for (int i = threadIdx.x; i < d4n; i += 256) {
+        const float4 pv = pos[i];
+        float4 acc = make_float4(dpos * pv.x, dpos * pv.y, dpos * pv.z, dpos * pv.w);
+        for (int m = 0; m < a.n_neg; ++m) {
+            const float cf = negl[m];
+            const float4 v = reinterpret_cast<const float4*>(negb + (long long)m * a.D)[i];
+            acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
+        }
+        out[i] = acc;
+    }
+}
+
+// d_neg[b][m][:] = sum_n coef[b,n,m] * tok[b,n,:]
+__global__ __launch_bounds__(256) void loss_dneg_kernel(const float* __restrict__ coef, const float* __restrict__ tok,
+                                                        float* __restrict__ d_neg, int N, int D, int n_neg) {
+    const int b = blockIdx.x / n_neg, m = blockIdx.x % n_neg;
+    const int d4n = D >> 2;
+    for (int i = threadIdx.x; i < d4n; i += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < N; ++n) {
+            const float cf = coef[((long long)b * N + n) * n_neg + m];
+            const float4 v = reinterpret_cast<const float4*>(tok + ((long long)b * N + n) * D)[i];
+            acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
+        }
+        reinterpret_cast<float4*>(d_neg + ((long long)b * n_neg + m) * D)[i] = acc;
+    }
+}
+
+// d_negw[m][:] = sum_b ( d_lang[b, L+m, :] + dlbar[b, :] / W + d_neg_align[b, m, :] )
+__global__ __launch_bounds__(256) void neg_token_grad_kernel(const float* __restrict__ d_lang, const float* __restrict__ dlbar,
+                                                             const float* __restrict__ d_neg_align, float* __restrict__ out,
+                                                             int B, int L, int n_neg, int D) {
+    const int m = blockIdx.x;
+    const int W = L + n_neg;
+    const float invw = 1.f / (float)W;
+    for (int i = threadIdx.x; i < (D >> 2); i += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            if (d_lang) {
+                const float4 v = reinterpret_cast<const float4*>(d_lang + ((long long)b * W + L + m) * D)[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (dlbar) {
+                const float4 v = reinterpret_cast<const float4*>(dlbar + (long long)b * D)[i];
+                acc.x += v.x * invw; acc.y += v.y * invw; acc.z += v.z * invw; acc.w += v.w * invw;
+            }
+            if (d_neg_align) {
+                const float4 v = reinterpret_cast<const float4*>(d_neg_align + ((long long)b * n_neg + m) * D)[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(out + (long long)m * D)[i] = acc;
+    }
+}
+
+}  // namespace
+
+int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
+    SOLA_ARG(d.groups > 0 && d.C % d.groups == 0, "group_norm_bwd: C=%d groups=%d", d.C, d.groups);
+    const int cg = d.C / d.groups;
+    SOLA_ARG(cg % 4 == 0 && cg / 4 <= 256, "group_norm_bwd: channels per group %d unsupported", cg);
+    SOLA_ARG(d.n_inst > 0 && d.ntok > 0 && d.inner > 0, "group_norm_bwd: bad sizes");
+    GnBwdArgs a;
+    a.x = d.x; a.dy = d.dy; a.dy2 = d.dy2; a.gamma = d.gamma; a.beta = d.beta; a.dx = d.dx; a.dgp = d.dgamma_part; a.dbp = d.dbeta_part;
+    a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky;
+    const double elems = (double)d.n_inst * d.ntok * d.C;
+    SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
+    hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_ws_backward(const WsBwdLayer* layers, int n_layers, hipStream_t s) {
+    SOLA_ARG(n_layers >= 1 && n_layers <= WSB_MAX_LAYERS, "ws_backward: %d layers", n_layers);
+    WsBwdArgs a;
+    a.n_layers = n_layers;
+    int blocks = 0;
+    double elems = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        SOLA_ARG(layers[i].cin * layers[i].k <= 256 * WSB_MAX_PER_THREAD && layers[i].cin * layers[i].k >= 2, "ws_backward: cin*k unsupported");
+        a.layer[i] = layers[i];
+        a.first_block[i] = blocks;
+        blocks += layers[i].cout;
+        elems += (double)layers[i].cout * layers[i].cin * layers[i].k;
+    }
+    a.first_block[n_layers] = blocks;
+    SolaProfScope prof(SOLA_PROF_WS, s, 12.0 * elems, 12.0 * elems);
+    hipLaunchKernelGGL(ws_backward_kernel, dim3(blocks), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_score_head_bwd(const HeadBwdDesc& d, hipStream_t s) {
+    SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.Tp > 0, "score_head_bwd: bad sizes");
+    HeadBwdArgs a{d.x, d.lbar, d.d_score, d.d_tok, d.dx, d.dlbar_part, d.N, d.Tp, d.D};
+    const size_t lds = (2 * (((size_t)d.Tp + 3) & ~(size_t)3) + 4) * sizeof(float);
+    SOLA_ARG(lds <= 60000, "score_head_bwd: T'=%d too long", d.Tp);
+    const double elems = (double)d.B * d.N * d.Tp * d.D;
+    SolaProfScope prof(SOLA_PROF_HEAD, s, 10.0 * elems, 12.0 * elems);
+    hipLaunchKernelGGL(score_head_bwd_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_loss_bwd(const LossBwdDesc& d, hipStream_t s) {
+    SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.n_neg > 0 && d.n_neg < 8192, "loss_bwd: bad sizes");
+    LossBwdArgs a{d.score_map, d.score_tokens, d.labels, d.pos, d.neg, d.neg_batch_stride, d.B, d.N, d.D, d.n_neg,
+                  d.pos_w, d.temp_scale, d.align_w, d.g3, d.d_score, d.d_tok, d.coef};
+    const size_t lds = ((((size_t)d.n_neg + 3) & ~(size_t)3) + 8) * sizeof(float);
+    SolaProfScope prof(SOLA_PROF_HEAD, s, 4.0 * d.B * d.N * (double)d.D * (d.n_neg + 1), 8.0 * d.B * d.N * (double)d.D);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    if (d.d_neg) {
+        hipLaunchKernelGGL(loss_dneg_kernel, dim3(d.B * d.n_neg), dim3(256), 0, s, d.coef, d.score_tokens, d.d_neg, d.N, d.D, d.n_neg);
+        SOLA_LAUNCH_CHECK();
+    }
+    return SOLA_OK;
+}
+
+int launch_neg_token_grad(const float* d_lang, const float* dlbar, const float* d_neg_align, float* d_negw, int B, int L,
+                          int n_neg, int D, hipStream_t s) {
+    SOLA_ARG(d_negw && B > 0 && n_neg > 0 && D % 4 == 0, "neg_token_grad: bad arguments");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 12.0 * B * n_neg * (double)D);
+    hipLaunchKernelGGL(neg_token_grad_kernel, dim3(n_neg), dim3(256), 0, s, d_lang, dlbar, d_neg_align, d_negw, B, L, n_neg, D);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}

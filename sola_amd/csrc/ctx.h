@@ -1,0 +1,73 @@
+// Context, weight registry and workspace plan shared by api.hip / forward.hip / backward.hip.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+struct ConvGeom {
+    int cin, cout, k, stride, pad;
+};
+struct Weight {
+    std::string name;
+    int64_t numel;
+    const float* ptr;  // borrowed parameter / buffer storage
+    float* grad;       // borrowed gradient storage (training only)
+};
+struct Buf {
+    size_t off;
+    int64_t rows, cols;
+};
+struct Plan {
+    int B = 0, N = 0, T = 0, L = 0, W = 0, Tp = 0, M = 0;
+    int Tl[6] = {0};
+    bool train = false;
+    std::unordered_map<std::string, Buf> bufs;
+    size_t total = 0;
+    size_t add(const std::string& name, int64_t rows, int64_t cols) {
+        const size_t off = total;
+        bufs[name] = Buf{off, rows, cols};
+        total += (((size_t)rows * (size_t)cols * sizeof(float)) + 255) & ~(size_t)255;
+        return off;
+    }
+};
+
+struct SolaCtx {
+    SolaConfig cfg;
+    int device;
+    ConvGeom conv[6];
+    std::vector<Weight> weights;
+    std::unordered_map<std::string, int> index;
+    float* ws_buf = nullptr;  // standardised conv weights [cout][k*cin], all six layers, ctx-owned
+    size_t ws_off[6];
+    bool ws_dirty = true;
+    bool ws_every_forward = true;
+    Plan last;                // plan of the last forward (taps, backward)
+    const float* last_obj = nullptr;  // input of the last training forward (conv0's weight gradient reads it)
+};
+
+static const int kConvIdx[6] = {0, 4, 8, 12, 16, 20};
+static const int kNormIdx[5] = {1, 5, 9, 13, 17};
+static const char* const kAttnShort[3] = {"obj", "mot", "o2l"};
+static const char* const kAttnLong[3] = {"obj_attn", "motion_attn", "object2lang_attn"};
+
+inline const float* ctx_weight(const SolaCtx* c, const std::string& name) {
+    auto it = c->index.find(name);
+    return it == c->index.end() ? nullptr : c->weights[it->second].ptr;
+}
+inline float* ctx_grad(const SolaCtx* c, const std::string& name) {
+    auto it = c->index.find(name);
+    return it == c->index.end() ? nullptr : c->weights[it->second].grad;
+}
+
+// Name of a per-attention buffer: shared scratch in inference, one per (layer, attention) when saving for backward.
+inline std::string abuf(bool train, int layer, const char* attn, const char* what) {
+    if (!train) return what;
+    return "l" + std::to_string(layer) + "_" + attn + "_" + what;
+}
+
+Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train);
+int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
+                      float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train);
+size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p);

@@ -1,0 +1,199 @@
+// Forward orchestration of LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162): host code that
+// sequences the kernels of gemm.hip / attn.hip / norm.hip / head.hip over one workspace arena.  With train = true every
+// attention keeps its own q/k/v/output/residual buffers plus the softmax log-sum-exp, which backward.hip consumes.
+#include <math.h>
+
+#include "ctx.h"
+
+Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
+    Plan p;
+    p.B = B; p.N = N; p.T = T; p.L = L; p.train = train;
+    p.W = L + c->cfg.n_negative;
+    int t = T;
+    for (int i = 0; i < 6; ++i) {
+        t = (t + 2 * c->conv[i].pad - c->conv[i].k) / c->conv[i].stride + 1;
+        p.Tl[i] = t;
+    }
+    p.Tp = p.Tl[5];
+    p.M = B * N * p.Tp;
+    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads;
+    const int64_t R = (int64_t)B * N;
+    for (int i = 0; i < 6; ++i) {
+        p.add("conv" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
+        if (i < 5) p.add("act" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
+    }
+    p.add("pe", p.Tp, D);
+    p.add("lang", (int64_t)B * p.W, D);
+    p.add("lbar", B, D);
+    const int n_sets = train ? c->cfg.n_layers : 1;
+    for (int l = 0; l < n_sets; ++l)
+        for (int a = 0; a < (train ? 3 : 1); ++a) {
+            p.add(abuf(train, l, kAttnShort[a], "q"), p.M, D);
+            if (!train || a < 2) {
+                p.add(abuf(train, l, kAttnShort[a], "k"), p.M, D);
+                p.add(abuf(train, l, kAttnShort[a], "v"), p.M, D);
+            }
+            p.add(abuf(train, l, kAttnShort[a], "attn"), p.M, D);
+            p.add(abuf(train, l, kAttnShort[a], "res"), p.M, D);
+            if (train) p.add(abuf(train, l, kAttnShort[a], "lse"), p.M, H);
+            if (!train || a == 2) {
+                p.add(abuf(train, l, kAttnShort[a], "lk"), (int64_t)B * p.W, D);
+                p.add(abuf(train, l, kAttnShort[a], "lv"), (int64_t)B * p.W, D);
+            }
+        }
+    for (int l = 0; l < c->cfg.n_layers; ++l) {
+        p.add("l" + std::to_string(l) + "_obj", p.M, D);
+        p.add("l" + std::to_string(l) + "_xpe", p.M, D);
+        p.add("l" + std::to_string(l) + "_motion", p.M, D);
+        p.add("l" + std::to_string(l) + "_o2l", p.M, D);
+    }
+    return p;
+}
+
+int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
+                      float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train) {
+    SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
+    SOLA_ARG(B > 0 && N > 0 && T > 0 && L >= 1, "forward: bad sizes B=%d N=%d T=%d L=%d", B, N, T, L);
+    for (const Weight& w : c->weights)
+        if (!w.ptr) {
+            sola_set_error("forward: weight '%s' has not been set", w.name.c_str());
+            return SOLA_ERR_WEIGHT;
+        }
+    Plan p = make_plan(c, B, N, T, L, train);
+    if (ws_bytes < p.total) {
+        sola_set_error("forward: workspace %zu bytes < required %zu", ws_bytes, p.total);
+        return SOLA_ERR_WORKSPACE;
+    }
+    SOLA_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "forward: workspace must be 256-byte aligned");
+    char* base = static_cast<char*>(workspace);
+    auto buf = [&](const std::string& name) { return reinterpret_cast<float*>(base + p.bufs.at(name).off); };
+    auto W = [&](const std::string& name) { return ctx_weight(c, name); };
+    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
+    const int Tp = p.Tp, M = p.M, Wn = p.W;
+    const int R = B * N;
+
+    // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
+    if (c->ws_dirty || c->ws_every_forward || train) {
+        WsLayer layers[6];
+        for (int i = 0; i < 6; ++i) {
+            const std::string nm = "short_motion_encoder." + std::to_string(kConvIdx[i]) + ".weight";
+            layers[i] = WsLayer{W(nm), c->ws_buf + c->ws_off[i], c->conv[i].cout, c->conv[i].cin, c->conv[i].k};
+        }
+        SOLA_TRY(launch_ws_standardize(layers, 6, s));
+        c->ws_dirty = false;
+    }
+
+    // a2: encoder (module/module.py:74-96,137-140)
+    const float* x = obj;
+    int t_in = T;
+    for (int i = 0; i < 6; ++i) {
+        const ConvGeom& g = c->conv[i];
+        const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
+        GemmDesc gd{};
+        gd.nprob = 1;
+        gd.p[0] = GemmProblem{x, c->ws_buf + c->ws_off[i], W(cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
+        gd.M = R * p.Tl[i]; gd.N = g.cout; gd.K = g.k * g.cin;
+        gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
+        gd.conv = g.k > 1 ? 1 : 0;
+        gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
+        SOLA_TRY(launch_gemm(gd, s));
+        if (i < 5) {
+            const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
+            GroupNormDesc nd{};
+            nd.x = buf("conv" + std::to_string(i)); nd.y = buf("act" + std::to_string(i)); nd.y2 = nullptr; nd.pe = nullptr;
+            nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
+            nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
+            nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
+            SOLA_TRY(launch_group_norm(nd, s));
+            x = buf("act" + std::to_string(i));
+        } else {
+            x = buf("conv5");
+        }
+        t_in = p.Tl[i];
+    }
+
+    // a3: positional table; text tokens ++ negative tokens and their mean (module/module.py:143-147)
+    SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
+    SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
+
+    // a5: alignment layers (module/module.py:22-52)
+    const float scale = 1.0f / sqrtf((float)DH);
+    auto linear3 = [&](const float* a0, const float* a1, const float* a2, const std::string& attn, int nprob, int rows,
+                       float* o0, float* o1, float* o2, int first_proj) -> int {
+        static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
+        const float* as[3] = {a0, a1, a2};
+        float* os[3] = {o0, o1, o2};
+        GemmDesc gd{};
+        gd.nprob = nprob;
+        for (int j = 0; j < nprob; ++j)
+            gd.p[j] = GemmProblem{as[j], W(attn + "." + pn[first_proj + j] + ".weight"),
+                                  W(attn + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
+        gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
+        return launch_gemm(gd, s);
+    };
+    auto out_proj = [&](const std::string& attn, const float* ao, const float* resid, float* res) -> int {
+        GemmDesc gd{};
+        gd.nprob = 1;
+        gd.p[0] = GemmProblem{ao, W(attn + ".out_proj.weight"), W(attn + ".out_proj.bias"), resid, res};
+        gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
+        return launch_gemm(gd, s);
+    };
+    auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,
+                  long long outer, long long inner_stride, long long tok_stride, int ntok) -> int {
+        GroupNormDesc nd{};
+        nd.x = res; nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
+        nd.gamma = W(lp + "norm." + std::to_string(idx) + ".weight");
+        nd.beta = W(lp + "norm." + std::to_string(idx) + ".bias");
+        nd.n_inst = n_inst; nd.inner = inner; nd.outer_stride = outer; nd.inner_stride = inner_stride;
+        nd.tok_stride = tok_stride; nd.ntok = ntok; nd.C = D; nd.groups = c->cfg.n_groups_module;
+        nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0;
+        return launch_group_norm(nd, s);
+    };
+    const float* xin = buf("conv5");
+    for (int l = 0; l < c->cfg.n_layers; ++l) {
+        const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
+        const std::string ls = "l" + std::to_string(l);
+        auto ab = [&](int a, const char* what) { return buf(abuf(train, l, kAttnShort[a], what)); };
+        auto lse = [&](int a) -> float* { return train ? ab(a, "lse") : nullptr; };
+        float* x_obj = buf(ls + "_obj");
+        float* x_pe = buf(ls + "_xpe");
+        float* x_mot = buf(ls + "_motion");
+        float* x_o2l = buf(ls + "_o2l");
+        // (i) inter-object attention over the N tracks of each (b, t'): module.py:31-35
+        SOLA_TRY(linear3(xin, xin, xin, lp + "obj_attn", 3, M, ab(0, "q"), ab(0, "k"), ab(0, "v"), 0));
+        {
+            AttnDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), D, D, D, D, B * Tp, H, DH, N, N, Tp,
+                        (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale, lse(0)};
+            SOLA_TRY(launch_attention(ad, s));
+        }
+        SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
+        SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
+        // (ii) motion attention over T' per track, PE on q and k only: module.py:38-43
+        SOLA_TRY(linear3(x_pe, x_pe, x_obj, lp + "motion_attn", 3, M, ab(1, "q"), ab(1, "k"), ab(1, "v"), 0));
+        {
+            AttnDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), D, D, D, D, B * N, H, DH, Tp, Tp, 1,
+                        (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale, lse(1)};
+            SOLA_TRY(launch_attention(ad, s));
+        }
+        SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
+        SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp));
+        // (iii) object -> language cross attention: module.py:46-50
+        SOLA_TRY(linear3(x_mot, nullptr, nullptr, lp + "object2lang_attn", 1, M, ab(2, "q"), nullptr, nullptr, 0));
+        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, B * Wn, ab(2, "lk"), ab(2, "lv"), nullptr, 1));
+        {
+            AttnDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
+                        (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale, lse(2)};
+            SOLA_TRY(launch_attention(ad, s));
+        }
+        SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));
+        SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp));
+        xin = x_o2l;
+    }
+
+    // a6: score head (module/module.py:152-160)
+    HeadDesc hd{xin, buf("lbar"), score_map, score_tokens, B, N, Tp, D};
+    SOLA_TRY(launch_score_head(hd, s));
+    c->last = p;
+    c->last_obj = train ? obj : nullptr;
+    return SOLA_OK;
+}

@@ -65,10 +65,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + lr + 32 * i;
         a_ok[i] = m < a.M;
-        if (a.conv) {
+        if (a.conv == 1) {
             const int r = m / a.T_out;
             const int to = m - r * a.T_out;
             a_t0[i] = to * a.stride - a.pad;
+            a_off[i] = (long long)r * a.T_in * a.Cin;
+        } else if (a.conv == 2) {
+            // transposed conv (dX): output row = (r, ti) of the conv INPUT; source rows are conv OUTPUT rows
+            // (r, to) with to * stride - pad + kk == ti.  Here T_out = rows per r of the result (= conv T_in),
+            // T_in = rows per r of the source (= conv T_out), Cin = source row width (= conv Cout).
+            const int r = m / a.T_out;
+            const int ti = m - r * a.T_out;
+            a_t0[i] = ti + a.pad;
             a_off[i] = (long long)r * a.T_in * a.Cin;
         } else {
             a_t0[i] = 0;
@@ -97,10 +105,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
         for (int i = 0; i < RA; ++i) {
             bool ok = a_ok[i] && kok;
             const float* src;
-            if (a.conv) {
+            if (a.conv == 1) {
                 const int ti = a_t0[i] + kk;
                 ok = ok && ti >= 0 && ti < a.T_in;
                 src = pr.A + a_off[i] + (long long)ti * a.Cin + ci;
+            } else if (a.conv == 2) {
+                const int num = a_t0[i] - kk;  // = to * stride
+                const int to = num / a.stride;
+                ok = ok && num >= 0 && to * a.stride == num && to < a.T_in;
+                src = pr.A + a_off[i] + (long long)to * a.Cin + ci;
             } else {
                 src = pr.A + a_off[i] + k;
             }

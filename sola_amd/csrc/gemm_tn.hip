@@ -1,0 +1,297 @@
+// Weight-gradient GEMM and its helpers (backward of F.linear / F.conv1d at tools/attention.py:63-73, module/ws.py:14-22):
+//   gemm_tn_f32_kernel : P[s][n][k] = sum_{m in split s} A[m][n] * B[m][k]   ("TN": both operands reduce over ROWS)
+//                        A = dY [M, N]; B = X [M, K] or the implicit im2col of the channels-last conv input.
+//   sum_slabs_kernel   : C[n][k] = sum_s P[s][n][k]  (fixed order: deterministic, no float atomics)
+//   transpose_kernel   : out[c][r] = in[r][c]  (W -> W^T so that dX = dY * W runs on the NT kernel)
+//   colsum_kernel      : out[seg][c] = sum_{r in segment} in[r][c]  (bias gradients, GroupNorm dgamma/dbeta, dlbar)
+// Exact f32 on v_mfma_f32_32x32x2_f32.  The reduction index m is the slow (row) index of both operands, so tiles are
+// staged [32 m][128 cols] with coalesced float4 row loads and the MFMA fragments are ds_read_b32 across the columns
+// (lanes 0-31 take row m, lanes 32-63 row m+1: consecutive addresses, conflict-free).
+#include "kernels.h"
+
+namespace {
+
+struct TnArgs {
+    const float* A;  // [M, N]
+    const float* B;  // [M, K] or conv source
+    float* P;        // [splits][N][K]
+    float* Pb;       // optional [splits][N]: column sums of A (bias gradient), written by the tk == 0 blocks
+    int M, N, K, lda, ldb;
+    int conv, T_in, T_out, stride, pad, Cin;  // conv gather on B (same convention as the NT kernel's mode 1)
+    int tiles_n, tiles_k, m_per_split;
+};
+
+constexpr int TB = 128;       // output tile (n and k)
+constexpr int TM = 32;        // rows of the reduction per LDS stage
+constexpr int TP = TB + 4;    // LDS pitch (floats), 16-byte aligned rows
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][TM][TP]
+    float* Bs = smem + 2 * TM * TP;   // [2][TM][TP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tn = blockIdx.x / a.tiles_k, tk = blockIdx.x % a.tiles_k;
+    const int n0 = tn * TB, k0 = tk * TB;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+
+    // loads: 32 lanes cover one 128-float row; 8 rows per pass, 4 passes
+    const int lrow = tid >> 5;         // 0..7
+    const int lcol = (tid & 31) << 2;  // 0..124
+    float4 ra[4], rb[4];
+    auto load_stage = [&](int mbase) {
+        int kk = 0, ci = k0 + lcol;
+        if (a.conv) {
+            kk = ci / a.Cin;
+            ci -= kk * a.Cin;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mbase + lrow + 8 * i;
+            const bool mok = m < m_end;
+            ra[i] = (mok && n0 + lcol < a.N) ? *reinterpret_cast<const float4*>(a.A + (long long)m * a.lda + n0 + lcol)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = mok && k0 + lcol < a.K;
+            const float* src;
+            if (a.conv) {
+                const int r = m / a.T_out;
+                const int to = m - r * a.T_out;
+                const int ti = to * a.stride - a.pad + kk;
+                ok = ok && ti >= 0 && ti < a.T_in;
+                src = a.B + ((long long)r * a.T_in + ti) * a.Cin + ci;
+            } else {
+                src = a.B + (long long)m * a.ldb + k0 + lcol;
+            }
+            rb[i] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(buf * TM + lrow + 8 * i) * TP + lcol]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[(buf * TM + lrow + 8 * i) * TP + lcol]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool want_bias = a.Pb != nullptr && tk == 0;
+
+    const int fcol = lane & 31, fm = lane >> 5;
+    const int nstage = (m_end - m_begin + TM - 1) / TM;
+    if (nstage > 0) {
+        load_stage(m_begin);
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
+        }
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) load_stage(m_begin + (st + 1) * TM);
+        const float* Ab = &As[(buf * TM + fm) * TP + wr * 64 + fcol];
+        const float* Bb = &Bs[(buf * TM + fm) * TP + wc * 64 + fcol];
+#pragma unroll
+        for (int mm = 0; mm < TM; mm += 2) {
+            const float a0 = Ab[mm * TP], a1 = Ab[mm * TP + 32];
+            const float b0 = Bb[mm * TP], b1 = Bb[mm * TP + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (st + 1 < nstage) {
+            if (want_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
+            }
+            store_stage(buf ^ 1);
+        }
+        __syncthreads();
+    }
+    if (want_bias) {
+        float* red = smem;  // [8][TB]: reduce the 8 row lanes (the stage buffers are free after the last barrier)
+        *reinterpret_cast<float4*>(&red[lrow * TB + lcol]) = bsum;
+        __syncthreads();
+        if (tid < TB && n0 + tid < a.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v += red[r * TB + tid];
+            a.Pb[(long long)split * a.N + n0 + tid] = v;
+        }
+    }
+    float* P = a.P + (long long)split * a.N * a.K;
+    const int col_l = lane & 31, row_l = (lane >> 5) << 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wc * 64 + j * 32 + col_l;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (n < a.N) P[(long long)n * a.K + k] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ void sum_slabs_kernel(const float* __restrict__ P, float* __restrict__ C, long long n4, int splits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = reinterpret_cast<const float4*>(P)[i];
+    for (int s = 1; s < splits; ++s) {
+        const float4 v = reinterpret_cast<const float4*>(P)[i + (long long)s * n4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(C)[i] = acc;
+}
+
+// out[c * ldo + col_off + r] = in[r * ldi + c], 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                        int cols, int ldi, int ldo, int col_off) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = in[(long long)r * ldi + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) out[(long long)c * ldo + col_off + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// out[(chunk * segments + seg)][c] (+)= scale * sum_{r in chunk of segment} in[(seg * seg_rows + r)][c]
+// block = 64 columns x 4 row lanes; grid.z splits long segments into row chunks (second launch adds the chunks up)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int seg_rows,
+                                                     int cols, int ld, int chunk_rows, float scale, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int seg = blockIdx.y;
+    const int r_begin = blockIdx.z * chunk_rows;
+    const int r_end = min(seg_rows, r_begin + chunk_rows);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r_begin + rl; r < r_end; r += 4) s += in[((long long)seg * seg_rows + r) * ld + c];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * scale;
+        float* o = out + ((long long)blockIdx.z * gridDim.y + seg) * cols + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+}  // namespace
+
+static int tn_splits(int M, int N, int K) {
+    const long long tiles = (long long)((N + TB - 1) / TB) * ((K + TB - 1) / TB);
+    int splits = (int)((768 + tiles - 1) / tiles);
+    const int max_splits = (M + 4 * TM - 1) / (4 * TM);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+size_t gemm_tn_scratch_bytes(int M, int N, int K) {
+    const int splits = tn_splits(M, N, K);
+    return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
+}
+
+int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
+    SOLA_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.N % 4 == 0 && d.K % 4 == 0, "gemm_tn: bad dims M=%d N=%d K=%d", d.M, d.N, d.K);
+    SOLA_ARG(d.lda % 4 == 0 && (d.conv || d.ldb % 4 == 0), "gemm_tn: leading dims must be multiples of 4");
+    if (d.conv) SOLA_ARG(d.Cin % 4 == 0 && d.K % d.Cin == 0, "gemm_tn conv: Cin=%d K=%d", d.Cin, d.K);
+    TnArgs a;
+    a.A = d.A; a.B = d.B; a.P = d.scratch; a.Pb = nullptr; a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb;
+    a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
+    a.tiles_n = (d.N + TB - 1) / TB;
+    a.tiles_k = (d.K + TB - 1) / TB;
+    const size_t need = gemm_tn_scratch_bytes(d.M, d.N, d.K);
+    if (d.scratch_bytes < need) {
+        sola_set_error("gemm_tn: scratch %zu < %zu", d.scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    const int splits = tn_splits(d.M, d.N, d.K);
+    if (d.bias_grad) a.Pb = d.scratch + (size_t)splits * d.N * d.K;
+    int mps = (d.M + splits - 1) / splits;
+    mps = (mps + TM - 1) / TM * TM;
+    a.m_per_split = mps;
+    constexpr size_t lds = (size_t)4 * TM * TP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        SolaProfScope prof(SOLA_PROF_GEMM_TN, s, 2.0 * d.M * d.N * (double)d.K, 4.0 * ((double)d.M * (d.N + d.K) + (double)splits * d.N * d.K));
+        hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(a.tiles_n * a.tiles_k, splits), dim3(256), lds, s, a);
+        SOLA_LAUNCH_CHECK();
+    }
+    {
+        const long long n4 = (long long)d.N * d.K / 4;
+        SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (splits + 1.0) * d.N * d.K);
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d.scratch, d.C, n4, splits);
+        SOLA_LAUNCH_CHECK();
+        if (d.bias_grad) {
+            const long long b4 = d.N / 4;
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, s, a.Pb, d.bias_grad, b4, splits);
+            SOLA_LAUNCH_CHECK();
+        }
+    }
+    return SOLA_OK;
+}
+
+int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off, hipStream_t s) {
+    SOLA_ARG(rows > 0 && cols > 0, "transpose: bad dims");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * cols);
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, out, rows, cols, ldi, ldo, col_off);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+size_t colsum_scratch_bytes(int segments, int seg_rows, int cols) {
+    if (seg_rows <= 256) return 0;
+    const int chunks = min(64, (seg_rows + 127) / 128);
+    return (size_t)chunks * segments * cols * sizeof(float);
+}
+
+int launch_colsum(const float* in, float* out, int segments, int seg_rows, int cols, int ld, float scale, int accumulate,
+                  float* scratch, size_t scratch_bytes, hipStream_t s) {
+    SOLA_ARG(segments > 0 && seg_rows > 0 && cols > 0 && segments <= 65535, "colsum: bad dims");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * segments * (double)seg_rows * cols);
+    const size_t need = colsum_scratch_bytes(segments, seg_rows, cols);
+    if (need == 0 || scratch == nullptr || scratch_bytes < need) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, segments, 1), dim3(256), 0, s, in, out, seg_rows, cols, ld,
+                           seg_rows, scale, accumulate);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
+    const int chunks = (int)(need / ((size_t)segments * cols * sizeof(float)));
+    const int chunk_rows = (seg_rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, segments, chunks), dim3(256), 0, s, in, scratch, seg_rows, cols,
+                       ld, chunk_rows, 1.0f, 0);
+    SOLA_LAUNCH_CHECK();
+    const int wide = segments * cols;  // second pass: [chunks][segments*cols] -> [segments*cols]
+    hipLaunchKernelGGL(colsum_kernel, dim3((wide + 63) / 64, 1, 1), dim3(256), 0, s, scratch, out, chunks, wide, wide, chunks,
+                       scale, accumulate);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}

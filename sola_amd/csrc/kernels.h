@@ -21,6 +21,24 @@ struct GemmDesc {
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 
+// ---- weight-gradient GEMM + helpers (gemm_tn.hip) ----------------------------------------------------------------
+struct GemmTnDesc {
+    const float* A;   // dY [M, N]
+    const float* B;   // X [M, K] (or conv source when conv = 1)
+    float* C;         // [N, K]
+    float* bias_grad; // optional [N] = column sums of A
+    int M, N, K, lda, ldb;
+    int conv, T_in, T_out, stride, pad, Cin;
+    float* scratch;
+    size_t scratch_bytes;
+};
+size_t gemm_tn_scratch_bytes(int M, int N, int K);
+int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s);
+int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off, hipStream_t s);
+size_t colsum_scratch_bytes(int segments, int seg_rows, int cols);
+int launch_colsum(const float* in, float* out, int segments, int seg_rows, int cols, int ld, float scale, int accumulate,
+                  float* scratch, size_t scratch_bytes, hipStream_t s);
+
 // ---- attention core (attn.hip) ---------------------------------------------------------------------------------
 struct AttnDesc {
     const float *q, *k, *v;
@@ -30,8 +48,67 @@ struct AttnDesc {
     long long q_outer, q_inner, q_rs;
     long long k_outer, k_inner, k_rs;
     float scale;
+    float* lse;  // optional [q rows][H]
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
+
+struct AttnBwdDesc {
+    const float *q, *k, *v, *o, *dout, *lse;
+    float *dq, *dk, *dv, *dvec;
+    int ldq, ldk, ldv, ldo;
+    int ld_dq, ld_dk, ld_dv;
+    int G, H, DH, Sq, Sk, inner;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+};
+int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);
+
+// ---- backward of the elementwise / reduction stages (bwd.hip) -------------------------------------------------
+struct GroupNormBwdDesc {
+    const float* x;    // pre-norm input (saved)
+    const float* dy;   // gradient wrt y
+    const float* dy2;  // optional second gradient stream (the x+pe side output), added to dy
+    const float *gamma, *beta;
+    float* dx;
+    float* dgamma_part;  // [n_inst][C] per-instance partial sums
+    float* dbeta_part;   // [n_inst][C]
+    int n_inst, inner;
+    long long outer_stride, inner_stride, tok_stride;
+    int ntok, C, groups;
+    float eps, slope;
+    int leaky;
+};
+int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
+struct WsBwdLayer {
+    const float* w;      // [cout, cin, k] original weights
+    const float* dwstd;  // [cout, k*cin] gradient wrt the standardised weights (GEMM layout)
+    float* dw;           // [cout, cin, k]
+    int cout, cin, k;
+};
+int launch_ws_backward(const WsBwdLayer* layers, int n_layers, hipStream_t s);
+struct HeadBwdDesc {
+    const float *x, *lbar, *d_score, *d_tok;
+    float* dx;          // [B, N, Tp, D]
+    float* dlbar_part;  // [B*N, D]
+    int B, N, Tp, D;
+};
+int launch_score_head_bwd(const HeadBwdDesc& d, hipStream_t s);
+struct LossBwdDesc {
+    const float *score_map, *score_tokens, *labels, *pos, *neg;
+    long long neg_batch_stride;
+    int B, N, D, n_neg;
+    float pos_w, temp_scale, align_w;
+    const float* g3;  // upstream gradients of {total, bce, alignment} (device, 3 floats)
+    float* d_score;   // [B*N]
+    float* d_tok;     // [B*N, D]
+    float* coef;      // [B*N, n_neg] scratch
+    float* d_neg;     // [B, n_neg, D]
+};
+int launch_loss_bwd(const LossBwdDesc& d, hipStream_t s);
+// d_negw[m] = sum_b (d_lang[b, L+m] + dlbar[b] / W) (+ d_neg_align[b, m]); also used to fold dlbar into d_lang rows
+int launch_neg_token_grad(const float* d_lang, const float* dlbar, const float* d_neg_align, float* d_negw, int B, int L,
+                          int n_neg, int D, hipStream_t s);
 
 // ---- normalisation / elementwise (norm.hip) --------------------------------------------------------------------
 struct WsLayer {

@@ -7,16 +7,9 @@ import torch.nn as nn
 from ._lib import SolaError, check, current_stream, lib, ptr, require_cuda
 
 
-def track_selection_losses(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight=1.5,
-                           temperature=0.07, alignment_weight=0.3, return_argmax=False):
-    """One fused evaluation of train.py:98-113: weighted BCE on the logits, AlignmentLoss, and their sum.
-
-    score_map [B,N], score_tokens [B,N,D], labels [B,N], pos_tokens [B,1,D]; neg_tokens [B,n_neg,D] or a
-    shared [n_neg,D] table (what train.py:92 builds by repeating ``negative_token.weight``).
-    Returns a float32 tensor ``[total, bce, alignment]`` on the device (no host sync)."""
+def _loss_forward(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight, temperature, alignment_weight,
+                  return_argmax):
     require_cuda(score_map, score_tokens, labels, pos_tokens, neg_tokens)
-    if torch.is_grad_enabled() and (score_map.requires_grad or score_tokens.requires_grad or neg_tokens.requires_grad):
-        raise SolaError("sola_amd: differentiable losses are not built yet; use torch.no_grad(). No PyTorch fallback.")
     B, N = score_map.shape
     D = score_tokens.shape[-1]
     f = lambda t: t.detach().to(torch.float32).contiguous()
@@ -36,12 +29,32 @@ def track_selection_losses(score_map, score_tokens, labels, pos_tokens, neg_toke
     check(lib().sola_loss(ptr(sm), ptr(st), ptr(lb), ptr(ps), ptr(ng), stride, B, N, D, n_neg, float(positive_weight),
                           float(temperature), float(alignment_weight), ptr(loss3), ptr(argmax), ptr(scratch),
                           scratch.numel() * 4, current_stream(dev)), "sola_loss")
+    return loss3, argmax
+
+
+def track_selection_losses(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight=1.5,
+                           temperature=0.07, alignment_weight=0.3, return_argmax=False):
+    """One fused evaluation of train.py:98-113: weighted BCE on the logits, AlignmentLoss, and their sum.
+
+    score_map [B,N], score_tokens [B,N,D], labels [B,N], pos_tokens [B,1,D]; neg_tokens [B,n_neg,D] or a
+    shared [n_neg,D] table (what train.py:92 builds by repeating ``negative_token.weight``).
+    Returns a float32 tensor ``[total, bce, alignment]`` on the device (no host sync); differentiable with respect to
+    score_map, score_tokens and neg_tokens (HIP backward, sola_loss_backward)."""
+    needs_grad = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (score_map, score_tokens, neg_tokens))
+    if needs_grad and not return_argmax:
+        from .autograd import _Losses
+
+        return _Losses.apply(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight, temperature,
+                             alignment_weight)
+    loss3, argmax = _loss_forward(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight, temperature,
+                                  alignment_weight, return_argmax)
     return (loss3, argmax) if return_argmax else loss3
 
 
 class AlignmentLoss(nn.Module):
     """tools/loss.py:4-58.  ``temperature`` stays a Parameter for interface parity; the reference never
-    optimises it (train.py:44-49), so its value is read on the host at call time."""
+    optimises it (train.py:44-49), so its value is read on the host at call time and it receives no gradient."""
 
     def __init__(self, positive_weight: float = 1.0, temperature: float = 0.07) -> None:
         super().__init__()
@@ -55,3 +68,14 @@ class AlignmentLoss(nn.Module):
                                        positive_weight=self.positive_weight, temperature=float(self.temperature.detach()),
                                        alignment_weight=0.0)
         return loss3[2]
+
+
+def weighted_bce_with_logits(score_logits, labels, positive_weight=1.5):
+    """train.py:98-104: F.binary_cross_entropy_with_logits(input, target, weight=where(labels>0, pw, 1)), mean."""
+    B, N = score_logits.shape
+    dev = score_logits.device
+    D = 4
+    z = torch.zeros((B, N, D), device=dev, dtype=torch.float32)
+    loss3 = track_selection_losses(score_logits, z, labels, torch.zeros((B, 1, D), device=dev), torch.zeros((1, D), device=dev),
+                                   positive_weight=positive_weight, temperature=0.0, alignment_weight=0.0)
+    return loss3[1]

@@ -84,6 +84,12 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._workspace = None
         self._last_shape = None
         self.ws_policy = "auto"
+        self.attention_dropout_p = 0.1  # tools/attention.py:12 (hard-coded in the reference)
+        self._train_ws = None
+        self._bwd_ws = None
+        self._train_inputs = None
+        self._train_shape = None
+        self._train_generation = 0
 
     # ------------------------------------------------------------------------------------------ library binding
     def _config_struct(self):
@@ -167,6 +173,48 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
                                  ptr(ws), ws.numel(), current_stream(dev)), "sola_forward")
         self._last_shape = (B, N, T, L)
         return score_map, score_tokens
+
+    # ------------------------------------------------------------------------------------------ training path
+    def _forward_train_impl(self, object_tokens, lang_tokens):
+        """sola_forward_train: same numerics as the inference forward, activations kept for sola_backward."""
+        B, N, T, d = object_tokens.shape
+        _, L, D = lang_tokens.shape
+        dev = object_tokens.device
+        obj = object_tokens.detach().to(torch.float32).contiguous()
+        lang = lang_tokens.detach().to(torch.float32).contiguous()
+        self._ensure_ctx(dev)
+        self._bind_weights()
+        nbytes = lib().sola_train_workspace_bytes(self._ctx, B, N, T, L)
+        if self._train_ws is None or self._train_ws.numel() < nbytes or self._train_ws.device != dev:
+            self._train_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        score_map = torch.empty((B, N), device=dev, dtype=torch.float32)
+        score_tokens = torch.empty((B, N, D), device=dev, dtype=torch.float32)
+        check(lib().sola_forward_train(self._ctx, ptr(obj), ptr(lang), B, N, T, L, ptr(score_map), ptr(score_tokens),
+                                       ptr(self._train_ws), self._train_ws.numel(), current_stream(dev)), "sola_forward_train")
+        self._train_inputs = (obj, lang)  # the conv0 weight gradient re-reads the tokens
+        self._train_shape = (B, N, T, L)
+        self._train_generation += 1
+        self._workspace = self._train_ws  # workspace_tap reads the arena of the last forward
+        return score_map, score_tokens
+
+    def _backward_impl(self, d_score_map, d_score_tokens):
+        B, N, T, L = self._train_shape
+        dev = self._train_ws.device
+        D = self.lang_token_dim
+        d_sm = torch.zeros((B, N), device=dev) if d_score_map is None else d_score_map.to(torch.float32).contiguous()
+        d_st = torch.zeros((B, N, D), device=dev) if d_score_tokens is None else d_score_tokens.to(torch.float32).contiguous()
+        grads = []
+        named = dict(self.named_parameters())
+        for key, p in named.items():
+            g = torch.empty_like(p, memory_format=torch.contiguous_format)
+            check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
+            grads.append(g)
+        nbytes = lib().sola_backward_workspace_bytes(self._ctx, B, N, T, L)
+        if self._bwd_ws is None or self._bwd_ws.numel() < nbytes or self._bwd_ws.device != dev:
+            self._bwd_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        check(lib().sola_backward(self._ctx, ptr(d_sm), ptr(d_st), ptr(self._train_ws), ptr(self._bwd_ws),
+                                  self._bwd_ws.numel(), current_stream(dev)), "sola_backward")
+        return grads
 
     def workspace_tap(self, name):
         """Copy of a named intermediate of the last forward (see sola_workspace_tap); for parity tests."""

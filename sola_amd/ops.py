@@ -72,7 +72,7 @@ def group_norm(x, gamma, beta, groups, n_inst, inner, outer_stride, inner_stride
     return y if pe is None else (y, y2)
 
 
-def attention(q, k, v, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None):
+def attention(q, k, v, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None, return_lse=False):
     """softmax(q k^T * scale) v over G groups x H heads; q,k,v are [rows, H*dh] matrices and
     ``q_addr``/``k_addr`` = (outer, inner_stride, row_stride) in rows (tools/attention.py:66-72)."""
     require_cuda(q, k, v)
@@ -81,10 +81,88 @@ def attention(q, k, v, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None):
     dh = D // H
     o = torch.zeros_like(q)
     scale = 1.0 / math.sqrt(dh) if scale is None else scale
+    lse = torch.zeros((q.shape[0], H), device=q.device, dtype=torch.float32) if return_lse else None
     check(lib().sola_attention(ptr(q), q.shape[-1], ptr(k), k.shape[-1], ptr(v), v.shape[-1], ptr(o), D, G, H, dh, Sq, Sk,
-                               inner, q_addr[0], q_addr[1], q_addr[2], k_addr[0], k_addr[1], k_addr[2], scale,
+                               inner, q_addr[0], q_addr[1], q_addr[2], k_addr[0], k_addr[1], k_addr[2], scale, ptr(lse),
                                current_stream(q.device)), "sola_attention")
-    return o
+    return (o, lse) if return_lse else o
+
+
+def attention_backward(q, k, v, o, dout, lse, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None):
+    """Backward of ``attention``: returns (dq, dk, dv) with the layouts of q, k, v."""
+    require_cuda(q, k, v, o, dout, lse)
+    q, k, v, o, dout, lse = (_f32c(t) for t in (q, k, v, o, dout, lse))
+    D = q.shape[-1]
+    dh = D // H
+    scale = 1.0 / math.sqrt(dh) if scale is None else scale
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    dvec = torch.zeros((q.shape[0], H), device=q.device, dtype=torch.float32)
+    check(lib().sola_attention_backward(ptr(q), q.shape[-1], ptr(k), k.shape[-1], ptr(v), v.shape[-1], ptr(o), ptr(dout), D,
+                                        ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(dvec), G, H, dh, Sq, Sk, inner,
+                                        q_addr[0], q_addr[1], q_addr[2], k_addr[0], k_addr[1], k_addr[2], scale,
+                                        current_stream(q.device)), "sola_attention_backward")
+    return dq, dk, dv
+
+
+def gemm_tn(a, b, want_bias_grad=False):
+    """a [M,N]^T @ b [M,K] -> [N,K] (weight gradient); optionally also the column sums of a (bias gradient)."""
+    require_cuda(a, b)
+    a, b = _f32c(a), _f32c(b)
+    M, N = a.shape
+    K = b.shape[1]
+    out = torch.empty((N, K), device=a.device, dtype=torch.float32)
+    bias = torch.empty((N,), device=a.device, dtype=torch.float32) if want_bias_grad else None
+    nb = lib().sola_gemm_tn_scratch_bytes(M, N, K)
+    scratch = torch.empty(nb, device=a.device, dtype=torch.uint8)
+    check(lib().sola_gemm_tn(ptr(a), N, ptr(b), K, ptr(out), ptr(bias), M, N, K, ptr(scratch), nb, current_stream(a.device)),
+          "sola_gemm_tn")
+    return (out, bias) if want_bias_grad else out
+
+
+def ws_backward(weight, dwstd):
+    """Backward of ``ws_standardize``: weight [cout,cin,k], dwstd [cout,k*cin] -> dweight [cout,cin,k]."""
+    require_cuda(weight, dwstd)
+    w, g = _f32c(weight), _f32c(dwstd)
+    cout, cin, k = w.shape
+    dw = torch.empty_like(w)
+    check(lib().sola_ws_backward(ptr(w), ptr(g), cout, cin, k, ptr(dw), current_stream(w.device)), "sola_ws_backward")
+    return dw
+
+
+def conv1d_cl_backward(x, w_std, dy, k, stride, pad, need_dx=True):
+    """Backward of ``conv1d_cl``: returns (dx or None, dw_std [cout,k*cin], dbias [cout])."""
+    require_cuda(x, w_std, dy)
+    x, w_std, dy = _f32c(x), _f32c(w_std), _f32c(dy)
+    R, T, cin = x.shape
+    cout = w_std.shape[0]
+    t_out = (T + 2 * pad - k) // stride + 1
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w_std)
+    db = torch.empty((cout,), device=x.device, dtype=torch.float32)
+    nb = max(lib().sola_gemm_tn_scratch_bytes(R * t_out, cout, k * cin), 4 * cout * k * cin)
+    scratch = torch.empty(nb, device=x.device, dtype=torch.uint8)
+    check(lib().sola_conv1d_cl_backward(ptr(x), ptr(w_std), ptr(dy), ptr(dx), ptr(dw), ptr(db), R, T, cin, cout, k, stride,
+                                        pad, ptr(scratch), nb, current_stream(x.device)), "sola_conv1d_cl_backward")
+    return dx, dw, db
+
+
+def group_norm_backward(x, dy, gamma, beta, groups, n_inst, inner, outer_stride, inner_stride, tok_stride, ntok, eps=1e-5,
+                        leaky_slope=None, dy2=None):
+    """Backward of ``group_norm``: returns (dx, dgamma, dbeta); ``dy2`` is the gradient of the y+pe side output."""
+    require_cuda(x, dy, gamma, beta, dy2)
+    x, dy = _f32c(x), _f32c(dy)
+    C_ = x.shape[-1]
+    dx = torch.empty_like(x)
+    dg = torch.empty((C_,), device=x.device, dtype=torch.float32)
+    db = torch.empty((C_,), device=x.device, dtype=torch.float32)
+    nb = 2 * n_inst * C_ * 4
+    scratch = torch.empty(nb, device=x.device, dtype=torch.uint8)
+    check(lib().sola_group_norm_backward(ptr(x), ptr(dy), ptr(None if dy2 is None else _f32c(dy2)), ptr(_f32c(gamma)),
+                                         ptr(_f32c(beta)), ptr(dx), ptr(dg), ptr(db), n_inst, inner, outer_stride,
+                                         inner_stride, tok_stride, ntok, C_, groups, eps,
+                                         0.0 if leaky_slope is None else leaky_slope, 0 if leaky_slope is None else 1,
+                                         ptr(scratch), nb, current_stream(x.device)), "sola_group_norm_backward")
+    return dx, dg, db
 
 
 def pos_encoding(gauss, t_len, max_temporal_length):

@@ -1,0 +1,302 @@
+"""Backward parity on the MI355X.  Per-kernel: each HIP backward against torch autograd of the float64 oracle on the
+same seeded inputs.  Whole path: every parameter gradient of loss.backward() against the gradients the REAL reference
+produced (tests/golden, full tensors for two small cases, per-parameter norms elsewhere) and against autograd through
+the oracle evaluated here."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import case_dict  # noqa: E402
+from oracle import sola_oracle  # noqa: E402
+from sola_amd import ops, synth  # noqa: E402
+from sola_amd.loss import track_selection_losses  # noqa: E402
+from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
+
+POS_W, TEMP, ALIGN_W = 1.5, 0.07, 0.3
+
+
+def cuda(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(size=shape) * scale).astype(np.float32)
+
+
+def t64(x, grad=False):
+    return torch.tensor(np.asarray(x), dtype=torch.float64, requires_grad=grad)
+
+
+def assert_close(got, ref, rel=3e-5, name=""):
+    got = got.detach().cpu().double().numpy()
+    ref = np.asarray(ref.detach().numpy() if isinstance(ref, torch.Tensor) else ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    tol = rel * max(1e-6, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (ref max {np.abs(ref).max():.3e})"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 70 * 4, 36), (16384, 1024, 1024), (48, 64, 128), (5, 4, 8)])
+def test_gemm_tn(M, N, K):
+    rng = np.random.default_rng(M + N)
+    a, b = rnd(rng, M, N), rnd(rng, M, K)
+    out, bias = ops.gemm_tn(cuda(a), cuda(b), want_bias_grad=True)
+    assert_close(out, a.astype(np.float64).T @ b.astype(np.float64), name="gemm_tn")
+    assert_close(bias, a.astype(np.float64).sum(axis=0), name="bias grad")
+
+
+@pytest.mark.parametrize("cout,cin,k", [(64, 32, 3), (512, 256, 3), (1024, 1024, 1), (8, 4, 3)])
+def test_ws_backward(cout, cin, k):
+    rng = np.random.default_rng(cout)
+    w = rnd(rng, cout, cin, k, scale=0.05) + 0.01
+    g = rnd(rng, cout, cin, k)
+    wt = t64(w, True)
+    sola_oracle.standardize_weight(wt).backward(t64(g))
+    g_k = np.ascontiguousarray(np.transpose(g, (0, 2, 1)).reshape(cout, k * cin))  # GEMM layout [cout][k][cin]
+    got = ops.ws_backward(cuda(w), cuda(g_k))
+    assert_close(got, wt.grad, name="ws backward")
+
+
+@pytest.mark.parametrize("R,T,cin,cout,k,s,p", [(5, 33, 32, 64, 3, 2, 1), (3, 8, 64, 64, 3, 1, 1), (4, 1, 32, 64, 3, 2, 1),
+                                                (64, 32, 256, 512, 3, 2, 1), (7, 5, 128, 128, 1, 1, 0), (2, 200, 32, 64, 3, 2, 1)])
+def test_conv1d_backward(R, T, cin, cout, k, s, p):
+    rng = np.random.default_rng(R * T + cin)
+    x, w, b = rnd(rng, R, T, cin), rnd(rng, cout, cin, k, scale=0.1), rnd(rng, cout)
+    xt, wt, bt = t64(x, True), t64(w, True), t64(b, True)
+    y = sola_oracle.conv1d_cl(xt, wt, bt, s, p)
+    dy = rnd(rng, *y.shape)
+    y.backward(t64(dy))
+    wk = np.ascontiguousarray(np.transpose(w, (0, 2, 1)).reshape(cout, k * cin))
+    dx, dw, db = ops.conv1d_cl_backward(cuda(x), cuda(wk), cuda(dy), k, s, p)
+    assert_close(dx, xt.grad, name="conv dx")
+    assert_close(dw.reshape(cout, k, cin).permute(0, 2, 1), wt.grad, name="conv dw")
+    assert_close(db, bt.grad, name="conv db")
+
+
+@pytest.mark.parametrize("B,N,Tp,C", [(2, 5, 3, 128), (1, 64, 4, 1024), (2, 3, 1, 64), (1, 7, 25, 512)])
+def test_group_norm_backward(B, N, Tp, C):
+    rng = np.random.default_rng(C + N)
+    x = rnd(rng, B, N, Tp, C) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(rng, C), 0.1 * rnd(rng, C)
+    dy, dy2 = rnd(rng, B, N, Tp, C), rnd(rng, B, N, Tp, C)
+    xc, dyc, dy2c = (cuda(t).reshape(B * N * Tp, C) for t in (x, dy, dy2))
+
+    def ref(view, unview, leaky, extra):
+        xt, gt, bt = t64(x, True), t64(gamma, True), t64(beta, True)
+        y = sola_oracle.group_norm_tokens(view(xt), gt, bt, 8)
+        if leaky:
+            y = sola_oracle.leaky_relu(y)
+        g = view(t64(dy)) + (view(t64(dy2)) if extra else 0)
+        y.backward(g)
+        return xt.grad, gt.grad, bt.grad
+
+    # per track (encoder with LeakyReLU, and motion norm)
+    for leaky in (True, False):
+        rx, rg, rb = ref(lambda t: t.reshape(B * N, Tp, C), None, leaky, False)
+        dx, dg, db = ops.group_norm_backward(xc, dyc, cuda(gamma), cuda(beta), 8, B * N, 1, Tp, 0, 1, Tp,
+                                             leaky_slope=0.01 if leaky else None)
+        assert_close(dx.reshape(B, N, Tp, C), rx, name=f"gn dx leaky={leaky}")
+        assert_close(dg, rg, name="gn dgamma")
+        assert_close(db, rb, name="gn dbeta")
+    # per (b, t') with the second gradient stream of the x+pe output
+    rx, rg, rb = ref(lambda t: t.permute(0, 2, 1, 3).reshape(B * Tp, N, C), None, False, True)
+    dx, dg, db = ops.group_norm_backward(xc, dyc, cuda(gamma), cuda(beta), 8, B * Tp, Tp, N * Tp, 1, Tp, N, dy2=dy2c)
+    assert_close(dx.reshape(B, N, Tp, C), rx, name="gn0 dx")
+    assert_close(dg, rg, name="gn0 dgamma")
+    assert_close(db, rb, name="gn0 dbeta")
+    # per sample
+    rx, rg, rb = ref(lambda t: t.reshape(B, N * Tp, C), None, False, False)
+    dx, dg, db = ops.group_norm_backward(xc, dyc, cuda(gamma), cuda(beta), 8, B, 1, N * Tp, 0, 1, N * Tp)
+    assert_close(dx.reshape(B, N, Tp, C), rx, name="gn2 dx")
+    assert_close(dg, rg, name="gn2 dgamma")
+
+
+def _attn_t(q, k, v, H):
+    G, Sq, D = q.shape
+    dh = D // H
+    qh = q.reshape(G, Sq, H, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(G, -1, H, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(G, -1, H, dh).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(G, Sq, D)
+
+
+@pytest.mark.parametrize("B,N,Tp,D", [(2, 5, 3, 128), (1, 64, 4, 1024), (1, 7, 16, 128), (1, 20, 25, 128), (2, 16, 4, 256), (1, 130, 2, 128)])
+def test_attention_backward_three_layouts(B, N, Tp, D):
+    H = 8
+    rng = np.random.default_rng(N * Tp + D)
+    q, k, v, do = (rnd(rng, B, N, Tp, D) for _ in range(4))
+    qc, kc, vc, doc = (cuda(t).reshape(B * N * Tp, D) for t in (q, k, v, do))
+
+    def run_ref(view):
+        qt, kt, vt = t64(q, True), t64(k, True), t64(v, True)
+        _attn_t(view(qt), view(kt), view(vt), H).backward(view(t64(do)))
+        return qt.grad, kt.grad, vt.grad
+
+    # inter-object
+    view = lambda t: t.permute(0, 2, 1, 3).reshape(B * Tp, N, D)
+    o, lse = ops.attention(qc, kc, vc, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp), return_lse=True)
+    got = ops.attention_backward(qc, kc, vc, o, doc, lse, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp))
+    for g, r, nm in zip(got, run_ref(view), "qkv"):
+        assert_close(g.reshape(B, N, Tp, D), r, name=f"obj d{nm}")
+    # motion
+    view = lambda t: t.reshape(B * N, Tp, D)
+    o, lse = ops.attention(qc, kc, vc, B * N, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1), return_lse=True)
+    got = ops.attention_backward(qc, kc, vc, o, doc, lse, B * N, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1))
+    for g, r, nm in zip(got, run_ref(view), "qkv"):
+        assert_close(g.reshape(B, N, Tp, D), r, name=f"motion d{nm}")
+    # object -> language
+    Wn = 37
+    lk, lv = rnd(rng, B, Wn, D), rnd(rng, B, Wn, D)
+    qt, kt, vt = t64(q, True), t64(lk, True), t64(lv, True)
+    _attn_t(qt.reshape(B, N * Tp, D), kt, vt, H).backward(t64(do).reshape(B, N * Tp, D))
+    lkc, lvc = cuda(lk).reshape(B * Wn, D), cuda(lv).reshape(B * Wn, D)
+    o, lse = ops.attention(qc, lkc, lvc, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1), return_lse=True)
+    dq, dk, dv = ops.attention_backward(qc, lkc, lvc, o, doc, lse, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1))
+    assert_close(dq.reshape(B, N, Tp, D), qt.grad, name="o2l dq")
+    assert_close(dk.reshape(B, Wn, D), kt.grad, name="o2l dk")
+    assert_close(dv.reshape(B, Wn, D), vt.grad, name="o2l dv")
+
+
+def test_loss_backward_vs_oracle_autograd():
+    rng = np.random.default_rng(4)
+    B, N, D, n_neg = 2, 9, 128, 4
+    sm, st = rnd(rng, B, N) * 3, rnd(rng, B, N, D)
+    labels = (rng.uniform(size=(B, N)) < 0.3).astype(np.float32)
+    pos, neg = rnd(rng, B, 1, D), rnd(rng, n_neg, D)
+    for shared in (True, False):
+        negv = neg if shared else np.ascontiguousarray(np.broadcast_to(neg[None], (B, n_neg, D))) + 0.01 * rnd(rng, B, n_neg, D)
+        smt, stt, ngt = t64(sm, True), t64(st, True), t64(negv, True)
+        ng_b = ngt.unsqueeze(0).expand(B, -1, -1) if shared else ngt
+        ls = sola_oracle.losses(smt, stt, labels, pos, ng_b, POS_W, TEMP, ALIGN_W, dtype=torch.float64)
+        (ls["total"] + 0.5 * ls["bce"] - 0.25 * ls["align"]).backward()
+        a, b, c = cuda(sm).requires_grad_(), cuda(st).requires_grad_(), cuda(negv).requires_grad_()
+        loss3 = track_selection_losses(a, b, cuda(labels), cuda(pos), c, POS_W, TEMP, ALIGN_W)
+        (loss3[0] + 0.5 * loss3[1] - 0.25 * loss3[2]).backward()
+        assert_close(a.grad, smt.grad, name="d score_map")
+        assert_close(b.grad, stt.grad, name="d score_tokens")
+        assert_close(c.grad, ngt.grad, name=f"d neg shared={shared}")
+
+
+# ------------------------------------------------------------------------------------------------ whole path
+def build(cfg, seed=42):
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    sd = synth.make_state_dict(cfg, seed)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval(), sd  # eval(): dropout off, as in the golden run; gradients still flow
+
+
+def train_step_grads(m, cfg, B, N, T, L, seed):
+    inp = synth.make_inputs(cfg, B, N, T, L, seed)
+    c = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    m.zero_grad(set_to_none=True)
+    sm, st = m(c["object_tokens"], c["lang_tokens"])
+    # train.py:92: neg_tokens is a (cloned, repeated) view of the parameter, so it also receives gradient
+    neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+    loss3 = track_selection_losses(sm, st, c["labels"], c["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
+    loss3[0].backward()
+    torch.cuda.synchronize()
+    return inp, loss3, {k: p.grad for k, p in m.named_parameters()}
+
+
+@pytest.fixture(scope="module")
+def small_model():
+    return build(synth.SMALL_MODEL_CFG)
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    return build(synth.DEFAULT_MODEL_CFG)
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_small_gradients_vs_reference(small_golden, small_model, ci):
+    m, _ = small_model
+    cfg = synth.SMALL_MODEL_CFG
+    B, N, T, L = [int(v) for v in small_golden["cases"][ci]]
+    g = case_dict(small_golden, ci)
+    _, loss3, grads = train_step_grads(m, cfg, B, N, T, L, 100 + ci)
+    np.testing.assert_allclose(loss3.detach().cpu().numpy().astype(np.float64), g["loss"], rtol=2e-4, atol=2e-4)
+    # Some gradients are mathematically zero (a key-projection bias shifts every score of a query equally; a single
+    # key when T'=1): both sides then hold fp32 noise, so the tolerance has a floor tied to the overall gradient scale.
+    total = float(dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))["total_grad_norm"])
+    bad = {}
+    for k, gr in grads.items():
+        assert gr is not None, k
+        if "grad." + k in g:  # full reference gradient
+            ref = g["grad." + k]
+            err = float(np.abs(gr.cpu().numpy() - ref).max())
+            tol = 2e-3 * float(np.abs(ref).max()) + 1e-6 * total
+            if err > tol:
+                bad[k] = (err, float(np.abs(ref).max()))
+        else:
+            ref = float(g["gradnorm." + k])
+            got = float(gr.double().norm())
+            if abs(got - ref) > 2e-3 * ref + 1e-5 * total:
+                bad[k] = (got, ref)
+    assert not bad, f"gradient mismatch: {bad}"
+    gnd = m.get_grad_norm_dict()
+    ref = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))
+    for k in ref:
+        assert gnd[k] == pytest.approx(ref[k], rel=2e-3), k
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_full_gradient_norms_vs_reference(full_golden, full_model, ci):
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
+    g = case_dict(full_golden, ci)
+    _, loss3, grads = train_step_grads(m, cfg, B, N, T, L, 200 + ci)
+    np.testing.assert_allclose(loss3.detach().cpu().numpy().astype(np.float64), g["loss"], rtol=2e-4, atol=2e-4)
+    total = float(dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))["total_grad_norm"])
+    bad = {}
+    for k, gr in grads.items():
+        ref = float(g["gradnorm." + k])
+        got = float(gr.double().norm())
+        if abs(got - ref) > 3e-3 * ref + 1e-5 * total:  # floor: exactly-zero gradients (key biases) are fp32 noise
+            bad[k] = (got, ref)
+    assert not bad, f"gradient-norm mismatch: {bad}"
+    gnd = m.get_grad_norm_dict()
+    ref = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))
+    for k in ref:
+        assert gnd[k] == pytest.approx(ref[k], rel=3e-3), k
+
+
+def test_small_gradients_vs_oracle_autograd(small_model):
+    """Every parameter gradient against float64 autograd through the oracle on a case with no fixture."""
+    m, sd = small_model
+    cfg = synth.SMALL_MODEL_CFG
+    B, N, T, L = 2, 6, 24, 7
+    inp, loss3, grads = train_step_grads(m, cfg, B, N, T, L, 4242)
+    tsd = {k: t64(v, True) for k, v in sd.items()}
+    sm, st = _oracle_forward_grad(tsd, cfg, inp)
+    neg = tsd["negative_token.weight"].unsqueeze(0).expand(B, -1, -1)
+    ls = sola_oracle.losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W, dtype=torch.float64)
+    ls["total"].backward()
+    assert abs(float(loss3[0].detach()) - float(ls["total"].detach())) < 2e-4
+    gmax = max(float(t.grad.abs().max()) for t in tsd.values() if t.grad is not None)
+    for k, gr in grads.items():
+        ref = tsd[k].grad.numpy()
+        err = float(np.abs(gr.cpu().double().numpy() - ref).max())
+        assert err <= 1e-3 * float(np.abs(ref).max()) + 1e-6 * gmax, (k, err, float(np.abs(ref).max()))
+
+
+def _oracle_forward_grad(tsd, cfg, inp):
+    """sola_oracle.forward without the detach of to_torch_state, so autograd reaches the weights."""
+    obj = t64(inp["object_tokens"])
+    lang = t64(inp["lang_tokens"])
+    B = obj.shape[0]
+    x = sola_oracle.encoder(tsd, cfg, obj)
+    pe = sola_oracle.positional_encoding(tsd, cfg, x.shape[2], torch.float64)
+    lang = torch.cat([lang, tsd["negative_token.weight"].unsqueeze(0).expand(B, -1, -1)], dim=1)
+    for layer in range(cfg["n_layers"]):
+        x = sola_oracle.align_layer(tsd, cfg, layer, x, pe, lang)
+    logits = torch.einsum("bntd,bwd->bntw", x, lang).mean(dim=-1)
+    a = torch.softmax(logits, dim=-1)
+    tok = (x * a.unsqueeze(-1)).sum(dim=2)
+    return torch.einsum("bnd,bwd->bnw", tok, lang).mean(dim=-1), tok
