@@ -136,6 +136,14 @@ int sola_pos_encoding(const float* dev_gauss, int D, int t_len, int max_temporal
  * registered with sola_set_grad for each of the 83 parameters (same names and sizes as sola_set_weight; the Fourier
  * buffer has no gradient).  Gradients flowing into negative_token.weight through the loss's neg_tokens argument come
  * from sola_loss_backward (d_neg) and are added by the caller, exactly as autograd does for train.py:92. */
+/* Dropout of the NEXT sola_forward_train (and of the sola_backward that follows it): p_encoder after every encoder
+ * LeakyReLU (nn.Dropout(p=dropout_p), module/module.py:78-94), p_attention on the attention probabilities
+ * (tools/attention.py:12,71, hard-coded 0.1 in the reference).  Masks are a pure function of (seed, element index), so
+ * nothing is stored; a given seed reproduces the same masks.  p = 0 disables (eval-mode numerics). */
+int sola_set_dropout(SolaCtx* ctx, float p_encoder, float p_attention, uint64_t seed);
+/* The same mask generator for the per-stage entry points sola_group_norm[_backward] / sola_attention[_backward]
+ * (thread-local; used by the parity tests). */
+int sola_set_stage_dropout(float p, uint64_t seed);
 size_t sola_train_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
 size_t sola_backward_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
 int sola_set_grad(SolaCtx* ctx, const char* name, void* dev_ptr, int64_t numel);

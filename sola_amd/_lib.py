@@ -56,6 +56,8 @@ SIGNATURES = {
     "sola_conv1d_cl": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sola_group_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp]),
     "sola_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp, _vp]),
+    "sola_set_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
+    "sola_set_stage_dropout": (_i, [_f, C.c_uint64]),
     "sola_train_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_backward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_set_grad": (_i, [_vp, C.c_char_p, _vp, _i64]),

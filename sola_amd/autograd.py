@@ -27,10 +27,6 @@ class _TrackSelection(torch.autograd.Function):
 
 
 def track_selection_forward(module, object_tokens, lang_tokens):
-    if module.training and (module.dropout_p > 0 or module.attention_dropout_p > 0):
-        raise SolaError(
-            "sola_amd: dropout is not implemented in the HIP training path yet; build the module with dropout_p=0 and "
-            "set module.attention_dropout_p=0 (or call module.eval()) - there is no PyTorch fallback")
     params = [p for p in module.parameters()]
     return _TrackSelection.apply(module, object_tokens, lang_tokens, *params)
 

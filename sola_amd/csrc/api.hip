@@ -224,6 +224,22 @@ extern "C" int sola_weights_changed(SolaCtx* c) {
     return SOLA_OK;
 }
 
+extern "C" int sola_set_dropout(SolaCtx* c, float p_encoder, float p_attention, uint64_t seed) {
+    SOLA_ARG(c && p_encoder >= 0.f && p_encoder < 1.f && p_attention >= 0.f && p_attention < 1.f, "set_dropout: bad argument");
+    c->p_drop_encoder = p_encoder;
+    c->p_drop_attention = p_attention;
+    c->drop_seed = seed;
+    return SOLA_OK;
+}
+
+// dropout applied by the per-stage entry points sola_group_norm[_backward] / sola_attention[_backward] (tests)
+static thread_local DropoutCfg g_stage_drop = {0u, 0u, 0xFFFFFFFFu, 1.f, 0};
+extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
+    SOLA_ARG(p >= 0.f && p < 1.f, "set_stage_dropout: p=%f", (double)p);
+    g_stage_drop = make_dropout(p, seed, 0);
+    return SOLA_OK;
+}
+
 extern "C" int sola_set_ws_policy(SolaCtx* c, int every) {
     SOLA_ARG(c, "set_ws_policy: null ctx");
     c->ws_every_forward = every != 0;
@@ -402,6 +418,7 @@ extern "C" int sola_group_norm(const float* x, float* y, float* y2, const float*
                                void* stream_) {
     SOLA_ARG(x && y && gamma && beta, "group_norm: null argument");
     GroupNormDesc d{x, y, y2, pe, gamma, beta, n_inst, inner, outer_stride, inner_stride, tok_stride, ntok, C, groups, eps, slope, leaky};
+    d.drop = g_stage_drop;
     return launch_group_norm(d, as_stream(stream_));
 }
 
@@ -420,6 +437,7 @@ extern "C" int sola_group_norm_backward(const float* x, const float* dy, const f
     float* gp = static_cast<float*>(scratch);
     float* bp = gp + (size_t)n_inst * C;
     GroupNormBwdDesc d{x, dy, dy2, gamma, beta, dx, gp, bp, n_inst, inner, outer_stride, inner_stride, tok_stride, ntok, C, groups, eps, slope, leaky};
+    d.drop = g_stage_drop;
     hipStream_t s = as_stream(stream_);
     SOLA_TRY(launch_group_norm_bwd(d, s));
     SOLA_TRY(launch_colsum(gp, dgamma, 1, n_inst, C, C, 1.f, 0, nullptr, 0, s));
@@ -432,6 +450,7 @@ extern "C" int sola_attention(const float* q, int ldq, const float* k, int ldk, 
                               void* stream_) {
     SOLA_ARG(q && k && v && o, "attention: null argument");
     AttnDesc d{q, k, v, o, ldq, ldk, ldv, ldo, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, lse};
+    d.drop = g_stage_drop;
     return launch_attention(d, as_stream(stream_));
 }
 
@@ -444,6 +463,7 @@ extern "C" int sola_attention_backward(const float* q, int ldq, const float* k, 
     SOLA_ARG(q && k && v && o && dout && lse && dq && dk && dv && dvec, "attention_backward: null argument");
     AttnBwdDesc d{q, k, v, o, dout, lse, dq, dk, dv, dvec, ldq, ldk, ldv, ldo, ldq, ldk, ldv, G, H, head_dim, Sq, Sk, inner,
                   q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale};
+    d.drop = g_stage_drop;
     return launch_attention_bwd(d, as_stream(stream_));
 }
 

@@ -29,6 +29,7 @@ struct AttnArgs {
     long long q_outer, q_inner, q_rs;
     long long k_outer, k_inner, k_rs;
     float scale;
+    DropoutCfg drop;
 };
 
 template <int DH, bool PRIVATE>
@@ -171,6 +172,14 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+        if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped
+            const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
+        }
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -239,6 +248,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale;
     a.lse = d.lse;
+    a.drop = d.drop;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     switch (d.DH) {

@@ -22,6 +22,7 @@ struct AttnBwdArgs {
     long long q_outer, q_inner, q_rs;
     long long k_outer, k_inner, k_rs;
     float scale;
+    DropoutCfg drop;
 };
 
 template <int DH>
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         for (int r = 0; r < 4; ++r) {
             const bool kok = kt0 + 4 * g4 + r < a.Sk;
             const float p = (kok && q_ok) ? __expf((s0[r] + s1[r]) - lse_q) : 0.f;
-            ds[r] = p * ((p0[r] + p1[r]) - dsum);
+            float dp = p0[r] + p1[r];
+            if (a.drop.enabled)  // O = (P o mask / (1-p)) V: dP = (dO V^T) o mask / (1-p); D = dO . O is unchanged
+                dp = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk + kt0 + 4 * g4 + r)
+                         ? dp * a.drop.scale : 0.f;
+            ds[r] = p * (dp - dsum);
         }
         // dQ^T[d][q] += sum_key K[key][d] * dS^T[key][q]
 #pragma unroll
@@ -232,7 +237,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
                 dv = a.dvec[row * a.H + h];
             }
             pr[r] = ok ? __expf((s0[r] + s1[r]) - lse) : 0.f;
-            ds[r] = pr[r] * ((p0[r] + p1[r]) - dv);
+            float dp = p0[r] + p1[r];
+            float keep = 1.f;
+            if (a.drop.enabled)
+                keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + q) * a.Sk + kj) ? a.drop.scale : 0.f;
+            ds[r] = pr[r] * (dp * keep - dv);
+            pr[r] *= keep;  // dV uses the dropped probabilities
         }
         // dV^T[d][key] += sum_q dO[q][d] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
 #pragma unroll
@@ -295,6 +305,7 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale;
+    a.drop = d.drop;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
     switch (d.DH) {

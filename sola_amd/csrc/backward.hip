@@ -127,8 +127,9 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     };
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
-                      int leaky) -> int {
+                      int leaky, const DropoutCfg* drop) -> int {
         GroupNormBwdDesc d{};
+        if (drop) d.drop = *drop;
         d.x = xpre; d.dy = dy; d.dy2 = dy2; d.gamma = W(wname + ".weight"); d.beta = W(wname + ".bias"); d.dx = dx;
         d.dgamma_part = ar.get("gpart"); d.dbeta_part = ar.get("bpart");
         d.n_inst = n_inst; d.inner = inner; d.outer_stride = outer; d.inner_stride = inner_stride; d.tok_stride = tok_stride;
@@ -175,11 +176,12 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         {
             const std::string an = lp + "object2lang_attn";
             SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, N * Tp, D,
-                            c->cfg.n_groups_module, 0));
+                            c->cfg.n_groups_module, 0, nullptr));
             SOLA_TRY(out_proj_bwd(2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
                            B, H, DH, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
+            ad.drop = c->attn_drop(l, 2);
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
             SOLA_TRY(grad_w(dqkv, 3 * D, x_mot, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
@@ -197,11 +199,12 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         {
             const std::string an = lp + "motion_attn";
             SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, B * N, 1, Tp, 0, 1, Tp, D,
-                            c->cfg.n_groups_module, 0));
+                            c->cfg.n_groups_module, 0, nullptr));
             SOLA_TRY(out_proj_bwd(1));
             AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
                            B * N, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
+            ad.drop = c->attn_drop(l, 1);
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
             const float* x_obj = fb(ls + "_obj");
@@ -219,11 +222,12 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         {
             const std::string an = lp + "obj_attn";
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, D,
-                            c->cfg.n_groups_module, 0));
+                            c->cfg.n_groups_module, 0, nullptr));
             SOLA_TRY(out_proj_bwd(0));
             AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
                            B * Tp, H, DH, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
+            ad.drop = c->attn_drop(l, 0);
             SOLA_TRY(launch_attention_bwd(ad, s));
             SOLA_TRY(grad_w(dqkv, 3 * D, xin, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
             SOLA_TRY(grad_w(dqkv + D, 3 * D, xin, D, M, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
@@ -283,8 +287,9 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         }
         // GroupNorm + LeakyReLU backward of stage i-1
         const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i - 1]);
+        const DropoutCfg edrop = c->enc_drop(i - 1);
         SOLA_TRY(gn_bwd(fb("conv" + std::to_string(i - 1)), dact, nullptr, np, enc[1], R, 1, t_in, 0, 1, t_in, g.cin,
-                        c->cfg.n_groups, 1));
+                        c->cfg.n_groups, 1, &edrop));
         dy = enc[1];  // dact (enc[0]) is consumed; the next stage's dX may overwrite it, its GN backward overwrites enc[1]
     }
     // weight-standardisation backward for all six convs

@@ -17,6 +17,7 @@ struct GnBwdArgs {
     int ntok, C, cg;
     float eps, slope;
     int leaky;
+    DropoutCfg drop;
 };
 
 __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) {
@@ -59,6 +60,12 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
         if (a.dy2) {
             const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
             d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+        }
+        if (a.drop.enabled) {  // y = dropout(lrelu(gn(x))): the mask is regenerated from the element index
+            d.x = dropout_keep(a.drop, (unsigned long long)off) ? d.x * a.drop.scale : 0.f;
+            d.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? d.y * a.drop.scale : 0.f;
+            d.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? d.z * a.drop.scale : 0.f;
+            d.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? d.w * a.drop.scale : 0.f;
         }
         if (a.leaky) {
             if (xh.x * ga.x + be.x < 0.f) d.x *= a.slope;
@@ -377,7 +384,7 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     GnBwdArgs a;
     a.x = d.x; a.dy = d.dy; a.dy2 = d.dy2; a.gamma = d.gamma; a.beta = d.beta; a.dx = d.dx; a.dgp = d.dgamma_part; a.dbp = d.dbeta_part;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop;
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
     hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);

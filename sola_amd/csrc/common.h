@@ -64,6 +64,32 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Counter-based dropout mask (nn.Dropout at module/module.py:78-94, SDPA dropout at tools/attention.py:71): the keep
+// decision of element `idx` is a pure function of (seed, idx), so the backward kernels regenerate the forward's mask
+// instead of storing it.  keep_thr = (1 - p) * 2^32; p = 0 -> keep_thr = 0xFFFFFFFF and `enabled` is false.
+struct DropoutCfg {
+    unsigned int seed_lo, seed_hi, keep_thr;
+    float scale;  // 1 / (1 - p)
+    int enabled;
+};
+__host__ __device__ __forceinline__ bool dropout_keep(const DropoutCfg& d, unsigned long long idx) {
+    unsigned int h = d.seed_lo ^ ((unsigned int)idx * 0x9E3779B1u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h ^= d.seed_hi + (unsigned int)(idx >> 32) * 0x27D4EB2Fu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h < d.keep_thr;
+}
+static inline DropoutCfg make_dropout(float p, unsigned long long seed, unsigned int stream_id) {
+    DropoutCfg d;
+    d.enabled = p > 0.f ? 1 : 0;
+    d.seed_lo = (unsigned int)seed ^ (stream_id * 0x9E3779B9u);
+    d.seed_hi = (unsigned int)(seed >> 32) + stream_id * 0x7F4A7C15u;
+    const double keep = 1.0 - (double)p;
+    d.keep_thr = keep >= 1.0 ? 0xFFFFFFFFu : (unsigned int)(keep * 4294967296.0);
+    d.scale = (float)(1.0 / keep);
+    return d;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Launch check used after every kernel launch.

@@ -45,6 +45,12 @@ struct SolaCtx {
     bool ws_every_forward = true;
     Plan last;                // plan of the last forward (taps, backward)
     const float* last_obj = nullptr;  // input of the last training forward (conv0's weight gradient reads it)
+    // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
+    // the seed used by the last sola_forward_train is kept for sola_backward
+    float p_drop_encoder = 0.f, p_drop_attention = 0.f;
+    unsigned long long drop_seed = 0;
+    DropoutCfg enc_drop(int conv_idx) const { return make_dropout(p_drop_encoder, drop_seed, 1u + (unsigned)conv_idx); }
+    DropoutCfg attn_drop(int layer, int a) const { return make_dropout(p_drop_attention, drop_seed, 100u + 3u * (unsigned)layer + (unsigned)a); }
 };
 
 static const int kConvIdx[6] = {0, 4, 8, 12, 16, 20};

@@ -104,6 +104,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
             nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
             nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
+            if (train) nd.drop = c->enc_drop(i);
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
         } else {
@@ -164,6 +165,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         {
             AttnDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), D, D, D, D, B * Tp, H, DH, N, N, Tp,
                         (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale, lse(0)};
+            if (train) ad.drop = c->attn_drop(l, 0);
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
@@ -173,6 +175,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         {
             AttnDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), D, D, D, D, B * N, H, DH, Tp, Tp, 1,
                         (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale, lse(1)};
+            if (train) ad.drop = c->attn_drop(l, 1);
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
@@ -183,6 +186,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         {
             AttnDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
                         (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale, lse(2)};
+            if (train) ad.drop = c->attn_drop(l, 2);
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));

@@ -49,6 +49,7 @@ struct AttnDesc {
     long long k_outer, k_inner, k_rs;
     float scale;
     float* lse;  // optional [q rows][H]
+    DropoutCfg drop;  // on the probabilities (tools/attention.py:71)
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 
@@ -61,6 +62,7 @@ struct AttnBwdDesc {
     long long q_outer, q_inner, q_rs;
     long long k_outer, k_inner, k_rs;
     float scale;
+    DropoutCfg drop;
 };
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);
 
@@ -78,6 +80,7 @@ struct GroupNormBwdDesc {
     int ntok, C, groups;
     float eps, slope;
     int leaky;
+    DropoutCfg drop;
 };
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
 struct WsBwdLayer {
@@ -129,6 +132,7 @@ struct GroupNormDesc {
     int ntok, C, groups;
     float eps, slope;
     int leaky;
+    DropoutCfg drop;
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);

@@ -71,6 +71,7 @@ struct GnArgs {
     int ntok, C, cg, groups;
     float eps, slope;
     int leaky;
+    DropoutCfg drop;  // applied after the LeakyReLU (module/module.py:78)
 };
 
 __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
@@ -121,6 +122,12 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
             o.y = o.y >= 0.f ? o.y : o.y * a.slope;
             o.z = o.z >= 0.f ? o.z : o.z * a.slope;
             o.w = o.w >= 0.f ? o.w : o.w * a.slope;
+        }
+        if (a.drop.enabled) {
+            o.x = dropout_keep(a.drop, (unsigned long long)off) ? o.x * a.drop.scale : 0.f;
+            o.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? o.y * a.drop.scale : 0.f;
+            o.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? o.z * a.drop.scale : 0.f;
+            o.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? o.w * a.drop.scale : 0.f;
         }
         *reinterpret_cast<float4*>(a.y + off) = o;
         if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
@@ -189,7 +196,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     GnArgs a;
     a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop;
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);
     hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);

@@ -184,6 +184,14 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         lang = lang_tokens.detach().to(torch.float32).contiguous()
         self._ensure_ctx(dev)
         self._bind_weights()
+        if self.training and (self.dropout_p > 0 or self.attention_dropout_p > 0):
+            # a fresh mask seed per step from torch's (seedable) CPU generator, like nn.Dropout under set_seed(42)
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            check(lib().sola_set_dropout(self._ctx, float(self.dropout_p), float(self.attention_dropout_p), seed), "sola_set_dropout")
+        else:
+            seed = 0
+            check(lib().sola_set_dropout(self._ctx, 0.0, 0.0, 0), "sola_set_dropout")
+        self._last_dropout_seed = seed
         nbytes = lib().sola_train_workspace_bytes(self._ctx, B, N, T, L)
         if self._train_ws is None or self._train_ws.numel() < nbytes or self._train_ws.device != dev:
             self._train_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)

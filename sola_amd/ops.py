@@ -19,6 +19,11 @@ def _f32c(t):
     return t.contiguous()
 
 
+def set_stage_dropout(p=0.0, seed=0):
+    """Dropout applied by group_norm / attention (and their backward) below; p = 0 turns it off."""
+    check(lib().sola_set_stage_dropout(float(p), int(seed)), "sola_set_stage_dropout")
+
+
 def ws_standardize(weight):
     """module/ws.py:9-13.  weight [cout, cin, k] -> standardised [cout, k*cin] (k-major GEMM layout)."""
     require_cuda(weight)
