@@ -159,6 +159,16 @@ int sola_loss_backward(const float* dev_score_map, const float* dev_score_tokens
                        int B, int N, int D, int n_neg, float positive_weight, float temperature, float alignment_weight,
                        const float* dev_g3, float* dev_d_score_map, float* dev_d_score_tokens, float* dev_d_neg,
                        void* dev_scratch, size_t scratch_bytes, void* stream);
+/* Gradient statistics of the training step.  sola_grad_sqnorms: out[g] = sum over the tensors of group g of |grad|^2
+ * for g < n_groups and out[n_groups] = their total (dev_out holds n_groups + 1 doubles)
+ * (replaces get_grad_norm_dict, module/module.py:164-199, which syncs the host once per parameter); the pointer /
+ * numel / group arrays are HOST arrays of n <= 128 entries.  sola_grad_clip scales every tensor in place by
+ * min(1, max_norm / (sqrt(*dev_total_sq) + 1e-6)) (torch.nn.utils.clip_grad_norm_, train.py:121-122) without a host sync. */
+size_t sola_grad_sqnorms_scratch_bytes(int n, const int64_t* numel);
+int sola_grad_sqnorms(const float* const* dev_grads, const int64_t* numel, const int32_t* group, int n, int n_groups,
+                      double* dev_out, void* dev_scratch, size_t scratch_bytes, void* stream);
+int sola_grad_clip(float* const* dev_grads, const int64_t* numel, int n, const double* dev_total_sq, float max_norm,
+                   void* stream);
 /* per-stage backward entry points (parity tests) */
 int sola_ws_backward(const float* dev_w, const float* dev_dwstd, int cout, int cin, int k, float* dev_dw, void* stream);
 /* C[N,K] = A[M,N]^T * B[M,K] (weight gradient), optional bias_grad[N] = column sums of A */
@@ -213,6 +223,9 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_GEMM_TN = 9,   /* gemm_tn_f32_kernel (weight gradients) */
        SOLA_PROF_ATTN_BWD = 10, /* attn_bwd_* kernels */
        SOLA_PROF_NCAT = 11 };
+/* Kernel-schedule switches for within-process A/B measurements ("gemm_variant": 0 simple / 1 mid-tile staging;
+ * "attn_variant": 0 baseline / 1 packed + q-block loop).  Results are identical across variants. */
+int sola_tune(const char* key, int value);
 int sola_profile_enable(int enable);
 /* Synchronises the recorded events and returns, per category: launches, total milliseconds, algorithmic flops,
  * algorithmic bytes accumulated since the last reset. Arrays have SOLA_PROF_NCAT entries. */

@@ -77,6 +77,10 @@ SIGNATURES = {
     "sola_mask_pair_counts": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
     "sola_mask_iou_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "sola_mask_iou_matrix": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sola_grad_sqnorms_scratch_bytes": (_sz, [_i, _vp]),
+    "sola_grad_sqnorms": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "sola_grad_clip": (_i, [_vp, _vp, _i, _vp, _f, _vp]),
+    "sola_tune": (_i, [C.c_char_p, _i]),
     "sola_profile_enable": (_i, [_i]),
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
 }

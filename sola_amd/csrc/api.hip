@@ -240,6 +240,16 @@ extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
     return SOLA_OK;
 }
 
+void sola_gemm_set_variant(int v);
+void sola_attn_set_variant(int v);
+extern "C" int sola_tune(const char* key, int value) {
+    SOLA_ARG(key, "tune: null key");
+    if (!strcmp(key, "gemm_variant")) { sola_gemm_set_variant(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }
+    sola_set_error("tune: unknown key '%s'", key);
+    return SOLA_ERR_ARG;
+}
+
 extern "C" int sola_set_ws_policy(SolaCtx* c, int every) {
     SOLA_ARG(c, "set_ws_policy: null ctx");
     c->ws_every_forward = every != 0;
@@ -324,6 +334,27 @@ extern "C" int sola_loss_backward(const float* score_map, const float* score_tok
     SOLA_TRY(launch_loss_bwd(d, as_stream(stream_)));
     if (shared) return launch_neg_token_grad(nullptr, nullptr, stage, d_neg, B, 0, n_neg, D, as_stream(stream_));
     return SOLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gradient norms / clipping (module/module.py:164-199, train.py:120-122)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t sola_grad_sqnorms_scratch_bytes(int n, const int64_t* numel) {
+    if (n <= 0 || !numel) return 0;
+    return mt_sqnorm_scratch_bytes(n, reinterpret_cast<const long long*>(numel));
+}
+
+extern "C" int sola_grad_sqnorms(const float* const* dev_grads, const int64_t* numel, const int32_t* group, int n,
+                                 int n_groups, double* dev_out, void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(dev_grads && numel && group && dev_out && scratch, "grad_sqnorms: null argument");
+    return launch_mt_sqnorm(dev_grads, reinterpret_cast<const long long*>(numel), group, n, n_groups, dev_out, scratch,
+                            scratch_bytes, as_stream(stream_));
+}
+
+extern "C" int sola_grad_clip(float* const* dev_grads, const int64_t* numel, int n, const double* dev_total_sq,
+                              float max_norm, void* stream_) {
+    SOLA_ARG(dev_grads && numel && dev_total_sq, "grad_clip: null argument");
+    return launch_mt_clip(dev_grads, reinterpret_cast<const long long*>(numel), n, dev_total_sq, max_norm, as_stream(stream_));
 }
 
 extern "C" int sola_select(const float* score, int64_t n, float thr, float* prob, float* pred, void* stream_) {

@@ -237,6 +237,9 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
 
 }  // namespace
 
+int g_attn_variant = 1;
+void sola_attn_set_variant(int v) { g_attn_variant = v; }
+
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");

@@ -26,7 +26,7 @@ struct GemmArgs {
 constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats (144 B: 16-byte aligned, conflict-free for b128 fragment reads)
 
-template <int BM, int BN>
+template <int BM, int BN, int PIPE>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte loads per thread per operand per k-tile
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
@@ -146,16 +146,11 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     const int frag_k = (lane >> 5) << 2;
     const int nk = (a.K + BK - 1) / BK;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    auto compute = [&](int buf, int ks_begin, int ks_end) {
         const float* Ab = &As[(buf * BM + wr * (BM / 2) + frag_row) * LDP + frag_k];
         const float* Wb = &Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP + frag_k];
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDP + ks * 8);
@@ -174,8 +169,35 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
                 }
             }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    if constexpr (PIPE == 0) {
+        // simple schedule: loads of tile k+1 in flight during tile k; LDS store + barrier at the tile boundary
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile((kt + 1) * BK);
+            compute(buf, 0, BK / 8);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // deeper schedule: the registers always hold tile k+1 on entry; its LDS store and the global loads of tile
+        // k+2 are issued in the MIDDLE of tile k's MFMA stream, so the tile boundary is a bare barrier + fragment read
+        load_tile(0);
+        store_tile(0);
+        if (nk > 1) load_tile(BK);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            compute(buf, 0, BK / 16);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            if (kt + 2 < nk) load_tile((kt + 2) * BK);
+            compute(buf, BK / 16, BK / 8);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PIPE>
 int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     GemmArgs a = base;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -210,17 +232,21 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     constexpr size_t lds = (size_t)(BM + BN) * 2 * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN, PIPE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, nprob);
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE>), grid, dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
+int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 by 5%, mid-tile staging on 64x64 by 6%), 0 / 1 force
+
 }  // namespace
+
+void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3, "gemm: nprob %d", d.nprob);
@@ -239,6 +265,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
     SolaProfScope prof(big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
-    if (big) return launch_tile<128, 128>(a, d.nprob, s);
-    return launch_tile<64, 64>(a, d.nprob, s);
+    const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
+    if (big) return pipe ? launch_tile<128, 128, 1>(a, d.nprob, s) : launch_tile<128, 128, 0>(a, d.nprob, s);
+    return pipe ? launch_tile<64, 64, 1>(a, d.nprob, s) : launch_tile<64, 64, 0>(a, d.nprob, s);
 }

@@ -113,6 +113,12 @@ int launch_loss_bwd(const LossBwdDesc& d, hipStream_t s);
 int launch_neg_token_grad(const float* d_lang, const float* dlbar, const float* d_neg_align, float* d_negw, int B, int L,
                           int n_neg, int D, hipStream_t s);
 
+// ---- multi-tensor gradient statistics (optim.hip) ---------------------------------------------------------------
+size_t mt_sqnorm_scratch_bytes(int n, const long long* numel);
+int launch_mt_sqnorm(const float* const* ptrs, const long long* numel, const int* group, int n, int n_groups, double* out,
+                     void* scratch, size_t scratch_bytes, hipStream_t s);
+int launch_mt_clip(float* const* ptrs, const long long* numel, int n, const double* total_sq, float max_norm, hipStream_t s);
+
 // ---- normalisation / elementwise (norm.hip) --------------------------------------------------------------------
 struct WsLayer {
     const float* w;  // [cout, cin, k]

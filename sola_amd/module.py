@@ -238,15 +238,56 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         groups = [("short_motion_encoder", list(self.short_motion_encoder.parameters()))]
         groups += [(f"scmola_layer_{i}", list(layer.parameters())) for i, layer in enumerate(self.object_lang_align_layers)]
         groups.append(("negative_token", list(self.negative_token.parameters())))
-        sq = []
-        for _name, params in groups:
-            gs = [p.grad for p in params if p.grad is not None]
-            if gs:
-                sq.append(torch.stack([g.detach().double().pow(2).sum() for g in gs]).sum())
-            else:
-                sq.append(torch.zeros((), dtype=torch.float64, device=self.negative_token.weight.device))
-        vals = torch.stack(sq).cpu().tolist()
+        tensors, group_ids = [], []
+        for gi, (_name, params) in enumerate(groups):
+            for p in params:
+                if p.grad is not None:
+                    tensors.append(p.grad)
+                    group_ids.append(gi)
+        n_groups = len(groups)
+        if not tensors:
+            vals = [0.0] * n_groups
+        else:
+            sq = self._grad_sqnorms(tensors, group_ids, n_groups)
+            self._last_grad_sq = sq  # device doubles, reused by clip_grad_norm_ without another reduction
+            vals = sq[:n_groups].cpu().tolist()  # the single host sync
         out = {"total_grad_norm": sum(vals) ** 0.5}
         for (name, _), v in zip(groups, vals):
             out[name] = v ** 0.5
         return out
+
+    def _grad_sqnorms(self, tensors, group_ids, n_groups):
+        """sola_grad_sqnorms: per-group sum of squares in one multi-tensor launch; slot n_groups holds the total."""
+        require_cuda(*tensors)
+        n = len(tensors)
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise SolaError("gradients must be contiguous float32 tensors")
+        dev = tensors[0].device
+        if n > 128:
+            raise SolaError("too many gradient tensors for one launch")
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        numel = (C.c_int64 * n)(*[t.numel() for t in tensors])
+        group = (C.c_int32 * n)(*group_ids)
+        out = torch.empty(n_groups + 1, dtype=torch.float64, device=dev)  # [groups..., total]
+        nb = lib().sola_grad_sqnorms_scratch_bytes(n, numel)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        check(lib().sola_grad_sqnorms(ptrs, numel, group, n, n_groups, ptr(out), ptr(scratch), nb, current_stream(dev)),
+              "sola_grad_sqnorms")
+        return out
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm) (train.py:121-122) as one in-place multi-tensor
+        launch driven by the device-side total from the last get_grad_norm_dict(); no host sync."""
+        grads = [p.grad for p in self.parameters() if p.grad is not None]
+        if not grads:
+            return
+        if getattr(self, "_last_grad_sq", None) is None:
+            self.get_grad_norm_dict()
+        n = len(grads)
+        dev = grads[0].device
+        ptrs = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+        numel = (C.c_int64 * n)(*[g.numel() for g in grads])
+        total = self._last_grad_sq[-1:]
+        check(lib().sola_grad_clip(ptrs, numel, n, ptr(total), float(max_norm), current_stream(dev)), "sola_grad_clip")
+        self._last_grad_sq = None

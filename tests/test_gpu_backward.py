@@ -300,3 +300,30 @@ def _oracle_forward_grad(tsd, cfg, inp):
     a = torch.softmax(logits, dim=-1)
     tok = (x * a.unsqueeze(-1)).sum(dim=2)
     return torch.einsum("bnd,bwd->bnw", tok, lang).mean(dim=-1), tok
+
+
+def test_grad_norm_dict_and_clip_match_torch(small_model):
+    """get_grad_norm_dict / clip_grad_norm_ run as multi-tensor HIP launches: same numbers as the per-parameter torch
+    formulation of module/module.py:164-199 and torch.nn.utils.clip_grad_norm_ (train.py:121-122)."""
+    m, _ = small_model
+    cfg = synth.SMALL_MODEL_CFG
+    train_step_grads(m, cfg, 2, 6, 24, 7, 9)
+    ref_groups = {"short_motion_encoder": list(m.short_motion_encoder.parameters()), "negative_token": list(m.negative_token.parameters())}
+    for i, layer in enumerate(m.object_lang_align_layers):
+        ref_groups[f"scmola_layer_{i}"] = list(layer.parameters())
+    ref = {k: math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in ps)) for k, ps in ref_groups.items()}
+    ref["total_grad_norm"] = math.sqrt(sum(v * v for v in ref.values()))
+    got = m.get_grad_norm_dict()
+    assert set(got) == set(ref)
+    for k in ref:
+        assert got[k] == pytest.approx(ref[k], rel=1e-6), k
+    before = {k: p.grad.clone() for k, p in m.named_parameters()}
+    max_norm = 0.37 * ref["total_grad_norm"]
+    m.clip_grad_norm_(max_norm)
+    coef = max_norm / (ref["total_grad_norm"] + 1e-6)
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, before[k] * coef, rtol=1e-6, atol=0)
+    assert m.get_grad_norm_dict()["total_grad_norm"] == pytest.approx(max_norm, rel=1e-5)
+    m.clip_grad_norm_(10 * max_norm)  # below the threshold: untouched
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, before[k] * coef, rtol=1e-6, atol=0)

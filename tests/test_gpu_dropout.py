@@ -152,6 +152,7 @@ def test_training_step_with_dropout_is_seeded_and_consistent():
     analytic = sum(float((g_a[k].double() * direction[k].double()).sum()) for k in params)
     eps = 1e-4  # fp32 finite differences of this loss are good to a few % (same spread in eval mode, tools/dd_probe.py)
     vals = []
+    saved = {k: p.detach().clone() for k, p in params.items()}
     for sgn in (+1, -1):
         with torch.no_grad():
             for k, p in params.items():
@@ -161,7 +162,7 @@ def test_training_step_with_dropout_is_seeded_and_consistent():
         vals.append(float(l[0]))
         with torch.no_grad():
             for k, p in params.items():
-                p.sub_(sgn * eps * direction[k])
+                p.copy_(saved[k])  # add-then-subtract does not restore fp32 weights bit-exactly
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert abs(numeric - analytic) <= 0.08 * abs(analytic) + 1e-3, (numeric, analytic)  # a wrong mask is O(1) off
     # p = 0 in train mode reproduces the eval numerics exactly
