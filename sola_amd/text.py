@@ -1,0 +1,50 @@
+"""Text side of the path: frozen RoBERTa stays on stock PyTorch-ROCm (north star); this module only wraps it.
+
+``encode(expressions) -> (lang_tokens [B,L,D], pos_tokens [B,1,D])`` is train.py:80-91 (tokenise, last_hidden_state,
+attention-mask mean pooling).  Neither box has network access or the checkpoint, so when
+``sentence-transformers/all-roberta-large-v1`` cannot be loaded from a local cache a deterministic hashed embedding
+with the same output contract is used instead (and says so once); it exists to let the entry points run end to end."""
+from __future__ import annotations
+
+import hashlib
+import warnings
+
+import numpy as np
+import torch
+
+
+class TextEncoder:
+    def __init__(self, name: str, dim: int, device):
+        self.dim, self.device = dim, device
+        self.tokenizer = self.model = None
+        try:
+            import os
+
+            os.environ.setdefault("HF_HUB_OFFLINE", "1")
+            from transformers import AutoModel, AutoTokenizer
+
+            self.tokenizer = AutoTokenizer.from_pretrained(name, local_files_only=True)
+            self.model = AutoModel.from_pretrained(name, local_files_only=True).to(device).eval()
+        except Exception as e:  # no local checkpoint
+            warnings.warn(f"text encoder '{name}' is not available offline ({type(e).__name__}); using hashed stand-in embeddings")
+
+    @torch.no_grad()
+    def encode(self, expressions):
+        if self.model is not None:
+            enc = self.tokenizer.batch_encode_plus(expressions, padding="longest", return_tensors="pt").to(self.device)
+            out = self.model(**enc)
+            tok = out.last_hidden_state
+            m = enc["attention_mask"].unsqueeze(-1).expand(tok.size()).float()
+            pos = (torch.sum(tok * m, 1) / torch.clamp(m.sum(1), min=1e-9)).unsqueeze(1)
+            return tok, pos
+        words = [["<s>"] + e.lower().split() + ["</s>"] for e in expressions]
+        L = max(len(w) for w in words)
+        tok = np.zeros((len(words), L, self.dim), dtype=np.float32)
+        mask = np.zeros((len(words), L, 1), dtype=np.float32)
+        for b, ws in enumerate(words):
+            for i, w in enumerate(ws):
+                seed = int.from_bytes(hashlib.sha256(w.encode()).digest()[:8], "little")
+                tok[b, i] = np.random.Generator(np.random.PCG64(seed)).standard_normal(self.dim) * 0.5
+                mask[b, i] = 1.0
+        pos = (tok * mask).sum(1, keepdims=True) / np.maximum(mask.sum(1, keepdims=True), 1e-9)
+        return torch.from_numpy(tok).to(self.device), torch.from_numpy(pos).to(self.device)

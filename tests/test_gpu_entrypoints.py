@@ -1,0 +1,42 @@
+"""End-to-end run of the three entry points on the GPU with the synthetic stand-in dataset: train one epoch (forward,
+losses, HIP backward, multi-tensor clip, AdamW), save epoch_1.pth in the reference layout, then eval and inference load it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_eval_inference_roundtrip(tmp_path):
+    os.makedirs(tmp_path / "configs" / "mevis")
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "mevis", "default.yaml")))
+    cfg["dataset"]["track_root"] = str(tmp_path / "no_such_dir")
+    yaml.safe_dump(cfg, open(tmp_path / "configs" / "mevis" / "default.yaml", "w"))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    common = ["--config", "mevis/default", "--synthetic", "true", "--synthetic_samples", "6", "--synthetic_tracks", "8", "--synthetic_frames", "16"]
+
+    def run(script, *extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script), *common, *extra], cwd=tmp_path, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stdout
+
+    out = run("train.py", "--n_epochs_override", "2")
+    wdir = tmp_path / "SOLA" / "TRAIN" / "default" / "mevis"
+    assert (wdir / "epoch_1.pth").exists() and (wdir / "epoch_2.pth").exists() and "EPOCH 2" in out
+    sd = torch.load(wdir / "epoch_2.pth", map_location="cpu", weights_only=True)
+    assert len(sd) == 84 and all(torch.isfinite(v).all() for v in sd.values())
+    sd1 = torch.load(wdir / "epoch_1.pth", map_location="cpu", weights_only=True)
+    assert any(not torch.equal(sd[k], sd1[k]) for k in sd)  # the optimizer moved the weights
+    run("eval.py", "--eval_weight_epoch", "2")
+    m = json.load(open(tmp_path / "SOLA" / "EVAL" / "default" / "mevis" / "pred_threshold_05" / "epoch_2" / "track_metrics.json"))
+    assert m["tp"] + m["fp"] + m["fn"] + m["tn"] == 6 * 8 and m["total"] > 0
+    run("inference.py", "--eval_weight_epoch", "2")
+    inf = tmp_path / "SOLA" / "INFERENCE" / "default" / "mevis" / "pred_threshold_05" / "epoch_2"
+    assert len(list(inf.rglob("*_pred.npy"))) == 6

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Training entry point with the reference's CLI / YAML / checkpoint layout (train.py of cvlab-kaist/SOLA), running
+the track-selection network, its losses, backward, gradient norms and clipping in libsola_hip.so.
+
+    python train.py --config mevis/default [--n_epochs_override 1] [--synthetic true]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config mevis/default
+
+One process per GPU; samples are sharded i % world == rank; the only collective is the RCCL all-reduce (average) of
+the 32.98M-element gradient before get_grad_norm_dict()/clipping, so every rank clips and steps identically
+(effective batch = world size; the reference itself is single-process, batch 1).  AdamW / ReduceLROnPlateau stay on
+PyTorch as in the reference (train.py:44-57).  Weights are saved as ``<output_dir>/epoch_{k}.pth`` (train.py:246).
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from sola_amd import dist as sdist
+from sola_amd.config import load_configs
+from sola_amd.data import make_loader
+from sola_amd.loss import track_selection_losses
+from sola_amd.module import LanguageAlignedTrackSelectionModule
+from sola_amd.text import TextEncoder
+
+
+def set_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1):
+    pw, temp, aw = tcfg["positive_weight"], tcfg["temperature"], tcfg["alignment_weight"]
+    module.train(train)
+    sums = torch.zeros(3, device=device)
+    counts = torch.zeros(4, device=device)  # TP FP FN TN
+    n = 0
+    for batch in loader:
+        obj = batch["object_tokens"].to(device, non_blocking=True)
+        labels = (batch["labels"][tcfg["positive_metric"]] > tcfg["positive_threshold"]).float().to(device)
+        lang, pos = text.encode(batch["expression"])
+        with torch.set_grad_enabled(train):
+            score, tokens = module(obj, lang)
+            # train.py:92 (batch_size = lang_tokens.shape[0])
+            neg = module.negative_token.weight.clone().unsqueeze(0).repeat(lang.shape[0], 1, 1)
+            loss3 = track_selection_losses(score, tokens, labels, pos, neg, pw, temp, aw)
+        if train:
+            optimizer.zero_grad(set_to_none=True)
+            loss3[0].backward()
+            sdist.allreduce_gradients(module.parameters(), world)
+            if tcfg["grad_clip_norm"] > 0:
+                gnd = module.get_grad_norm_dict()  # one host sync for all five norms
+                if gnd["total_grad_norm"] > tcfg["grad_clip_norm"]:
+                    module.clip_grad_norm_(tcfg["grad_clip_norm"])
+            optimizer.step()
+        else:
+            pred = (torch.sigmoid(score) > tcfg["pred_threshold"]).float()
+            counts += torch.stack([(pred * labels).sum(), (pred * (1 - labels)).sum(), ((1 - pred) * labels).sum(),
+                                   ((1 - pred) * (1 - labels)).sum()])
+        sums += loss3.detach()
+        n += 1
+    stats = torch.cat([sums, counts, torch.tensor([float(n)], device=device)])
+    if world > 1:
+        torch.distributed.all_reduce(stats)
+    stats = stats.cpu().tolist()
+    n_tot = max(stats[7], 1.0)
+    return {"total": stats[0] / n_tot, "bce": stats[1] / n_tot, "alignment": stats[2] / n_tot, "tp": stats[3], "fp": stats[4],
+            "fn": stats[5], "tn": stats[6]}
+
+
+def train(cfg):
+    rank, local_rank, world = sdist.init_from_env()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    module = LanguageAlignedTrackSelectionModule(cfg["model"]).to(device)
+    if world > 1:  # identical initial weights on every rank
+        for t in module.state_dict().values():
+            torch.distributed.broadcast(t, src=0)
+    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device)
+    synthetic = cfg.get("synthetic", None)
+    train_loader, _ = make_loader(cfg["dataset"], "train", rank, world, synthetic, cfg["model"])
+    valid_loader, _ = make_loader(cfg["dataset"], "valid", rank, world, synthetic, cfg["model"])
+    tcfg = cfg["train"]
+    optimizer = torch.optim.AdamW(module.parameters(), lr=tcfg["lr"])
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=tcfg["lr_factor"], patience=tcfg["lr_patience"])
+    n_epochs = int(cfg.get("n_epochs_override", tcfg["n_epochs"]))
+    for epoch in range(n_epochs):
+        t0 = time.time()
+        tr = run_split(module, text, train_loader, tcfg, device, True, optimizer, world)
+        va = run_split(module, text, valid_loader, tcfg, device, False, None, world)
+        scheduler.step(va["total"])
+        if rank == 0:
+            prec = va["tp"] / max(va["tp"] + va["fp"], 1.0)
+            rec = va["tp"] / max(va["tp"] + va["fn"], 1.0)
+            line = (f"EPOCH {epoch + 1} | train total {tr['total']:.4f} bce {tr['bce']:.4f} align {tr['alignment']:.4f} | "
+                    f"valid total {va['total']:.4f} bce {va['bce']:.4f} align {va['alignment']:.4f} | precision {prec:.4f} "
+                    f"recall {rec:.4f} | {time.time() - t0:.1f} s")
+            print(line, flush=True)
+            with open(os.path.join(cfg["results"]["output_dir"], "log.txt"), "a") as f:
+                f.write(line + "\n")
+            torch.save(module.state_dict(), os.path.join(cfg["results"]["output_dir"], f"epoch_{epoch + 1}.pth"))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    configs = load_configs("train")
+    set_seed(42)
+    train(configs)
