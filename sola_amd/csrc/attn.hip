@@ -7,15 +7,19 @@
 //
 // HBM-bound kernel: q, k, v are read once and o written once per (group, head).  One wave (64 lanes) owns a
 // 16-query tile and walks the keys 16 at a time with v_mfma_f32_16x16x4_f32 (exact f32):
-//   S^T = K Q^T   : A = K rows (ds_read_b128 from LDS), B = Q rows (held in registers for the whole kernel).
+//   S^T = K Q^T   : A = K rows (ds_read_b128 from LDS), B = Q rows (held in registers).
 //                   Lane l then holds the scores of query (l & 15) against keys 4*(l >> 4)+{0..3}: a softmax row
 //                   lives in one 16-lane column, so max/sum are 3 in-lane ops + 2 xor-shuffles (16, 32).
 //   O^T = V^T P^T : A = V^T (ds_read_b32 from LDS), B = P straight from the score registers (same lane, same
 //                   key slots - no cross-lane movement).  Lane l ends with o[q = l & 15][16*dt + 4*(l >> 4) + {0..3}],
 //                   i.e. one float4 store per 16-wide head-dim tile.
-// Online softmax across 64-key LDS tiles handles any Sk.  Two staging modes:
-//   shared : 4 waves = 4 query tiles of one (group, head); K/V tile staged once per block (obj / obj->lang attention)
-//   private: every wave owns its own (group, head) with Sq, Sk <= 16 (motion attention over T' <= 16 steps)
+// Two staging modes:
+//   shared : a block serves one (group, head): K/V are staged once per 64-key tile (LDS sized by the real key count)
+//            and, when all keys fit one tile, the block loops over several 64-query blocks against the resident K/V
+//            (object->language: 256..2048 queries x 48 keys).  Online softmax across tiles handles any Sk.
+//   packed : sequences of <= 16 steps (motion attention over T').  16 / pow2(T') independent (group, head) units share
+//            ONE 16x16 MFMA tile as a block-diagonal problem (cross-unit scores masked to -inf), so a T'=4 launch
+//            issues a quarter of the waves and MFMAs and each wave moves 4x the bytes per tile.
 #include "kernels.h"
 
 namespace {
@@ -30,79 +34,143 @@ struct AttnArgs {
     long long k_outer, k_inner, k_rs;
     float scale;
     DropoutCfg drop;
+    int kv_rows;      // shared: LDS rows per tile = min(64, round16(Sk))
+    int qsplit;       // shared: blocks per (group, head); each handles q-blocks qs, qs + qsplit, ...
+    int sp_log2;      // packed: log2 of the per-unit slot count SP (SP = pow2 >= max(Sq, Sk)), units per tile = 16 >> sp_log2
 };
 
-template <int DH, bool PRIVATE>
+template <int DH, bool PACKED>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
     constexpr int NC = DH / 16;   // 16-wide head-dim chunks
     constexpr int LDK = DH + 8;   // K pitch: ds_read_b128 by 16-lane groups lands on 16 distinct 16-B slots
     constexpr int LDV = DH + 4;   // V pitch: ds_read_b32, the two 16-lane halves of a 32-lane group are 16 banks apart
     constexpr int F4 = DH / 4;    // float4 per row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;               // [64][LDK]
-    float* Vs = smem + 64 * LDK;    // [64][LDV]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
 
-    int grp, h, qi;
-    bool unit_ok = true;
-    if constexpr (PRIVATE) {
-        const long long unit = (long long)blockIdx.x * 4 + wave;
-        unit_ok = unit < (long long)a.G * a.H;
-        grp = unit_ok ? (int)(unit / a.H) : 0;
-        h = unit_ok ? (int)(unit % a.H) : 0;
-        qi = c16;
-    } else {
-        int b = blockIdx.x;
-        const int qb = b % a.nqb;
-        b /= a.nqb;
-        h = b % a.H;
-        grp = b / a.H;
-        qi = qb * 64 + wave * 16 + c16;
-    }
-    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
-    const bool q_ok = unit_ok && qi < a.Sq;
-
-    // Q fragment (B operand of S^T = K Q^T): lane holds q[qi][16c + 4*g4 + {0..3}], pre-scaled
-    float4 qf[NC];
-    {
-        const float* qp = a.q + (qrow0 + (long long)qi * a.q_rs) * a.ldq + h * DH + 4 * g4;
+    if constexpr (PACKED) {
+        // ---------------------------------------------------------------- packed: 16 >> sp_log2 units per wave tile
+        float* Ks = smem + wave * 16 * (LDK + LDV);
+        float* Vs = Ks + 16 * LDK;
+        const int SP = 1 << a.sp_log2, U = 16 >> a.sp_log2;
+        const long long units = (long long)a.G * a.H;
+        const long long unit0 = ((long long)blockIdx.x * 4 + wave) * U;
+        auto row_unit = [&](int r, int& grp, int& h, int& j) -> bool {  // tile row -> (group, head, step)
+            const long long u = unit0 + (r >> a.sp_log2);
+            j = r & (SP - 1);
+            const bool ok = u < units;
+            grp = ok ? (int)(u / a.H) : 0;
+            h = ok ? (int)(u % a.H) : 0;
+            return ok;
+        };
+        int grp, h, jq;
+        const bool unit_ok = row_unit(c16, grp, h, jq);
+        const bool q_ok = unit_ok && jq < a.Sq;
+        const long long qrow = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner + (long long)jq * a.q_rs;
+        float4 qf[NC];
+        {
+            const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float4 v = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            qf[c] = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+            for (int c = 0; c < NC; ++c) {
+                const float4 v = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                qf[c] = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+            }
         }
-    }
-
-    f32x4 oacc[NC];
+        // stage this wave's 16 key rows (each row may belong to a different unit)
+        for (int idx = lane; idx < 16 * F4; idx += 64) {
+            const int r = idx / F4, c4 = idx - r * F4;
+            int kg, kh, kj;
+            const bool ok = row_unit(r, kg, kh, kj) && kj < a.Sk;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (ok) {
+                const long long row = (long long)(kg / a.inner) * a.k_outer + (long long)(kg % a.inner) * a.k_inner + (long long)kj * a.k_rs;
+                kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + kh * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + kh * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
+        }
+        __syncthreads();
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float* kp = &Ks[c16 * LDK + 4 * g4];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    constexpr int KT = PRIVATE ? 16 : 64;
-    const int row_base = PRIVATE ? wave * 16 : 0;
-    for (int kt0 = 0; kt0 < a.Sk; kt0 += KT) {
-        const int nrows = min(KT, a.Sk - kt0);
-        const int nrows16 = (nrows + 15) & ~15;
-        __syncthreads();  // the previous tile has been consumed by every wave
-        if constexpr (PRIVATE) {
-            if (unit_ok) {
-                for (int idx = lane; idx < 16 * F4; idx += 64) {
-                    const int r = idx / F4, c4 = idx - r * F4;
-                    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-                    if (r < nrows) {
-                        const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
-                        kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
-                        vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
-                    }
-                    *reinterpret_cast<float4*>(&Ks[(row_base + r) * LDK + c4 * 4]) = kv;
-                    *reinterpret_cast<float4*>(&Vs[(row_base + r) * LDV + c4 * 4]) = vv;
+            for (int c = 0; c < NC; ++c) {
+                const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
+                if (c & 1) {
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a1, 0, 0, 0);
+                } else {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a0, 0, 0, 0);
                 }
             }
-        } else {
+        }
+        // block-diagonal mask: key slot (4*g4 + r) is visible to query row c16 only inside the same unit
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kr = 4 * g4 + r;
+            const bool vis = (kr >> a.sp_log2) == (c16 >> a.sp_log2) && (kr & (SP - 1)) < a.Sk;
+            sc[r] = vis ? (a0[r] + a1[r]) : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;  // rows of absent units: keep exp() finite, nothing is stored for them
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = __expf(sc[r] - mx);
+            rs += sc[r];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        if (a.drop.enabled) {
+            const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * a.Sq + jq) * a.Sk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sc[r] = dropout_keep(a.drop, rbase + ((4 * g4 + r) & (SP - 1))) ? sc[r] * a.drop.scale : 0.f;
+        }
+        f32x4 oacc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = &Vs[(4 * g4 + r) * LDV + c16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[c * 16], sc[r], oacc[c], 0, 0, 0);
+        }
+        if (q_ok) {
+            if (a.lse && g4 == 0) a.lse[qrow * a.H + h] = mx + logf(rs);
+            const float inv = 1.f / rs;
+            float* op = a.o + qrow * a.ldo + h * DH + 4 * g4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                *reinterpret_cast<float4*>(op + c * 16) =
+                    make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        }
+    } else {
+        // ---------------------------------------------------------------- shared: one (group, head) per block
+        float* Ks = smem;                       // [kv_rows][LDK]
+        float* Vs = smem + a.kv_rows * LDK;     // [kv_rows][LDV]
+        int b = blockIdx.x;
+        const int qs = b % a.qsplit;
+        b /= a.qsplit;
+        const int h = b % a.H;
+        const int grp = b / a.H;
+        const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        const bool single_tile = a.Sk <= a.kv_rows;
+        auto stage = [&](int kt0, int nrows, int nrows16) {
             for (int idx = tid; idx < nrows16 * F4; idx += 256) {
                 const int r = idx / F4, c4 = idx - r * F4;
                 float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -114,122 +182,175 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
                 *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = kv;
                 *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
             }
+        };
+        if (single_tile) {
+            stage(0, a.Sk, (a.Sk + 15) & ~15);
+            __syncthreads();
         }
-        __syncthreads();
-
-        constexpr int NT = KT / 16;
-        const int ntile = nrows16 >> 4;
-        // ---- scores: s[t][r] = q(c16) . k(kt0 + 16t + 4*g4 + r)
-        f32x4 sc[NT];
+        // the next q-block's fragment is fetched while the current one is being computed (no barrier inside this loop
+        // when K/V are resident, so the loads simply stay in flight under the MFMAs)
+        auto load_q = [&](int qb, float4 (&dst)[NC]) {
+            const int qi = qb * 64 + wave * 16 + c16;
+            const bool ok = qb < a.nqb && qi < a.Sq;
+            const float* qp = a.q + (qrow0 + (long long)qi * a.q_rs) * a.ldq + h * DH + 4 * g4;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < ntile) {
-                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                const float* kp = &Ks[(row_base + t * 16 + c16) * LDK + 4 * g4];
+            for (int c = 0; c < NC; ++c) dst[c] = ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        float4 qnext[NC];
+        load_q(qs, qnext);
+        for (int qb = qs; qb < a.nqb; qb += a.qsplit) {
+            const int qi = qb * 64 + wave * 16 + c16;
+            const bool q_ok = qi < a.Sq;
+            float4 qf[NC];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
-                    if (c & 1) {
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a1, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a1, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a1, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a1, 0, 0, 0);
+            for (int c = 0; c < NC; ++c)
+                qf[c] = make_float4(qnext[c].x * a.scale, qnext[c].y * a.scale, qnext[c].z * a.scale, qnext[c].w * a.scale);
+            if (qb + a.qsplit < a.nqb) load_q(qb + a.qsplit, qnext);
+            f32x4 oacc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float m_run = -INFINITY, l_run = 0.f;
+            for (int kt0 = 0; kt0 < a.Sk; kt0 += 64) {
+                const int nrows = min(64, a.Sk - kt0);
+                const int nrows16 = (nrows + 15) & ~15;
+                if (!single_tile) {
+                    __syncthreads();  // the previous tile has been consumed by every wave
+                    stage(kt0, nrows, nrows16);
+                    __syncthreads();
+                }
+                const int ntile = nrows16 >> 4;
+                // ---- scores: s[t][r] = q(c16) . k(kt0 + 16t + 4*g4 + r)
+                f32x4 sc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < ntile) {
+                        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                        const float* kp = &Ks[(t * 16 + c16) * LDK + 4 * g4];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
+                            if (c & 1) {
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a1, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a1, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a1, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a1, 0, 0, 0);
+                            } else {
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a0, 0, 0, 0);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a0, 0, 0, 0);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a0, 0, 0, 0);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a0, 0, 0, 0);
+                            }
+                        }
+                        const int key0 = kt0 + t * 16 + 4 * g4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < a.Sk) ? (a0[r] + a1[r]) : -INFINITY;
                     } else {
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a0, 0, 0, 0);
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a0, 0, 0, 0);
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a0, 0, 0, 0);
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a0, 0, 0, 0);
+                        sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                     }
                 }
-                const int key0 = kt0 + t * 16 + 4 * g4;
+                // ---- online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
+                float mx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < a.Sk) ? (a0[r] + a1[r]) : -INFINITY;
-            } else {
-                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            }
-        }
-        // ---- online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
-        float mx = -INFINITY;
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+                float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
-        float rs = 0.f;
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+                    for (int r = 0; r < 4; ++r) {
+                        sc[t][r] = __expf(sc[t][r] - m_new);
+                        rs += sc[t][r];
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sc[t][r] = __expf(sc[t][r] - m_new);
-                rs += sc[t][r];
-            }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+                for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+                if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped
+                    const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
-        if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped
-            const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk;
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                        for (int r = 0; r < 4; ++r)
+                            sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
+                }
+                // ---- O^T += V^T P^T
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
-        }
-        // ---- O^T += V^T P^T
+                for (int t = 0; t < 4; ++t) {
+                    if (t < ntile) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < ntile) {
+                        for (int r = 0; r < 4; ++r) {
+                            const float* vp = &Vs[(t * 16 + 4 * g4 + r) * LDV + c16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float* vp = &Vs[(row_base + t * 16 + 4 * g4 + r) * LDV + c16];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[c * 16], sc[t][r], oacc[c], 0, 0, 0);
+                            for (int c = 0; c < NC; ++c)
+                                oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[c * 16], sc[t][r], oacc[c], 0, 0, 0);
+                        }
+                    }
                 }
             }
+            if (q_ok) {
+                if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * a.q_rs) * a.H + h] = m_run + logf(l_run);
+                const float inv = 1.f / l_run;
+                float* op = a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH + 4 * g4;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    *reinterpret_cast<float4*>(op + c * 16) =
+                        make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+            }
         }
     }
-
-    if (q_ok) {
-        if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * a.q_rs) * a.H + h] = m_run + logf(l_run);
-        const float inv = 1.f / l_run;
-        float* op = a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH + 4 * g4;
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            *reinterpret_cast<float4*>(op + c * 16) =
-                make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
-    }
 }
+
+int g_attn_target_blocks = 512;  // resident-K/V mode: blocks per launch (measured flat from 256 to 1024, worse above)
+int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
 
 template <int DH>
 int launch_dh(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
-    constexpr size_t lds = (size_t)64 * ((DH + 8) + (DH + 4)) * sizeof(float);
-    const bool priv = a.Sq <= 16 && a.Sk <= 16;
+    constexpr size_t lds_max = (size_t)64 * ((DH + 8) + (DH + 4)) * sizeof(float);
+    const bool packed = a.Sq <= 16 && a.Sk <= 16;
     static bool attr_set = false;
     if (!attr_set) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set = true;
     }
-    if (priv) {
+    if (packed) {
+        int need = a.Sq > a.Sk ? a.Sq : a.Sk, lg = 0;
+        while ((1 << lg) < need) ++lg;
+        if (g_attn_variant == 0) lg = 4;  // baseline: one unit per wave tile
+        a.sp_log2 = lg;
+        const int U = 16 >> lg;
         const long long units = (long long)a.G * a.H;
-        a.nqb = 1;
-        dim3 grid((unsigned)((units + 3) / 4));
-        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true>), grid, dim3(256), lds, s, a);
+        const long long tiles = (units + U - 1) / U;
+        a.nqb = 1; a.kv_rows = 16; a.qsplit = 1;
+        dim3 grid((unsigned)((tiles + 3) / 4));
+        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true>), grid, dim3(256), lds_max, s, a);
     } else {
         a.nqb = (a.Sq + 63) / 64;
-        const long long blocks = (long long)a.G * a.H * a.nqb;
+        a.sp_log2 = 4;
+        const int r16 = (a.Sk + 15) & ~15;
+        a.kv_rows = g_attn_variant == 0 ? 64 : (r16 < 64 ? r16 : 64);
+        const long long gh = (long long)a.G * a.H;
+        int qsplit = a.nqb;
+        if (g_attn_variant != 0 && a.Sk <= a.kv_rows) {  // K/V resident: loop q-blocks, keep >= ~1024 blocks in the grid
+            qsplit = (int)((g_attn_target_blocks + gh - 1) / gh);
+            if (qsplit < 1) qsplit = 1;
+            if (qsplit > a.nqb) qsplit = a.nqb;
+        }
+        a.qsplit = qsplit;
+        const long long blocks = gh * qsplit;
         SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
-        dim3 grid((unsigned)blocks);
-        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false>), grid, dim3(256), lds, s, a);
+        const size_t lds = (size_t)a.kv_rows * ((DH + 8) + (DH + 4)) * sizeof(float);
+        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -237,8 +358,8 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
 
 }  // namespace
 
-int g_attn_variant = 1;
 void sola_attn_set_variant(int v) { g_attn_variant = v; }
+void sola_attn_set_target_blocks(int v) { g_attn_target_blocks = v; }
 
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
@@ -252,6 +373,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.scale = d.scale;
     a.lse = d.lse;
     a.drop = d.drop;
+    a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     switch (d.DH) {

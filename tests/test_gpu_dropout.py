@@ -59,7 +59,7 @@ def test_encoder_dropout_mask_rate_scale_and_backward():
     assert ((y2 != 0) != keep).mean() > 0.2
 
 
-@pytest.mark.parametrize("layout", ["obj", "motion", "o2l"])
+@pytest.mark.parametrize("layout", ["obj", "motion", "motion_packed", "o2l"])
 def test_attention_dropout_same_mask_forward_and_backward(layout):
     """V = one-hot rows exposes the dropped probability matrix as the attention output, which yields the mask."""
     H, dh, p = 8, 16, 0.1
@@ -70,8 +70,8 @@ def test_attention_dropout_same_mask_forward_and_backward(layout):
         G, Sq, Sk, inner, qa, ka = B * Tp, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp)
         view = lambda t: t.reshape(B, N, Tp, D).permute(0, 2, 1, 3).reshape(G, N, D)
         rows_q = rows_k = B * N * Tp
-    elif layout == "motion":
-        B, N, Tp = 2, 5, 9
+    elif layout in ("motion", "motion_packed"):
+        B, N, Tp = (2, 5, 9) if layout == "motion" else (3, 7, 4)  # T'=4: four (track, head) units share one MFMA tile
         G, Sq, Sk, inner, qa, ka = B * N, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1)
         view = lambda t: t.reshape(G, Tp, D)
         rows_q = rows_k = B * N * Tp
