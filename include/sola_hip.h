@@ -71,6 +71,19 @@ int sola_set_weight(SolaCtx* ctx, const char* name, const void* dev_ptr, int64_t
 int sola_weights_changed(SolaCtx* ctx);
 int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
 
+/* Inference arithmetic of the dense contractions (convs and projections, 98 % of the FLOPs):
+ *   0  exact f32: v_mfma_f32_32x32x2_f32 on f32 operands (default);
+ *   1  split-f16: every operand value x is carried as (f16 hi, f16 lo) with hi + lo = x to 22 bits, in the same 4 bytes,
+ *      and each product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation - 3/16 of the f32
+ *      matrix-pipe time (gfx950 has no xf32/TF32).  Softmax, GroupNorm statistics, score head and losses stay f32.
+ * The training path (sola_forward_train / sola_backward) always runs exact f32. */
+int sola_set_precision(SolaCtx* ctx, int precision);
+/* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
+int sola_cast_sp16(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float scale, void* stream);
+/* C = out_scale * (A W^T) + bias (+ R) with A [M,K], W [N,K] (and optionally R) in the split-f16 format */
+int sola_gemm_nt_split(const float* dev_a_sp, int lda, const float* dev_w_sp, const float* dev_bias, const float* dev_r,
+                       int ldr, int r_is_split, float* dev_c, int ldc, int M, int N, int K, float out_scale, void* stream);
+
 /* ---- forward: replaces LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162) ------------------ */
 size_t sola_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
 int sola_forward(SolaCtx* ctx,
@@ -222,7 +235,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_GEMM_SMALL = 8, /* gemm_nt_f32_kernel<64,64> (small grids) */
        SOLA_PROF_GEMM_TN = 9,   /* gemm_tn_f32_kernel (weight gradients) */
        SOLA_PROF_ATTN_BWD = 10, /* attn_bwd_* kernels */
-       SOLA_PROF_NCAT = 11 };
+       SOLA_PROF_GEMM_SPLIT = 11, /* gemm_nt_f32_kernel<..,1>: split-f16 operands, 3 x f16 MFMA */
+       SOLA_PROF_NCAT = 12 };
 /* Kernel-schedule switches for within-process A/B measurements ("gemm_variant": 0 simple / 1 mid-tile staging;
  * "attn_variant": 0 baseline / 1 packed + q-block loop).  Results are identical across variants. */
 int sola_tune(const char* key, int value);

@@ -46,6 +46,9 @@ SIGNATURES = {
     "sola_set_weight": (_i, [_vp, C.c_char_p, _vp, _i64]),
     "sola_weights_changed": (_i, [_vp]),
     "sola_set_ws_policy": (_i, [_vp, _i]),
+    "sola_set_precision": (_i, [_vp, _i]),
+    "sola_cast_sp16": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp]),
+    "sola_gemm_nt_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sola_workspace_tap": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -85,7 +88,7 @@ SIGNATURES = {
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
 }
 
-PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64", "gemm_tn", "attn_bwd"]
+PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64", "gemm_tn", "attn_bwd", "gemm_split"]
 
 _lib = None
 

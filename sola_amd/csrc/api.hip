@@ -170,6 +170,8 @@ extern "C" int sola_ctx_create(const SolaConfig* cfg, int device, SolaCtx** out)
 extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (!c) return SOLA_OK;
     if (c->ws_buf) (void)hipFree(c->ws_buf);
+    if (c->ws16_buf) (void)hipFree(c->ws16_buf);
+    if (c->lin16_buf) (void)hipFree(c->lin16_buf);
     delete c;
     return SOLA_OK;
 }
@@ -278,8 +280,41 @@ extern "C" int sola_workspace_tap(const SolaCtx* c, const char* name, size_t* of
     return SOLA_OK;
 }
 
+extern "C" int sola_set_precision(SolaCtx* c, int precision) {
+    SOLA_ARG(c && (precision == 0 || precision == 1), "set_precision: 0 (f32) or 1 (split-f16)");
+    if (precision == 1 && !c->lin16_buf) {
+        const size_t D = c->cfg.lang_token_dim;
+        size_t ws_total = 0;
+        for (int i = 0; i < 6; ++i) ws_total += (size_t)c->conv[i].cout * c->conv[i].cin * c->conv[i].k;
+        SOLA_HIP(hipSetDevice(c->device));
+        SOLA_HIP(hipMalloc(&c->ws16_buf, ws_total * sizeof(float)));
+        SOLA_HIP(hipMalloc(&c->lin16_buf, (size_t)c->cfg.n_layers * 12 * D * D * sizeof(float)));
+    }
+    c->precision = precision;
+    c->ws_dirty = true;
+    return SOLA_OK;
+}
+
+extern "C" int sola_cast_sp16(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int K, float scale, void* stream_) {
+    return launch_cast_sp16(in, ld_in, out, ld_out, rows, K, scale, as_stream(stream_));
+}
+
+// split-f16 GEMM entry point (tests): a_sp [M,K] and w_sp [N,K] in the split format, f32 result
+extern "C" int sola_gemm_nt_split(const float* a_sp, int lda, const float* w_sp, const float* bias, const float* r, int ldr,
+                                  int r_sp16, float* cmat, int ldc, int M, int N, int K, float out_scale, void* stream_) {
+    SOLA_ARG(a_sp && w_sp && cmat, "gemm_nt_split: null argument");
+    GemmDesc gd{};
+    gd.nprob = 1;
+    gd.p[0] = GemmProblem{a_sp, w_sp, bias, r, cmat};
+    gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
+    gd.arith = 1; gd.out_scale = out_scale; gd.r_sp16 = r_sp16;
+    return launch_gemm(gd, as_stream(stream_));
+}
+
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
+    if (c && c->precision == 1)
+        return sola_forward_fast_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_));
     return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_), false);
 }
 

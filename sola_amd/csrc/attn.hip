@@ -36,8 +36,37 @@ struct AttnArgs {
     DropoutCfg drop;
     int kv_rows;      // shared: LDS rows per tile = min(64, round16(Sk))
     int qsplit;       // shared: blocks per (group, head); each handles q-blocks qs, qs + qsplit, ...
+    int o_sp16;       // write o as split-f16 pairs (cast.hip) for the 3 x f16 MFMA out-projection
     int sp_log2;      // packed: log2 of the per-unit slot count SP (SP = pow2 >= max(Sq, Sk)), units per tile = 16 >> sp_log2
 };
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// Store one query row's output tile.  op points at o[row][h*DH]; this lane holds d = 16c + 4*g4 + {0..3} of every chunk c.
+template <int NC>
+__device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[NC], float inv, int sp16) {
+    if (!sp16) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) =
+                make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        return;
+    }
+    // split-f16: an 8-wide block is held by the lane pair (g4, g4 ^ 1) = lanes l and l ^ 16
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float v0 = oacc[c][0] * inv, v1 = oacc[c][1] * inv, v2 = oacc[c][2] * inv, v3 = oacc[c][3] * inv;
+        const float n0 = __shfl_xor(v0, 16, 64), n1 = __shfl_xor(v1, 16, 64), n2 = __shfl_xor(v2, 16, 64), n3 = __shfl_xor(v3, 16, 64);
+        if ((g4 & 1) == 0) {
+            const float v[8] = {v0, v1, v2, v3, n0, n1, n2, n3};
+            half8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
+            half8* dst = reinterpret_cast<half8*>(op + 4 * g4 + c * 16);
+            dst[0] = hi; dst[1] = lo;
+        }
+    }
+}
 
 template <int DH, bool PACKED>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
@@ -152,11 +181,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
         if (q_ok) {
             if (a.lse && g4 == 0) a.lse[qrow * a.H + h] = mx + logf(rs);
             const float inv = 1.f / rs;
-            float* op = a.o + qrow * a.ldo + h * DH + 4 * g4;
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                *reinterpret_cast<float4*>(op + c * 16) =
-                    make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+            store_o<NC>(a.o + qrow * a.ldo + h * DH, g4, oacc, inv, a.o_sp16);
         }
     } else {
         // ---------------------------------------------------------------- shared: one (group, head) per block
@@ -297,11 +322,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
             if (q_ok) {
                 if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * a.q_rs) * a.H + h] = m_run + logf(l_run);
                 const float inv = 1.f / l_run;
-                float* op = a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH + 4 * g4;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    *reinterpret_cast<float4*>(op + c * 16) =
-                        make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+                store_o<NC>(a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH, g4, oacc, inv, a.o_sp16);
             }
         }
     }
@@ -373,6 +394,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.scale = d.scale;
     a.lse = d.lse;
     a.drop = d.drop;
+    a.o_sp16 = d.o_sp16;
     a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

@@ -45,6 +45,12 @@ struct SolaCtx {
     bool ws_every_forward = true;
     Plan last;                // plan of the last forward (taps, backward)
     const float* last_obj = nullptr;  // input of the last training forward (conv0's weight gradient reads it)
+    // inference precision: 0 = exact f32 MFMA; 1 = split-f16 operands, 3 x f16 MFMA with f32 accumulation (cast.hip).
+    // ctx-owned split-f16 copies of the weights: standardised conv weights (same offsets as ws_buf) and the
+    // 12 * n_layers linear weights pre-scaled by 64 (index (layer * 3 + attn) * 4 + proj, D*D floats each).
+    int precision = 0;
+    float* ws16_buf = nullptr;
+    float* lin16_buf = nullptr;
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
     // the seed used by the last sola_forward_train is kept for sola_backward
     float p_drop_encoder = 0.f, p_drop_attention = 0.f;
@@ -76,4 +82,6 @@ inline std::string abuf(bool train, int layer, const char* attn, const char* wha
 Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train);
 int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                       float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train);
+int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
+                           float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s);
 size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p);

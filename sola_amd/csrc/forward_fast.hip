@@ -1,0 +1,182 @@
+// Inference forward in the split-f16 precision mode (sola_set_precision(ctx, 1)).
+//
+// Same network, same kernels and the same single [B,N,T',D] layout as forward.hip; what changes is the arithmetic of
+// the dense contractions (98 % of the FLOPs).  f32 MFMA runs at 1/16 of the f16 MFMA rate on gfx950 and there is no
+// xf32, so every GEMM operand is kept as an (f16 hi, f16 lo) pair in the 4 bytes of the f32 it replaces and each
+// product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation (gemm.hip ARITH 1):
+// ~22-bit products, 3/16 of the matrix-pipe time, identical bytes.  The producers emit the split format directly -
+// GroupNorm epilogue, attention epilogue - so only three tensors are converted by a separate pass (the input tokens,
+// the conv5 output that layer 0 consumes, the text tokens).  Softmax, GroupNorm statistics, the score head and the
+// losses stay in f32.  Parity: the same golden-vector tests and 1e-3 bound as the f32 mode (tests/test_gpu_fast.py).
+#include <math.h>
+
+#include "ctx.h"
+
+namespace {
+constexpr float kLinScale = 64.f;  // linear weights are U(-1/32, 1/32)-sized: pre-scale so their lo halves are normal f16
+}
+
+int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
+                           float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s) {
+    SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
+    SOLA_ARG(B > 0 && N > 0 && T > 0 && L >= 1, "forward: bad sizes B=%d N=%d T=%d L=%d", B, N, T, L);
+    SOLA_ARG(c->cfg.object_token_dim % 8 == 0 && (c->cfg.lang_token_dim / c->cfg.n_groups_module) % 8 == 0 &&
+                 (2 * c->cfg.object_token_dim / c->cfg.n_groups) % 8 == 0 && (c->cfg.lang_token_dim / c->cfg.n_groups) % 8 == 0,
+             "split-f16 mode needs channel counts per GroupNorm group that are multiples of 8");
+    for (const Weight& w : c->weights)
+        if (!w.ptr) {
+            sola_set_error("forward: weight '%s' has not been set", w.name.c_str());
+            return SOLA_ERR_WEIGHT;
+        }
+    Plan p = make_plan(c, B, N, T, L, false);
+    if (ws_bytes < p.total) {
+        sola_set_error("forward: workspace %zu bytes < required %zu", ws_bytes, p.total);
+        return SOLA_ERR_WORKSPACE;
+    }
+    SOLA_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "forward: workspace must be 256-byte aligned");
+    char* base = static_cast<char*>(workspace);
+    auto buf = [&](const std::string& name) { return reinterpret_cast<float*>(base + p.bufs.at(name).off); };
+    auto W = [&](const std::string& name) { return ctx_weight(c, name); };
+    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
+    const int Tp = p.Tp, M = p.M, Wn = p.W;
+    const int R = B * N;
+    auto lin16 = [&](int layer, int attn, int proj) { return c->lin16_buf + ((size_t)(layer * 3 + attn) * 4 + proj) * D * D; };
+
+    // ---- weights: standardise the conv weights (module/ws.py:9-13) and refresh the split-f16 copies
+    if (c->ws_dirty || c->ws_every_forward) {
+        WsLayer layers[6];
+        for (int i = 0; i < 6; ++i) {
+            const std::string nm = "short_motion_encoder." + std::to_string(kConvIdx[i]) + ".weight";
+            layers[i] = WsLayer{W(nm), c->ws_buf + c->ws_off[i], c->conv[i].cout, c->conv[i].cin, c->conv[i].k};
+        }
+        SOLA_TRY(launch_ws_standardize(layers, 6, s));
+        for (int i = 0; i < 6; ++i) {
+            const int kc = c->conv[i].k * c->conv[i].cin;
+            SOLA_TRY(launch_cast_sp16(c->ws_buf + c->ws_off[i], kc, c->ws16_buf + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, s));
+        }
+        static const char* pn[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
+        for (int l = 0; l < c->cfg.n_layers; ++l)
+            for (int a = 0; a < 3; ++a)
+                for (int j = 0; j < 4; ++j) {
+                    const std::string nm = "object_lang_align_layers." + std::to_string(l) + "." + kAttnLong[a] + "." + pn[j] + ".weight";
+                    SOLA_TRY(launch_cast_sp16(W(nm), D, lin16(l, a, j), D, D, D, kLinScale, s));
+                }
+        c->ws_dirty = false;
+    }
+
+    // ---- encoder: split-f16 activations between the stages, f32 conv outputs into GroupNorm
+    SOLA_TRY(launch_cast_sp16(obj, c->cfg.object_token_dim, buf("obj_sp"), c->cfg.object_token_dim, (long long)R * T,
+                              c->cfg.object_token_dim, 1.f, s));
+    const float* x = buf("obj_sp");
+    int t_in = T;
+    for (int i = 0; i < 6; ++i) {
+        const ConvGeom& g = c->conv[i];
+        const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
+        GemmDesc gd{};
+        gd.nprob = 1;
+        gd.p[0] = GemmProblem{x, c->ws16_buf + c->ws_off[i], W(cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
+        gd.M = R * p.Tl[i]; gd.N = g.cout; gd.K = g.k * g.cin;
+        gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
+        gd.conv = g.k > 1 ? 1 : 0;
+        gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
+        gd.arith = 1; gd.out_scale = 1.f;
+        SOLA_TRY(launch_gemm(gd, s));
+        if (i < 5) {
+            const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
+            GroupNormDesc nd{};
+            nd.x = buf("conv" + std::to_string(i)); nd.y = buf("act" + std::to_string(i)); nd.y2 = nullptr; nd.pe = nullptr;
+            nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
+            nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
+            nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
+            nd.out_sp16 = 1;
+            SOLA_TRY(launch_group_norm(nd, s));
+            x = buf("act" + std::to_string(i));
+        }
+        t_in = p.Tl[i];
+    }
+    SOLA_TRY(launch_cast_sp16(buf("conv5"), D, buf("conv5_sp"), D, M, D, 1.f, s));
+
+    SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
+    SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
+    SOLA_TRY(launch_cast_sp16(buf("lang"), D, buf("lang_sp"), D, (long long)B * Wn, D, 1.f, s));
+
+    const float scale = 1.0f / sqrtf((float)DH);
+    auto linear3 = [&](const float* a0, const float* a1, const float* a2, int layer, int attn, int nprob, int rows, float* o0,
+                       float* o1, float* o2, int first_proj) -> int {
+        static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
+        const std::string an = "object_lang_align_layers." + std::to_string(layer) + "." + kAttnLong[attn];
+        const float* as[3] = {a0, a1, a2};
+        float* os[3] = {o0, o1, o2};
+        GemmDesc gd{};
+        gd.nprob = nprob;
+        for (int j = 0; j < nprob; ++j)
+            gd.p[j] = GemmProblem{as[j], lin16(layer, attn, first_proj + j), W(an + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
+        gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
+        gd.arith = 1; gd.out_scale = 1.f / kLinScale;
+        return launch_gemm(gd, s);
+    };
+    auto out_proj = [&](int layer, int attn, const float* resid, int resid_sp16) -> int {
+        const std::string an = "object_lang_align_layers." + std::to_string(layer) + "." + kAttnLong[attn];
+        GemmDesc gd{};
+        gd.nprob = 1;
+        gd.p[0] = GemmProblem{buf("attn"), lin16(layer, attn, 3), W(an + ".out_proj.bias"), resid, buf("res")};
+        gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
+        gd.arith = 1; gd.out_scale = 1.f / kLinScale; gd.r_sp16 = resid_sp16;
+        return launch_gemm(gd, s);
+    };
+    auto gn = [&](const std::string& lp, int idx, float* y, float* y2, int sp16, int n_inst, int inner, long long outer,
+                  long long inner_stride, long long tok_stride, int ntok) -> int {
+        GroupNormDesc nd{};
+        nd.x = buf("res"); nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
+        nd.gamma = W(lp + "norm." + std::to_string(idx) + ".weight");
+        nd.beta = W(lp + "norm." + std::to_string(idx) + ".bias");
+        nd.n_inst = n_inst; nd.inner = inner; nd.outer_stride = outer; nd.inner_stride = inner_stride;
+        nd.tok_stride = tok_stride; nd.ntok = ntok; nd.C = D; nd.groups = c->cfg.n_groups_module;
+        nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0; nd.out_sp16 = sp16;
+        return launch_group_norm(nd, s);
+    };
+    auto attention = [&](const float* q, const float* k, const float* v, int G, int Sq, int Sk, int inner, long long qo,
+                         long long qi, long long qr, long long ko, long long ki, long long kr) -> int {
+        AttnDesc ad{q, k, v, buf("attn"), D, D, D, D, G, H, DH, Sq, Sk, inner, qo, qi, qr, ko, ki, kr, scale, nullptr};
+        ad.o_sp16 = 1;
+        return launch_attention(ad, s);
+    };
+
+    const float* xin = buf("conv5_sp");  // split-f16 A operand of the layer
+    const float* xres = buf("conv5");    // residual of the first sub-block (f32 for layer 0, split-f16 afterwards)
+    int xres_sp = 0;
+    for (int l = 0; l < c->cfg.n_layers; ++l) {
+        const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
+        const std::string ls = "l" + std::to_string(l);
+        const bool last = l + 1 == c->cfg.n_layers;
+        float *q = buf("q"), *k = buf("k"), *v = buf("v");
+        float* x_obj = buf(ls + "_obj");
+        float* x_pe = buf(ls + "_xpe");
+        float* x_mot = buf(ls + "_motion");
+        float* x_o2l = buf(ls + "_o2l");
+        // (i) inter-object attention (module.py:31-35)
+        SOLA_TRY(linear3(xin, xin, xin, l, 0, 3, M, q, k, v, 0));
+        SOLA_TRY(attention(q, k, v, B * Tp, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp));
+        SOLA_TRY(out_proj(l, 0, xres, xres_sp));
+        SOLA_TRY(gn(lp, 0, x_obj, x_pe, 1, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
+        // (ii) motion attention (module.py:38-43)
+        SOLA_TRY(linear3(x_pe, x_pe, x_obj, l, 1, 3, M, q, k, v, 0));
+        SOLA_TRY(attention(q, k, v, B * N, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1));
+        SOLA_TRY(out_proj(l, 1, x_obj, 1));
+        SOLA_TRY(gn(lp, 1, x_mot, nullptr, 1, B * N, 1, Tp, 0, 1, Tp));
+        // (iii) object -> language attention (module.py:46-50)
+        SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0));
+        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1));
+        SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1));
+        SOLA_TRY(out_proj(l, 2, x_mot, 1));
+        SOLA_TRY(gn(lp, 2, x_o2l, nullptr, last ? 0 : 1, B, 1, (long long)N * Tp, 0, 1, N * Tp));  // the score head reads f32
+        xin = x_o2l;
+        xres = x_o2l;
+        xres_sp = 1;
+    }
+    HeadDesc hd{xin, buf("lbar"), score_map, score_tokens, B, N, Tp, D};
+    SOLA_TRY(launch_score_head(hd, s));
+    c->last = p;
+    c->last_obj = nullptr;
+    return SOLA_OK;
+}

@@ -21,12 +21,22 @@ struct GemmArgs {
     int M, N, K, lda, ldr, ldc;
     int conv, T_in, T_out, stride, pad, Cin;
     int tiles_m, tiles_n, xcd_remap;
+    float out_scale;  // result multiplier (power of two undoing the weight pre-scale of the split-f16 path)
+    int r_sp16;       // residual R is stored as split-f16 pairs
 };
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats (144 B: 16-byte aligned, conflict-free for b128 fragment reads)
 
-template <int BM, int BN, int PIPE>
+// ARITH 0: operands are f32, v_mfma_f32_32x32x2_f32 (exact).
+// ARITH 1: operands are "split-f16" rows - every 8 consecutive f32 values x are stored in the same 32 bytes as
+//          [8 x f16 hi | 8 x f16 lo] with hi = f16(x), lo = f16(x - hi) - and each product runs as three
+//          v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, f32 accumulate): ~22-bit products at 3/16 of the f32 MFMA
+//          cost.  Bytes per element, tile staging and LDS layout are identical to ARITH 0 (a k16 MFMA step consumes
+//          two 32-byte blocks; lanes 0-31 take the first, lanes 32-63 the second - exactly the MFMA A/B fragment).
+template <int BM, int BN, int PIPE, int ARITH>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte loads per thread per operand per k-tile
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
@@ -147,6 +157,35 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     const int nk = (a.K + BK - 1) / BK;
 
     auto compute = [&](int buf, int ks_begin, int ks_end) {
+        if constexpr (ARITH == 1) {
+            const char* Ab = reinterpret_cast<const char*>(&As[(buf * BM + wr * (BM / 2) + frag_row) * LDP]) + (lane >> 5) * 32;
+            const char* Wb = reinterpret_cast<const char*>(&Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP]) + (lane >> 5) * 32;
+#pragma unroll
+            for (int s16 = ks_begin / 2; s16 < ks_end / 2; ++s16) {
+                half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const char* p = Ab + i * 32 * LDP * 4 + s16 * 64;
+                    ah[i] = *reinterpret_cast<const half8*>(p);
+                    al[i] = *reinterpret_cast<const half8*>(p + 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const char* p = Wb + j * 32 * LDP * 4 + s16 * 64;
+                    bh[j] = *reinterpret_cast<const half8*>(p);
+                    bl[j] = *reinterpret_cast<const half8*>(p + 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         const float* Ab = &As[(buf * BM + wr * (BM / 2) + frag_row) * LDP + frag_k];
         const float* Wb = &Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP + frag_k];
 #pragma unroll
@@ -214,8 +253,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                 if (m < a.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (pr.R) v += pr.R[(long long)m * a.ldr + n];
+                    float v = acc[i][j][r] * a.out_scale + bv;
+                    if (pr.R) {
+                        if (a.r_sp16) {  // residual kept as split-f16 pairs: element n sits in block n/8 as hi[n%8], lo[n%8]
+                            const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7));
+                            v += (float)rb[n & 7] + (float)rb[8 + (n & 7)];
+                        } else {
+                            v += pr.R[(long long)m * a.ldr + n];
+                        }
+                    }
                     pr.C[(long long)m * a.ldc + n] = v;
                 }
             }
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int PIPE>
+template <int BM, int BN, int PIPE, int ARITH>
 int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     GemmArgs a = base;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -232,12 +278,12 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     constexpr size_t lds = (size_t)(BM + BN) * 2 * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN, PIPE>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, nprob);
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>), grid, dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -261,11 +307,18 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.tiles_m = a.tiles_n = a.xcd_remap = 0;
+    a.out_scale = d.arith == 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
+    a.r_sp16 = d.r_sp16;
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
-    SolaProfScope prof(big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
+    SolaProfScope prof(d.arith == 1 ? SOLA_PROF_GEMM_SPLIT : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL), s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
     const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
-    if (big) return pipe ? launch_tile<128, 128, 1>(a, d.nprob, s) : launch_tile<128, 128, 0>(a, d.nprob, s);
-    return pipe ? launch_tile<64, 64, 1>(a, d.nprob, s) : launch_tile<64, 64, 0>(a, d.nprob, s);
+    if (d.arith == 1) {
+        SOLA_ARG(d.K % 16 == 0 && (d.conv ? d.Cin % 8 == 0 : d.lda % 8 == 0), "split-f16 gemm: K %% 16 and row pitch %% 8 required");
+        if (big) return pipe ? launch_tile<128, 128, 1, 1>(a, d.nprob, s) : launch_tile<128, 128, 0, 1>(a, d.nprob, s);
+        return pipe ? launch_tile<64, 64, 1, 1>(a, d.nprob, s) : launch_tile<64, 64, 0, 1>(a, d.nprob, s);
+    }
+    if (big) return pipe ? launch_tile<128, 128, 1, 0>(a, d.nprob, s) : launch_tile<128, 128, 0, 0>(a, d.nprob, s);
+    return pipe ? launch_tile<64, 64, 1, 0>(a, d.nprob, s) : launch_tile<64, 64, 0, 0>(a, d.nprob, s);
 }

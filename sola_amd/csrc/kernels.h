@@ -16,8 +16,11 @@ struct GemmDesc {
     int M, N, K;
     int lda, ldr, ldc;  // ldw == K
     // implicit im2col for the k=3 channels-last conv: row m = (r, t_out); k = kk*Cin + ci
-    int conv;  // 0: plain; 1: gather window
+    int conv;  // 0: plain; 1: gather window; 2: transposed-conv gather
     int T_in, T_out, stride, pad, Cin;
+    int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate)
+    float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
+    int r_sp16;       // arith 1: the residual R is split-f16
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 
@@ -50,6 +53,7 @@ struct AttnDesc {
     float scale;
     float* lse;  // optional [q rows][H]
     DropoutCfg drop;  // on the probabilities (tools/attention.py:71)
+    int o_sp16;       // output as split-f16 pairs
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 
@@ -139,8 +143,10 @@ struct GroupNormDesc {
     float eps, slope;
     int leaky;
     DropoutCfg drop;
+    int out_sp16;  // y / y2 written as split-f16 pairs
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
+int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
 int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
 int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,

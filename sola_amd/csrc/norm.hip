@@ -72,7 +72,10 @@ struct GnArgs {
     float eps, slope;
     int leaky;
     DropoutCfg drop;  // applied after the LeakyReLU (module/module.py:78)
+    int out_sp16;     // write y / y2 as split-f16 pairs (cast.hip) instead of f32
 };
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     __shared__ float red[4];
@@ -128,6 +131,28 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
             o.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? o.y * a.drop.scale : 0.f;
             o.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? o.z * a.drop.scale : 0.f;
             o.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? o.w * a.drop.scale : 0.f;
+        }
+        if (a.out_sp16) {
+            // split-f16 output for the 3 x f16 MFMA GEMMs: lanes c4 and c4^1 hold the two halves of an 8-channel block
+            const float4 o2 = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+            const float4 n = make_float4(__shfl_xor(o.x, 1, 64), __shfl_xor(o.y, 1, 64), __shfl_xor(o.z, 1, 64), __shfl_xor(o.w, 1, 64));
+            const float4 n2 = make_float4(__shfl_xor(o2.x, 1, 64), __shfl_xor(o2.y, 1, 64), __shfl_xor(o2.z, 1, 64), __shfl_xor(o2.w, 1, 64));
+            if ((c4 & 1) == 0) {
+                const float v[8] = {o.x, o.y, o.z, o.w, n.x, n.y, n.z, n.w};
+                half8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
+                half8* dst = reinterpret_cast<half8*>(a.y + off);
+                dst[0] = hi; dst[1] = lo;
+                if (a.y2) {
+                    const float w[8] = {o2.x, o2.y, o2.z, o2.w, n2.x, n2.y, n2.z, n2.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)w[j]; lo[j] = (_Float16)(w[j] - (float)hi[j]); }
+                    half8* dst2 = reinterpret_cast<half8*>(a.y2 + off);
+                    dst2[0] = hi; dst2[1] = lo;
+                }
+            }
+            continue;
         }
         *reinterpret_cast<float4*>(a.y + off) = o;
         if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
@@ -196,7 +221,8 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     GnArgs a;
     a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16;
+    SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);
     hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);

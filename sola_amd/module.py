@@ -85,6 +85,10 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._last_shape = None
         self.ws_policy = "auto"
         self.attention_dropout_p = 0.1  # tools/attention.py:12 (hard-coded in the reference)
+        # inference arithmetic of the convs / projections: "f32" (exact f32 MFMA) or "f16x3" (split-f16 operands, three
+        # f16 MFMAs per product with f32 accumulation, ~22-bit products); training always runs exact f32
+        self.precision = "f32"
+        self._ctx_precision = None
         self._train_ws = None
         self._bwd_ws = None
         self._train_inputs = None
@@ -105,6 +109,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         check(lib().sola_ctx_create(C.byref(cfg), device.index if device.index is not None else torch.cuda.current_device(),
                                     C.byref(handle)), "sola_ctx_create")
         self._ctx, self._ctx_device, self._bound = handle, device, {}
+        self._ctx_precision = None
 
     def _release_ctx(self):
         if getattr(self, "_ctx", None) is not None:
@@ -139,6 +144,11 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # weight changes; "always" / "cached" force either behaviour (bench.py uses "always")
         every = self.training if self.ws_policy == "auto" else self.ws_policy == "always"
         check(lib().sola_set_ws_policy(self._ctx, 1 if every else 0), "sola_set_ws_policy")
+        if self.precision not in ("f32", "f16x3"):
+            raise SolaError(f"precision must be 'f32' or 'f16x3', got {self.precision!r}")
+        if self._ctx_precision != self.precision:
+            check(lib().sola_set_precision(self._ctx, 1 if self.precision == "f16x3" else 0), "sola_set_precision")
+            self._ctx_precision = self.precision
 
     def _get_workspace(self, nbytes, device):
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:

@@ -48,6 +48,37 @@ def gemm_nt(a, w, bias=None, residual=None):
     return out
 
 
+def cast_sp16(x, scale=1.0):
+    """f32 [rows, K] -> split-f16 rows (a float32-typed container of the same shape holding [8 x f16 hi | 8 x f16 lo]
+    per 8 values, hi + lo = scale * x to 22 bits).  ``scale`` must be a power of two."""
+    require_cuda(x)
+    x = _f32c(x)
+    rows, K = x.shape
+    out = torch.empty_like(x)
+    check(lib().sola_cast_sp16(ptr(x), K, ptr(out), K, rows, K, float(scale), current_stream(x.device)), "sola_cast_sp16")
+    return out
+
+
+def decode_sp16(x_sp):
+    """Inverse of ``cast_sp16`` (host-side view arithmetic, for tests): returns hi + lo as float32."""
+    rows, K = x_sp.shape
+    h = x_sp.contiguous().view(torch.float16).reshape(rows, K // 8, 2, 8).to(torch.float32)
+    return (h[:, :, 0, :] + h[:, :, 1, :]).reshape(rows, K)
+
+
+def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False, out_scale=1.0):
+    """out_scale * (A W^T) + bias (+ residual) on split-f16 operands (three f16 MFMAs per product, f32 accumulate)."""
+    require_cuda(a_sp, w_sp, bias, residual)
+    a_sp, w_sp = _f32c(a_sp), _f32c(w_sp)
+    M, K = a_sp.shape
+    N = w_sp.shape[0]
+    out = torch.empty((M, N), device=a_sp.device, dtype=torch.float32)
+    check(lib().sola_gemm_nt_split(ptr(a_sp), K, ptr(w_sp), ptr(None if bias is None else _f32c(bias)),
+                                   ptr(None if residual is None else _f32c(residual)), N, 1 if residual_is_split else 0,
+                                   ptr(out), N, M, N, K, float(out_scale), current_stream(a_sp.device)), "sola_gemm_nt_split")
+    return out
+
+
 def conv1d_cl(x, w_std, bias, k, stride, pad):
     """Channels-last conv along T (module/ws.py:14-22): x [R,T,cin], w_std [cout,k*cin] -> [R,T_out,cout]."""
     require_cuda(x, w_std, bias)
