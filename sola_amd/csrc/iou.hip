@@ -41,9 +41,13 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const PackArgs a) {
                 const uint4 v = *reinterpret_cast<const uint4*>(src + p0);
                 const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bits |= (((wv[j] >> (8 * i)) & 0xffu) != 0u ? 1u : 0u) << (4 * j + i);
+                for (int j = 0; j < 4; ++j) {
+                    // word-parallel "byte != 0" -> one bit per byte: high bit of each non-zero byte, moved to bit 0 of its
+                    // byte, then the four byte flags are gathered into a nibble by one multiply (no carries reach bits 24-27)
+                    const unsigned w = wv[j];
+                    const unsigned nz = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u) >> 7;
+                    bits |= ((nz * 0x01020408u) >> 24 & 0xfu) << (4 * j);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -74,6 +78,53 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const PackArgs a) {
         if (word < a.words) a.bits[(long long)n * a.words + word] = bits | (other << 16);
     }
     int cnt = __popc(bits);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = red[0] + red[1] + red[2] + red[3];
+        if (tot) atomicAdd(&a.area[n], (unsigned long long)tot);
+    }
+}
+
+// Streaming fast path for the common case (uint8 masks already at the comparison resolution, 32-byte aligned rows of
+// H*W % 32 == 0 pixels): a lane packs one whole 32-bit word from 32 bytes, four words per lane with all eight 16-byte
+// loads in flight before the first use, one area atomic per 32 KiB of mask.
+__device__ __forceinline__ unsigned pack16(const uint4 v) {
+    const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned w = wv[j];
+        const unsigned nz = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u) >> 7;
+        bits |= ((nz * 0x01020408u) >> 24 & 0xfu) << (4 * j);
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void mask_pack_u8_stream_kernel(const PackArgs a) {
+    __shared__ int red[4];
+    constexpr int IT = 4;
+    const int n = blockIdx.y;
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.src) + (long long)n * a.hw_src);
+    const long long w0 = (long long)blockIdx.x * (256 * IT) + threadIdx.x;
+    uint4 lo[IT], hi[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const long long w = w0 + it * 256;
+        const bool ok = w < a.words;
+        lo[it] = ok ? src[2 * w] : make_uint4(0u, 0u, 0u, 0u);
+        hi[it] = ok ? src[2 * w + 1] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const long long w = w0 + it * 256;
+        const unsigned word = pack16(lo[it]) | (pack16(hi[it]) << 16);
+        if (w < a.words) a.bits[(long long)n * a.words + w] = word;
+        cnt += __popc(word);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -162,7 +213,9 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
     const unsigned blocks = (unsigned)((runs + 255) / 256);
     const double src_bytes = (double)n * h * w * (elem_type ? 4 : 1);
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, src_bytes + (double)n * a.words * 4);
-    if (elem_type == 0)
+    if (elem_type == 0 && a.identity && a.HW % 32 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0)
+        hipLaunchKernelGGL(mask_pack_u8_stream_kernel, dim3((unsigned)((a.words + 1023) / 1024), n), dim3(256), 0, s, a);
+    else if (elem_type == 0)
         hipLaunchKernelGGL(mask_pack_kernel<uint8_t>, dim3(blocks, n), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(mask_pack_kernel<float>, dim3(blocks, n), dim3(256), 0, s, a);
