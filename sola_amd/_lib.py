@@ -98,6 +98,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be the HIP runtime of the process (it owns the device memory and streams
+    # handed to the library), so it is loaded before libsola_hip.so resolves its HIP symbols.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise SolaLibraryError(
             f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
