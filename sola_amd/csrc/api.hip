@@ -210,6 +210,7 @@ extern "C" int sola_set_weight(SolaCtx* c, const char* name, const void* dev_ptr
     SOLA_TRY(find_weight(c, "set_weight", name, dev_ptr, numel, &w));
     w->ptr = static_cast<const float*>(dev_ptr);
     c->ws_dirty = true;
+    c->lin16_dirty = true;
     return SOLA_OK;
 }
 
@@ -223,6 +224,7 @@ extern "C" int sola_set_grad(SolaCtx* c, const char* name, void* dev_ptr, int64_
 extern "C" int sola_weights_changed(SolaCtx* c) {
     SOLA_ARG(c, "weights_changed: null ctx");
     c->ws_dirty = true;
+    c->lin16_dirty = true;
     return SOLA_OK;
 }
 
@@ -243,11 +245,13 @@ extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
 }
 
 void sola_gemm_set_variant(int v);
+void sola_gemm_set_glds(int v);
 void sola_attn_set_variant(int v);
 void sola_attn_set_target_blocks(int v);
 extern "C" int sola_tune(const char* key, int value) {
     SOLA_ARG(key, "tune: null key");
     if (!strcmp(key, "gemm_variant")) { sola_gemm_set_variant(value); return SOLA_OK; }
+    if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
     if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
     sola_set_error("tune: unknown key '%s'", key);
@@ -292,6 +296,7 @@ extern "C" int sola_set_precision(SolaCtx* c, int precision) {
     }
     c->precision = precision;
     c->ws_dirty = true;
+    c->lin16_dirty = true;
     return SOLA_OK;
 }
 

@@ -49,6 +49,7 @@ struct SolaCtx {
     // ctx-owned split-f16 copies of the weights: standardised conv weights (same offsets as ws_buf) and the
     // 12 * n_layers linear weights pre-scaled by 64 (index (layer * 3 + attn) * 4 + proj, D*D floats each).
     int precision = 0;
+    bool lin16_dirty = true;  // split copies of the projection weights are stale
     float* ws16_buf = nullptr;
     float* lin16_buf = nullptr;
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);

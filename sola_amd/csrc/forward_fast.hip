@@ -54,6 +54,11 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
             const int kc = c->conv[i].k * c->conv[i].cin;
             SOLA_TRY(launch_cast_sp16(c->ws_buf + c->ws_off[i], kc, c->ws16_buf + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, s));
         }
+        c->ws_dirty = false;
+    }
+    // The projection weights are used as they are by the reference (no per-forward transform), so their split copies
+    // are refreshed only when a weight pointer or value changed (sola_set_weight / sola_weights_changed).
+    if (c->lin16_dirty) {
         static const char* pn[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
         for (int l = 0; l < c->cfg.n_layers; ++l)
             for (int a = 0; a < 3; ++a)
@@ -61,7 +66,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
                     const std::string nm = "object_lang_align_layers." + std::to_string(l) + "." + kAttnLong[a] + "." + pn[j] + ".weight";
                     SOLA_TRY(launch_cast_sp16(W(nm), D, lin16(l, a, j), D, D, D, kLinScale, s));
                 }
-        c->ws_dirty = false;
+        c->lin16_dirty = false;
     }
 
     // ---- encoder: split-f16 activations between the stages, f32 conv outputs into GroupNorm

@@ -292,7 +292,11 @@ int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 
 
 }  // namespace
 
+int g_gemm_glds = 1;  // split-f16 GEMM: direct-to-LDS staging (gemm_glds.hip) when the shape allows
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
+void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
+bool gemm_split_glds_supported(const GemmDesc& d);
+int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s);
 
 int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3, "gemm: nprob %d", d.nprob);
@@ -314,6 +318,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SolaProfScope prof(d.arith == 1 ? SOLA_PROF_GEMM_SPLIT : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL), s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
     const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
+    if (d.arith == 1 && big && g_gemm_glds && gemm_split_glds_supported(d)) return launch_gemm_split_glds(d, s);
     if (d.arith == 1) {
         SOLA_ARG(d.K % 16 == 0 && (d.conv ? d.Cin % 8 == 0 : d.lda % 8 == 0), "split-f16 gemm: K %% 16 and row pitch %% 8 required");
         if (big) return pipe ? launch_tile<128, 128, 1, 1>(a, d.nprob, s) : launch_tile<128, 128, 0, 1>(a, d.nprob, s);
