@@ -225,6 +225,21 @@ def main():
                          "unit": "GB/s", "frac": round(a_gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
                          "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 2)}
         kernels_ms = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
+        # HBM traffic cannot be read from inside the run (PMC needs rocprofv3); it is the committed per-launch PMC
+        # measurement of this same command line (tools/profile_bench.sh -> profiles/r01_traffic.json), used only when the
+        # batch matches the profiled one, else null
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            tr = json.load(open(tpath))
+            if tr.get("batch") == B and (N, T, L) == (64, 32, 16):
+                kk = tr["kernels"]
+                gk = "gemm_nt_split_glds_kernel" if args.precision == "f16x3" else "gemm_nt_f32_kernel<128, 128, 0, 0>"
+                if gk in kk:
+                    roofline["traffic"] = kk[gk]["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = tr["source"]
+                ak = [kk[k]["hbm_bytes_per_launch"] for k in ("attn_fwd_f32_kernel<128, false>", "attn_fwd_f32_kernel<128, true>") if k in kk]
+                if len(ak) == 2:
+                    roofline_attn["traffic"] = int((2 * ak[0] + ak[1]) / 3)  # obj + o2l (shared K/V) and motion (packed) launches
         out = {
             "metric": "track-selection forward+loss samples/sec at (T=32,N=64,d=256)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
