@@ -223,6 +223,28 @@ size_t sola_mask_iou_scratch_bytes(int P, int R, int H, int W);
 int sola_mask_iou_matrix(const void* dev_a, const void* dev_b, int elem_type, int P, int R, int H, int W, int h, int w,
                          int64_t* dev_inter, int64_t* dev_union, void* dev_scratch, size_t scratch_bytes, void* stream);
 
+/* ---- masklet resampling / decoding on the same packed representation ----------------------
+ * sola_mask_bilinear_pack replaces track_generation/seg_utils.py:145-160 (reshape_masklet): bilinear resample
+ * (align_corners=False, ATen's source-index rule) of n {0,1} masks [n,h,w] to H x W, `> 0.5`, bit-pack, area.
+ * elem_type 0 = uint8 (non-zero counts as 1.0), 1 = float32 (any values; the fp32 arithmetic order is ATen's),
+ * 2 = float32 tracker logits, binarised as (v > 0) while reading — the `(out_mask_logits > 0.0).float()` of
+ * generate_tokens_grid.py:215-222 folded in.  W <= 8192. */
+int sola_mask_bilinear_pack(const void* dev_masks, int elem_type, int n, int h, int w, int H, int W,
+                            uint32_t* dev_bits, int64_t* dev_area, void* stream);
+/* packed bits -> {0,1} images [n,H,W] (elem_type 0 = uint8, 1 = float32): the tensor reshape_masklet returns. */
+int sola_mask_unpack(const uint32_t* dev_bits, int n, int H, int W, void* dev_out, int elem_type, void* stream);
+/* COCO run-length masks -> OR of K masks per frame, replaces dataloader.py:305-369 (rle_masklet_decode + np.logical_or
+ * in get_sam2_masklet / get_gt_masklet).  Mask (frame f, slot k) owns the runs dev_off[f*K+k] .. dev_off[f*K+k+1] of
+ * dev_cum, the inclusive prefix sums of its run lengths (uint32, column-major positions as in pycocotools); an empty
+ * range is an absent / unselected mask.  dev_out [n_frames,h,w] uint8 row-major and/or dev_bits + dev_area. */
+int sola_rle_fill_or(const uint32_t* dev_cum, const int64_t* dev_off, int n_frames, int K, int h, int w,
+                     uint8_t* dev_out, uint32_t* dev_bits, int64_t* dev_area, void* stream);
+
+/* Host-only helper: COCO compressed RLE string (pycocotools rleFrString format) -> inclusive prefix sums of its run
+ * lengths in host_cum[0..cap).  Returns the number of runs, or a negative status (malformed string, more than cap runs,
+ * or runs covering more than `limit` pixels; limit < 0 disables that check). */
+int64_t sola_rle_string_to_cum(const char* str, int64_t len, uint32_t* host_cum, int64_t cap, int64_t limit);
+
 /* ---- in-library kernel timing (HIP events on the launch stream; used by bench.py's roofline object) ------------ */
 enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_ATTN = 1,      /* attn_fwd_f32_kernel */

@@ -78,6 +78,10 @@ SIGNATURES = {
     "sola_mask_words": (_i64, [_i, _i]),
     "sola_mask_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sola_mask_pair_counts": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "sola_mask_bilinear_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sola_mask_unpack": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "sola_rle_fill_or": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sola_rle_string_to_cum": (_i64, [C.c_char_p, _i64, _vp, _i64, _i64]),
     "sola_mask_iou_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "sola_mask_iou_matrix": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sola_grad_sqnorms_scratch_bytes": (_sz, [_i, _vp]),

@@ -565,6 +565,68 @@ extern "C" int sola_mask_pair_counts(const uint32_t* a_bits, const int64_t* a_ar
                             reinterpret_cast<long long*>(inter), reinterpret_cast<long long*>(uni), as_stream(stream_));
 }
 
+extern "C" int sola_mask_bilinear_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
+                                       int64_t* area, void* stream_) {
+    SOLA_ARG(masks && bits && area, "mask_bilinear_pack: null argument");
+    return launch_mask_bilinear_pack(masks, elem_type, n, h, w, H, W, bits, reinterpret_cast<long long*>(area), as_stream(stream_));
+}
+
+extern "C" int sola_mask_unpack(const uint32_t* bits, int n, int H, int W, void* out, int elem_type, void* stream_) {
+    SOLA_ARG(bits && out, "mask_unpack: null argument");
+    return launch_mask_unpack(bits, n, H, W, out, elem_type, as_stream(stream_));
+}
+
+extern "C" int sola_rle_fill_or(const uint32_t* cum, const int64_t* off, int n_frames, int K, int h, int w, uint8_t* out,
+                                uint32_t* bits, int64_t* area, void* stream_) {
+    SOLA_ARG(off, "rle_fill_or: null offsets");
+    return launch_rle_fill_or(cum, reinterpret_cast<const long long*>(off), n_frames, K, h, w, out, bits,
+                              reinterpret_cast<long long*>(area), as_stream(stream_));
+}
+
+// Host helper (no GPU work): COCO compressed run-length string -> inclusive prefix sums of the run lengths, the form
+// sola_rle_fill_or consumes.  pycocotools rleFrString: 5 data bits + continuation bit per char (offset 48), sign
+// extension from bit 4 of the last char, runs from the 4th on stored as a delta to the run two places back.
+extern "C" int64_t sola_rle_string_to_cum(const char* str, int64_t len, uint32_t* cum, int64_t cap, int64_t limit) {
+    if (!str || !cum || len < 0 || cap < 0) {
+        sola_set_error("rle_string_to_cum: bad arguments");
+        return SOLA_ERR_ARG;
+    }
+    int64_t n = 0, p = 0;
+    long long prev1 = 0, prev2 = 0;  // counts[n-1], counts[n-2]
+    unsigned long long sum = 0;
+    while (p < len) {
+        long long x = 0;
+        int k = 0;
+        bool more = true;
+        while (more) {
+            if (p >= len || k > 12) {
+                sola_set_error("rle_string_to_cum: truncated or over-long run at char %lld", (long long)p);
+                return SOLA_ERR_ARG;
+            }
+            const long long c = (long long)(unsigned char)str[p] - 48;
+            x |= (c & 0x1f) << (5 * k);
+            more = (c & 0x20) != 0;
+            ++p;
+            ++k;
+            if (!more && (c & 0x10)) x |= -1ll << (5 * k);
+        }
+        if (n > 2) x += prev2;
+        if (x < 0 || n >= cap) {
+            sola_set_error(x < 0 ? "rle_string_to_cum: negative run length" : "rle_string_to_cum: more runs than the output holds");
+            return SOLA_ERR_ARG;
+        }
+        sum += (unsigned long long)x;
+        if (limit >= 0 && sum > (unsigned long long)limit) {
+            sola_set_error("rle_string_to_cum: runs cover %llu pixels, image has %lld", sum, (long long)limit);
+            return SOLA_ERR_ARG;
+        }
+        cum[n++] = (uint32_t)sum;
+        prev2 = prev1;
+        prev1 = x;
+    }
+    return n;
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" size_t sola_mask_iou_scratch_bytes(int P, int R, int H, int W) {

@@ -179,3 +179,10 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
 int launch_mask_pair(const uint32_t* a_bits, const long long* a_area, int P, int T, const uint32_t* b_bits,
                      const long long* b_area, int R, const int32_t* a_frame, long long words, long long* inter,
                      long long* uni, hipStream_t s);
+
+// ---- masklet resampling / decoding (masklet.hip) -----------------------------------------------------------------
+int launch_mask_bilinear_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
+                              long long* area, hipStream_t s);
+int launch_mask_unpack(const uint32_t* bits, int n, int H, int W, void* out, int elem_type, hipStream_t s);
+int launch_rle_fill_or(const uint32_t* cum, const long long* off, int n_frames, int K, int h, int w, uint8_t* out,
+                       uint32_t* bits, long long* area, hipStream_t s);

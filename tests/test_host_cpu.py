@@ -81,3 +81,26 @@ def test_synth_is_deterministic_and_shaped():
     fl = synth.flops_per_sample(synth.DEFAULT_MODEL_CFG, 64, 32, 16)
     assert abs(fl["total"] / 1e9 - 16.381) < 0.01
     assert abs(synth.attn_bytes_per_sample(synth.DEFAULT_MODEL_CFG, 64, 32, 16) / 1e6 - 21.76) < 0.01
+
+
+def test_rle_string_parser_host_helper_matches_oracle():
+    """sola_rle_string_to_cum is pure host code (no GPU): prefix sums of the runs of a COCO compressed RLE string."""
+    import ctypes
+
+    from oracle import masklet_oracle as mo
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    cases = [[0, 4], [5, 40, 3, 2, 100000, 1, 7], [1000, 3, 2, 1, 900, 2, 1], [0, 1, 0, 1], []]
+    cases += [rng.integers(0, 5000, size=int(rng.integers(1, 200))).tolist() for _ in range(20)]
+    for counts in cases:
+        s = mo.rle_counts_to_string(counts).encode()
+        assert mo.rle_string_to_counts(s) == counts
+        buf = np.zeros(max(1, len(s)), np.uint32)
+        n = L.sola_rle_string_to_cum(s, len(s), ctypes.c_void_p(buf.ctypes.data), len(buf), -1)
+        assert n == len(counts)
+        np.testing.assert_array_equal(buf[:n], np.cumsum(np.asarray(counts, np.int64)).astype(np.uint32))
+    buf = np.zeros(4, np.uint32)
+    p = ctypes.c_void_p(buf.ctypes.data)
+    assert L.sola_rle_string_to_cum(b"1o", 2, p, 4, -1) < 0 and b"truncated" in L.sola_last_error()
+    assert L.sola_rle_string_to_cum(b"11111", 5, p, 4, -1) < 0  # more runs than the buffer holds
+    assert L.sola_rle_string_to_cum(b"99", 2, p, 4, 10) < 0 and b"cover" in L.sola_last_error()  # 18 pixels > 10
