@@ -47,7 +47,7 @@ def inference(cfg):
             if hasattr(dataset, "merged_masklet"):
                 from PIL import Image
 
-                masklet = dataset.merged_masklet(vid, eid, pred[b])
+                masklet = dataset.merged_masklet(vid, eid, pred[b], device=device).cpu().numpy()  # RLE decode + OR on the GPU
                 os.makedirs(os.path.join(out_dir, vid, eid), exist_ok=True)
                 for frame_id, mask in zip(batch["frames"][b], masklet):
                     Image.fromarray((np.asarray(mask) * 255).astype(np.uint8)).save(os.path.join(out_dir, vid, eid, f"{frame_id}.png"))

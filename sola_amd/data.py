@@ -141,21 +141,30 @@ class TrackDataset(torch.utils.data.Dataset):
         return {**s, "object_tokens": torch.stack(tokens, 0), "labels": {"iou": torch.tensor(iou)} if has_gt else None,
                 "root_type": root_type, "prompt_type": prompt_type, "sam2_anno_id": sam2_ids, "gt_anno_id": gt_ids}
 
-    def merged_masklet(self, video_id, expression_id, preds):
-        """OR of the RLE-decoded masklets of the selected tracks (dataloader.py:305-351)."""
-        merged, i = None, 0
+    def merged_masklet(self, video_id, expression_id, preds, device=None):
+        """OR of the RLE-decoded masklets of the selected tracks (dataloader.py:305-351).  With ``device`` the run
+        lengths of all selected tracks are decoded and OR-ed in one launch (seg_utils.rle_merge_or) and the result is a
+        uint8 CUDA tensor; without it the host decoder is used (numpy array)."""
+        merged, i, selected = None, 0, []
         for root in self.roots:
             mdir, _ = self._dirs(root, video_id, expression_id)
             for name in sorted(os.listdir(mdir)):
                 with open(os.path.join(mdir, name), "r") as f:
                     info = json.load(f)
-                if preds[i] > 0:
+                if preds[i] > 0 and device is not None:
+                    selected.append(info["rle"])
+                elif preds[i] > 0:
                     m = masklet_decode(info["rle"])
                     merged = m if merged is None else np.logical_or(merged, m)
                 elif merged is None:
                     h, w = info["rle"][0]["size"]
                     merged = np.zeros((len(info["rle"]), h, w), dtype=np.uint8)
                 i += 1
+        if selected:
+            from . import seg_utils
+            return seg_utils.rle_merge_or(selected, device)
+        if merged is not None and device is not None:
+            return torch.from_numpy(np.ascontiguousarray(merged, dtype=np.uint8)).to(device)
         return merged
 
 

@@ -201,3 +201,30 @@ def test_dedup_with_fused_reshape_matches_two_step(su):
         assert a["status"] == b["status"] == c["status"]
         assert a.get("filtered_by") == b.get("filtered_by") == c.get("filtered_by")
         assert a.get("filtered_iou") == b.get("filtered_iou") == c.get("filtered_iou")
+
+
+def test_dataset_merged_masklet_on_device_matches_host_decoder(su, tmp_path):
+    """dataloader.py:305-351 through TrackDataset: the GPU decode+OR equals the host decoder for every selection,
+    including "nothing selected" (zeros) and compressed-string RLEs."""
+    import json
+
+    from sola_amd import data as sdata
+    data_root, track_root = tmp_path / "data", tmp_path / "tracks"
+    os.makedirs(data_root / "mevis" / "valid_u")
+    meta = {"videos": {"vidA": {"frames": ["00000", "00001", "00002"], "expressions": {"0": {"exp": "a cat", "anno_id": [3]}}}}}
+    json.dump(meta, open(data_root / "mevis" / "valid_u" / "meta_expressions.json", "w"))
+    mdir = track_root / "grid_tracks" / "mevis" / "valid_u" / "sam2_masklets" / "vidA"
+    tdir = track_root / "grid_tracks" / "mevis" / "valid_u" / "sam2_object_tokens" / "vidA"
+    os.makedirs(mdir), os.makedirs(tdir)
+    for aid in (2, 5, 11):
+        frames = mc.blob_masklet(3, 40, 64, aid)
+        rle = [{"size": [40, 64], "counts": mo.rle_counts_to_string(mo.mask_to_counts(f))} for f in frames]
+        json.dump({"anno_id": aid, "prompt_type": "X", "rle": rle}, open(mdir / f"{aid:05d}.json", "w"))
+        np.save(tdir / f"{aid:05d}.npy", np.zeros((3, 256), np.float32))
+    split = {"data_name": "mevis", "data_type": "valid_u", "sam2_output_dirs": "grid_tracks", "batch_size": 1}
+    ds = sdata.TrackDataset(split, str(data_root), str(track_root))
+    for preds in ([1, 0, 1], [0, 1, 0], [1, 1, 1], [0, 0, 0]):
+        host = ds.merged_masklet("vidA", "0", np.array(preds))
+        devm = ds.merged_masklet("vidA", "0", np.array(preds), device="cuda")
+        assert devm.is_cuda and devm.dtype == torch.uint8
+        np.testing.assert_array_equal(devm.cpu().numpy() != 0, np.asarray(host) != 0)
