@@ -204,8 +204,9 @@ def main():
             # against the dense f16 MFMA peak with the work it actually executes (3 x 2MNK); the algorithmic rate is kept
             g = prof["gemm_split"]
             alg = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            roofline = {"kernel": "gemm_nt_split_glds_kernel (128x128x32 tile, split-f16 operands, 3 x v_mfma_f32_32x32x16_f16, "
-                                  "direct-to-LDS staging); small grids use gemm_nt_f32_kernel<64,64,1,1>", "bound": "mfma",
+            roofline = {"kernel": "gemm_nt_split_glds_kernel (256x256x32 blocks of 128x64 wave tiles, or 128x128x32 where those do "
+                                  "not fill whole rounds; split-f16 operands, 3 x v_mfma_f32_32x32x16_f16, direct-to-LDS "
+                                  "staging); small grids use gemm_nt_f32_kernel<64,64,1,1>", "bound": "mfma",
                         "achieved": round(3 * alg, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(3 * alg / F16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_tflops": round(alg, 2),
                         "algorithmic_vs_f32_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 3),
