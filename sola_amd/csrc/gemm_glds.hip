@@ -46,7 +46,7 @@ __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0
 constexpr int GBK = 32;
 constexpr int ROWB = 128;  // bytes per tile row (32 elements x 4 B)
 
-template <int MI, int WAVES_M, int WAVES_N, int STAGES, bool CONV>
+template <int MI, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool SCHED>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_kernel(const GldsArgs a) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
@@ -184,6 +184,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         if (kt + STAGES - 1 < nk && !(a.ablate & 1)) issue((stage + STAGES - 1) % STAGES);
         load_frags(sbase, 1, f1);
         mfmas(f0);
+        if (SCHED) {
+            // ask the scheduler to spread the second half's fragment reads between the first half's MFMAs
+            // (3 MFMA : 2 ds_read for 64x64 wave tiles, 2 : 1 for 128x64) instead of one burst after the first MFMA
+#pragma unroll
+            for (int g = 0; g < (MI == 2 ? 4 : 12); ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MI == 2 ? 3 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MI == 2 ? 2 : 1, 0);
+            }
+        }
         mfmas(f1);
         // tile kt+1 has landed (it had one / two whole MFMA phases); only the newest tile's pieces may be outstanding
         if (STAGES == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");
@@ -272,7 +281,7 @@ bool gemm_split_glds_supported(const GemmDesc& d) {
     return d.lda % 8 == 0;
 }
 
-template <int MI, int WAVES_M, int WAVES_N, int STAGES, bool CONV>
+template <int MI, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool SCHED>
 static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     a.tiles_m = (M + GBM - 1) / GBM;
@@ -281,11 +290,11 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr size_t lds = (size_t)STAGES * (GBM + GBN) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, STAGES, CONV>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, STAGES, CONV, SCHED>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, STAGES, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
+    hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, STAGES, CONV, SCHED>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
                        dim3(WAVES_M * WAVES_N * 64), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -293,9 +302,11 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
 
 template <bool CONV>
 static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
-    if (shape == 4) return launch_glds<4, 2, 4, 2, CONV>(a, M, N, nprob, s);
-    if (shape == 2) return launch_glds<2, 4, 2, 3, CONV>(a, M, N, nprob, s);
-    return launch_glds<2, 2, 2, 2, CONV>(a, M, N, nprob, s);
+    // SCHED (fragment reads spread between the MFMAs by sched_group_barrier): +2-5 % on the 64x64 wave tile, nothing on
+    // the 128x64 one (A/B in tools/gemm_ablate.py history)
+    if (shape == 4) return launch_glds<4, 2, 4, 2, CONV, false>(a, M, N, nprob, s);
+    if (shape == 2) return launch_glds<2, 4, 2, 3, CONV, true>(a, M, N, nprob, s);
+    return launch_glds<2, 2, 2, 2, CONV, true>(a, M, N, nprob, s);
 }
 
 extern int g_gemm_glds;

@@ -77,6 +77,55 @@ struct GnArgs {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// normalise + affine (+ LeakyReLU, dropout, the y + pe side output, split-f16 emission) of one float4 and its store
+__device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, const float4 v, float mean, float rstd, const float4 ga,
+                                               const float4 be, const float4 pe, int c4) {
+    float4 o;
+    o.x = (v.x - mean) * rstd * ga.x + be.x;
+    o.y = (v.y - mean) * rstd * ga.y + be.y;
+    o.z = (v.z - mean) * rstd * ga.z + be.z;
+    o.w = (v.w - mean) * rstd * ga.w + be.w;
+    if (a.leaky) {
+        o.x = o.x >= 0.f ? o.x : o.x * a.slope;
+        o.y = o.y >= 0.f ? o.y : o.y * a.slope;
+        o.z = o.z >= 0.f ? o.z : o.z * a.slope;
+        o.w = o.w >= 0.f ? o.w : o.w * a.slope;
+    }
+    if (a.drop.enabled) {
+        o.x = dropout_keep(a.drop, (unsigned long long)off) ? o.x * a.drop.scale : 0.f;
+        o.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? o.y * a.drop.scale : 0.f;
+        o.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? o.z * a.drop.scale : 0.f;
+        o.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? o.w * a.drop.scale : 0.f;
+    }
+    if (a.out_sp16) {
+        // split-f16 output for the 3 x f16 MFMA GEMMs: lanes c4 and c4^1 hold the two halves of an 8-channel block
+        // (every lane of the wave must get here: the shuffles are unconditional)
+        const float4 o2 = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+        const float4 n = make_float4(__shfl_xor(o.x, 1, 64), __shfl_xor(o.y, 1, 64), __shfl_xor(o.z, 1, 64), __shfl_xor(o.w, 1, 64));
+        const float4 n2 = make_float4(__shfl_xor(o2.x, 1, 64), __shfl_xor(o2.y, 1, 64), __shfl_xor(o2.z, 1, 64), __shfl_xor(o2.w, 1, 64));
+        if ((c4 & 1) == 0 && off >= 0) {
+            const float v8[8] = {o.x, o.y, o.z, o.w, n.x, n.y, n.z, n.w};
+            half8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v8[j]; lo[j] = (_Float16)(v8[j] - (float)hi[j]); }
+            half8* dst = reinterpret_cast<half8*>(a.y + off);
+            dst[0] = hi; dst[1] = lo;
+            if (a.y2) {
+                const float w8[8] = {o2.x, o2.y, o2.z, o2.w, n2.x, n2.y, n2.z, n2.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)w8[j]; lo[j] = (_Float16)(w8[j] - (float)hi[j]); }
+                half8* dst2 = reinterpret_cast<half8*>(a.y2 + off);
+                dst2[0] = hi; dst2[1] = lo;
+            }
+        }
+        return;
+    }
+    if (off < 0) return;
+    *reinterpret_cast<float4*>(a.y + off) = o;
+    if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+}
+
+// General shape: three passes over an L2-resident unit (any token count).
 __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     __shared__ float red[4];
     const int g = blockIdx.y;
@@ -114,48 +163,58 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)(inst % a.inner) * a.C + ch);
     for (int t = tl; t < a.ntok; t += tpp) {
         const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
-        const float4 v = *reinterpret_cast<const float4*>(a.x + off);
-        float4 o;
-        o.x = (v.x - mean) * rstd * ga.x + be.x;
-        o.y = (v.y - mean) * rstd * ga.y + be.y;
-        o.z = (v.z - mean) * rstd * ga.z + be.z;
-        o.w = (v.w - mean) * rstd * ga.w + be.w;
-        if (a.leaky) {
-            o.x = o.x >= 0.f ? o.x : o.x * a.slope;
-            o.y = o.y >= 0.f ? o.y : o.y * a.slope;
-            o.z = o.z >= 0.f ? o.z : o.z * a.slope;
-            o.w = o.w >= 0.f ? o.w : o.w * a.slope;
-        }
-        if (a.drop.enabled) {
-            o.x = dropout_keep(a.drop, (unsigned long long)off) ? o.x * a.drop.scale : 0.f;
-            o.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? o.y * a.drop.scale : 0.f;
-            o.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? o.z * a.drop.scale : 0.f;
-            o.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? o.w * a.drop.scale : 0.f;
-        }
-        if (a.out_sp16) {
-            // split-f16 output for the 3 x f16 MFMA GEMMs: lanes c4 and c4^1 hold the two halves of an 8-channel block
-            const float4 o2 = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
-            const float4 n = make_float4(__shfl_xor(o.x, 1, 64), __shfl_xor(o.y, 1, 64), __shfl_xor(o.z, 1, 64), __shfl_xor(o.w, 1, 64));
-            const float4 n2 = make_float4(__shfl_xor(o2.x, 1, 64), __shfl_xor(o2.y, 1, 64), __shfl_xor(o2.z, 1, 64), __shfl_xor(o2.w, 1, 64));
-            if ((c4 & 1) == 0) {
-                const float v[8] = {o.x, o.y, o.z, o.w, n.x, n.y, n.z, n.w};
-                half8 hi, lo;
+        gn_apply_store(a, off, *reinterpret_cast<const float4*>(a.x + off), mean, rstd, ga, be, pe, c4);
+    }
+}
+
+// Register-resident shape: the whole unit is read ONCE into R float4 per lane, mean and the centred second moment are
+// taken from the registers, and the result is written straight out - one HBM read + one write, no re-read.
+//   WAVE = true : one wave per unit (units of <= 64*4*R floats: the encoder norms and the motion norm, 1-4 KiB each),
+//                 four units per block, shuffle reductions only;
+//   WAVE = false: one block per unit (the inter-object norm, 32 KiB, R = 8; the object->language norm, 128 KiB, R = 32).
+template <int R, bool WAVE>
+__global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, long long n_units) {
+    __shared__ float red[4];
+    const int f4 = a.cg >> 2;
+    const int nthr = WAVE ? 64 : 256;
+    const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+    const long long unit = WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
+    if (WAVE && unit >= n_units) return;  // a whole wave leaves; the WAVE shape has no block-level sync
+    const int inst = (int)(unit / a.groups), g = (int)(unit - (long long)inst * a.groups);
+    const int tpp = nthr / f4;
+    const int tl = tid / f4, c4 = tid - tl * f4;
+    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const int ch = g * a.cg + c4 * 4;
+    const float cnt = (float)a.ntok * (float)a.cg;
+    float4 v[R];
+    float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
-                half8* dst = reinterpret_cast<half8*>(a.y + off);
-                dst[0] = hi; dst[1] = lo;
-                if (a.y2) {
-                    const float w[8] = {o2.x, o2.y, o2.z, o2.w, n2.x, n2.y, n2.z, n2.w};
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        v[r] = t < a.ntok ? *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+    }
+    const float mean = (WAVE ? wave_sum(s) : block_sum_256(s, red)) / cnt;
+    float q = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)w[j]; lo[j] = (_Float16)(w[j] - (float)hi[j]); }
-                    half8* dst2 = reinterpret_cast<half8*>(a.y2 + off);
-                    dst2[0] = hi; dst2[1] = lo;
-                }
-            }
-            continue;
+    for (int r = 0; r < R; ++r) {
+        if (tl + r * tpp < a.ntok) {
+            const float d0 = v[r].x - mean, d1 = v[r].y - mean, d2 = v[r].z - mean, d3 = v[r].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
-        *reinterpret_cast<float4*>(a.y + off) = o;
-        if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+    }
+    const float var = (WAVE ? wave_sum(q) : block_sum_256(q, red)) / cnt;  // biased, as nn.GroupNorm
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)(inst % a.inner) * a.C + ch);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        // out-of-range token slots still take part in the split-f16 shuffles; off < 0 marks "do not store"
+        const long long off = t < a.ntok ? (row0 + (long long)t * a.tok_stride) * a.C + ch : -1;
+        gn_apply_store(a, off, v[r], mean, rstd, ga, be, pe, c4);
     }
 }
 
@@ -212,6 +271,9 @@ int launch_ws_standardize(const WsLayer* layers, int n_layers, hipStream_t s) {
     return SOLA_OK;
 }
 
+int g_gn_variant = 1;  // 0 = always the three-pass kernel (A/B), 1 = register-resident shapes where the unit fits
+void sola_gn_set_variant(int v) { g_gn_variant = v; }
+
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     SOLA_ARG(d.groups > 0 && d.C % d.groups == 0, "group_norm: C=%d groups=%d", d.C, d.groups);
     const int cg = d.C / d.groups;
@@ -225,7 +287,25 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);
-    hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+    const int f4 = cg / 4;
+    const long long n_units = (long long)d.n_inst * d.groups;
+    const int rw = 64 % f4 == 0 ? (d.ntok + 64 / f4 - 1) / (64 / f4) : 1 << 30;     // float4 per lane, one wave per unit
+    const int rb = 256 % f4 == 0 ? (d.ntok + 256 / f4 - 1) / (256 / f4) : 1 << 30;  // ... one block per unit
+    if (g_gn_variant != 0 && rw <= 4 && n_units < (1ll << 31)) {
+        const dim3 grid((unsigned)((n_units + 3) / 4));
+        if (rw == 1) hipLaunchKernelGGL((group_norm_reg_kernel<1, true>), grid, dim3(256), 0, s, a, n_units);
+        else if (rw == 2) hipLaunchKernelGGL((group_norm_reg_kernel<2, true>), grid, dim3(256), 0, s, a, n_units);
+        else hipLaunchKernelGGL((group_norm_reg_kernel<4, true>), grid, dim3(256), 0, s, a, n_units);
+    } else if (g_gn_variant != 0 && rb <= 32 && n_units < (1ll << 31)) {
+        const dim3 grid((unsigned)n_units);
+        if (rb <= 2) hipLaunchKernelGGL((group_norm_reg_kernel<2, false>), grid, dim3(256), 0, s, a, n_units);
+        else if (rb <= 4) hipLaunchKernelGGL((group_norm_reg_kernel<4, false>), grid, dim3(256), 0, s, a, n_units);
+        else if (rb <= 8) hipLaunchKernelGGL((group_norm_reg_kernel<8, false>), grid, dim3(256), 0, s, a, n_units);
+        else if (rb <= 16) hipLaunchKernelGGL((group_norm_reg_kernel<16, false>), grid, dim3(256), 0, s, a, n_units);
+        else hipLaunchKernelGGL((group_norm_reg_kernel<32, false>), grid, dim3(256), 0, s, a, n_units);
+    } else {
+        hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+    }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
