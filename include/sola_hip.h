@@ -260,7 +260,7 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_GEMM_SPLIT = 11, /* gemm_nt_f32_kernel<..,1>: split-f16 operands, 3 x f16 MFMA */
        SOLA_PROF_NCAT = 12 };
 /* Kernel-schedule switches for within-process A/B measurements ("gemm_variant": 0 simple / 1 mid-tile staging;
- * "gemm_glds": split-f16 GEMM staging, 0 registers / 1 direct-to-LDS 128x128 / 2 256x128 / 4 256x256 / 3 auto;
+ * "gemm_glds": split-f16 GEMM staging, 0 registers / 1 direct-to-LDS 128x128 blocks / 4 256x256 blocks / 3 auto;
  * "gemm_ablate": measurement only, 1 no DMA after the first tiles | 4 no epilogue (results are then WRONG);
  * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
  * "attn_target_blocks").  Except under gemm_ablate, results are identical across variants up to f32 summation order. */

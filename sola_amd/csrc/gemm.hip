@@ -292,7 +292,7 @@ int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 
 
 }  // namespace
 
-int g_gemm_glds = 3;  // split-f16 GEMM, direct-to-LDS staging (gemm_glds.hip): 0 off, 1 128x128 blocks, 2 256x128, 4 256x256, 3 auto
+int g_gemm_glds = 3;  // split-f16 GEMM, direct-to-LDS staging (gemm_glds.hip): 0 off, 1 128x128 blocks, 4 256x256 blocks, 3 auto
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);

@@ -11,16 +11,21 @@
 //   * conv zero-padding rows read a 16-byte zero page instead (the DMA cannot predicate data); rows beyond M / N are
 //     clamped to the last valid row (their products only reach outputs the epilogue never stores).
 //
-// What bounds it (tools/gemm_ablate.py, tools/pmc_gemm.sh): LDS bandwidth.  With 64x64 wave tiles a k-tile costs, per
-// CU, 128 KiB of fragment reads + 64 KiB of DMA writes = 1536 LDS cycles at 128 B/clk against 1536 MFMA cycles per SIMD:
-// the LDS is ~100 % busy at full MFMA rate, and the measured MFMA-only loop (no DMA, no epilogue) reaches 57-61 %.
-// Block shapes <MI, WAVES_M, WAVES_N, STAGES>:
-//   <2,2,2,2>  128x128, 4 waves of 64x64, 64 KiB LDS, two blocks per CU   — general shape
-//   <2,4,2,3>  256x128, 8 waves of 64x64, 144 KiB, DMA two k-tiles ahead   — A/B measurement only (no faster: latency is
-//                                                                            not the bound)
-//   <4,2,4,2>  256x256, 8 waves of 128x64, 128 KiB, one block per CU       — 25 % fewer fragment bytes and half the DMA
-//                                                                            bytes per MFMA (LDS ~67 % at full MFMA rate)
-// The DMA of a tile is drained (vmcnt) right before the barrier that publishes it.
+// Schedule: two LDS stages, ONE barrier per k-tile placed between its two 16-wide halves.  By then every wave holds both
+// halves' fragments of tile kt in registers (so its stage can take the DMA of tile kt+2) and tile kt+1 has had a whole
+// tile time to land, so its first fragments are fetched under the second half's MFMAs: no LDS latency is exposed behind
+// a barrier and the DMA always has one full tile of MFMA work (~1.4 us) to cover its latency.
+//
+// Block shapes <MI, WAVES_M, WAVES_N>:
+//   <2,2,2>  128x128, 4 waves of 64x64, 64 KiB LDS, two blocks per CU   - general shape
+//   <4,2,4>  256x256, 8 waves of 128x64, 128 KiB, one block per CU      - 25 % fewer fragment bytes and half the DMA
+//                                                                         bytes per MFMA; used when its grid fills
+//                                                                         whole rounds of one block per CU
+// Measured (tools/gemm_ablate.py, tools/pmc_gemm.sh, tools/pmc_clock.sh; M=16384 N=K=1024, 2.05 GHz effective clock):
+// 256x256: 107 us total = 63-66 us MFMA+LDS loop alone (matrix pipe busy 68 % of cycles) + ~15 us of imperfect DMA
+// overlap + ~28 us epilogue (HBM-bound: C once, residual once; with one round of blocks nothing overlaps it).  Also
+// tried and dropped: a 256x128 / 3-stage shape (DMA two tiles ahead: no faster, latency was not the bound) and
+// sched_group_barrier interleaving of fragment reads (+2-5 % on 64x64 wave tiles only, subsumed by this schedule).
 #include "kernels.h"
 
 namespace {
@@ -46,9 +51,10 @@ __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0
 constexpr int GBK = 32;
 constexpr int ROWB = 128;  // bytes per tile row (32 elements x 4 B)
 
-template <int MI, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool SCHED>
+template <int MI, int WAVES_M, int WAVES_N, bool CONV>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_kernel(const GldsArgs a) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
+    constexpr int STAGES = 2;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
     constexpr int NWAVE = WAVES_M * WAVES_N;
     constexpr int APW = GBM / 8 / NWAVE, WPW = GBN / 8 / NWAVE;  // 8-row DMA pieces per wave per k-tile
@@ -167,38 +173,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 
     const int nk = a.K / GBK;
     issue(0);
-    if (STAGES == 3 && nk > 1) {
-        issue(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");  // the pieces of tile 1 may still be in flight
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int stage = 0;
+    Frags f0, f1;
+    load_frags(lds, 0, f0);
+    if (nk > 1 && !(a.ablate & 1)) issue(1);
     for (int kt = 0; kt < nk; ++kt) {
-        const char* sbase = lds + stage * STAGE_BYTES;
-        Frags f0, f1;
-        // order of issue: first half's fragments, the DMA of a later tile (its address arithmetic runs under the LDS
-        // latency), second half's fragments, then the MFMAs back to back
-        load_frags(sbase, 0, f0);
-        if (kt + STAGES - 1 < nk && !(a.ablate & 1)) issue((stage + STAGES - 1) % STAGES);
-        load_frags(sbase, 1, f1);
+        load_frags(lds + stage * STAGE_BYTES, 1, f1);
         mfmas(f0);
-        if (SCHED) {
-            // ask the scheduler to spread the second half's fragment reads between the first half's MFMAs
-            // (3 MFMA : 2 ds_read for 64x64 wave tiles, 2 : 1 for 128x64) instead of one burst after the first MFMA
-#pragma unroll
-            for (int g = 0; g < (MI == 2 ? 4 : 12); ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MI == 2 ? 3 : 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, MI == 2 ? 2 : 1, 0);
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (issued one tile time ago)
+        __syncthreads();                                   // ... and nobody reads this stage any more
+        if (kt + 2 < nk && !(a.ablate & 1)) issue(stage);
+        load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);  // past the last tile this reads stale LDS and is never used
         mfmas(f1);
-        // tile kt+1 has landed (it had one / two whole MFMA phases); only the newest tile's pieces may be outstanding
-        if (STAGES == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
+        stage ^= 1;
     }
 
     // ---- epilogue: the accumulators (one column per lane, 16 scattered rows) go through this wave's 16 KiB of the
@@ -281,20 +270,20 @@ bool gemm_split_glds_supported(const GemmDesc& d) {
     return d.lda % 8 == 0;
 }
 
-template <int MI, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool SCHED>
+template <int MI, int WAVES_M, int WAVES_N, bool CONV>
 static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     a.tiles_m = (M + GBM - 1) / GBM;
     a.tiles_n = (N + GBN - 1) / GBN;
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
-    constexpr size_t lds = (size_t)STAGES * (GBM + GBN) * ROWB;
+    constexpr size_t lds = (size_t)2 * (GBM + GBN) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, STAGES, CONV, SCHED>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, STAGES, CONV, SCHED>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
+    hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
                        dim3(WAVES_M * WAVES_N * 64), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -302,11 +291,8 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
 
 template <bool CONV>
 static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
-    // SCHED (fragment reads spread between the MFMAs by sched_group_barrier): +2-5 % on the 64x64 wave tile, nothing on
-    // the 128x64 one (A/B in tools/gemm_ablate.py history)
-    if (shape == 4) return launch_glds<4, 2, 4, 2, CONV, false>(a, M, N, nprob, s);
-    if (shape == 2) return launch_glds<2, 4, 2, 3, CONV, true>(a, M, N, nprob, s);
-    return launch_glds<2, 2, 2, 2, CONV, true>(a, M, N, nprob, s);
+    if (shape == 4) return launch_glds<4, 2, 4, CONV>(a, M, N, nprob, s);
+    return launch_glds<2, 2, 2, CONV>(a, M, N, nprob, s);
 }
 
 extern int g_gemm_glds;
@@ -321,10 +307,10 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
     a.r_sp16 = d.r_sp16;
     a.ablate = g_gemm_ablate;
-    // g_gemm_glds: 1 = 128x128 blocks, 2 = 256x128 (3 stages), 4 = 256x256, 3 = auto: 256x256 when its grid fills whole
-    // rounds of one block per CU (a partial last round of 256x256 blocks costs more than the shape gains)
+    // g_gemm_glds: 1 = 128x128 blocks, 4 = 256x256, anything else = auto: 256x256 when its grid fills whole rounds of one
+    // block per CU (a partial last round of 256x256 blocks costs more than the shape gains)
     int shape = g_gemm_glds;
-    if (shape != 1 && shape != 2 && shape != 4) {
+    if (shape != 1 && shape != 4) {
         const long long t = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nprob;
         shape = (t >= 256 && (t % 256 == 0 || t >= 2048)) ? 4 : 1;
     }

@@ -7,5 +7,7 @@ v = int(sys.argv[1]); M, N, K = (int(x) for x in sys.argv[2:5]) if len(sys.argv)
 x = torch.randn(M, K, device="cuda"); wt = torch.randn(N, K, device="cuda") * 0.03
 a = ops.cast_sp16(x); w = ops.cast_sp16(wt, 64.0); b = torch.randn(N, device="cuda"); r = ops.cast_sp16(torch.randn(M, N, device="cuda"))
 _lib.lib().sola_tune(b"gemm_glds", v)
+import os
+_lib.lib().sola_tune(b"gemm_ablate", int(os.environ.get("SOLA_ABLATE", "0")))
 for _ in range(5): ops.gemm_nt_split(a, w, b, r, True, 1 / 64)
 torch.cuda.synchronize()
