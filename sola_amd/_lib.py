@@ -92,7 +92,8 @@ SIGNATURES = {
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
 }
 
-PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64", "gemm_tn", "attn_bwd", "gemm_split"]
+PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64", "gemm_tn", "attn_bwd", "gemm_split",
+                   "gemm_split256"]
 
 _lib = None
 

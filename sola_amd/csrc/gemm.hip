@@ -297,6 +297,7 @@ void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s);
+int gemm_split_glds_shape(const GemmDesc& d);  // 4 = 256x256 blocks, 1 = 128x128
 
 int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3, "gemm: nprob %d", d.nprob);
@@ -315,10 +316,13 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.r_sp16 = d.r_sp16;
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
-    SolaProfScope prof(d.arith == 1 ? SOLA_PROF_GEMM_SPLIT : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL), s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
+    const bool glds = d.arith == 1 && big && g_gemm_glds && gemm_split_glds_supported(d);
+    const int cat = d.arith == 1 ? (glds && gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT)
+                                 : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL);
+    SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
     const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
-    if (d.arith == 1 && big && g_gemm_glds && gemm_split_glds_supported(d)) return launch_gemm_split_glds(d, s);
+    if (glds) return launch_gemm_split_glds(d, s);
     if (d.arith == 1) {
         SOLA_ARG(d.K % 16 == 0 && (d.conv ? d.Cin % 8 == 0 : d.lda % 8 == 0), "split-f16 gemm: K %% 16 and row pitch %% 8 required");
         if (big) return pipe ? launch_tile<128, 128, 1, 1>(a, d.nprob, s) : launch_tile<128, 128, 0, 1>(a, d.nprob, s);

@@ -296,6 +296,7 @@ static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStre
 }
 
 extern int g_gemm_glds;
+int gemm_split_glds_shape(const GemmDesc& d);
 int g_gemm_ablate = 0;
 void sola_gemm_set_ablate(int v) { g_gemm_ablate = v; }
 
@@ -307,12 +308,14 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
     a.r_sp16 = d.r_sp16;
     a.ablate = g_gemm_ablate;
-    // g_gemm_glds: 1 = 128x128 blocks, 4 = 256x256, anything else = auto: 256x256 when its grid fills whole rounds of one
-    // block per CU (a partial last round of 256x256 blocks costs more than the shape gains)
-    int shape = g_gemm_glds;
-    if (shape != 1 && shape != 4) {
-        const long long t = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nprob;
-        shape = (t >= 256 && (t % 256 == 0 || t >= 2048)) ? 4 : 1;
-    }
+    const int shape = gemm_split_glds_shape(d);
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);
+}
+
+// g_gemm_glds: 1 = 128x128 blocks, 4 = 256x256, anything else = auto: 256x256 when its grid fills whole rounds of one
+// block per CU (a partial last round of 256x256 blocks costs more than the shape gains)
+int gemm_split_glds_shape(const GemmDesc& d) {
+    if (g_gemm_glds == 1 || g_gemm_glds == 4) return g_gemm_glds;
+    const long long t = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nprob;
+    return (t >= 256 && (t % 256 == 0 || t >= 2048)) ? 4 : 1;
 }
