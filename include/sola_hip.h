@@ -228,7 +228,7 @@ int sola_mask_iou_matrix(const void* dev_a, const void* dev_b, int elem_type, in
  * (align_corners=False, ATen's source-index rule) of n {0,1} masks [n,h,w] to H x W, `> 0.5`, bit-pack, area.
  * elem_type 0 = uint8 (non-zero counts as 1.0), 1 = float32 (any values; the fp32 arithmetic order is ATen's),
  * 2 = float32 tracker logits, binarised as (v > 0) while reading — the `(out_mask_logits > 0.0).float()` of
- * generate_tokens_grid.py:215-222 folded in.  W <= 8192. */
+ * generate_tokens_grid.py:215-222 folded in.  W <= 4096. */
 int sola_mask_bilinear_pack(const void* dev_masks, int elem_type, int n, int h, int w, int H, int W,
                             uint32_t* dev_bits, int64_t* dev_area, void* stream);
 /* packed bits -> {0,1} images [n,H,W] (elem_type 0 = uint8, 1 = float32): the tensor reshape_masklet returns. */

@@ -248,6 +248,7 @@ void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
 void sola_gemm_set_ablate(int v);
 void sola_gn_set_variant(int v);
+void sola_bilinear_set_staged(int v);
 void sola_attn_set_variant(int v);
 void sola_attn_set_target_blocks(int v);
 extern "C" int sola_tune(const char* key, int value) {
@@ -256,6 +257,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gn_variant")) { sola_gn_set_variant(value); return SOLA_OK; }
+    if (!strcmp(key, "bilinear_staged")) { sola_bilinear_set_staged(value); return SOLA_OK; }
     if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
     sola_set_error("tune: unknown key '%s'", key);

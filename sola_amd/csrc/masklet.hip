@@ -55,9 +55,14 @@ __device__ __forceinline__ float mask_value(T v) {
 // ballot.  Neighbouring lanes read neighbouring (or identical) source elements, so the four taps are coalesced row
 // segments.  ALIGNED (W % 32 == 0): the ballot is two whole words of the packed row; otherwise the 64 bits straddle up
 // to three words shared with other waves and are OR-ed into a pre-zeroed row atomically.
-template <typename T, int MODE, bool ALIGNED>
+// STAGED (w % 4 == 0): the source rows the block's destination rows touch are first streamed into LDS with 16-byte
+// (4-byte for u8) loads, binarised to one byte per pixel on the way, and the four taps come from LDS - the scattered
+// per-pixel dword loads of the direct version were bound by the L1/TA rate (~12 cycles per wave-load), not by HBM.
+// Plain float32 masks (MODE 1) are staged too: a block that meets a value other than 0 or 1 while staging falls back
+// to the direct float taps for its rows, so arbitrary float images keep ATen's arithmetic.
+template <typename T, int MODE, bool ALIGNED, bool STAGED>
 __global__ __launch_bounds__(256) void mask_bilinear_pack_kernel(const BilinearArgs a) {
-    extern __shared__ int2 xtab[];  // [W] (i0, bits of l1)
+    extern __shared__ int2 xtab[];  // [W] (i0, bits of l1), then the staged rows
     __shared__ int red[4];
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,18 +72,49 @@ __global__ __launch_bounds__(256) void mask_bilinear_pack_kernel(const BilinearA
         source_index(a.sx, x, a.w, a.W, i0, l1);
         xtab[x] = make_int2(i0, __float_as_int(l1));
     }
-    __syncthreads();
     const T* src = reinterpret_cast<const T*>(a.src) + (long long)n * a.hw_src;
     uint32_t* dst = a.bits + (long long)n * a.words;
     int cnt = 0;
-    const int y_end = min(a.H, ((int)blockIdx.x + 1) * a.rows_per_block);
-    for (int y = blockIdx.x * a.rows_per_block; y < y_end; ++y) {
+    const int y_begin = blockIdx.x * a.rows_per_block;
+    const int y_end = min(a.H, y_begin + a.rows_per_block);
+    uint8_t* rows8 = reinterpret_cast<uint8_t*>(xtab + a.W);
+    int ys0 = 0;
+    int not_binary = 0;
+    if (STAGED) {
+        int yl;
+        float unused;
+        source_index(a.sy, y_begin, a.h, a.H, ys0, unused);
+        source_index(a.sy, y_end - 1, a.h, a.H, yl, unused);
+        const int nrows = yl + (yl < a.h - 1 ? 1 : 0) - ys0 + 1;
+        const int wq = a.w >> 2;
+        uint32_t* rows32 = reinterpret_cast<uint32_t*>(rows8);
+        for (int idx = threadIdx.x; idx < nrows * wq; idx += 256) {
+            const int r = idx / wq, c = idx - r * wq;
+            uint32_t packed;
+            if constexpr (sizeof(T) == 4) {
+                const float4 v = reinterpret_cast<const float4*>(src + (long long)(ys0 + r) * a.w)[c];
+                if (MODE == 1)
+                    not_binary |= (v.x != 0.f && v.x != 1.f) | (v.y != 0.f && v.y != 1.f) | (v.z != 0.f && v.z != 1.f) | (v.w != 0.f && v.w != 1.f);
+                packed = (uint32_t)(mask_value<float, MODE>(v.x) != 0.f) | (uint32_t)(mask_value<float, MODE>(v.y) != 0.f) << 8 |
+                         (uint32_t)(mask_value<float, MODE>(v.z) != 0.f) << 16 | (uint32_t)(mask_value<float, MODE>(v.w) != 0.f) << 24;
+            } else {
+                const uint32_t wv = reinterpret_cast<const uint32_t*>(src + (long long)(ys0 + r) * a.w)[c];
+                packed = ((((wv & 0x7f7f7f7fu) + 0x7f7f7f7fu) | wv) & 0x80808080u) >> 7;  // byte != 0 -> 1
+            }
+            rows32[idx] = packed;
+        }
+    }
+    const int any_not_binary = __syncthreads_or(not_binary);  // the barrier also publishes xtab and the staged rows
+    const bool from_lds = STAGED && any_not_binary == 0;
+    for (int y = y_begin; y < y_end; ++y) {
         int y0;
         float ly1;
         source_index(a.sy, y, a.h, a.H, y0, ly1);
         const float ly0 = __fsub_rn(1.f, ly1);
         const T* r0 = src + (long long)y0 * a.w;
         const T* r1 = r0 + (y0 < a.h - 1 ? a.w : 0);
+        const uint8_t* s0 = rows8 + (y0 - ys0) * a.w;
+        const uint8_t* s1 = s0 + (y0 < a.h - 1 ? a.w : 0);
         const long long rowbit = (long long)y * a.W;
         for (int x0 = wave * 64; x0 < a.W; x0 += 256) {
             const int x = x0 + lane;
@@ -86,8 +122,13 @@ __global__ __launch_bounds__(256) void mask_bilinear_pack_kernel(const BilinearA
             const int2 e = xtab[ok ? x : 0];
             const int i0 = e.x, i1 = e.x + (e.x < a.w - 1 ? 1 : 0);
             const float lx1 = __int_as_float(e.y), lx0 = __fsub_rn(1.f, lx1);
-            const float v00 = mask_value<T, MODE>(r0[i0]), v01 = mask_value<T, MODE>(r0[i1]);
-            const float v10 = mask_value<T, MODE>(r1[i0]), v11 = mask_value<T, MODE>(r1[i1]);
+            float v00, v01, v10, v11;
+            if (from_lds) {
+                v00 = (float)s0[i0]; v01 = (float)s0[i1]; v10 = (float)s1[i0]; v11 = (float)s1[i1];
+            } else {
+                v00 = mask_value<T, MODE>(r0[i0]); v01 = mask_value<T, MODE>(r0[i1]);
+                v10 = mask_value<T, MODE>(r1[i0]); v11 = mask_value<T, MODE>(r1[i1]);
+            }
             const float t = __fmaf_rn(lx0, v00, __fmul_rn(lx1, v01));
             const float u = __fmaf_rn(lx0, v10, __fmul_rn(lx1, v11));
             const float o = __fmaf_rn(ly0, t, __fmul_rn(ly1, u));
@@ -200,19 +241,28 @@ __global__ __launch_bounds__(256) void rle_fill_or_kernel(const RleArgs a) {
 }  // namespace
 
 template <typename T, int MODE>
-static void launch_bilinear(const BilinearArgs& a, int n, bool aligned, hipStream_t s) {
+static void launch_bilinear(const BilinearArgs& a, int n, bool aligned, size_t staged_bytes, hipStream_t s) {
     const dim3 grid((a.H + a.rows_per_block - 1) / a.rows_per_block, n), block(256);
-    const size_t lds = (size_t)a.W * sizeof(int2);
-    if (aligned) hipLaunchKernelGGL((mask_bilinear_pack_kernel<T, MODE, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((mask_bilinear_pack_kernel<T, MODE, false>), grid, block, lds, s, a);
+    const size_t lds = (size_t)a.W * sizeof(int2) + staged_bytes;
+    if (staged_bytes) {
+        if (aligned) hipLaunchKernelGGL((mask_bilinear_pack_kernel<T, MODE, true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((mask_bilinear_pack_kernel<T, MODE, false, true>), grid, block, lds, s, a);
+    } else {
+        if (aligned) hipLaunchKernelGGL((mask_bilinear_pack_kernel<T, MODE, true, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((mask_bilinear_pack_kernel<T, MODE, false, false>), grid, block, lds, s, a);
+    }
 }
+
+int g_bilinear_staged = 1;  // 0 = always the direct-load version, 1 = stage uint8 sources (measured: 77 -> 58 us per 64 720p
+                            // frames; float sources gain nothing at 720p and lose at 1080p, their loop is VALU-bound), 2 = stage all
+void sola_bilinear_set_staged(int v) { g_bilinear_staged = v; }
 
 int launch_mask_bilinear_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
                               long long* area, hipStream_t s) {
     SOLA_ARG(n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "mask_bilinear_pack: bad sizes");
     SOLA_ARG(elem_type >= 0 && elem_type <= 2, "mask_bilinear_pack: elem_type %d (0=u8, 1=f32, 2=f32 logits)", elem_type);
     SOLA_ARG(n <= 65535, "mask_bilinear_pack: n=%d exceeds 65535 masks per call", n);
-    SOLA_ARG(W <= 8192, "mask_bilinear_pack: destination width %d exceeds 8192", W);
+    SOLA_ARG(W <= 4096, "mask_bilinear_pack: destination width %d exceeds 4096", W);
     SOLA_ARG((long long)H * W < (1ll << 31) && (long long)h * w < (1ll << 31), "mask_bilinear_pack: image too large");
     BilinearArgs a;
     a.src = masks; a.bits = bits; a.area = reinterpret_cast<unsigned long long*>(area);
@@ -222,13 +272,26 @@ int launch_mask_bilinear_pack(const void* masks, int elem_type, int n, int h, in
     // ~16 blocks per CU over the whole launch (measured optimum 2K-8K blocks for 64 frames of 540x960): more blocks only
     // add same-address area atomics, which are the scarce resource
     a.rows_per_block = (int)std::min<long long>(H, std::max<long long>(1, ((long long)H * n + 4095) / 4096));
+    // staged version: the source rows of a block (rows_per_block * h/H + 2, one byte per pixel) must fit beside the x table
+    size_t staged_bytes = 0;
+    const int esz = elem_type ? 4 : 1;
+    if ((g_bilinear_staged == 2 || (g_bilinear_staged == 1 && elem_type == 0)) && w % 4 == 0 && (reinterpret_cast<uintptr_t>(masks) & (uintptr_t)(4 * esz - 1)) == 0) {
+        a.rows_per_block = std::max(a.rows_per_block, std::min(H, 4));
+        for (;;) {
+            const long long src_rows = (long long)a.rows_per_block * h / H + 3;
+            staged_bytes = (size_t)src_rows * w;
+            if ((size_t)W * sizeof(int2) + staged_bytes <= 60 * 1024) break;
+            if (a.rows_per_block == 1) { staged_bytes = 0; break; }
+            a.rows_per_block = std::max(1, a.rows_per_block / 2);
+        }
+    }
     SOLA_HIP(hipMemsetAsync(area, 0, sizeof(long long) * n, s));
     const bool aligned = W % 32 == 0;
     if (!aligned) SOLA_HIP(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)n * a.words, s));
-    SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)n * h * w * (elem_type ? 4 : 1) + (double)n * a.words * 4);
-    if (elem_type == 0) launch_bilinear<uint8_t, 0>(a, n, aligned, s);
-    else if (elem_type == 1) launch_bilinear<float, 1>(a, n, aligned, s);
-    else launch_bilinear<float, 2>(a, n, aligned, s);
+    SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)n * h * w * esz + (double)n * a.words * 4);
+    if (elem_type == 0) launch_bilinear<uint8_t, 0>(a, n, aligned, staged_bytes, s);
+    else if (elem_type == 1) launch_bilinear<float, 1>(a, n, aligned, staged_bytes, s);
+    else launch_bilinear<float, 2>(a, n, aligned, staged_bytes, s);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -228,3 +228,34 @@ def test_dataset_merged_masklet_on_device_matches_host_decoder(su, tmp_path):
         devm = ds.merged_masklet("vidA", "0", np.array(preds), device="cuda")
         assert devm.is_cuda and devm.dtype == torch.uint8
         np.testing.assert_array_equal(devm.cpu().numpy() != 0, np.asarray(host) != 0)
+
+
+@pytest.mark.parametrize("staged", [1, 2])
+def test_float_images_that_are_not_binary_keep_aten_arithmetic(su, staged):
+    """elem_type float32 with values outside {0,1}: the `> 0.5` mask equals the oracle's float resample (ATen's rule),
+    also when only ONE pixel of the image is soft - with the direct kernel (default for float sources) and with the
+    LDS-staged one, whose blocks fall back to float taps when they meet a non-binary value."""
+    from sola_amd import _lib
+    _lib.lib().sola_tune(b"bilinear_staged", staged)
+    try:
+        _soft_mask_checks(su)
+    finally:
+        _lib.lib().sola_tune(b"bilinear_staged", 1)
+
+
+def _soft_mask_checks(su):
+    rng = np.random.default_rng(21)
+    for (n, h, w, H, W) in [(2, 64, 96, 54, 96), (2, 120, 160, 90, 128), (1, 480, 856, 540, 960)]:
+        x = rng.random((n, h, w)).astype(np.float32)           # soft masks
+        want = (mo.bilinear_resize(x, H, W) > np.float32(0.5)).astype(np.float32)
+        got = su.reshape_masklet(dev(x), (H, W)).cpu().numpy()
+        assert (got != want).mean() < 2e-5  # values within 1 ulp of 0.5 may round differently under the fused sums
+        y = (rng.random((n, h, w)) < 0.5).astype(np.float32)
+        y[0, h // 2, w // 2] = 0.75                             # one soft pixel in a binary image
+        want = (mo.bilinear_resize(y, H, W) > np.float32(0.5)).astype(np.float32)
+        got = su.reshape_masklet(dev(y), (H, W)).cpu().numpy()
+        assert (got != want).mean() < 2e-5
+        # and the soft pixel matters: the all-binary version of the same image differs somewhere near it
+        y2 = y.copy(); y2[0, h // 2, w // 2] = 1.0
+        got2 = su.reshape_masklet(dev(y2), (H, W)).cpu().numpy()
+        np.testing.assert_array_equal(got2, mo.reshape_masklet(y2, (H, W)))
