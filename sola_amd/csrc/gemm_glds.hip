@@ -5,9 +5,11 @@
 //     pointers just advance 128 B per k-tile (also for the implicit-im2col conv, see below);
 //   * the DMA writes LDS linearly (wave-uniform base + lane * 16 B), so tile rows are 128 contiguous bytes (8 lanes
 //     per row, 8 rows per piece) and bank conflicts are removed by an XOR swizzle of the 16-byte chunks,
-//     chunk' = chunk ^ (row & 7), applied on the SOURCE address when loading and on the fragment address when reading
-//     (the same involution on both sides): a ds_read_b128 is served 8 lanes at a time, and 8 consecutive rows reading the
-//     same logical chunk hit 8 different 16-byte slots = all 32 banks once;
+//     chunk' = chunk ^ ((row >> 1) & 7), applied on the SOURCE address when loading and on the fragment address when
+//     reading (the same involution on both sides).  gfx950's LDS has 64 banks (256 B/clk): a ds_read_b128 is served 16
+//     lanes at a time, and 16 consecutive rows reading the same logical chunk must land in 16 different 16-byte slots of
+//     the 256-byte bank line - (row & 1) picks the half, the key the slot.  (A key of row & 7, right for a 32-bank LDS,
+//     measured exactly half the read rate: tools/micro/lds_bw.hip, 69 vs 116 TB/s aggregate.)
 //   * conv zero-padding rows read a 16-byte zero page instead (the DMA cannot predicate data); rows beyond M / N are
 //     clamped to the last valid row (their products only reach outputs the epilogue never stores).
 //
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
         const int r = (wave * APW + i) * 8 + lrow;     // tile-local A row
-        const int col_bytes = (chunk ^ (r & 7)) * 16;  // logical 16-byte chunk that must land in this physical slot
+        const int col_bytes = (chunk ^ ((r >> 1) & 7)) * 16;  // logical 16-byte chunk that must land in this physical slot
         const int m = min(m0 + r, a.M - 1);
         if (CONV) {
             const int rr = m / a.T_out, to = m - rr * a.T_out;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     for (int i = 0; i < WPW; ++i) {
         const int r = (wave * WPW + i) * 8 + lrow;  // tile-local W row
         const int n = min(n0 + r, a.N - 1);
-        w_ptr[i] = reinterpret_cast<const char*>(pr.W + (long long)n * a.K) + (chunk ^ (r & 7)) * 16;
+        w_ptr[i] = reinterpret_cast<const char*>(pr.W + (long long)n * a.K) + (chunk ^ ((r >> 1) & 7)) * 16;
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     int conv_kk = 0, conv_c = 0;  // CONV: tap index and channel offset of the next k-tile to issue (uniform)
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment addresses of this lane; the swizzle key row & 7 is the same for all its rows (they differ by multiples of 32)
-    const int fr = lane & 31, fh = lane >> 5, key = lane & 7;
+    // fragment addresses of this lane; the swizzle key (row >> 1) & 7 is the same for all its rows (they differ by multiples of 32)
+    const int fr = lane & 31, fh = lane >> 5, key = (lane >> 1) & 7;
     const int a_frag = (wr * MI * 32 + fr) * ROWB, w_frag = GBM * ROWB + (wc * 64 + fr) * ROWB;
 
     struct Frags { half8 ah[MI], al[MI], bh[2], bl[2]; };
@@ -179,14 +181,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     Frags f0, f1;
     load_frags(lds, 0, f0);
     if (nk > 1 && !(a.ablate & 1)) issue(1);
+    constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;  // fragment reads and MFMAs of one half
     for (int kt = 0; kt < nk; ++kt) {
+        // Each half = one MFMA batch with the NEXT half's fragment reads issued right behind its first MFMA.  The compiler
+        // waits lgkmcnt(0) in front of a batch (scalar loads in the loop keep it from counting LDS returns), so reads
+        // issued just before a batch - where the scheduler puts them on its own, to shorten live ranges - stall that
+        // batch for the whole LDS latency of 8 waves reading at once; behind the first MFMA they have a batch to land.
         load_frags(lds + stage * STAGE_BYTES, 1, f1);
         mfmas(f0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (issued one tile time ago)
         __syncthreads();                                   // ... and nobody reads this stage any more
         if (kt + 2 < nk && !(a.ablate & 1)) issue(stage);
+        __builtin_amdgcn_sched_barrier(0);
         load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);  // past the last tile this reads stale LDS and is never used
         mfmas(f1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         stage ^= 1;
     }
 
