@@ -24,6 +24,11 @@
 
 namespace {
 
+#ifndef SOLA_ATTN_LDK_PAD
+#define SOLA_ATTN_LDK_PAD 4
+#endif
+constexpr int LDK_PAD = SOLA_ATTN_LDK_PAD;  // 8 was the 32-bank choice; gfx950 has 64 banks
+
 struct AttnArgs {
     const float *q, *k, *v;
     float* o;
@@ -71,7 +76,7 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
 template <int DH, bool PACKED>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
     constexpr int NC = DH / 16;   // 16-wide head-dim chunks
-    constexpr int LDK = DH + 8;   // K pitch: ds_read_b128 by 16-lane groups lands on 16 distinct 16-B slots
+    constexpr int LDK = DH + LDK_PAD;  // K pitch: ds_read_b128, 16 key rows per 16-lane group -> 16 distinct 16-B slots of the 64-bank line needs pitch = 4 (mod 64)
     constexpr int LDV = DH + 4;   // V pitch: ds_read_b32, the two 16-lane halves of a 32-lane group are 16 banks apart
     constexpr int F4 = DH / 4;    // float4 per row
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -334,7 +339,7 @@ int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over reside
 template <int DH>
 int launch_dh(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
-    constexpr size_t lds_max = (size_t)64 * ((DH + 8) + (DH + 4)) * sizeof(float);
+    constexpr size_t lds_max = (size_t)64 * ((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
     const bool packed = a.Sq <= 16 && a.Sk <= 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -370,7 +375,7 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         a.qsplit = qsplit;
         const long long blocks = gh * qsplit;
         SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
-        const size_t lds = (size_t)a.kv_rows * ((DH + 8) + (DH + 4)) * sizeof(float);
+        const size_t lds = (size_t)a.kv_rows * ((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
         hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     }
     SOLA_LAUNCH_CHECK();
