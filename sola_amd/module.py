@@ -156,20 +156,28 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         return self._workspace
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, object_tokens, lang_tokens):
-        require_cuda(object_tokens, lang_tokens)
-        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
-            from .autograd import track_selection_forward  # backward kernels
-            return track_selection_forward(self, object_tokens, lang_tokens)
-        return self._forward_impl(object_tokens, lang_tokens)
-
-    def _forward_impl(self, object_tokens, lang_tokens):
+    def _check_inputs(self, object_tokens, lang_tokens):
         if object_tokens.dim() != 4 or lang_tokens.dim() != 3:
             raise SolaError("object_tokens must be [B,N,T,d] and lang_tokens [B,L,D]")
         B, N, T, d = object_tokens.shape
         Bl, L, D = lang_tokens.shape
         if d != self.object_token_dim or D != self.lang_token_dim or Bl != B:
             raise SolaError(f"shape mismatch: object_tokens {tuple(object_tokens.shape)}, lang_tokens {tuple(lang_tokens.shape)}")
+        if min(B, N, T, L) < 1:
+            raise SolaError(f"empty input: object_tokens {tuple(object_tokens.shape)}, lang_tokens {tuple(lang_tokens.shape)}")
+
+    def forward(self, object_tokens, lang_tokens):
+        require_cuda(object_tokens, lang_tokens)
+        self._check_inputs(object_tokens, lang_tokens)
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            from .autograd import track_selection_forward  # backward kernels
+            return track_selection_forward(self, object_tokens, lang_tokens)
+        return self._forward_impl(object_tokens, lang_tokens)
+
+    def _forward_impl(self, object_tokens, lang_tokens):
+        self._check_inputs(object_tokens, lang_tokens)
+        B, N, T, d = object_tokens.shape
+        Bl, L, D = lang_tokens.shape
         dev = object_tokens.device
         obj = object_tokens.to(torch.float32).contiguous()
         lang = lang_tokens.to(torch.float32).contiguous()
