@@ -74,7 +74,7 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
 }
 
 template <int DH, bool PACKED>
-__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) {
     constexpr int NC = DH / 16;   // 16-wide head-dim chunks
     constexpr int LDK = DH + LDK_PAD;  // K pitch: ds_read_b128, 16 key rows per 16-lane group -> 16 distinct 16-B slots of the 64-bank line needs pitch = 4 (mod 64)
     constexpr int LDV = DH + 4;   // V pitch: ds_read_b32, the two 16-lane halves of a 32-lane group are 16 banks apart
@@ -189,53 +189,93 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
             store_o<NC>(a.o + qrow * a.ldo + h * DH, g4, oacc, inv, a.o_sp16);
         }
     } else {
-        // ---------------------------------------------------------------- shared: one (group, head) per block
+        // ---------------------------------------------------------------- shared: (group, head, q-split) units, a block
+        // walks units blockIdx.x, + gridDim.x, ...  While a unit is being computed, the NEXT unit's K/V tile is already in
+        // flight into registers (committed to LDS at the unit boundary) and so is its first Q fragment, so neither pipe
+        // waits a full memory latency per unit (one unit per block left both the matrix pipe and HBM ~35-40 % busy).
         float* Ks = smem;                       // [kv_rows][LDK]
         float* Vs = smem + a.kv_rows * LDK;     // [kv_rows][LDV]
-        int b = blockIdx.x;
-        const int qs = b % a.qsplit;
-        b /= a.qsplit;
-        const int h = b % a.H;
-        const int grp = b / a.H;
-        const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-        const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        struct Unit { int qs, h, grp; long long qrow0, krow0; };
+        auto decode = [&](long long u) {
+            Unit c;
+            c.qs = (int)(u % a.qsplit);
+            u /= a.qsplit;
+            c.h = (int)(u % a.H);
+            c.grp = (int)(u / a.H);
+            c.qrow0 = (long long)(c.grp / a.inner) * a.q_outer + (long long)(c.grp % a.inner) * a.q_inner;
+            c.krow0 = (long long)(c.grp / a.inner) * a.k_outer + (long long)(c.grp % a.inner) * a.k_inner;
+            return c;
+        };
+        const long long n_units = (long long)a.G * a.H * a.qsplit;
         const bool single_tile = a.Sk <= a.kv_rows;
-        auto stage = [&](int kt0, int nrows, int nrows16) {
+        const int res_rows16 = (a.Sk + 15) & ~15;  // rows of the resident tile (single_tile)
+        // ONE register buffer serves both prefetches: K of the next unit is in flight from the start of a unit until the
+        // unit's last QK^T is done (then it replaces Ks), V of the next unit from there until the unit's end.
+        constexpr int KVR = F4 / 4;  // float4 per thread for a 64-row tile
+        float4 pre[KVR];
+        auto fetch = [&](const float* base, int ld, const Unit& c) {
+#pragma unroll
+            for (int i = 0; i < KVR; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / F4, c4 = idx - r * F4;
+                pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < a.Sk) pre[i] = *reinterpret_cast<const float4*>(base + (c.krow0 + (long long)r * a.k_rs) * ld + c.h * DH + c4 * 4);
+            }
+        };
+        auto commit = [&](float* dst, int pitch) {
+#pragma unroll
+            for (int i = 0; i < KVR; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / F4, c4 = idx - r * F4;
+                if (r < res_rows16) *reinterpret_cast<float4*>(&dst[r * pitch + c4 * 4]) = pre[i];
+            }
+        };
+        long long u = blockIdx.x;
+        Unit cur = decode(u);
+        auto stage = [&](int kt0, int nrows, int nrows16) {  // multi-tile path: straight to LDS
             for (int idx = tid; idx < nrows16 * F4; idx += 256) {
                 const int r = idx / F4, c4 = idx - r * F4;
                 float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
                 if (r < nrows) {
-                    const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
-                    kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
-                    vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+                    const long long row = cur.krow0 + (long long)(kt0 + r) * a.k_rs;
+                    kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + cur.h * DH + c4 * 4);
+                    vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + cur.h * DH + c4 * 4);
                 }
                 *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = kv;
                 *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
             }
         };
-        if (single_tile) {
-            stage(0, a.Sk, (a.Sk + 15) & ~15);
-            __syncthreads();
-        }
-        // the next q-block's fragment is fetched while the current one is being computed (no barrier inside this loop
-        // when K/V are resident, so the loads simply stay in flight under the MFMAs)
-        auto load_q = [&](int qb, float4 (&dst)[NC]) {
+        auto load_q = [&](const Unit& c, int qb, float4 (&dst)[NC]) {
             const int qi = qb * 64 + wave * 16 + c16;
             const bool ok = qb < a.nqb && qi < a.Sq;
-            const float* qp = a.q + (qrow0 + (long long)qi * a.q_rs) * a.ldq + h * DH + 4 * g4;
+            const float* qp = a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH + 4 * g4;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) dst[c] = ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < NC; ++j) dst[j] = ok ? *reinterpret_cast<const float4*>(qp + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
         };
-        float4 qnext[NC];
-        load_q(qs, qnext);
-        for (int qb = qs; qb < a.nqb; qb += a.qsplit) {
+        // ONE Q fragment buffer: it is only needed by the QK^T phase, so the next q-block's (or next unit's) fragment is
+        // loaded into it as soon as the last key tile's scores exist, and lands under the PV phase.  (scale is applied to the
+        // scores, not to q.)
+        float4 qf[NC];
+        load_q(cur, cur.qs, qf);
+        if (single_tile) {  // first unit: K straight in, V follows through the same buffer
+            fetch(a.k, a.ldk, cur);
+            commit(Ks, LDK);
+            fetch(a.v, a.ldv, cur);
+        }
+        for (; u < n_units; u += gridDim.x) {
+        const bool has_next = u + gridDim.x < n_units;
+        const Unit nxt = decode(has_next ? u + gridDim.x : u);
+        if (single_tile) {
+            __syncthreads();  // every wave is done with the previous unit's V
+            commit(Vs, LDV);
+            __syncthreads();  // K (committed mid-way through the previous unit) and V are visible
+            if (has_next) fetch(a.k, a.ldk, nxt);
+        }
+        const int h = cur.h, grp = cur.grp;
+        const long long qrow0 = cur.qrow0;
+        for (int qb = cur.qs; qb < a.nqb; qb += a.qsplit) {
             const int qi = qb * 64 + wave * 16 + c16;
             const bool q_ok = qi < a.Sq;
-            float4 qf[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                qf[c] = make_float4(qnext[c].x * a.scale, qnext[c].y * a.scale, qnext[c].z * a.scale, qnext[c].w * a.scale);
-            if (qb + a.qsplit < a.nqb) load_q(qb + a.qsplit, qnext);
             f32x4 oacc[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -273,10 +313,14 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
                         }
                         const int key0 = kt0 + t * 16 + 4 * g4;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < a.Sk) ? (a0[r] + a1[r]) : -INFINITY;
+                        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < a.Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
                     } else {
                         sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                     }
+                }
+                if (kt0 + 64 >= a.Sk) {  // q is dead for this q-block: fetch the next fragment into the same registers
+                    if (qb + a.qsplit < a.nqb) load_q(cur, qb + a.qsplit, qf);
+                    else if (has_next) load_q(nxt, nxt.qs, qf);
                 }
                 // ---- online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
                 float mx = -INFINITY;
@@ -310,6 +354,12 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
                         for (int r = 0; r < 4; ++r)
                             sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
                 }
+                if (single_tile && has_next && qb + a.qsplit >= a.nqb) {
+                    // last QK^T of this unit is done: Ks can take the next unit's K, and its V starts to travel
+                    __syncthreads();
+                    commit(Ks, LDK);
+                    fetch(a.v, a.ldv, nxt);
+                }
                 // ---- O^T += V^T P^T
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -330,10 +380,13 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnArgs a) {
                 store_o<NC>(a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH, g4, oacc, inv, a.o_sp16);
             }
         }
+        cur = nxt;
+        }
     }
 }
 
 int g_attn_target_blocks = 512;  // resident-K/V mode: blocks per launch (measured flat from 256 to 1024, worse above)
+int g_attn_resident_blocks = 512;  // shared mode: grid size cap (2 blocks per CU x 256 CUs)
 int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
 
 template <int DH>
@@ -373,8 +426,9 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
             if (qsplit > a.nqb) qsplit = a.nqb;
         }
         a.qsplit = qsplit;
-        const long long blocks = gh * qsplit;
+        long long blocks = gh * qsplit;  // units; the grid is capped at two resident blocks per CU, blocks walk the rest
         SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+        if (g_attn_variant != 0 && blocks > g_attn_resident_blocks) blocks = g_attn_resident_blocks;
         const size_t lds = (size_t)a.kv_rows * ((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
         hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     }
