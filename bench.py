@@ -117,11 +117,19 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # SOLA_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of this code path on a 1-GPU box;
+        # RCCL refuses two ranks on one device).  The driver's runs use the default: nccl (= RCCL), one rank per GPU.
+        backend = os.environ.get("SOLA_BENCH_BACKEND", "nccl")
+        dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     from sola_amd import _lib, synth
     from sola_amd.loss import track_selection_losses

@@ -40,3 +40,18 @@ def test_train_eval_inference_roundtrip(tmp_path):
     run("inference.py", "--eval_weight_epoch", "2")
     inf = tmp_path / "SOLA" / "INFERENCE" / "default" / "mevis" / "pred_threshold_05" / "epoch_2"
     assert len(list(inf.rglob("*_pred.npy"))) == 6
+
+
+def test_bench_two_ranks_code_path(tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks (gloo, both on cuda:0 - RCCL refuses two ranks per device): the
+    barrier / max-over-ranks / whole-job aggregation path the driver uses at N > 1 prints one well-formed JSON line."""
+    env = dict(os.environ, PYTHONPATH=ROOT, SOLA_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--cpu-seconds", "0"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "samples/s"
+    assert out["config"]["sharding"] == "per-sample x2" and "roofline" in out and "cpu_baseline" not in out
