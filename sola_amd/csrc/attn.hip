@@ -46,7 +46,6 @@ struct AttnArgs {
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
 // Store one query row's output tile.  op points at o[row][h*DH]; this lane holds d = 16c + 4*g4 + {0..3} of every chunk c.
 template <int NC>
 __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[NC], float inv, int sp16) {
@@ -73,8 +72,11 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
     }
 }
 
-template <int DH, bool PACKED>
-__global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) {
+// NW = waves per block of the shared mode (4: 64-query blocks, K/V tiles of up to 64 rows, two blocks per CU; 8: 128-query
+// blocks and a resident K/V tile of up to 128 rows for units of 65..128 keys, one block per CU).  The packed mode uses 4.
+template <int DH, bool PACKED, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs a) {
+    constexpr int NT = NW * 64;
     constexpr int NC = DH / 16;   // 16-wide head-dim chunks
     constexpr int LDK = DH + LDK_PAD;  // K pitch: ds_read_b128, 16 key rows per 16-lane group -> 16 distinct 16-B slots of the 64-bank line needs pitch = 4 (mod 64)
     constexpr int LDV = DH + 4;   // V pitch: ds_read_b32, the two 16-lane halves of a 32-lane group are 16 banks apart
@@ -216,24 +218,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
         auto fetch = [&](const float* base, int ld, const Unit& c) {
 #pragma unroll
             for (int i = 0; i < KVR; ++i) {
-                const int idx = tid + 256 * i;
+                const int idx = tid + NT * i;
                 const int r = idx / F4, c4 = idx - r * F4;
                 pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < a.Sk) pre[i] = *reinterpret_cast<const float4*>(base + (c.krow0 + (long long)r * a.k_rs) * ld + c.h * DH + c4 * 4);
             }
         };
-        auto commit = [&](float* dst, int pitch) {
+        auto put_k = [&](int r, int c4, const float4 v) { *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = v; };
+        auto put_v = [&](int r, int c4, const float4 v) { *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = v; };
+        auto commit = [&](bool is_k) {
 #pragma unroll
             for (int i = 0; i < KVR; ++i) {
-                const int idx = tid + 256 * i;
+                const int idx = tid + NT * i;
                 const int r = idx / F4, c4 = idx - r * F4;
-                if (r < res_rows16) *reinterpret_cast<float4*>(&dst[r * pitch + c4 * 4]) = pre[i];
+                if (r < res_rows16) {
+                    if (is_k) put_k(r, c4, pre[i]);
+                    else put_v(r, c4, pre[i]);
+                }
             }
         };
         long long u = blockIdx.x;
         Unit cur = decode(u);
         auto stage = [&](int kt0, int nrows, int nrows16) {  // multi-tile path: straight to LDS
-            for (int idx = tid; idx < nrows16 * F4; idx += 256) {
+            for (int idx = tid; idx < nrows16 * F4; idx += NT) {
                 const int r = idx / F4, c4 = idx - r * F4;
                 float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
                 if (r < nrows) {
@@ -241,12 +248,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
                     kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + cur.h * DH + c4 * 4);
                     vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + cur.h * DH + c4 * 4);
                 }
-                *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = kv;
-                *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
+                put_k(r, c4, kv);
+                put_v(r, c4, vv);
             }
         };
         auto load_q = [&](const Unit& c, int qb, float4 (&dst)[NC]) {
-            const int qi = qb * 64 + wave * 16 + c16;
+            const int qi = qb * (NW * 16) + wave * 16 + c16;
             const bool ok = qb < a.nqb && qi < a.Sq;
             const float* qp = a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH + 4 * g4;
 #pragma unroll
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
         load_q(cur, cur.qs, qf);
         if (single_tile) {  // first unit: K straight in, V follows through the same buffer
             fetch(a.k, a.ldk, cur);
-            commit(Ks, LDK);
+            commit(true);
             fetch(a.v, a.ldv, cur);
         }
         for (; u < n_units; u += gridDim.x) {
@@ -267,14 +274,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
         const Unit nxt = decode(has_next ? u + gridDim.x : u);
         if (single_tile) {
             __syncthreads();  // every wave is done with the previous unit's V
-            commit(Vs, LDV);
+            commit(false);
             __syncthreads();  // K (committed mid-way through the previous unit) and V are visible
             if (has_next) fetch(a.k, a.ldk, nxt);
         }
         const int h = cur.h, grp = cur.grp;
         const long long qrow0 = cur.qrow0;
         for (int qb = cur.qs; qb < a.nqb; qb += a.qsplit) {
-            const int qi = qb * 64 + wave * 16 + c16;
+            const int qi = qb * (NW * 16) + wave * 16 + c16;
             const bool q_ok = qi < a.Sq;
             f32x4 oacc[NC];
 #pragma unroll
@@ -289,13 +296,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
                     __syncthreads();
                 }
                 const int ntile = nrows16 >> 4;
+                const int kbase = single_tile ? kt0 : 0;  // a resident tile holds all keys; a restaged one starts at row 0
                 // ---- scores: s[t][r] = q(c16) . k(kt0 + 16t + 4*g4 + r)
                 f32x4 sc[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (t < ntile) {
                         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                        const float* kp = &Ks[(t * 16 + c16) * LDK + 4 * g4];
+                        const float* kp = &Ks[(kbase + t * 16 + c16) * LDK + 4 * g4];
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
                             const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
@@ -354,10 +362,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
                         for (int r = 0; r < 4; ++r)
                             sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
                 }
-                if (single_tile && has_next && qb + a.qsplit >= a.nqb) {
+                if (single_tile && has_next && qb + a.qsplit >= a.nqb && kt0 + 64 >= a.Sk) {
                     // last QK^T of this unit is done: Ks can take the next unit's K, and its V starts to travel
                     __syncthreads();
-                    commit(Ks, LDK);
+                    commit(true);
                     fetch(a.v, a.ldv, nxt);
                 }
                 // ---- O^T += V^T P^T
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const AttnArgs a) 
                     if (t < ntile) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float* vp = &Vs[(t * 16 + 4 * g4 + r) * LDV + c16];
+                            const float* vp = &Vs[(kbase + t * 16 + 4 * g4 + r) * LDV + c16];
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[c * 16], sc[t][r], oacc[c], 0, 0, 0);
@@ -389,20 +397,29 @@ int g_attn_target_blocks = 512;  // resident-K/V mode: blocks per launch (measur
 int g_attn_resident_blocks = 512;  // shared mode: grid size cap (2 blocks per CU x 256 CUs)
 int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
 
+template <int DH, int NW>
+static void launch_shared(const AttnArgs& a, long long blocks, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
+}
+
 template <int DH>
 int launch_dh(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
-    constexpr size_t lds_max = (size_t)64 * ((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
+    constexpr size_t row_bytes = (size_t)((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
     const bool packed = a.Sq <= 16 && a.Sk <= 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        attr_set = true;
-    }
     if (packed) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * row_bytes)));
+            attr_set = true;
+        }
         int need = a.Sq > a.Sk ? a.Sq : a.Sk, lg = 0;
         while ((1 << lg) < need) ++lg;
         if (g_attn_variant == 0) lg = 4;  // baseline: one unit per wave tile
@@ -412,12 +429,16 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         const long long tiles = (units + U - 1) / U;
         a.nqb = 1; a.kv_rows = 16; a.qsplit = 1;
         dim3 grid((unsigned)((tiles + 3) / 4));
-        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true>), grid, dim3(256), lds_max, s, a);
+        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true, 4>), grid, dim3(256), 64 * row_bytes, s, a);
     } else {
-        a.nqb = (a.Sq + 63) / 64;
+        // units of 65..128 keys: eight waves and a resident 128-row K/V tile (135 KB, one block per CU) instead of
+        // restaging two 64-row tiles for every q-block
+        const bool wide = g_attn_variant != 0 && a.Sk > 64 && a.Sk <= 128 && 128 * row_bytes <= 160 * 1024;
+        const int qrows = wide ? 128 : 64;
+        a.nqb = (a.Sq + qrows - 1) / qrows;
         a.sp_log2 = 4;
         const int r16 = (a.Sk + 15) & ~15;
-        a.kv_rows = g_attn_variant == 0 ? 64 : (r16 < 64 ? r16 : 64);
+        a.kv_rows = g_attn_variant == 0 ? 64 : (r16 < qrows ? r16 : qrows);
         const long long gh = (long long)a.G * a.H;
         int qsplit = a.nqb;
         if (g_attn_variant != 0 && a.Sk <= a.kv_rows) {  // K/V resident: loop q-blocks, keep >= ~1024 blocks in the grid
@@ -426,11 +447,13 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
             if (qsplit > a.nqb) qsplit = a.nqb;
         }
         a.qsplit = qsplit;
-        long long blocks = gh * qsplit;  // units; the grid is capped at two resident blocks per CU, blocks walk the rest
+        long long blocks = gh * qsplit;  // units; the grid is capped at the resident block count, blocks walk the rest
         SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
-        if (g_attn_variant != 0 && blocks > g_attn_resident_blocks) blocks = g_attn_resident_blocks;
-        const size_t lds = (size_t)a.kv_rows * ((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
-        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+        const long long resident = wide ? g_attn_resident_blocks / 2 : g_attn_resident_blocks;
+        if (g_attn_variant != 0 && blocks > resident) blocks = resident;
+        const size_t lds = (size_t)a.kv_rows * row_bytes;
+        if (wide) launch_shared<DH, 8>(a, blocks, lds, s);
+        else launch_shared<DH, 4>(a, blocks, lds, s);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;

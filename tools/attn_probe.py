@@ -3,15 +3,17 @@ import sys, torch
 sys.path.insert(0, "/root/repo")
 from sola_amd import ops, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-N, Tp, D, H, Wn = 64, 4, 1024, 8, 48
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+Tp = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+D, H, Wn = 1024, 8, 48
 M = B * N * Tp
 lib = _lib.lib()
 q, k, v = (torch.randn(M, D, device="cuda") for _ in range(3))
 lk, lv = torch.randn(B * Wn, D, device="cuda"), torch.randn(B * Wn, D, device="cuda")
 cases = {
-    "obj (Sq=Sk=64)": (lambda: ops.attention(q, k, v, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp)), 4 * M * D * 4),
-    "motion (Sq=Sk=4)": (lambda: ops.attention(q, k, v, B * N, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1)), 4 * M * D * 4),
-    "o2l (Sq=256,Sk=48)": (lambda: ops.attention(q, lk, lv, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1)), (2 * M + 2 * B * Wn) * D * 4),
+    f"obj (Sq=Sk={N})": (lambda: ops.attention(q, k, v, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp)), 4 * M * D * 4),
+    f"motion (Sq=Sk={Tp})": (lambda: ops.attention(q, k, v, B * N, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1)), 4 * M * D * 4),
+    f"o2l (Sq={N * Tp},Sk=48)": (lambda: ops.attention(q, lk, lv, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1)), (2 * M + 2 * B * Wn) * D * 4),
 }
 for name, (fn, nbytes) in cases.items():
     best, outs = {}, {}
@@ -25,5 +27,5 @@ for name, (fn, nbytes) in cases.items():
             e1.record(); torch.cuda.synchronize()
             best[var] = min(best.get(var, 1e9), e0.elapsed_time(e1) / 20)
     print(f"{name:22s} " + "  ".join(f"v{var}: {best[var]*1e3:7.1f} us {nbytes/best[var]/1e6:7.1f} GB/s ({nbytes/best[var]/1e6/8000*100:4.1f}% of 8 TB/s)" for var in (0, 1)),
-          " maxdiff", float((outs[0] - outs[1]).abs().max()))
+          " maxdiff", float((outs[0] - outs[1]).abs().max()), "scale", float(outs[0].abs().max()))
 lib.sola_tune(b"attn_variant", 1)
