@@ -162,6 +162,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    # The interpreter's cyclic garbage collector is parked for the timed region (as timeit does): with torch imported a full
+    # collection takes ~37 ms on the host, the GPU queue runs dry behind it, and where it lands is a matter of luck
+    # (tools/benchdbg.py: it was one 35-39 ms stall in the first timed step, +2-4 ms/step at the default 10-20 steps).
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -172,6 +178,7 @@ def main():
         loss3, pred = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     prof = _lib.profile_read(reset=True)
     _lib.profile_enable(False)
     assert torch.isfinite(loss3).all()

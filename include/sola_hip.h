@@ -80,9 +80,11 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
 int sola_set_precision(SolaCtx* ctx, int precision);
 /* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
 int sola_cast_sp16(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float scale, void* stream);
-/* C = out_scale * (A W^T) + bias (+ R) with A [M,K], W [N,K] (and optionally R) in the split-f16 format */
+/* C = out_scale * (A W^T) + bias (+ R) with A [M,K], W [N,K] (and optionally R) in the split-f16 format; C is written
+ * as f32, or as split-f16 pairs when c_is_split (N % 8 == 0) */
 int sola_gemm_nt_split(const float* dev_a_sp, int lda, const float* dev_w_sp, const float* dev_bias, const float* dev_r,
-                       int ldr, int r_is_split, float* dev_c, int ldc, int M, int N, int K, float out_scale, void* stream);
+                       int ldr, int r_is_split, float* dev_c, int ldc, int c_is_split, int M, int N, int K, float out_scale,
+                       void* stream);
 
 /* ---- forward: replaces LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162) ------------------ */
 size_t sola_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
@@ -184,6 +186,12 @@ int sola_grad_clip(float* const* dev_grads, const int64_t* numel, int n, const d
                    void* stream);
 /* per-stage backward entry points (parity tests) */
 int sola_ws_backward(const float* dev_w, const float* dev_dwstd, int cout, int cin, int k, float* dev_dw, void* stream);
+/* The same attention with q, k, v given as split-f16 rows: every product runs as three v_mfma_f32_16x16x16_f16 with f32
+ * accumulation instead of the exact-f32 MFMA (the inference fast path; sequences longer than 16 steps only). */
+int sola_attention_split(const float* dev_q_sp, int ldq, const float* dev_k_sp, int ldk, const float* dev_v_sp, int ldv,
+                         float* dev_o, int ldo, int o_is_split, int G, int H, int head_dim, int Sq, int Sk, int inner,
+                         int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
+                         int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, float* dev_lse, void* stream);
 /* C[N,K] = A[M,N]^T * B[M,K] (weight gradient), optional bias_grad[N] = column sums of A */
 size_t sola_gemm_tn_scratch_bytes(int M, int N, int K);
 int sola_gemm_tn(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, float* dev_bias_grad,

@@ -48,7 +48,7 @@ SIGNATURES = {
     "sola_set_ws_policy": (_i, [_vp, _i]),
     "sola_set_precision": (_i, [_vp, _i]),
     "sola_cast_sp16": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp]),
-    "sola_gemm_nt_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sola_gemm_nt_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sola_workspace_tap": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -59,6 +59,7 @@ SIGNATURES = {
     "sola_conv1d_cl": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sola_group_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp]),
     "sola_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp, _vp]),
+    "sola_attention_split": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp, _vp]),
     "sola_set_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
     "sola_set_stage_dropout": (_i, [_f, C.c_uint64]),
     "sola_train_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

@@ -85,6 +85,13 @@ SolaProfScope::~SolaProfScope() {
 extern "C" int sola_profile_enable(int enable) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.enabled = enable != 0;
+    // events are only recycled when the counters are read, so a timed region of K unsynchronised steps needs two per kernel
+    // launch per step: create them here, outside anybody's timed region (hipEventCreate costs 3-20 us a piece)
+    while (enable && g_prof.pool.size() < 8192) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        g_prof.pool.push_back(e);
+    }
     return SOLA_OK;
 }
 extern "C" int sola_profile_read(int64_t* launches, double* ms, double* flops, double* bytes, int reset) {
@@ -312,13 +319,13 @@ extern "C" int sola_cast_sp16(const float* in, int ld_in, float* out, int ld_out
 
 // split-f16 GEMM entry point (tests): a_sp [M,K] and w_sp [N,K] in the split format, f32 result
 extern "C" int sola_gemm_nt_split(const float* a_sp, int lda, const float* w_sp, const float* bias, const float* r, int ldr,
-                                  int r_sp16, float* cmat, int ldc, int M, int N, int K, float out_scale, void* stream_) {
+                                  int r_sp16, float* cmat, int ldc, int c_sp16, int M, int N, int K, float out_scale, void* stream_) {
     SOLA_ARG(a_sp && w_sp && cmat, "gemm_nt_split: null argument");
     GemmDesc gd{};
     gd.nprob = 1;
     gd.p[0] = GemmProblem{a_sp, w_sp, bias, r, cmat};
     gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
-    gd.arith = 1; gd.out_scale = out_scale; gd.r_sp16 = r_sp16;
+    gd.arith = 1; gd.out_scale = out_scale; gd.r_sp16 = r_sp16; gd.c_sp16 = c_sp16;
     return launch_gemm(gd, as_stream(stream_));
 }
 
@@ -530,6 +537,19 @@ extern "C" int sola_attention(const float* q, int ldq, const float* k, int ldk, 
     SOLA_ARG(q && k && v && o, "attention: null argument");
     AttnDesc d{q, k, v, o, ldq, ldk, ldv, ldo, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, lse};
     d.drop = g_stage_drop;
+    return launch_attention(d, as_stream(stream_));
+}
+
+// q, k, v given as split-f16 rows (sola_cast_sp16 or a split GEMM with c_is_split): the split-f16 MFMA shape of the kernel
+extern "C" int sola_attention_split(const float* q_sp, int ldq, const float* k_sp, int ldk, const float* v_sp, int ldv, float* o,
+                                    int ldo, int o_is_split, int G, int H, int head_dim, int Sq, int Sk, int inner,
+                                    int64_t q_outer, int64_t q_inner, int64_t q_rs, int64_t k_outer, int64_t k_inner, int64_t k_rs,
+                                    float scale, float* lse, void* stream_) {
+    SOLA_ARG(q_sp && k_sp && v_sp && o, "attention_split: null argument");
+    AttnDesc d{q_sp, k_sp, v_sp, o, ldq, ldk, ldv, ldo, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, lse};
+    d.drop = g_stage_drop;
+    d.o_sp16 = o_is_split;
+    d.in_sp16 = 1;
     return launch_attention(d, as_stream(stream_));
 }
 

@@ -43,9 +43,31 @@ struct AttnArgs {
     int qsplit;       // shared: blocks per (group, head); each handles q-blocks qs, qs + qsplit, ...
     int o_sp16;       // write o as split-f16 pairs (cast.hip) for the 3 x f16 MFMA out-projection
     int sp_log2;      // packed: log2 of the per-unit slot count SP (SP = pow2 >= max(Sq, Sk)), units per tile = 16 >> sp_log2
+    int in_sp16;      // shared: q, k, v are split-f16 rows (the SPLIT kernel shape)
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+// SPLIT shape of the shared mode (inference fast path): q, k, v arrive as split-f16 rows straight from the projection
+// GEMM's epilogue (every 8 values = 32 bytes [hi8 | lo8], cast.hip), so nothing is converted here; every product runs as
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x16_f16 with f32 accumulation (~22-bit products, as in gemm_glds.hip).  The
+// exact-f32 v_mfma_f32_16x16x4_f32 has 1/16 of that rate and made the kernel co-bound by the matrix pipe (218 us of MFMA
+// against 215 us of HBM at N = 128).  A lane's 4 consecutive head dims are (hi4, lo4) = two 8-byte pieces of one block.
+struct HL4 { half4v hi, lo; };
+__device__ __forceinline__ HL4 split4(float x, float y, float z, float w) {
+    HL4 r;
+    r.hi[0] = (_Float16)x; r.hi[1] = (_Float16)y; r.hi[2] = (_Float16)z; r.hi[3] = (_Float16)w;
+    r.lo[0] = (_Float16)(x - (float)r.hi[0]); r.lo[1] = (_Float16)(y - (float)r.hi[1]);
+    r.lo[2] = (_Float16)(z - (float)r.hi[2]); r.lo[3] = (_Float16)(w - (float)r.hi[3]);
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma3(const HL4& a, const HL4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.hi, c, 0, 0, 0);
+}
+
 // Store one query row's output tile.  op points at o[row][h*DH]; this lane holds d = 16c + 4*g4 + {0..3} of every chunk c.
 template <int NC>
 __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[NC], float inv, int sp16) {
@@ -74,7 +96,7 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
 
 // NW = waves per block of the shared mode (4: 64-query blocks, K/V tiles of up to 64 rows, two blocks per CU; 8: 128-query
 // blocks and a resident K/V tile of up to 128 rows for units of 65..128 keys, one block per CU).  The packed mode uses 4.
-template <int DH, bool PACKED, int NW>
+template <int DH, bool PACKED, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs a) {
     constexpr int NT = NW * 64;
     constexpr int NC = DH / 16;   // 16-wide head-dim chunks
@@ -255,9 +277,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         auto load_q = [&](const Unit& c, int qb, float4 (&dst)[NC]) {
             const int qi = qb * (NW * 16) + wave * 16 + c16;
             const bool ok = qb < a.nqb && qi < a.Sq;
-            const float* qp = a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH + 4 * g4;
+            if constexpr (SPLIT) {
+                // chunk j, lane slot g4 -> block 2j + (g4 >> 1), half (g4 & 1): hi4 and lo4 are 8 bytes each, 16 bytes apart;
+                // they travel in the two halves of the float4 slot
+                const char* qp = reinterpret_cast<const char*>(a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH) +
+                                 (g4 >> 1) * 32 + (g4 & 1) * 8;
 #pragma unroll
-            for (int j = 0; j < NC; ++j) dst[j] = ok ? *reinterpret_cast<const float4*>(qp + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < NC; ++j) {
+                    float2 hi = make_float2(0.f, 0.f), lo = hi;
+                    if (ok) {
+                        hi = *reinterpret_cast<const float2*>(qp + j * 64);
+                        lo = *reinterpret_cast<const float2*>(qp + j * 64 + 16);
+                    }
+                    dst[j] = make_float4(hi.x, hi.y, lo.x, lo.y);
+                }
+            } else {
+                const float* qp = a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH + 4 * g4;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) dst[j] = ok ? *reinterpret_cast<const float4*>(qp + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto as_hl4 = [](const float2 hi, const float2 lo) {
+            HL4 r;
+            r.hi = __builtin_bit_cast(half4v, hi);
+            r.lo = __builtin_bit_cast(half4v, lo);
+            return r;
         };
         // ONE Q fragment buffer: it is only needed by the QK^T phase, so the next q-block's (or next unit's) fragment is
         // loaded into it as soon as the last key tile's scores exist, and lands under the PV phase.  (scale is applied to the
@@ -304,6 +348,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                     if (t < ntile) {
                         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                         const float* kp = &Ks[(kbase + t * 16 + c16) * LDK + 4 * g4];
+                        if constexpr (SPLIT) {
+                            // A = K rows as (hi4, lo4) of head dims 16c + 4*g4 .. +3: two 8-byte reads of block 2c + (g4 >> 1)
+                            const char* kb = reinterpret_cast<const char*>(&Ks[(kbase + t * 16 + c16) * LDK]) + (g4 >> 1) * 32 + (g4 & 1) * 8;
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                const HL4 kf = as_hl4(*reinterpret_cast<const float2*>(kb + c * 64), *reinterpret_cast<const float2*>(kb + c * 64 + 16));
+                                const HL4 qq = as_hl4(make_float2(qf[c].x, qf[c].y), make_float2(qf[c].z, qf[c].w));
+                                if (c & 1) a1 = mfma3(kf, qq, a1);
+                                else a0 = mfma3(kf, qq, a0);
+                            }
+                        } else
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
                             const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
@@ -372,6 +427,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (t < ntile) {
+                        if constexpr (SPLIT) {
+                            // A = V^T: row d = 16c + c16, k = keys 16t + 4*g4 + {0..3}: element (key, d) of the split-f16 row is the
+                            // half at block d/8, slot d%8 (hi) and +16 bytes (lo); B = P from the score registers, split here
+                            const HL4 ps = split4(sc[t][0], sc[t][1], sc[t][2], sc[t][3]);
+                            const char* vb = reinterpret_cast<const char*>(&Vs[(kbase + t * 16 + 4 * g4) * LDV]) + (c16 >> 3) * 32 + (c16 & 7) * 2;
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                HL4 vf;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    vf.hi[j] = *reinterpret_cast<const _Float16*>(vb + j * (LDV * 4) + c * 64);
+                                    vf.lo[j] = *reinterpret_cast<const _Float16*>(vb + j * (LDV * 4) + c * 64 + 16);
+                                }
+                                oacc[c] = mfma3(vf, ps, oacc[c]);
+                            }
+                        } else
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float* vp = &Vs[(kbase + t * 16 + 4 * g4 + r) * LDV + c16];
@@ -397,15 +468,15 @@ int g_attn_target_blocks = 512;  // resident-K/V mode: blocks per launch (measur
 int g_attn_resident_blocks = 512;  // shared mode: grid size cap (2 blocks per CU x 256 CUs)
 int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
 
-template <int DH, int NW>
+template <int DH, int NW, bool SPLIT>
 static void launch_shared(const AttnArgs& a, long long blocks, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW, SPLIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false, NW, SPLIT>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
 }
 
 template <int DH>
@@ -413,10 +484,12 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     constexpr size_t row_bytes = (size_t)((DH + LDK_PAD) + (DH + 4)) * sizeof(float);
     const bool packed = a.Sq <= 16 && a.Sk <= 16;
+    SOLA_ARG(!(packed && a.in_sp16), "attention: split-f16 q/k/v are not supported for sequences of <= 16 steps (packed shape)");
+    SOLA_ARG(!a.in_sp16 || DH % 16 == 0, "attention: split-f16 q/k/v need head_dim %% 16 == 0");
     if (packed) {
         static bool attr_set = false;
         if (!attr_set) {
-            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true, 4>),
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true, 4, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * row_bytes)));
             attr_set = true;
         }
@@ -429,7 +502,7 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         const long long tiles = (units + U - 1) / U;
         a.nqb = 1; a.kv_rows = 16; a.qsplit = 1;
         dim3 grid((unsigned)((tiles + 3) / 4));
-        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true, 4>), grid, dim3(256), 64 * row_bytes, s, a);
+        hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, true, 4, false>), grid, dim3(256), 64 * row_bytes, s, a);
     } else {
         // units of 65..128 keys: eight waves and a resident 128-row K/V tile (135 KB, one block per CU) instead of
         // restaging two 64-row tiles for every q-block
@@ -452,8 +525,13 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         const long long resident = wide ? g_attn_resident_blocks / 2 : g_attn_resident_blocks;
         if (g_attn_variant != 0 && blocks > resident) blocks = resident;
         const size_t lds = (size_t)a.kv_rows * row_bytes;
-        if (wide) launch_shared<DH, 8>(a, blocks, lds, s);
-        else launch_shared<DH, 4>(a, blocks, lds, s);
+        if (a.in_sp16) {
+            if (wide) launch_shared<DH, 8, true>(a, blocks, lds, s);
+            else launch_shared<DH, 4, true>(a, blocks, lds, s);
+        } else {
+            if (wide) launch_shared<DH, 8, false>(a, blocks, lds, s);
+            else launch_shared<DH, 4, false>(a, blocks, lds, s);
+        }
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -477,6 +555,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.lse = d.lse;
     a.drop = d.drop;
     a.o_sp16 = d.o_sp16;
+    a.in_sp16 = d.in_sp16;
     a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

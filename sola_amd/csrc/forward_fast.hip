@@ -107,7 +107,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
 
     const float scale = 1.0f / sqrtf((float)DH);
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, int layer, int attn, int nprob, int rows, float* o0,
-                       float* o1, float* o2, int first_proj) -> int {
+                       float* o1, float* o2, int first_proj, int out_sp16) -> int {
         static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
         const std::string an = "object_lang_align_layers." + std::to_string(layer) + "." + kAttnLong[attn];
         const float* as[3] = {a0, a1, a2};
@@ -117,7 +117,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         for (int j = 0; j < nprob; ++j)
             gd.p[j] = GemmProblem{as[j], lin16(layer, attn, first_proj + j), W(an + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
         gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
-        gd.arith = 1; gd.out_scale = 1.f / kLinScale;
+        gd.arith = 1; gd.out_scale = 1.f / kLinScale; gd.c_sp16 = out_sp16;
         return launch_gemm(gd, s);
     };
     auto out_proj = [&](int layer, int attn, const float* resid, int resid_sp16) -> int {
@@ -141,11 +141,17 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         return launch_group_norm(nd, s);
     };
     auto attention = [&](const float* q, const float* k, const float* v, int G, int Sq, int Sk, int inner, long long qo,
-                         long long qi, long long qr, long long ko, long long ki, long long kr) -> int {
+                         long long qi, long long qr, long long ko, long long ki, long long kr, int in_sp16) -> int {
         AttnDesc ad{q, k, v, buf("attn"), D, D, D, D, G, H, DH, Sq, Sk, inner, qo, qi, qr, ko, ki, kr, scale, nullptr};
         ad.o_sp16 = 1;
+        ad.in_sp16 = in_sp16;
         return launch_attention(ad, s);
     };
+    // q/k/v leave the projection GEMM already split when the attention that reads them runs the split-f16 MFMA shape.
+    // Measured (tools/attn_probe.py): with <= 64 keys per unit the exact-f32 MFMA kernel is as fast or faster (the kernel
+    // is then bound by latency and LDS traffic, not by the matrix pipe); with 65..128 keys the split shape wins by 14 %.
+    const int obj_sp = (N > 64 && DH % 16 == 0) ? 1 : 0;
+    const int o2l_sp = (Wn > 64 && DH % 16 == 0) ? 1 : 0;
 
     const float* xin = buf("conv5_sp");  // split-f16 A operand of the layer
     const float* xres = buf("conv5");    // residual of the first sub-block (f32 for layer 0, split-f16 afterwards)
@@ -160,19 +166,20 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         float* x_mot = buf(ls + "_motion");
         float* x_o2l = buf(ls + "_o2l");
         // (i) inter-object attention (module.py:31-35)
-        SOLA_TRY(linear3(xin, xin, xin, l, 0, 3, M, q, k, v, 0));
-        SOLA_TRY(attention(q, k, v, B * Tp, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp));
+        SOLA_TRY(linear3(xin, xin, xin, l, 0, 3, M, q, k, v, 0, obj_sp));
+        SOLA_TRY(attention(q, k, v, B * Tp, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, obj_sp));
         SOLA_TRY(out_proj(l, 0, xres, xres_sp));
         SOLA_TRY(gn(lp, 0, x_obj, x_pe, 1, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
         // (ii) motion attention (module.py:38-43)
-        SOLA_TRY(linear3(x_pe, x_pe, x_obj, l, 1, 3, M, q, k, v, 0));
-        SOLA_TRY(attention(q, k, v, B * N, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1));
+        const int mot_sp = (Tp > 64 && DH % 16 == 0) ? 1 : 0;
+        SOLA_TRY(linear3(x_pe, x_pe, x_obj, l, 1, 3, M, q, k, v, 0, mot_sp));
+        SOLA_TRY(attention(q, k, v, B * N, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, mot_sp));
         SOLA_TRY(out_proj(l, 1, x_obj, 1));
         SOLA_TRY(gn(lp, 1, x_mot, nullptr, 1, B * N, 1, Tp, 0, 1, Tp));
         // (iii) object -> language attention (module.py:46-50)
-        SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0));
-        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1));
-        SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1));
+        SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0, o2l_sp));
+        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1, o2l_sp));
+        SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, o2l_sp));
         SOLA_TRY(out_proj(l, 2, x_mot, 1));
         SOLA_TRY(gn(lp, 2, x_o2l, nullptr, last ? 0 : 1, B, 1, (long long)N * Tp, 0, 1, N * Tp));  // the score head reads f32
         xin = x_o2l;

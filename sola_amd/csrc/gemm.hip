@@ -23,6 +23,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, xcd_remap;
     float out_scale;  // result multiplier (power of two undoing the weight pre-scale of the split-f16 path)
     int r_sp16;       // residual R is stored as split-f16 pairs
+    int c_sp16;       // C is written as split-f16 pairs
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -262,7 +263,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
                             v += pr.R[(long long)m * a.ldr + n];
                         }
                     }
-                    pr.C[(long long)m * a.ldc + n] = v;
+                    if (a.c_sp16) {  // element n of block n/8: hi[n%8] | lo[n%8]
+                        _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7));
+                        const _Float16 hi = (_Float16)v;
+                        cb[n & 7] = hi;
+                        cb[8 + (n & 7)] = (_Float16)(v - (float)hi);
+                    } else {
+                        pr.C[(long long)m * a.ldc + n] = v;
+                    }
                 }
             }
         }
@@ -314,6 +322,8 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.tiles_m = a.tiles_n = a.xcd_remap = 0;
     a.out_scale = d.arith == 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
     a.r_sp16 = d.r_sp16;
+    a.c_sp16 = d.arith == 1 ? d.c_sp16 : 0;
+    SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
     const bool glds = d.arith == 1 && big && g_gemm_glds && gemm_split_glds_supported(d);

@@ -38,7 +38,7 @@ struct GldsArgs {
     int conv, T_in, T_out, stride, pad, Cin;
     int tiles_m, tiles_n, xcd_remap;
     float out_scale;
-    int r_sp16;
+    int r_sp16, c_sp16;
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 1 = no DMA after the first tiles, 4 = no epilogue
                  // (no switch around the MFMAs: control flow there makes the compiler shuttle the accumulators AGPR<->VGPR)
 };
@@ -266,7 +266,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
                         if (n + e < a.N) v[e] += pr.R[(long long)m * a.ldr + n + e];
                 }
             }
-            if (vec_ok) {
+            if (a.c_sp16) {
+                // 4 consecutive columns of one 8-wide block: hi[4] and lo[4] leave as two aligned 8-byte stores
+                _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+                half4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                *reinterpret_cast<half4*>(cb) = hh;
+                *reinterpret_cast<half4*>(cb + 8) = ll;
+            } else if (vec_ok) {
                 *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
@@ -323,6 +331,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
     a.r_sp16 = d.r_sp16;
+    a.c_sp16 = d.c_sp16;
     a.ablate = g_gemm_ablate;
     const int shape = gemm_split_glds_shape(d);
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);

@@ -21,6 +21,7 @@ struct GemmDesc {
     int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate)
     float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
     int r_sp16;       // arith 1: the residual R is split-f16
+    int c_sp16;       // arith 1: write C as split-f16 pairs (N % 8 == 0), e.g. q/k/v for the split attention kernel
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 
@@ -54,6 +55,7 @@ struct AttnDesc {
     float* lse;  // optional [q rows][H]
     DropoutCfg drop;  // on the probabilities (tools/attention.py:71)
     int o_sp16;       // output as split-f16 pairs
+    int in_sp16;      // q, k, v are split-f16 rows (written by a GEMM with c_sp16); not for sequences of <= 16 steps
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 

@@ -66,8 +66,9 @@ def decode_sp16(x_sp):
     return (h[:, :, 0, :] + h[:, :, 1, :]).reshape(rows, K)
 
 
-def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False, out_scale=1.0):
-    """out_scale * (A W^T) + bias (+ residual) on split-f16 operands (three f16 MFMAs per product, f32 accumulate)."""
+def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False, out_scale=1.0, out_split=False):
+    """out_scale * (A W^T) + bias (+ residual) on split-f16 operands (three f16 MFMAs per product, f32 accumulate);
+    ``out_split`` writes the result as split-f16 pairs (decode with ``decode_sp16``)."""
     require_cuda(a_sp, w_sp, bias, residual)
     a_sp, w_sp = _f32c(a_sp), _f32c(w_sp)
     M, K = a_sp.shape
@@ -75,7 +76,8 @@ def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False,
     out = torch.empty((M, N), device=a_sp.device, dtype=torch.float32)
     check(lib().sola_gemm_nt_split(ptr(a_sp), K, ptr(w_sp), ptr(None if bias is None else _f32c(bias)),
                                    ptr(None if residual is None else _f32c(residual)), N, 1 if residual_is_split else 0,
-                                   ptr(out), N, M, N, K, float(out_scale), current_stream(a_sp.device)), "sola_gemm_nt_split")
+                                   ptr(out), N, 1 if out_split else 0, M, N, K, float(out_scale), current_stream(a_sp.device)),
+          "sola_gemm_nt_split")
     return out
 
 
@@ -122,6 +124,21 @@ def attention(q, k, v, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None, return_l
                                inner, q_addr[0], q_addr[1], q_addr[2], k_addr[0], k_addr[1], k_addr[2], scale, ptr(lse),
                                current_stream(q.device)), "sola_attention")
     return (o, lse) if return_lse else o
+
+
+def attention_split(q_sp, k_sp, v_sp, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None, out_split=False):
+    """``attention`` on split-f16 q, k, v (``cast_sp16`` rows): three f16 MFMAs per product, f32 accumulation."""
+    require_cuda(q_sp, k_sp, v_sp)
+    q_sp, k_sp, v_sp = _f32c(q_sp), _f32c(k_sp), _f32c(v_sp)
+    D = q_sp.shape[-1]
+    dh = D // H
+    o = torch.zeros_like(q_sp)
+    scale = 1.0 / math.sqrt(dh) if scale is None else scale
+    check(lib().sola_attention_split(ptr(q_sp), D, ptr(k_sp), k_sp.shape[-1], ptr(v_sp), v_sp.shape[-1], ptr(o), D,
+                                     1 if out_split else 0, G, H, dh, Sq, Sk, inner, q_addr[0], q_addr[1], q_addr[2],
+                                     k_addr[0], k_addr[1], k_addr[2], scale, None, current_stream(q_sp.device)),
+          "sola_attention_split")
+    return o
 
 
 def attention_backward(q, k, v, o, dout, lse, G, H, Sq, Sk, inner, q_addr, k_addr, scale=None):

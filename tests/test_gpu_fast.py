@@ -128,3 +128,57 @@ def test_small_cases_in_split_mode(small_golden, ci):
     ref = g["tap.l1_motion"]
     got = ops.decode_sp16(m.workspace_tap("l1_motion")).cpu().numpy().reshape(ref.shape)
     assert np.abs(got - ref).max() <= 3e-4 * max(1.0, np.abs(ref).max())
+
+
+def _attn_ref64(q, k, v, H):
+    G, Sq, D = q.shape
+    dh = D // H
+    qh = q.reshape(G, Sq, H, dh).transpose(0, 2, 1, 3)
+    kh = k.reshape(G, -1, H, dh).transpose(0, 2, 1, 3)
+    vh = v.reshape(G, -1, H, dh).transpose(0, 2, 1, 3)
+    s = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(dh)
+    s = s - s.max(axis=-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(axis=-1, keepdims=True)
+    return (p @ vh).transpose(0, 2, 1, 3).reshape(G, Sq, D)
+
+
+@pytest.mark.parametrize("B,N,Tp,D", [(1, 64, 4, 1024), (2, 80, 1, 1024), (1, 130, 2, 128), (1, 20, 25, 128), (1, 128, 2, 1024), (2, 17, 3, 256)])
+def test_split_attention_kernel_vs_float64(B, N, Tp, D):
+    """sola_attention_split (q, k, v as split-f16 rows, three f16 MFMAs per product) in the inter-object and
+    object->language layouts, f32 and split-f16 output, against float64 softmax attention: f32-class error."""
+    H = 8
+    rng = np.random.default_rng(N * Tp + D)
+    q, k, v = (rng.standard_normal((B, N, Tp, D)).astype(np.float32) for _ in range(3))
+    q64, k64, v64 = (t.astype(np.float64) for t in (q, k, v))
+    dev = lambda t: torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    qs, ks, vs = (ops.cast_sp16(dev(t).reshape(B * N * Tp, D)) for t in (q, k, v))
+    tr = lambda t: np.transpose(t, (0, 2, 1, 3)).reshape(B * Tp, N, D)
+    ref = _attn_ref64(tr(q64), tr(k64), tr(v64), H).reshape(B, Tp, N, D).transpose(0, 2, 1, 3)
+    got = ops.attention_split(qs, ks, vs, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp)).reshape(B, N, Tp, D).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    exact = ops.attention(dev(q).reshape(-1, D), dev(k).reshape(-1, D), dev(v).reshape(-1, D), B * Tp, H, N, N, Tp,
+                          (N * Tp, 1, Tp), (N * Tp, 1, Tp)).reshape(B, N, Tp, D).cpu().numpy()
+    assert np.abs(got - ref).max() <= 4 * np.abs(exact - ref).max() + 2e-6  # same class as the exact-f32 MFMA kernel
+    got16 = ops.decode_sp16(ops.attention_split(qs, ks, vs, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp), out_split=True))
+    assert np.abs(got16.reshape(B, N, Tp, D).cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    for Wn in (48, 37, 70):
+        lk, lv = (rng.standard_normal((B, Wn, D)).astype(np.float32) for _ in range(2))
+        ref = _attn_ref64(q64.reshape(B, N * Tp, D), lk.astype(np.float64), lv.astype(np.float64), H).reshape(B, N, Tp, D)
+        got = ops.attention_split(qs, ops.cast_sp16(dev(lk).reshape(B * Wn, D)), ops.cast_sp16(dev(lv).reshape(B * Wn, D)), B, H, N * Tp,
+                                  Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1)).reshape(B, N, Tp, D).cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (Wn, np.abs(got - ref).max())
+
+
+def test_split_gemm_split_output():
+    """c_is_split: the GEMM writes its result as split-f16 pairs (what the split attention reads)."""
+    rng = np.random.default_rng(3)
+    for (M, N, K) in [(16384, 1024, 1024), (300, 72, 96), (4096, 512, 768)]:
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        asp, wsp = ops.cast_sp16(torch.from_numpy(a).cuda()), ops.cast_sp16(torch.from_numpy(w).cuda(), 64.0)
+        ref = ops.gemm_nt_split(asp, wsp, torch.from_numpy(b).cuda(), out_scale=1 / 64)
+        got = ops.decode_sp16(ops.gemm_nt_split(asp, wsp, torch.from_numpy(b).cuda(), out_scale=1 / 64, out_split=True))
+        err = (got - ref).abs().max().item()
+        assert err <= 2.0 ** -21 * ref.abs().max().item() + 1e-7, (M, N, K, err)

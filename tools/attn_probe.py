@@ -29,3 +29,19 @@ for name, (fn, nbytes) in cases.items():
     print(f"{name:22s} " + "  ".join(f"v{var}: {best[var]*1e3:7.1f} us {nbytes/best[var]/1e6:7.1f} GB/s ({nbytes/best[var]/1e6/8000*100:4.1f}% of 8 TB/s)" for var in (0, 1)),
           " maxdiff", float((outs[0] - outs[1]).abs().max()), "scale", float(outs[0].abs().max()))
 lib.sola_tune(b"attn_variant", 1)
+# the split-f16 MFMA shape on q, k, v already stored as split-f16 rows (what the fast forward path runs)
+qs, ks, vs = (ops.cast_sp16(t) for t in (q, k, v)); lks, lvs = ops.cast_sp16(lk), ops.cast_sp16(lv)
+split_cases = {
+    f"obj split (Sq=Sk={N})": (lambda: ops.attention_split(qs, ks, vs, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp), out_split=True), 4 * M * D * 4),
+    f"o2l split (Sq={N * Tp},Sk=48)": (lambda: ops.attention_split(qs, lks, lvs, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1), out_split=True), (2 * M + 2 * B * Wn) * D * 4),
+}
+if N > 16:
+    for name, (fn, nbytes) in split_cases.items():
+        fn(); torch.cuda.synchronize(); best = 1e9
+        for rnd in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): fn()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20)
+        print(f"{name:28s} {best*1e3:7.1f} us {nbytes/best/1e6:7.1f} GB/s ({nbytes/best/1e6/8000*100:4.1f}% of 8 TB/s)")
