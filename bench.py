@@ -164,7 +164,7 @@ def main():
 
     # The interpreter's cyclic garbage collector is parked for the timed region (as timeit does): with torch imported a full
     # collection takes ~37 ms on the host, the GPU queue runs dry behind it, and where it lands is a matter of luck
-    # (tools/benchdbg.py: it was one 35-39 ms stall in the first timed step, +2-4 ms/step at the default 10-20 steps).
+    # (tools/gc_stall_probe.py: it was one 35-39 ms stall in the first timed step, +2-4 ms/step at the default 10-20 steps).
     import gc
     gc.collect()
     gc.disable()
