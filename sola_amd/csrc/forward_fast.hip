@@ -79,7 +79,11 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
         GemmDesc gd{};
         gd.nprob = 1;
-        gd.p[0] = GemmProblem{x, c->ws16_buf + c->ws_off[i], W(cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
+        // conv5 (no norm behind it) feeds layer 0 both as the projections' A operand and as the first residual: its
+        // epilogue writes the split-f16 form directly, no f32 copy and no cast pass
+        const bool last_conv = i == 5 && g.cout % 8 == 0;
+        gd.p[0] = GemmProblem{x, c->ws16_buf + c->ws_off[i], W(cp + ".bias"), nullptr, last_conv ? buf("conv5_sp") : buf("conv" + std::to_string(i))};
+        gd.c_sp16 = last_conv ? 1 : 0;
         gd.M = R * p.Tl[i]; gd.N = g.cout; gd.K = g.k * g.cin;
         gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
         gd.conv = g.k > 1 ? 1 : 0;
@@ -99,7 +103,8 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         }
         t_in = p.Tl[i];
     }
-    SOLA_TRY(launch_cast_sp16(buf("conv5"), D, buf("conv5_sp"), D, M, D, 1.f, s));
+    const bool conv5_split = c->conv[5].cout % 8 == 0;
+    if (!conv5_split) SOLA_TRY(launch_cast_sp16(buf("conv5"), D, buf("conv5_sp"), D, M, D, 1.f, s));
 
     SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
     SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
@@ -154,8 +159,8 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
     const int o2l_sp = (Wn > 64 && DH % 16 == 0) ? 1 : 0;
 
     const float* xin = buf("conv5_sp");  // split-f16 A operand of the layer
-    const float* xres = buf("conv5");    // residual of the first sub-block (f32 for layer 0, split-f16 afterwards)
-    int xres_sp = 0;
+    const float* xres = conv5_split ? buf("conv5_sp") : buf("conv5");  // residual of the first sub-block
+    int xres_sp = conv5_split ? 1 : 0;
     for (int l = 0; l < c->cfg.n_layers; ++l) {
         const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
         const std::string ls = "l" + std::to_string(l);
