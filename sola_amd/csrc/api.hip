@@ -253,6 +253,7 @@ extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
 
 void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
+void sola_gemm_set_splitk(int v);
 void sola_gemm_set_ablate(int v);
 void sola_gn_set_variant(int v);
 void sola_bilinear_set_staged(int v);
@@ -262,6 +263,7 @@ extern "C" int sola_tune(const char* key, int value) {
     SOLA_ARG(key, "tune: null key");
     if (!strcmp(key, "gemm_variant")) { sola_gemm_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
+    if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gn_variant")) { sola_gn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "bilinear_staged")) { sola_bilinear_set_staged(value); return SOLA_OK; }

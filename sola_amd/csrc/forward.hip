@@ -22,6 +22,8 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
         p.add("conv" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
         if (i < 5) p.add("act" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
     }
+    // single-sample regime: scratch for the two-pass split-K of the GEMMs whose grid is smaller than the chip (gemm.hip)
+    if ((long long)B * N * p.Tp <= 8192) p.add("splitk", 8192, 1024);
     p.add("pe", p.Tp, D);
     p.add("lang", (int64_t)B * p.W, D);
     p.add("lbar", B, D);
@@ -72,6 +74,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     SOLA_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "forward: workspace must be 256-byte aligned");
     char* base = static_cast<char*>(workspace);
     auto buf = [&](const std::string& name) { return reinterpret_cast<float*>(base + p.bufs.at(name).off); };
+    float* const splitk_ws = p.bufs.count("splitk") ? buf("splitk") : nullptr;
+    const size_t splitk_bytes = splitk_ws ? (size_t)p.bufs.at("splitk").rows * p.bufs.at("splitk").cols * sizeof(float) : 0;
     auto W = [&](const std::string& name) { return ctx_weight(c, name); };
     const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
     const int Tp = p.Tp, M = p.M, Wn = p.W;
@@ -101,6 +105,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
+        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
@@ -135,6 +140,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             gd.p[j] = GemmProblem{as[j], W(attn + "." + pn[first_proj + j] + ".weight"),
                                   W(attn + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
         gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
+        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         return launch_gemm(gd, s);
     };
     auto out_proj = [&](const std::string& attn, const float* ao, const float* resid, float* res) -> int {
@@ -142,6 +148,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.nprob = 1;
         gd.p[0] = GemmProblem{ao, W(attn + ".out_proj.weight"), W(attn + ".out_proj.bias"), resid, res};
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
+        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         return launch_gemm(gd, s);
     };
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,

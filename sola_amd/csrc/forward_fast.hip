@@ -36,6 +36,8 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
     SOLA_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "forward: workspace must be 256-byte aligned");
     char* base = static_cast<char*>(workspace);
     auto buf = [&](const std::string& name) { return reinterpret_cast<float*>(base + p.bufs.at(name).off); };
+    float* const splitk_ws = p.bufs.count("splitk") ? buf("splitk") : nullptr;
+    const size_t splitk_bytes = splitk_ws ? (size_t)p.bufs.at("splitk").rows * p.bufs.at("splitk").cols * sizeof(float) : 0;
     auto W = [&](const std::string& name) { return ctx_weight(c, name); };
     const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
     const int Tp = p.Tp, M = p.M, Wn = p.W;
@@ -89,6 +91,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
         gd.arith = 1; gd.out_scale = 1.f;
+        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
@@ -123,6 +126,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
             gd.p[j] = GemmProblem{as[j], lin16(layer, attn, first_proj + j), W(an + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
         gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
         gd.arith = 1; gd.out_scale = 1.f / kLinScale; gd.c_sp16 = out_sp16;
+        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         return launch_gemm(gd, s);
     };
     auto out_proj = [&](int layer, int attn, const float* resid, int resid_sp16) -> int {
@@ -132,6 +136,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         gd.p[0] = GemmProblem{buf("attn"), lin16(layer, attn, 3), W(an + ".out_proj.bias"), resid, buf("res")};
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         gd.arith = 1; gd.out_scale = 1.f / kLinScale; gd.r_sp16 = resid_sp16;
+        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         return launch_gemm(gd, s);
     };
     auto gn = [&](const std::string& lp, int idx, float* y, float* y2, int sp16, int n_inst, int inner, long long outer,

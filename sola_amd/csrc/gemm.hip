@@ -12,6 +12,8 @@
 // k = 8s+{0..3}, lanes 32-63 take k = 8s+{4..7}; operands A and B use the same k permutation so the sum is unchanged.
 // Double-buffered LDS, one barrier per 32-deep k-tile; the next tile's global loads are in flight during the MFMAs.
 // Up to three problems that share all dimensions run in one launch (q/k/v projections) via blockIdx.z.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -24,6 +26,9 @@ struct GemmArgs {
     float out_scale;  // result multiplier (power of two undoing the weight pre-scale of the split-f16 path)
     int r_sp16;       // residual R is stored as split-f16 pairs
     int c_sp16;       // C is written as split-f16 pairs
+    int ksplit;       // > 1: blockIdx.y owns k-tiles [y*kt_per, (y+1)*kt_per) and writes raw partial sums to `part`
+    int kt_per;
+    float* part;      // [nprob][ksplit][M][N]
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -211,30 +216,33 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
         }
     };
 
+    // split-K: this block's share of the k-tiles
+    const int ktb = a.ksplit > 1 ? (int)blockIdx.y * a.kt_per : 0;
+    const int kte = a.ksplit > 1 ? min(nk, ktb + a.kt_per) : nk;
     if constexpr (PIPE == 0) {
         // simple schedule: loads of tile k+1 in flight during tile k; LDS store + barrier at the tile boundary
-        load_tile(0);
+        load_tile(ktb * BK);
         store_tile(0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        for (int kt = ktb; kt < kte; ++kt) {
+            const int buf = (kt - ktb) & 1;
+            if (kt + 1 < kte) load_tile((kt + 1) * BK);
             compute(buf, 0, BK / 8);
-            if (kt + 1 < nk) store_tile(buf ^ 1);
+            if (kt + 1 < kte) store_tile(buf ^ 1);
             __syncthreads();
         }
     } else {
         // deeper schedule: the registers always hold tile k+1 on entry; its LDS store and the global loads of tile
         // k+2 are issued in the MIDDLE of tile k's MFMA stream, so the tile boundary is a bare barrier + fragment read
-        load_tile(0);
+        load_tile(ktb * BK);
         store_tile(0);
-        if (nk > 1) load_tile(BK);
+        if (ktb + 1 < kte) load_tile((ktb + 1) * BK);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
+        for (int kt = ktb; kt < kte; ++kt) {
+            const int buf = (kt - ktb) & 1;
             compute(buf, 0, BK / 16);
-            if (kt + 1 < nk) store_tile(buf ^ 1);
-            if (kt + 2 < nk) load_tile((kt + 2) * BK);
+            if (kt + 1 < kte) store_tile(buf ^ 1);
+            if (kt + 2 < kte) load_tile((kt + 2) * BK);
             compute(buf, BK / 16, BK / 8);
             __syncthreads();
         }
@@ -243,6 +251,22 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31;
     const int row_l = (lane >> 5) << 2;
+    if (a.ksplit > 1) {  // raw partial sums; splitk_reduce_kernel applies scale, bias, residual and the output format
+        float* part = a.part + ((long long)blockIdx.z * a.ksplit + blockIdx.y) * a.M * a.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 32 + col_l;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                    if (m < a.M) part[(long long)m * a.N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wc * (BN / 2) + j * 32 + col_l;
@@ -277,6 +301,48 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     }
 }
 
+// Second pass of the split-K: C = out_scale * (sum over the S partials, in index order) + bias (+ R), 4 columns per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
+    const GemmProblem pr = a.p[blockIdx.z];
+    const int n4 = a.N >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+    const float* part = a.part + (long long)blockIdx.z * a.ksplit * a.M * a.N + (long long)m * a.N + n;
+    float4 sum = *reinterpret_cast<const float4*>(part);
+    for (int sidx = 1; sidx < a.ksplit; ++sidx) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (long long)sidx * a.M * a.N);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    float v[4] = {sum.x * a.out_scale, sum.y * a.out_scale, sum.z * a.out_scale, sum.w * a.out_scale};
+    if (pr.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += pr.bias[n + e];
+    }
+    if (pr.R) {
+        if (a.r_sp16) {
+            const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rb[e] + (float)rb[8 + e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += pr.R[(long long)m * a.ldr + n + e];
+        }
+    }
+    if (a.c_sp16) {
+        _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 hi = (_Float16)v[e];
+            cb[e] = hi;
+            cb[8 + e] = (_Float16)(v[e] - (float)hi);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pr.C[(long long)m * a.ldc + n + e] = v[e];
+    }
+}
+
 template <int BM, int BN, int PIPE, int ARITH>
 int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     GemmArgs a = base;
@@ -290,18 +356,25 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(a.tiles_m * a.tiles_n, 1, nprob);
+    dim3 grid(a.tiles_m * a.tiles_n, a.ksplit > 1 ? a.ksplit : 1, nprob);
     hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>), grid, dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const long long quads = (long long)a.M * (a.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256), 1, nprob), dim3(256), 0, s, a);
+        SOLA_LAUNCH_CHECK();
+    }
     return SOLA_OK;
 }
 
+int g_gemm_splitk = 1;  // 0 disables the split-K of small grids (A/B)
 int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 by 5%, mid-tile staging on 64x64 by 6%), 0 / 1 force
 
 }  // namespace
 
 int g_gemm_glds = 3;  // split-f16 GEMM, direct-to-LDS staging (gemm_glds.hip): 0 off, 1 128x128 blocks, 4 256x256 blocks, 3 auto
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
+void sola_gemm_set_splitk(int v) { g_gemm_splitk = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s);
@@ -323,6 +396,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.out_scale = d.arith == 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
     a.r_sp16 = d.r_sp16;
     a.c_sp16 = d.arith == 1 ? d.c_sp16 : 0;
+    a.ksplit = 1; a.kt_per = 0; a.part = nullptr;
     SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
@@ -332,6 +406,22 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
     const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
+    // small grids (fewer 64x64 tiles than CUs, the single-sample regime): split K over up to 8 blocks per tile so the
+    // serial k-loop gets ~8x shorter; partial sums go through the caller's scratch and are reduced in a fixed order
+    {
+        const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nprob;
+        const int nk_all = (d.K + BK - 1) / BK;
+        if (g_gemm_splitk && !big && d.splitk_ws && t64 < 256 && nk_all >= 8 && d.N % 4 == 0 && d.ldc % 4 == 0 && (!a.c_sp16 || d.N % 8 == 0)) {
+            long long S = std::min<long long>(8, std::min<long long>(nk_all / 4, (512 + t64 - 1) / t64));
+            const long long per_split = (long long)d.nprob * d.M * d.N * 4;
+            S = std::min<long long>(S, (long long)(d.splitk_bytes / (size_t)per_split));
+            if (S >= 2) {
+                a.kt_per = (int)((nk_all + S - 1) / S);
+                a.ksplit = (nk_all + a.kt_per - 1) / a.kt_per;  // no empty split
+                a.part = d.splitk_ws;
+            }
+        }
+    }
     if (glds) return launch_gemm_split_glds(d, s);
     if (d.arith == 1) {
         SOLA_ARG(d.K % 16 == 0 && (d.conv ? d.Cin % 8 == 0 : d.lda % 8 == 0), "split-f16 gemm: K %% 16 and row pitch %% 8 required");

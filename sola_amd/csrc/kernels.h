@@ -22,6 +22,10 @@ struct GemmDesc {
     float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
     int r_sp16;       // arith 1: the residual R is split-f16
     int c_sp16;       // arith 1: write C as split-f16 pairs (N % 8 == 0), e.g. q/k/v for the split attention kernel
+    // optional scratch for the two-pass split-K of small grids (fewer 64x64 tiles than CUs): S partial sums per problem,
+    // [nprob][S][M][N] f32, reduced in a fixed order (deterministic).  Null = never split.
+    float* splitk_ws;
+    size_t splitk_bytes;
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 

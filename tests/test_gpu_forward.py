@@ -110,7 +110,10 @@ def test_full_ns_vs_float64_oracle(full_model):
 
 def test_batch_independence_and_track_permutation(full_model):
     """Size-independent properties at the north-star shape: samples of a batch do not interact (GroupNorm statistics
-    never cross samples) and the network is permutation-equivariant over tracks."""
+    never cross samples) and the network is permutation-equivariant over tracks.  A one-sample call runs its GEMMs
+    split over K (small grids), a batched one does not, so the two differ by fp32 summation order: each sits within the
+    fp32 noise floor of this network from the float64 value (<= 5e-4, see test_full_ns_vs_float64_oracle), so they are
+    compared at the north-star bound of 1e-3, not at zero."""
     m, _ = full_model
     cfg = synth.DEFAULT_MODEL_CFG
     inp = synth.make_inputs(cfg, 3, 64, 32, 16, 31)
@@ -119,8 +122,8 @@ def test_batch_independence_and_track_permutation(full_model):
         sm, st = m(obj, lang)
         for b in range(3):
             sm1, st1 = m(obj[b:b + 1], lang[b:b + 1])
-            assert (sm1[0] - sm[b]).abs().max().item() <= 2e-4
-            assert (st1[0] - st[b]).abs().max().item() <= 2e-4
+            assert (sm1[0] - sm[b]).abs().max().item() <= 1e-3
+            assert (st1[0] - st[b]).abs().max().item() <= 1e-3
         perm = torch.randperm(64, generator=torch.Generator().manual_seed(0)).cuda()
         smp, stp = m(obj[:, perm], lang)
     assert (smp - sm[:, perm]).abs().max().item() <= 2e-4
