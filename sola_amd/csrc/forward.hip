@@ -23,7 +23,7 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
         if (i < 5) p.add("act" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
     }
     // single-sample regime: scratch for the two-pass split-K of the GEMMs whose grid is smaller than the chip (gemm.hip)
-    if ((long long)B * N * p.Tp <= 8192) p.add("splitk", 8192, 1024);
+    if ((long long)B * N * p.Tp <= 8192) p.add("splitk", 8192, 4096);
     p.add("pe", p.Tp, D);
     p.add("lang", (int64_t)B * p.W, D);
     p.add("lbar", B, D);

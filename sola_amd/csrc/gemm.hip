@@ -368,13 +368,14 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
 }
 
 int g_gemm_splitk = 1;  // 0 disables the split-K of small grids (A/B)
+int g_gemm_splitk_tiles = 512;  // grids with fewer 64x64 tiles than this are split (target: twice as many blocks)
 int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 by 5%, mid-tile staging on 64x64 by 6%), 0 / 1 force
 
 }  // namespace
 
 int g_gemm_glds = 3;  // split-f16 GEMM, direct-to-LDS staging (gemm_glds.hip): 0 off, 1 128x128 blocks, 4 256x256 blocks, 3 auto
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
-void sola_gemm_set_splitk(int v) { g_gemm_splitk = v; }
+void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_splitk_tiles = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s);
@@ -411,8 +412,8 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nprob;
         const int nk_all = (d.K + BK - 1) / BK;
-        if (g_gemm_splitk && !big && d.splitk_ws && t64 < 256 && nk_all >= 8 && d.N % 4 == 0 && d.ldc % 4 == 0 && (!a.c_sp16 || d.N % 8 == 0)) {
-            long long S = std::min<long long>(8, std::min<long long>(nk_all / 4, (512 + t64 - 1) / t64));
+        if (g_gemm_splitk && !big && d.splitk_ws && t64 < g_gemm_splitk_tiles && nk_all >= 8 && d.N % 4 == 0 && d.ldc % 4 == 0 && (!a.c_sp16 || d.N % 8 == 0)) {
+            long long S = std::min<long long>(8, std::min<long long>(nk_all / 4, (2 * g_gemm_splitk_tiles + t64 - 1) / t64));
             const long long per_split = (long long)d.nprob * d.M * d.N * 4;
             S = std::min<long long>(S, (long long)(d.splitk_bytes / (size_t)per_split));
             if (S >= 2) {

@@ -7,9 +7,11 @@ from sola_amd.module import LanguageAlignedTrackSelectionModule
 cfg = synth.DEFAULT_MODEL_CFG
 m = LanguageAlignedTrackSelectionModule(cfg); m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()})
 m = m.cuda().eval()
+from sola_amd import _lib
+if len(sys.argv) > 1: _lib.lib().sola_tune(b"gemm_splitk", int(sys.argv[1]))
 for prec in ("f16x3", "f32"):
     m.precision = prec
-    for (B, N, T) in [(1, 64, 32), (1, 16, 32), (1, 128, 128), (8, 64, 32)]:
+    for (B, N, T) in [(1, 64, 32), (1, 16, 32), (1, 128, 128), (4, 64, 32), (8, 64, 32), (16, 64, 32)]:
         inp = synth.make_inputs(cfg, B, N, T, 16, 3)
         obj, lang = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
         labels, pos = torch.from_numpy(inp["labels"]).cuda(), torch.from_numpy(inp["pos_tokens"]).cuda()
