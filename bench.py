@@ -258,7 +258,7 @@ def main():
                     roofline["traffic_kernel"] = gk
                     roofline["traffic"] = kk[gk]["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = tr["source"]
-                ak = [kk[k]["hbm_bytes_per_launch"] for k in ("attn_fwd_f32_kernel<128, false>", "attn_fwd_f32_kernel<128, true>") if k in kk]
+                ak = [kk[k]["hbm_bytes_per_launch"] for k in ("attn_fwd_f32_kernel<128, false, 4, false>", "attn_fwd_f32_kernel<128, true, 4, false>") if k in kk]
                 if len(ak) == 2:
                     roofline_attn["traffic"] = int((2 * ak[0] + ak[1]) / 3)  # obj + o2l (shared K/V) and motion (packed) launches
         out = {
