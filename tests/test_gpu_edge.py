@@ -54,3 +54,15 @@ def test_bad_inputs_raise(model):
                 m(obj[:, :0], lang)                     # no tracks
             with pytest.raises(SolaError):
                 m(obj[0], lang)                         # missing batch dimension
+
+
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 4)), int(rng.integers(1, 41)), int(rng.integers(1, 71)), int(rng.integers(1, 21))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("shape", _random_shapes(12, 2024))
+def test_random_shapes_both_precisions(model, shape):
+    """Seeded random (B, N, T, L): every kernel-selection branch (packed / shared / wide attention, 64x64 / split-K /
+    direct-to-LDS GEMMs, wave / block GroupNorm units) is reached by some of them."""
+    test_edge_shapes_both_precisions(model, shape)
