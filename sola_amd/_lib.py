@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsola_hip.so")
+LIB_PATH = os.environ.get("SOLA_HIP_LIB") or os.path.join(_HERE, "lib", "libsola_hip.so")  # override: kernel experiments only
 
 
 class SolaLibraryError(RuntimeError):

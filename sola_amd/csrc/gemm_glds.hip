@@ -29,6 +29,7 @@
 // tried and dropped: a 256x128 / 3-stage shape (DMA two tiles ahead: no faster, latency was not the bound) and
 // sched_group_barrier interleaving of fragment reads (+2-5 % on 64x64 wave tiles only, subsumed by this schedule).
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -36,11 +37,11 @@ struct GldsArgs {
     GemmProblem p[3];
     int M, N, K, lda, ldr, ldc;
     int conv, T_in, T_out, stride, pad, Cin;
-    int tiles_m, tiles_n, xcd_remap;
+    int tiles_m, tiles_n, xcd_remap, nprob;
     float out_scale;
     int r_sp16, c_sp16;
-    int ablate;  // measurement only (sola_tune "gemm_ablate"): 1 = no DMA after the first tiles, 4 = no epilogue
-                 // (no switch around the MFMAs: control flow there makes the compiler shuttle the accumulators AGPR<->VGPR)
+    int stagger_phases, stagger_ticks;  // first-round start offsets (see the kernel); ticks of the 100 MHz wall clock
+    int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -80,6 +81,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     }
     const int m0 = rt * GBM, n0 = ct * GBN;
 
+    // Phase stagger.  All tiles of a launch take the same time, so without it every CU reaches its epilogue at the same
+    // moment: the matrix pipes idle while HBM takes the whole C (+ residual) burst, then HBM idles during the next loop.
+    // The blocks of the FIRST round (one per CU) start `phase / phases` of a tile time late; later blocks inherit the
+    // offset of the block they replace, so from then on a fraction of the CUs is always in its epilogue.
+    if (a.stagger_phases > 1 && blockIdx.z == 0 && blockIdx.x < 256) {
+        const int phase = (blockIdx.x >> 3) % a.stagger_phases;
+        const long long wait = (long long)a.stagger_ticks * phase / a.stagger_phases;
+        const long long t0 = wall_clock64();
+        while ((long long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+
     // ---- DMA coordinates: this wave owns row groups wave*APW + i (8 rows each) of the A tile and wave*WPW + i of the
     //      W tile; lane -> (row = rg*8 + lane/8, physical 16-byte chunk = lane%8).  Each piece keeps a running source
     //      pointer that advances 128 B per k-tile: also for the implicit-im2col conv, where the receptive field of an
@@ -110,9 +122,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         w_ptr[i] = reinterpret_cast<const char*>(pr.W + (long long)n * a.K) + (chunk ^ ((r >> 1) & 7)) * 16;
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int nk = a.K / GBK;
     int conv_kk = 0, conv_c = 0;  // CONV: tap index and channel offset of the next k-tile to issue (uniform)
+    int dma_kt = 0;               // index of the next k-tile to issue
 
-    // issues k-tiles in increasing order, one per call
+    // Issues k-tiles in increasing order, one per call.  It is called once per loop iteration without a condition (the
+    // eight pieces are interleaved with the MFMAs by sched_group_barrier, which needs one basic block): past the last
+    // k-tile the pointers stop advancing, so the surplus calls re-read the last k-tile into a stage nobody reads.
     auto issue = [&](int stage) {
         char* sbase = lds + stage * STAGE_BYTES;
 #pragma unroll
@@ -120,17 +136,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
             const char* src = a_ptr[i];
             if (CONV) src = (unsigned)(a_t0[i] + conv_kk) < (unsigned)a.T_in ? src : zero;  // zero padding in time
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
-            a_ptr[i] += GBK * 4;
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             __builtin_amdgcn_global_load_lds((gptr_t)w_ptr[i], (lptr_t)(sbase + GBM * ROWB + (wave * WPW + i) * 1024), 16, 0, 0);
-            w_ptr[i] += GBK * 4;
         }
-        if (CONV) {
-            conv_c += GBK;
-            if (conv_c == a.Cin) { conv_c = 0; ++conv_kk; }
+        const bool more = dma_kt + 1 < nk;
+        const int adv = more ? GBK * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_ptr[i] += adv;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) w_ptr[i] += adv;
+        if (CONV) {  // branch-free: a branch here would split the basic block the DMA is interleaved in
+            conv_c += more ? GBK : 0;
+            const bool wrap = conv_c == a.Cin;
+            conv_c = wrap ? 0 : conv_c;
+            conv_kk += wrap ? 1 : 0;
         }
+        ++dma_kt;
     };
 
     f32x16 acc[MI][2];
@@ -173,15 +196,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
             }
     };
 
-    const int nk = a.K / GBK;
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int stage = 0;
     Frags f0, f1;
     load_frags(lds, 0, f0);
-    if (nk > 1 && !(a.ablate & 1)) issue(1);
+    issue(1);
     constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;  // fragment reads and MFMAs of one half
+    constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;  // one DMA piece behind every DMA_GAP MFMAs of the second half
     for (int kt = 0; kt < nk; ++kt) {
         // Each half = one MFMA batch with the NEXT half's fragment reads issued right behind its first MFMA.  The compiler
         // waits lgkmcnt(0) in front of a batch (scalar loads in the loop keep it from counting LDS returns), so reads
@@ -195,16 +218,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (issued one tile time ago)
         __syncthreads();                                   // ... and nobody reads this stage any more
-        if (kt + 2 < nk && !(a.ablate & 1)) issue(stage);
         __builtin_amdgcn_sched_barrier(0);
+        // The eight DMA pieces of k-tile kt+2 are spread over this half's MFMAs: issued back to back behind the barrier
+        // by all eight waves at once they queue in the CU's one texture-address unit (1 KiB per instruction = 16 clocks),
+        // and a wave stuck at a full memory queue issues no MFMAs either (measured: +800 clocks per k-tile).
         load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);  // past the last tile this reads stale LDS and is never used
+        issue(stage);  // after the reads in program order: the compiler cannot tell the two stages apart and keeps LDS accesses ordered
         mfmas(f1);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+#pragma unroll
+        for (int g = 0; g < NDMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
         __builtin_amdgcn_sched_barrier(0);
         stage ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA of the last iterations must not land in the epilogue's staging
+    __syncthreads();
 
     // ---- epilogue: the accumulators (one column per lane, 16 scattered rows) go through this wave's 16 KiB of the
     //      now idle stage buffers, 64 rows at a time, and leave as whole 16-byte row pieces (16 lanes cover one 256-byte
@@ -286,6 +319,393 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     }
 }
 
+
+// ---- persistent 256x256 variant ----------------------------------------------------------------------------------
+// One block per CU walks tiles blockIdx.x, +gridDim.x, ...  What the one-tile-per-block kernel above loses between
+// tiles (measured, M=65536 N=K=1024: loop 70 us per tile, + ~12 us of DMA start-up and block turnover, + 20 us
+// epilogue, 30 us with a residual) is removed by treating the k-tiles of ALL the block's tiles as one DMA stream:
+//   * while tile t runs its last two k-tiles the DMA already fetches k-tiles 0 and 1 of tile t+1 (the source pointers
+//     are switched to the next tile's rows when the stream crosses the boundary), so a tile starts with its
+//     fragments in LDS and no pipeline fill;
+//   * the epilogue does not touch the stage buffers: each wave transposes its accumulators through a private 4-KiB
+//     strip (16 rows x 64 columns) in the 32 KiB of LDS above the stages, eight strips per wave tile, with no block
+//     barrier (LDS executes one wave's instructions in order), and its stores drain under the next tile's MFMAs.
+// gfx950 counts loads and stores in one in-order vmcnt, so the first k-tile wait of a tile would also wait for the
+// store acknowledgements of the epilogue before it; that wait names the number of stores instead (the DMA of k-tile 1
+// is older than every one of them).
+// RMODE: 0 = no residual, 1 = f32 residual, 2 = split-f16 residual; CSP: the output is written as split-f16 pairs.  They are
+// compile-time so that the epilogue is straight-line code (with run-time flags the residual registers of the fast path
+// flow through phi nodes the register allocator keeps - and spills - across the whole tile loop).
+template <bool CONV, int RMODE, bool CSP>
+__global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
+    constexpr int MI = 4, WAVES_N = 4, GBM = 256, GBN = 256, NWAVE = 8;
+    constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
+    constexpr int APW = GBM / 8 / NWAVE, WPW = GBN / 8 / NWAVE;
+    constexpr int STRIP_ROWS = 16;
+    constexpr int RB = 4;  // strips per residual batch (16 registers each)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int tiles_per_prob = a.tiles_m * a.tiles_n;
+    const int total = tiles_per_prob * a.nprob;
+    const int nk = a.K / GBK;
+
+    auto decode = [&](int tile, int& z, int& m0, int& n0) {
+        z = tile / tiles_per_prob;
+        const int bid = tile - z * tiles_per_prob;
+        int rt, ct;
+        if (a.xcd_remap) {
+            const int x = bid & 7, j = bid >> 3;
+            rt = x + 8 * (j / a.tiles_n);
+            ct = j % a.tiles_n;
+        } else {
+            rt = bid / a.tiles_n;
+            ct = bid % a.tiles_n;
+        }
+        m0 = rt * GBM;
+        n0 = ct * GBN;
+    };
+
+    // ---- DMA stream state (same piece layout as the kernel above)
+    const int lrow = lane >> 3, chunk = lane & 7;
+    const char* a_ptr0;  // piece 0's running source pointer; pieces 1.. are a_ptr0 + a_d[i] (rows of a tile ascend in memory)
+    const char* w_ptr0;
+    int a_d[APW], w_d[WPW];
+    int a_t0[APW];
+    int conv_kk = 0, conv_c = 0;
+    int dma_kt = 0;  // next k-tile of the DMA stream within its tile
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    auto setup_dma = [&](int tile) {
+        int z, m0, n0;
+        decode(tile, z, m0, n0);
+        const float* A = a.p[z].A;
+        const float* Wt = a.p[z].W;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int r = (wave * APW + i) * 8 + lrow;
+            const int col_bytes = (chunk ^ ((r >> 1) & 7)) * 16;
+            const int m = min(m0 + r, a.M - 1);
+            const char* p;
+            if (CONV) {
+                const int rr = m / a.T_out, to = m - rr * a.T_out;
+                a_t0[i] = to * a.stride - a.pad;
+                p = reinterpret_cast<const char*>(A) + ((long long)rr * a.T_in + a_t0[i]) * a.Cin * 4 + col_bytes;
+            } else {
+                a_t0[i] = 0;
+                p = reinterpret_cast<const char*>(A + (long long)m * a.lda) + col_bytes;
+            }
+            if (i == 0) a_ptr0 = p;
+            a_d[i] = (int)(p - a_ptr0);
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int r = (wave * WPW + i) * 8 + lrow;
+            const int n = min(n0 + r, a.N - 1);
+            const char* p = reinterpret_cast<const char*>(Wt + (long long)n * a.K) + (chunk ^ ((r >> 1) & 7)) * 16;
+            if (i == 0) w_ptr0 = p;
+            w_d[i] = (int)(p - w_ptr0);
+        }
+        conv_kk = 0;
+        conv_c = 0;
+        dma_kt = 0;
+    };
+    auto issue = [&](int stage) {
+        char* sbase = lds + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const char* src = a_ptr0 + a_d[i];
+            if (CONV) src = (unsigned)(a_t0[i] + conv_kk) < (unsigned)a.T_in ? src : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr0 + w_d[i]), (lptr_t)(sbase + GBM * ROWB + (wave * WPW + i) * 1024), 16, 0, 0);
+        }
+        // past the last k-tile of the last tile the stream re-reads that k-tile (see the one-tile kernel)
+        const bool more = dma_kt + 1 < nk;
+        const int adv = more ? GBK * 4 : 0;
+        a_ptr0 += adv;
+        w_ptr0 += adv;
+        if (CONV) {  // branch-free: a branch here would split the basic block the DMA is interleaved in
+            conv_c += more ? GBK : 0;
+            const bool wrap = conv_c == a.Cin;
+            conv_c = wrap ? 0 : conv_c;
+            conv_kk += wrap ? 1 : 0;
+        }
+        ++dma_kt;
+    };
+
+    const int fr = lane & 31, fh = lane >> 5, key = (lane >> 1) & 7;
+    const int a_frag = (wr * MI * 32 + fr) * ROWB, w_frag = GBM * ROWB + (wc * 64 + fr) * ROWB;
+    struct Frags { half8 ah[MI], al[MI], bh[2], bl[2]; };
+    auto load_frags = [&](const char* sbase, int s16, Frags& f) {
+        const int hi_off = (((s16 * 2 + fh) * 2) ^ key) << 4;
+        const int lo_off = hi_off ^ 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* q = sbase + w_frag + j * 32 * ROWB;
+            f.bh[j] = *reinterpret_cast<const half8*>(q + hi_off);
+            f.bl[j] = *reinterpret_cast<const half8*>(q + lo_off);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const char* p = sbase + a_frag + i * 32 * ROWB;
+            f.ah[i] = *reinterpret_cast<const half8*>(p + hi_off);
+            f.al[i] = *reinterpret_cast<const half8*>(p + lo_off);
+        }
+    };
+    f32x16 acc[MI][2];
+    auto mfmas = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    if (a.stagger_phases > 1) {
+        // start offsets of up to stagger_ticks (100 MHz wall clock) so that the CUs do not hit L2 / HBM in lockstep
+        const int phase = (blockIdx.x >> 3) % a.stagger_phases;
+        const long long wait = (long long)a.stagger_ticks * phase / a.stagger_phases;
+        const long long t0 = wall_clock64();
+        while ((long long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
+    }
+    bool prev_fast = false;  // the previous tile of this block left through the interior epilogue
+    setup_dma(tile);
+    issue(0);
+    issue(1);  // nk >= 2 (checked by the launcher)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");  // k-tile 0 is the older half of what is in flight
+    __syncthreads();
+    int stage = 0;
+    constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;
+    constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
+    for (; tile < total; tile += gridDim.x) {
+        int z, m0, n0;
+        decode(tile, z, m0, n0);
+        const int next = tile + gridDim.x;
+        const bool has_next = next < total;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // k-tile 0 of this tile is in LDS (waited for and published by the barrier of the previous tile's last k-tile, or by
+        // the prologue).  Its first fragments are fetched here rather than kept in registers across the epilogue.
+        Frags f0, f1;
+        load_frags(lds + stage * STAGE_BYTES, 0, f0);
+        // One k-tile.  The k-loop itself must stay free of conditions: a scalar branch in front of the barrier (the relaxed
+        // wait below) or behind it (switching the DMA stream to the next tile) cost 10 % and 2 % of the loop (measured,
+        // one tile per CU), so the first k-tile is peeled for the wait and the last two for the stream switch.
+        auto ktile = [&](auto first) {
+            load_frags(lds + stage * STAGE_BYTES, 1, f1);
+            mfmas(f0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // k-tile kt+1 has landed.  At kt == 0 behind an interior tile's epilogue that is k-tile 1, issued BEFORE the
+            // epilogue's stores: naming the store count (32 float4 or 64 half4 stores per wave; the counter is in order)
+            // waits for the DMA without waiting for the stores to be acknowledged.
+            if (decltype(first)::value && prev_fast) {
+                if (CSP) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);  // after the last k-tile: unused
+            issue(stage);
+            mfmas(f1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+            for (int g = 0; g < NDMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage ^= 1;
+        };
+        // k-tile kt issues the DMA of k-tile kt+2; from kt = nk-2 on that is the next tile's stream
+        int kt = 1;
+        if (nk == 2 && has_next) setup_dma(next);
+        ktile(std::true_type{});
+        for (; kt < nk - 2; ++kt) ktile(std::false_type{});
+        if (nk > 2 && has_next) setup_dma(next);
+        for (; kt < nk; ++kt) ktile(std::false_type{});
+        if (a.ablate & 4) continue;
+
+        // ---- epilogue: eight 16-row strips per wave tile through this wave's private LDS strip
+        const GemmProblem pr = a.p[z];
+        // Everything the epilogue derives from the lane id goes through an opaque copy made here: otherwise the row
+        // offsets of all 32 passes (64-bit, tile-invariant) are hoisted out of the tile loop and live - spilled - across
+        // the k-loop.
+        int le = tid;
+        asm volatile("" : "+v"(le));
+        const int lane_e = le & 63, wave_e = le >> 6;
+        const int fh_e = lane_e >> 5;
+        float* strip = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave_e * (STRIP_ROWS * 64);
+        const int col_l = lane_e & 31;
+        const int c4 = lane_e & 15, rsub = lane_e >> 4;
+        const int wr_e = wave_e / WAVES_N, wc_e = wave_e % WAVES_N;
+        const int n = n0 + wc_e * 64 + c4 * 4;
+        const bool vec_ok = (a.ldc & 3) == 0 && n + 3 < a.N && (RMODE != 1 || (a.ldr & 3) == 0);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr.bias) {
+            bv.x = n < a.N ? pr.bias[n] : 0.f;
+            bv.y = n + 1 < a.N ? pr.bias[n + 1] : 0.f;
+            bv.z = n + 2 < a.N ? pr.bias[n + 2] : 0.f;
+            bv.w = n + 3 < a.N ? pr.bias[n + 3] : 0.f;
+        }
+        // Interior tiles (every row and column in range, 16-byte aligned rows) take a straight-line path: no per-lane
+        // predicates, so the number of stores a wave issues is known (see the relaxed wait at the next tile's first
+        // k-tile), and the residual is fetched four strips ahead (64 registers; the fragment registers are dead here).
+        // vmcnt is one in-order counter for loads and stores: a residual load issued between stores would have to wait for
+        // the acknowledgement of every store before it, so the loads of a batch are issued together, in front of its stores.
+        const bool interior = m0 + GBM <= a.M && n0 + GBN <= a.N && (a.ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
+        prev_fast = interior;
+        if (interior) {
+#pragma unroll
+            for (int b = 0; b < 8 / RB; ++b) {
+                f32x4 rbuf[RB * 4];
+                if (RMODE) {
+#pragma unroll
+                    for (int sp = 0; sp < RB * 4; ++sp) {
+                        const int st = b * RB + (sp >> 2), pass = sp & 3;  // strip 0..7 = (i, hf)
+                        const int m = m0 + wr_e * 128 + (st >> 1) * 32 + (st & 1) * 16 + pass * 4 + rsub;
+                        if (RMODE == 2) {
+                            const char* rb = reinterpret_cast<const char*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4) * 2;
+                            const float2 h = *reinterpret_cast<const float2*>(rb), l = *reinterpret_cast<const float2*>(rb + 16);
+                            rbuf[sp] = f32x4{h.x, h.y, l.x, l.y};
+                        } else {
+                            rbuf[sp] = *reinterpret_cast<const f32x4*>(pr.R + (long long)m * a.ldr + n);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < RB; ++sl) {
+                    const int st = b * RB + sl, i = st >> 1, hf = st & 1;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int row = (q & 3) + 8 * (q >> 2) + 4 * fh_e;
+                            const int col = (j * 32 + col_l) ^ (fh_e << 5);
+                            strip[row * 64 + col] = acc[i][j][hf * 8 + q];
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int row = pass * 4 + rsub;
+                        const int m = m0 + wr_e * 128 + i * 32 + hf * 16 + row;
+                        const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
+                        float v[4] = {t.x * a.out_scale + bv.x, t.y * a.out_scale + bv.y, t.z * a.out_scale + bv.z, t.w * a.out_scale + bv.w};
+                        if (RMODE) {
+                            const f32x4 rv = rbuf[sl * 4 + pass];
+                            if (RMODE == 2) {
+                                const half4 hh = __builtin_bit_cast(half4, float2{rv[0], rv[1]}), ll = __builtin_bit_cast(half4, float2{rv[2], rv[3]});
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)hh[e] + (float)ll[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                            }
+                        }
+                        if (CSP) {
+                            _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+                            half4 hh, ll;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                            *reinterpret_cast<half4*>(cb) = hh;
+                            *reinterpret_cast<half4*>(cb + 8) = ll;
+                        } else {
+                            *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                // rows of a 32x32 accumulator block held by this lane: (r & 3) + 8 * (r >> 2) + 4 * fh_e; r = hf*8 .. hf*8+7
+                // are strip rows (q & 3) + 8 * (q >> 2) + 4 * fh.  Bit 2 of the strip row (= fh) flips the column's bit 5
+                // so the two half waves write different banks.
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int row = (q & 3) + 8 * (q >> 2) + 4 * fh_e;
+                        const int col = (j * 32 + col_l) ^ (fh_e << 5);
+                        strip[row * 64 + col] = acc[i][j][hf * 8 + q];
+                    }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = pass * 4 + rsub;
+                    const int m = m0 + wr_e * 128 + i * 32 + hf * 16 + row;
+                    const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
+                    if (m >= a.M) continue;
+                    float v[4] = {t.x * a.out_scale + bv.x, t.y * a.out_scale + bv.y, t.z * a.out_scale + bv.z, t.w * a.out_scale + bv.w};
+                    if (RMODE) {
+                        if (RMODE == 2) {
+                            const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
+                            if (n + 3 < a.N) {
+                                const half4 hh = *reinterpret_cast<const half4*>(rb), ll = *reinterpret_cast<const half4*>(rb + 8);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)hh[e] + (float)ll[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < a.N) v[e] += (float)rb[e] + (float)rb[8 + e];
+                            }
+                        } else if (vec_ok) {
+                            const float4 rv = *reinterpret_cast<const float4*>(pr.R + (long long)m * a.ldr + n);
+                            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < a.N) v[e] += pr.R[(long long)m * a.ldr + n + e];
+                        }
+                    }
+                    if (CSP) {
+                        _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+                        half4 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                        *reinterpret_cast<half4*>(cb) = hh;
+                        *reinterpret_cast<half4*>(cb + 8) = ll;
+                    } else if (vec_ok) {
+                        *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < a.N) pr.C[(long long)m * a.ldc + n + e] = v[e];
+                    }
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool gemm_split_glds_supported(const GemmDesc& d) {
@@ -300,11 +720,12 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = (M + GBM - 1) / GBM;
     a.tiles_n = (N + GBN - 1) / GBN;
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
-    constexpr size_t lds = (size_t)2 * (GBM + GBN) * ROWB;
+    extern int g_gemm_lds_pad;
+    const size_t lds = (size_t)2 * (GBM + GBN) * ROWB + (MI == 4 ? g_gemm_lds_pad : 0);
     static bool attr_set = false;
     if (!attr_set) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (GBM + GBN) * ROWB + (MI == 4 ? 32768 : 0))));
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
@@ -313,8 +734,57 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     return SOLA_OK;
 }
 
+int g_gemm_lds_pad = 0;  // measurement only
+void sola_gemm_set_lds_pad(int v) { g_gemm_lds_pad = v; }
+int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
+void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
+
+template <bool CONV, int RMODE, bool CSP>
+static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    a.tiles_m = (M + 255) / 256;
+    a.tiles_n = (N + 255) / 256;
+    a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
+    a.nprob = nprob;
+    constexpr size_t lds = (size_t)2 * 512 * ROWB + 8 * 16 * 64 * 4;  // two stages + eight epilogue strips = 160 KiB
+    static bool attr_set = false;
+    static int n_cu = 256;
+    if (!attr_set) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int total = a.tiles_m * a.tiles_n * nprob;
+    const int grid = total < n_cu ? total : n_cu;
+    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>), dim3(grid), dim3(512), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+template <bool CONV>
+static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    const int rmode = !a.p[0].R ? 0 : (a.r_sp16 ? 2 : 1);
+    if (a.c_sp16) {
+        if (CONV || rmode == 0) return launch_persist_t<CONV, 0, true>(a, M, N, nprob, s);
+        return rmode == 2 ? launch_persist_t<false, 2, true>(a, M, N, nprob, s) : launch_persist_t<false, 1, true>(a, M, N, nprob, s);
+    }
+    if (CONV || rmode == 0) return launch_persist_t<CONV, 0, false>(a, M, N, nprob, s);
+    return rmode == 2 ? launch_persist_t<false, 2, false>(a, M, N, nprob, s) : launch_persist_t<false, 1, false>(a, M, N, nprob, s);
+}
+
+// the persistent kernel takes residual / no residual from the launch, so every problem of the launch must agree
+static bool persist_uniform(const GldsArgs& a, int conv) {
+    for (int i = 1; i < a.nprob; ++i)
+        if ((a.p[i].R != nullptr) != (a.p[0].R != nullptr)) return false;
+    return !(conv && a.p[0].R);
+}
+
 template <bool CONV>
 static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
+    if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV)) return launch_persist<CONV>(a, M, N, nprob, s);
     if (shape == 4) return launch_glds<4, 2, 4, CONV>(a, M, N, nprob, s);
     return launch_glds<2, 2, 2, CONV>(a, M, N, nprob, s);
 }
@@ -323,6 +793,10 @@ extern int g_gemm_glds;
 int gemm_split_glds_shape(const GemmDesc& d);
 int g_gemm_ablate = 0;
 void sola_gemm_set_ablate(int v) { g_gemm_ablate = v; }
+int g_gemm_stagger = 0;          // phases (0/1 = off)
+int g_gemm_stagger_ns_kt = 2200;  // estimated time of one 256x256x32 k-tile, ns
+void sola_gemm_set_stagger(int v) { g_gemm_stagger = v; }
+void sola_gemm_set_stagger_ns(int v) { g_gemm_stagger_ns_kt = v; }
 
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     GldsArgs a;
@@ -332,8 +806,11 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
     a.r_sp16 = d.r_sp16;
     a.c_sp16 = d.c_sp16;
+    a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
     const int shape = gemm_split_glds_shape(d);
+    a.stagger_phases = shape == 4 ? g_gemm_stagger : 0;
+    a.stagger_ticks = g_gemm_persist ? g_gemm_stagger_ns_kt / 10 : (int)((long long)(d.K / GBK) * g_gemm_stagger_ns_kt / 10);
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);
 }
 

@@ -9,5 +9,7 @@ a = ops.cast_sp16(x); w = ops.cast_sp16(wt, 64.0); b = torch.randn(N, device="cu
 _lib.lib().sola_tune(b"gemm_glds", v)
 import os
 _lib.lib().sola_tune(b"gemm_ablate", int(os.environ.get("SOLA_ABLATE", "0")))
+_lib.lib().sola_tune(b"gemm_persist", int(os.environ.get("SOLA_PERSIST", "1")))
+if os.environ.get("SOLA_NORES"): r = None
 for _ in range(5): ops.gemm_nt_split(a, w, b, r, True, 1 / 64)
 torch.cuda.synchronize()
