@@ -374,6 +374,8 @@ int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 
 }  // namespace
 
 int g_gemm_glds = 3;  // split-f16 GEMM, direct-to-LDS staging (gemm_glds.hip): 0 off, 1 128x128 blocks, 4 256x256 blocks, 3 auto
+int g_gemm_glds_force = 0;  // tests: take the direct-to-LDS kernels for grids of any size
+void sola_gemm_set_glds_force(int v) { g_gemm_glds_force = v; }
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_splitk_tiles = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
@@ -401,7 +403,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
-    const bool glds = d.arith == 1 && big && g_gemm_glds && gemm_split_glds_supported(d);
+    const bool glds = d.arith == 1 && (big || g_gemm_glds_force) && g_gemm_glds && gemm_split_glds_supported(d);
     const int cat = d.arith == 1 ? (glds && gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT)
                                  : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL);
     SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
                 }
             }
             if (a.c_sp16) {
+                if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
                 // 4 consecutive columns of one 8-wide block: hi[4] and lo[4] leave as two aligned 8-byte stores
                 _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
                 half4 hh, ll;
@@ -685,6 +686,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                         }
                     }
                     if (CSP) {
+                        if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
                         _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
                         half4 hh, ll;
 #pragma unroll

@@ -182,3 +182,65 @@ def test_split_gemm_split_output():
         got = ops.decode_sp16(ops.gemm_nt_split(asp, wsp, torch.from_numpy(b).cuda(), out_scale=1 / 64, out_split=True))
         err = (got - ref).abs().max().item()
         assert err <= 2.0 ** -21 * ref.abs().max().item() + 1e-7, (M, N, K, err)
+
+
+def _tune(**kv):
+    from sola_amd import _lib
+    for k, v in kv.items():
+        _lib.check(_lib.lib().sola_tune(k.encode(), int(v)), "sola_tune")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 96), (777, 264, 64), (2048, 1024, 160), (300, 72, 96), (4100, 256, 320)])
+def test_split_gemm_block_shapes_bit_identical(M, N, K):
+    """The 128x128 kernel, the one-tile 256x256 kernel and the persistent 256x256 kernel accumulate every output element
+    in the same order, so they must agree bit for bit - on ragged M / N (clamped DMA rows, the predicated epilogue), with
+    no / f32 / split residual and with f32 / split output; one variant is also checked against float64."""
+    rng = np.random.default_rng(M * 7 + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    asp, wsp, bd, rd = ops.cast_sp16(cuda(a)), ops.cast_sp16(cuda(w), 64.0), cuda(b), cuda(r)
+    rsp = ops.cast_sp16(rd) if N % 8 == 0 else None
+    settings = [dict(gemm_glds=1, gemm_persist=0), dict(gemm_glds=4, gemm_persist=0), dict(gemm_glds=4, gemm_persist=1)]
+    try:
+        _tune(gemm_glds_force=1)  # these grids are far too small for the direct-to-LDS kernels to be chosen
+        for res, res_split, out_split in [(None, False, False), (rd, False, False), (rsp, True, False), (None, False, True), (rsp, True, True)]:
+            if res_split and rsp is None:
+                continue
+            if out_split and N % 8:
+                continue
+            outs = []
+            for st in settings:
+                _tune(**st)
+                outs.append(ops.gemm_nt_split(asp, wsp, bd, res, res_split, 1.0 / 64.0, out_split).clone())
+            torch.cuda.synchronize()
+            for o in outs[1:]:
+                assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32)), (res is not None, res_split, out_split)
+        _tune(gemm_glds=4, gemm_persist=1)
+        got = ops.gemm_nt_split(asp, wsp, bd, rd, False, 1.0 / 64.0).cpu().numpy()
+        ref = ops.decode_sp16(asp).double().cpu().numpy() @ (ops.decode_sp16(wsp).double().cpu().numpy() / 64.0).T + b + r
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    finally:
+        _tune(gemm_glds=3, gemm_persist=1, gemm_glds_force=0)
+
+
+def test_forward_identical_across_gemm_kernels(full_fast):
+    """Whole split-mode forward (implicit-im2col conv launches, three-problem q/k/v launches, residual and split-output
+    epilogues) through the persistent kernel, the one-tile kernel and the 128x128 kernel: same bits."""
+    m, _ = full_fast
+    inp = synth.make_inputs(synth.DEFAULT_MODEL_CFG, 8, 40, 32, 12, 5)
+    obj, lang = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
+    outs = []
+    try:
+        _tune(gemm_glds_force=1)
+        for st in [dict(gemm_glds=4, gemm_persist=1), dict(gemm_glds=4, gemm_persist=0), dict(gemm_glds=1, gemm_persist=0)]:
+            _tune(**st)
+            with torch.no_grad():
+                sm, tok = m(obj, lang)
+            outs.append((sm.clone(), tok.clone()))
+        torch.cuda.synchronize()
+    finally:
+        _tune(gemm_glds=3, gemm_persist=1, gemm_glds_force=0)
+    for sm, tok in outs[1:]:
+        assert torch.equal(outs[0][0], sm) and torch.equal(outs[0][1], tok)
