@@ -218,12 +218,13 @@ def main():
             # split-f16 GEMM: every algorithmic f32 FMA is issued as three f16 MFMA products, so the kernel is priced
             # against the dense f16 MFMA peak with the work it actually executes (3 x 2MNK); the algorithmic rate is kept
             # the dominant kernel is whichever split-GEMM shape took more of the step: the 256x256 direct-to-LDS blocks
-            # (their own profiler category, = rocprofv3's gemm_nt_split_glds_kernel<4, 2, 4, *>) or the rest
+            # (their own profiler category, = rocprofv3's gemm_nt_split_glds_persist_kernel<*> instantiations) or the rest
             g256, grest = prof["gemm_split256"], prof["gemm_split"]
             g = g256 if g256["ms"] >= grest["ms"] else grest
             alg = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            gname = ("gemm_nt_split_glds_kernel<4,2,4,*> (256x256x32 blocks, 8 waves of 128x64, split-f16 operands, "
-                     "3 x v_mfma_f32_32x32x16_f16 per product, direct-to-LDS staging)") if g is g256 else \
+            gname = ("gemm_nt_split_glds_persist_kernel<conv, residual, split-out> (persistent 256x256x32 blocks, 8 waves of "
+                     "128x64, split-f16 operands, 3 x v_mfma_f32_32x32x16_f16 per product, direct-to-LDS staging; all "
+                     "instantiations of a step)") if g is g256 else \
                     "gemm_nt_split_glds_kernel<2,2,2,*> / gemm_nt_f32_kernel<64,64,1,1> (128x128 and 64x64 split-f16 blocks)"
             roofline = {"kernel": gname, "bound": "mfma",
                         "achieved": round(3 * alg, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -351,20 +351,22 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
     const int total = tiles_per_prob * a.nprob;
     const int nk = a.K / GBK;
 
+    // Tile order: the problems of a launch (q/k/v projections of the same rows) are the innermost index next to the column
+    // tile, so the nprob * tiles_n tiles that read one 256-row block of A run back to back on one XCD and A comes from HBM once.
+    const int tiles_row = a.tiles_n * a.nprob;
     auto decode = [&](int tile, int& z, int& m0, int& n0) {
-        z = tile / tiles_per_prob;
-        const int bid = tile - z * tiles_per_prob;
-        int rt, ct;
+        int rt, c;
         if (a.xcd_remap) {
-            const int x = bid & 7, j = bid >> 3;
-            rt = x + 8 * (j / a.tiles_n);
-            ct = j % a.tiles_n;
+            const int x = tile & 7, j = tile >> 3;
+            rt = x + 8 * (j / tiles_row);
+            c = j % tiles_row;
         } else {
-            rt = bid / a.tiles_n;
-            ct = bid % a.tiles_n;
+            rt = tile / tiles_row;
+            c = tile % tiles_row;
         }
+        z = c / a.tiles_n;
         m0 = rt * GBM;
-        n0 = ct * GBN;
+        n0 = (c - z * a.tiles_n) * GBN;
     };
 
     // ---- DMA stream state (same piece layout as the kernel above)
