@@ -818,10 +818,12 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);
 }
 
-// g_gemm_glds: 1 = 128x128 blocks, 4 = 256x256, anything else = auto: 256x256 when its grid fills whole rounds of one
-// block per CU (a partial last round of 256x256 blocks costs more than the shape gains)
+// g_gemm_glds: 1 = 128x128 blocks, 4 = 256x256, anything else = auto: 256x256 when its tiles keep at least 3/4 of the
+// CUs busy over its whole rounds of one block per CU (the 256x256 kernel is 15-25 % faster per flop than the 128x128
+// one, so a last round down to half full still wins; below that the idle CUs cost more than the shape gains)
 int gemm_split_glds_shape(const GemmDesc& d) {
     if (g_gemm_glds == 1 || g_gemm_glds == 4) return g_gemm_glds;
     const long long t = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nprob;
-    return (t >= 256 && (t % 256 == 0 || t >= 2048)) ? 4 : 1;
+    const long long rounds = (t + 255) / 256;
+    return (t >= 256 && 4 * t >= 3 * rounds * 256) ? 4 : 1;
 }
