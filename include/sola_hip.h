@@ -266,11 +266,13 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_GEMM_TN = 9,   /* gemm_tn_f32_kernel (weight gradients) */
        SOLA_PROF_ATTN_BWD = 10, /* attn_bwd_* kernels */
        SOLA_PROF_GEMM_SPLIT = 11, /* split-f16 GEMMs other than the 256x256 shape (128x128 glds blocks, 64x64 small grids) */
-       SOLA_PROF_GEMM_SPLIT256 = 12, /* gemm_nt_split_glds_kernel<4,2,4,*>: 256x256 blocks, split-f16, 3 x f16 MFMA */
+       SOLA_PROF_GEMM_SPLIT256 = 12, /* gemm_nt_split_glds_persist_kernel<*> (and the one-tile <4,2,4,*> kernel): 256x256 blocks, split-f16, 3 x f16 MFMA */
        SOLA_PROF_NCAT = 13 };
 /* Kernel-schedule switches for within-process A/B measurements ("gemm_variant": 0 simple / 1 mid-tile staging;
  * "gemm_glds": split-f16 GEMM staging, 0 registers / 1 direct-to-LDS 128x128 blocks / 4 256x256 blocks / 3 auto;
- * "gemm_ablate": measurement only, 1 no DMA after the first tiles | 4 no epilogue (results are then WRONG);
+ * "gemm_persist": 256x256 shape, 1 persistent kernel (default) / 0 one tile per block; "gemm_glds_force": tests only, take the
+ * direct-to-LDS kernels for grids of any size; "gemm_splitk", "bilinear_staged";
+ * "gemm_ablate": measurement only, 4 = no epilogue (results are then WRONG);
  * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
  * "attn_target_blocks").  Except under gemm_ablate, results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);

@@ -255,11 +255,8 @@ void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
 void sola_gemm_set_ablate(int v);
-void sola_gemm_set_stagger(int v);
 void sola_gemm_set_persist(int v);
 void sola_gemm_set_glds_force(int v);
-void sola_gemm_set_lds_pad(int v);
-void sola_gemm_set_stagger_ns(int v);
 void sola_gn_set_variant(int v);
 void sola_bilinear_set_staged(int v);
 void sola_attn_set_variant(int v);
@@ -270,11 +267,8 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
-    if (!strcmp(key, "gemm_lds_pad")) { sola_gemm_set_lds_pad(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_persist")) { sola_gemm_set_persist(value); return SOLA_OK; }
-    if (!strcmp(key, "gemm_stagger")) { sola_gemm_set_stagger(value); return SOLA_OK; }
-    if (!strcmp(key, "gemm_stagger_ns")) { sola_gemm_set_stagger_ns(value); return SOLA_OK; }
     if (!strcmp(key, "gn_variant")) { sola_gn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "bilinear_staged")) { sola_bilinear_set_staged(value); return SOLA_OK; }
     if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }

@@ -40,7 +40,6 @@ struct GldsArgs {
     int tiles_m, tiles_n, xcd_remap, nprob;
     float out_scale;
     int r_sp16, c_sp16;
-    int stagger_phases, stagger_ticks;  // first-round start offsets (see the kernel); ticks of the 100 MHz wall clock
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
 };
 
@@ -80,17 +79,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         }
     }
     const int m0 = rt * GBM, n0 = ct * GBN;
-
-    // Phase stagger.  All tiles of a launch take the same time, so without it every CU reaches its epilogue at the same
-    // moment: the matrix pipes idle while HBM takes the whole C (+ residual) burst, then HBM idles during the next loop.
-    // The blocks of the FIRST round (one per CU) start `phase / phases` of a tile time late; later blocks inherit the
-    // offset of the block they replace, so from then on a fraction of the CUs is always in its epilogue.
-    if (a.stagger_phases > 1 && blockIdx.z == 0 && blockIdx.x < 256) {
-        const int phase = (blockIdx.x >> 3) % a.stagger_phases;
-        const long long wait = (long long)a.stagger_ticks * phase / a.stagger_phases;
-        const long long t0 = wall_clock64();
-        while ((long long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
 
     // ---- DMA coordinates: this wave owns row groups wave*APW + i (8 rows each) of the A tile and wave*WPW + i of the
     //      W tile; lane -> (row = rg*8 + lane/8, physical 16-byte chunk = lane%8).  Each piece keeps a running source
@@ -471,13 +459,6 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 
     int tile = blockIdx.x;
     if (tile >= total) return;
-    if (a.stagger_phases > 1) {
-        // start offsets of up to stagger_ticks (100 MHz wall clock) so that the CUs do not hit L2 / HBM in lockstep
-        const int phase = (blockIdx.x >> 3) % a.stagger_phases;
-        const long long wait = (long long)a.stagger_ticks * phase / a.stagger_phases;
-        const long long t0 = wall_clock64();
-        while ((long long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
-    }
     bool prev_fast = false;  // the previous tile of this block left through the interior epilogue
     setup_dma(tile);
     issue(0);
@@ -724,12 +705,11 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = (M + GBM - 1) / GBM;
     a.tiles_n = (N + GBN - 1) / GBN;
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
-    extern int g_gemm_lds_pad;
-    const size_t lds = (size_t)2 * (GBM + GBN) * ROWB + (MI == 4 ? g_gemm_lds_pad : 0);
+    constexpr size_t lds = (size_t)2 * (GBM + GBN) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (GBM + GBN) * ROWB + (MI == 4 ? 32768 : 0))));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
@@ -738,8 +718,6 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     return SOLA_OK;
 }
 
-int g_gemm_lds_pad = 0;  // measurement only
-void sola_gemm_set_lds_pad(int v) { g_gemm_lds_pad = v; }
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 
@@ -797,10 +775,6 @@ extern int g_gemm_glds;
 int gemm_split_glds_shape(const GemmDesc& d);
 int g_gemm_ablate = 0;
 void sola_gemm_set_ablate(int v) { g_gemm_ablate = v; }
-int g_gemm_stagger = 0;          // phases (0/1 = off)
-int g_gemm_stagger_ns_kt = 2200;  // estimated time of one 256x256x32 k-tile, ns
-void sola_gemm_set_stagger(int v) { g_gemm_stagger = v; }
-void sola_gemm_set_stagger_ns(int v) { g_gemm_stagger_ns_kt = v; }
 
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     GldsArgs a;
@@ -813,8 +787,6 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
     const int shape = gemm_split_glds_shape(d);
-    a.stagger_phases = shape == 4 ? g_gemm_stagger : 0;
-    a.stagger_ticks = g_gemm_persist ? g_gemm_stagger_ns_kt / 10 : (int)((long long)(d.K / GBK) * g_gemm_stagger_ns_kt / 10);
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);
 }
 
