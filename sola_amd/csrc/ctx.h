@@ -64,6 +64,7 @@ static const int kConvIdx[6] = {0, 4, 8, 12, 16, 20};
 static const int kNormIdx[5] = {1, 5, 9, 13, 17};
 static const char* const kAttnShort[3] = {"obj", "mot", "o2l"};
 static const char* const kAttnLong[3] = {"obj_attn", "motion_attn", "object2lang_attn"};
+constexpr float kLinScale = 64.f;  // linear weights are U(-1/32, 1/32)-sized: pre-scale so the lo halves of their split-f16 copies are normal f16
 
 inline const float* ctx_weight(const SolaCtx* c, const std::string& name) {
     auto it = c->index.find(name);

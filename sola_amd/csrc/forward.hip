@@ -2,6 +2,9 @@
 // sequences the kernels of gemm.hip / attn.hip / norm.hip / head.hip over one workspace arena.  With train = true every
 // attention keeps its own q/k/v/output/residual buffers plus the softmax log-sum-exp, which backward.hip consumes.
 #include <math.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "ctx.h"
 
@@ -31,6 +34,14 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
         p.add("obj_sp", R * T, c->cfg.object_token_dim);
         p.add("conv5_sp", p.M, D);
         p.add("lang_sp", (int64_t)B * p.W, D);
+    }
+    if (train && c->precision == 1) {
+        // split-f16 training forward: every GEMM input is cast into one of two scratch buffers right before its launch
+        // (the f32 activations stay where the backward reads them)
+        int64_t amax = std::max<int64_t>(R * T * c->cfg.object_token_dim, std::max<int64_t>((int64_t)p.M * D, (int64_t)B * p.W * D));
+        for (int i = 0; i < 5; ++i) amax = std::max<int64_t>(amax, R * p.Tl[i] * c->conv[i].cout);
+        p.add("sp_a", amax, 1);
+        p.add("sp_b", (int64_t)p.M, D);
     }
     const int n_sets = train ? c->cfg.n_layers : 1;
     for (int l = 0; l < n_sets; ++l)
@@ -80,6 +91,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
     const int Tp = p.Tp, M = p.M, Wn = p.W;
     const int R = B * N;
+    // training forward in the split-f16 mode (sola_set_precision 1): the same GEMM kernels as forward_fast.hip on casts of
+    // the f32 activations, everything the backward reads stays f32
+    const bool split = train && c->precision == 1 && D % 32 == 0 && c->cfg.object_token_dim % 32 == 0;
 
     // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
     if (c->ws_dirty || c->ws_every_forward || train) {
@@ -89,8 +103,32 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             layers[i] = WsLayer{W(nm), c->ws_buf + c->ws_off[i], c->conv[i].cout, c->conv[i].cin, c->conv[i].k};
         }
         SOLA_TRY(launch_ws_standardize(layers, 6, s));
+        if (split)
+            for (int i = 0; i < 6; ++i) {
+                const int kc = c->conv[i].k * c->conv[i].cin;
+                SOLA_TRY(launch_cast_sp16(c->ws_buf + c->ws_off[i], kc, c->ws16_buf + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, s));
+            }
         c->ws_dirty = false;
     }
+    auto lin16 = [&](const std::string& attn, int proj) -> const float* {  // attn = "object_lang_align_layers.<l>.<name>"
+        const int l = attn[attn.find('.') + 1] - '0';
+        int a3 = 0;
+        for (int a = 0; a < 3; ++a)
+            if (attn.size() >= strlen(kAttnLong[a]) && attn.compare(attn.size() - strlen(kAttnLong[a]), std::string::npos, kAttnLong[a]) == 0) a3 = a;
+        return c->lin16_buf + ((size_t)(l * 3 + a3) * 4 + proj) * D * D;
+    };
+    if (split && c->lin16_dirty) {
+        static const char* pn4[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
+        for (int l = 0; l < c->cfg.n_layers; ++l)
+            for (int a3 = 0; a3 < 3; ++a3)
+                for (int j = 0; j < 4; ++j) {
+                    const std::string nm = "object_lang_align_layers." + std::to_string(l) + "." + kAttnLong[a3] + "." + pn4[j] + ".weight";
+                    SOLA_TRY(launch_cast_sp16(W(nm), D, c->lin16_buf + ((size_t)(l * 3 + a3) * 4 + j) * D * D, D, D, D, kLinScale, s));
+                }
+        c->lin16_dirty = false;
+    }
+    float* const sp_a = split ? buf("sp_a") : nullptr;
+    float* const sp_b = split ? buf("sp_b") : nullptr;
 
     // a2: encoder (module/module.py:74-96,137-140)
     const float* x = obj;
@@ -106,6 +144,11 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (split && g.cin % 32 == 0) {
+            SOLA_TRY(launch_cast_sp16(x, g.cin, sp_a, g.cin, (long long)R * t_in, g.cin, 1.f, s));
+            gd.p[0].A = sp_a; gd.p[0].W = c->ws16_buf + c->ws_off[i];
+            gd.arith = 1; gd.out_scale = 1.f;
+        }
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
@@ -141,6 +184,24 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                                   W(attn + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
         gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (split) {
+            float* dst[2] = {sp_a, sp_b};
+            const float* src[2] = {nullptr, nullptr};
+            int nsrc = 0;
+            for (int j = 0; j < nprob; ++j) {
+                int at = -1;
+                for (int e = 0; e < nsrc; ++e)
+                    if (src[e] == as[j]) at = e;
+                if (at < 0) {
+                    at = nsrc++;
+                    src[at] = as[j];
+                    SOLA_TRY(launch_cast_sp16(as[j], D, dst[at], D, rows, D, 1.f, s));
+                }
+                gd.p[j].A = dst[at];
+                gd.p[j].W = lin16(attn, first_proj + j);
+            }
+            gd.arith = 1; gd.out_scale = 1.f / kLinScale;
+        }
         return launch_gemm(gd, s);
     };
     auto out_proj = [&](const std::string& attn, const float* ao, const float* resid, float* res) -> int {
@@ -149,6 +210,11 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.p[0] = GemmProblem{ao, W(attn + ".out_proj.weight"), W(attn + ".out_proj.bias"), resid, res};
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (split) {
+            SOLA_TRY(launch_cast_sp16(ao, D, sp_a, D, M, D, 1.f, s));
+            gd.p[0].A = sp_a; gd.p[0].W = lin16(attn, 3);
+            gd.arith = 1; gd.out_scale = 1.f / kLinScale;
+        }
         return launch_gemm(gd, s);
     };
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,

@@ -13,7 +13,6 @@
 #include "ctx.h"
 
 namespace {
-constexpr float kLinScale = 64.f;  // linear weights are U(-1/32, 1/32)-sized: pre-scale so their lo halves are normal f16
 }
 
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,

@@ -245,13 +245,20 @@ def test_small_gradients_vs_reference(small_golden, small_model, ci):
         assert gnd[k] == pytest.approx(ref[k], rel=2e-3), k
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("ci", [0, 1, 2])
-def test_full_gradient_norms_vs_reference(full_golden, full_model, ci):
+def test_full_gradient_norms_vs_reference(full_golden, full_model, ci, precision):
+    """precision "f16x3": the training forward's GEMMs run on split-f16 casts of the f32 activations (the backward stays
+    exact f32); same bar against the reference's losses and gradients."""
     m, _ = full_model
     cfg = synth.DEFAULT_MODEL_CFG
     B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
     g = case_dict(full_golden, ci)
-    _, loss3, grads = train_step_grads(m, cfg, B, N, T, L, 200 + ci)
+    m.precision = precision
+    try:
+        _, loss3, grads = train_step_grads(m, cfg, B, N, T, L, 200 + ci)
+    finally:
+        m.precision = "f32"
     np.testing.assert_allclose(loss3.detach().cpu().numpy().astype(np.float64), g["loss"], rtol=2e-4, atol=2e-4)
     total = float(dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))["total_grad_norm"])
     bad = {}
