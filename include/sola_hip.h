@@ -76,15 +76,25 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  *   1  split-f16: every operand value x is carried as (f16 hi, f16 lo) with hi + lo = x to 22 bits, in the same 4 bytes,
  *      and each product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation - 3/16 of the f32
  *      matrix-pipe time (gfx950 has no xf32/TF32).  Softmax, GroupNorm statistics, score head and losses stay f32.
- * The training path (sola_forward_train / sola_backward) always runs exact f32. */
+ * In training (sola_forward_train / sola_backward) precision 1 runs the forward GEMMs and the projection dX GEMMs of the
+ * backward on split-f16 casts of the f32 activations / gradients; the weight-gradient GEMMs, the transposed-conv dX and
+ * everything saved for the backward stay f32. */
 int sola_set_precision(SolaCtx* ctx, int precision);
 /* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
 int sola_cast_sp16(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float scale, void* stream);
+/* The same conversion with a data-dependent power-of-two scale, for operands whose magnitude the host does not know
+ * (gradients: mostly below the f16 normal range).  dev_scal = 2 floats: [0] receives max|in| (float bits), [1] the
+ * inverse of the scale applied (max|in| lands in [2^13, 2^14)); pass dev_scal + 1 as dev_out_scale below. */
+int sola_cast_sp16_auto(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float* dev_scal, void* stream);
 /* C = out_scale * (A W^T) + bias (+ R) with A [M,K], W [N,K] (and optionally R) in the split-f16 format; C is written
  * as f32, or as split-f16 pairs when c_is_split (N % 8 == 0) */
 int sola_gemm_nt_split(const float* dev_a_sp, int lda, const float* dev_w_sp, const float* dev_bias, const float* dev_r,
                        int ldr, int r_is_split, float* dev_c, int ldc, int c_is_split, int M, int N, int K, float out_scale,
                        void* stream);
+/* ... with a further result multiplier read from device memory (NULL = none) */
+int sola_gemm_nt_split_scaled(const float* dev_a_sp, int lda, const float* dev_w_sp, const float* dev_bias, const float* dev_r,
+                              int ldr, int r_is_split, float* dev_c, int ldc, int c_is_split, int M, int N, int K,
+                              float out_scale, const float* dev_out_scale, void* stream);
 
 /* ---- forward: replaces LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162) ------------------ */
 size_t sola_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);

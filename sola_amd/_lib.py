@@ -49,6 +49,8 @@ SIGNATURES = {
     "sola_set_precision": (_i, [_vp, _i]),
     "sola_cast_sp16": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp]),
     "sola_gemm_nt_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "sola_cast_sp16_auto": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),
+    "sola_gemm_nt_split_scaled": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sola_workspace_tap": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_i64)]),

@@ -335,6 +335,22 @@ extern "C" int sola_gemm_nt_split(const float* a_sp, int lda, const float* w_sp,
     return launch_gemm(gd, as_stream(stream_));
 }
 
+extern "C" int sola_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int K, float* scal, void* stream_) {
+    return launch_cast_sp16_auto(in, ld_in, out, ld_out, rows, K, scal, as_stream(stream_));
+}
+
+extern "C" int sola_gemm_nt_split_scaled(const float* a_sp, int lda, const float* w_sp, const float* bias, const float* r, int ldr,
+                                         int r_sp16, float* cmat, int ldc, int c_sp16, int M, int N, int K, float out_scale,
+                                         const float* out_scale_dev, void* stream_) {
+    SOLA_ARG(a_sp && w_sp && cmat, "gemm_nt_split_scaled: null argument");
+    GemmDesc gd{};
+    gd.nprob = 1;
+    gd.p[0] = GemmProblem{a_sp, w_sp, bias, r, cmat};
+    gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
+    gd.arith = 1; gd.out_scale = out_scale; gd.out_scale_dev = out_scale_dev; gd.r_sp16 = r_sp16; gd.c_sp16 = c_sp16;
+    return launch_gemm(gd, as_stream(stream_));
+}
+
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     if (c && c->precision == 1)

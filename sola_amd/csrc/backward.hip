@@ -61,6 +61,11 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
     a.add("colsum", colsum_scratch_bytes(1, (int)std::max(R, (size_t)p.B * p.Tp), (int)D) / sizeof(float) + 64);
+    if (c->precision == 1) {  // split-f16 dX GEMMs: casts of dY and of the transposed weights, the data-dependent scale
+        a.add("dy_sp", std::max(M, BW) * 3 * D);
+        a.add("wt_sp", wt_max);
+        a.add("scal", 64);
+    }
     return a;
 }
 
@@ -105,6 +110,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     float* tn = ar.get("tn");
     const size_t tn_bytes = ar.total - ar.off.at("tn");  // upper bound; launch_gemm_tn checks its own need
     float* wt = ar.get("wt");
+    const bool split = c->precision == 1 && ar.off.count("dy_sp") != 0;
 
     // ---- helpers ----------------------------------------------------------------------------------------------
     // dW[N_out, K_in] = dY^T X, db = colsum(dY)
@@ -120,6 +126,15 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         d.nprob = 1;
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
         d.M = rows; d.N = k_in; d.K = n_cat; d.lda = ldy; d.ldr = k_in; d.ldc = k_in;
+        if (split && n_cat % 32 == 0 && ldy % 4 == 0) {
+            // split-f16: dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal
+            // range), the transposed weights with the fixed 2^6; the epilogue undoes both
+            float* scal = ar.get("scal");
+            SOLA_TRY(launch_cast_sp16_auto(dY, ldy, ar.get("dy_sp"), n_cat, rows, n_cat, scal, s));
+            SOLA_TRY(launch_cast_sp16(wt, n_cat, ar.get("wt_sp"), n_cat, k_in, n_cat, kLinScale, s));
+            d.p[0].A = ar.get("dy_sp"); d.p[0].W = ar.get("wt_sp");
+            d.lda = n_cat; d.arith = 1; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
+        }
         return launch_gemm(d, s);
     };
     auto transpose_into = [&](const float* w, int n_out, int k_in, int n_cat, int col_off) -> int {

@@ -4,6 +4,8 @@
 // so hi + lo carries 22 significant bits of s*x.  The weight matrices are pre-scaled (s = 64: |w| <= 1/32 would put
 // the lo halves in the f16 subnormal range) and the GEMM epilogue multiplies the result by 1/s.
 // HBM-bound streaming kernel: one thread per 8-element block (two 16-byte loads, two 16-byte stores).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -30,7 +32,70 @@ __global__ __launch_bounds__(256) void cast_sp16_kernel(const float* __restrict_
     o[1] = lo;
 }
 
+// max |x| of a strided matrix as float bits (non-negative floats order like their bit patterns).  A thread owns one float4
+// column of a 64-row slab: coalesced row reads, no index arithmetic in the loop, one atomic per wave.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ in, unsigned* __restrict__ out, long long rows, int f4_per_row, int ld_in) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.f;
+    if (c < f4_per_row) {
+        const long long r0 = (long long)blockIdx.y * 64;
+        const int nr = (int)min((long long)64, rows - r0);
+        const float* p = in + r0 * ld_in + (long long)c * 4;
+#pragma unroll 8
+        for (int r = 0; r < nr; ++r, p += ld_in) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(out, __float_as_uint(m));
+}
+
+// scale = 2^(13 - floor(log2(amax))): the largest magnitude lands in [2^13, 2^14), far from the f16 overflow at 65504
+__device__ __forceinline__ float auto_scale(unsigned amax_bits) {
+    const int e = (int)(amax_bits >> 23) - 127;  // floor(log2(amax)) for normal floats
+    if (amax_bits == 0u) return 1.f;
+    const int k = min(max(13 - e, -100), 100);
+    return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+__global__ __launch_bounds__(256) void cast_sp16_auto_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows,
+                                                             int blocks_per_row, int ld_in, int ld_out, float* __restrict__ scal) {
+    const float scale = auto_scale(reinterpret_cast<const unsigned*>(scal)[0]);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) scal[1] = 1.f / scale;
+    if (i >= rows * blocks_per_row) return;
+    const long long r = i / blocks_per_row;
+    const int b = (int)(i - r * blocks_per_row);
+    const float4 v0 = *reinterpret_cast<const float4*>(in + r * ld_in + b * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(in + r * ld_in + b * 8 + 4);
+    const float v[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (_Float16)v[j];
+        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+    }
+    half8* o = reinterpret_cast<half8*>(out + r * ld_out + b * 8);
+    o[0] = hi;
+    o[1] = lo;
+}
+
 }  // namespace
+
+int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && scal && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_sp16_auto: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 12.0 * rows * K);
+    SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
+                       reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
+    SOLA_LAUNCH_CHECK();
+    const long long n = rows * (K / 8);
+    hipLaunchKernelGGL(cast_sp16_auto_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, rows, K / 8, ld_in, ld_out, scal);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s) {
     SOLA_ARG(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_sp16: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);

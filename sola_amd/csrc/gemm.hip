@@ -24,6 +24,7 @@ struct GemmArgs {
     int conv, T_in, T_out, stride, pad, Cin;
     int tiles_m, tiles_n, xcd_remap;
     float out_scale;  // result multiplier (power of two undoing the weight pre-scale of the split-f16 path)
+    const float* out_scale_dev;  // optional further multiplier in device memory (GemmDesc::out_scale_dev)
     int r_sp16;       // residual R is stored as split-f16 pairs
     int c_sp16;       // C is written as split-f16 pairs
     int ksplit;       // > 1: blockIdx.y owns k-tiles [y*kt_per, (y+1)*kt_per) and writes raw partial sums to `part`
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
         }
         return;
     }
+    const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wc * (BN / 2) + j * 32 + col_l;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                 if (m < a.M) {
-                    float v = acc[i][j][r] * a.out_scale + bv;
+                    float v = acc[i][j][r] * osc + bv;
                     if (pr.R) {
                         if (a.r_sp16) {  // residual kept as split-f16 pairs: element n sits in block n/8 as hi[n%8], lo[n%8]
                             const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7));
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
         const float4 v = *reinterpret_cast<const float4*>(part + (long long)sidx * a.M * a.N);
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     }
-    float v[4] = {sum.x * a.out_scale, sum.y * a.out_scale, sum.z * a.out_scale, sum.w * a.out_scale};
+    const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+    float v[4] = {sum.x * osc, sum.y * osc, sum.z * osc, sum.w * osc};
     if (pr.bias) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += pr.bias[n + e];
@@ -397,6 +400,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.tiles_m = a.tiles_n = a.xcd_remap = 0;
     a.out_scale = d.arith == 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
+    a.out_scale_dev = d.arith == 1 ? d.out_scale_dev : nullptr;
     a.r_sp16 = d.r_sp16;
     a.c_sp16 = d.arith == 1 ? d.c_sp16 : 0;
     a.ksplit = 1; a.kt_per = 0; a.part = nullptr;

@@ -39,6 +39,7 @@ struct GldsArgs {
     int conv, T_in, T_out, stride, pad, Cin;
     int tiles_m, tiles_n, xcd_remap, nprob;
     float out_scale;
+    const float* out_scale_dev;
     int r_sp16, c_sp16;
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
 };
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     //      row segment) instead of 64 strided dword stores per lane.  Bias, output scale and the residual are applied on
     //      the way out.
     if (a.ablate & 4) return;
+    const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
     float* tile = reinterpret_cast<float*>(lds) + wave * (64 * 64);  // [64 rows][64 cols] f32 (256-B rows: b32 writes and b128 reads are conflict-free)
     const int col_l = lane & 31, row_l = (lane >> 5) << 2;
     const int c4 = lane & 15;    // 16-byte column piece
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
             const int m = m0 + wr * MI * 32 + h * 64 + row;
             const float4 t = *reinterpret_cast<const float4*>(&tile[row * 64 + c4 * 4]);
             if (m >= a.M) continue;
-            float v[4] = {t.x * a.out_scale + bv.x, t.y * a.out_scale + bv.y, t.z * a.out_scale + bv.z, t.w * a.out_scale + bv.w};
+            float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
             if (pr.R) {
                 if (a.r_sp16) {
                     // 4 consecutive columns sit in one 8-wide block: hi[4] and lo[4] are two aligned 8-byte loads
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 
         // ---- epilogue: eight 16-row strips per wave tile through this wave's private LDS strip
         const GemmProblem pr = a.p[z];
+        const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
         // Everything the epilogue derives from the lane id goes through an opaque copy made here: otherwise the row
         // offsets of all 32 passes (64-bit, tile-invariant) are hoisted out of the tile loop and live - spilled - across
         // the k-loop.
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                         const int row = pass * 4 + rsub;
                         const int m = m0 + wr_e * 128 + i * 32 + hf * 16 + row;
                         const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
-                        float v[4] = {t.x * a.out_scale + bv.x, t.y * a.out_scale + bv.y, t.z * a.out_scale + bv.z, t.w * a.out_scale + bv.w};
+                        float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
                         if (RMODE) {
                             const f32x4 rv = rbuf[sl * 4 + pass];
                             if (RMODE == 2) {
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     const int m = m0 + wr_e * 128 + i * 32 + hf * 16 + row;
                     const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
                     if (m >= a.M) continue;
-                    float v[4] = {t.x * a.out_scale + bv.x, t.y * a.out_scale + bv.y, t.z * a.out_scale + bv.z, t.w * a.out_scale + bv.w};
+                    float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
                     if (RMODE) {
                         if (RMODE == 2) {
                             const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
@@ -782,6 +785,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
+    a.out_scale_dev = d.out_scale_dev;
     a.r_sp16 = d.r_sp16;
     a.c_sp16 = d.c_sp16;
     a.nprob = d.nprob;

@@ -20,6 +20,8 @@ struct GemmDesc {
     int T_in, T_out, stride, pad, Cin;
     int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate)
     float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
+    const float* out_scale_dev;  // arith 1, optional: a further multiplier read from device memory (the inverse of the
+                                 // data-dependent scale launch_cast_sp16_auto gave the A operand)
     int r_sp16;       // arith 1: the residual R is split-f16
     int c_sp16;       // arith 1: write C as split-f16 pairs (N % 8 == 0), e.g. q/k/v for the split attention kernel
     // optional scratch for the two-pass split-K of small grids (fewer 64x64 tiles than CUs): S partial sums per problem,
@@ -153,6 +155,10 @@ struct GroupNormDesc {
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
+// Same conversion with a data-dependent power-of-two scale (gradients: their magnitude is not known on the host and
+// mostly below the f16 normal range).  scal[0] receives max|in| (as float bits), the cast maps it into [2^13, 2^14) and
+// writes the inverse scale to scal[1] for the GEMM's out_scale_dev.  scal = 2 device floats.
+int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
 int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,

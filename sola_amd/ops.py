@@ -66,7 +66,19 @@ def decode_sp16(x_sp):
     return (h[:, :, 0, :] + h[:, :, 1, :]).reshape(rows, K)
 
 
-def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False, out_scale=1.0, out_split=False):
+def cast_sp16_auto(x):
+    """f32 [rows, K] -> (split-f16 rows scaled by a data-dependent power of two, scal) where scal[1] is the inverse scale
+    on the device (pass it as ``out_scale_dev`` of ``gemm_nt_split``) and scal[0] = max|x|."""
+    require_cuda(x)
+    x = _f32c(x)
+    rows, K = x.shape
+    out = torch.empty_like(x)
+    scal = torch.empty(2, device=x.device, dtype=torch.float32)
+    check(lib().sola_cast_sp16_auto(ptr(x), K, ptr(out), K, rows, K, ptr(scal), current_stream(x.device)), "sola_cast_sp16_auto")
+    return out, scal
+
+
+def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False, out_scale=1.0, out_split=False, out_scale_dev=None):
     """out_scale * (A W^T) + bias (+ residual) on split-f16 operands (three f16 MFMAs per product, f32 accumulate);
     ``out_split`` writes the result as split-f16 pairs (decode with ``decode_sp16``)."""
     require_cuda(a_sp, w_sp, bias, residual)
@@ -74,10 +86,10 @@ def gemm_nt_split(a_sp, w_sp, bias=None, residual=None, residual_is_split=False,
     M, K = a_sp.shape
     N = w_sp.shape[0]
     out = torch.empty((M, N), device=a_sp.device, dtype=torch.float32)
-    check(lib().sola_gemm_nt_split(ptr(a_sp), K, ptr(w_sp), ptr(None if bias is None else _f32c(bias)),
-                                   ptr(None if residual is None else _f32c(residual)), N, 1 if residual_is_split else 0,
-                                   ptr(out), N, 1 if out_split else 0, M, N, K, float(out_scale), current_stream(a_sp.device)),
-          "sola_gemm_nt_split")
+    check(lib().sola_gemm_nt_split_scaled(ptr(a_sp), K, ptr(w_sp), ptr(None if bias is None else _f32c(bias)),
+                                          ptr(None if residual is None else _f32c(residual)), N, 1 if residual_is_split else 0,
+                                          ptr(out), N, 1 if out_split else 0, M, N, K, float(out_scale), ptr(out_scale_dev),
+                                          current_stream(a_sp.device)), "sola_gemm_nt_split_scaled")
     return out
 
 

@@ -274,6 +274,32 @@ def test_full_gradient_norms_vs_reference(full_golden, full_model, ci, precision
         assert gnd[k] == pytest.approx(ref[k], rel=3e-3), k
 
 
+def test_split_training_gradients_match_exact_f32(full_model):
+    """precision "f16x3" in training: forward GEMMs and the projection dX GEMMs on split-f16 operands (dY cast with a
+    data-dependent power-of-two scale: its entries are ~1e-4..1e-9, below the f16 normal range).  Every parameter
+    gradient must agree with the exact-f32 path element-wise to 1 % of its largest entry - the size of the exact-f32 path's own
+    distance to the reference's gradients (2e-3..3e-3 on norms above): rounding differences of either path are amplified by the
+    two alignment layers and the GroupNorm backward chain on the way down to the encoder weights."""
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    grads = {}
+    try:
+        for prec in ("f32", "f16x3"):
+            m.precision = prec
+            _, _, g = train_step_grads(m, cfg, 3, 24, 32, 10, 77)
+            grads[prec] = {k: v.clone() for k, v in g.items()}
+    finally:
+        m.precision = "f32"
+    total = math.sqrt(sum(float(v.double().pow(2).sum()) for v in grads["f32"].values()))
+    bad = {}
+    for k, ref in grads["f32"].items():
+        err = float((grads["f16x3"][k] - ref).abs().max())
+        tol = 1e-2 * float(ref.abs().max()) + 1e-6 * total
+        if err > tol:
+            bad[k] = (err, float(ref.abs().max()))
+    assert not bad, bad
+
+
 def test_small_gradients_vs_oracle_autograd(small_model):
     """Every parameter gradient against float64 autograd through the oracle on a case with no fixture."""
     m, sd = small_model

@@ -2,6 +2,8 @@
 on (f16 hi, f16 lo) operand pairs with f32 accumulation.  It must satisfy the SAME parity bar as the exact-f32 mode:
 logits/tokens within the north-star 1e-3 of the reference's golden vectors, bit-exact selections / arg-max / hardest
 negatives, plus kernel-level checks of the split representation (22-bit products) against float64."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,23 @@ def test_forward_identical_across_gemm_kernels(full_fast):
         _tune(gemm_glds=3, gemm_persist=1, gemm_glds_force=0)
     for sm, tok in outs[1:]:
         assert torch.equal(outs[0][0], sm) and torch.equal(outs[0][1], tok)
+
+
+@pytest.mark.parametrize("mag", [1e-9, 3e-6, 1e-3, 40.0, 3e4])
+@pytest.mark.parametrize("M,N,K", [(300, 72, 96), (16384, 1024, 1024)])
+def test_split_gemm_auto_scaled_operand(M, N, K, mag):
+    """cast_sp16_auto: an operand of unknown magnitude (gradients; far below or above the f16 range) is scaled by a
+    data-dependent power of two on the device and the GEMM undoes it through out_scale_dev - same relative accuracy as
+    for O(1) data, for entries spanning six decades inside the tensor."""
+    rng = np.random.default_rng(int(M + K))
+    a = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-14, 0, size=(M, 1))) * mag).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+    asp, scal = ops.cast_sp16_auto(cuda(a))
+    assert float(scal[0]) == float(np.abs(a).max())
+    inv = float(scal[1])
+    assert inv > 0 and math.log2(inv) == int(math.log2(inv)) and 2.0 ** 13 <= float(np.abs(a).max()) / inv < 2.0 ** 14
+    got = ops.gemm_nt_split(asp, ops.cast_sp16(cuda(w), 64.0), out_scale=1.0 / 64.0, out_scale_dev=scal[1:]).cpu().numpy()
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    f32 = ops.gemm_nt(cuda(a), cuda(w)).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= max(4 * np.abs(f32 - ref).max(), 2e-6 * np.abs(ref).max())
