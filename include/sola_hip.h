@@ -206,6 +206,12 @@ int sola_attention_split(const float* dev_q_sp, int ldq, const float* dev_k_sp, 
 size_t sola_gemm_tn_scratch_bytes(int M, int N, int K);
 int sola_gemm_tn(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, float* dev_bias_grad,
                  int M, int N, int K, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* The same weight gradient on the split-f16 MFMA path (training precision 1): both operands are written transposed in
+ * the split-f16 format (dY with a power-of-two scale found on the device), the product is the NT split GEMM with the
+ * reduction cut into ranges, partial sums folded in a fixed order.  N % 8 == 0, K % 8 == 0, M >= 64. */
+size_t sola_gemm_tn_split_scratch_bytes(int M, int N, int K);
+int sola_gemm_tn_split(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, int M, int N, int K,
+                       void* dev_scratch, size_t scratch_bytes, void* stream);
 int sola_conv1d_cl_backward(const float* dev_x, const float* dev_wstd, const float* dev_dy, float* dev_dx,
                             float* dev_dwstd, float* dev_dbias, int R, int T_in, int cin, int cout, int k, int stride,
                             int pad, void* dev_scratch, size_t scratch_bytes, void* stream);

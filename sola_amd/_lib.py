@@ -72,6 +72,8 @@ SIGNATURES = {
     "sola_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sola_ws_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sola_gemm_tn_scratch_bytes": (_sz, [_i, _i, _i]),
+    "sola_gemm_tn_split_scratch_bytes": (_sz, [_i, _i, _i]),
+    "sola_gemm_tn_split": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sola_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sola_conv1d_cl_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sola_group_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),

@@ -465,6 +465,15 @@ extern "C" int sola_gemm_nt(const float* a, int lda, const float* w, const float
 }
 
 extern "C" size_t sola_gemm_tn_scratch_bytes(int M, int N, int K) { return gemm_tn_scratch_bytes(M, N, K); }
+extern "C" size_t sola_gemm_tn_split_scratch_bytes(int M, int N, int K) { return gemm_tn_split_supported(M, N, K) ? gemm_tn_split_scratch_bytes(M, N, K, 1) : 0; }
+extern "C" int sola_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* cmat, int M, int N, int K, void* scratch,
+                                  size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(a && b && cmat && scratch, "gemm_tn_split: null argument");
+    GemmTnSplitDesc d{};
+    d.A[0] = a; d.B[0] = b; d.C[0] = cmat; d.nprob = 1; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb;
+    d.scratch = static_cast<float*>(scratch); d.scratch_bytes = scratch_bytes;
+    return launch_gemm_tn_split(d, as_stream(stream_));
+}
 
 extern "C" int sola_gemm_tn(const float* a, int lda, const float* b, int ldb, float* cmat, float* bias_grad, int M, int N,
                             int K, void* scratch, size_t scratch_bytes, void* stream_) {

@@ -60,11 +60,17 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("tn", tn_max / sizeof(float) + 64);
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
-    a.add("colsum", colsum_scratch_bytes(1, (int)std::max(R, (size_t)p.B * p.Tp), (int)D) / sizeof(float) + 64);
+    a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, (size_t)p.B * p.Tp)), (int)D) / sizeof(float) + 64);
     if (c->precision == 1) {  // split-f16 dX GEMMs: casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
         a.add("scal", 64);
+        // split-f16 weight gradients of the projections (gemm_tn_split.hip): transposed operands + partial sums
+        if (gemm_tn_split_supported((int)M, (int)D, (int)D)) {
+            size_t need = gemm_tn_split_scratch_bytes((int)M, (int)D, (int)D, 3);
+            if (gemm_tn_split_supported((int)BW, (int)D, (int)D)) need = std::max(need, gemm_tn_split_scratch_bytes((int)BW, (int)D, (int)D, 2));
+            a.add("tns", need / sizeof(float) + 64);
+        }
     }
     return a;
 }
@@ -119,6 +125,27 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         d.A = dY; d.B = X; d.C = dW; d.bias_grad = db; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
         d.scratch = tn; d.scratch_bytes = tn_bytes;
         return launch_gemm_tn(d, s);
+    };
+    // up to three weight gradients sharing rows / sizes / pitches (q, k, v of one attention): one launch on the split-f16
+    // path (gemm_tn_split.hip) + the bias gradients as column sums, or the f32 kernel per problem
+    struct WG { const float* dY; const float* X; float* dW; float* db; };
+    auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in) -> int {
+        if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
+            GemmTnSplitDesc d{};
+            d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
+            for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
+            d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
+            if (d.scratch_bytes >= gemm_tn_split_scratch_bytes(rows, n_out, k_in, n)) {
+                SOLA_TRY(launch_gemm_tn_split(d, s));
+                float* cs = ar.get("colsum");
+                const size_t csb = ar.total - ar.off.at("colsum");  // upper bound; launch_colsum uses what it needs
+                for (int j = 0; j < n; ++j)
+                    if (g[j].db) SOLA_TRY(launch_colsum(g[j].dY, g[j].db, 1, rows, n_out, ldy, 1.f, 0, cs, csb, s));
+                return SOLA_OK;
+            }
+        }
+        for (int j = 0; j < n; ++j) SOLA_TRY(grad_w(g[j].dY, ldy, g[j].X, ldx, rows, n_out, k_in, g[j].dW, g[j].db));
+        return SOLA_OK;
     };
     // dX[rows, k_in] = dY[rows, n_cat] * Wcat (+ R), where wt holds Wcat^T as [k_in][n_cat]
     auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX) -> int {
@@ -182,7 +209,8 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         // common tail of every sub-block: out_proj backward  (res = resid + attn * Wo^T + bo)
         auto out_proj_bwd = [&](int a) -> int {
             const std::string an = lp + kAttnLong[a];
-            SOLA_TRY(grad_w(dres, D, ab(a, "attn"), D, M, D, D, G(an + ".out_proj.weight"), G(an + ".out_proj.bias")));
+            const WG wo[1] = {{dres, ab(a, "attn"), G(an + ".out_proj.weight"), G(an + ".out_proj.bias")}};
+            SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D));
             SOLA_TRY(transpose_into(W(an + ".out_proj.weight"), D, D, D, 0));
             return grad_x(dres, D, M, D, D, nullptr, dattn);
         };
@@ -199,9 +227,11 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             ad.drop = c->attn_drop(l, 2);
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
-            SOLA_TRY(grad_w(dqkv, 3 * D, x_mot, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
-            SOLA_TRY(grad_w(dlkv, 2 * D, fb("lang"), D, B * Wn, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
-            SOLA_TRY(grad_w(dlkv + D, 2 * D, fb("lang"), D, B * Wn, D, D, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")));
+            const WG wq[1] = {{dqkv, x_mot, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")}};
+            SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D));
+            const WG wkv[2] = {{dlkv, fb("lang"), G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
+                               {dlkv + D, fb("lang"), G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
+            SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, B * Wn, D, D));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, D, 0));
             SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur]));  // d x_mot = dres + dq Wq
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
@@ -223,9 +253,10 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
             const float* x_obj = fb(ls + "_obj");
-            SOLA_TRY(grad_w(dqkv, 3 * D, x_pe, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
-            SOLA_TRY(grad_w(dqkv + D, 3 * D, x_pe, D, M, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
-            SOLA_TRY(grad_w(dqkv + 2 * D, 3 * D, x_obj, D, M, D, D, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")));
+            const WG w3[3] = {{dqkv, x_pe, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")},
+                              {dqkv + D, x_pe, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
+                              {dqkv + 2 * D, x_obj, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
+            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, D));
             SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad));  // d(x_obj + pe) = dq Wq + dk Wk
@@ -244,9 +275,10 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
                            B * Tp, H, DH, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
             ad.drop = c->attn_drop(l, 0);
             SOLA_TRY(launch_attention_bwd(ad, s));
-            SOLA_TRY(grad_w(dqkv, 3 * D, xin, D, M, D, D, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")));
-            SOLA_TRY(grad_w(dqkv + D, 3 * D, xin, D, M, D, D, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")));
-            SOLA_TRY(grad_w(dqkv + 2 * D, 3 * D, xin, D, M, D, D, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")));
+            const WG w3[3] = {{dqkv, xin, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")},
+                              {dqkv + D, xin, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
+                              {dqkv + 2 * D, xin, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
+            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 3 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 3 * D, D));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 3 * D, 2 * D));

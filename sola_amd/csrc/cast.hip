@@ -84,6 +84,15 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_kernel(const float* __rest
 
 }  // namespace
 
+int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, float* scal, hipStream_t s) {
+    SOLA_ARG(in && scal && rows > 0 && K > 0 && K % 4 == 0 && ld_in % 4 == 0, "amax: K=%d ld_in=%d", K, ld_in);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * rows * K);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
+                       reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s) {
     SOLA_ARG(in && out && scal && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_sp16_auto: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 12.0 * rows * K);

@@ -407,7 +407,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
-    const bool glds = d.arith == 1 && (big || g_gemm_glds_force) && g_gemm_glds && gemm_split_glds_supported(d);
+    const bool glds = d.arith == 1 && (big || g_gemm_glds_force || d.ksplit > 1) && g_gemm_glds && gemm_split_glds_supported(d);
     const int cat = d.arith == 1 ? (glds && gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT)
                                  : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL);
     SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
@@ -428,6 +428,18 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
                 a.part = d.splitk_ws;
             }
         }
+    }
+    if (glds && d.ksplit > 1) {
+        SOLA_ARG(d.splitk_ws && d.K % (32 * d.ksplit) == 0 && d.K / 32 / d.ksplit >= 2 && d.N % 4 == 0 && d.ldc % 4 == 0 &&
+                     d.splitk_bytes >= (size_t)d.nprob * d.ksplit * d.M * d.N * sizeof(float),
+                 "gemm: split-K over %d ranges needs K %% (32 * ksplit) == 0 (K=%d) and a scratch of nprob*ksplit*M*N floats", d.ksplit, d.K);
+        a.ksplit = d.ksplit;
+        a.part = d.splitk_ws;
+        SOLA_TRY(launch_gemm_split_glds(d, s));
+        const long long quads = (long long)a.M * (a.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256), 1, d.nprob), dim3(256), 0, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
     }
     if (glds) return launch_gemm_split_glds(d, s);
     if (d.arith == 1) {

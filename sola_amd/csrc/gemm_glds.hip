@@ -38,6 +38,8 @@ struct GldsArgs {
     int M, N, K, lda, ldr, ldc;
     int conv, T_in, T_out, stride, pad, Cin;
     int tiles_m, tiles_n, xcd_remap, nprob;
+    int ksplit, kper;  // persistent kernel: > 1 = the reduction dim is cut into ksplit ranges of kper k-tiles, each an own work item
+    float* part;       // ... writing raw partial sums to part[(problem * ksplit + range)][M][N] (gemm.hip reduces them)
     float out_scale;
     const float* out_scale_dev;
     int r_sp16, c_sp16;
@@ -337,14 +339,15 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-    const int tiles_per_prob = a.tiles_m * a.tiles_n;
-    const int total = tiles_per_prob * a.nprob;
-    const int nk = a.K / GBK;
+    const int ks_n = a.ksplit > 1 ? a.ksplit : 1;
+    const int nk = a.ksplit > 1 ? a.kper : a.K / GBK;
 
     // Tile order: the problems of a launch (q/k/v projections of the same rows) are the innermost index next to the column
     // tile, so the nprob * tiles_n tiles that read one 256-row block of A run back to back on one XCD and A comes from HBM once.
-    const int tiles_row = a.tiles_n * a.nprob;
-    auto decode = [&](int tile, int& z, int& m0, int& n0) {
+    // The k ranges of a split-K launch are further "problems" in that order.
+    const int tiles_row = a.tiles_n * a.nprob * ks_n;
+    const int total = a.tiles_m * tiles_row;
+    auto decode = [&](int tile, int& z, int& ks, int& m0, int& n0) {
         int rt, c;
         if (a.xcd_remap) {
             const int x = tile & 7, j = tile >> 3;
@@ -354,9 +357,11 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
             rt = tile / tiles_row;
             c = tile % tiles_row;
         }
-        z = c / a.tiles_n;
+        const int zz = c / a.tiles_n;
+        z = zz / ks_n;
+        ks = zz - z * ks_n;
         m0 = rt * GBM;
-        n0 = (c - z * a.tiles_n) * GBN;
+        n0 = (c - zz * a.tiles_n) * GBN;
     };
 
     // ---- DMA stream state (same piece layout as the kernel above)
@@ -369,10 +374,11 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
     int dma_kt = 0;  // next k-tile of the DMA stream within its tile
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     auto setup_dma = [&](int tile) {
-        int z, m0, n0;
-        decode(tile, z, m0, n0);
-        const float* A = a.p[z].A;
-        const float* Wt = a.p[z].W;
+        int z, ks, m0, n0;
+        decode(tile, z, ks, m0, n0);
+        const int k0 = ks * nk * GBK;  // first reduction index of this work item
+        const float* A = a.p[z].A + k0;
+        const float* Wt = a.p[z].W + k0;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int r = (wave * APW + i) * 8 + lrow;
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
             if (i == 0) w_ptr0 = p;
             w_d[i] = (int)(p - w_ptr0);
         }
-        conv_kk = 0;
-        conv_c = 0;
+        conv_kk = CONV ? k0 / a.Cin : 0;
+        conv_c = CONV ? k0 - conv_kk * a.Cin : 0;
         dma_kt = 0;
     };
     auto issue = [&](int stage) {
@@ -471,8 +477,8 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
     constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;
     constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
     for (; tile < total; tile += gridDim.x) {
-        int z, m0, n0;
-        decode(tile, z, m0, n0);
+        int z, ks, m0, n0;
+        decode(tile, z, ks, m0, n0);
         const int next = tile + gridDim.x;
         const bool has_next = next < total;
 #pragma unroll
@@ -531,8 +537,15 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         if (a.ablate & 4) continue;
 
         // ---- epilogue: eight 16-row strips per wave tile through this wave's private LDS strip
-        const GemmProblem pr = a.p[z];
-        const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+        GemmProblem pr = a.p[z];
+        float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+        int ldc = a.ldc;
+        if (a.ksplit > 1) {  // raw partial sums; scale, bias, residual and the output format are the reduce pass's
+            pr.C = a.part + (long long)(z * a.ksplit + ks) * a.M * a.N;
+            pr.bias = nullptr;
+            ldc = a.N;
+            osc = 1.f;
+        }
         // Everything the epilogue derives from the lane id goes through an opaque copy made here: otherwise the row
         // offsets of all 32 passes (64-bit, tile-invariant) are hoisted out of the tile loop and live - spilled - across
         // the k-loop.
@@ -545,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         const int c4 = lane_e & 15, rsub = lane_e >> 4;
         const int wr_e = wave_e / WAVES_N, wc_e = wave_e % WAVES_N;
         const int n = n0 + wc_e * 64 + c4 * 4;
-        const bool vec_ok = (a.ldc & 3) == 0 && n + 3 < a.N && (RMODE != 1 || (a.ldr & 3) == 0);
+        const bool vec_ok = (ldc & 3) == 0 && n + 3 < a.N && (RMODE != 1 || (a.ldr & 3) == 0);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pr.bias) {
             bv.x = n < a.N ? pr.bias[n] : 0.f;
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         // k-tile), and the residual is fetched four strips ahead (64 registers; the fragment registers are dead here).
         // vmcnt is one in-order counter for loads and stores: a residual load issued between stores would have to wait for
         // the acknowledgement of every store before it, so the loads of a batch are issued together, in front of its stores.
-        const bool interior = m0 + GBM <= a.M && n0 + GBN <= a.N && (a.ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
+        const bool interior = m0 + GBM <= a.M && n0 + GBN <= a.N && (ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
         prev_fast = interior;
         if (interior) {
 #pragma unroll
@@ -610,14 +623,14 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             }
                         }
                         if (CSP) {
-                            _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+                            _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                             half4 hh, ll;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
                             *reinterpret_cast<half4*>(cb) = hh;
                             *reinterpret_cast<half4*>(cb + 8) = ll;
                         } else {
-                            *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(pr.C + (long long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -673,18 +686,18 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     }
                     if (CSP) {
                         if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
-                        _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+                        _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                         half4 hh, ll;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
                         *reinterpret_cast<half4*>(cb) = hh;
                         *reinterpret_cast<half4*>(cb + 8) = ll;
                     } else if (vec_ok) {
-                        *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(pr.C + (long long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (n + e < a.N) pr.C[(long long)m * a.ldc + n + e] = v[e];
+                            if (n + e < a.N) pr.C[(long long)m * ldc + n + e] = v[e];
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -742,7 +755,7 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
             n_cu = prop.multiProcessorCount;
         attr_set = true;
     }
-    const int total = a.tiles_m * a.tiles_n * nprob;
+    const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
     hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>), dim3(grid), dim3(512), lds, s, a);
     SOLA_LAUNCH_CHECK();
@@ -751,6 +764,7 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
 
 template <bool CONV>
 static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    if (a.ksplit > 1) return launch_persist_t<CONV, 0, false>(a, M, N, nprob, s);  // partial sums: f32, no residual
     const int rmode = !a.p[0].R ? 0 : (a.r_sp16 ? 2 : 1);
     if (a.c_sp16) {
         if (CONV || rmode == 0) return launch_persist_t<CONV, 0, true>(a, M, N, nprob, s);
@@ -769,6 +783,7 @@ static bool persist_uniform(const GldsArgs& a, int conv) {
 
 template <bool CONV>
 static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
+    if (a.ksplit > 1) return launch_persist<CONV>(a, M, N, nprob, s);
     if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV)) return launch_persist<CONV>(a, M, N, nprob, s);
     if (shape == 4) return launch_glds<4, 2, 4, CONV>(a, M, N, nprob, s);
     return launch_glds<2, 2, 2, CONV>(a, M, N, nprob, s);
@@ -790,6 +805,9 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.c_sp16 = d.c_sp16;
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
+    a.ksplit = d.ksplit > 1 ? d.ksplit : 1;
+    a.kper = d.K / GBK / a.ksplit;
+    a.part = d.splitk_ws;
     const int shape = gemm_split_glds_shape(d);
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);
 }

@@ -1,0 +1,120 @@
+// Weight gradients dW[n][k] = sum_m dY[m][n] X[m][k] on the split-f16 MFMA path (training, precision 1).
+// The reduction runs over the ROWS of both operands, so each is first written transposed in the split-f16 format
+// ([N][Mp] and [K][Mp], Mp = M rounded up and zero-filled) - one streaming pass that replaces the f32 kernel's strided
+// staging - and the product is then the ordinary NT GEMM of gemm_glds.hip with the reduction dim = Mp.  dW has only
+// (N/256) x (K/256) output tiles (16 for the 1024 x 1024 projections), so the reduction is cut into `ksplit` ranges,
+// one persistent-kernel work item each, and gemm.hip's splitk_reduce_kernel folds the partial sums in a fixed order.
+// dY is a gradient (entries ~1e-4..1e-9): it is scaled by a data-dependent power of two found on the device
+// (cast.hip's amax pass; all problems of a launch share the scale), undone by the GEMM's out_scale_dev.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float auto_scale_t(unsigned amax_bits) {  // as cast.hip: max|x| -> [2^13, 2^14)
+    if (amax_bits == 0u) return 1.f;
+    const int e = (int)(amax_bits >> 23) - 127;
+    const int k = min(max(13 - e, -100), 100);
+    return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+// in [rows][cols] f32 (pitch ld_in) -> out [cols][ld_out] split-f16, out[c][8b..8b+7] = scale * in[8b..8b+7][c]; rows beyond
+// `rows` up to ld_out are written as zeros.  Tile = 128 rows x 64 columns through LDS.
+__global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
+                                                          int ld_in, long long ld_out, float* __restrict__ scal) {
+    __shared__ float tile[128][65];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
+    float scale = 1.f;
+    if (scal) {
+        scale = auto_scale_t(reinterpret_cast<const unsigned*>(scal)[0]);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) scal[1] = 1.f / scale;
+    }
+    {
+        const int c = t & 63, rq = t >> 6;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int r = i * 4 + rq;
+            tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(long long)(r0 + r) * ld_in + c0 + c] * scale : 0.f;
+        }
+    }
+    __syncthreads();
+    const int b = t & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = (t >> 4) + 16 * j;
+        if (c0 + c >= cols) continue;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = tile[8 * b + e][c];
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+        half8* o = reinterpret_cast<half8*>(out + (long long)(c0 + c) * ld_out + r0 + 8 * b);
+        o[0] = hi;
+        o[1] = lo;
+    }
+}
+
+int cast_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * cols);
+    hipLaunchKernelGGL(cast_sp16_t_kernel, dim3((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64)), dim3(256), 0, s, in, out, rows,
+                       cols, ld_in, ld_out, scal);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+void geometry(int M, int& ksplit, long long& Mp) {
+    ksplit = M >= 8192 ? 16 : (M >= 2048 ? 8 : (M >= 512 ? 4 : 2));
+    const long long q = 64LL * ksplit;  // every range at least two 32-wide k-tiles; a multiple of the 128-row cast tile
+    Mp = (M + q - 1) / q * q;
+}
+
+}  // namespace
+
+bool gemm_tn_split_supported(int M, int N, int K) { return N % 8 == 0 && K % 8 == 0 && M >= 64; }
+
+size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob) {
+    int ks; long long Mp;
+    geometry(M, ks, Mp);
+    const size_t el = (size_t)nprob * N * Mp + (size_t)nprob * K * Mp + (size_t)nprob * ks * N * K + 64;
+    return el * sizeof(float);
+}
+
+int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
+    SOLA_ARG(d.nprob >= 1 && d.nprob <= 3 && d.scratch, "gemm_tn_split: nprob %d", d.nprob);
+    SOLA_ARG(gemm_tn_split_supported(d.M, d.N, d.K) && d.lda % 4 == 0, "gemm_tn_split: M=%d N=%d K=%d lda=%d", d.M, d.N, d.K, d.lda);
+    SOLA_ARG(d.scratch_bytes >= gemm_tn_split_scratch_bytes(d.M, d.N, d.K, d.nprob), "gemm_tn_split: scratch too small");
+    int ks; long long Mp;
+    geometry(d.M, ks, Mp);
+    float* at = d.scratch;
+    float* xt = at + (size_t)d.nprob * d.N * Mp;
+    float* slabs = xt + (size_t)d.nprob * d.K * Mp;
+    float* scal = slabs + (size_t)d.nprob * ks * d.N * d.K;
+    // one scale for all problems: the amax passes accumulate into the same slot
+    SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
+    for (int j = 0; j < d.nprob; ++j) SOLA_TRY(launch_amax_accumulate(d.A[j], d.lda, d.M, d.N, scal, s));
+    const float* xt_of[3] = {nullptr, nullptr, nullptr};
+    int n_xt = 0;
+    for (int j = 0; j < d.nprob; ++j) {
+        SOLA_TRY(cast_t(d.A[j], d.lda, at + (size_t)j * d.N * Mp, Mp, d.M, d.N, scal, s));
+        for (int e = 0; e < j; ++e)
+            if (d.B[e] == d.B[j]) xt_of[j] = xt_of[e];
+        if (!xt_of[j]) {
+            float* dst = xt + (size_t)n_xt++ * d.K * Mp;
+            SOLA_TRY(cast_t(d.B[j], d.ldb, dst, Mp, d.M, d.K, nullptr, s));
+            xt_of[j] = dst;
+        }
+    }
+    GemmDesc g{};
+    g.nprob = d.nprob;
+    for (int j = 0; j < d.nprob; ++j) g.p[j] = GemmProblem{at + (size_t)j * d.N * Mp, xt_of[j], nullptr, nullptr, d.C[j]};
+    g.M = d.N; g.N = d.K; g.K = (int)Mp; g.lda = (int)Mp; g.ldr = 0; g.ldc = d.K;
+    g.arith = 1; g.out_scale = 1.f; g.out_scale_dev = scal + 1;
+    g.ksplit = ks; g.splitk_ws = slabs; g.splitk_bytes = (size_t)d.nprob * ks * d.N * d.K * sizeof(float);
+    return launch_gemm(g, s);
+}

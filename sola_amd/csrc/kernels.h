@@ -20,6 +20,8 @@ struct GemmDesc {
     int T_in, T_out, stride, pad, Cin;
     int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate)
     float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
+    int ksplit;  // arith 1, direct-to-LDS kernels: > 1 cuts the reduction into that many ranges, one work item each (few output
+                 // tiles, long K: weight gradients); needs splitk_ws of nprob * ksplit * M * N floats and K % (32 * ksplit) == 0
     const float* out_scale_dev;  // arith 1, optional: a further multiplier read from device memory (the inverse of the
                                  // data-dependent scale launch_cast_sp16_auto gave the A operand)
     int r_sp16;       // arith 1: the residual R is split-f16
@@ -42,6 +44,18 @@ struct GemmTnDesc {
     float* scratch;
     size_t scratch_bytes;
 };
+// Split-f16 version (gemm_tn_split.hip): up to three problems dW_j = A_j^T B_j sharing M, N, K and the pitches
+struct GemmTnSplitDesc {
+    const float* A[3];  // dY_j [M, N], pitch lda (column slices of one buffer are fine)
+    const float* B[3];  // X_j [M, K], pitch ldb; equal pointers are transposed once
+    float* C[3];        // dW_j [N, K], contiguous
+    int nprob, M, N, K, lda, ldb;
+    float* scratch;
+    size_t scratch_bytes;
+};
+bool gemm_tn_split_supported(int M, int N, int K);
+size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob);
+int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s);
 size_t gemm_tn_scratch_bytes(int M, int N, int K);
 int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s);
 int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off, hipStream_t s);
@@ -158,6 +172,8 @@ int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long lo
 // Same conversion with a data-dependent power-of-two scale (gradients: their magnitude is not known on the host and
 // mostly below the f16 normal range).  scal[0] receives max|in| (as float bits), the cast maps it into [2^13, 2^14) and
 // writes the inverse scale to scal[1] for the GEMM's out_scale_dev.  scal = 2 device floats.
+// scal[0] = max(scal[0], max|in|) as float bits (the caller zeroes the slot); the first half of launch_cast_sp16_auto
+int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, float* scal, hipStream_t s);
 int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows

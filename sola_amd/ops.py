@@ -184,6 +184,20 @@ def gemm_tn(a, b, want_bias_grad=False):
     return (out, bias) if want_bias_grad else out
 
 
+def gemm_tn_split(a, b):
+    """a [M,N]^T @ b [M,K] -> [N,K] on the split-f16 MFMA path (transposing casts + split-K NT GEMM)."""
+    require_cuda(a, b)
+    a, b = _f32c(a), _f32c(b)
+    M, N = a.shape
+    K = b.shape[1]
+    out = torch.empty((N, K), device=a.device, dtype=torch.float32)
+    nb = lib().sola_gemm_tn_split_scratch_bytes(M, N, K)
+    scratch = torch.empty(nb, device=a.device, dtype=torch.uint8)
+    check(lib().sola_gemm_tn_split(ptr(a), N, ptr(b), K, ptr(out), M, N, K, ptr(scratch), nb, current_stream(a.device)),
+          "sola_gemm_tn_split")
+    return out
+
+
 def ws_backward(weight, dwstd):
     """Backward of ``ws_standardize``: weight [cout,cin,k], dwstd [cout,k*cin] -> dweight [cout,cin,k]."""
     require_cuda(weight, dwstd)

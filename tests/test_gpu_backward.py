@@ -49,6 +49,18 @@ def test_gemm_tn(M, N, K):
     assert_close(bias, a.astype(np.float64).sum(axis=0), name="bias grad")
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-7])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 280, 40), (16384, 1024, 1024), (70, 64, 128), (5000, 520, 264)])
+def test_gemm_tn_split(M, N, K, mag):
+    """Weight gradient on the split-f16 path: transposing casts (zero-padded rows, ragged column tiles), device-side scale
+    for gradient-sized dY, split-K persistent GEMM + ordered reduce; against float64, same bar as the f32 kernel."""
+    rng = np.random.default_rng(M + N)
+    a, b = rnd(rng, M, N, scale=mag), rnd(rng, M, K)
+    out = ops.gemm_tn_split(cuda(a), cuda(b))
+    assert_close(out, a.astype(np.float64).T @ b.astype(np.float64), name="gemm_tn_split")
+    assert torch.equal(out, ops.gemm_tn_split(cuda(a), cuda(b)))  # fixed reduction order
+
+
 @pytest.mark.parametrize("cout,cin,k", [(64, 32, 3), (512, 256, 3), (1024, 1024, 1), (8, 4, 3)])
 def test_ws_backward(cout, cin, k):
     rng = np.random.default_rng(cout)
