@@ -33,19 +33,36 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
         scale = auto_scale_t(reinterpret_cast<const unsigned*>(scal)[0]);
         if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) scal[1] = 1.f / scale;
     }
-    {
-        const int c = t & 63, rq = t >> 6;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-            const int r = i * 4 + rq;
-            tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(long long)(r0 + r) * ld_in + c0 + c] * scale : 0.f;
+    {   // 16-byte loads when the pitch allows; LDS pitch 65: bank = (row + col) % 64, conflict-free for both phases
+        const int c4 = (t & 15) * 4, rq = t >> 4;
+        const bool vec = (ld_in & 3) == 0 && c0 + 64 <= cols;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 16 + rq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + r < rows) {
+                const float* p = in + (long long)(r0 + r) * ld_in + c0 + c4;
+                if (vec) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + c4 + e < cols) v[e] = p[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][c4 + e] = v[e] * scale;
         }
     }
     __syncthreads();
-    const int b = t & 15;
+    // a lane owns (8-row block b, column cc) of an 8 x 8 patch: banks 8 b + cc + e are all different; 8 lanes write the 256
+    // contiguous bytes of one output row
+    const int lane = t & 63, wave = t >> 6;
+    const int b8 = lane & 7, cc = lane >> 3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int c = (t >> 4) + 16 * j;
+        const int c = wave * 16 + cc + 8 * (j & 1), b = b8 + 8 * (j >> 1);
         if (c0 + c >= cols) continue;
         half8 hi, lo;
 #pragma unroll
