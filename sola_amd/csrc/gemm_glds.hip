@@ -534,7 +534,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         for (; kt < nk - 2; ++kt) ktile(std::false_type{});
         if (nk > 2 && has_next) setup_dma(next);
         for (; kt < nk; ++kt) ktile(std::false_type{});
-        if (a.ablate & 4) continue;
+        if (a.ablate & 4) {
+            prev_fast = false;  // no stores went out: the next tile's first wait must be the full one
+            continue;
+        }
 
         // ---- epilogue: eight 16-row strips per wave tile through this wave's private LDS strip
         GemmProblem pr = a.p[z];
