@@ -65,6 +65,11 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
         a.add("scal", 64);
+        {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather
+            size_t zmax = 0;
+            for (int i = 1; i < 6; ++i) zmax = std::max(zmax, R * p.Tl[i] * (size_t)c->conv[i].k * c->conv[i].cin);
+            a.add("zcol", zmax);
+        }
         // split-f16 weight gradients of the projections (gemm_tn_split.hip): transposed operands + partial sums
         if (gemm_tn_split_supported((int)M, (int)D, (int)D)) {
             size_t need = gemm_tn_split_scratch_bytes((int)M, (int)D, (int)D, 3);
@@ -321,6 +326,20 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         // d act_{i-1}[(r, ti)][ci] = sum_{kk, co} dY[(r, to)][co] w_std[co][kk][ci]: the NT kernel with the transposed-conv
         // gather over dY and the weights re-laid-out to [cin][kk*cout + co]
         float* dact = enc[0];
+        if (split && g.cout % 128 == 0 && g.cin % 8 == 0 && (size_t)rows * g.cout <= std::max((size_t)M, (size_t)B * Wn) * 3 * D) {
+            // split-f16: z[(r,to)][kk*cin+ci] = sum_co dY[(r,to)][co] w_std[co][kk*cin+ci] in ONE NT GEMM over the output steps (a
+            // strided conv's gather form would multiply zeros for every skipped step), then the k taps are gathered into dX
+            float* scal = ar.get("scal");
+            SOLA_TRY(launch_cast_sp16_auto(dy, g.cout, ar.get("dy_sp"), g.cout, rows, g.cout, scal, s));
+            SOLA_TRY(launch_cast_sp16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
+            GemmDesc d{};
+            d.nprob = 1;
+            d.p[0] = GemmProblem{ar.get("dy_sp"), ar.get("wt_sp"), nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
+            d.M = rows; d.N = g.k * g.cin; d.K = g.cout; d.lda = g.cout; d.ldc = g.k * g.cin;
+            d.arith = 1; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
+            SOLA_TRY(launch_gemm(d, s));
+            if (g.k > 1) SOLA_TRY(launch_col2im(ar.get("zcol"), dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s));
+        } else {
         for (int kk = 0; kk < g.k; ++kk)
             SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, wt, g.cout, g.cin, g.k * g.cin,
                                       g.k * g.cout, kk * g.cout, s));
@@ -331,6 +350,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             d.M = R * t_in; d.N = g.cin; d.K = g.k * g.cout; d.lda = g.cout; d.ldc = g.cin;
             d.conv = g.k > 1 ? 2 : 0; d.T_in = p.Tl[i]; d.T_out = t_in; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cout;
             SOLA_TRY(launch_gemm(d, s));
+        }
         }
         // GroupNorm + LeakyReLU backward of stage i-1
         const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i - 1]);

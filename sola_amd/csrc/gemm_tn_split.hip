@@ -77,6 +77,29 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
     }
 }
 
+// Transposed-conv scatter as a gather: z [R*T_out][k*cin] holds, for every output step, its contribution to each of the k
+// input steps it touches (z = dY W, one GEMM); dx[(r, ti)][ci] = sum over the taps kk with (ti + pad - kk) = to * stride,
+// 0 <= to < T_out, of z[(r, to)][kk*cin + ci].  One thread per float4 of dx; fixed tap order.
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z, float* __restrict__ dx, long long n4, int T_in, int T_out,
+                                                     int cin4, int k, int stride, int pad) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % cin4);
+    const long long rt = i / cin4;
+    const int ti = (int)(rt % T_in);
+    const long long r = rt / T_in;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kk = 0; kk < k; ++kk) {
+        const int u = ti + pad - kk;
+        if (u < 0 || u % stride) continue;
+        const int to = u / stride;
+        if (to >= T_out) continue;
+        const float4 v = *reinterpret_cast<const float4*>(z + ((r * T_out + to) * k + kk) * (long long)(cin4 * 4) + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = acc;
+}
+
 int cast_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * cols);
     hipLaunchKernelGGL(cast_sp16_t_kernel, dim3((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64)), dim3(256), 0, s, in, out, rows,
@@ -92,6 +115,20 @@ void geometry(int M, int& ksplit, long long& Mp) {
 }
 
 }  // namespace
+
+int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && rows > 0 && cols > 0 && ld_out % 128 == 0 && ld_out >= rows, "cast_sp16_t: rows=%d ld_out=%lld", rows, ld_out);
+    return cast_t(in, ld_in, out, ld_out, rows, cols, scal, s);
+}
+
+int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s) {
+    SOLA_ARG(z && dx && cin % 4 == 0 && k >= 1 && stride >= 1, "col2im: cin=%d k=%d stride=%d", cin, k, stride);
+    const long long n4 = R * T_in * (cin / 4);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (R * T_out * (double)k * cin + R * T_in * (double)cin));
+    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, T_in, T_out, cin / 4, k, stride, pad);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 bool gemm_tn_split_supported(int M, int N, int K) { return N % 8 == 0 && K % 8 == 0 && M >= 64; }
 

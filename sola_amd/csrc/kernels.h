@@ -53,6 +53,11 @@ struct GemmTnSplitDesc {
     float* scratch;
     size_t scratch_bytes;
 };
+// in [rows][cols] f32 -> out [cols][ld_out] split-f16 (rows rows..ld_out zero-filled; ld_out % 128 == 0); scal: optional
+// device pair as for launch_cast_sp16_auto with scal[0] = max|in| already there
+int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s);
+// dx[(r, ti)][ci] = sum over taps of z[(r, to)][kk*cin + ci] (the scatter of a transposed conv, as a gather)
+int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s);
 bool gemm_tn_split_supported(int M, int N, int K);
 size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob);
 int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s);
