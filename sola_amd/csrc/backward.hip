@@ -74,6 +74,9 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
         if (gemm_tn_split_supported((int)M, (int)D, (int)D)) {
             size_t need = gemm_tn_split_scratch_bytes((int)M, (int)D, (int)D, 3);
             if (gemm_tn_split_supported((int)BW, (int)D, (int)D)) need = std::max(need, gemm_tn_split_scratch_bytes((int)BW, (int)D, (int)D, 2));
+            for (int i = 0; i < 6; ++i)
+                if (gemm_tn_split_supported((int)(R * p.Tl[i]), c->conv[i].cout, c->conv[i].k * c->conv[i].cin))
+                    need = std::max(need, gemm_tn_split_scratch_bytes((int)(R * p.Tl[i]), c->conv[i].cout, c->conv[i].k * c->conv[i].cin, 1));
             a.add("tns", need / sizeof(float) + 64);
         }
     }
@@ -314,7 +317,16 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         const int rows = R * p.Tl[i];
         const float* x_in = i == 0 ? nullptr : fb("act" + std::to_string(i - 1));
         // dW_std[cout][k*cin] = dY^T im2col(x_in), db
-        {
+        if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, g.cout, g.k * g.cin) &&
+            ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes(rows, g.cout, g.k * g.cin, 1)) {
+            GemmTnSplitDesc d{};
+            d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
+            d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
+            d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
+            d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
+            SOLA_TRY(launch_gemm_tn_split(d, s));
+            SOLA_TRY(launch_colsum(dy, G(cp + ".bias"), 1, rows, g.cout, g.cout, 1.f, 0, ar.get("colsum"), ar.total - ar.off.at("colsum"), s));
+        } else {
             GemmTnDesc d{};
             d.A = dy; d.B = i == 0 ? c->last_obj : x_in; d.C = dwstd + ws_off[i]; d.bias_grad = G(cp + ".bias");
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;

@@ -23,8 +23,11 @@ __device__ __forceinline__ float auto_scale_t(unsigned amax_bits) {  // as cast.
 
 // in [rows][cols] f32 (pitch ld_in) -> out [cols][ld_out] split-f16, out[c][8b..8b+7] = scale * in[8b..8b+7][c]; rows beyond
 // `rows` up to ld_out are written as zeros.  Tile = 128 rows x 64 columns through LDS.
+// With conv_T_out > 0 the input is the implicit im2col of a channels-last conv for ONE tap: row m = (r, to) reads source row
+// r * conv_T_in + to * conv_stride + conv_toff (tap - pad), zeros outside [0, conv_T_in).
 __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
-                                                          int ld_in, long long ld_out, float* __restrict__ scal) {
+                                                          int ld_in, long long ld_out, float* __restrict__ scal, int conv_T_in,
+                                                          int conv_T_out, int conv_stride, int conv_toff) {
     __shared__ float tile[128][65];
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
@@ -40,8 +43,15 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
         for (int i = 0; i < 8; ++i) {
             const int r = i * 16 + rq;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (r0 + r < rows) {
-                const float* p = in + (long long)(r0 + r) * ld_in + c0 + c4;
+            long long src = r0 + r;
+            bool ok = r0 + r < rows;
+            if (conv_T_out > 0 && ok) {
+                const int m = r0 + r, rr = m / conv_T_out, tt = (m - rr * conv_T_out) * conv_stride + conv_toff;
+                ok = (unsigned)tt < (unsigned)conv_T_in;
+                src = (long long)rr * conv_T_in + tt;
+            }
+            if (ok) {
+                const float* p = in + src * ld_in + c0 + c4;
                 if (vec) {
                     const float4 q = *reinterpret_cast<const float4*>(p);
                     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
@@ -100,10 +110,11 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z
     *reinterpret_cast<float4*>(dx + i * 4) = acc;
 }
 
-int cast_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
+int cast_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
+           int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0) {
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * cols);
     hipLaunchKernelGGL(cast_sp16_t_kernel, dim3((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64)), dim3(256), 0, s, in, out, rows,
-                       cols, ld_in, ld_out, scal);
+                       cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -142,6 +153,7 @@ size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob) {
 int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3 && d.scratch, "gemm_tn_split: nprob %d", d.nprob);
     SOLA_ARG(gemm_tn_split_supported(d.M, d.N, d.K) && d.lda % 4 == 0, "gemm_tn_split: M=%d N=%d K=%d lda=%d", d.M, d.N, d.K, d.lda);
+    SOLA_ARG(!d.conv || (d.Cin > 0 && d.K % d.Cin == 0 && d.T_out > 0 && d.M % d.T_out == 0), "gemm_tn_split: conv geometry K=%d Cin=%d", d.K, d.Cin);
     SOLA_ARG(d.scratch_bytes >= gemm_tn_split_scratch_bytes(d.M, d.N, d.K, d.nprob), "gemm_tn_split: scratch too small");
     int ks; long long Mp;
     geometry(d.M, ks, Mp);
@@ -160,7 +172,12 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             if (d.B[e] == d.B[j]) xt_of[j] = xt_of[e];
         if (!xt_of[j]) {
             float* dst = xt + (size_t)n_xt++ * d.K * Mp;
-            SOLA_TRY(cast_t(d.B[j], d.ldb, dst, Mp, d.M, d.K, nullptr, s));
+            if (d.conv) {  // rows [kk*Cin, (kk+1)*Cin) of X^T = tap kk of the implicit im2col
+                for (int kk = 0; kk < d.K / d.Cin; ++kk)
+                    SOLA_TRY(cast_t(d.B[j], d.ldb, dst + (size_t)kk * d.Cin * Mp, Mp, d.M, d.Cin, nullptr, s, d.T_in, d.T_out, d.stride, kk - d.pad));
+            } else {
+                SOLA_TRY(cast_t(d.B[j], d.ldb, dst, Mp, d.M, d.K, nullptr, s));
+            }
             xt_of[j] = dst;
         }
     }

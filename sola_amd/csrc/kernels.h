@@ -50,6 +50,7 @@ struct GemmTnSplitDesc {
     const float* B[3];  // X_j [M, K], pitch ldb; equal pointers are transposed once
     float* C[3];        // dW_j [N, K], contiguous
     int nprob, M, N, K, lda, ldb;
+    int conv, T_in, T_out, stride, pad, Cin;  // conv = 1: B is the channels-last conv input [R*T_in, Cin], K = k*Cin (implicit im2col)
     float* scratch;
     size_t scratch_bytes;
 };
