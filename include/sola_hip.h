@@ -215,6 +215,11 @@ int sola_gemm_tn_split(const float* dev_a, int lda, const float* dev_b, int ldb,
 int sola_conv1d_cl_backward(const float* dev_x, const float* dev_wstd, const float* dev_dy, float* dev_dx,
                             float* dev_dwstd, float* dev_dbias, int R, int T_in, int cin, int cout, int k, int stride,
                             int pad, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* ... on the split-f16 MFMA path (what sola_backward runs under precision 1); cout % 128 == 0, cin % 8 == 0, R*T_out >= 64 */
+size_t sola_conv1d_cl_backward_split_scratch_bytes(int R, int T_in, int cin, int cout, int k, int stride, int pad);
+int sola_conv1d_cl_backward_split(const float* dev_x, const float* dev_wstd, const float* dev_dy, float* dev_dx,
+                                  float* dev_dwstd, float* dev_dbias, int R, int T_in, int cin, int cout, int k, int stride,
+                                  int pad, void* dev_scratch, size_t scratch_bytes, void* stream);
 int sola_group_norm_backward(const float* dev_x, const float* dev_dy, const float* dev_dy2, const float* dev_gamma,
                              const float* dev_beta, float* dev_dx, float* dev_dgamma, float* dev_dbeta,
                              int n_inst, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tok_stride,

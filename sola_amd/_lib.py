@@ -76,6 +76,8 @@ SIGNATURES = {
     "sola_gemm_tn_split": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sola_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sola_conv1d_cl_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sola_conv1d_cl_backward_split_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "sola_conv1d_cl_backward_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sola_group_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
     "sola_attention_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                      _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),

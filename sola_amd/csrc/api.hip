@@ -529,6 +529,66 @@ extern "C" int sola_conv1d_cl_backward(const float* x, const float* wstd, const 
     return launch_gemm(gd, s);
 }
 
+// The same backward on the split-f16 MFMA path (what sola_backward runs under precision 1): dwstd through
+// gemm_tn_split.hip with per-tap transposing im2col casts, dx as ONE GEMM over the output steps + a col2im gather.
+// Needs cout % 128 == 0, cin % 8 == 0, R*T_out >= 64.
+static size_t conv_bwd_split_layout(int R, int T_in, int cin, int cout, int k, int stride, int pad, size_t off[5]) {
+    const int T_out = (T_in + 2 * pad - k) / stride + 1;
+    const size_t M = (size_t)R * T_out;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t o = 0;
+    off[0] = o; o += up(gemm_tn_split_scratch_bytes((int)M, cout, k * cin, 1));
+    off[1] = o; o += up(M * cout * sizeof(float));                      // dy_sp
+    off[2] = o; o += up((size_t)k * cin * cout * sizeof(float));        // wt_sp
+    off[3] = o; o += up(M * (size_t)k * cin * sizeof(float));           // z
+    off[4] = o; o += 256;                                               // scal
+    return o;
+}
+extern "C" size_t sola_conv1d_cl_backward_split_scratch_bytes(int R, int T_in, int cin, int cout, int k, int stride, int pad) {
+    size_t off[5];
+    const int T_out = (T_in + 2 * pad - k) / stride + 1;
+    if (R <= 0 || T_out <= 0 || cout % 128 || cin % 8 || !gemm_tn_split_supported(R * T_out, cout, k * cin)) return 0;
+    return conv_bwd_split_layout(R, T_in, cin, cout, k, stride, pad, off);
+}
+extern "C" int sola_conv1d_cl_backward_split(const float* x, const float* wstd, const float* dy, float* dx, float* dwstd,
+                                             float* dbias, int R, int T_in, int cin, int cout, int k, int stride, int pad,
+                                             void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(x && wstd && dy && dwstd && scratch && R > 0 && T_in > 0 && k >= 1 && stride >= 1, "conv1d_cl_backward_split: bad argument");
+    const size_t need = sola_conv1d_cl_backward_split_scratch_bytes(R, T_in, cin, cout, k, stride, pad);
+    SOLA_ARG(need > 0, "conv1d_cl_backward_split: needs cout %% 128 == 0, cin %% 8 == 0, R*T_out >= 64 (cout=%d cin=%d)", cout, cin);
+    if (scratch_bytes < need) {
+        sola_set_error("conv1d_cl_backward_split: scratch %zu < %zu", scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    size_t off[5];
+    conv_bwd_split_layout(R, T_in, cin, cout, k, stride, pad, off);
+    char* base = static_cast<char*>(scratch);
+    const int T_out = (T_in + 2 * pad - k) / stride + 1, M = R * T_out;
+    hipStream_t s = as_stream(stream_);
+    GemmTnSplitDesc d{};
+    d.nprob = 1; d.A[0] = dy; d.B[0] = x; d.C[0] = dwstd; d.M = M; d.N = cout; d.K = k * cin; d.lda = cout; d.ldb = cin;
+    d.conv = (k > 1 || stride > 1 || pad > 0) ? 1 : 0; d.T_in = T_in; d.T_out = T_out; d.stride = stride; d.pad = pad; d.Cin = cin;
+    d.scratch = reinterpret_cast<float*>(base + off[0]); d.scratch_bytes = off[1] - off[0];
+    SOLA_TRY(launch_gemm_tn_split(d, s));
+    if (dbias) SOLA_TRY(launch_colsum(dy, dbias, 1, M, cout, cout, 1.f, 0, nullptr, 0, s));
+    if (!dx) return SOLA_OK;
+    float* dy_sp = reinterpret_cast<float*>(base + off[1]);
+    float* wt_sp = reinterpret_cast<float*>(base + off[2]);
+    float* z = reinterpret_cast<float*>(base + off[3]);
+    float* scal = reinterpret_cast<float*>(base + off[4]);
+    SOLA_TRY(launch_cast_sp16_auto(dy, cout, dy_sp, cout, M, cout, scal, s));
+    SOLA_TRY(launch_cast_sp16_t(wstd, k * cin, wt_sp, cout, cout, k * cin, nullptr, s));
+    GemmDesc gd{};
+    gd.nprob = 1;
+    const bool gather = d.conv != 0;
+    gd.p[0] = GemmProblem{dy_sp, wt_sp, nullptr, nullptr, gather ? z : dx};
+    gd.M = M; gd.N = k * cin; gd.K = cout; gd.lda = cout; gd.ldc = k * cin;
+    gd.arith = 1; gd.out_scale = 1.f; gd.out_scale_dev = scal + 1;
+    SOLA_TRY(launch_gemm(gd, s));
+    if (gather) SOLA_TRY(launch_col2im(z, dx, R, T_in, T_out, cin, k, stride, pad, s));
+    return SOLA_OK;
+}
+
 extern "C" int sola_group_norm(const float* x, float* y, float* y2, const float* pe, const float* gamma,
                                const float* beta, int n_inst, int inner, int64_t outer_stride, int64_t inner_stride,
                                int64_t tok_stride, int ntok, int C, int groups, float eps, float slope, int leaky,

@@ -208,8 +208,8 @@ def ws_backward(weight, dwstd):
     return dw
 
 
-def conv1d_cl_backward(x, w_std, dy, k, stride, pad, need_dx=True):
-    """Backward of ``conv1d_cl``: returns (dx or None, dw_std [cout,k*cin], dbias [cout])."""
+def conv1d_cl_backward(x, w_std, dy, k, stride, pad, need_dx=True, split=False):
+    """Backward of ``conv1d_cl``: returns (dx or None, dw_std [cout,k*cin], dbias [cout]); ``split`` = the split-f16 path."""
     require_cuda(x, w_std, dy)
     x, w_std, dy = _f32c(x), _f32c(w_std), _f32c(dy)
     R, T, cin = x.shape
@@ -218,6 +218,12 @@ def conv1d_cl_backward(x, w_std, dy, k, stride, pad, need_dx=True):
     dx = torch.empty_like(x) if need_dx else None
     dw = torch.empty_like(w_std)
     db = torch.empty((cout,), device=x.device, dtype=torch.float32)
+    if split:
+        nb = lib().sola_conv1d_cl_backward_split_scratch_bytes(R, T, cin, cout, k, stride, pad)
+        scratch = torch.empty(max(nb, 1), device=x.device, dtype=torch.uint8)
+        check(lib().sola_conv1d_cl_backward_split(ptr(x), ptr(w_std), ptr(dy), ptr(dx), ptr(dw), ptr(db), R, T, cin, cout, k,
+                                                  stride, pad, ptr(scratch), nb, current_stream(x.device)), "sola_conv1d_cl_backward_split")
+        return dx, dw, db
     nb = max(lib().sola_gemm_tn_scratch_bytes(R * t_out, cout, k * cin), 4 * cout * k * cin)
     scratch = torch.empty(nb, device=x.device, dtype=torch.uint8)
     check(lib().sola_conv1d_cl_backward(ptr(x), ptr(w_std), ptr(dy), ptr(dx), ptr(dw), ptr(db), R, T, cin, cout, k, stride,

@@ -89,6 +89,25 @@ def test_conv1d_backward(R, T, cin, cout, k, s, p):
     assert_close(db, bt.grad, name="conv db")
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-6])
+@pytest.mark.parametrize("R,T,cin,cout,k,s,p", [(64, 32, 256, 512, 3, 2, 1), (16, 16, 128, 128, 3, 1, 1), (9, 41, 64, 128, 3, 2, 1),
+                                                (7, 20, 128, 128, 1, 1, 0), (33, 4, 512, 1024, 3, 1, 1)])
+def test_conv1d_backward_split(R, T, cin, cout, k, s, p, mag):
+    """The split-f16 conv backward of the training path (per-tap transposing im2col casts + split-K GEMM for dW; one GEMM
+    over the output steps + col2im gather for dX), gradient-sized dY included, against float64 autograd."""
+    rng = np.random.default_rng(R * T + cin)
+    x, w, b = rnd(rng, R, T, cin), rnd(rng, cout, cin, k, scale=0.1), rnd(rng, cout)
+    xt, wt, bt = t64(x, True), t64(w, True), t64(b, True)
+    y = sola_oracle.conv1d_cl(xt, wt, bt, s, p)
+    dy = rnd(rng, *y.shape, scale=mag)
+    y.backward(t64(dy))
+    wk = np.ascontiguousarray(np.transpose(w, (0, 2, 1)).reshape(cout, k * cin))
+    dx, dw, db = ops.conv1d_cl_backward(cuda(x), cuda(wk), cuda(dy), k, s, p, split=True)
+    assert_close(dx, xt.grad, name="conv dx")
+    assert_close(dw.reshape(cout, k, cin).permute(0, 2, 1), wt.grad, name="conv dw")
+    assert_close(db, bt.grad, name="conv db")
+
+
 @pytest.mark.parametrize("B,N,Tp,C", [(2, 5, 3, 128), (1, 64, 4, 1024), (2, 3, 1, 64), (1, 7, 25, 512)])
 def test_group_norm_backward(B, N, Tp, C):
     rng = np.random.default_rng(C + N)
