@@ -65,6 +65,11 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
         a.add("scal", 64);
+        {   // per-64-row-slab column sums of a gradient matrix (launch_amax_colsum): bias gradients without a second read
+            size_t cp = std::max((M / 64 + 1) * 3 * D, (BW / 64 + 1) * 2 * D);
+            for (int i = 0; i < 6; ++i) cp = std::max(cp, (R * p.Tl[i] / 64 + 1) * (size_t)c->conv[i].cout);
+            a.add("cpart", cp);
+        }
         {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather
             size_t zmax = 0;
             for (int i = 1; i < 6; ++i) zmax = std::max(zmax, R * p.Tl[i] * (size_t)c->conv[i].k * c->conv[i].cin);
@@ -136,10 +141,30 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     };
     // up to three weight gradients sharing rows / sizes / pitches (q, k, v of one attention): one launch on the split-f16
     // path (gemm_tn_split.hip) + the bias gradients as column sums, or the f32 kernel per problem
+    // Split mode reads every gradient matrix ONCE for its scale (max|dY|, shared by the dW and dX GEMMs that consume it) and
+    // its bias gradients (per-slab column sums, folded by a tiny second pass): stats() -> scale slot, bias_from_stats().
+    float* cpart = split ? ar.get("cpart") : nullptr;
+    int cpart_cols = 0, cpart_slabs = 0;
+    auto stats = [&](const float* dY, int ld, int rows, int cols, int slot, float** sc_out) -> int {
+        *sc_out = nullptr;
+        if (!split || cols % 4 || ld % 4) return SOLA_OK;
+        float* sc = ar.get("scal") + slot;
+        SOLA_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(float), s));
+        SOLA_TRY(launch_amax_colsum(dY, ld, rows, cols, sc, cpart, s));
+        cpart_cols = cols;
+        cpart_slabs = (rows + 63) / 64;
+        *sc_out = sc;
+        return SOLA_OK;
+    };
+    auto bias_from_stats = [&](int col_off, int ncols, float* db) -> int {
+        return launch_colsum(cpart + col_off, db, 1, cpart_slabs, ncols, cpart_cols, 1.f, 0, nullptr, 0, s);
+    };
     struct WG { const float* dY; const float* X; float* dW; float* db; };
-    auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in) -> int {
+    // sc: scale slot from stats() over a matrix containing every dY of the call; db_done: the bias gradients were taken from it
+    auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in, float* sc = nullptr, bool db_done = false) -> int {
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
+            d.scal = sc;
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
@@ -147,7 +172,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
                 SOLA_TRY(launch_gemm_tn_split(d, s));
                 float* cs = ar.get("colsum");
                 const size_t csb = ar.total - ar.off.at("colsum");  // upper bound; launch_colsum uses what it needs
-                for (int j = 0; j < n; ++j)
+                for (int j = 0; j < n && !db_done; ++j)
                     if (g[j].db) SOLA_TRY(launch_colsum(g[j].dY, g[j].db, 1, rows, n_out, ldy, 1.f, 0, cs, csb, s));
                 return SOLA_OK;
             }
@@ -156,7 +181,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         return SOLA_OK;
     };
     // dX[rows, k_in] = dY[rows, n_cat] * Wcat (+ R), where wt holds Wcat^T as [k_in][n_cat]
-    auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX) -> int {
+    auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX, float* sc = nullptr) -> int {
         GemmDesc d{};
         d.nprob = 1;
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
@@ -164,8 +189,9 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         if (split && n_cat % 32 == 0 && ldy % 4 == 0) {
             // split-f16: dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal
             // range), the transposed weights with the fixed 2^6; the epilogue undoes both
-            float* scal = ar.get("scal");
-            SOLA_TRY(launch_cast_sp16_auto(dY, ldy, ar.get("dy_sp"), n_cat, rows, n_cat, scal, s));
+            float* scal = sc ? sc : ar.get("scal");
+            if (sc) SOLA_TRY(launch_cast_sp16_scaled(dY, ldy, ar.get("dy_sp"), n_cat, rows, n_cat, scal, s));
+            else SOLA_TRY(launch_cast_sp16_auto(dY, ldy, ar.get("dy_sp"), n_cat, rows, n_cat, scal, s));
             SOLA_TRY(launch_cast_sp16(wt, n_cat, ar.get("wt_sp"), n_cat, k_in, n_cat, kLinScale, s));
             d.p[0].A = ar.get("dy_sp"); d.p[0].W = ar.get("wt_sp");
             d.lda = n_cat; d.arith = 1; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
@@ -217,10 +243,13 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         // common tail of every sub-block: out_proj backward  (res = resid + attn * Wo^T + bo)
         auto out_proj_bwd = [&](int a) -> int {
             const std::string an = lp + kAttnLong[a];
+            float* sc;
+            SOLA_TRY(stats(dres, D, M, D, 2, &sc));
+            if (sc) SOLA_TRY(bias_from_stats(0, D, G(an + ".out_proj.bias")));
             const WG wo[1] = {{dres, ab(a, "attn"), G(an + ".out_proj.weight"), G(an + ".out_proj.bias")}};
-            SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D));
+            SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D, sc, sc != nullptr));
             SOLA_TRY(transpose_into(W(an + ".out_proj.weight"), D, D, D, 0));
-            return grad_x(dres, D, M, D, D, nullptr, dattn);
+            return grad_x(dres, D, M, D, D, nullptr, dattn, sc);
         };
 
         // (iii) object -> language: x_o2l = GN2(x_mot + attn(q(x_mot), k(lang), v(lang)) Wo)
@@ -235,16 +264,24 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             ad.drop = c->attn_drop(l, 2);
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
+            float *scq, *sckv;
+            SOLA_TRY(stats(dqkv, 3 * D, M, D, 4, &scq));
+            if (scq) SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
             const WG wq[1] = {{dqkv, x_mot, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")}};
-            SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D));
+            SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr));
+            SOLA_TRY(stats(dlkv, 2 * D, B * Wn, 2 * D, 6, &sckv));
+            if (sckv) {
+                SOLA_TRY(bias_from_stats(0, D, G(an + ".k_proj.bias")));
+                SOLA_TRY(bias_from_stats(D, D, G(an + ".v_proj.bias")));
+            }
             const WG wkv[2] = {{dlkv, fb("lang"), G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                                {dlkv + D, fb("lang"), G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
-            SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, B * Wn, D, D));
+            SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, B * Wn, D, D, sckv, sckv != nullptr));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, D, 0));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur]));  // d x_mot = dres + dq Wq
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur], scq));  // d x_mot = dres + dq Wq
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 2 * D, D));
-            SOLA_TRY(grad_x(dlkv, 2 * D, B * Wn, 2 * D, D, dlang_init ? dlang : nullptr, dlang));  // accumulate over layers
+            SOLA_TRY(grad_x(dlkv, 2 * D, B * Wn, 2 * D, D, dlang_init ? dlang : nullptr, dlang, sckv));  // accumulate over layers
             dlang_init = true;
             cur = 1 - cur;
         }
@@ -261,15 +298,22 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
             const float* x_obj = fb(ls + "_obj");
+            float* sc3;
+            SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3));
+            if (sc3) {
+                SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
+                SOLA_TRY(bias_from_stats(D, D, G(an + ".k_proj.bias")));
+                SOLA_TRY(bias_from_stats(2 * D, D, G(an + ".v_proj.bias")));
+            }
             const WG w3[3] = {{dqkv, x_pe, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")},
                               {dqkv + D, x_pe, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                               {dqkv + 2 * D, x_obj, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
-            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D));
+            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, D));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad));  // d(x_obj + pe) = dq Wq + dk Wk
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad, sc3));  // d(x_obj + pe) = dq Wq + dk Wk
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, D, 0));
-            SOLA_TRY(grad_x(dqkv + 2 * D, 3 * D, M, D, D, dres, gbuf[1 - cur]));  // d x_obj (direct) = dres + dv Wv
+            SOLA_TRY(grad_x(dqkv + 2 * D, 3 * D, M, D, D, dres, gbuf[1 - cur], sc3));  // d x_obj (direct) = dres + dv Wv
             cur = 1 - cur;
         }
         // (i) inter-object: x_obj = GN0(xin + attn(q,k,v(xin)) Wo); x_obj also feeds x_obj + pe
@@ -283,14 +327,21 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
                            B * Tp, H, DH, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
             ad.drop = c->attn_drop(l, 0);
             SOLA_TRY(launch_attention_bwd(ad, s));
+            float* sc3;
+            SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3));
+            if (sc3) {
+                SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
+                SOLA_TRY(bias_from_stats(D, D, G(an + ".k_proj.bias")));
+                SOLA_TRY(bias_from_stats(2 * D, D, G(an + ".v_proj.bias")));
+            }
             const WG w3[3] = {{dqkv, xin, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")},
                               {dqkv + D, xin, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                               {dqkv + 2 * D, xin, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
-            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D));
+            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 3 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 3 * D, D));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 3 * D, 2 * D));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur]));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur], sc3));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
             cur = 1 - cur;
         }
     }
@@ -317,15 +368,19 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         const int rows = R * p.Tl[i];
         const float* x_in = i == 0 ? nullptr : fb("act" + std::to_string(i - 1));
         // dW_std[cout][k*cin] = dY^T im2col(x_in), db
+        float* scc = nullptr;  // scale slot of this layer's dY (shared by its dW and dX GEMMs)
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, g.cout, g.k * g.cin) &&
             ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes(rows, g.cout, g.k * g.cin, 1)) {
+            SOLA_TRY(stats(dy, g.cout, rows, g.cout, 8, &scc));
             GemmTnSplitDesc d{};
+            d.scal = scc;
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
-            SOLA_TRY(launch_colsum(dy, G(cp + ".bias"), 1, rows, g.cout, g.cout, 1.f, 0, ar.get("colsum"), ar.total - ar.off.at("colsum"), s));
+            if (scc) SOLA_TRY(bias_from_stats(0, g.cout, G(cp + ".bias")));
+            else SOLA_TRY(launch_colsum(dy, G(cp + ".bias"), 1, rows, g.cout, g.cout, 1.f, 0, ar.get("colsum"), ar.total - ar.off.at("colsum"), s));
         } else {
             GemmTnDesc d{};
             d.A = dy; d.B = i == 0 ? c->last_obj : x_in; d.C = dwstd + ws_off[i]; d.bias_grad = G(cp + ".bias");
@@ -341,8 +396,9 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         if (split && g.cout % 128 == 0 && g.cin % 8 == 0 && (size_t)rows * g.cout <= std::max((size_t)M, (size_t)B * Wn) * 3 * D) {
             // split-f16: z[(r,to)][kk*cin+ci] = sum_co dY[(r,to)][co] w_std[co][kk*cin+ci] in ONE NT GEMM over the output steps (a
             // strided conv's gather form would multiply zeros for every skipped step), then the k taps are gathered into dX
-            float* scal = ar.get("scal");
-            SOLA_TRY(launch_cast_sp16_auto(dy, g.cout, ar.get("dy_sp"), g.cout, rows, g.cout, scal, s));
+            float* scal = scc ? scc : ar.get("scal");
+            if (scc) SOLA_TRY(launch_cast_sp16_scaled(dy, g.cout, ar.get("dy_sp"), g.cout, rows, g.cout, scal, s));
+            else SOLA_TRY(launch_cast_sp16_auto(dy, g.cout, ar.get("dy_sp"), g.cout, rows, g.cout, scal, s));
             SOLA_TRY(launch_cast_sp16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
             GemmDesc d{};
             d.nprob = 1;

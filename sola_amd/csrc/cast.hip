@@ -52,6 +52,30 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ in,
     if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(out, __float_as_uint(m));
 }
 
+// amax_kernel that also leaves the column sums of every 64-row slab in part[slab][cols] (bias gradients: the second, tiny
+// pass over the slabs is colsum_kernel's) - the gradient matrix is read once for both.
+__global__ __launch_bounds__(256) void amax_colsum_kernel(const float* __restrict__ in, unsigned* __restrict__ out, float* __restrict__ part,
+                                                          long long rows, int f4_per_row, int ld_in) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.f;
+    if (c < f4_per_row) {
+        const long long r0 = (long long)blockIdx.y * 64;
+        const int nr = (int)min((long long)64, rows - r0);
+        const float* p = in + r0 * ld_in + (long long)c * 4;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int r = 0; r < nr; ++r, p += ld_in) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * f4_per_row + c) * 4) = sum;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(out, __float_as_uint(m));
+}
+
 // scale = 2^(13 - floor(log2(amax))): the largest magnitude lands in [2^13, 2^14), far from the f16 overflow at 65504
 __device__ __forceinline__ float auto_scale(unsigned amax_bits) {
     const int e = (int)(amax_bits >> 23) - 127;  // floor(log2(amax)) for normal floats
@@ -89,6 +113,24 @@ int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, fl
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * rows * K);
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
                        reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_amax_colsum(const float* in, int ld_in, long long rows, int K, float* scal, float* part, hipStream_t s) {
+    SOLA_ARG(in && scal && part && rows > 0 && K > 0 && K % 4 == 0 && ld_in % 4 == 0, "amax_colsum: K=%d ld_in=%d", K, ld_in);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * rows * K);
+    hipLaunchKernelGGL(amax_colsum_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
+                       reinterpret_cast<unsigned*>(scal), part, rows, K / 4, ld_in);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_cast_sp16_scaled(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && scal && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_sp16_scaled: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * K);
+    const long long n = rows * (K / 8);
+    hipLaunchKernelGGL(cast_sp16_auto_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, rows, K / 8, ld_in, ld_out, scal);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -160,10 +160,11 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     float* at = d.scratch;
     float* xt = at + (size_t)d.nprob * d.N * Mp;
     float* slabs = xt + (size_t)d.nprob * d.K * Mp;
-    float* scal = slabs + (size_t)d.nprob * ks * d.N * d.K;
-    // one scale for all problems: the amax passes accumulate into the same slot
-    SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
-    for (int j = 0; j < d.nprob; ++j) SOLA_TRY(launch_amax_accumulate(d.A[j], d.lda, d.M, d.N, scal, s));
+    float* scal = d.scal ? d.scal : slabs + (size_t)d.nprob * ks * d.N * d.K;
+    if (!d.scal) {  // one scale for all problems: the amax passes accumulate into the same slot
+        SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
+        for (int j = 0; j < d.nprob; ++j) SOLA_TRY(launch_amax_accumulate(d.A[j], d.lda, d.M, d.N, scal, s));
+    }
     const float* xt_of[3] = {nullptr, nullptr, nullptr};
     int n_xt = 0;
     for (int j = 0; j < d.nprob; ++j) {

@@ -51,6 +51,7 @@ struct GemmTnSplitDesc {
     float* C[3];        // dW_j [N, K], contiguous
     int nprob, M, N, K, lda, ldb;
     int conv, T_in, T_out, stride, pad, Cin;  // conv = 1: B is the channels-last conv input [R*T_in, Cin], K = k*Cin (implicit im2col)
+    float* scal;  // optional device pair with scal[0] = max|A| over all problems already computed (else found here)
     float* scratch;
     size_t scratch_bytes;
 };
@@ -180,6 +181,11 @@ int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long lo
 // writes the inverse scale to scal[1] for the GEMM's out_scale_dev.  scal = 2 device floats.
 // scal[0] = max(scal[0], max|in|) as float bits (the caller zeroes the slot); the first half of launch_cast_sp16_auto
 int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, float* scal, hipStream_t s);
+// amax into scal[0] (accumulating; the caller zeroes the pair) AND the column sums of every 64-row slab into
+// part[(rows + 63) / 64][K]: one read of a gradient matrix for its scale and its bias gradients
+int launch_amax_colsum(const float* in, int ld_in, long long rows, int K, float* scal, float* part, hipStream_t s);
+// the cast half of launch_cast_sp16_auto: scal[0] already holds max|in|
+int launch_cast_sp16_scaled(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
