@@ -76,9 +76,9 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  *   1  split-f16: every operand value x is carried as (f16 hi, f16 lo) with hi + lo = x to 22 bits, in the same 4 bytes,
  *      and each product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation - 3/16 of the f32
  *      matrix-pipe time (gfx950 has no xf32/TF32).  Softmax, GroupNorm statistics, score head and losses stay f32.
- * In training (sola_forward_train / sola_backward) precision 1 runs the forward GEMMs and the projection dX GEMMs of the
- * backward on split-f16 casts of the f32 activations / gradients; the weight-gradient GEMMs, the transposed-conv dX and
- * everything saved for the backward stay f32. */
+ * In training (sola_forward_train / sola_backward) precision 1 runs every GEMM of the step (forward, dX and dW of the
+ * projections and convs) on split-f16 casts of the f32 activations / gradients, from 1024 token rows on; attention and
+ * GroupNorm backward and everything saved for the backward stay f32. */
 int sola_set_precision(SolaCtx* ctx, int precision);
 /* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
 int sola_cast_sp16(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float scale, void* stream);
@@ -293,6 +293,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "gemm_glds": split-f16 GEMM staging, 0 registers / 1 direct-to-LDS 128x128 blocks / 4 256x256 blocks / 3 auto;
  * "gemm_persist": 256x256 shape, 1 persistent kernel (default) / 0 one tile per block; "gemm_glds_force": tests only, take the
  * direct-to-LDS kernels for grids of any size; "gemm_splitk", "bilinear_staged";
+ * "train_split_min_rows": precision 1 in training takes the split-f16 GEMMs from this many token rows (B*N*T') on, default 1024
+ * (below that the step is launch-bound and the cast launches cost more than the GEMMs gain); tests set 0;
  * "gemm_ablate": measurement only, 4 = no epilogue (results are then WRONG);
  * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
  * "attn_target_blocks").  Except under gemm_ablate, results are identical across variants up to f32 summation order. */

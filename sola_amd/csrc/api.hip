@@ -256,6 +256,7 @@ void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
+void sola_set_train_split_min_rows(int v);
 void sola_gemm_set_glds_force(int v);
 void sola_gn_set_variant(int v);
 void sola_bilinear_set_staged(int v);
@@ -268,6 +269,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }
+    if (!strcmp(key, "train_split_min_rows")) { sola_set_train_split_min_rows(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_persist")) { sola_gemm_set_persist(value); return SOLA_OK; }
     if (!strcmp(key, "gn_variant")) { sola_gn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "bilinear_staged")) { sola_bilinear_set_staged(value); return SOLA_OK; }

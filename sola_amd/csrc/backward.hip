@@ -8,6 +8,8 @@
 
 #include "ctx.h"
 
+extern int g_train_split_min_rows;
+
 namespace {
 
 struct Arena {
@@ -61,7 +63,7 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
     a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, (size_t)p.B * p.Tp)), (int)D) / sizeof(float) + 64);
-    if (c->precision == 1) {  // split-f16 dX GEMMs: casts of dY and of the transposed weights, the data-dependent scale
+    if (c->precision == 1 && p.M >= g_train_split_min_rows) {  // split-f16 dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
         a.add("scal", 64);

@@ -8,6 +8,9 @@
 
 #include "ctx.h"
 
+int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
+void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
+
 Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
     Plan p;
     p.B = B; p.N = N; p.T = T; p.L = L; p.train = train;
@@ -35,7 +38,7 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
         p.add("conv5_sp", p.M, D);
         p.add("lang_sp", (int64_t)B * p.W, D);
     }
-    if (train && c->precision == 1) {
+    if (train && c->precision == 1 && p.M >= g_train_split_min_rows) {
         // split-f16 training forward: every GEMM input is cast into one of two scratch buffers right before its launch
         // (the f32 activations stay where the backward reads them)
         int64_t amax = std::max<int64_t>(R * T * c->cfg.object_token_dim, std::max<int64_t>((int64_t)p.M * D, (int64_t)B * p.W * D));
@@ -93,7 +96,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     const int R = B * N;
     // training forward in the split-f16 mode (sola_set_precision 1): the same GEMM kernels as forward_fast.hip on casts of
     // the f32 activations, everything the backward reads stays f32
-    const bool split = train && c->precision == 1 && D % 32 == 0 && c->cfg.object_token_dim % 32 == 0;
+    // (from ~1024 token rows on: below that the step is launch-bound and the extra cast launches cost more than the GEMMs gain)
+    const bool split = train && c->precision == 1 && D % 32 == 0 && c->cfg.object_token_dim % 32 == 0 && p.M >= g_train_split_min_rows;
 
     // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
     if (c->ws_dirty || c->ws_every_forward || train) {

@@ -86,8 +86,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self.ws_policy = "auto"
         self.attention_dropout_p = 0.1  # tools/attention.py:12 (hard-coded in the reference)
         # inference arithmetic of the convs / projections: "f32" (exact f32 MFMA) or "f16x3" (split-f16 operands, three
-        # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers the forward GEMMs and the
-        # projection dX / dW GEMMs of the backward (conv gradients, attention and GroupNorm backward stay f32)
+        # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers every GEMM of the
+        # step, forward and backward (attention and GroupNorm backward stay f32)
         self.precision = "f32"
         self._ctx_precision = None
         self._train_ws = None
