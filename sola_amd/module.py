@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -88,7 +90,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # inference arithmetic of the convs / projections: "f32" (exact f32 MFMA) or "f16x3" (split-f16 operands, three
         # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers every GEMM of the
         # step, forward and backward (attention and GroupNorm backward stay f32)
-        self.precision = "f32"
+        self.precision = os.environ.get("SOLA_PRECISION", "f32")  # the entry points take it from the environment
         self._ctx_precision = None
         self._train_ws = None
         self._bwd_ws = None
