@@ -326,6 +326,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 // gfx950 counts loads and stores in one in-order vmcnt, so the first k-tile wait of a tile would also wait for the
 // store acknowledgements of the epilogue before it; that wait names the number of stores instead (the DMA of k-tile 1
 // is older than every one of them).
+// Split-K (GldsArgs::ksplit > 1; weight gradients: 16 output tiles, reduction over ~16 K rows): every (tile, k-range) pair is a
+// work item of its own, ordered like further problems of the launch, and leaves raw partial sums for gemm.hip's ordered reduce.
 // RMODE: 0 = no residual, 1 = f32 residual, 2 = split-f16 residual; CSP: the output is written as split-f16 pairs.  They are
 // compile-time so that the epilogue is straight-line code (with run-time flags the residual registers of the fast path
 // flow through phi nodes the register allocator keeps - and spills - across the whole tile loop).
