@@ -227,6 +227,35 @@ def test_split_gemm_block_shapes_bit_identical(M, N, K):
         _tune(gemm_glds=3, gemm_persist=1, gemm_glds_force=0)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_split_gemm_block_shapes_random(seed):
+    """Seeded random shapes (ragged M, N % 8 == 0, K % 32 == 0, 2..20 k-tiles) through the three direct-to-LDS kernels: bit
+    identical to each other for every epilogue flavour, and right against float64."""
+    rng = np.random.default_rng(1000 + seed)
+    M, N, K = int(rng.integers(1, 3000)), 8 * int(rng.integers(1, 140)), 32 * int(rng.integers(2, 21))
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    asp, wsp, bd, rd = ops.cast_sp16(cuda(a)), ops.cast_sp16(cuda(w), 64.0), cuda(b), cuda(r)
+    rsp = ops.cast_sp16(rd)
+    try:
+        _tune(gemm_glds_force=1)
+        for res, res_split, out_split in [(None, False, False), (rd, False, False), (rsp, True, False), (rsp, True, True)]:
+            outs = []
+            for st in [dict(gemm_glds=1, gemm_persist=0), dict(gemm_glds=4, gemm_persist=0), dict(gemm_glds=4, gemm_persist=1)]:
+                _tune(**st)
+                outs.append(ops.gemm_nt_split(asp, wsp, bd, res, res_split, 1.0 / 64.0, out_split).clone())
+            torch.cuda.synchronize()
+            for o in outs[1:]:
+                assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32)), (M, N, K, res is not None, res_split, out_split)
+        got = ops.gemm_nt_split(asp, wsp, bd, rd, False, 1.0 / 64.0).cpu().numpy()
+        ref = ops.decode_sp16(asp).double().cpu().numpy() @ (ops.decode_sp16(wsp).double().cpu().numpy() / 64.0).T + b + r
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (M, N, K)
+    finally:
+        _tune(gemm_glds=3, gemm_persist=1, gemm_glds_force=0)
+
+
 def test_forward_identical_across_gemm_kernels(full_fast):
     """Whole split-mode forward (implicit-im2col conv launches, three-problem q/k/v launches, residual and split-output
     epilogues) through the persistent kernel, the one-tile kernel and the 128x128 kernel: same bits."""
