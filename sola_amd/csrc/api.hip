@@ -19,7 +19,7 @@ void sola_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sola_last_error(void) { return g_err; }
-extern "C" const char* sola_version(void) { return "sola_hip 0.3 (gfx950; f32 and split-f16 MFMA forward, f32 backward, mask IoU + masklet rows)"; }
+extern "C" const char* sola_version(void) { return "sola_hip 0.4 (gfx950; f32 and split-f16 MFMA forward and backward, mask IoU + masklet rows)"; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // event profiler: start/stop HIP events on the launch stream around every kernel launch while enabled
