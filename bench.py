@@ -24,6 +24,8 @@ Prints ONE JSON line with the driver's contract plus:
                   f16x3 mode: the executed 3 x 2MNK against the 2.5 PFLOP/s dense f16 MFMA peak (algorithmic rate kept)
   roofline_attention - the attention-core kernel named by the north star, against the 8 TB/s HBM peak
   cpu_baseline  - the PyTorch-CPU oracle (a port of the reference path) timed on this box's host cores (rank 0, N=1)
+  training_step - (rank 0, N=1, outside the timed region) one optimizer step of the same network at up to 64 samples, exact
+                  f32 and with the split-f16 GEMMs
 """
 import argparse
 import json
@@ -53,6 +55,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--text-len", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=5, help="steps of the training_step leg (rank 0, N=1, outside the timed region; 0 = skip)")
     ap.add_argument("--cached-ws", action="store_true", help="inference mode: standardise conv weights once (not the headline)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("SOLA_PRECISION", "f16x3"),
                     help="arithmetic of the convs/projections: exact f32 MFMA, or split-f16 operands (3 f16 MFMAs per product, "
@@ -106,6 +109,47 @@ def cpu_baseline(cfg, sd, N, T, L, budget_s):
     return {"value": it / el, "unit": "samples/s", "cores": best, "kind": "port",
             "sample": f"{it} batch-1 forward+loss iterations of the PyTorch-CPU oracle at (T={T},N={N},L={L}) in {el:.1f} s with "
                       f"torch.set_num_threads({best}) (best of sweep {sweep}; host has {ncpu} logical CPUs)"}
+
+
+def training_leg(cfg, sd, dev, B, N, T, L, steps):
+    """Outside the timed region, rank 0 at N=1 only, reported beside the headline: one optimizer step of the same network
+    (sola_forward_train + losses + sola_backward + gradient norms / clip + AdamW) at up to 64 samples, exact f32 and with
+    the split-f16 GEMMs (module.precision = "f16x3")."""
+    from sola_amd import synth
+    from sola_amd.loss import track_selection_losses
+    from sola_amd.module import LanguageAlignedTrackSelectionModule
+
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m = m.to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(cfg, B, N, T, L, 1).items()}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        sm, st = m(inp["object_tokens"], inp["lang_tokens"])
+        neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+        loss3 = track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, 1.5, 0.07, 0.3)
+        loss3[0].backward()
+        m.clip_grad_norm_(1.0)
+        opt.step()
+
+    res = {"batch": B, "steps": steps, "unit": "samples/s",
+           "what": "forward_train + BCE/alignment losses + backward + clip + AdamW; dropout on, one GPU"}
+    for prec in ("f32", "f16x3"):
+        m.precision = prec
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[prec] = {"value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
+    del m, opt
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -280,6 +324,8 @@ def main():
         }
         if exact is not None:
             out["exact_f32_mode"] = exact
+        if world == 1 and args.train_steps > 0:
+            out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps)
         if world == 1 and args.cpu_seconds > 0:
             cb = cpu_baseline(cfg, sd, N, T, L, args.cpu_seconds)
             cb["value"] = round(cb["value"], 3)
