@@ -179,6 +179,69 @@ __global__ __launch_bounds__(256) void loss_terms_rows_kernel(const LossArgs a) 
     }
 }
 
+// The same block shape with the token rows in REGISTERS: the LDS version above reads 8 token float4s from LDS per negative
+// float4 it loads (1056 ds_read_b128 per lane, 8.8 GB of LDS traffic at the headline batch: LDS-bound at ~130 us); here
+// every wave keeps its lanes' slices of the 8 rows (NI float4 per row) and only the n_neg + 1 vectors stream through.
+// Same per-lane summation order, so the logits are bit-identical to the LDS version's.
+template <int NI>
+__global__ __launch_bounds__(256) void loss_terms_regs_kernel(const LossArgs a) {
+    extern __shared__ float sh[];
+    float* logit = sh;  // [RPB][n_neg + 1], pos last
+    const int d4n = a.D >> 2;
+    const int b = blockIdx.y, n0 = blockIdx.x * LOSS_RPB;
+    const int rows = min(LOSS_RPB, a.N - n0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 tk[LOSS_RPB][NI];
+#pragma unroll
+    for (int r = 0; r < LOSS_RPB; ++r)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            tk[r][i] = r < rows ? reinterpret_cast<const float4*>(a.score_tokens + ((long long)b * a.N + n0 + r) * a.D)[lane + 64 * i]
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* negb = a.neg + (long long)b * a.neg_batch_stride;
+    const int stride = a.n_neg + 1;
+    for (int m = wave; m <= a.n_neg; m += 4) {
+        const float4* vec = reinterpret_cast<const float4*>(m < a.n_neg ? negb + (long long)m * a.D : a.pos + (long long)b * a.D);
+        float s[LOSS_RPB];
+#pragma unroll
+        for (int r = 0; r < LOSS_RPB; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 v = vec[lane + 64 * i];
+#pragma unroll
+            for (int r = 0; r < LOSS_RPB; ++r) {
+                const float4 tv = tk[r][i];
+                s[r] += (tv.x * v.x + tv.y * v.y) + (tv.z * v.z + tv.w * v.w);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < LOSS_RPB; ++r) {
+            const float t = wave_sum(s[r]);
+            if (lane == 0) logit[r * stride + m] = t * a.temp_scale;  // tools/loss.py:29-36
+        }
+    }
+    (void)d4n;
+    __syncthreads();
+    if (threadIdx.x < rows) {
+        const int r = threadIdx.x;
+        const long long bn = (long long)b * a.N + n0 + r;
+        const float* negl = logit + r * stride;
+        const float y = a.labels[bn];
+        const float x = a.score_map[bn];
+        const float w = y > 0.f ? a.pos_w : 1.f;  // train.py:98-99
+        int arg = 0;
+        float best = negl[0];
+        for (int m = 1; m < a.n_neg; ++m)  // torch.argmax: first maximum (tools/loss.py:40)
+            if (negl[m] > best) { best = negl[m]; arg = m; }
+        float neg_sum = 0.f;
+        for (int m = 0; m < a.n_neg; ++m) neg_sum += bce_logits(negl[m], m == arg ? (1.f - y) : 0.f);
+        a.terms[bn * 3 + 0] = w * bce_logits(x, y);
+        a.terms[bn * 3 + 1] = bce_logits(negl[a.n_neg], y);
+        a.terms[bn * 3 + 2] = neg_sum;
+        if (a.neg_argmax) a.neg_argmax[bn] = arg;
+    }
+}
+
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* terms, int n, int n_neg, float pos_w,
                                                           float align_w, float* loss3) {
     __shared__ float red[4];
@@ -231,7 +294,12 @@ int launch_loss(const LossDesc& d, hipStream_t s) {
         SolaProfScope prof(SOLA_PROF_HEAD, s, 2.0 * d.B * d.N * (double)d.D * (d.n_neg + 1),
                            4.0 * d.B * d.N * (double)d.D);
         const size_t lds_rows = ((size_t)LOSS_RPB * d.D + (size_t)LOSS_RPB * (d.n_neg + 1)) * 4;
-        if (lds_rows <= 64 * 1024)
+        const size_t lds_logits = (size_t)LOSS_RPB * (d.n_neg + 1) * 4;
+        if (d.D == 1024 && lds_logits <= 64 * 1024)
+            hipLaunchKernelGGL(loss_terms_regs_kernel<4>, dim3((d.N + LOSS_RPB - 1) / LOSS_RPB, d.B), dim3(256), lds_logits, s, a);
+        else if (d.D == 512 && lds_logits <= 64 * 1024)
+            hipLaunchKernelGGL(loss_terms_regs_kernel<2>, dim3((d.N + LOSS_RPB - 1) / LOSS_RPB, d.B), dim3(256), lds_logits, s, a);
+        else if (lds_rows <= 64 * 1024)
             hipLaunchKernelGGL(loss_terms_rows_kernel, dim3((d.N + LOSS_RPB - 1) / LOSS_RPB, d.B), dim3(256), lds_rows, s, a);
         else
             hipLaunchKernelGGL(loss_terms_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
