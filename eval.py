@@ -27,7 +27,8 @@ def evaluate(cfg):
     module = LanguageAlignedTrackSelectionModule(cfg["model"])
     module.load_state_dict(torch.load(cfg["eval"]["weight_path"], map_location="cpu", weights_only=True))
     module = module.to(device).eval()
-    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device)
+    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device,
+                       allow_standin=bool(cfg.get("synthetic", False)))
     loader, _ = make_loader(cfg["dataset"], "valid", rank, world, cfg.get("synthetic", None), cfg["model"])
     tcfg = dict(cfg["train"])
     tcfg["pred_threshold"] = cfg["eval"]["pred_threshold"]

@@ -80,6 +80,21 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  * projections and convs) on split-f16 casts of the f32 activations / gradients, from 1024 token rows on; attention and
  * GroupNorm backward and everything saved for the backward stay f32. */
 int sola_set_precision(SolaCtx* ctx, int precision);
+/* Range handling of precision 1 in sola_forward / sola_forward_ragged.  The split-f16 pairs keep 22 significant bits for
+ * every value within 2^-16 of its tensor's largest, on top of a per-tensor power-of-two scale:
+ *   - the caller's object tokens and text tokens and every projection weight matrix get a data-dependent scale found on the
+ *     device (largest magnitude -> [2^13, 2^14)), undone in the consuming GEMM's epilogue: any input scale, weight outliers;
+ *   - the activations between the stages use a fixed scale; every kernel that writes one checks the value against the f16
+ *     range (non-finite or |v| >= 65000 sets a guard word), and when the weights change the rms each GroupNorm will emit,
+ *     sqrt(mean(gamma^2 + beta^2)), is checked against [2^-6, 2^9].
+ * With the guard enabled (default) the forward reads the guard words (a 4-byte copy and ONE stream synchronisation per
+ * call) and, when one is set, repeats the call on the exact-f32 kernels in the same workspace, so the caller never sees a
+ * result computed outside the format's range.  enable = 0 keeps the call fully asynchronous (also while the stream is
+ * being captured into a graph, where the check is skipped automatically); the words can then be read with
+ * sola_split_fallback_count: *count = calls repeated in f32 so far, *last_guard = guard bits of the last checked call
+ * (bit 0: a value left the f16 range, bit 1: GroupNorm weights outside the covered magnitude). */
+int sola_set_split_guard(SolaCtx* ctx, int enable);
+int sola_split_fallback_count(const SolaCtx* ctx, int64_t* count, int32_t* last_guard);
 /* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
 int sola_cast_sp16(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float scale, void* stream);
 /* The same conversion with a data-dependent power-of-two scale, for operands whose magnitude the host does not know

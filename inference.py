@@ -29,7 +29,8 @@ def inference(cfg):
     module = LanguageAlignedTrackSelectionModule(cfg["model"])
     module.load_state_dict(torch.load(cfg["eval"]["weight_path"], map_location="cpu", weights_only=True))
     module = module.to(device).eval()
-    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device)
+    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device,
+                       allow_standin=bool(cfg.get("synthetic", False)))
     loader, dataset = make_loader(cfg["dataset"], "test", rank, world, cfg.get("synthetic", None), cfg["model"])
     thr = cfg["eval"]["pred_threshold"]
     out_dir = cfg["results"]["test_output_dir"]

@@ -47,6 +47,8 @@ SIGNATURES = {
     "sola_weights_changed": (_i, [_vp]),
     "sola_set_ws_policy": (_i, [_vp, _i]),
     "sola_set_precision": (_i, [_vp, _i]),
+    "sola_set_split_guard": (_i, [_vp, _i]),
+    "sola_split_fallback_count": (_i, [_vp, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "sola_cast_sp16": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp]),
     "sola_gemm_nt_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "sola_cast_sp16_auto": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),

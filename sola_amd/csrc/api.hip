@@ -19,7 +19,7 @@ void sola_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sola_last_error(void) { return g_err; }
-extern "C" const char* sola_version(void) { return "sola_hip 0.4 (gfx950; f32 and split-f16 MFMA forward and backward, mask IoU + masklet rows)"; }
+extern "C" const char* sola_version(void) { return "sola_hip 0.5 (gfx950; f32 and range-guarded split-f16 MFMA forward and backward, ragged batches, mask IoU + masklet rows)"; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // event profiler: start/stop HIP events on the launch stream around every kernel launch while enabled
@@ -179,6 +179,8 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (c->ws_buf) (void)hipFree(c->ws_buf);
     if (c->ws16_buf) (void)hipFree(c->ws16_buf);
     if (c->lin16_buf) (void)hipFree(c->lin16_buf);
+    if (c->scal_buf) (void)hipFree(c->scal_buf);
+    if (c->guard_host) (void)hipHostFree(c->guard_host);
     delete c;
     return SOLA_OK;
 }
@@ -314,6 +316,12 @@ extern "C" int sola_set_precision(SolaCtx* c, int precision) {
         SOLA_HIP(hipSetDevice(c->device));
         SOLA_HIP(hipMalloc(&c->ws16_buf, ws_total * sizeof(float)));
         SOLA_HIP(hipMalloc(&c->lin16_buf, (size_t)c->cfg.n_layers * 12 * D * D * sizeof(float)));
+        const size_t n_pairs = 2 + (size_t)c->cfg.n_layers * 12;
+        SOLA_HIP(hipMalloc(&c->scal_buf, (2 * n_pairs + 2) * sizeof(float)));
+        SOLA_HIP(hipMemset(c->scal_buf, 0, (2 * n_pairs + 2) * sizeof(float)));
+        c->guard = reinterpret_cast<int*>(c->scal_buf + 2 * n_pairs);
+        SOLA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->guard_host), 2 * sizeof(int), hipHostMallocDefault));
+        c->guard_host[0] = c->guard_host[1] = 0;
     }
     c->precision = precision;
     c->ws_dirty = true;
@@ -353,11 +361,49 @@ extern "C" int sola_gemm_nt_split_scaled(const float* a_sp, int lda, const float
     return launch_gemm(gd, as_stream(stream_));
 }
 
+// Reads the guard words the split-f16 forward left (ctx.h) and reports whether the call must be repeated in exact f32.
+// Synchronises the stream (4 bytes back to the host), so it is skipped while the stream is being captured into a graph.
+int sola_split_guard_tripped(SolaCtx* c, hipStream_t s, bool* tripped) {
+    *tripped = false;
+    if (!c->split_guard || !c->guard) return SOLA_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return SOLA_OK;
+    SOLA_HIP(hipMemcpyAsync(c->guard_host, c->guard, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SOLA_HIP(hipStreamSynchronize(s));
+    *tripped = (c->guard_host[0] | c->guard_host[1]) != 0;
+    return SOLA_OK;
+}
+
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
-    if (c && c->precision == 1)
-        return sola_forward_fast_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_));
-    return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_), false);
+    hipStream_t s = as_stream(stream_);
+    if (c && c->precision == 1) {
+        SOLA_TRY(sola_forward_fast_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s));
+        bool tripped = false;
+        SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
+        if (!tripped) return SOLA_OK;
+        // a value left the range the split-f16 pairs cover (or the weights say it would): same call, exact-f32 kernels.
+        // The f32 plan is a subset of the split plan, so the workspace fits.
+        c->split_fallbacks += 1;
+        c->precision = 0;
+        const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
+        c->precision = 1;
+        return st;
+    }
+    return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
+}
+
+extern "C" int sola_set_split_guard(SolaCtx* c, int enable) {
+    SOLA_ARG(c, "set_split_guard: null ctx");
+    c->split_guard = enable != 0;
+    return SOLA_OK;
+}
+
+extern "C" int sola_split_fallback_count(const SolaCtx* c, int64_t* count, int32_t* last_guard) {
+    SOLA_ARG(c && count, "split_fallback_count: null argument");
+    *count = c->split_fallbacks;
+    if (last_guard) *last_guard = c->guard_host ? (c->guard_host[0] | c->guard_host[1]) : 0;
+    return SOLA_OK;
 }
 
 extern "C" int sola_forward_train(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L,

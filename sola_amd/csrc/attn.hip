@@ -44,6 +44,7 @@ struct AttnArgs {
     int o_sp16;       // write o as split-f16 pairs (cast.hip) for the 3 x f16 MFMA out-projection
     int sp_log2;      // packed: log2 of the per-unit slot count SP (SP = pow2 >= max(Sq, Sk)), units per tile = 16 >> sp_log2
     int in_sp16;      // shared: q, k, v are split-f16 rows (the SPLIT kernel shape)
+    int* guard;       // o_sp16: range guard word (AttnDesc::guard), null = unchecked
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -70,7 +71,7 @@ __device__ __forceinline__ f32x4 mfma3(const HL4& a, const HL4& b, f32x4 c) {
 
 // Store one query row's output tile.  op points at o[row][h*DH]; this lane holds d = 16c + 4*g4 + {0..3} of every chunk c.
 template <int NC>
-__device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[NC], float inv, int sp16) {
+__device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[NC], float inv, int sp16, int* guard) {
     if (!sp16) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -90,6 +91,12 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
             for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
             half8* dst = reinterpret_cast<half8*>(op + 4 * g4 + c * 16);
             dst[0] = hi; dst[1] = lo;
+            if (guard) {  // NaN fails the comparison too
+                float m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+                if (!(m < 65000.f)) atomicOr(guard, 1);
+            }
         }
     }
 }
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         if (q_ok) {
             if (a.lse && g4 == 0) a.lse[qrow * a.H + h] = mx + logf(rs);
             const float inv = 1.f / rs;
-            store_o<NC>(a.o + qrow * a.ldo + h * DH, g4, oacc, inv, a.o_sp16);
+            store_o<NC>(a.o + qrow * a.ldo + h * DH, g4, oacc, inv, a.o_sp16, a.guard);
         }
     } else {
         // ---------------------------------------------------------------- shared: (group, head, q-split) units, a block
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
             if (q_ok) {
                 if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * a.q_rs) * a.H + h] = m_run + logf(l_run);
                 const float inv = 1.f / l_run;
-                store_o<NC>(a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH, g4, oacc, inv, a.o_sp16);
+                store_o<NC>(a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH, g4, oacc, inv, a.o_sp16, a.guard);
             }
         }
         cur = nxt;
@@ -469,14 +476,16 @@ int g_attn_resident_blocks = 512;  // shared mode: grid size cap (2 blocks per C
 int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
 
 template <int DH, int NW, bool SPLIT>
-static void launch_shared(const AttnArgs& a, long long blocks, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW, SPLIT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+static int launch_shared(const AttnArgs& a, long long blocks, size_t lds, hipStream_t s) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW, SPLIT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once.done(dev);
     }
     hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false, NW, SPLIT>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
+    return SOLA_OK;
 }
 
 template <int DH>
@@ -487,11 +496,12 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
     SOLA_ARG(!(packed && a.in_sp16), "attention: split-f16 q/k/v are not supported for sequences of <= 16 steps (packed shape)");
     SOLA_ARG(!a.in_sp16 || DH % 16 == 0, "attention: split-f16 q/k/v need head_dim %% 16 == 0");
     if (packed) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce once;
+        int dev;
+        if (once.needed(&dev)) {
             SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, true, 4, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * row_bytes)));
-            attr_set = true;
+            once.done(dev);
         }
         int need = a.Sq > a.Sk ? a.Sq : a.Sk, lg = 0;
         while ((1 << lg) < need) ++lg;
@@ -526,11 +536,11 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         if (g_attn_variant != 0 && blocks > resident) blocks = resident;
         const size_t lds = (size_t)a.kv_rows * row_bytes;
         if (a.in_sp16) {
-            if (wide) launch_shared<DH, 8, true>(a, blocks, lds, s);
-            else launch_shared<DH, 4, true>(a, blocks, lds, s);
+            if (wide) SOLA_TRY((launch_shared<DH, 8, true>(a, blocks, lds, s)));
+            else SOLA_TRY((launch_shared<DH, 4, true>(a, blocks, lds, s)));
         } else {
-            if (wide) launch_shared<DH, 8, false>(a, blocks, lds, s);
-            else launch_shared<DH, 4, false>(a, blocks, lds, s);
+            if (wide) SOLA_TRY((launch_shared<DH, 8, false>(a, blocks, lds, s)));
+            else SOLA_TRY((launch_shared<DH, 4, false>(a, blocks, lds, s)));
         }
     }
     SOLA_LAUNCH_CHECK();
@@ -556,6 +566,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.drop = d.drop;
     a.o_sp16 = d.o_sp16;
     a.in_sp16 = d.in_sp16;
+    a.guard = d.o_sp16 ? d.guard : nullptr;
     a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

@@ -271,13 +271,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 template <int DH>
 int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * 2 * 16 * (DH + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        once.done(dev);
     }
     AttnBwdArgs a = a0;
     a.ntile = (a.Sq + 15) / 16;

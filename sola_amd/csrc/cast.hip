@@ -106,7 +106,89 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_kernel(const float* __rest
     o[1] = lo;
 }
 
+// ---- the same pair of passes for a set of equally shaped matrices (the 12 * n_layers projection weights): blockIdx.z picks
+//      the matrix, its scale pair sits at scal + 2 * z
+constexpr int MULTI_MAX = 64;
+struct MultiArgs {
+    const float* in[MULTI_MAX];
+    float* out[MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void amax_multi_kernel(const MultiArgs a, unsigned* __restrict__ scal, long long n4) {
+    const float* in = a.in[blockIdx.z];
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(in + i * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(scal + 2 * blockIdx.z, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void cast_sp16_auto_multi_kernel(const MultiArgs a, float* __restrict__ scal, long long n8) {
+    const float* in = a.in[blockIdx.z];
+    float* out = a.out[blockIdx.z];
+    float* sc = scal + 2 * blockIdx.z;
+    const float scale = auto_scale(reinterpret_cast<const unsigned*>(sc)[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[1] = 1.f / scale;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const float4 v0 = *reinterpret_cast<const float4*>(in + i * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(in + i * 8 + 4);
+        const float v[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (_Float16)v[j];
+            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        }
+        half8* o = reinterpret_cast<half8*>(out + i * 8);
+        o[0] = hi;
+        o[1] = lo;
+    }
+}
+
+// one block per GroupNorm: rms over the channels of sqrt(gamma^2 + beta^2) = the rms of that norm's output
+constexpr int NORM_MAX = 32;
+struct NormArgs {
+    NormPair n[NORM_MAX];
+};
+__global__ __launch_bounds__(256) void norm_range_check_kernel(const NormArgs a, int* guard) {
+    __shared__ float red[4];
+    const NormPair np = a.n[blockIdx.x];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < np.C; c += 256) s += np.gamma[c] * np.gamma[c] + np.beta[c] * np.beta[c];
+    const float rms = sqrtf(block_sum_256(s, red) / (float)np.C);
+    if (threadIdx.x == 0 && !(rms >= 0.015625f && rms <= 512.f)) atomicOr(guard, 2);
+}
+
 }  // namespace
+
+int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n, int rows, int K, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && scal && n > 0 && rows > 0 && K > 0 && K % 8 == 0, "cast_sp16_auto_multi: n=%d rows=%d K=%d", n, rows, K);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 12.0 * n * rows * K);
+    SOLA_HIP(hipMemsetAsync(scal, 0, (size_t)2 * n * sizeof(float), s));
+    const long long elems = (long long)rows * K;
+    const unsigned blocks = (unsigned)std::min<long long>(1024, (elems / 8 + 255) / 256);
+    for (int i0 = 0; i0 < n; i0 += MULTI_MAX) {
+        const int nn = std::min(MULTI_MAX, n - i0);
+        MultiArgs a;
+        for (int i = 0; i < nn; ++i) { a.in[i] = in[i0 + i]; a.out[i] = out[i0 + i]; }
+        for (int i = nn; i < MULTI_MAX; ++i) { a.in[i] = nullptr; a.out[i] = nullptr; }
+        hipLaunchKernelGGL(amax_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, reinterpret_cast<unsigned*>(scal + 2 * i0), elems / 4);
+        SOLA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cast_sp16_auto_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, scal + 2 * i0, elems / 8);
+        SOLA_LAUNCH_CHECK();
+    }
+    return SOLA_OK;
+}
+
+int launch_norm_range_check(const NormPair* norms, int n, int* guard, hipStream_t s) {
+    SOLA_ARG(norms && guard && n > 0 && n <= NORM_MAX, "norm_range_check: n=%d (1..%d)", n, NORM_MAX);
+    NormArgs a;
+    for (int i = 0; i < NORM_MAX; ++i) a.n[i] = norms[i < n ? i : 0];
+    hipLaunchKernelGGL(norm_range_check_kernel, dim3(n), dim3(256), 0, s, a, guard);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, float* scal, hipStream_t s) {
     SOLA_ARG(in && scal && rows > 0 && K > 0 && K % 4 == 0 && ld_in % 4 == 0, "amax: K=%d ld_in=%d", K, ld_in);

@@ -92,6 +92,32 @@ static inline DropoutCfg make_dropout(float p, unsigned long long seed, unsigned
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Function attributes (MaxDynamicSharedMemorySize) and the CU count belong to a DEVICE: a launcher keeps one
+// DeviceOnce per kernel instantiation and runs its set-up the first time each device launches it.
+// `if (once.needed(&dev)) { ...; once.done(dev); }` - setting an attribute twice from two racing threads is harmless.
+struct DeviceOnce {
+    unsigned long long mask = 0;  // bit d: device d has been set up (read/written with relaxed atomics)
+    bool needed(int* dev) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) d = 0;
+        *dev = d;
+        return ((__atomic_load_n(&mask, __ATOMIC_ACQUIRE) >> d) & 1ull) == 0;
+    }
+    void done(int dev) { __atomic_fetch_or(&mask, 1ull << dev, __ATOMIC_RELEASE); }
+};
+// multiProcessorCount of the current device (cached per device)
+static inline int sola_cu_count() {
+    static int n_cu[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) d = 0;
+    int v = __atomic_load_n(&n_cu[d], __ATOMIC_RELAXED);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    __atomic_store_n(&n_cu[d], v, __ATOMIC_RELAXED);
+    return v;
+}
+
 // Launch check used after every kernel launch.
 #define SOLA_LAUNCH_CHECK()                                                                      \
     do {                                                                                         \

@@ -52,6 +52,19 @@ struct SolaCtx {
     bool lin16_dirty = true;  // split copies of the projection weights are stale
     float* ws16_buf = nullptr;
     float* lin16_buf = nullptr;
+    // Range handling of the split-f16 mode (device floats, ctx-owned): (max|x| bits, 1/scale) pairs of the data-dependent
+    // power-of-two scales - [0] object tokens, [1] text ++ negative tokens, [2 + i] projection weight i (same index as
+    // lin16_buf) - followed by the guard words: guard[0] is cleared by every inference forward and gets bit 0 from any kernel
+    // that had to write a non-finite or out-of-f16-range value as a split-f16 pair; guard[1] is recomputed when the weights
+    // change (bit 1: a GroupNorm's (gamma, beta) put its output outside the magnitude the fixed activation scale covers).
+    // Either sends the call to the exact-f32 kernels (api.hip: sola_forward).
+    float* scal_buf = nullptr;
+    int* guard = nullptr;
+    int* guard_host = nullptr;      // pinned, 2 ints
+    bool split_guard = true;        // sola_set_split_guard
+    long long split_fallbacks = 0;  // calls that were repeated in exact f32
+    float* scal_pair(int i) const { return scal_buf + 2 * i; }
+    const float* lin_inv_scale(int layer, int attn, int proj) const { return scal_buf + 2 * (2 + (layer * 3 + attn) * 4 + proj) + 1; }
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
     // the seed used by the last sola_forward_train is kept for sola_backward
     float p_drop_encoder = 0.f, p_drop_attention = 0.f;
@@ -64,7 +77,10 @@ static const int kConvIdx[6] = {0, 4, 8, 12, 16, 20};
 static const int kNormIdx[5] = {1, 5, 9, 13, 17};
 static const char* const kAttnShort[3] = {"obj", "mot", "o2l"};
 static const char* const kAttnLong[3] = {"obj_attn", "motion_attn", "object2lang_attn"};
-constexpr float kLinScale = 64.f;  // linear weights are U(-1/32, 1/32)-sized: pre-scale so the lo halves of their split-f16 copies are normal f16
+constexpr float kLinScale = 64.f;  // backward only (transposed weight casts): linear weights are U(-1/32, 1/32)-sized
+// (re)builds the split-f16 copies of the projection weights with a per-matrix power-of-two scale and runs the weight-time
+// range check; no-op unless the copies are stale
+int sola_refresh_lin16(SolaCtx* c, hipStream_t s);
 
 inline const float* ctx_weight(const SolaCtx* c, const std::string& name) {
     auto it = c->index.find(name);

@@ -114,23 +114,16 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             }
         c->ws_dirty = false;
     }
-    auto lin16 = [&](const std::string& attn, int proj) -> const float* {  // attn = "object_lang_align_layers.<l>.<name>"
+    auto lin_idx = [&](const std::string& attn, int proj) -> int {  // attn = "object_lang_align_layers.<l>.<name>"
         const int l = attn[attn.find('.') + 1] - '0';
         int a3 = 0;
         for (int a = 0; a < 3; ++a)
             if (attn.size() >= strlen(kAttnLong[a]) && attn.compare(attn.size() - strlen(kAttnLong[a]), std::string::npos, kAttnLong[a]) == 0) a3 = a;
-        return c->lin16_buf + ((size_t)(l * 3 + a3) * 4 + proj) * D * D;
+        return (l * 3 + a3) * 4 + proj;
     };
-    if (split && c->lin16_dirty) {
-        static const char* pn4[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
-        for (int l = 0; l < c->cfg.n_layers; ++l)
-            for (int a3 = 0; a3 < 3; ++a3)
-                for (int j = 0; j < 4; ++j) {
-                    const std::string nm = "object_lang_align_layers." + std::to_string(l) + "." + kAttnLong[a3] + "." + pn4[j] + ".weight";
-                    SOLA_TRY(launch_cast_sp16(W(nm), D, c->lin16_buf + ((size_t)(l * 3 + a3) * 4 + j) * D * D, D, D, D, kLinScale, s));
-                }
-        c->lin16_dirty = false;
-    }
+    auto lin16 = [&](const std::string& attn, int proj) -> const float* { return c->lin16_buf + (size_t)lin_idx(attn, proj) * D * D; };
+    auto lin_inv = [&](const std::string& attn, int proj) -> const float* { return c->scal_buf + 2 * (2 + lin_idx(attn, proj)) + 1; };
+    if (split) SOLA_TRY(sola_refresh_lin16(c, s));
     float* const sp_a = split ? buf("sp_a") : nullptr;
     float* const sp_b = split ? buf("sp_b") : nullptr;
 
@@ -149,7 +142,12 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split && g.cin % 32 == 0) {
-            SOLA_TRY(launch_cast_sp16(x, g.cin, sp_a, g.cin, (long long)R * t_in, g.cin, 1.f, s));
+            if (i == 0) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip)
+                SOLA_TRY(launch_cast_sp16_auto(x, g.cin, sp_a, g.cin, (long long)R * t_in, g.cin, c->scal_pair(0), s));
+                gd.out_scale_dev = c->scal_pair(0) + 1;
+            } else {
+                SOLA_TRY(launch_cast_sp16(x, g.cin, sp_a, g.cin, (long long)R * t_in, g.cin, 1.f, s));
+            }
             gd.p[0].A = sp_a; gd.p[0].W = c->ws16_buf + c->ws_off[i];
             gd.arith = 1; gd.out_scale = 1.f;
         }
@@ -177,7 +175,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     // a5: alignment layers (module/module.py:22-52)
     const float scale = 1.0f / sqrtf((float)DH);
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, const std::string& attn, int nprob, int rows,
-                       float* o0, float* o1, float* o2, int first_proj) -> int {
+                       float* o0, float* o1, float* o2, int first_proj, float* a_scal = nullptr) -> int {
         static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
         const float* as[3] = {a0, a1, a2};
         float* os[3] = {o0, o1, o2};
@@ -199,12 +197,15 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                 if (at < 0) {
                     at = nsrc++;
                     src[at] = as[j];
-                    SOLA_TRY(launch_cast_sp16(as[j], D, dst[at], D, rows, D, 1.f, s));
+                    if (a_scal) SOLA_TRY(launch_cast_sp16_auto(as[j], D, dst[at], D, rows, D, a_scal, s));
+                    else SOLA_TRY(launch_cast_sp16(as[j], D, dst[at], D, rows, D, 1.f, s));
                 }
                 gd.p[j].A = dst[at];
                 gd.p[j].W = lin16(attn, first_proj + j);
+                gd.p[j].scale_dev = lin_inv(attn, first_proj + j);
             }
-            gd.arith = 1; gd.out_scale = 1.f / kLinScale;
+            gd.arith = 1; gd.out_scale = 1.f;
+            if (a_scal) gd.out_scale_dev = a_scal + 1;
         }
         return launch_gemm(gd, s);
     };
@@ -216,8 +217,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split) {
             SOLA_TRY(launch_cast_sp16(ao, D, sp_a, D, M, D, 1.f, s));
-            gd.p[0].A = sp_a; gd.p[0].W = lin16(attn, 3);
-            gd.arith = 1; gd.out_scale = 1.f / kLinScale;
+            gd.p[0].A = sp_a; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
+            gd.arith = 1; gd.out_scale = 1.f;
         }
         return launch_gemm(gd, s);
     };
@@ -264,7 +265,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp));
         // (iii) object -> language cross attention: module.py:46-50
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, lp + "object2lang_attn", 1, M, ab(2, "q"), nullptr, nullptr, 0));
-        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, B * Wn, ab(2, "lk"), ab(2, "lv"), nullptr, 1));
+        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, B * Wn, ab(2, "lk"), ab(2, "lv"), nullptr, 1,
+                         split ? c->scal_pair(1) : nullptr));
         {
             AttnDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
                         (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale, lse(2)};

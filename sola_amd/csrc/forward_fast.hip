@@ -10,9 +10,54 @@
 // losses stay in f32.  Parity: the same golden-vector tests and 1e-3 bound as the f32 mode (tests/test_gpu_fast.py).
 #include <math.h>
 
+#include <algorithm>
+
 #include "ctx.h"
 
-namespace {
+// Split-f16 copies of the 12 * n_layers projection weights, each with its own power-of-two scale (max|w| -> [2^13, 2^14),
+// found on the device: a trained matrix may be far from the U(-1/32, 1/32) of the default init, and a few outliers must not
+// push the rest into f16 subnormals - the pair format keeps 22 bits for everything within 2^-16 of the largest entry), plus
+// the weight-time range check of the activations the GroupNorms will emit (kernels.h: launch_norm_range_check).
+int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
+    if (!c->lin16_dirty) return SOLA_OK;
+    SOLA_ARG(c->lin16_buf && c->scal_buf, "split-f16 weights requested before sola_set_precision(ctx, 1)");
+    static const char* pn[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
+    const int D = c->cfg.lang_token_dim;
+    std::vector<const float*> in;
+    std::vector<float*> out;
+    for (int l = 0; l < c->cfg.n_layers; ++l)
+        for (int a = 0; a < 3; ++a)
+            for (int j = 0; j < 4; ++j) {
+                const std::string nm = "object_lang_align_layers." + std::to_string(l) + "." + kAttnLong[a] + "." + pn[j] + ".weight";
+                const float* w = ctx_weight(c, nm);
+                if (!w) {
+                    sola_set_error("forward: weight '%s' has not been set", nm.c_str());
+                    return SOLA_ERR_WEIGHT;
+                }
+                in.push_back(w);
+                out.push_back(c->lin16_buf + ((size_t)(l * 3 + a) * 4 + j) * D * D);
+            }
+    SOLA_TRY(launch_cast_sp16_auto_multi(in.data(), out.data(), (int)in.size(), D, D, c->scal_pair(2), s));
+    std::vector<NormPair> norms;
+    for (int i = 0; i < 5; ++i) {
+        const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
+        norms.push_back(NormPair{ctx_weight(c, np + ".weight"), ctx_weight(c, np + ".bias"), c->conv[i].cout});
+    }
+    for (int l = 0; l < c->cfg.n_layers; ++l)
+        for (int j = 0; j < 3; ++j) {
+            const std::string np = "object_lang_align_layers." + std::to_string(l) + ".norm." + std::to_string(j);
+            norms.push_back(NormPair{ctx_weight(c, np + ".weight"), ctx_weight(c, np + ".bias"), D});
+        }
+    for (const NormPair& n : norms)
+        if (!n.gamma || !n.beta) {
+            sola_set_error("forward: a GroupNorm weight has not been set");
+            return SOLA_ERR_WEIGHT;
+        }
+    SOLA_HIP(hipMemsetAsync(c->guard + 1, 0, sizeof(int), s));
+    for (size_t i0 = 0; i0 < norms.size(); i0 += 32)
+        SOLA_TRY(launch_norm_range_check(norms.data() + i0, (int)std::min<size_t>(32, norms.size() - i0), c->guard + 1, s));
+    c->lin16_dirty = false;
+    return SOLA_OK;
 }
 
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
@@ -59,20 +104,14 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
     }
     // The projection weights are used as they are by the reference (no per-forward transform), so their split copies
     // are refreshed only when a weight pointer or value changed (sola_set_weight / sola_weights_changed).
-    if (c->lin16_dirty) {
-        static const char* pn[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
-        for (int l = 0; l < c->cfg.n_layers; ++l)
-            for (int a = 0; a < 3; ++a)
-                for (int j = 0; j < 4; ++j) {
-                    const std::string nm = "object_lang_align_layers." + std::to_string(l) + "." + kAttnLong[a] + "." + pn[j] + ".weight";
-                    SOLA_TRY(launch_cast_sp16(W(nm), D, lin16(l, a, j), D, D, D, kLinScale, s));
-                }
-        c->lin16_dirty = false;
-    }
+    SOLA_TRY(sola_refresh_lin16(c, s));
+    SOLA_HIP(hipMemsetAsync(c->guard, 0, sizeof(int), s));  // per-call range guard word (ctx.h)
 
-    // ---- encoder: split-f16 activations between the stages, f32 conv outputs into GroupNorm
-    SOLA_TRY(launch_cast_sp16(obj, c->cfg.object_token_dim, buf("obj_sp"), c->cfg.object_token_dim, (long long)R * T,
-                              c->cfg.object_token_dim, 1.f, s));
+    // ---- encoder: split-f16 activations between the stages, f32 conv outputs into GroupNorm.
+    // The caller's tokens come with an unknown magnitude (SAM2 memory-attention features here, anything elsewhere): their
+    // largest entry is mapped into [2^13, 2^14) by a power of two found on the device and conv0's epilogue undoes it.
+    SOLA_TRY(launch_cast_sp16_auto(obj, c->cfg.object_token_dim, buf("obj_sp"), c->cfg.object_token_dim, (long long)R * T,
+                                   c->cfg.object_token_dim, c->scal_pair(0), s));
     const float* x = buf("obj_sp");
     int t_in = T;
     for (int i = 0; i < 6; ++i) {
@@ -90,6 +129,8 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
         gd.arith = 1; gd.out_scale = 1.f;
+        if (i == 0) gd.out_scale_dev = c->scal_pair(0) + 1;
+        gd.guard = c->guard;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
@@ -100,6 +141,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
             nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
             nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
             nd.out_sp16 = 1;
+            nd.guard = c->guard;
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
         }
@@ -110,11 +152,11 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
 
     SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
     SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
-    SOLA_TRY(launch_cast_sp16(buf("lang"), D, buf("lang_sp"), D, (long long)B * Wn, D, 1.f, s));
+    SOLA_TRY(launch_cast_sp16_auto(buf("lang"), D, buf("lang_sp"), D, (long long)B * Wn, D, c->scal_pair(1), s));
 
     const float scale = 1.0f / sqrtf((float)DH);
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, int layer, int attn, int nprob, int rows, float* o0,
-                       float* o1, float* o2, int first_proj, int out_sp16) -> int {
+                       float* o1, float* o2, int first_proj, int out_sp16, const float* a_inv_scale = nullptr) -> int {
         static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
         const std::string an = "object_lang_align_layers." + std::to_string(layer) + "." + kAttnLong[attn];
         const float* as[3] = {a0, a1, a2};
@@ -122,9 +164,10 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         GemmDesc gd{};
         gd.nprob = nprob;
         for (int j = 0; j < nprob; ++j)
-            gd.p[j] = GemmProblem{as[j], lin16(layer, attn, first_proj + j), W(an + "." + pn[first_proj + j] + ".bias"), nullptr, os[j]};
+            gd.p[j] = GemmProblem{as[j], lin16(layer, attn, first_proj + j), W(an + "." + pn[first_proj + j] + ".bias"), nullptr, os[j],
+                                  c->lin_inv_scale(layer, attn, first_proj + j)};
         gd.M = rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
-        gd.arith = 1; gd.out_scale = 1.f / kLinScale; gd.c_sp16 = out_sp16;
+        gd.arith = 1; gd.out_scale = 1.f; gd.out_scale_dev = a_inv_scale; gd.c_sp16 = out_sp16; gd.guard = c->guard;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         return launch_gemm(gd, s);
     };
@@ -132,9 +175,9 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         const std::string an = "object_lang_align_layers." + std::to_string(layer) + "." + kAttnLong[attn];
         GemmDesc gd{};
         gd.nprob = 1;
-        gd.p[0] = GemmProblem{buf("attn"), lin16(layer, attn, 3), W(an + ".out_proj.bias"), resid, buf("res")};
+        gd.p[0] = GemmProblem{buf("attn"), lin16(layer, attn, 3), W(an + ".out_proj.bias"), resid, buf("res"), c->lin_inv_scale(layer, attn, 3)};
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
-        gd.arith = 1; gd.out_scale = 1.f / kLinScale; gd.r_sp16 = resid_sp16;
+        gd.arith = 1; gd.out_scale = 1.f; gd.r_sp16 = resid_sp16;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         return launch_gemm(gd, s);
     };
@@ -146,7 +189,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         nd.beta = W(lp + "norm." + std::to_string(idx) + ".bias");
         nd.n_inst = n_inst; nd.inner = inner; nd.outer_stride = outer; nd.inner_stride = inner_stride;
         nd.tok_stride = tok_stride; nd.ntok = ntok; nd.C = D; nd.groups = c->cfg.n_groups_module;
-        nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0; nd.out_sp16 = sp16;
+        nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0; nd.out_sp16 = sp16; nd.guard = c->guard;
         return launch_group_norm(nd, s);
     };
     auto attention = [&](const float* q, const float* k, const float* v, int G, int Sq, int Sk, int inner, long long qo,
@@ -154,6 +197,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         AttnDesc ad{q, k, v, buf("attn"), D, D, D, D, G, H, DH, Sq, Sk, inner, qo, qi, qr, ko, ki, kr, scale, nullptr};
         ad.o_sp16 = 1;
         ad.in_sp16 = in_sp16;
+        ad.guard = c->guard;
         return launch_attention(ad, s);
     };
     // q/k/v leave the projection GEMM already split when the attention that reads them runs the split-f16 MFMA shape.
@@ -187,7 +231,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         SOLA_TRY(gn(lp, 1, x_mot, nullptr, 1, B * N, 1, Tp, 0, 1, Tp));
         // (iii) object -> language attention (module.py:46-50)
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0, o2l_sp));
-        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1, o2l_sp));
+        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1, o2l_sp, c->scal_pair(1) + 1));
         SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, o2l_sp));
         SOLA_TRY(out_proj(l, 2, x_mot, 1));
         SOLA_TRY(gn(lp, 2, x_o2l, nullptr, last ? 0 : 1, B, 1, (long long)N * Tp, 0, 1, N * Tp));  // the score head reads f32

@@ -30,7 +30,13 @@ struct GemmArgs {
     int ksplit;       // > 1: blockIdx.y owns k-tiles [y*kt_per, (y+1)*kt_per) and writes raw partial sums to `part`
     int kt_per;
     float* part;      // [nprob][ksplit][M][N]
+    int* guard;       // c_sp16: range guard word (GemmDesc::guard)
 };
+
+// |v| must stay inside the f16 range to be written as a split-f16 pair; NaN fails the comparison too
+__device__ __forceinline__ void guard_sp16(int* guard, float m) {
+    if (guard && !(m < 65000.f)) atomicOr(guard, 1);
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
         }
         return;
     }
-    const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+    const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wc * (BN / 2) + j * 32 + col_l;
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
                         const _Float16 hi = (_Float16)v;
                         cb[n & 7] = hi;
                         cb[8 + (n & 7)] = (_Float16)(v - (float)hi);
+                        guard_sp16(a.guard, fabsf(v));
                     } else {
                         pr.C[(long long)m * a.ldc + n] = v;
                     }
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
         const float4 v = *reinterpret_cast<const float4*>(part + (long long)sidx * a.M * a.N);
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     }
-    const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+    const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
     float v[4] = {sum.x * osc, sum.y * osc, sum.z * osc, sum.w * osc};
     if (pr.bias) {
 #pragma unroll
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
             cb[e] = hi;
             cb[8 + e] = (_Float16)(v[e] - (float)hi);
         }
+        guard_sp16(a.guard, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) pr.C[(long long)m * a.ldc + n + e] = v[e];
@@ -353,11 +361,12 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
     constexpr size_t lds = (size_t)(BM + BN) * 2 * LDP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        once.done(dev);
     }
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit > 1 ? a.ksplit : 1, nprob);
     hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>), grid, dim3(256), lds, s, a);
@@ -404,6 +413,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.r_sp16 = d.r_sp16;
     a.c_sp16 = d.arith == 1 ? d.c_sp16 : 0;
     a.ksplit = 1; a.kt_per = 0; a.part = nullptr;
+    a.guard = a.c_sp16 ? d.guard : nullptr;
     SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs

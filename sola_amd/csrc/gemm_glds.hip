@@ -44,7 +44,13 @@ struct GldsArgs {
     const float* out_scale_dev;
     int r_sp16, c_sp16;
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
+    int* guard;  // c_sp16: range guard word (GemmDesc::guard), null = unchecked
 };
+
+__device__ __forceinline__ void guard_sp16x4(int* guard, const float (&v)[4]) {
+    const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (guard && !(m < 65000.f)) atomicOr(guard, 1);  // NaN fails the comparison too
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     //      row segment) instead of 64 strided dword stores per lane.  Bias, output scale and the residual are applied on
     //      the way out.
     if (a.ablate & 4) return;
-    const float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+    const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
     float* tile = reinterpret_cast<float*>(lds) + wave * (64 * 64);  // [64 rows][64 cols] f32 (256-B rows: b32 writes and b128 reads are conflict-free)
     const int col_l = lane & 31, row_l = (lane >> 5) << 2;
     const int c4 = lane & 15;    // 16-byte column piece
@@ -300,6 +306,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
                 for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
                 *reinterpret_cast<half4*>(cb) = hh;
                 *reinterpret_cast<half4*>(cb + 8) = ll;
+                guard_sp16x4(a.guard, v);
             } else if (vec_ok) {
                 *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 
         // ---- epilogue: eight 16-row strips per wave tile through this wave's private LDS strip
         GemmProblem pr = a.p[z];
-        float osc = a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale;
+        float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
         int ldc = a.ldc;
         if (a.ksplit > 1) {  // raw partial sums; scale, bias, residual and the output format are the reduce pass's
             pr.C = a.part + (long long)(z * a.ksplit + ks) * a.M * a.N;
@@ -634,6 +641,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
                             *reinterpret_cast<half4*>(cb) = hh;
                             *reinterpret_cast<half4*>(cb + 8) = ll;
+                            guard_sp16x4(a.guard, v);
                         } else {
                             *reinterpret_cast<float4*>(pr.C + (long long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                         }
@@ -697,6 +705,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                         for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
                         *reinterpret_cast<half4*>(cb) = hh;
                         *reinterpret_cast<half4*>(cb + 8) = ll;
+                        guard_sp16x4(a.guard, v);
                     } else if (vec_ok) {
                         *reinterpret_cast<float4*>(pr.C + (long long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
@@ -727,11 +736,12 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_n = (N + GBN - 1) / GBN;
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
     constexpr size_t lds = (size_t)2 * (GBM + GBN) * ROWB;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        once.done(dev);
     }
     hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
                        dim3(WAVES_M * WAVES_N * 64), lds, s, a);
@@ -749,17 +759,14 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
     a.nprob = nprob;
     constexpr size_t lds = (size_t)2 * 512 * ROWB + 8 * 16 * 64 * 4;  // two stages + eight epilogue strips = 160 KiB
-    static bool attr_set = false;
-    static int n_cu = 256;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n_cu = prop.multiProcessorCount;
-        attr_set = true;
+        once.done(dev);
     }
+    const int n_cu = sola_cu_count();
     const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
     hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>), dim3(grid), dim3(512), lds, s, a);
@@ -810,6 +817,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.c_sp16 = d.c_sp16;
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
+    a.guard = d.c_sp16 ? d.guard : nullptr;
     a.ksplit = d.ksplit > 1 ? d.ksplit : 1;
     a.kper = d.K / GBK / a.ksplit;
     a.part = d.splitk_ws;

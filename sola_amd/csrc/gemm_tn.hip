@@ -234,11 +234,12 @@ int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
     mps = (mps + TM - 1) / TM * TM;
     a.m_per_split = mps;
     constexpr size_t lds = (size_t)4 * TM * TP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        once.done(dev);
     }
     {
         SolaProfScope prof(SOLA_PROF_GEMM_TN, s, 2.0 * d.M * d.N * (double)d.K, 4.0 * ((double)d.M * (d.N + d.K) + (double)splits * d.N * d.K));

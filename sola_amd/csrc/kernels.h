@@ -9,6 +9,8 @@ struct GemmProblem {
     const float* bias;  // [N] or null
     const float* R;     // [M, N] residual or null
     float* C;           // [M, N]
+    const float* scale_dev;  // arith 1, optional: this problem's own result multiplier in device memory (the inverse of the
+                             // data-dependent power-of-two scale its W operand was cast with); null = 1
 };
 struct GemmDesc {
     GemmProblem p[3];
@@ -30,6 +32,9 @@ struct GemmDesc {
     // [nprob][S][M][N] f32, reduced in a fixed order (deterministic).  Null = never split.
     float* splitk_ws;
     size_t splitk_bytes;
+    // arith 1 with c_sp16, optional: device word that gets bit 0 set when a value written as split-f16 is not finite or
+    // beyond the f16 range (|v| >= 65000): the inference forward then repeats the call on the exact-f32 kernels
+    int* guard;
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 
@@ -83,6 +88,7 @@ struct AttnDesc {
     DropoutCfg drop;  // on the probabilities (tools/attention.py:71)
     int o_sp16;       // output as split-f16 pairs
     int in_sp16;      // q, k, v are split-f16 rows (written by a GEMM with c_sp16); not for sequences of <= 16 steps
+    int* guard;       // o_sp16, optional: range guard word (see GemmDesc::guard)
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 
@@ -173,6 +179,7 @@ struct GroupNormDesc {
     int leaky;
     DropoutCfg drop;
     int out_sp16;  // y / y2 written as split-f16 pairs
+    int* guard;    // out_sp16, optional: range guard word (see GemmDesc::guard)
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
@@ -187,6 +194,15 @@ int launch_amax_colsum(const float* in, int ld_in, long long rows, int K, float*
 // the cast half of launch_cast_sp16_auto: scal[0] already holds max|in|
 int launch_cast_sp16_scaled(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
+// The same for up to 64 equally shaped matrices in three launches (the projection weights): in[i] [rows][K] -> out[i], scale pair
+// of matrix i at scal + 2 * i
+int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n, int rows, int K, float* scal, hipStream_t s);
+// Weight-time range check of the split-f16 activations: a GroupNorm output has E[y^2] = gamma^2 + beta^2 per channel (its
+// input is normalised), so the magnitude of every tensor the norms emit is known from the weights alone.  Sets bit 1 of
+// *guard when the rms of any (gamma, beta) pair lies outside [2^-6, 2^9] - where the fixed-scale split-f16 activations would
+// lose bits to f16 subnormals or come near the f16 overflow.
+struct NormPair { const float *gamma, *beta; int C; };
+int launch_norm_range_check(const NormPair* norms, int n, int* guard, hipStream_t s);
 int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, hipStream_t s);
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
 int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,

@@ -73,6 +73,7 @@ struct GnArgs {
     int leaky;
     DropoutCfg drop;  // applied after the LeakyReLU (module/module.py:78)
     int out_sp16;     // write y / y2 as split-f16 pairs (cast.hip) instead of f32
+    int* guard;       // out_sp16: range guard word (GroupNormDesc::guard), null = unchecked
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -110,6 +111,12 @@ __device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, c
             for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v8[j]; lo[j] = (_Float16)(v8[j] - (float)hi[j]); }
             half8* dst = reinterpret_cast<half8*>(a.y + off);
             dst[0] = hi; dst[1] = lo;
+            if (a.guard) {  // |y + pe| <= |y| + 1: one test covers both outputs (NaN fails the comparison too)
+                float m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v8[j]));
+                if (!(m < 65000.f)) atomicOr(a.guard, 1);
+            }
             if (a.y2) {
                 const float w8[8] = {o2.x, o2.y, o2.z, o2.w, n2.x, n2.y, n2.z, n2.w};
 #pragma unroll
@@ -283,7 +290,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     GnArgs a;
     a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = d.out_sp16 ? d.guard : nullptr;
     SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);

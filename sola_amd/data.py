@@ -200,7 +200,10 @@ def make_loader(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, 
     from .dist import shard_indices
 
     sc = cfg_dataset[split]
-    use_syn = synthetic if synthetic is not None else not os.path.isdir(str(cfg_dataset.get("track_root", "")))
+    use_syn = bool(synthetic)
+    if not use_syn and not os.path.isdir(str(cfg_dataset.get("track_root", ""))):
+        raise FileNotFoundError(f"dataset.track_root '{cfg_dataset.get('track_root')}' does not exist; pass --synthetic true "
+                                "for a plumbing run on generated tracks")
     if use_syn:
         ds = SyntheticTracks(n_samples=int(cfg_dataset.get("synthetic_samples", 32)), n_tracks=int(cfg_dataset.get("synthetic_tracks", 64)),
                              n_frames=int(cfg_dataset.get("synthetic_frames", 32)),
@@ -208,7 +211,8 @@ def make_loader(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, 
                              with_labels=split != "test")
     else:
         ds = TrackDataset(sc, cfg_dataset["data_root"], cfg_dataset["track_root"])
-    sub = torch.utils.data.Subset(ds, shard_indices(len(ds), rank, world))
+    # training shards are padded to equal length: one gradient all-reduce per step must meet its peers on every rank
+    sub = torch.utils.data.Subset(ds, shard_indices(len(ds), rank, world, pad=(split == "train")))
     loader = torch.utils.data.DataLoader(sub, batch_size=sc.get("batch_size", 1), shuffle=(split == "train"),
                                          num_workers=0 if use_syn else int(cfg_dataset.get("num_workers", 0)), pin_memory=True, collate_fn=collate)
     return loader, ds

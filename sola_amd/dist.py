@@ -31,8 +31,17 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
-def shard_indices(n_samples, rank, world):
-    """Static round-robin ownership: sample i belongs to rank i % world."""
+def shard_indices(n_samples, rank, world, pad=False):
+    """Static round-robin ownership: sample i belongs to rank i % world.
+
+    ``pad=True`` (training): every rank gets exactly ceil(n / world) indices, the short shards being completed by
+    wrapping around to the first samples (torch's DistributedSampler rule with drop_last=False).  Training issues one
+    gradient all-reduce per optimizer step, so ranks with different step counts would pair a 131.9 MB gradient bucket
+    with another rank's 8-float statistics reduce - a hang or silent corruption on RCCL."""
+    if pad and world > 1 and n_samples > 0:
+        total = -(-n_samples // world) * world
+        order = [i % n_samples for i in range(total)]  # the index list, completed from its own head
+        return order[rank::world]
     return list(range(rank, n_samples, world))
 
 

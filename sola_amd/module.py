@@ -92,6 +92,11 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # step, forward and backward (attention and GroupNorm backward stay f32)
         self.precision = os.environ.get("SOLA_PRECISION", "f32")  # the entry points take it from the environment
         self._ctx_precision = None
+        # "f16x3" inference calls are range-guarded: a value outside the split-f16 pairs' range (or GroupNorm weights that
+        # would put activations there) makes the library repeat the call on the exact-f32 kernels (one 4-byte read-back and
+        # stream sync per call; set False for fully asynchronous calls / graph capture).  See sola_set_split_guard.
+        self.split_guard = True
+        self._ctx_guard = None
         self._train_ws = None
         self._bwd_ws = None
         self._train_inputs = None
@@ -113,6 +118,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
                                     C.byref(handle)), "sola_ctx_create")
         self._ctx, self._ctx_device, self._bound = handle, device, {}
         self._ctx_precision = None
+        self._ctx_guard = None
 
     def _release_ctx(self):
         if getattr(self, "_ctx", None) is not None:
@@ -152,6 +158,17 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         if self._ctx_precision != self.precision:
             check(lib().sola_set_precision(self._ctx, 1 if self.precision == "f16x3" else 0), "sola_set_precision")
             self._ctx_precision = self.precision
+        if self._ctx_guard != bool(self.split_guard):
+            check(lib().sola_set_split_guard(self._ctx, 1 if self.split_guard else 0), "sola_set_split_guard")
+            self._ctx_guard = bool(self.split_guard)
+
+    def split_fallbacks(self):
+        """(calls repeated in exact f32 because the split-f16 range guard tripped, guard bits of the last checked call)."""
+        if self._ctx is None:
+            return 0, 0
+        n, g = C.c_int64(), C.c_int32()
+        check(lib().sola_split_fallback_count(self._ctx, C.byref(n), C.byref(g)), "sola_split_fallback_count")
+        return int(n.value), int(g.value)
 
     def _get_workspace(self, nbytes, device):
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
@@ -270,7 +287,10 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             vals = [0.0] * n_groups
         else:
             sq = self._grad_sqnorms(tensors, group_ids, n_groups)
-            self._last_grad_sq = sq  # device doubles, reused by clip_grad_norm_ without another reduction
+            # device doubles, reused by clip_grad_norm_ without another reduction - but only for these very gradient
+            # values: the tag is every gradient's (storage, version), so an all-reduce, unscale, accumulation or a new
+            # backward in between makes clip_grad_norm_ reduce again instead of clipping with a stale norm
+            self._last_grad_sq = (sq, self._grad_tag([p.grad for p in self.parameters() if p.grad is not None]))
             vals = sq[:n_groups].cpu().tolist()  # the single host sync
         out = {"total_grad_norm": sum(vals) ** 0.5}
         for (name, _), v in zip(groups, vals):
@@ -297,18 +317,23 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
               "sola_grad_sqnorms")
         return out
 
+    def _grad_tag(self, grads):
+        # the HIP backward writes gradient storage behind torch's back (no version bump): the step counter covers that
+        return (self._train_generation,) + tuple((g.data_ptr(), g._version) for g in grads)
+
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm) (train.py:121-122) as one in-place multi-tensor
         launch driven by the device-side total from the last get_grad_norm_dict(); no host sync."""
         grads = [p.grad for p in self.parameters() if p.grad is not None]
         if not grads:
             return
-        if getattr(self, "_last_grad_sq", None) is None:
+        cached = getattr(self, "_last_grad_sq", None)
+        if cached is None or cached[1] != self._grad_tag(grads):
             self.get_grad_norm_dict()
         n = len(grads)
         dev = grads[0].device
         ptrs = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
         numel = (C.c_int64 * n)(*[g.numel() for g in grads])
-        total = self._last_grad_sq[-1:]
+        total = self._last_grad_sq[0][-1:]
         check(lib().sola_grad_clip(ptrs, numel, n, ptr(total), float(max_norm), current_stream(dev)), "sola_grad_clip")
         self._last_grad_sq = None

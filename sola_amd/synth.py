@@ -106,6 +106,47 @@ def make_state_dict(cfg, seed=42):
     return out
 
 
+# Range cases of the split-f16 mode (tests/golden/range_golden.npz): weights away from the default-init scale and inputs
+# away from N(0,1).  Every variant is a formula on top of make_state_dict, so both boxes regenerate it.
+WEIGHT_VARIANTS = ("base", "lin_x2", "lin_x8", "lin_div64", "lin_outliers", "conv_x100", "gamma_div256", "gamma_x300", "gamma_x3000")
+# (object-token scale, text-token scale).  The encoder's first GroupNorm removes the object-token scale, so any value is a
+# well-posed case; the text tokens feed the object->language softmax directly, which saturates into an arg-max beyond a scale
+# of ~16 - there the reference's own fp32 result is 1e-2 away from exact arithmetic and parity is not defined (see "cond").
+RANGE_INPUT_SCALES = ((1e-5, 1.0), (1e-3, 1.0), (1e-1, 1.0), (10.0, 1.0), (1e3, 1.0), (1.0, 1e-5), (1.0, 1e-3), (1.0, 16.0),
+                      (1e-4, 1e-2), (1e3, 4.0))
+
+
+def make_state_dict_variant(cfg, seed=42, variant="base"):
+    sd = make_state_dict(cfg, seed)
+    if variant == "base":
+        return sd
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    for key in sd:
+        is_lin = "_proj.weight" in key
+        is_conv = key.startswith("short_motion_encoder") and key.endswith(".weight") and sd[key].ndim == 3
+        is_norm = (".norm." in key) or (key.startswith("short_motion_encoder") and sd[key].ndim == 1 and
+                                        int(key.split(".")[1]) in (1, 5, 9, 13, 17))
+        if variant == "lin_x2" and is_lin:
+            sd[key] = sd[key] * np.float32(2.0)
+        elif variant == "lin_x8" and is_lin:  # attention scores x64: saturated softmax, the reference itself is ill-conditioned here
+            sd[key] = sd[key] * np.float32(8.0)
+        elif variant == "lin_div64" and is_lin:
+            sd[key] = sd[key] * np.float32(1.0 / 64.0)
+        elif variant == "lin_outliers" and is_lin:  # 16 entries per matrix at 64x the init bound
+            flat = sd[key].reshape(-1)
+            idx = rng.choice(flat.size, size=16, replace=False)
+            flat[idx] = np.where(rng.uniform(size=16) < 0.5, -2.0, 2.0).astype(np.float32)
+        elif variant == "conv_x100" and is_conv:  # weight standardisation removes the scale (module/ws.py:9-13)
+            sd[key] = sd[key] * np.float32(100.0)
+        elif variant == "gamma_div256" and is_norm:  # GroupNorm outputs of rms ~ 0.004: below what the fixed activation scale covers
+            sd[key] = sd[key] * np.float32(1.0 / 256.0)
+        elif variant == "gamma_x300" and is_norm:
+            sd[key] = sd[key] * np.float32(300.0)
+        elif variant == "gamma_x3000" and is_norm:
+            sd[key] = sd[key] * np.float32(3000.0)
+    return {k: np.ascontiguousarray(v.astype(np.float32)) for k, v in sd.items()}
+
+
 def make_inputs(cfg, B, N, T, L, seed=0, pos_rate=0.2):
     """Synthetic sample batch: object tokens and text tokens ~ N(0,1), labels ~ Bernoulli,
     pos_tokens = mean over the L text tokens (what train.py:86-90 yields for an unpadded batch)."""

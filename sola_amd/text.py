@@ -1,9 +1,12 @@
 """Text side of the path: frozen RoBERTa stays on stock PyTorch-ROCm (north star); this module only wraps it.
 
 ``encode(expressions) -> (lang_tokens [B,L,D], pos_tokens [B,1,D])`` is train.py:80-91 (tokenise, last_hidden_state,
-attention-mask mean pooling).  Neither box has network access or the checkpoint, so when
-``sentence-transformers/all-roberta-large-v1`` cannot be loaded from a local cache a deterministic hashed embedding
-with the same output contract is used instead (and says so once); it exists to let the entry points run end to end."""
+attention-mask mean pooling).  A missing checkpoint is an ERROR, as in the reference (train.py:31-35 fails when
+``AutoModel.from_pretrained`` does): masks, metrics or weights computed from meaningless language tokens must not be
+written with exit code 0.  Neither box here has network access or the checkpoint, so a deterministic hashed embedding
+with the same output contract exists for plumbing runs - only when asked for explicitly: ``allow_standin=True``
+(the entry points pass it for ``--synthetic true``) or ``SOLA_ALLOW_TEXT_STANDIN=1``.  ``TextEncoder.kind`` says which
+encoder produced the tokens ("roberta" / "hashed-standin"); eval.py records it in its JSON."""
 from __future__ import annotations
 
 import hashlib
@@ -14,19 +17,29 @@ import torch
 
 
 class TextEncoder:
-    def __init__(self, name: str, dim: int, device):
+    def __init__(self, name: str, dim: int, device, allow_standin: bool = False):
+        import os
+
         self.dim, self.device = dim, device
         self.tokenizer = self.model = None
+        self.kind = "roberta"
+        allow_standin = bool(allow_standin) or os.environ.get("SOLA_ALLOW_TEXT_STANDIN", "0") == "1"
         try:
-            import os
-
             os.environ.setdefault("HF_HUB_OFFLINE", "1")
             from transformers import AutoModel, AutoTokenizer
 
             self.tokenizer = AutoTokenizer.from_pretrained(name, local_files_only=True)
             self.model = AutoModel.from_pretrained(name, local_files_only=True).to(device).eval()
         except Exception as e:  # no local checkpoint
-            warnings.warn(f"text encoder '{name}' is not available offline ({type(e).__name__}); using hashed stand-in embeddings")
+            if not allow_standin:
+                raise RuntimeError(
+                    f"text encoder '{name}' could not be loaded from the local cache ({type(e).__name__}: {e}). "
+                    "Refusing to continue with stand-in embeddings: results would be meaningless. For a plumbing run "
+                    "pass --synthetic true or set SOLA_ALLOW_TEXT_STANDIN=1.") from e
+            self.tokenizer = self.model = None
+            self.kind = "hashed-standin"
+            warnings.warn(f"text encoder '{name}' is not available offline ({type(e).__name__}); using hashed stand-in "
+                          "embeddings because the stand-in was explicitly allowed")
 
     @torch.no_grad()
     def encode(self, expressions):

@@ -152,6 +152,45 @@ def gen_model_golden():
     print("full_golden.npz", os.path.getsize(os.path.join(HERE, "full_golden.npz")) / 1e6, "MB")
 
 
+def gen_range_golden():
+    """Reference outputs for inputs away from N(0,1) and weights away from the default-init scale (the range cases of the
+    split-f16 mode): full configuration at the headline shape, outputs only."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    B, N, T, L = 1, 64, 32, 16
+    store = {"shape": np.array([B, N, T, L], dtype=np.int32), "input_scales": np.array(synth.RANGE_INPUT_SCALES, dtype=np.float64),
+             "weight_variants": np.array(synth.WEIGHT_VARIANTS)}
+    inp = synth.make_inputs(cfg, B, N, T, L, seed=300)
+
+    from oracle import sola_oracle  # float64 evaluation: how far the reference's own fp32 result is from exact arithmetic
+
+    def run(m, so, sl):
+        with torch.no_grad():
+            sm, st = m(torch.from_numpy(inp["object_tokens"] * np.float32(so)), torch.from_numpy(inp["lang_tokens"] * np.float32(sl)))
+        return sm.numpy(), st.numpy()
+
+    def cond(sd, so, sl, sm, st):
+        osm, ost = sola_oracle.forward(sola_oracle.to_torch_state(sd), cfg, inp["object_tokens"] * np.float32(so),
+                                       inp["lang_tokens"] * np.float32(sl), dtype=torch.float64)
+        return np.array([np.abs(osm.numpy() - sm).max(), np.abs(ost.numpy() - st).max()])
+
+    m, base_sd = build_reference(cfg, seed=42)
+    for i, (so, sl) in enumerate(synth.RANGE_INPUT_SCALES):
+        sm, st = run(m, so, sl)
+        store[f"in{i}.score_map"], store[f"in{i}.score_tokens"] = sm, st[:, :8]  # tokens of the first 8 tracks
+        store[f"in{i}.cond"] = cond(base_sd, so, sl, sm, st)
+        print("input scales", (so, sl), "max|score|", np.abs(sm).max(), "max|tokens|", np.abs(st).max(), "cond", store[f"in{i}.cond"])
+    for v in synth.WEIGHT_VARIANTS:
+        m = LanguageAlignedTrackSelectionModule(cfg)
+        sd = synth.make_state_dict_variant(cfg, 42, v)
+        m.load_state_dict({k: torch.from_numpy(a) for k, a in sd.items()}, strict=True)
+        sm, st = run(m.eval(), 1.0, 1.0)
+        store[f"w.{v}.score_map"], store[f"w.{v}.score_tokens"] = sm, st[:, :8]
+        store[f"w.{v}.cond"] = cond(sd, 1.0, 1.0, sm, st)
+        print("weights", v, "max|score|", np.abs(sm).max(), "max|tokens|", np.abs(st).max(), "cond", store[f"w.{v}.cond"])
+    np.savez_compressed(os.path.join(HERE, "range_golden.npz"), **store)
+    print("range_golden.npz", os.path.getsize(os.path.join(HERE, "range_golden.npz")) / 1e6, "MB")
+
+
 def rect_masks(rng, n, H, W, base=None, jitter=0):
     out = np.zeros((n, H, W), dtype=np.uint8)
     boxes = []
@@ -255,3 +294,5 @@ if __name__ == "__main__":
         gen_iou_golden()
     if which in ("all", "model"):
         gen_model_golden()
+    if which in ("all", "range"):
+        gen_range_golden()

@@ -1,0 +1,165 @@
+"""Range safety of the split-f16 mode (module.precision = "f16x3"), against outputs of the REAL reference
+(tests/golden/range_golden.npz, made by tests/golden/gen_golden.py from module/module.py:130-162):
+
+* object / text tokens scaled by 1e-5 ... 1e3: the data-dependent power-of-two scales keep the split path itself inside
+  the parity bar - no fallback is allowed to hide a failure here;
+* projection weights scaled, shrunk or carrying outliers, conv weights x100: per-matrix device-side scales, no fallback;
+* GroupNorm weights that put activations outside what the fixed activation scale covers, or a value beyond the f16 range:
+  the guard trips and the call is repeated on the exact-f32 kernels (bit-identical to the f32 mode);
+* a 256-sample batch at the headline shape, sampled rows against the oracle.
+
+Tolerance: the north-star 1e-3 on logits of the usual magnitude (|score| <= 16); where the scaled inputs / weights make the
+logits themselves large the same RELATIVE bar is used (1e-3 / 16 of the largest reference logit).  Two variants (weights
+x8, GroupNorm x300 / x3000) saturate the softmaxes into arg-maxes: there the reference's own fp32 result sits up to 0.1
+from a float64 evaluation (stored as "cond" next to each golden output) and the bar is 3x that distance - those cases
+check that nothing overflows or falls apart, not the fourth digit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import _load  # noqa: E402
+from oracle import sola_oracle  # noqa: E402
+from sola_amd import synth  # noqa: E402
+from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
+
+CFG = synth.DEFAULT_MODEL_CFG
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return _load("range_golden.npz")
+
+
+def build(variant, precision):
+    m = LanguageAlignedTrackSelectionModule(CFG)
+    sd = synth.make_state_dict_variant(CFG, 42, variant)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    m.precision = precision
+    return m, sd
+
+
+@pytest.fixture(scope="module")
+def base_models():
+    return {p: build("base", p)[0] for p in ("f16x3", "f32")}
+
+
+def forward(m, gold, so=1.0, sl=1.0):
+    B, N, T, L = [int(v) for v in gold["shape"]]
+    inp = synth.make_inputs(CFG, B, N, T, L, seed=300)
+    obj = torch.from_numpy(inp["object_tokens"] * np.float32(so)).cuda()
+    lang = torch.from_numpy(inp["lang_tokens"] * np.float32(sl)).cuda()
+    with torch.no_grad():
+        sm, st = m(obj, lang)
+    return sm.cpu().numpy(), st.cpu().numpy()
+
+
+def check(sm, st, g_sm, g_st, what, cond=(0.0, 0.0)):
+    tol_sm = max(1e-3 * max(1.0, float(np.abs(g_sm).max()) / 16.0), 3.0 * float(cond[0]))
+    tol_st = max(1e-3 * max(1.0, float(np.abs(g_st).max()) / 16.0), 3.0 * float(cond[1]))
+    e_sm = float(np.abs(sm - g_sm).max())
+    e_st = float(np.abs(st[:, :8] - g_st).max())
+    print(f"{what}: |score_map err| {e_sm:.3e} (tol {tol_sm:.1e}), |score_tokens err| {e_st:.3e} (tol {tol_st:.1e})")
+    assert e_sm <= tol_sm and e_st <= tol_st, (what, e_sm, tol_sm, e_st, tol_st)
+    # decisions: identical wherever the reference logit is not within the tolerance of the threshold
+    clear = np.abs(g_sm) > 2 * tol_sm
+    np.testing.assert_array_equal((sm > 0)[clear], (g_sm > 0)[clear])
+
+
+@pytest.mark.parametrize("i", range(len(synth.RANGE_INPUT_SCALES)))
+def test_input_scales_split_path_meets_the_bar_without_fallback(gold, base_models, i):
+    so, sl = synth.RANGE_INPUT_SCALES[i]
+    assert tuple(gold["input_scales"][i]) == (so, sl)
+    m = base_models["f16x3"]
+    n0, _ = m.split_fallbacks()
+    sm, st = forward(m, gold, so, sl)
+    n1, bits = m.split_fallbacks()
+    assert n1 == n0 and bits == 0, f"the split path itself must hold at token scales {(so, sl)} (guard bits {bits})"
+    cond = gold[f"in{i}.cond"]
+    assert cond.max() < 1e-2  # the input-scale cases are well-conditioned: the plain bar applies (3 x cond matters only at (1, 16))
+    check(sm, st, gold[f"in{i}.score_map"], gold[f"in{i}.score_tokens"], f"f16x3 token scales {(so, sl)}", cond)
+    sm32, st32 = forward(base_models["f32"], gold, so, sl)
+    check(sm32, st32, gold[f"in{i}.score_map"], gold[f"in{i}.score_tokens"], f"f32   token scales {(so, sl)}", cond)
+
+
+@pytest.mark.parametrize("variant", [v for v in synth.WEIGHT_VARIANTS])
+def test_weight_variants(gold, variant):
+    m, _ = build(variant, "f16x3")
+    sm, st = forward(m, gold)
+    n, bits = m.split_fallbacks()
+    check(sm, st, gold[f"w.{variant}.score_map"], gold[f"w.{variant}.score_tokens"], f"f16x3 weights {variant}", gold[f"w.{variant}.cond"])
+    if variant in ("gamma_div256", "gamma_x3000"):
+        # GroupNorm outputs of rms ~0.004 / ~3000: outside what the fixed activation scale covers -> exact-f32 kernels
+        assert n == 1 and (bits & 2), (variant, n, bits)
+        m32, _ = build(variant, "f32")
+        sm32, st32 = forward(m32, gold)
+        np.testing.assert_array_equal(sm, sm32)
+        np.testing.assert_array_equal(st, st32)
+    elif variant != "gamma_x300":
+        assert n == 0 and bits == 0, f"{variant}: the per-matrix scales must keep the split path in range (guard bits {bits})"
+
+
+def test_value_beyond_f16_range_trips_the_guard_and_the_call_is_repeated_in_f32(gold):
+    """One conv5 bias channel at 1e5: conv5's output is written as split-f16 pairs, whose hi half would be inf."""
+    outs = {}
+    for prec in ("f16x3", "f32"):
+        m, _ = build("base", prec)
+        with torch.no_grad():
+            m.short_motion_encoder[20].bias[3] = 1.0e5
+        outs[prec] = forward(m, gold)
+        if prec == "f16x3":
+            n, bits = m.split_fallbacks()
+            assert n == 1 and (bits & 1), (n, bits)
+            m.split_guard = False  # fully asynchronous call: the result is the split path's, the guard is not consulted
+            sm_u, _ = forward(m, gold)
+            assert m.split_fallbacks()[0] == 1
+            assert not np.isfinite(sm_u).all() or np.abs(sm_u - outs["f16x3"][0]).max() > 0  # it really was out of range
+    assert np.isfinite(outs["f32"][0]).all()
+    np.testing.assert_array_equal(outs["f16x3"][0], outs["f32"][0])
+    np.testing.assert_array_equal(outs["f16x3"][1], outs["f32"][1])
+
+
+def test_weights_changed_rebuilds_scales_and_rechecks(gold):
+    """In-place weight updates (optimizer step, load_state_dict) must refresh the per-matrix scales and the norm check."""
+    m, sd = build("base", "f16x3")
+    forward(m, gold)
+    assert m.split_fallbacks() == (0, 0)
+    big = synth.make_state_dict_variant(CFG, 42, "lin_x8")
+    with torch.no_grad():
+        for k, p in m.state_dict(keep_vars=True).items():
+            p.copy_(torch.from_numpy(big[k]))
+    sm, st = forward(m, gold)
+    check(sm, st, gold["w.lin_x8.score_map"], gold["w.lin_x8.score_tokens"], "f16x3 after in-place x8", gold["w.lin_x8.cond"])
+    assert m.split_fallbacks() == (0, 0)
+    small = synth.make_state_dict_variant(CFG, 42, "gamma_div256")
+    with torch.no_grad():
+        for k, p in m.state_dict(keep_vars=True).items():
+            p.copy_(torch.from_numpy(small[k]))
+    sm, st = forward(m, gold)
+    check(sm, st, gold["w.gamma_div256.score_map"], gold["w.gamma_div256.score_tokens"], "f16x3 after in-place gamma/256")
+    n, bits = m.split_fallbacks()
+    assert n == 1 and (bits & 2)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_batch_256_sampled_rows_vs_oracle(base_models, precision):
+    """The benched batch: 256 samples at (T=32, N=64, L=16) in one call; six of them against the per-sample oracle."""
+    B, N, T, L = 256, 64, 32, 16
+    inp = synth.make_inputs(CFG, B, N, T, L, seed=1000)  # bench.py's rank-0 batch
+    m = base_models[precision]
+    with torch.no_grad():
+        sm, st = m(torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda())
+    sm, st = sm.cpu().numpy(), st.cpu().numpy()
+    assert m.split_fallbacks()[1] == 0
+    sd = synth.make_state_dict(CFG, 42)
+    tsd = sola_oracle.to_torch_state(sd)
+    worst = 0.0
+    for b in (0, 1, 77, 128, 200, 255):
+        rsm, rst = sola_oracle.forward(tsd, CFG, inp["object_tokens"][b:b + 1], inp["lang_tokens"][b:b + 1])
+        e = max(float(np.abs(sm[b] - rsm.numpy()[0]).max()), float(np.abs(st[b] - rst.numpy()[0]).max()))
+        worst = max(worst, e)
+        np.testing.assert_array_equal(sm[b] > 0, rsm.numpy()[0] > 0)
+    print(f"{precision}: worst sampled-row error vs the fp32 oracle at B=256: {worst:.3e}")
+    assert worst <= 1e-3

@@ -104,3 +104,35 @@ def test_rle_string_parser_host_helper_matches_oracle():
     assert L.sola_rle_string_to_cum(b"1o", 2, p, 4, -1) < 0 and b"truncated" in L.sola_last_error()
     assert L.sola_rle_string_to_cum(b"11111", 5, p, 4, -1) < 0  # more runs than the buffer holds
     assert L.sola_rle_string_to_cum(b"99", 2, p, 4, 10) < 0 and b"cover" in L.sola_last_error()  # 18 pixels > 10
+
+
+def test_training_shards_have_equal_length_on_every_rank():
+    """train.py issues one gradient all-reduce per optimizer step, so every rank must run the same number
+    of steps - the training shards are padded like DistributedSampler(drop_last=False); eval shards stay exact."""
+    from sola_amd.dist import shard_indices
+
+    for n in (1, 2, 3, 7, 11, 23051):
+        for world in (1, 2, 3, 8):
+            shards = [shard_indices(n, r, world, pad=True) for r in range(world)]
+            assert len({len(s) for s in shards}) == 1, (n, world)
+            assert set(sum(shards, [])) == set(range(n)), (n, world)
+            assert sum(len(s) for s in shards) - n < world
+            exact = [shard_indices(n, r, world) for r in range(world)]
+            assert sorted(sum(exact, [])) == list(range(n))
+
+
+def test_text_encoder_stand_in_needs_explicit_opt_in(monkeypatch):
+    """without the RoBERTa checkpoint the entry points must fail, not score hashed embeddings."""
+    from sola_amd.text import TextEncoder
+
+    monkeypatch.delenv("SOLA_ALLOW_TEXT_STANDIN", raising=False)
+    with pytest.raises(RuntimeError, match="could not be loaded"):
+        TextEncoder("no-such-org/no-such-model", 64, "cpu")
+    with pytest.warns(UserWarning):
+        enc = TextEncoder("no-such-org/no-such-model", 64, "cpu", allow_standin=True)
+    assert enc.kind == "hashed-standin"
+    tok, pos = enc.encode(["a cat", "the dog on the left"])
+    assert tok.shape == (2, 7, 64) and pos.shape == (2, 1, 64)
+    monkeypatch.setenv("SOLA_ALLOW_TEXT_STANDIN", "1")
+    with pytest.warns(UserWarning):
+        assert TextEncoder("no-such-org/no-such-model", 64, "cpu").kind == "hashed-standin"

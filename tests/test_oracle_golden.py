@@ -137,3 +137,29 @@ def test_dedup_loop(iou_golden):
     np.testing.assert_array_equal([p["status"] for p in prompts], iou_golden["dedup_status_out"])
     np.testing.assert_array_equal([p.get("filtered_by", -1) for p in prompts], iou_golden["dedup_filtered_by"])
     np.testing.assert_array_equal([p.get("filtered_iou", -1.0) for p in prompts], iou_golden["dedup_filtered_iou"])
+
+
+def test_range_cases_vs_reference():
+    """tests/golden/range_golden.npz (inputs scaled by 1e-5..1e3, weights away from the default-init scale): the oracle
+    follows the reference there too, at the magnitude-relative bar tests/test_gpu_range.py uses."""
+    from conftest import _load
+
+    g = _load("range_golden.npz")
+    cfg = synth.DEFAULT_MODEL_CFG
+    B, N, T, L = [int(v) for v in g["shape"]]
+    inp = synth.make_inputs(cfg, B, N, T, L, seed=300)
+
+    def check(sd, so, sl, g_sm, g_st, what, cond=(0.0, 0.0)):
+        sm, st = sola_oracle.forward(sd, cfg, inp["object_tokens"] * np.float32(so), inp["lang_tokens"] * np.float32(sl))
+        tol_sm = max(5e-4 * max(1.0, float(np.abs(g_sm).max()) / 16.0), 3.0 * float(cond[0]))
+        tol_st = max(5e-4 * max(1.0, float(np.abs(g_st).max()) / 16.0), 3.0 * float(cond[1]))
+        assert np.abs(sm.numpy() - g_sm).max() <= tol_sm, what
+        assert np.abs(st.numpy()[:, :8] - g_st).max() <= tol_st, what
+
+    base = sola_oracle.to_torch_state(synth.make_state_dict(cfg, 42))
+    for i in (0, 2, 4, 7, 8):
+        so, sl = synth.RANGE_INPUT_SCALES[i]
+        check(base, so, sl, g[f"in{i}.score_map"], g[f"in{i}.score_tokens"], f"input scales {(so, sl)}")
+    for v in ("lin_outliers", "gamma_div256", "gamma_x300"):
+        sd = sola_oracle.to_torch_state(synth.make_state_dict_variant(cfg, 42, v))
+        check(sd, 1.0, 1.0, g[f"w.{v}.score_map"], g[f"w.{v}.score_tokens"], f"weights {v}", g[f"w.{v}.cond"])

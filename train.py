@@ -79,7 +79,8 @@ def train(cfg):
     if world > 1:  # identical initial weights on every rank
         for t in module.state_dict().values():
             torch.distributed.broadcast(t, src=0)
-    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device)
+    text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device,
+                       allow_standin=bool(cfg.get("synthetic", False)))
     synthetic = cfg.get("synthetic", None)
     train_loader, _ = make_loader(cfg["dataset"], "train", rank, world, synthetic, cfg["model"])
     valid_loader, _ = make_loader(cfg["dataset"], "valid", rank, world, synthetic, cfg["model"])
