@@ -121,6 +121,40 @@ int sola_forward(SolaCtx* ctx,
                  float* dev_score_tokens,        /* [B,N,lang_token_dim]     */
                  void* dev_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- ragged batches: many (video, expression) samples of different shapes in one pass ---------------------------------
+ * The reference scores ONE sample per call (configs/mevis/default.yaml:37,42,47 batch_size 1; inference.py:44-58,
+ * evaluator.py:88-112) with per-sample N tracks, T frames, L text tokens.  sola_forward_ragged takes the token rows of all
+ * samples concatenated - no padding: no GroupNorm statistic or softmax sees a token that is not the sample's own - and
+ * separates the VIDEOS (object sets) from the SAMPLES that refer to them: everything that does not depend on the text (the
+ * motion encoder and layer 0's inter-object and motion sub-blocks, 57 % of a sample's FLOPs at the headline shape) is
+ * computed once per video and shared by all its expressions, which inference.py:44-58 recomputes per expression.
+ *   dev_object_tokens [sum_v N_v*T_v, object_token_dim]   video-major, then track, then frame (= [N_v,T_v,d] blocks)
+ *   dev_lang_tokens   [sum_i L_i, lang_token_dim]          sample-major
+ *   dev_score_map     [sum_i N_v(i)]                       sample-major, then track
+ *   dev_score_tokens  [sum_i N_v(i), lang_token_dim]
+ * All descriptor arrays are HOST arrays, read before the call returns.  n_samples == n_videos with sample_video[i] == i is
+ * the plain ragged batch.  Results equal per-sample sola_forward calls up to f32 summation order. */
+typedef struct SolaRaggedBatch {
+    int32_t n_videos;
+    const int32_t* video_tracks;     /* [n_videos]  N_v >= 1 */
+    const int32_t* video_frames;     /* [n_videos]  T_v >= 1 */
+    int32_t n_samples;
+    const int32_t* sample_video;     /* [n_samples] index of the sample's video */
+    const int32_t* sample_text_len;  /* [n_samples] L_i >= 1 */
+} SolaRaggedBatch;
+size_t sola_ragged_workspace_bytes(const SolaCtx* ctx, const SolaRaggedBatch* batch);
+int sola_forward_ragged(SolaCtx* ctx, const float* dev_object_tokens, const float* dev_lang_tokens, const SolaRaggedBatch* batch,
+                        float* dev_score_map, float* dev_score_tokens, void* dev_workspace, size_t workspace_bytes, void* stream);
+/* sola_loss for a ragged batch: sample b owns the tracks dev_track_offsets[b] .. dev_track_offsets[b+1] (DEVICE int32,
+ * n_samples + 1 entries) of the concatenated score_map / score_tokens / labels; dev_pos_tokens is [n_samples, D].  Every
+ * sample gets its own means - what train.py:98-113 / evaluator.py compute at the reference's batch size of 1 - in
+ * dev_loss3 [n_samples, 3] = {total, bce, alignment}.  Scratch: 3 * total_tracks floats. */
+int sola_loss_ragged(const float* dev_score_map, const float* dev_score_tokens, const float* dev_labels,
+                     const float* dev_pos_tokens, const float* dev_neg_tokens, int64_t neg_batch_stride, int n_samples,
+                     const int32_t* dev_track_offsets, int max_tracks, int64_t total_tracks, int D, int n_neg,
+                     float positive_weight, float temperature, float alignment_weight, float* dev_loss3,
+                     int32_t* dev_neg_argmax, void* dev_scratch, size_t scratch_bytes, void* stream);
+
 /* Location of a named intermediate of the LAST forward inside the workspace (parity tests / debugging).
  * Names: conv0..conv5 (pre-norm encoder conv outputs [B*N*T_l, C_l]), pe [T',D], lang [B*W,D],
  * l<i>_obj, l<i>_motion, l<i>_o2l (post-GroupNorm activations [B*N*T', D]). */

@@ -33,6 +33,18 @@ class SolaConfig(C.Structure):
     ]
 
 
+class SolaRaggedBatch(C.Structure):
+    """include/sola_hip.h: host descriptor of a ragged batch (videos = object sets, samples = (video, expression))."""
+    _fields_ = [
+        ("n_videos", C.c_int32),
+        ("video_tracks", C.POINTER(C.c_int32)),
+        ("video_frames", C.POINTER(C.c_int32)),
+        ("n_samples", C.c_int32),
+        ("sample_video", C.POINTER(C.c_int32)),
+        ("sample_text_len", C.POINTER(C.c_int32)),
+    ]
+
+
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/sola_hip.h declares
@@ -55,6 +67,9 @@ SIGNATURES = {
     "sola_gemm_nt_split_scaled": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sola_ragged_workspace_bytes": (_sz, [_vp, C.POINTER(SolaRaggedBatch)]),
+    "sola_forward_ragged": (_i, [_vp, _vp, _vp, C.POINTER(SolaRaggedBatch), _vp, _vp, _vp, _sz, _vp]),
+    "sola_loss_ragged": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _i, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "sola_workspace_tap": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_i64)]),
     "sola_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "sola_select": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),

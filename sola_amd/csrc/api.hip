@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "ctx.h"
@@ -181,6 +182,7 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (c->lin16_buf) (void)hipFree(c->lin16_buf);
     if (c->scal_buf) (void)hipFree(c->scal_buf);
     if (c->guard_host) (void)hipHostFree(c->guard_host);
+    sola_rag_stage_free(c->rag_stage);
     delete c;
     return SOLA_OK;
 }
@@ -391,6 +393,55 @@ extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int
         return st;
     }
     return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
+}
+
+extern "C" size_t sola_ragged_workspace_bytes(const SolaCtx* c, const SolaRaggedBatch* batch) {
+    if (!c || !batch) return 0;
+    // the exact-f32 repeat of a guarded split-f16 call runs in the same arena: size it for the larger of the two plans
+    size_t n = sola_ragged_workspace_bytes_impl(c, batch);
+    if (c->precision == 1) {
+        SolaCtx* m = const_cast<SolaCtx*>(c);
+        m->precision = 0;
+        n = std::max(n, sola_ragged_workspace_bytes_impl(c, batch));
+        m->precision = 1;
+    }
+    return n;
+}
+
+extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch, float* score_map,
+                                   float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
+    hipStream_t s = as_stream(stream_);
+    SOLA_TRY(sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s));
+    if (c->precision != 1) return SOLA_OK;
+    bool tripped = false;
+    SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
+    if (!tripped) return SOLA_OK;
+    c->split_fallbacks += 1;
+    c->precision = 0;
+    const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
+    c->precision = 1;
+    return st;
+}
+
+extern "C" int sola_loss_ragged(const float* score_map, const float* score_tokens, const float* labels, const float* pos,
+                                const float* neg, int64_t neg_batch_stride, int n_samples, const int32_t* dev_track_offsets,
+                                int max_tracks, int64_t total_tracks, int D, int n_neg, float pw, float temperature, float aw,
+                                float* loss3, int32_t* neg_argmax, void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(score_map && score_tokens && labels && pos && neg && loss3 && scratch && dev_track_offsets, "loss_ragged: null argument");
+    SOLA_ARG(n_samples > 0 && max_tracks > 0 && total_tracks > 0 && D > 0 && n_neg > 0, "loss_ragged: bad sizes");
+    const size_t need = (size_t)total_tracks * 3 * sizeof(float);
+    if (scratch_bytes < need) {
+        sola_set_error("loss_ragged: scratch %zu bytes < required %zu", scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    LossDesc d{};
+    d.score_map = score_map; d.score_tokens = score_tokens; d.labels = labels; d.pos = pos;
+    d.neg = neg; d.neg_batch_stride = neg_batch_stride;
+    d.B = n_samples; d.N = max_tracks; d.D = D; d.n_neg = n_neg;
+    d.pos_w = pw; d.temp_scale = expf(temperature); d.align_w = aw;
+    d.terms = static_cast<float*>(scratch); d.loss3 = loss3; d.neg_argmax = neg_argmax;
+    d.trk_off = dev_track_offsets;
+    return launch_loss(d, as_stream(stream_));
 }
 
 extern "C" int sola_set_split_guard(SolaCtx* c, int enable) {

@@ -45,7 +45,34 @@ struct AttnArgs {
     int sp_log2;      // packed: log2 of the per-unit slot count SP (SP = pow2 >= max(Sq, Sk)), units per tile = 16 >> sp_log2
     int in_sp16;      // shared: q, k, v are split-f16 rows (the SPLIT kernel shape)
     int* guard;       // o_sp16: range guard word (AttnDesc::guard), null = unchecked
+    const int4 *q_units, *k_units;  // ragged batches: per-group (first row, row stride, length, -) (AttnDesc::q_units)
 };
+
+// Geometry of one group: first rows, row strides and lengths of its query and key sequences.  With unit tables the values
+// are loaded per group (and made wave-uniform by hand: the compiler cannot know a table entry is the same for all lanes).
+struct AttnGeo { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
+__device__ __forceinline__ AttnGeo attn_geo(const AttnArgs& a, int grp) {
+    AttnGeo g;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        g.q0 = qu.x; g.q_rs = qu.y; g.Sq = qu.z;
+        g.k0 = ku.x; g.k_rs = ku.y; g.Sk = ku.z;
+    } else {
+        g.q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        g.k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        g.q_rs = a.q_rs; g.k_rs = a.k_rs; g.Sq = a.Sq; g.Sk = a.Sk;
+    }
+    return g;
+}
+__device__ __forceinline__ AttnGeo attn_geo_uniform(const AttnArgs& a, int grp) {  // grp is wave-uniform
+    AttnGeo g = attn_geo(a, grp);
+    if (a.q_units) {
+        g.q0 = __builtin_amdgcn_readfirstlane((int)g.q0); g.k0 = __builtin_amdgcn_readfirstlane((int)g.k0);
+        g.q_rs = __builtin_amdgcn_readfirstlane((int)g.q_rs); g.k_rs = __builtin_amdgcn_readfirstlane((int)g.k_rs);
+        g.Sq = __builtin_amdgcn_readfirstlane(g.Sq); g.Sk = __builtin_amdgcn_readfirstlane(g.Sk);
+    }
+    return g;
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -133,8 +160,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         };
         int grp, h, jq;
         const bool unit_ok = row_unit(c16, grp, h, jq);
-        const bool q_ok = unit_ok && jq < a.Sq;
-        const long long qrow = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner + (long long)jq * a.q_rs;
+        const AttnGeo gq = attn_geo(a, grp);  // this lane's query row's unit
+        const bool q_ok = unit_ok && jq < gq.Sq;
+        const long long qrow = gq.q0 + (long long)jq * gq.q_rs;
         float4 qf[NC];
         {
             const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
@@ -148,10 +176,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         for (int idx = lane; idx < 16 * F4; idx += 64) {
             const int r = idx / F4, c4 = idx - r * F4;
             int kg, kh, kj;
-            const bool ok = row_unit(r, kg, kh, kj) && kj < a.Sk;
+            const bool uok = row_unit(r, kg, kh, kj);
+            const AttnGeo gk = attn_geo(a, kg);
+            const bool ok = uok && kj < gk.Sk;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
             if (ok) {
-                const long long row = (long long)(kg / a.inner) * a.k_outer + (long long)(kg % a.inner) * a.k_inner + (long long)kj * a.k_rs;
+                const long long row = gk.k0 + (long long)kj * gk.k_rs;
                 kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + kh * DH + c4 * 4);
                 vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + kh * DH + c4 * 4);
             }
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kr = 4 * g4 + r;
-            const bool vis = (kr >> a.sp_log2) == (c16 >> a.sp_log2) && (kr & (SP - 1)) < a.Sk;
+            const bool vis = (kr >> a.sp_log2) == (c16 >> a.sp_log2) && (kr & (SP - 1)) < gq.Sk;
             sc[r] = vis ? (a0[r] + a1[r]) : -INFINITY;
             mx = fmaxf(mx, sc[r]);
         }
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         rs += __shfl_xor(rs, 16, 64);
         rs += __shfl_xor(rs, 32, 64);
         if (a.drop.enabled) {
-            const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * a.Sq + jq) * a.Sk;
+            const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * gq.Sq + jq) * gq.Sk;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 sc[r] = dropout_keep(a.drop, rbase + ((4 * g4 + r) & (SP - 1))) ? sc[r] * a.drop.scale : 0.f;
@@ -226,20 +256,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         // waits a full memory latency per unit (one unit per block left both the matrix pipe and HBM ~35-40 % busy).
         float* Ks = smem;                       // [kv_rows][LDK]
         float* Vs = smem + a.kv_rows * LDK;     // [kv_rows][LDV]
-        struct Unit { int qs, h, grp; long long qrow0, krow0; };
+        struct Unit { int qs, h, grp, Sq, Sk, nqb; long long qrow0, krow0, q_rs, k_rs; };
         auto decode = [&](long long u) {
             Unit c;
             c.qs = (int)(u % a.qsplit);
             u /= a.qsplit;
             c.h = (int)(u % a.H);
             c.grp = (int)(u / a.H);
-            c.qrow0 = (long long)(c.grp / a.inner) * a.q_outer + (long long)(c.grp % a.inner) * a.q_inner;
-            c.krow0 = (long long)(c.grp / a.inner) * a.k_outer + (long long)(c.grp % a.inner) * a.k_inner;
+            const AttnGeo g = attn_geo_uniform(a, c.grp);
+            c.qrow0 = g.q0; c.krow0 = g.k0; c.q_rs = g.q_rs; c.k_rs = g.k_rs; c.Sq = g.Sq; c.Sk = g.Sk;
+            c.nqb = a.q_units ? (g.Sq + NW * 16 - 1) / (NW * 16) : a.nqb;
             return c;
         };
         const long long n_units = (long long)a.G * a.H * a.qsplit;
         const bool single_tile = a.Sk <= a.kv_rows;
-        const int res_rows16 = (a.Sk + 15) & ~15;  // rows of the resident tile (single_tile)
+        const int res_rows16 = a.q_units ? a.kv_rows : (a.Sk + 15) & ~15;  // rows of the resident tile (single_tile); zero-filled past a unit's keys
         // ONE register buffer serves both prefetches: K of the next unit is in flight from the start of a unit until the
         // unit's last QK^T is done (then it replaces Ks), V of the next unit from there until the unit's end.
         constexpr int KVR = F4 / 4;  // float4 per thread for a 64-row tile
@@ -250,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                 const int idx = tid + NT * i;
                 const int r = idx / F4, c4 = idx - r * F4;
                 pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < a.Sk) pre[i] = *reinterpret_cast<const float4*>(base + (c.krow0 + (long long)r * a.k_rs) * ld + c.h * DH + c4 * 4);
+                if (r < c.Sk) pre[i] = *reinterpret_cast<const float4*>(base + (c.krow0 + (long long)r * c.k_rs) * ld + c.h * DH + c4 * 4);
             }
         };
         auto put_k = [&](int r, int c4, const float4 v) { *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = v; };
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                 const int r = idx / F4, c4 = idx - r * F4;
                 float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
                 if (r < nrows) {
-                    const long long row = cur.krow0 + (long long)(kt0 + r) * a.k_rs;
+                    const long long row = cur.krow0 + (long long)(kt0 + r) * cur.k_rs;
                     kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + cur.h * DH + c4 * 4);
                     vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + cur.h * DH + c4 * 4);
                 }
@@ -283,11 +314,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         };
         auto load_q = [&](const Unit& c, int qb, float4 (&dst)[NC]) {
             const int qi = qb * (NW * 16) + wave * 16 + c16;
-            const bool ok = qb < a.nqb && qi < a.Sq;
+            const bool ok = qb < c.nqb && qi < c.Sq;
             if constexpr (SPLIT) {
                 // chunk j, lane slot g4 -> block 2j + (g4 >> 1), half (g4 & 1): hi4 and lo4 are 8 bytes each, 16 bytes apart;
                 // they travel in the two halves of the float4 slot
-                const char* qp = reinterpret_cast<const char*>(a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH) +
+                const char* qp = reinterpret_cast<const char*>(a.q + (c.qrow0 + (long long)qi * c.q_rs) * a.ldq + c.h * DH) +
                                  (g4 >> 1) * 32 + (g4 & 1) * 8;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
@@ -299,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                     dst[j] = make_float4(hi.x, hi.y, lo.x, lo.y);
                 }
             } else {
-                const float* qp = a.q + (c.qrow0 + (long long)qi * a.q_rs) * a.ldq + c.h * DH + 4 * g4;
+                const float* qp = a.q + (c.qrow0 + (long long)qi * c.q_rs) * a.ldq + c.h * DH + 4 * g4;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) dst[j] = ok ? *reinterpret_cast<const float4*>(qp + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -331,15 +362,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
         }
         const int h = cur.h, grp = cur.grp;
         const long long qrow0 = cur.qrow0;
-        for (int qb = cur.qs; qb < a.nqb; qb += a.qsplit) {
+        for (int qb = cur.qs; qb < cur.nqb; qb += a.qsplit) {
             const int qi = qb * (NW * 16) + wave * 16 + c16;
-            const bool q_ok = qi < a.Sq;
+            const bool q_ok = qi < cur.Sq;
             f32x4 oacc[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             float m_run = -INFINITY, l_run = 0.f;
-            for (int kt0 = 0; kt0 < a.Sk; kt0 += 64) {
-                const int nrows = min(64, a.Sk - kt0);
+            for (int kt0 = 0; kt0 < cur.Sk; kt0 += 64) {
+                const int nrows = min(64, cur.Sk - kt0);
                 const int nrows16 = (nrows + 15) & ~15;
                 if (!single_tile) {
                     __syncthreads();  // the previous tile has been consumed by every wave
@@ -383,13 +414,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                         }
                         const int key0 = kt0 + t * 16 + 4 * g4;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < a.Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
+                        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < cur.Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
                     } else {
                         sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                     }
                 }
-                if (kt0 + 64 >= a.Sk) {  // q is dead for this q-block: fetch the next fragment into the same registers
-                    if (qb + a.qsplit < a.nqb) load_q(cur, qb + a.qsplit, qf);
+                if (kt0 + 64 >= cur.Sk) {  // q is dead for this q-block: fetch the next fragment into the same registers
+                    if (qb + a.qsplit < cur.nqb) load_q(cur, qb + a.qsplit, qf);
                     else if (has_next) load_q(nxt, nxt.qs, qf);
                 }
                 // ---- online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
@@ -417,14 +448,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
 #pragma unroll
                 for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
                 if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped
-                    const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk;
+                    const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * cur.Sq + qi) * cur.Sk;
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
                 }
-                if (single_tile && has_next && qb + a.qsplit >= a.nqb && kt0 + 64 >= a.Sk) {
+                if (single_tile && has_next && qb + a.qsplit >= cur.nqb && kt0 + 64 >= cur.Sk) {
                     // last QK^T of this unit is done: Ks can take the next unit's K, and its V starts to travel
                     __syncthreads();
                     commit(true);
@@ -461,9 +492,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                 }
             }
             if (q_ok) {
-                if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * a.q_rs) * a.H + h] = m_run + logf(l_run);
+                if (a.lse && g4 == 0) a.lse[(qrow0 + (long long)qi * cur.q_rs) * a.H + h] = m_run + logf(l_run);
                 const float inv = 1.f / l_run;
-                store_o<NC>(a.o + (qrow0 + (long long)qi * a.q_rs) * a.ldo + h * DH, g4, oacc, inv, a.o_sp16, a.guard);
+                store_o<NC>(a.o + (qrow0 + (long long)qi * cur.q_rs) * a.ldo + h * DH, g4, oacc, inv, a.o_sp16, a.guard);
             }
         }
         cur = nxt;
@@ -524,7 +555,9 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         a.kv_rows = g_attn_variant == 0 ? 64 : (r16 < qrows ? r16 : qrows);
         const long long gh = (long long)a.G * a.H;
         int qsplit = a.nqb;
-        if (g_attn_variant != 0 && a.Sk <= a.kv_rows) {  // K/V resident: loop q-blocks, keep >= ~1024 blocks in the grid
+        if (a.q_units) {
+            qsplit = 1;  // ragged: every (group, head) is one unit that walks its own q-blocks (each group has at least one)
+        } else if (g_attn_variant != 0 && a.Sk <= a.kv_rows) {  // K/V resident: loop q-blocks, keep >= ~1024 blocks in the grid
             qsplit = (int)((g_attn_target_blocks + gh - 1) / gh);
             if (qsplit < 1) qsplit = 1;
             if (qsplit > a.nqb) qsplit = a.nqb;
@@ -567,6 +600,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.o_sp16 = d.o_sp16;
     a.in_sp16 = d.in_sp16;
     a.guard = d.o_sp16 ? d.guard : nullptr;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

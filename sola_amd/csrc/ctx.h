@@ -33,6 +33,9 @@ struct Plan {
     }
 };
 
+struct SolaRagStage;  // pinned staging ring of the ragged forward's descriptor upload (forward_ragged.hip)
+void sola_rag_stage_free(SolaRagStage* st);
+
 struct SolaCtx {
     SolaConfig cfg;
     int device;
@@ -63,6 +66,7 @@ struct SolaCtx {
     int* guard_host = nullptr;      // pinned, 2 ints
     bool split_guard = true;        // sola_set_split_guard
     long long split_fallbacks = 0;  // calls that were repeated in exact f32
+    SolaRagStage* rag_stage = nullptr;
     float* scal_pair(int i) const { return scal_buf + 2 * i; }
     const float* lin_inv_scale(int layer, int attn, int proj) const { return scal_buf + 2 * (2 + (layer * 3 + attn) * 4 + proj) + 1; }
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
@@ -103,3 +107,6 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                            float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s);
 size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p);
+size_t sola_ragged_workspace_bytes_impl(const SolaCtx* c, const SolaRaggedBatch* b);
+int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch, float* score_map,
+                             float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s);

@@ -22,6 +22,7 @@ struct GemmArgs {
     GemmProblem p[3];
     int M, N, K, lda, ldr, ldc;
     int conv, T_in, T_out, stride, pad, Cin;
+    const int2* rowmap;  // conv 1, ragged batches (GemmDesc::rowmap)
     int tiles_m, tiles_n, xcd_remap;
     float out_scale;  // result multiplier (power of two undoing the weight pre-scale of the split-f16 path)
     const float* out_scale_dev;  // optional further multiplier in device memory (GemmDesc::out_scale_dev)
@@ -88,7 +89,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + lr + 32 * i;
         a_ok[i] = m < a.M;
-        if (a.conv == 1) {
+        if (a.conv == 1 && a.rowmap) {
+            // ragged: a_t0 = tap-validity bits, a_off = offset of the window's tap 0 (possibly outside the sequence)
+            const int2 rm = a.rowmap[a_ok[i] ? m : a.M - 1];
+            a_t0[i] = rm.y;
+            a_off[i] = (long long)rm.x * a.Cin;
+        } else if (a.conv == 1) {
             const int r = m / a.T_out;
             const int to = m - r * a.T_out;
             a_t0[i] = to * a.stride - a.pad;
@@ -128,7 +134,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
         for (int i = 0; i < RA; ++i) {
             bool ok = a_ok[i] && kok;
             const float* src;
-            if (a.conv == 1) {
+            if (a.conv == 1 && a.rowmap) {
+                ok = ok && ((a_t0[i] >> kk) & 1);
+                src = pr.A + a_off[i] + (long long)kk * a.Cin + ci;
+            } else if (a.conv == 1) {
                 const int ti = a_t0[i] + kk;
                 ok = ok && ti >= 0 && ti < a.T_in;
                 src = pr.A + a_off[i] + (long long)ti * a.Cin + ci;
@@ -399,7 +408,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3, "gemm: nprob %d", d.nprob);
     SOLA_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.K % 4 == 0, "gemm: bad dims M=%d N=%d K=%d (K %% 4 == 0 required)", d.M, d.N, d.K);
     if (d.conv) {
-        SOLA_ARG(d.Cin % 4 == 0 && d.K % d.Cin == 0, "conv gemm: Cin=%d K=%d", d.Cin, d.K);
+        SOLA_ARG(d.Cin % 4 == 0 && d.K % d.Cin == 0 && d.K / d.Cin <= 8, "conv gemm: Cin=%d K=%d (at most 8 taps)", d.Cin, d.K);
     } else {
         SOLA_ARG(d.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", d.lda);
     }
@@ -407,6 +416,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     for (int i = 0; i < 3; ++i) a.p[i] = d.p[i < d.nprob ? i : 0];
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
+    a.rowmap = d.conv == 1 ? d.rowmap : nullptr;
     a.tiles_m = a.tiles_n = a.xcd_remap = 0;
     a.out_scale = d.arith == 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
     a.out_scale_dev = d.arith == 1 ? d.out_scale_dev : nullptr;

@@ -37,6 +37,7 @@ struct GldsArgs {
     GemmProblem p[3];
     int M, N, K, lda, ldr, ldc;
     int conv, T_in, T_out, stride, pad, Cin;
+    const int2* rowmap;  // conv, ragged batches: (source row of tap 0, tap-validity bits) per output row (GemmDesc::rowmap)
     int tiles_m, tiles_n, xcd_remap, nprob;
     int ksplit, kper;  // persistent kernel: > 1 = the reduction dim is cut into ksplit ranges of kper k-tiles, each an own work item
     float* part;       // ... writing raw partial sums to part[(problem * ksplit + range)][M][N] (gemm.hip reduces them)
@@ -61,6 +62,14 @@ __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0
 
 constexpr int GBK = 32;
 constexpr int ROWB = 128;  // bytes per tile row (32 elements x 4 B)
+
+// bit kk set <=> 0 <= t0 + kk < T_in, for the (at most 8) taps of a conv window starting at time t0
+__device__ __forceinline__ int conv_tap_bits(int t0, int T_in) {
+    int bits = 0;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) bits |= ((unsigned)(t0 + kk) < (unsigned)T_in) ? (1 << kk) : 0;
+    return bits;
+}
 
 template <int MI, int WAVES_M, int WAVES_N, bool CONV>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_kernel(const GldsArgs a) {
@@ -104,9 +113,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         const int col_bytes = (chunk ^ ((r >> 1) & 7)) * 16;  // logical 16-byte chunk that must land in this physical slot
         const int m = min(m0 + r, a.M - 1);
         if (CONV) {
-            const int rr = m / a.T_out, to = m - rr * a.T_out;
-            a_t0[i] = to * a.stride - a.pad;
-            a_ptr[i] = reinterpret_cast<const char*>(pr.A) + ((long long)rr * a.T_in + a_t0[i]) * a.Cin * 4 + col_bytes;
+            // a_t0 = validity bits of the window's taps (bit kk: tap kk lies inside the sequence)
+            if (a.rowmap) {
+                const int2 rm = a.rowmap[m];
+                a_t0[i] = rm.y;
+                a_ptr[i] = reinterpret_cast<const char*>(pr.A) + (long long)rm.x * a.Cin * 4 + col_bytes;
+            } else {
+                const int rr = m / a.T_out, to = m - rr * a.T_out;
+                const int t0 = to * a.stride - a.pad;
+                a_t0[i] = conv_tap_bits(t0, a.T_in);
+                a_ptr[i] = reinterpret_cast<const char*>(pr.A) + ((long long)rr * a.T_in + t0) * a.Cin * 4 + col_bytes;
+            }
         } else {
             a_t0[i] = 0;
             a_ptr[i] = reinterpret_cast<const char*>(pr.A + (long long)m * a.lda) + col_bytes;
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const char* src = a_ptr[i];
-            if (CONV) src = (unsigned)(a_t0[i] + conv_kk) < (unsigned)a.T_in ? src : zero;  // zero padding in time
+            if (CONV) src = ((a_t0[i] >> conv_kk) & 1) ? src : zero;  // zero padding in time
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
@@ -395,9 +412,16 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
             const int m = min(m0 + r, a.M - 1);
             const char* p;
             if (CONV) {
-                const int rr = m / a.T_out, to = m - rr * a.T_out;
-                a_t0[i] = to * a.stride - a.pad;
-                p = reinterpret_cast<const char*>(A) + ((long long)rr * a.T_in + a_t0[i]) * a.Cin * 4 + col_bytes;
+                if (a.rowmap) {
+                    const int2 rm = a.rowmap[m];
+                    a_t0[i] = rm.y;
+                    p = reinterpret_cast<const char*>(A) + (long long)rm.x * a.Cin * 4 + col_bytes;
+                } else {
+                    const int rr = m / a.T_out, to = m - rr * a.T_out;
+                    const int t0 = to * a.stride - a.pad;
+                    a_t0[i] = conv_tap_bits(t0, a.T_in);
+                    p = reinterpret_cast<const char*>(A) + ((long long)rr * a.T_in + t0) * a.Cin * 4 + col_bytes;
+                }
             } else {
                 a_t0[i] = 0;
                 p = reinterpret_cast<const char*>(A + (long long)m * a.lda) + col_bytes;
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const char* src = a_ptr0 + a_d[i];
-            if (CONV) src = (unsigned)(a_t0[i] + conv_kk) < (unsigned)a.T_in ? src : zero;
+            if (CONV) src = ((a_t0[i] >> conv_kk) & 1) ? src : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
@@ -811,6 +835,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     for (int i = 0; i < 3; ++i) a.p[i] = d.p[i < d.nprob ? i : 0];
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
+    a.rowmap = d.conv == 1 ? d.rowmap : nullptr;
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
     a.out_scale_dev = d.out_scale_dev;
     a.r_sp16 = d.r_sp16;

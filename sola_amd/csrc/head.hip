@@ -12,6 +12,7 @@ struct HeadArgs {
     float* score_map;
     float* score_tokens;
     int N, Tp, D;
+    const int4* units;  // ragged batches: (first row, -, T', sample) per track (HeadDesc::units)
 };
 
 // score_logits[t] = x[t,:] . mean_w(lang)   (== mean_w(x . lang_w), module.py:152-153)
@@ -21,12 +22,17 @@ __global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
     float* logits = sh;               // [Tp]
     float* red = sh + ((a.Tp + 3) & ~3);
     const int bn = blockIdx.x;
-    const int b = bn / a.N;
+    int b = bn / a.N, Tp = a.Tp;
+    long long row0 = (long long)bn * a.Tp;
+    if (a.units) {
+        const int4 u = a.units[bn];
+        row0 = u.x; Tp = u.z; b = u.w;
+    }
     const int d4n = a.D >> 2;
-    const float4* xb = reinterpret_cast<const float4*>(a.x + (long long)bn * a.Tp * a.D);
+    const float4* xb = reinterpret_cast<const float4*>(a.x + row0 * a.D);
     const float4* lb = reinterpret_cast<const float4*>(a.lbar + (long long)b * a.D);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = wave; t < a.Tp; t += 4) {
+    for (int t = wave; t < Tp; t += 4) {
         float s = 0.f;
         for (int i = lane; i < d4n; i += 64) {
             const float4 xv = xb[(long long)t * d4n + i], lv = lb[i];
@@ -37,17 +43,17 @@ __global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
     }
     __syncthreads();
     float mx = -INFINITY;
-    for (int t = 0; t < a.Tp; ++t) mx = fmaxf(mx, logits[t]);
+    for (int t = 0; t < Tp; ++t) mx = fmaxf(mx, logits[t]);
     float den = 0.f;
-    for (int t = 0; t < a.Tp; ++t) den += expf(logits[t] - mx);
+    for (int t = 0; t < Tp; ++t) den += expf(logits[t] - mx);
     __syncthreads();
-    for (int t = threadIdx.x; t < a.Tp; t += 256) logits[t] = expf(logits[t] - mx) / den;
+    for (int t = threadIdx.x; t < Tp; t += 256) logits[t] = expf(logits[t] - mx) / den;
     __syncthreads();
     float part = 0.f;
     float4* out = reinterpret_cast<float4*>(a.score_tokens + (long long)bn * a.D);
     for (int i = threadIdx.x; i < d4n; i += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < a.Tp; ++t) {
+        for (int t = 0; t < Tp; ++t) {
             const float w = logits[t];
             const float4 xv = xb[(long long)t * d4n + i];
             acc.x += xv.x * w; acc.y += xv.y * w; acc.z += xv.z * w; acc.w += xv.w * w;
@@ -67,7 +73,13 @@ struct LossArgs {
     float pos_w, temp_scale;
     float* terms;
     int32_t* neg_argmax;
+    const int32_t* trk_off;  // ragged batches: tracks of sample b = trk_off[b] .. trk_off[b + 1] (LossDesc::trk_off)
 };
+// first track and track count of sample b
+__device__ __forceinline__ void sample_tracks(const LossArgs& a, int b, long long& first, int& count) {
+    if (a.trk_off) { first = a.trk_off[b]; count = a.trk_off[b + 1] - a.trk_off[b]; }
+    else { first = (long long)b * a.N; count = a.N; }
+}
 
 __device__ __forceinline__ float bce_logits(float x, float y) {
     // F.binary_cross_entropy_with_logits: max(x,0) - x*y + log(1 + exp(-|x|))
@@ -129,11 +141,15 @@ __global__ __launch_bounds__(256) void loss_terms_rows_kernel(const LossArgs a) 
     float4* tok = reinterpret_cast<float4*>(sh);                      // [RPB][D]
     float* logit = sh + (size_t)LOSS_RPB * a.D;                       // [RPB][n_neg + 1], pos last
     const int b = blockIdx.y, n0 = blockIdx.x * LOSS_RPB;
-    const int rows = min(LOSS_RPB, a.N - n0);
+    long long first;
+    int count;
+    sample_tracks(a, b, first, count);
+    if (n0 >= count) return;  // ragged: the grid is sized by the largest sample
+    const int rows = min(LOSS_RPB, count - n0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < LOSS_RPB * d4n; i += 256) {
         const int r = i / d4n, c = i - r * d4n;
-        tok[i] = r < rows ? reinterpret_cast<const float4*>(a.score_tokens + ((long long)b * a.N + n0 + r) * a.D)[c]
+        tok[i] = r < rows ? reinterpret_cast<const float4*>(a.score_tokens + (first + n0 + r) * a.D)[c]
                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256) void loss_terms_rows_kernel(const LossArgs a) 
     __syncthreads();
     if (threadIdx.x < rows) {
         const int r = threadIdx.x;
-        const long long bn = (long long)b * a.N + n0 + r;
+        const long long bn = first + n0 + r;
         const float* negl = logit + r * stride;
         const float y = a.labels[bn];
         const float x = a.score_map[bn];
@@ -189,14 +205,18 @@ __global__ __launch_bounds__(256) void loss_terms_regs_kernel(const LossArgs a) 
     float* logit = sh;  // [RPB][n_neg + 1], pos last
     const int d4n = a.D >> 2;
     const int b = blockIdx.y, n0 = blockIdx.x * LOSS_RPB;
-    const int rows = min(LOSS_RPB, a.N - n0);
+    long long first;
+    int count;
+    sample_tracks(a, b, first, count);
+    if (n0 >= count) return;  // ragged: the grid is sized by the largest sample
+    const int rows = min(LOSS_RPB, count - n0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 tk[LOSS_RPB][NI];
 #pragma unroll
     for (int r = 0; r < LOSS_RPB; ++r)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            tk[r][i] = r < rows ? reinterpret_cast<const float4*>(a.score_tokens + ((long long)b * a.N + n0 + r) * a.D)[lane + 64 * i]
+            tk[r][i] = r < rows ? reinterpret_cast<const float4*>(a.score_tokens + (first + n0 + r) * a.D)[lane + 64 * i]
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     const float* negb = a.neg + (long long)b * a.neg_batch_stride;
     const int stride = a.n_neg + 1;
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(256) void loss_terms_regs_kernel(const LossArgs a) 
     __syncthreads();
     if (threadIdx.x < rows) {
         const int r = threadIdx.x;
-        const long long bn = (long long)b * a.N + n0 + r;
+        const long long bn = first + n0 + r;
         const float* negl = logit + r * stride;
         const float y = a.labels[bn];
         const float x = a.score_map[bn];
@@ -263,6 +283,30 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* terms, in
     }
 }
 
+// ragged batches: one block per sample, the means run over the sample's own tracks (the reference's batch size of 1)
+__global__ __launch_bounds__(256) void loss_reduce_ragged_kernel(const float* terms, const int32_t* trk_off, int n_neg, float pos_w,
+                                                                 float align_w, float* loss3) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int first = trk_off[b], n = trk_off[b + 1] - first;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        s0 += terms[(long long)(first + i) * 3 + 0];
+        s1 += terms[(long long)(first + i) * 3 + 1];
+        s2 += terms[(long long)(first + i) * 3 + 2];
+    }
+    s0 = block_sum_256(s0, red);
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+        const float bce = s0 / (float)n;
+        const float align = pos_w * (s1 / (float)n) + s2 / ((float)n * (float)n_neg);
+        loss3[b * 3 + 0] = bce + align_w * align;
+        loss3[b * 3 + 1] = bce;
+        loss3[b * 3 + 2] = align;
+    }
+}
+
 __global__ void select_kernel(const float* score, long long n, float thr, float* prob, float* pred) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -275,7 +319,7 @@ __global__ void select_kernel(const float* score, long long n, float thr, float*
 
 int launch_score_head(const HeadDesc& d, hipStream_t s) {
     SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.Tp > 0, "score_head: bad sizes");
-    HeadArgs a{d.x, d.lbar, d.score_map, d.score_tokens, d.N, d.Tp, d.D};
+    HeadArgs a{d.x, d.lbar, d.score_map, d.score_tokens, d.N, d.Tp, d.D, d.units};
     const size_t lds = (((size_t)d.Tp + 3) & ~(size_t)3) * 4 + 16;
     SOLA_ARG(lds <= 60000, "score_head: T'=%d too long", d.Tp);
     const double elems = (double)d.B * d.N * d.Tp * d.D;
@@ -288,7 +332,7 @@ int launch_score_head(const HeadDesc& d, hipStream_t s) {
 int launch_loss(const LossDesc& d, hipStream_t s) {
     SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.n_neg > 0 && d.n_neg < 8192, "loss: bad sizes");
     LossArgs a{d.score_map, d.score_tokens, d.labels, d.pos, d.neg, d.neg_batch_stride, d.N, d.D, d.n_neg,
-               d.pos_w, d.temp_scale, d.terms, d.neg_argmax};
+               d.pos_w, d.temp_scale, d.terms, d.neg_argmax, d.trk_off};
     const size_t lds = (((size_t)d.n_neg + 3) & ~(size_t)3) * 4 + 16;
     {
         SolaProfScope prof(SOLA_PROF_HEAD, s, 2.0 * d.B * d.N * (double)d.D * (d.n_neg + 1),
@@ -301,14 +345,18 @@ int launch_loss(const LossDesc& d, hipStream_t s) {
             hipLaunchKernelGGL(loss_terms_regs_kernel<2>, dim3((d.N + LOSS_RPB - 1) / LOSS_RPB, d.B), dim3(256), lds_logits, s, a);
         else if (lds_rows <= 64 * 1024)
             hipLaunchKernelGGL(loss_terms_rows_kernel, dim3((d.N + LOSS_RPB - 1) / LOSS_RPB, d.B), dim3(256), lds_rows, s, a);
-        else
+        else {
+            SOLA_ARG(!d.trk_off, "loss: ragged batches need D and n_neg that fit the row kernels' LDS");
             hipLaunchKernelGGL(loss_terms_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
+        }
         SOLA_LAUNCH_CHECK();
     }
     {
         SolaProfScope prof(SOLA_PROF_HEAD, s, 0, 12.0 * d.B * d.N);
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, d.terms, d.B * d.N, d.n_neg, d.pos_w,
-                           d.align_w, d.loss3);
+        if (d.trk_off)
+            hipLaunchKernelGGL(loss_reduce_ragged_kernel, dim3(d.B), dim3(256), 0, s, d.terms, d.trk_off, d.n_neg, d.pos_w, d.align_w, d.loss3);
+        else
+            hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, d.terms, d.B * d.N, d.n_neg, d.pos_w, d.align_w, d.loss3);
         SOLA_LAUNCH_CHECK();
     }
     return SOLA_OK;

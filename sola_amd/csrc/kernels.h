@@ -20,6 +20,10 @@ struct GemmDesc {
     // implicit im2col for the k=3 channels-last conv: row m = (r, t_out); k = kk*Cin + ci
     int conv;  // 0: plain; 1: gather window; 2: transposed-conv gather
     int T_in, T_out, stride, pad, Cin;
+    // conv == 1, optional: ragged batches (sequences of different lengths in one launch).  Output row m reads its window from
+    // source row rowmap[m].x (the row of tap 0, may lie outside the sequence) and bit kk of rowmap[m].y says whether tap kk
+    // is inside the sequence (else it reads zeros).  T_in / T_out / stride / pad are then unused.
+    const int2* rowmap;
     int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate)
     float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
     int ksplit;  // arith 1, direct-to-LDS kernels: > 1 cuts the reduction into that many ranges, one work item each (few output
@@ -89,6 +93,9 @@ struct AttnDesc {
     int o_sp16;       // output as split-f16 pairs
     int in_sp16;      // q, k, v are split-f16 rows (written by a GEMM with c_sp16); not for sequences of <= 16 steps
     int* guard;       // o_sp16, optional: range guard word (see GemmDesc::guard)
+    // optional, ragged batches: group g attends q_units[g] = (first row, row stride, Sq_g, -) over k_units[g] = (first row,
+    // row stride, Sk_g, -); Sq / Sk are then the LARGEST lengths (they select the kernel shape and size the LDS)
+    const int4 *q_units, *k_units;
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 
@@ -180,6 +187,9 @@ struct GroupNormDesc {
     DropoutCfg drop;
     int out_sp16;  // y / y2 written as split-f16 pairs
     int* guard;    // out_sp16, optional: range guard word (see GemmDesc::guard)
+    // optional, ragged batches: instance i covers the tokens units[i] = (first row, row stride, token count, pe row) instead
+    // of the strided pattern above; ntok is then the LARGEST token count (it selects the kernel shape)
+    const int4* units;
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
@@ -207,6 +217,11 @@ int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
 int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,
                        hipStream_t s);
+// ragged: sample b has units[b] = (first input row, L_b, first output row, L_b + n_neg)
+int launch_lang_concat_ragged(const float* lang, const float* neg, float* out, float* lbar, int B, const int4* units, int n_neg,
+                              int D, hipStream_t s);
+// dst rows list[i].x .. + list[i].z  <-  src rows list[i].y .. (row_floats floats each); n entries
+int launch_gather_rows(const float* src, float* dst, const int4* list, int n, int row_floats, long long total_rows, hipStream_t s);
 
 // ---- score head + losses (head.hip) ----------------------------------------------------------------------------
 struct HeadDesc {
@@ -215,6 +230,9 @@ struct HeadDesc {
     float* score_map;   // [B, N]
     float* score_tokens;  // [B, N, D]
     int B, N, Tp, D;
+    // optional, ragged batches: B*N = number of tracks; track j has units[j] = (first row, -, T'_j, sample index) and
+    // Tp is the largest T'
+    const int4* units;
 };
 int launch_score_head(const HeadDesc& d, hipStream_t s);
 struct LossDesc {
@@ -225,6 +243,9 @@ struct LossDesc {
     float* terms;  // [B*N, 3] scratch
     float* loss3;
     int32_t* neg_argmax;  // optional
+    // optional, ragged batches: sample b owns the tracks trk_off[b] .. trk_off[b + 1] (device, B + 1 entries; N = the largest
+    // count) and loss3 is [B][3]: every sample's own means, i.e. what the reference computes at its batch size of 1
+    const int32_t* trk_off;
 };
 int launch_loss(const LossDesc& d, hipStream_t s);
 int launch_select(const float* score, long long n, float thr, float* prob, float* pred, hipStream_t s);

@@ -4,6 +4,8 @@
 //   pos_encoding    : module/module.py:112-128
 //   lang_concat     : module/module.py:146-147 (text tokens ++ negative tokens) and the mean over W of :152-153
 // All reductions are wave-shuffle + LDS trees with a fixed order (deterministic, no atomics).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -74,7 +76,22 @@ struct GnArgs {
     DropoutCfg drop;  // applied after the LeakyReLU (module/module.py:78)
     int out_sp16;     // write y / y2 as split-f16 pairs (cast.hip) instead of f32
     int* guard;       // out_sp16: range guard word (GroupNormDesc::guard), null = unchecked
+    const int4* units;  // ragged batches: (first row, row stride, token count, pe row) per instance (GroupNormDesc::units)
 };
+
+// The token set of instance `inst`: first row, row stride, token count and the positional-encoding row of the y + pe output.
+struct GnUnit { long long row0, tok_stride; int ntok, pe_row; };
+__device__ __forceinline__ GnUnit gn_unit(const GnArgs& a, int inst) {
+    GnUnit u;
+    if (a.units) {
+        const int4 d = a.units[inst];
+        u.row0 = d.x; u.tok_stride = d.y; u.ntok = d.z; u.pe_row = d.w;
+    } else {
+        u.row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+        u.tok_stride = a.tok_stride; u.ntok = a.ntok; u.pe_row = inst % a.inner;
+    }
+    return u;
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -142,22 +159,24 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     const int tpp = 256 / lpt;                // tokens per pass
     const int tl = threadIdx.x / lpt;         // token slot of this thread
     const int c4 = threadIdx.x - tl * lpt;    // float4 index inside the slice
-    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const GnUnit un = gn_unit(a, inst);
+    const long long row0 = un.row0, tok_stride = un.tok_stride;
+    const int ntok = un.ntok;
     const int ch = g * a.cg + c4 * 4;
     const bool active = tl < tpp;
-    const float cnt = (float)a.ntok * (float)a.cg;
+    const float cnt = (float)ntok * (float)a.cg;
 
     float s = 0.f;
     if (active)
-        for (int t = tl; t < a.ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+        for (int t = tl; t < ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
             s += (v.x + v.y) + (v.z + v.w);
         }
     const float mean = block_sum_256(s, red) / cnt;
     float q = 0.f;
     if (active)
-        for (int t = tl; t < a.ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+        for (int t = tl; t < ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
             const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -167,9 +186,9 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
     float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)(inst % a.inner) * a.C + ch);
-    for (int t = tl; t < a.ntok; t += tpp) {
-        const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch);
+    for (int t = tl; t < ntok; t += tpp) {
+        const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
         gn_apply_store(a, off, *reinterpret_cast<const float4*>(a.x + off), mean, rstd, ga, be, pe, c4);
     }
 }
@@ -190,22 +209,24 @@ __global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, lon
     const int inst = (int)(unit / a.groups), g = (int)(unit - (long long)inst * a.groups);
     const int tpp = nthr / f4;
     const int tl = tid / f4, c4 = tid - tl * f4;
-    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const GnUnit un = gn_unit(a, inst);
+    const long long row0 = un.row0, tok_stride = un.tok_stride;
+    const int ntok = un.ntok;
     const int ch = g * a.cg + c4 * 4;
-    const float cnt = (float)a.ntok * (float)a.cg;
+    const float cnt = (float)ntok * (float)a.cg;
     float4 v[R];
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
-        v[r] = t < a.ntok ? *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[r] = t < ntok ? *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
     }
     const float mean = (WAVE ? wave_sum(s) : block_sum_256(s, red)) / cnt;
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (tl + r * tpp < a.ntok) {
+        if (tl + r * tpp < ntok) {
             const float d0 = v[r].x - mean, d1 = v[r].y - mean, d2 = v[r].z - mean, d3 = v[r].w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -215,12 +236,12 @@ __global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, lon
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
     float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)(inst % a.inner) * a.C + ch);
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
         // out-of-range token slots still take part in the split-f16 shuffles; off < 0 marks "do not store"
-        const long long off = t < a.ntok ? (row0 + (long long)t * a.tok_stride) * a.C + ch : -1;
+        const long long off = t < ntok ? (row0 + (long long)t * tok_stride) * a.C + ch : -1;
         gn_apply_store(a, off, v[r], mean, rstd, ga, be, pe, c4);
     }
 }
@@ -255,7 +276,58 @@ __global__ void lang_concat_kernel(const float* __restrict__ lang, const float* 
     *reinterpret_cast<float4*>(lbar + (long long)b * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
+// ragged batches: sample b reads L_b text rows from lang[units[b].x ..] and writes W_b = L_b + n_neg rows at out[units[b].z ..]
+__global__ void lang_concat_ragged_kernel(const float* __restrict__ lang, const float* __restrict__ neg, float* out, float* lbar,
+                                          int B, const int4* __restrict__ units, int n_neg, int D) {
+    const int d4 = D >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d4) return;
+    const int b = i / d4, c = (i - b * d4) * 4;
+    const int4 u = units[b];
+    const int L = u.y, W = L + n_neg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < W; ++w) {
+        const float4 v = w < L ? *reinterpret_cast<const float4*>(lang + ((long long)u.x + w) * D + c)
+                               : *reinterpret_cast<const float4*>(neg + (long long)(w - L) * D + c);
+        *reinterpret_cast<float4*>(out + ((long long)u.z + w) * D + c) = v;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float inv = 1.f / (float)W;
+    *reinterpret_cast<float4*>(lbar + (long long)b * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+// dst rows list[i].x + r  <-  src rows list[i].y + r, r < list[i].z: the per-video activations repeated for every expression
+// that is scored against the video (HBM copy, 16 bytes per lane)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          const int4* __restrict__ list, int row_f4) {
+    const int4 e = list[blockIdx.y];
+    const long long n = (long long)e.z * row_f4;
+    const float4* s4 = reinterpret_cast<const float4*>(src) + (long long)e.y * row_f4;
+    float4* d4 = reinterpret_cast<float4*>(dst) + (long long)e.x * row_f4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d4[i] = s4[i];
+}
+
 }  // namespace
+
+int launch_lang_concat_ragged(const float* lang, const float* neg, float* out, float* lbar, int B, const int4* units, int n_neg,
+                              int D, hipStream_t s) {
+    SOLA_ARG(D % 4 == 0 && B > 0 && n_neg >= 0 && units, "lang_concat_ragged: bad arguments");
+    const int n = B * (D / 4);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 0);
+    hipLaunchKernelGGL(lang_concat_ragged_kernel, dim3((n + 255) / 256), dim3(256), 0, s, lang, neg, out, lbar, B, units, n_neg, D);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_gather_rows(const float* src, float* dst, const int4* list, int n, int row_floats, long long total_rows, hipStream_t s) {
+    SOLA_ARG(src && dst && list && n > 0 && row_floats % 4 == 0, "gather_rows: bad arguments");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * total_rows * row_floats);
+    const long long per = (total_rows / n + 1) * (row_floats / 4);
+    const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>(64, (per + 1023) / 1024));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(bx, n), dim3(256), 0, s, src, dst, list, row_floats / 4);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 int launch_ws_standardize(const WsLayer* layers, int n_layers, hipStream_t s) {
     SOLA_ARG(n_layers >= 1 && n_layers <= WS_MAX_LAYERS, "ws: %d layers", n_layers);
@@ -290,7 +362,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     GnArgs a;
     a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = d.out_sp16 ? d.guard : nullptr;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = d.out_sp16 ? d.guard : nullptr; a.units = d.units;
     SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);

@@ -79,3 +79,39 @@ def weighted_bce_with_logits(score_logits, labels, positive_weight=1.5):
     loss3 = track_selection_losses(score_logits, z, labels, torch.zeros((B, 1, D), device=dev), torch.zeros((1, D), device=dev),
                                    positive_weight=positive_weight, temperature=0.0, alignment_weight=0.0)
     return loss3[1]
+
+
+@torch.no_grad()
+def track_selection_losses_ragged(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets, counts,
+                                  positive_weight=1.5, temperature=0.07, alignment_weight=0.3, return_argmax=False):
+    """``track_selection_losses`` for the flat outputs of ``forward_ragged``: every sample gets its OWN means over its own
+    tracks - what train.py:98-113 / evaluator.py:88-112 compute at the reference's batch size of 1 (sola_loss_ragged).
+
+    score_map [sum N_i], score_tokens [sum N_i, D], labels [sum N_i]; pos_tokens [S, D] (or [S,1,D]); neg_tokens a shared
+    [n_neg, D] table or [S, n_neg, D]; track_offsets int32 [S+1] on the device; counts = python list of N_i.
+    Returns float32 [S, 3] = {total, bce, alignment} per sample (and int32 [sum N_i] hardest-negative indices)."""
+    require_cuda(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets)
+    S = len(counts)
+    total = int(score_map.numel())
+    D = score_tokens.shape[-1]
+    if track_offsets.dtype != torch.int32 or track_offsets.numel() != S + 1 or sum(counts) != total:
+        raise SolaError("track_offsets must be int32 [S+1] and counts must sum to the number of tracks")
+    f = lambda t: t.detach().to(torch.float32).contiguous()
+    sm, st, lb, ps, ng = f(score_map), f(score_tokens), f(labels), f(pos_tokens), f(neg_tokens)
+    if ps.numel() != S * D or lb.numel() != total:
+        raise SolaError("pos_tokens must be [S,D] and labels [sum N_i]")
+    if ng.dim() == 2:
+        n_neg, stride = ng.shape[0], 0
+    else:
+        if ng.shape[0] != S:
+            raise SolaError("neg_tokens batch dimension mismatch")
+        n_neg, stride = ng.shape[1], ng.shape[1] * D
+    dev = sm.device
+    loss3 = torch.empty((S, 3), device=dev, dtype=torch.float32)
+    argmax = torch.empty(total, device=dev, dtype=torch.int32) if return_argmax else None
+    scratch = torch.empty(total * 3, device=dev, dtype=torch.float32)
+    check(lib().sola_loss_ragged(ptr(sm), ptr(st), ptr(lb), ptr(ps), ptr(ng), stride, S, ptr(track_offsets.contiguous()),
+                                 max(counts), total, D, n_neg, float(positive_weight), float(temperature),
+                                 float(alignment_weight), ptr(loss3), ptr(argmax), ptr(scratch), scratch.numel() * 4,
+                                 current_stream(dev)), "sola_loss_ragged")
+    return (loss3, argmax) if return_argmax else loss3

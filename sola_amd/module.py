@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import SolaConfig, SolaError, check, current_stream, lib, ptr, require_cuda
+from ._lib import SolaConfig, SolaError, SolaRaggedBatch, check, current_stream, lib, ptr, require_cuda
 
 NUM_HEADS = 8  # module/module.py:13-15
 
@@ -211,6 +211,66 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
                                  ptr(ws), ws.numel(), current_stream(dev)), "sola_forward")
         self._last_shape = (B, N, T, L)
         return score_map, score_tokens
+
+    # ------------------------------------------------------------------------------------------ ragged batches
+    @torch.no_grad()
+    def forward_ragged(self, object_tokens, lang_tokens, sample_video=None):
+        """Score many (video, expression) samples of different shapes in ONE pass (sola_forward_ragged).
+
+        object_tokens : list of V tensors [N_v, T_v, d] - one per VIDEO (object set)
+        lang_tokens   : list of S tensors [L_i, D]      - one per SAMPLE
+        sample_video  : list of S video indices (default: sample i scores video i, S == V)
+
+        Everything that does not depend on the text (encoder, layer 0's inter-object and motion sub-blocks) runs once per
+        video and is shared by the samples that refer to it; inference.py:44-58 recomputes it per expression.
+        Returns ``(score_maps, score_tokens)``: lists of S tensors [N_i] and [N_i, D] (views of two flat buffers, also
+        available as ``self.last_ragged``: flat score_map, flat score_tokens, int32 track offsets on the device).
+        Inference only (no autograd).  Each sample's result equals ``self(obj[None], lang[None])`` up to f32 summation order."""
+        V, S = len(object_tokens), len(lang_tokens)
+        if V < 1 or S < 1:
+            raise SolaError("forward_ragged: need at least one video and one sample")
+        if sample_video is None:
+            if S != V:
+                raise SolaError("forward_ragged: sample_video is required when the sample count differs from the video count")
+            sample_video = list(range(S))
+        if len(sample_video) != S:
+            raise SolaError("forward_ragged: sample_video must have one entry per sample")
+        require_cuda(*object_tokens, *lang_tokens)
+        d, D = self.object_token_dim, self.lang_token_dim
+        for t in object_tokens:
+            if t.dim() != 3 or t.shape[2] != d or t.shape[0] < 1 or t.shape[1] < 1:
+                raise SolaError(f"forward_ragged: object tokens must be [N,T,{d}], got {tuple(t.shape)}")
+        for t in lang_tokens:
+            if t.dim() != 2 or t.shape[1] != D or t.shape[0] < 1:
+                raise SolaError(f"forward_ragged: text tokens must be [L,{D}], got {tuple(t.shape)}")
+        for v in sample_video:
+            if not 0 <= int(v) < V:
+                raise SolaError(f"forward_ragged: sample_video entry {v} out of range")
+        dev = object_tokens[0].device
+        obj = torch.cat([t.reshape(-1, d) for t in object_tokens], 0).to(torch.float32).contiguous()
+        lang = torch.cat(list(lang_tokens), 0).to(torch.float32).contiguous()
+        vN = (C.c_int32 * V)(*[int(t.shape[0]) for t in object_tokens])
+        vT = (C.c_int32 * V)(*[int(t.shape[1]) for t in object_tokens])
+        sV = (C.c_int32 * S)(*[int(v) for v in sample_video])
+        sL = (C.c_int32 * S)(*[int(t.shape[0]) for t in lang_tokens])
+        batch = SolaRaggedBatch(V, vN, vT, S, sV, sL)
+        self._ensure_ctx(dev)
+        self._bind_weights()
+        nbytes = lib().sola_ragged_workspace_bytes(self._ctx, C.byref(batch))
+        if nbytes == 0:
+            raise SolaError("forward_ragged: invalid batch description: " + (lib().sola_last_error() or b"").decode())
+        ws = self._get_workspace(nbytes, dev)
+        counts = [int(object_tokens[int(v)].shape[0]) for v in sample_video]
+        total = sum(counts)
+        score_map = torch.empty(total, device=dev, dtype=torch.float32)
+        score_tokens = torch.empty((total, D), device=dev, dtype=torch.float32)
+        check(lib().sola_forward_ragged(self._ctx, ptr(obj), ptr(lang), C.byref(batch), ptr(score_map), ptr(score_tokens),
+                                        ptr(ws), ws.numel(), current_stream(dev)), "sola_forward_ragged")
+        offs = [0]
+        for n in counts:
+            offs.append(offs[-1] + n)
+        self.last_ragged = (score_map, score_tokens, torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True), counts)
+        return list(torch.split(score_map, counts)), list(torch.split(score_tokens, counts))
 
     # ------------------------------------------------------------------------------------------ training path
     def _forward_train_impl(self, object_tokens, lang_tokens):

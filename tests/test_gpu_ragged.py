@@ -1,0 +1,179 @@
+"""Ragged batches (sola_forward_ragged / sola_loss_ragged): many (video, expression) samples of DIFFERENT (N, T, L) in one
+pass, with the text-independent part of the network computed once per video.
+
+* every sample of a ragged batch equals its own one-sample call (the reference's batch size of 1:
+  configs/mevis/default.yaml:37,42,47; inference.py:44-58) and the reference's golden vectors;
+* several expressions per video share the encoder + layer-0 object/motion sub-blocks and still equal per-sample calls;
+* shapes: T' = 1, odd lengths, one track, more than 64 tracks (split-f16 attention shape), more than 16 encoded steps
+  (motion attention leaves the packed 16-step shape), text lengths 1..40."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import case_dict  # noqa: E402
+from sola_amd import SolaError, synth  # noqa: E402
+from sola_amd.loss import track_selection_losses, track_selection_losses_ragged  # noqa: E402
+from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
+
+POS_W, TEMP, ALIGN_W = 1.5, 0.07, 0.3
+
+
+def build(cfg, precision):
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    sd = synth.make_state_dict(cfg, 42)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    m.precision = precision
+    return m
+
+
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
+def small(request):
+    return build(synth.SMALL_MODEL_CFG, request.param)
+
+
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
+def full(request):
+    return build(synth.DEFAULT_MODEL_CFG, request.param)
+
+
+def make_videos(cfg, shapes, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [torch.from_numpy(rng.standard_normal((N, T, cfg["object_token_dim"])).astype(np.float32)).cuda() for N, T in shapes]
+
+
+def make_texts(cfg, lens, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [torch.from_numpy(rng.standard_normal((L, cfg["lang_token_dim"])).astype(np.float32)).cuda() for L in lens]
+
+
+def per_sample(m, videos, texts, sample_video):
+    outs = []
+    for i, v in enumerate(sample_video):
+        with torch.no_grad():
+            sm, st = m(videos[v][None], texts[i][None])
+        outs.append((sm[0].clone(), st[0].clone()))
+    return outs
+
+
+SHAPES = [(8, 8), (5, 20), (16, 32), (3, 1), (7, 33), (1, 9), (20, 200), (70, 17), (2, 64), (11, 130)]
+LENS = [5, 6, 9, 4, 16, 1, 7, 40, 3, 12]
+
+
+def test_ragged_equals_per_sample_small(small):
+    cfg = synth.SMALL_MODEL_CFG
+    videos, texts = make_videos(cfg, SHAPES, 1), make_texts(cfg, LENS, 2)
+    sms, sts = small.forward_ragged(videos, texts)
+    ref = per_sample(small, videos, texts, list(range(len(videos))))
+    for i, ((rsm, rst), sm, st) in enumerate(zip(ref, sms, sts)):
+        assert sm.shape == rsm.shape and st.shape == rst.shape
+        torch.testing.assert_close(sm, rsm, rtol=0, atol=2e-4, msg=lambda s, i=i: f"sample {i} {SHAPES[i]}: {s}")
+        torch.testing.assert_close(st, rst, rtol=0, atol=2e-4, msg=lambda s, i=i: f"sample {i} {SHAPES[i]}: {s}")
+
+
+def test_shared_videos_equal_per_sample_small(small):
+    """14 expressions over 4 videos (one video unused by any sample would be legal too): the per-video half is computed once."""
+    cfg = synth.SMALL_MODEL_CFG
+    shapes = [(6, 24), (17, 40), (3, 9), (66, 16)]
+    sample_video = [0, 1, 1, 3, 0, 2, 1, 3, 3, 0, 2, 2, 1, 0]
+    lens = [3, 8, 1, 20, 5, 6, 7, 2, 33, 4, 9, 10, 11, 12]
+    videos, texts = make_videos(cfg, shapes, 3), make_texts(cfg, lens, 4)
+    sms, sts = small.forward_ragged(videos, texts, sample_video)
+    ref = per_sample(small, videos, texts, sample_video)
+    for i, ((rsm, rst), sm, st) in enumerate(zip(ref, sms, sts)):
+        torch.testing.assert_close(sm, rsm, rtol=0, atol=2e-4, msg=lambda s, i=i: f"sample {i}: {s}")
+        torch.testing.assert_close(st, rst, rtol=0, atol=2e-4, msg=lambda s, i=i: f"sample {i}: {s}")
+
+
+def test_all_golden_cases_in_one_ragged_batch(full, full_golden):
+    """The reference's golden samples of five different shapes - incl. (N=128, T=128) and (N=80) - scored in ONE call."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    videos, texts, gold = [], [], []
+    for ci in range(5):
+        B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
+        inp = synth.make_inputs(cfg, B, N, T, L, 200 + ci)
+        g = case_dict(full_golden, ci)
+        for b in range(B):
+            videos.append(torch.from_numpy(inp["object_tokens"][b]).cuda())
+            texts.append(torch.from_numpy(inp["lang_tokens"][b]).cuda())
+            gold.append((g["score_map"][b], g["score_tokens"][b], g["selected"][b], int(g["argmax_track"][b])))
+    sms, sts = full.forward_ragged(videos, texts)
+    assert full.split_fallbacks()[1] == 0
+    for i, (gsm, gst, gsel, garg) in enumerate(gold):
+        sm, st = sms[i].cpu().numpy(), sts[i].cpu().numpy()
+        assert np.abs(sm - gsm).max() <= 1e-3 and np.abs(st - gst).max() <= 1e-3, (i, np.abs(sm - gsm).max(), np.abs(st - gst).max())
+        np.testing.assert_array_equal((1.0 / (1.0 + np.exp(-sm)) > 0.5).astype(np.float32), gsel)
+        assert int(sm.argmax()) == garg
+
+
+def test_small_golden_cases_in_one_ragged_batch(small, small_golden):
+    cfg = synth.SMALL_MODEL_CFG
+    videos, texts, gold = [], [], []
+    for ci in range(6):
+        B, N, T, L = [int(v) for v in small_golden["cases"][ci]]
+        inp = synth.make_inputs(cfg, B, N, T, L, 100 + ci)
+        g = case_dict(small_golden, ci)
+        for b in range(B):
+            videos.append(torch.from_numpy(inp["object_tokens"][b]).cuda())
+            texts.append(torch.from_numpy(inp["lang_tokens"][b]).cuda())
+            gold.append((g["score_map"][b], g["score_tokens"][b]))
+    sms, sts = small.forward_ragged(videos, texts)
+    for i, (gsm, gst) in enumerate(gold):
+        assert np.abs(sms[i].cpu().numpy() - gsm).max() <= 1e-3 and np.abs(sts[i].cpu().numpy() - gst).max() <= 1e-3, i
+
+
+def test_ragged_losses_equal_per_sample_losses(full):
+    cfg = synth.DEFAULT_MODEL_CFG
+    shapes, lens = [(16, 32), (64, 32), (9, 40), (80, 24)], [16, 7, 11, 3]
+    sample_video = [0, 1, 1, 2, 3, 0]
+    lens = lens + [5, 21]
+    videos, texts = make_videos(cfg, shapes, 5), make_texts(cfg, lens, 6)
+    rng = np.random.Generator(np.random.PCG64(7))
+    labels = [torch.from_numpy((rng.uniform(size=shapes[v][0]) < 0.3).astype(np.float32)).cuda() for v in sample_video]
+    pos = torch.stack([t.mean(0) for t in texts], 0)
+    sms, sts = full.forward_ragged(videos, texts, sample_video)
+    flat_sm, flat_st, offs, counts = full.last_ragged
+    neg = full.negative_token.weight
+    loss, argmax = track_selection_losses_ragged(flat_sm, flat_st, torch.cat(labels), pos, neg, offs, counts, POS_W, TEMP, ALIGN_W,
+                                                 return_argmax=True)
+    assert loss.shape == (len(sample_video), 3)
+    o = 0
+    for i in range(len(sample_video)):
+        l3, am = track_selection_losses(sms[i][None], sts[i][None], labels[i][None], pos[i][None, None], neg, POS_W, TEMP, ALIGN_W,
+                                        return_argmax=True)
+        torch.testing.assert_close(loss[i], l3, rtol=1e-5, atol=1e-6)
+        assert torch.equal(argmax[o:o + counts[i]], am[0])
+        o += counts[i]
+
+
+def test_ragged_argument_errors(small):
+    cfg = synth.SMALL_MODEL_CFG
+    videos, texts = make_videos(cfg, [(4, 8), (3, 5)], 8), make_texts(cfg, [3, 4], 9)
+    with pytest.raises(SolaError):
+        small.forward_ragged(videos, texts[:1])  # sample count != video count without sample_video
+    with pytest.raises(SolaError):
+        small.forward_ragged(videos, texts, [0, 2])  # video index out of range
+    with pytest.raises(SolaError):
+        small.forward_ragged([videos[0][:, :, :8]], texts[:1])  # wrong token width
+    with pytest.raises(SolaError):
+        small.forward_ragged([v.cpu() for v in videos], texts)  # no CPU path
+    sms, _ = small.forward_ragged(videos, texts)  # still usable afterwards
+    assert [tuple(s.shape) for s in sms] == [(4,), (3,)]
+
+
+def test_ragged_is_deterministic_and_independent_of_batch_composition(full):
+    cfg = synth.DEFAULT_MODEL_CFG
+    shapes, lens = [(16, 32), (64, 32), (9, 40)], [16, 7, 11]
+    videos, texts = make_videos(cfg, shapes, 10), make_texts(cfg, lens, 11)
+    a, _ = full.forward_ragged(videos, texts)
+    b, _ = full.forward_ragged(videos, texts)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # the same samples in another order and next to other samples: same values up to summation order
+    c, _ = full.forward_ragged([videos[2], videos[0], videos[1], videos[0]], [texts[2], texts[0], texts[1], texts[0]])
+    torch.testing.assert_close(c[1], a[0], rtol=0, atol=2e-4)
+    torch.testing.assert_close(c[2], a[1], rtol=0, atol=2e-4)
+    torch.testing.assert_close(c[0], a[2], rtol=0, atol=2e-4)
+    assert torch.equal(c[1], c[3])
