@@ -12,22 +12,29 @@ runs its own batch (per-sample sharding, no data-path collective): weak scaling,
 
 Arithmetic of the convs/projections (98 % of the FLOPs), --precision:
   f16x3 (default) every f32 operand value is carried as an (f16 hi, f16 lo) pair in the same 4 bytes and each product is
-        hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation (~22-bit products).  It meets the same
-        parity bar as exact f32 (1e-3 on logits vs the reference's golden vectors, bit-exact selections) and is CLOSER
-        to a float64 evaluation than the f32 MFMA path (1.9e-4 vs 4.0e-4, tests/test_gpu_fast.py).
+        hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation (~22-bit products), with device-side
+        power-of-two scales for the caller's tokens and every weight matrix and a range guard that repeats a call on the
+        exact-f32 kernels if a value leaves the format's range (include/sola_hip.h: sola_set_split_guard; the guard's
+        read-back is inside the timed region).  It meets the same parity bar as exact f32 at every input scale
+        (tests/test_gpu_range.py) and is closer to a float64 evaluation than the f32 MFMA path.
   f32   exact v_mfma_f32_32x32x2_f32.  In the default mode the same workload is also timed on this path after the timed
-        region and reported as "exact_f32_mode" together with the largest logit difference between the two modes.
+        region and reported as "exact_f32_mode" with its own roofline entries.
 
-Prints ONE JSON line with the driver's contract plus:
-  roofline      - the dominant kernel (the MFMA GEMM gemm_nt_f32_kernel<128,128,..>): FLOPs of its launches in the timed
-                  region / their HIP-event durations.  f32 mode: algorithmic 2MNK against the 157.3 TFLOP/s f32 MFMA peak;
-                  f16x3 mode: the executed 3 x 2MNK against the 2.5 PFLOP/s dense f16 MFMA peak (algorithmic rate kept)
-  roofline_attention - the attention-core kernel named by the north star, against the 8 TB/s HBM peak
-  cpu_baseline  - the PyTorch-CPU oracle (a port of the reference path) timed on this box's host cores (rank 0, N=1)
-  training_step - (rank 0, N=1, outside the timed region) one optimizer step of the same network at up to 64 samples, exact
-                  f32 and with the split-f16 GEMMs
+The ONE JSON line carries the driver's contract plus (rank 0; the legs after the timed region run at N=1 only):
+  roofline            the dominant kernel of the headline mode.  `achieved` / `frac` are ALGORITHMIC (2MNK per GEMM) against
+                      the dense MFMA peak of the instruction the kernel issues; the split-f16 kernel executes 3 f16 MFMA
+                      products per algorithmic product, so `achieved_executed` / `frac_executed` give the matrix-pipe view
+  roofline_attention  the attention-core kernel named by the north star, against the 8 TB/s HBM peak
+  exact_f32_mode      the same step on the exact-f32 kernels: value + roofline (f32 MFMA peak) + roofline_attention
+  stress_T128_N128    BASELINE config C4 (T=128, N=128): value + roofline + roofline_attention
+  ragged              sola_forward_ragged on a MeViS-like mix (N 8..80, T 20..200, L 4..24): one expression per video, and
+                      four expressions per video (the text-independent half runs once per video)
+  iou                 the mask-IoU de-dup predicate at its real call sizes (P=4 x R=16/64/256 at 540x960): HBM roofline + CPU
+  training_step       one optimizer step at up to 64 samples, both precisions, with the per-kernel breakdown
+  cpu_baseline        the PyTorch-CPU oracle (a port of the reference path) timed on this box's host cores
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -43,6 +50,7 @@ import torch  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+POS_W, TEMP, ALIGN_W = 1.5, 0.07, 0.3
 
 
 def parse():
@@ -56,6 +64,7 @@ def parse():
     ap.add_argument("--text-len", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=5, help="steps of the training_step leg (rank 0, N=1, outside the timed region; 0 = skip)")
+    ap.add_argument("--extra-legs", type=int, default=1, help="0 skips the stress / ragged / iou legs (profiling runs)")
     ap.add_argument("--cached-ws", action="store_true", help="inference mode: standardise conv weights once (not the headline)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("SOLA_PRECISION", "f16x3"),
                     help="arithmetic of the convs/projections: exact f32 MFMA, or split-f16 operands (3 f16 MFMAs per product, "
@@ -63,6 +72,103 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------ helpers
+def cpu_info():
+    model, phys = "unknown", None
+    try:
+        cores = set()
+        pkg = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pkg = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pkg is not None and core is not None:
+                    cores.add((pkg, core))
+                pkg = core = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys
+
+
+def timed(fn, steps, sync, warmup=2):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def profiled(fn, steps, sync, warmup=2):
+    """(seconds per step, per-category profile of the timed steps)"""
+    from sola_amd import _lib
+
+    for _ in range(warmup):
+        fn()
+    sync()
+    _lib.profile_enable(True)
+    _lib.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    prof = _lib.profile_read(reset=True)
+    _lib.profile_enable(False)
+    return dt, prof
+
+
+def gemm_roofline(prof, precision, step_s, steps):
+    """Dominant GEMM kernel of a profiled leg, ALGORITHMIC flops (2MNK summed over its launches) / HIP-event time."""
+    if precision == "f16x3":
+        g256, grest = prof["gemm_split256"], prof["gemm_split"]
+        g = g256 if g256["ms"] >= grest["ms"] else grest
+        if g["ms"] <= 0:
+            return None
+        alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        name = ("gemm_nt_split_glds_persist_kernel<conv, residual, split-out> (persistent 256x256x32 blocks, 8 waves of 128x64, "
+                "split-f16 operands, 3 x v_mfma_f32_32x32x16_f16 per product, direct-to-LDS staging; all instantiations of a step)") \
+            if g is g256 else "gemm_nt_split_glds_kernel<2,2,2,*> / gemm_nt_f32_kernel<64,64,1,1> (128x128 and 64x64 split-f16 blocks)"
+        return {"kernel": name, "bound": "mfma", "achieved": round(alg, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(alg / F16_MFMA_PEAK_TFLOPS, 4), "frac_algorithmic": round(alg / F16_MFMA_PEAK_TFLOPS, 4),
+                "achieved_executed": round(3 * alg, 2), "frac_executed": round(3 * alg / F16_MFMA_PEAK_TFLOPS, 4),
+                "what": "achieved/frac: algorithmic 2MNK flops per second vs the dense f16 MFMA peak; *_executed: the 3 f16 MFMA "
+                        "products the kernel issues per algorithmic product (hi*hi + hi*lo + lo*hi)",
+                "algorithmic_vs_f32_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 3), "traffic": None,
+                "launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
+                "share_of_step_time": round(g["ms"] * 1e-3 / (step_s * steps), 4)}
+    g = prof["gemm128"] if prof["gemm128"]["ms"] >= prof["gemm64"]["ms"] else prof["gemm64"]
+    if g["ms"] <= 0:
+        return None
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    return {"kernel": "gemm_nt_f32_kernel<128,128> (v_mfma_f32_32x32x2_f32, exact f32)" if g is prof["gemm128"] else "gemm_nt_f32_kernel<64,64>",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": g["launches"],
+            "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2), "share_of_step_time": round(g["ms"] * 1e-3 / (step_s * steps), 4)}
+
+
+def attn_roofline(prof):
+    a = prof["attn"]
+    if a["ms"] <= 0:
+        return None
+    gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+    return {"kernel": "attn_fwd_f32_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
+            "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 2)}
+
+
+def kernel_ms(prof, steps):
+    return {k: round(v["ms"] / steps, 4) for k, v in prof.items() if v["launches"]}
+
+
+# --------------------------------------------------------------------------------------------------------------- legs
 def cpu_baseline(cfg, sd, N, T, L, budget_s):
     """The oracle (PyTorch-CPU restatement of the reference path) on a bounded sample: batch-1 forward + loss
     iterations at the headline shape, all host cores, until ~budget_s seconds are used."""
@@ -77,7 +183,7 @@ def cpu_baseline(cfg, sd, N, T, L, budget_s):
     def one():
         with torch.no_grad():
             sm, st = sola_oracle.forward(tsd, cfg, inp["object_tokens"], inp["lang_tokens"])
-            sola_oracle.losses(sm, st, inp["labels"], inp["pos_tokens"], neg, 1.5, 0.07, 0.3)
+            sola_oracle.losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
             sola_oracle.select(sm)
 
     # torch's intra-op pool collapses when every SMT thread of a 2-socket host joins ops this small (39 s/sample at
@@ -106,15 +212,16 @@ def cpu_baseline(cfg, sd, N, T, L, budget_s):
         if el >= budget_s or it >= 2000:
             break
     sweep = ", ".join(f"{c}t:{1e3 * v:.0f}ms" for c, v in trials.items())
-    return {"value": it / el, "unit": "samples/s", "cores": best, "kind": "port",
+    model, phys = cpu_info()
+    return {"value": round(it / el, 3), "unit": "samples/s", "cores": best, "kind": "port", "cpu_model": model, "physical_cores": phys,
+            "logical_cpus": ncpu, "one_thread_value": round(1.0 / trials[1], 3) if 1 in trials else None,
             "sample": f"{it} batch-1 forward+loss iterations of the PyTorch-CPU oracle at (T={T},N={N},L={L}) in {el:.1f} s with "
-                      f"torch.set_num_threads({best}) (best of sweep {sweep}; host has {ncpu} logical CPUs)"}
+                      f"torch.set_num_threads({best}) (best of sweep {sweep}; host: {model}, {phys} physical cores, {ncpu} logical CPUs)"}
 
 
 def training_leg(cfg, sd, dev, B, N, T, L, steps):
-    """Outside the timed region, rank 0 at N=1 only, reported beside the headline: one optimizer step of the same network
-    (sola_forward_train + losses + sola_backward + gradient norms / clip + AdamW) at up to 64 samples, exact f32 and with
-    the split-f16 GEMMs (module.precision = "f16x3")."""
+    """Outside the timed region, rank 0 at N=1 only: one optimizer step of the same network (sola_forward_train + losses +
+    sola_backward + gradient norms / clip + AdamW) at up to 64 samples, exact f32 and with the split-f16 GEMMs."""
     from sola_amd import synth
     from sola_amd.loss import track_selection_losses
     from sola_amd.module import LanguageAlignedTrackSelectionModule
@@ -129,26 +236,156 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
         opt.zero_grad(set_to_none=True)
         sm, st = m(inp["object_tokens"], inp["lang_tokens"])
         neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
-        loss3 = track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, 1.5, 0.07, 0.3)
+        loss3 = track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
         loss3[0].backward()
         m.clip_grad_norm_(1.0)
         opt.step()
 
+    fl = synth.flops_per_sample(cfg, N, T, L)
     res = {"batch": B, "steps": steps, "unit": "samples/s",
-           "what": "forward_train + BCE/alignment losses + backward + clip + AdamW; dropout on, one GPU"}
+           "what": "forward_train + BCE/alignment losses + backward + clip + AdamW; dropout on, one GPU",
+           "gflop_per_sample_fwd_bwd": round(3 * fl["total"] / 1e9, 2)}
+    sync = lambda: torch.cuda.synchronize(dev)
     for prec in ("f32", "f16x3"):
         m.precision = prec
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        res[prec] = {"value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
+        dt = timed(step, steps, sync)
+        _dtp, prof = profiled(step, max(2, steps // 2), sync, warmup=0)
+        kms = kernel_ms(prof, max(2, steps // 2))
+        gk = "gemm_split256" if prec == "f16x3" else "gemm128"
+        g = prof[gk]
+        alg = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        peak = F16_MFMA_PEAK_TFLOPS if prec == "f16x3" else F32_MFMA_PEAK_TFLOPS
+        res[prec] = {"value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "model_tflops": round(3 * fl["total"] * B / dt / 1e12, 1),
+                     "kernel_ms_per_step": kms,
+                     "roofline": {"kernel": gk + " (forward, dX and dW GEMMs of the step)", "bound": "mfma", "achieved": round(alg, 2),
+                                  "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
+                                  **({"achieved_executed": round(3 * alg, 2), "frac_executed": round(3 * alg / peak, 4)} if prec == "f16x3" else {}),
+                                  "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2)}}
     del m, opt
     torch.cuda.empty_cache()
+    return res
+
+
+def stress_leg(cfg, m, dev, precision, steps):
+    """BASELINE config C4: long-video stress T=128, N=128 (T'=16, 2048 tokens per sample), 32 samples per step."""
+    from sola_amd import ops, synth
+    from sola_amd.loss import track_selection_losses
+
+    B, N, T, L = 32, 128, 128, 16
+    inp = synth.make_inputs(cfg, B, N, T, L, seed=77)
+    c = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+
+    def step():
+        with torch.no_grad():
+            sm, st = m(c["object_tokens"], c["lang_tokens"])
+            track_selection_losses(sm, st, c["labels"], c["pos_tokens"], m.negative_token.weight, POS_W, TEMP, ALIGN_W)
+            ops.select(sm, 0.5)
+
+    sync = lambda: torch.cuda.synchronize(dev)
+    dt, prof = profiled(step, steps, sync)
+    fl = synth.flops_per_sample(cfg, N, T, L)
+    out = {"workload": f"T={T} N={N} L={L}, {B} samples/step", "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3),
+           "gflop_per_sample": round(fl["total"] / 1e9, 2), "model_tflops": round(B / dt * fl["total"] / 1e12, 2),
+           "roofline": gemm_roofline(prof, precision, dt, steps), "roofline_attention": attn_roofline(prof),
+           "kernel_ms_per_step": kernel_ms(prof, steps)}
+    del c
+    torch.cuda.empty_cache()
+    return out
+
+
+def ragged_leg(cfg, m, dev, steps, uniform_model_tflops):
+    """sola_forward_ragged + sola_loss_ragged + sola_select on a MeViS-like mix of shapes (N in [8,80] tracks, T in [20,200]
+    frames, L in [4,24] text tokens; seeded), 128 samples per launch: (a) one expression per video, (b) four expressions per
+    video.  FLOPs: `reference` = what per-sample forwards of these samples cost (the reference's batch-1 loop, and this
+    library's sola_forward), `executed` = with the text-independent half computed once per video."""
+    from sola_amd import ops, synth
+    from sola_amd.loss import track_selection_losses_ragged
+
+    rng = np.random.Generator(np.random.PCG64(2024))
+    S = 128
+    out = {"samples_per_launch": S, "shapes": "N~U[8,80], T~U[20,200], L~U[4,24], seed 2024"}
+    d, D = cfg["object_token_dim"], cfg["lang_token_dim"]
+    for tag, per_video in (("one_expression_per_video", 1), ("four_expressions_per_video", 4)):
+        V = S // per_video
+        shapes = [(int(rng.integers(8, 81)), int(rng.integers(20, 201))) for _ in range(V)]
+        lens = [int(rng.integers(4, 25)) for _ in range(S)]
+        sample_video = [i // per_video for i in range(S)]
+        videos = [torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)).to(dev) for n, t in shapes]
+        texts = [torch.from_numpy(rng.standard_normal((ln, D)).astype(np.float32)).to(dev) for ln in lens]
+        labels = torch.cat([torch.from_numpy((rng.uniform(size=shapes[v][0]) < 0.2).astype(np.float32)) for v in sample_video]).to(dev)
+        pos = torch.stack([t.mean(0) for t in texts], 0)
+
+        def step():
+            m.forward_ragged(videos, texts, sample_video)
+            flat, tok, offs, counts = m.last_ragged
+            track_selection_losses_ragged(flat, tok, labels, pos, m.negative_token.weight, offs, counts, POS_W, TEMP, ALIGN_W)
+            ops.select(flat, 0.5)
+
+        sync = lambda: torch.cuda.synchronize(dev)
+        dt, prof = profiled(step, steps, sync)
+        f_ref = f_exec = 0.0
+        for i, v in enumerate(sample_video):
+            n, t = shapes[v]
+            fl = synth.flops_per_sample(cfg, n, t, lens[i])
+            shared = fl["conv"] + synth.shared_flops_per_video(cfg, n, t)
+            f_ref += fl["total"]
+            f_exec += fl["total"] - shared + (shared if i % per_video == 0 else 0.0)
+        rows = sum(n * t for n, t in shapes)
+        out[tag] = {"videos": V, "value": round(S / dt, 1), "unit": "samples/s", "ms_per_launch": round(dt * 1e3, 3),
+                    "object_token_rows": rows, "gflop_per_sample_reference": round(f_ref / S / 1e9, 2),
+                    "model_tflops_reference": round(f_ref / dt / 1e12, 1), "model_tflops_executed": round(f_exec / dt / 1e12, 1),
+                    "executed_vs_uniform_batch_model_tflops": round(f_exec / dt / 1e12 / uniform_model_tflops, 3) if uniform_model_tflops else None,
+                    "roofline_attention": attn_roofline(prof), "kernel_ms_per_launch": kernel_ms(prof, steps)}
+        del videos, texts
+        torch.cuda.empty_cache()
+    return out
+
+
+def iou_leg(dev, cpu_seconds):
+    """The mask-IoU de-dup predicate (seg_utils.py:128-142 through generate_tokens_grid.py:266-278) at its real call sizes:
+    P=4 new-track masks against R prompt masks at 540x960 uint8.  Algorithmic bytes = (P+R)*H*W (every mask read once)."""
+    from oracle import iou_oracle
+    from sola_amd import _lib, seg_utils
+
+    H, W, P = 540, 960, 4
+    rng = np.random.default_rng(0)
+
+    def rects(n):
+        out = np.zeros((n, H, W), np.uint8)
+        for i in range(n):
+            y0, x0 = rng.integers(0, H // 2), rng.integers(0, W // 2)
+            out[i, y0:y0 + rng.integers(8, H // 2), x0:x0 + rng.integers(8, W // 2)] = 1
+        return out
+
+    res = {"workload": "compute_mask_iou matrix, P=4 tracks x R prompts, 540x960 uint8 masks resident in HBM", "cases": []}
+    sync = lambda: torch.cuda.synchronize(dev)
+    for R in (16, 64, 256):
+        A, Bm = rects(P), rects(R)
+        a, b = torch.from_numpy(A).to(dev), torch.from_numpy(Bm).to(dev)
+        inter, union = seg_utils.mask_iou_matrix(a, b)
+        if R <= 64:
+            ri, ru = iou_oracle.iou_matrix(A, Bm)
+            assert np.array_equal(inter.cpu().numpy(), ri) and np.array_equal(union.cpu().numpy(), ru)
+        dt, prof = profiled(lambda: seg_utils.mask_iou_matrix(a, b), 50, sync, warmup=5)
+        k_ms = (prof["iou_pack"]["ms"] + prof["iou_pair"]["ms"]) / 50
+        nbytes = (P + R) * H * W
+        res["cases"].append({"R": R, "pairs": P * R, "call_us_wall": round(dt * 1e6, 1), "kernels_us": round(k_ms * 1e3, 1),
+                             "launches_per_call": (prof["iou_pack"]["launches"] + prof["iou_pair"]["launches"]) // 50,
+                             "pairs_per_s": round(P * R / dt),
+                             "roofline": {"kernel": "mask IoU kernels of one call (pack + pair)", "bound": "hbm",
+                                          "achieved": round(nbytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
+                                          "frac_wall": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4)}})
+    if cpu_seconds > 0:
+        A, Bm = rects(1), rects(8)
+        t0 = time.perf_counter()
+        it = 0
+        while time.perf_counter() - t0 < min(3.0, cpu_seconds):
+            iou_oracle.iou_matrix(A, Bm)
+            it += 8
+        el = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(it / el, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{it} mask pairs through the numpy oracle (oracle/iou_oracle.py) in {el:.1f} s, one thread"}
     return res
 
 
@@ -157,6 +394,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend_name = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
@@ -170,15 +408,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        backend_name = dist.get_backend()
+        assert dist.get_world_size() == world
     else:
         dev_index = 0
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
 
-    from sola_amd import _lib, synth
+    from sola_amd import _lib, ops, synth
     from sola_amd.loss import track_selection_losses
     from sola_amd.module import LanguageAlignedTrackSelectionModule
-    from sola_amd import ops
 
     cfg = synth.DEFAULT_MODEL_CFG
     B, N, T, L = args.batch, args.tracks, args.frames, args.text_len
@@ -197,7 +436,7 @@ def main():
     def step():
         with torch.no_grad():
             sm, st = m(obj, lang)
-            loss3 = track_selection_losses(sm, st, labels, pos, m.negative_token.weight, 1.5, 0.07, 0.3)
+            loss3 = track_selection_losses(sm, st, labels, pos, m.negative_token.weight, POS_W, TEMP, ALIGN_W)
             _prob, pred = ops.select(sm, 0.5)
         return loss3, pred
 
@@ -209,7 +448,6 @@ def main():
     # The interpreter's cyclic garbage collector is parked for the timed region (as timeit does): with torch imported a full
     # collection takes ~37 ms on the host, the GPU queue runs dry behind it, and where it lands is a matter of luck
     # (tools/gc_stall_probe.py: it was one 35-39 ms stall in the first timed step, +2-4 ms/step at the default 10-20 steps).
-    import gc
     gc.collect()
     gc.disable()
     for _ in range(args.warmup):
@@ -226,6 +464,7 @@ def main():
     prof = _lib.profile_read(reset=True)
     _lib.profile_enable(False)
     assert torch.isfinite(loss3).all()
+    fallbacks, guard_bits = m.split_fallbacks()
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -233,103 +472,82 @@ def main():
         elapsed = float(t.item())
     total_samples = B * args.steps * world
     value = total_samples / elapsed
+    sync = lambda: torch.cuda.synchronize(dev)
 
-    # transparency leg (after the timed region, N=1 only): the same workload on the exact-f32 MFMA path, and the
-    # largest difference between the two modes' logits on this batch
+    # transparency leg (after the timed region, N=1 only): the same workload on the exact-f32 MFMA path with its own
+    # roofline entries, and the largest difference between the two modes' logits on this batch
     exact = None
     if args.precision == "f16x3" and world == 1:
         with torch.no_grad():
             sm_split, _ = m(obj, lang)
         m.precision = "f32"
         k = max(3, args.steps // 4)
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(k):
-            step()
-        torch.cuda.synchronize(dev)
-        el32 = time.perf_counter() - t1
+        dt32, prof32 = profiled(step, k, sync)
         with torch.no_grad():
             sm_f32, _ = m(obj, lang)
-        exact = {"value": round(B * k / el32, 2), "unit": "samples/s", "ms_per_step": round(1e3 * el32 / k, 4), "steps": k,
+        exact = {"value": round(B / dt32, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt32, 4), "steps": k, "dtype": "f32",
+                 "roofline": gemm_roofline(prof32, "f32", dt32, k), "roofline_attention": attn_roofline(prof32),
+                 "kernel_ms_per_step": kernel_ms(prof32, k),
                  "max_abs_logit_diff_vs_split_mode": float((sm_f32 - sm_split).abs().max())}
         m.precision = args.precision
 
     if rank == 0:
         fl = synth.flops_per_sample(cfg, N, T, L)
-        if args.precision == "f16x3":
-            # split-f16 GEMM: every algorithmic f32 FMA is issued as three f16 MFMA products, so the kernel is priced
-            # against the dense f16 MFMA peak with the work it actually executes (3 x 2MNK); the algorithmic rate is kept
-            # the dominant kernel is whichever split-GEMM shape took more of the step: the 256x256 direct-to-LDS blocks
-            # (their own profiler category, = rocprofv3's gemm_nt_split_glds_persist_kernel<*> instantiations) or the rest
-            g256, grest = prof["gemm_split256"], prof["gemm_split"]
-            g = g256 if g256["ms"] >= grest["ms"] else grest
-            alg = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            gname = ("gemm_nt_split_glds_persist_kernel<conv, residual, split-out> (persistent 256x256x32 blocks, 8 waves of "
-                     "128x64, split-f16 operands, 3 x v_mfma_f32_32x32x16_f16 per product, direct-to-LDS staging; all "
-                     "instantiations of a step)") if g is g256 else \
-                    "gemm_nt_split_glds_kernel<2,2,2,*> / gemm_nt_f32_kernel<64,64,1,1> (128x128 and 64x64 split-f16 blocks)"
-            roofline = {"kernel": gname, "bound": "mfma",
-                        "achieved": round(3 * alg, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(3 * alg / F16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_tflops": round(alg, 2),
-                        "algorithmic_vs_f32_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 3),
-                        "launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
-                        "share_of_step_time": round(g["ms"] * 1e-3 / elapsed, 4)}
-        else:
-            g = prof["gemm128"] if prof["gemm128"]["ms"] >= prof["gemm64"]["ms"] else prof["gemm64"]
-            gname = "gemm_nt_f32_kernel<128,128>" if g is prof["gemm128"] else "gemm_nt_f32_kernel<64,64>"
-            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            roofline = {"kernel": gname, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
-                        "share_of_step_time": round(g["ms"] * 1e-3 / elapsed, 4)}
-        a = prof["attn"]
-        a_gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
-        roofline_attn = {"kernel": "attn_fwd_f32_kernel", "bound": "hbm", "achieved": round(a_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(a_gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
-                         "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 2)}
-        kernels_ms = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
+        step_s = elapsed / args.steps
+        roofline = gemm_roofline(prof, args.precision, step_s, args.steps)
+        roofline_attn = attn_roofline(prof)
         # HBM traffic cannot be read from inside the run (PMC needs rocprofv3); it is the committed per-launch PMC
-        # measurement of this same command line (tools/profile_bench.sh -> profiles/r01_traffic.json), used only when the
+        # measurement of this same command line (tools/profile_bench.sh -> profiles/r0X_traffic.json), used only when the
         # batch matches the profiled one, else null
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if not os.path.exists(tpath):
+                continue
             tr = json.load(open(tpath))
             if tr.get("batch") == B and (N, T, L) == (64, 32, 16):
                 kk = tr["kernels"]
                 gk = tr.get("dominant_gemm") if args.precision == "f16x3" else "gemm_nt_f32_kernel<128, 128, 0, 0>"
-                if gk in kk:
+                if roofline and gk in kk:
                     roofline["traffic_kernel"] = gk
                     roofline["traffic"] = kk[gk]["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = tr["source"]
                 ak = [kk[k]["hbm_bytes_per_launch"] for k in ("attn_fwd_f32_kernel<128, false, 4, false>", "attn_fwd_f32_kernel<128, true, 4, false>") if k in kk]
-                if len(ak) == 2:
+                if roofline_attn and len(ak) == 2:
                     roofline_attn["traffic"] = int((2 * ak[0] + ak[1]) / 3)  # obj + o2l (shared K/V) and motion (packed) launches
+                if exact and exact.get("roofline") and "gemm_nt_f32_kernel<128, 128, 0, 0>" in kk:
+                    exact["roofline"]["traffic"] = kk["gemm_nt_f32_kernel<128, 128, 0, 0>"]["hbm_bytes_per_launch"]
+            break
         out = {
             "metric": "track-selection forward+loss samples/sec at (T=32,N=64,d=256)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * step_s, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (hi+lo f16 operand pairs, 3 f16 MFMAs per product, f32 accumulate)",
+            "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (hi+lo f16 operand pairs, 3 f16 MFMAs per product, f32 accumulate; "
+                                                              "device-side scales + range guard with exact-f32 repeat)",
             "config": {"workload": f"SOLA track selection forward+BCE+alignment loss+selection, T={T} N={N} d=256 L={L}, "
                                    f"configs/mevis/default.yaml model (32.98M params, random-init PCG64 seed 42), "
                                    f"{B} samples/step/GPU, "
                                    + ("conv weights standardised once (inference cache)" if args.cached_ws
                                       else "conv weights re-standardised every step"),
-                       "batch_per_gpu": B, "tracks": N, "frames": T, "text_len": L, "sharding": f"per-sample x{world}"},
+                       "batch_per_gpu": B, "tracks": N, "frames": T, "text_len": L, "sharding": f"per-sample x{world}",
+                       "collective_backend": backend_name, "world_size_reported_by_backend": world if world > 1 else None},
             "gflop_per_sample": round(fl["total"] / 1e9, 3),
             "model_tflops": round(value * fl["total"] / 1e12, 2),
-            "roofline": roofline, "roofline_attention": roofline_attn, "kernel_ms_per_step": kernels_ms,
+            "roofline": roofline, "roofline_attention": roofline_attn, "kernel_ms_per_step": kernel_ms(prof, args.steps),
         }
+        if args.precision == "f16x3":
+            out["split_guard"] = {"enabled": bool(m.split_guard), "calls_repeated_in_f32": fallbacks, "guard_bits_last_call": guard_bits}
         if exact is not None:
             out["exact_f32_mode"] = exact
+        if world == 1 and args.extra_legs:
+            k = max(3, args.steps // 4)
+            out["stress_T128_N128"] = stress_leg(cfg, m, dev, args.precision, k)
+            out["ragged"] = ragged_leg(cfg, m, dev, k, out["model_tflops"])
+            out["iou"] = iou_leg(dev, args.cpu_seconds)
         if world == 1 and args.train_steps > 0:
             out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps)
         if world == 1 and args.cpu_seconds > 0:
-            cb = cpu_baseline(cfg, sd, N, T, L, args.cpu_seconds)
-            cb["value"] = round(cb["value"], 3)
-            out["cpu_baseline"] = cb
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, N, T, L, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

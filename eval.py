@@ -3,8 +3,15 @@
 
     python eval.py --config mevis/default --eval_weight_epoch K [--eval_pred_threshold 0.5] [--synthetic true]
 
-Reports the losses (train.py:98-113 assembly) and track-level TP/FP/FN/TN of the valid split and writes
-``<eval_output_dir>/track_metrics.json``.  Mask-level J&F (evaluator.py:174-247) is outside the accelerated path.
+Reports the losses and track-level TP/FP/FN/TN of the valid split and writes ``<eval_output_dir>/track_metrics.json``.
+Scoring runs on ragged batches (sola_forward_ragged: up to ``--ragged_max_samples`` samples of different shapes per launch,
+one pass of the text-independent half per video); every sample's losses are its own means, as at the reference's batch
+size of 1.  Mask-level J&F (evaluator.py:174-247) is outside the accelerated path.
+
+BCE convention: ``bce`` / ``total`` follow train.py:98-113 (BCE-with-logits on the LOGITS, what the
+network is trained and validated with).  The reference's evaluator applies binary_cross_entropy_with_logits to the
+already SIGMOID-ed scores (evaluator.py:101,107-111) - a double sigmoid; that number is reported separately as
+``bce_evaluator_convention`` so eval JSONs can be compared line by line, and never enters ``total``.
 """
 import json
 import os
@@ -13,10 +20,10 @@ import torch
 
 from sola_amd import dist as sdist
 from sola_amd.config import load_configs
-from sola_amd.data import make_loader
+from sola_amd.data import make_ragged_batches
 from sola_amd.module import LanguageAlignedTrackSelectionModule
 from sola_amd.text import TextEncoder
-from train import run_split
+from train import run_split_ragged
 
 
 @torch.no_grad()
@@ -29,10 +36,11 @@ def evaluate(cfg):
     module = module.to(device).eval()
     text = TextEncoder(cfg["model"]["roberta_version"], cfg["model"]["lang_token_dim"], device,
                        allow_standin=bool(cfg.get("synthetic", False)))
-    loader, _ = make_loader(cfg["dataset"], "valid", rank, world, cfg.get("synthetic", None), cfg["model"])
+    batches, _ = make_ragged_batches(cfg["dataset"], "valid", rank, world, cfg.get("synthetic", None), cfg["model"])
     tcfg = dict(cfg["train"])
     tcfg["pred_threshold"] = cfg["eval"]["pred_threshold"]
-    m = run_split(module, text, loader, tcfg, device, False, None, world)
+    m = run_split_ragged(module, text, batches, tcfg, device, world)
+    m["text_encoder"] = text.kind
     m["precision"] = m["tp"] / max(m["tp"] + m["fp"], 1.0)
     m["recall"] = m["tp"] / max(m["tp"] + m["fn"], 1.0)
     if rank == 0:

@@ -51,8 +51,8 @@ def load_configs(mode: str, argv=None, config_root="configs"):
     with open(os.path.join(config_root, f"{args.config}.yaml"), "r") as f:
         cfg = yaml.safe_load(f)
     cfg.update(parse_overrides(unknown))
-    for k in list(cfg):  # build-side knobs of the synthetic stand-in dataset: --synthetic_samples / _tracks / _frames
-        if k.startswith("synthetic_"):
+    for k in list(cfg):  # build-side knobs: the synthetic stand-in dataset (--synthetic_samples / _tracks / _frames /
+        if k.startswith("synthetic_") or k.startswith("ragged_"):  # _per_video / _ragged) and the ragged batcher's bounds
             cfg["dataset"][k] = cfg[k]
     res = cfg["results"]
     weight_dir = os.path.join(res["output_dir"], cfg["exp_name"], cfg["dataset"]["train"]["data_name"])

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <mutex>
 
 #include "ctx.h"
@@ -398,29 +399,39 @@ extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int
 extern "C" size_t sola_ragged_workspace_bytes(const SolaCtx* c, const SolaRaggedBatch* batch) {
     if (!c || !batch) return 0;
     // the exact-f32 repeat of a guarded split-f16 call runs in the same arena: size it for the larger of the two plans
-    size_t n = sola_ragged_workspace_bytes_impl(c, batch);
-    if (c->precision == 1) {
-        SolaCtx* m = const_cast<SolaCtx*>(c);
-        m->precision = 0;
-        n = std::max(n, sola_ragged_workspace_bytes_impl(c, batch));
-        m->precision = 1;
+    try {
+        size_t n = sola_ragged_workspace_bytes_impl(c, batch);
+        if (c->precision == 1) {
+            SolaCtx* m = const_cast<SolaCtx*>(c);
+            m->precision = 0;
+            n = std::max(n, sola_ragged_workspace_bytes_impl(c, batch));
+            m->precision = 1;
+        }
+        return n;
+    } catch (const std::exception& e) {
+        sola_set_error("ragged_workspace_bytes: %s", e.what());
+        return 0;
     }
-    return n;
 }
 
 extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch, float* score_map,
                                    float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
-    SOLA_TRY(sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s));
-    if (c->precision != 1) return SOLA_OK;
-    bool tripped = false;
-    SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
-    if (!tripped) return SOLA_OK;
-    c->split_fallbacks += 1;
-    c->precision = 0;
-    const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
-    c->precision = 1;
-    return st;
+    try {  // the host-side plan allocates; nothing may throw across the ABI
+        SOLA_TRY(sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s));
+        if (c->precision != 1) return SOLA_OK;
+        bool tripped = false;
+        SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
+        if (!tripped) return SOLA_OK;
+        c->split_fallbacks += 1;
+        c->precision = 0;
+        const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
+        c->precision = 1;
+        return st;
+    } catch (const std::exception& e) {
+        sola_set_error("forward_ragged: %s", e.what());
+        return SOLA_ERR_ARG;
+    }
 }
 
 extern "C" int sola_loss_ragged(const float* score_map, const float* score_tokens, const float* labels, const float* pos,

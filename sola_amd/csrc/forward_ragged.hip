@@ -215,7 +215,7 @@ RagPlan rag_plan(const SolaCtx* c, const RagShape& r) {
     p.add("v_xpe", (size_t)r.Mv * D * f);
     p.add("v_motion", (size_t)r.Mv * D * f);
     if (!r.identity) p.add("s_motion0", (size_t)r.Ms * D * f);
-    p.add("s_o2l0", (size_t)r.Ms * D * f);
+    p.add("s0_o2l", (size_t)r.Ms * D * f);
     for (int l = 1; l < c->cfg.n_layers; ++l) {
         const std::string ls = "s" + std::to_string(l);
         p.add(ls + "_obj", (size_t)r.Ms * D * f);
@@ -509,7 +509,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
             x_mot = buf(ls + "_motion");
         }
         // object -> language attention (module/module.py:46-50)
-        float* x_o2l = buf(ls + (l == 0 ? "_o2l0" : "_o2l"));
+        float* x_o2l = buf(ls + "_o2l");
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0, o2l_in_sp, nullptr));
         SOLA_TRY(linear3(lang_in, lang_in, nullptr, l, 2, 2, r.LW, buf("lk"), buf("lv"), nullptr, 1, o2l_in_sp, sp ? c->scal_pair(1) + 1 : nullptr));
         SOLA_TRY(attention(q, buf("lk"), buf("lv"), S, tab4("u_smp"), tab4("u_langk"), r.maxRowsSample, r.maxW, o2l_in_sp));

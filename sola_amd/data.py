@@ -138,8 +138,13 @@ class TrackDataset(torch.utils.data.Dataset):
                 prompt_type.append(info["prompt_type"])
                 tokens.append(torch.from_numpy(np.load(os.path.join(tdir, f"{info['anno_id']:05d}.npy"))).float())
         assert tokens, "object_tokens is empty"
+        # roots with per-expression tracks (GroundingDINO prompts) make the token set expression-specific; grid / GT roots
+        # are per video, so all expressions of the video score the same tokens (shared by the ragged forward)
+        per_expression = any("gdino" in root for root in self.roots)
+        key = (s["video_id"], s["expression_id"]) if per_expression else (s["video_id"],)
         return {**s, "object_tokens": torch.stack(tokens, 0), "labels": {"iou": torch.tensor(iou)} if has_gt else None,
-                "root_type": root_type, "prompt_type": prompt_type, "sam2_anno_id": sam2_ids, "gt_anno_id": gt_ids}
+                "root_type": root_type, "prompt_type": prompt_type, "sam2_anno_id": sam2_ids, "gt_anno_id": gt_ids,
+                "token_key": "/".join(key)}
 
     def merged_masklet(self, video_id, expression_id, preds, device=None):
         """OR of the RLE-decoded masklets of the selected tracks (dataloader.py:305-351).  With ``device`` the run
@@ -170,29 +175,108 @@ class TrackDataset(torch.utils.data.Dataset):
 
 class SyntheticTracks(torch.utils.data.Dataset):
     """Deterministic stand-in with the real sample dictionary: N tracks x T frames of N(0,1) tokens, IoU labels with
-    ~20 % positives, a made-up expression string."""
+    ~20 % positives, a made-up expression string.  ``per_video`` expressions share one video (same tokens, as the grid
+    tracks of dataloader.py:87-199 do: <track_root>/.../sam2_object_tokens/<video>/).  With ``ragged`` every video draws its
+    own N in [8, 80] and T in [20, 200] (a MeViS-like mix); otherwise all videos are n_tracks x n_frames."""
 
-    def __init__(self, n_samples=32, n_tracks=64, n_frames=32, token_dim=256, seed=0, with_labels=True):
+    def __init__(self, n_samples=32, n_tracks=64, n_frames=32, token_dim=256, seed=0, with_labels=True, per_video=4, ragged=False):
         self.n, self.N, self.T, self.d, self.seed, self.with_labels = n_samples, n_tracks, n_frames, token_dim, seed, with_labels
+        self.per_video, self.ragged = max(1, int(per_video)), bool(ragged)
 
     def __len__(self):
         return self.n
 
+    def video_shape(self, vid):
+        if not self.ragged:
+            return self.N, self.T
+        rng = np.random.Generator(np.random.PCG64(self.seed * 7919 + 104729 * (vid + 1)))
+        return int(rng.integers(8, 81)), int(rng.integers(20, 201))
+
+    def token_key(self, idx):
+        """Samples with the same key have the same object tokens (one video's tracks): scored once per video."""
+        return f"synthetic_{idx // self.per_video:04d}"
+
     def __getitem__(self, idx):
-        rng = np.random.Generator(np.random.PCG64(self.seed * 1000003 + idx))
-        tok = torch.from_numpy(rng.standard_normal((self.N, self.T, self.d)).astype(np.float32))
-        iou = torch.from_numpy(np.where(rng.uniform(size=self.N) < 0.2, 0.9, 0.1).astype(np.float32))
-        return {"video_id": f"synthetic_{idx // 4:04d}", "expression_id": str(idx % 4), "expression": f"the object number {idx} moving left",
-                "anno_ids": [0], "frames": [f"{t:05d}" for t in range(self.T)], "object_tokens": tok,
-                "labels": {"iou": iou} if self.with_labels else None, "root_type": ["synthetic"] * self.N,
-                "prompt_type": ["SYNTHETIC"] * self.N, "sam2_anno_id": list(range(self.N)), "gt_anno_id": [0] * self.N}
+        vid = idx // self.per_video
+        N, T = self.video_shape(vid)
+        vrng = np.random.Generator(np.random.PCG64(self.seed * 1000003 + 7 * vid + 1))  # tokens belong to the VIDEO
+        tok = torch.from_numpy(vrng.standard_normal((N, T, self.d)).astype(np.float32))
+        rng = np.random.Generator(np.random.PCG64(self.seed * 1000003 + 1000 * idx + 3))
+        iou = torch.from_numpy(np.where(rng.uniform(size=N) < 0.2, 0.9, 0.1).astype(np.float32))
+        words = ["the", "object", "number", str(idx), "moving", "left", "behind", "a", "tree", "quickly"][: 3 + idx % 8]
+        return {"video_id": f"synthetic_{vid:04d}", "expression_id": str(idx % self.per_video), "expression": " ".join(words),
+                "anno_ids": [0], "frames": [f"{t:05d}" for t in range(T)], "object_tokens": tok,
+                "labels": {"iou": iou} if self.with_labels else None, "root_type": ["synthetic"] * N,
+                "prompt_type": ["SYNTHETIC"] * N, "sam2_anno_id": list(range(N)), "gt_anno_id": [0] * N,
+                "token_key": self.token_key(idx)}
+
+
+class RaggedBatcher:
+    """Groups consecutive samples of a dataset shard into ragged batches for ``forward_ragged``: up to ``max_samples``
+    (video, expression) pairs per launch, bounded by ``max_rows`` object-token rows (sum of N*T over the batch's videos,
+    which bounds the workspace), with samples of one video (same ``token_key``) sharing one entry of the video list.
+
+    Yields dictionaries: ``videos`` (list of [N_v,T_v,d] tensors), ``sample_video`` (index per sample), ``samples`` (the
+    dataset's sample dictionaries, tokens removed)."""
+
+    def __init__(self, dataset, indices, max_samples=128, max_rows=1 << 20):
+        self.dataset, self.indices = dataset, list(indices)
+        self.max_samples, self.max_rows = int(max_samples), int(max_rows)
+
+    def __iter__(self):
+        videos, keys, sample_video, samples, rows = [], {}, [], [], 0
+        for idx in self.indices:
+            smp = self.dataset[idx]
+            tok = smp.pop("object_tokens")
+            key = smp.get("token_key", ("sample", idx))
+            new_rows = 0 if key in keys else int(tok.shape[0]) * int(tok.shape[1])
+            if samples and (len(samples) >= self.max_samples or (new_rows > 0 and rows + new_rows > self.max_rows)):
+                yield {"videos": videos, "sample_video": sample_video, "samples": samples}
+                videos, keys, sample_video, samples, rows = [], {}, [], [], 0
+                new_rows = int(tok.shape[0]) * int(tok.shape[1])
+            if key not in keys:
+                keys[key] = len(videos)
+                videos.append(tok)
+                rows += new_rows
+            sample_video.append(keys[key])
+            samples.append(smp)
+        if samples:
+            yield {"videos": videos, "sample_video": sample_video, "samples": samples}
+
+
+def make_ragged_batches(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, model_cfg=None):
+    """(iterable of ragged batches over the rank's shard, dataset).  ``dataset.ragged_max_samples`` / ``ragged_max_rows``
+    bound a batch (defaults 128 samples, 2^20 token rows = 1 GiB of object tokens)."""
+    from .dist import shard_indices
+
+    ds = make_dataset(cfg_dataset, split, synthetic, model_cfg)
+    # contiguous shards keep a video's expressions on one rank (round-robin would scatter them and lose the sharing)
+    n = len(ds)
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    idx = list(range(lo, hi)) if world > 1 else shard_indices(n, 0, 1)
+    return RaggedBatcher(ds, idx, int(cfg_dataset.get("ragged_max_samples", 128)), int(cfg_dataset.get("ragged_max_rows", 1 << 20))), ds
 
 
 def collate(batch):
-    out = {k: [b[k] for b in batch] for k in batch[0] if k not in ("object_tokens", "labels")}
+    out = {k: [b[k] for b in batch] for k in batch[0] if k not in ("object_tokens", "labels", "token_key")}
     out["object_tokens"] = torch.stack([b["object_tokens"] for b in batch], 0)
     out["labels"] = None if batch[0]["labels"] is None else {"iou": torch.stack([b["labels"]["iou"] for b in batch], 0)}
     return out
+
+
+def make_dataset(cfg_dataset: dict, split: str, synthetic=None, model_cfg=None):
+    sc = cfg_dataset[split]
+    use_syn = bool(synthetic)
+    if not use_syn and not os.path.isdir(str(cfg_dataset.get("track_root", ""))):
+        raise FileNotFoundError(f"dataset.track_root '{cfg_dataset.get('track_root')}' does not exist; pass --synthetic true "
+                                "for a plumbing run on generated tracks")
+    if use_syn:
+        return SyntheticTracks(n_samples=int(cfg_dataset.get("synthetic_samples", 32)), n_tracks=int(cfg_dataset.get("synthetic_tracks", 64)),
+                               n_frames=int(cfg_dataset.get("synthetic_frames", 32)),
+                               token_dim=(model_cfg or {}).get("object_token_dim", 256), seed={"train": 0, "valid": 1, "test": 2}[split],
+                               with_labels=split != "test", per_video=int(cfg_dataset.get("synthetic_per_video", 4)),
+                               ragged=bool(cfg_dataset.get("synthetic_ragged", False)))
+    return TrackDataset(sc, cfg_dataset["data_root"], cfg_dataset["track_root"])
 
 
 def make_loader(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, model_cfg=None):
@@ -201,16 +285,7 @@ def make_loader(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, 
 
     sc = cfg_dataset[split]
     use_syn = bool(synthetic)
-    if not use_syn and not os.path.isdir(str(cfg_dataset.get("track_root", ""))):
-        raise FileNotFoundError(f"dataset.track_root '{cfg_dataset.get('track_root')}' does not exist; pass --synthetic true "
-                                "for a plumbing run on generated tracks")
-    if use_syn:
-        ds = SyntheticTracks(n_samples=int(cfg_dataset.get("synthetic_samples", 32)), n_tracks=int(cfg_dataset.get("synthetic_tracks", 64)),
-                             n_frames=int(cfg_dataset.get("synthetic_frames", 32)),
-                             token_dim=(model_cfg or {}).get("object_token_dim", 256), seed={"train": 0, "valid": 1, "test": 2}[split],
-                             with_labels=split != "test")
-    else:
-        ds = TrackDataset(sc, cfg_dataset["data_root"], cfg_dataset["track_root"])
+    ds = make_dataset(cfg_dataset, split, synthetic, model_cfg)
     # training shards are padded to equal length: one gradient all-reduce per step must meet its peers on every rank
     sub = torch.utils.data.Subset(ds, shard_indices(len(ds), rank, world, pad=(split == "train")))
     loader = torch.utils.data.DataLoader(sub, batch_size=sc.get("batch_size", 1), shuffle=(split == "train"),

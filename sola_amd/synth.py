@@ -187,6 +187,17 @@ def flops_per_sample(cfg, N, T, L):
     return {"conv": conv, "proj": proj, "attn": attn, "score": score, "total": conv + proj + attn + score}
 
 
+def shared_flops_per_video(cfg, N, T):
+    """Layer 0's inter-object and motion sub-blocks (q/k/v/out projections + attention cores, module/module.py:31-43): with
+    the conv encoder, the part of a sample's forward that does not depend on the text - sola_forward_ragged computes it
+    once per video (the "conv" entry of flops_per_sample is the rest of that part)."""
+    D, H = cfg["lang_token_dim"], NUM_HEADS
+    dh = D // H
+    Tp = t_out_lengths(T)[-1]
+    M = N * Tp
+    return 8 * 2 * M * D * D + Tp * H * 4 * N * N * dh + N * H * 4 * Tp * Tp * dh
+
+
 def attn_bytes_per_sample(cfg, N, T, L, elem=4):
     """Algorithmic attention-core bytes (q,k,v read once + o written once)."""
     D = cfg["lang_token_dim"]

@@ -42,6 +42,24 @@ class TextEncoder:
                           "embeddings because the stand-in was explicitly allowed")
 
     @torch.no_grad()
+    def encode_ragged(self, expressions):
+        """``(list of [L_i, D] token tensors, pos [S, D])`` for a ragged batch: every expression keeps its OWN length (the
+        reference encodes one expression at a time, train.py:80-91 at batch_size 1, so it never sees padding; here the
+        padded positions of the batched encoder are cut off again with the attention mask)."""
+        if self.model is not None:
+            enc = self.tokenizer.batch_encode_plus(expressions, padding="longest", return_tensors="pt").to(self.device)
+            tok = self.model(**enc).last_hidden_state
+            lens = enc["attention_mask"].sum(1).tolist()
+            toks = [tok[b, :int(n)] for b, n in enumerate(lens)]
+        else:
+            toks = []
+            for e in expressions:
+                t, _ = self.encode([e])
+                toks.append(t[0])
+        pos = torch.stack([t.mean(0) for t in toks], 0)
+        return toks, pos
+
+    @torch.no_grad()
     def encode(self, expressions):
         if self.model is not None:
             enc = self.tokenizer.batch_encode_plus(expressions, padding="longest", return_tensors="pt").to(self.device)

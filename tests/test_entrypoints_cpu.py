@@ -72,3 +72,35 @@ def test_track_dataset_reads_the_on_disk_contract(tmp_path):
     assert merged.shape == (2, 4, 6) and merged.dtype == bool or merged.dtype == np.uint8
     b = sdata.collate([s])
     assert b["object_tokens"].shape == (1, 4, 2, 256) and b["expression"] == ["a cat"]
+
+
+def test_ragged_batcher_groups_samples_and_shares_videos():
+    """Host logic of the ragged entry points: consecutive samples are grouped up to the sample / token-row budgets, the
+    expressions of one video share one entry of the video list, and every sample is yielded exactly once."""
+    ds = sdata.SyntheticTracks(n_samples=23, token_dim=8, seed=3, per_video=4, ragged=True)
+    shapes = {v: ds.video_shape(v) for v in range(6)}
+    assert len(set(shapes.values())) > 1 and all(8 <= n <= 80 and 20 <= t <= 200 for n, t in shapes.values())
+    assert torch.equal(ds[4]["object_tokens"], ds[7]["object_tokens"]) and ds[4]["token_key"] == ds[7]["token_key"]
+    assert ds[3]["token_key"] != ds[4]["token_key"]
+    seen = []
+    for batch in sdata.RaggedBatcher(ds, range(23), max_samples=10, max_rows=1 << 30):
+        assert len(batch["samples"]) <= 10 and len(batch["sample_video"]) == len(batch["samples"])
+        assert max(batch["sample_video"]) == len(batch["videos"]) - 1
+        for smp, v in zip(batch["samples"], batch["sample_video"]):
+            vid = int(smp["video_id"].split("_")[1])
+            assert tuple(batch["videos"][v].shape[:2]) == shapes[vid] and "object_tokens" not in smp
+            seen.append((smp["video_id"], smp["expression_id"]))
+        assert len(batch["videos"]) <= (len(batch["samples"]) + 3) // 4 + 1  # four expressions per video share one entry
+    assert len(seen) == 23 and len(set(seen)) == 23
+    # the row budget closes a batch early; a single video larger than the budget still forms its own batch
+    small = list(sdata.RaggedBatcher(ds, range(23), max_samples=1000, max_rows=1))
+    assert len(small) == 6 and sum(len(b["samples"]) for b in small) == 23 and all(len(b["videos"]) == 1 for b in small)
+    # samples without a token key are never merged
+    class NoKey(torch.utils.data.Dataset):
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            return {"object_tokens": torch.zeros(2, 3, 8), "expression": "x"}
+    b = list(sdata.RaggedBatcher(NoKey(), range(3)))
+    assert len(b) == 1 and b[0]["sample_video"] == [0, 1, 2]

@@ -37,9 +37,28 @@ def test_train_eval_inference_roundtrip(tmp_path):
     run("eval.py", "--eval_weight_epoch", "2")
     m = json.load(open(tmp_path / "SOLA" / "EVAL" / "default" / "mevis" / "pred_threshold_05" / "epoch_2" / "track_metrics.json"))
     assert m["tp"] + m["fp"] + m["fn"] + m["tn"] == 6 * 8 and m["total"] > 0
+    assert m["samples"] == 6 and m["text_encoder"] == "hashed-standin" and m["bce_evaluator_convention"] > 0
     run("inference.py", "--eval_weight_epoch", "2")
     inf = tmp_path / "SOLA" / "INFERENCE" / "default" / "mevis" / "pred_threshold_05" / "epoch_2"
     assert len(list(inf.rglob("*_pred.npy"))) == 6
+    # a MeViS-like mix of shapes (N in [8,80], T in [20,200], four expressions per video): 24 samples in ONE ragged launch
+    # give the decisions of 24 one-sample launches (the reference's batch size of 1)
+    import numpy as np
+    import shutil
+
+    rag = ["--config", "mevis/default", "--synthetic", "true", "--synthetic_samples", "24", "--synthetic_ragged", "true"]
+    preds = {}
+    for tag, extra in (("one", ["--ragged_max_samples", "1"]), ("many", ["--ragged_max_samples", "64"])):
+        shutil.rmtree(inf)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py"), *rag, "--eval_weight_epoch", "2", *extra], cwd=tmp_path,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert ("24 samples / 6 video passes in 1 ragged calls" in r.stdout) == (tag == "many"), r.stdout[-500:]
+        preds[tag] = {str(f.relative_to(inf)): np.load(f) for f in sorted(inf.rglob("*_pred.npy"))}
+    assert len(preds["one"]) == 24 and preds["one"].keys() == preds["many"].keys()
+    assert len({v.shape for v in preds["many"].values()}) > 1  # really ragged
+    for k in preds["one"]:
+        np.testing.assert_array_equal(preds["one"][k], preds["many"][k], err_msg=k)
 
 
 def test_bench_two_ranks_code_path(tmp_path):

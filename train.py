@@ -19,8 +19,8 @@ import torch
 
 from sola_amd import dist as sdist
 from sola_amd.config import load_configs
-from sola_amd.data import make_loader
-from sola_amd.loss import track_selection_losses
+from sola_amd.data import make_loader, make_ragged_batches
+from sola_amd.loss import track_selection_losses, track_selection_losses_ragged
 from sola_amd.module import LanguageAlignedTrackSelectionModule
 from sola_amd.text import TextEncoder
 
@@ -71,6 +71,45 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
             "fn": stats[5], "tn": stats[6]}
 
 
+@torch.no_grad()
+def run_split_ragged(module, text, batches, tcfg, device, world=1):
+    """Validation / evaluation over ragged batches (sola_forward_ragged + sola_loss_ragged): the same per-sample numbers as
+    ``run_split(train=False)`` - each sample's losses are means over its own tracks, as at the reference's batch size of 1
+    (train.py:147-216, evaluator.py:88-112) - at up to ``ragged_max_samples`` samples per launch, the expressions of one
+    video sharing the text-independent half of the network."""
+    pw, temp, aw = tcfg["positive_weight"], tcfg["temperature"], tcfg["alignment_weight"]
+    module.eval()
+    sums = torch.zeros(3, device=device)
+    counts4 = torch.zeros(4, device=device)  # TP FP FN TN
+    bce_eval = torch.zeros(1, device=device)
+    n = 0
+    for batch in batches:
+        videos = [v.to(device, non_blocking=True) for v in batch["videos"]]
+        texts, pos = text.encode_ragged([s["expression"] for s in batch["samples"]])
+        module.forward_ragged(videos, texts, batch["sample_video"])
+        flat, tok, offs, counts = module.last_ragged
+        labels = torch.cat([(s["labels"][tcfg["positive_metric"]] > tcfg["positive_threshold"]).float() for s in batch["samples"]]).to(device)
+        loss = track_selection_losses_ragged(flat, tok, labels, pos, module.negative_token.weight, offs, counts, pw, temp, aw)
+        sums += loss.sum(0)
+        prob = torch.sigmoid(flat)
+        pred = (prob > tcfg["pred_threshold"]).float()
+        counts4 += torch.stack([(pred * labels).sum(), (pred * (1 - labels)).sum(), ((1 - pred) * labels).sum(),
+                                ((1 - pred) * (1 - labels)).sum()])
+        # the reference's evaluator feeds the SIGMOID-ed scores to binary_cross_entropy_with_logits (evaluator.py:101,107-111;
+        # SURVEY appendix A): reported next to the train.py:98-104 value so eval JSONs of the two code bases can be compared
+        w = torch.where(labels > 0, torch.full_like(labels, pw), torch.ones_like(labels))
+        per_track = torch.nn.functional.binary_cross_entropy_with_logits(prob, labels, weight=w, reduction="none")
+        bce_eval += torch.stack([t.mean() for t in torch.split(per_track, counts)]).sum()
+        n += len(counts)
+    stats = torch.cat([sums, counts4, torch.tensor([float(n)], device=device), bce_eval])
+    if world > 1:
+        torch.distributed.all_reduce(stats)
+    stats = stats.cpu().tolist()
+    n_tot = max(stats[7], 1.0)
+    return {"total": stats[0] / n_tot, "bce": stats[1] / n_tot, "alignment": stats[2] / n_tot, "tp": stats[3], "fp": stats[4],
+            "fn": stats[5], "tn": stats[6], "bce_evaluator_convention": stats[8] / n_tot, "samples": stats[7]}
+
+
 def train(cfg):
     rank, local_rank, world = sdist.init_from_env()
     device = torch.device("cuda", local_rank)
@@ -83,7 +122,7 @@ def train(cfg):
                        allow_standin=bool(cfg.get("synthetic", False)))
     synthetic = cfg.get("synthetic", None)
     train_loader, _ = make_loader(cfg["dataset"], "train", rank, world, synthetic, cfg["model"])
-    valid_loader, _ = make_loader(cfg["dataset"], "valid", rank, world, synthetic, cfg["model"])
+    valid_batches, _ = make_ragged_batches(cfg["dataset"], "valid", rank, world, synthetic, cfg["model"])
     tcfg = cfg["train"]
     optimizer = torch.optim.AdamW(module.parameters(), lr=tcfg["lr"])
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=tcfg["lr_factor"], patience=tcfg["lr_patience"])
@@ -91,7 +130,7 @@ def train(cfg):
     for epoch in range(n_epochs):
         t0 = time.time()
         tr = run_split(module, text, train_loader, tcfg, device, True, optimizer, world)
-        va = run_split(module, text, valid_loader, tcfg, device, False, None, world)
+        va = run_split_ragged(module, text, valid_batches, tcfg, device, world)
         scheduler.step(va["total"])
         if rank == 0:
             prec = va["tp"] / max(va["tp"] + va["fp"], 1.0)
