@@ -226,6 +226,16 @@ int sola_forward_train(SolaCtx* ctx, const float* dev_object_tokens, const float
                        void* dev_workspace, size_t workspace_bytes, void* stream);
 int sola_backward(SolaCtx* ctx, const float* dev_d_score_map, const float* dev_d_score_tokens,
                   const void* dev_forward_workspace, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* Gradient buckets for multi-GPU training (train.py under torchrun: one RCCL all-reduce of the gradient per step, the only
+ * collective of the path).  sola_backward finishes the parameters' gradients in a fixed order: alignment layer n-1, ...,
+ * layer 1, then layer 0 together with negative_token.weight (which collects contributions from every layer), then the
+ * encoder - sola_grad_bucket_count() = n_layers + 1 buckets, sola_grad_bucket_of(name) gives a parameter's bucket.  A caller
+ * that lays its gradient buffers out bucket by bucket in ONE flat allocation can all-reduce each bucket in place, and
+ * sola_backward_wait_bucket(ctx, k, stream) makes `stream` wait (device-side, hipStreamWaitEvent) for the moment bucket k
+ * is final, so its all-reduce overlaps the rest of the backward.  Valid after sola_backward until the next one. */
+int sola_grad_bucket_count(const SolaCtx* ctx);
+int sola_grad_bucket_of(const SolaCtx* ctx, const char* name);
+int sola_backward_wait_bucket(SolaCtx* ctx, int bucket, void* stream);
 /* Backward of sola_loss.  dev_g3 = upstream gradients of {total, bce, alignment} (3 floats on the device).
  * Writes d(score_map) [B,N], d(score_tokens) [B,N,D] and (optional) d(neg_tokens) [B,n_neg,D].  Scratch: B*N*n_neg floats. */
 int sola_loss_backward(const float* dev_score_map, const float* dev_score_tokens, const float* dev_labels,

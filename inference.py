@@ -29,7 +29,7 @@ from sola_amd.text import TextEncoder
 @torch.no_grad()
 def inference(cfg):
     rank, local_rank, world = sdist.init_from_env()
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     module = LanguageAlignedTrackSelectionModule(cfg["model"])
     module.load_state_dict(torch.load(cfg["eval"]["weight_path"], map_location="cpu", weights_only=True))

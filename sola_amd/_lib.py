@@ -86,6 +86,9 @@ SIGNATURES = {
     "sola_set_grad": (_i, [_vp, C.c_char_p, _vp, _i64]),
     "sola_forward_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sola_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sola_grad_bucket_count": (_i, [_vp]),
+    "sola_grad_bucket_of": (_i, [_vp, C.c_char_p]),
+    "sola_backward_wait_bucket": (_i, [_vp, _i, _vp]),
     "sola_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sola_ws_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sola_gemm_tn_scratch_bytes": (_sz, [_i, _i, _i]),

@@ -184,6 +184,7 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (c->scal_buf) (void)hipFree(c->scal_buf);
     if (c->guard_host) (void)hipHostFree(c->guard_host);
     sola_rag_stage_free(c->rag_stage);
+    for (hipEvent_t e : c->bucket_ev) (void)hipEventDestroy(e);
     delete c;
     return SOLA_OK;
 }

@@ -106,26 +106,25 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
                 make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
         return;
     }
-    // split-f16: an 8-wide block is held by the lane pair (g4, g4 ^ 1) = lanes l and l ^ 16
+    // split-f16: an 8-wide block [hi8 | lo8] is held by the lane pair (g4, g4 ^ 1); each lane writes the hi and the lo halves
+    // of its OWN four values as two 8-byte stores (block offset 8 * (g4 & 1), lo 16 bytes behind) - no cross-lane traffic
+    // (the lanes of a pair are 16 apart, a shuffle between them goes through the LDS crossbar)
+    float m = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const float v0 = oacc[c][0] * inv, v1 = oacc[c][1] * inv, v2 = oacc[c][2] * inv, v3 = oacc[c][3] * inv;
-        const float n0 = __shfl_xor(v0, 16, 64), n1 = __shfl_xor(v1, 16, 64), n2 = __shfl_xor(v2, 16, 64), n3 = __shfl_xor(v3, 16, 64);
-        if ((g4 & 1) == 0) {
-            const float v[8] = {v0, v1, v2, v3, n0, n1, n2, n3};
-            half8 hi, lo;
+        const float v[4] = {oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv};
+        half4v hi, lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
-            half8* dst = reinterpret_cast<half8*>(op + 4 * g4 + c * 16);
-            dst[0] = hi; dst[1] = lo;
-            if (guard) {  // NaN fails the comparison too
-                float m = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
-                if (!(m < 65000.f)) atomicOr(guard, 1);
-            }
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = (_Float16)v[j];
+            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+            m = fmaxf(m, fabsf(v[j]));
         }
+        char* dst = reinterpret_cast<char*>(op + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+        *reinterpret_cast<half4v*>(dst) = hi;
+        *reinterpret_cast<half4v*>(dst + 16) = lo;
     }
+    if (guard && !(m < 65000.f)) atomicOr(guard, 1);  // NaN fails the comparison too
 }
 
 // NW = waves per block of the shared mode (4: 64-query blocks, K/V tiles of up to 64 rows, two blocks per CU; 8: 128-query

@@ -3,6 +3,7 @@
 // attn_bwd.hip, bwd.hip over the activations saved by sola_forward_impl(train = true).  Gradients of all 83
 // parameters are written to the borrowed buffers registered with sola_set_grad (overwrite semantics).
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -223,6 +224,13 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     const std::string last = "l" + std::to_string(c->cfg.n_layers - 1) + "_o2l";
     float* gbuf[2] = {ar.get("g0"), ar.get("g1")};
     int cur = 0;
+    // gradient-bucket events (ctx.h): created once, recorded as each bucket's last gradient kernel is enqueued
+    if ((int)c->bucket_ev.size() != c->n_buckets()) {
+        for (hipEvent_t e : c->bucket_ev) (void)hipEventDestroy(e);
+        c->bucket_ev.assign(c->n_buckets(), nullptr);
+        for (hipEvent_t& e : c->bucket_ev) SOLA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    c->bucket_recorded = false;
     {
         HeadBwdDesc d{fb(last), fb("lbar"), d_score_map, d_score_tokens, gbuf[cur], ar.get("dlbar_part"), B, N, Tp, D};
         SOLA_TRY(launch_score_head_bwd(d, s));
@@ -346,10 +354,12 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur], sc3));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
             cur = 1 - cur;
         }
+        if (l > 0) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final
     }
 
     // ---- negative tokens: rows L.. of d(lang ++ neg) from the k/v projections + the mean-over-W of the score head
     SOLA_TRY(launch_neg_token_grad(dlang, ar.get("dlbar"), nullptr, G("negative_token.weight"), B, L, c->cfg.n_negative, D, s));
+    SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1], s));  // layer 0 + negative tokens
 
     // ---- encoder ----------------------------------------------------------------------------------------------
     const float* dy = gbuf[cur];  // gradient wrt conv5 output [R*T', D]
@@ -438,5 +448,33 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         }
         SOLA_TRY(launch_ws_backward(layers, 6, s));
     }
+    SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers], s));  // encoder
+    c->bucket_recorded = true;
+    return SOLA_OK;
+}
+
+extern "C" int sola_grad_bucket_count(const SolaCtx* c) { return c ? c->n_buckets() : 0; }
+
+// bucket of a parameter: layers in reverse order, then layer 0 together with the negative tokens, then the encoder
+extern "C" int sola_grad_bucket_of(const SolaCtx* c, const char* name) {
+    SOLA_ARG(c && name, "grad_bucket_of: null argument");
+    const std::string n(name);
+    if (c->index.find(n) == c->index.end() || n == "positional_encoding_gaussian_matrix") {
+        sola_set_error("grad_bucket_of: '%s' is not a parameter", name);
+        return SOLA_ERR_WEIGHT;
+    }
+    const std::string lp = "object_lang_align_layers.";
+    if (n.compare(0, lp.size(), lp) == 0) return c->cfg.n_layers - 1 - atoi(n.c_str() + lp.size());
+    if (n == "negative_token.weight") return c->cfg.n_layers - 1;
+    return c->cfg.n_layers;
+}
+
+extern "C" int sola_backward_wait_bucket(SolaCtx* c, int bucket, void* stream_) {
+    SOLA_ARG(c && bucket >= 0 && bucket < c->n_buckets(), "backward_wait_bucket: bucket %d out of range", bucket);
+    if (!c->bucket_recorded) {
+        sola_set_error("backward_wait_bucket: no completed sola_backward on this context");
+        return SOLA_ERR_STATE;
+    }
+    SOLA_HIP(hipStreamWaitEvent(as_stream(stream_), c->bucket_ev[bucket], 0));
     return SOLA_OK;
 }

@@ -67,6 +67,13 @@ struct SolaCtx {
     bool split_guard = true;        // sola_set_split_guard
     long long split_fallbacks = 0;  // calls that were repeated in exact f32
     SolaRagStage* rag_stage = nullptr;
+    // Gradient buckets of sola_backward, in the order their gradients become final: layer n-1, ..., layer 1, layer 0 (+ the
+    // negative tokens, whose gradient collects contributions from every layer), encoder.  An event is recorded on the
+    // backward's stream when a bucket is complete, so the caller can start that bucket's all-reduce on another stream
+    // while the rest of the backward still runs (sola_backward_wait_bucket).
+    std::vector<hipEvent_t> bucket_ev;
+    bool bucket_recorded = false;
+    int n_buckets() const { return cfg.n_layers + 1; }
     float* scal_pair(int i) const { return scal_buf + 2 * i; }
     const float* lin_inv_scale(int layer, int attn, int proj) const { return scal_buf + 2 * (2 + (layer * 3 + attn) * 4 + proj) + 1; }
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);

@@ -21,8 +21,8 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # SOLA_DIST_BACKEND=gloo: several ranks on one GPU (tests; RCCL refuses two ranks per device)
+            backend = os.environ.get("SOLA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
@@ -82,6 +82,48 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, average=True)
         size += nb
     flush()
     return n_coll
+
+
+def allreduce_gradient_arena(module, world=None, average=True, overlap=True):
+    """The training step's one collective, in place and overlapped: the module keeps all gradients in ONE flat arena laid
+    out in the order sola_backward finishes them (layer n-1 ... layer 0 + negative tokens, encoder: n_layers + 1 buckets of
+    30-50 MB at the default size - xGMI is point-to-point, so few large messages).  Called right after ``loss.backward()``
+    has ENQUEUED the backward, it makes a side stream wait (device-side) for each bucket's completion event and issues that
+    bucket's all-reduce there, so the layer buckets travel while the encoder's backward still runs; the caller's stream
+    then waits for the side stream.  Every rank issues the same collectives in the same order.  Returns their number.
+
+    Falls back to ``allreduce_gradients`` when the last backward did not write into the arena (gradient accumulation)."""
+    from ._lib import check, lib
+
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return 0
+    if not getattr(module, "_grads_in_arena", False):
+        return allreduce_gradients(module.parameters(), world, average=average)
+    buckets = module.grad_buckets()
+    dev = buckets[0].device
+    nccl = dist.get_backend() == "nccl"
+    main = torch.cuda.current_stream(dev)
+    side = getattr(module, "_comm_stream", None)
+    if side is None or side.device != dev:
+        side = module._comm_stream = torch.cuda.Stream(device=dev)
+    if not overlap:
+        side = main
+    for k, flat in enumerate(buckets):
+        if overlap:
+            check(lib().sola_backward_wait_bucket(module._ctx, k, side.cuda_stream), "sola_backward_wait_bucket")
+        with torch.cuda.stream(side):
+            if nccl and average:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)  # RCCL averages in the collective
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                if average:
+                    flat.div_(world)
+    if overlap:
+        main.wait_stream(side)
+    module._last_grad_sq = None  # (the in-place collective also bumped the arena's version counter, which every view shares)
+    return len(buckets)
 
 
 def gather_scores(local, rank, world):

@@ -102,6 +102,10 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._train_inputs = None
         self._train_shape = None
         self._train_generation = 0
+        self._grad_arena = None
+        self._grad_ctx = None
+        self._grad_bound = None
+        self._grads_in_arena = False
 
     # ------------------------------------------------------------------------------------------ library binding
     def _config_struct(self):
@@ -303,23 +307,73 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._workspace = self._train_ws  # workspace_tap reads the arena of the last forward
         return score_map, score_tokens
 
+    def _grad_layout(self):
+        """Flat gradient arena: every parameter's gradient is a view of ONE allocation, laid out bucket by bucket in the
+        order sola_backward finishes them (sola_grad_bucket_of), so the multi-GPU path all-reduces each bucket in place
+        while the rest of the backward still runs (sola_amd/dist.py: allreduce_gradient_arena).  64-float alignment keeps
+        every view 256-byte aligned."""
+        named = list(self.named_parameters())
+        dev = named[0][1].device
+        if getattr(self, "_grad_arena", None) is not None and self._grad_arena.device == dev and self._grad_ctx is self._ctx:
+            return
+        nb = lib().sola_grad_bucket_count(self._ctx)
+        order = []
+        for key, p in named:
+            b = lib().sola_grad_bucket_of(self._ctx, key.encode())
+            if b < 0:
+                check(b, f"sola_grad_bucket_of({key})")
+            order.append((b, len(order), key, p))
+        order.sort(key=lambda t: (t[0], t[1]))
+        off, spans, starts = 0, [], {}
+        for b, _i, key, p in order:
+            starts.setdefault(b, off)
+            spans.append((key, off, p.numel(), tuple(p.shape)))
+            off += (p.numel() + 63) // 64 * 64
+        self._grad_arena = torch.zeros(off, device=dev, dtype=torch.float32)
+        self._grad_views = {key: self._grad_arena[o:o + n].view(shape) for key, o, n, shape in spans}
+        bounds = [starts[b] for b in range(nb)] + [off]
+        self._grad_buckets = [(bounds[b], bounds[b + 1]) for b in range(nb)]
+        for key, g in self._grad_views.items():
+            check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
+        self._grad_ctx = self._ctx
+        self._grad_bound = "arena"
+
+    def grad_buckets(self):
+        """[(flat view of bucket k)] of the gradient arena, in completion order (valid after a backward)."""
+        return [self._grad_arena[a:b] for a, b in self._grad_buckets]
+
     def _backward_impl(self, d_score_map, d_score_tokens):
         B, N, T, L = self._train_shape
         dev = self._train_ws.device
         D = self.lang_token_dim
         d_sm = torch.zeros((B, N), device=dev) if d_score_map is None else d_score_map.to(torch.float32).contiguous()
         d_st = torch.zeros((B, N, D), device=dev) if d_score_tokens is None else d_score_tokens.to(torch.float32).contiguous()
-        grads = []
         named = dict(self.named_parameters())
-        for key, p in named.items():
-            g = torch.empty_like(p, memory_format=torch.contiguous_format)
-            check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
-            grads.append(g)
+        self._grad_layout()
+        lo, hi = self._grad_arena.data_ptr(), self._grad_arena.data_ptr() + 4 * self._grad_arena.numel()
+        # sola_backward OVERWRITES its gradient buffers.  If a parameter still holds a gradient that lives in the arena (the
+        # caller accumulates over several backwards instead of zero_grad(set_to_none=True)), writing there would clobber
+        # what autograd is about to add to: such a step gets fresh buffers, exactly the pre-arena behaviour.
+        aliased = any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in named.values())
+        if aliased:
+            grads = []
+            for key, p in named.items():
+                g = torch.empty_like(p, memory_format=torch.contiguous_format)
+                check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
+                grads.append(g)
+            self._grad_bound = "fresh"
+        else:
+            if self._grad_bound != "arena":
+                for key, g in self._grad_views.items():
+                    check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
+                self._grad_bound = "arena"
+            grads = [self._grad_views[key] for key in named]
         nbytes = lib().sola_backward_workspace_bytes(self._ctx, B, N, T, L)
         if self._bwd_ws is None or self._bwd_ws.numel() < nbytes or self._bwd_ws.device != dev:
             self._bwd_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         check(lib().sola_backward(self._ctx, ptr(d_sm), ptr(d_st), ptr(self._train_ws), ptr(self._bwd_ws),
                                   self._bwd_ws.numel(), current_stream(dev)), "sola_backward")
+        self._grads_in_arena = not aliased
         return grads
 
     def workspace_tap(self, name):

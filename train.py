@@ -50,7 +50,7 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
         if train:
             optimizer.zero_grad(set_to_none=True)
             loss3[0].backward()
-            sdist.allreduce_gradients(module.parameters(), world)
+            sdist.allreduce_gradient_arena(module, world)  # in place on the flat arena, bucket by bucket, overlapping the backward
             if tcfg["grad_clip_norm"] > 0:
                 gnd = module.get_grad_norm_dict()  # one host sync for all five norms
                 if gnd["total_grad_norm"] > tcfg["grad_clip_norm"]:
@@ -112,7 +112,7 @@ def run_split_ragged(module, text, batches, tcfg, device, world=1):
 
 def train(cfg):
     rank, local_rank, world = sdist.init_from_env()
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     module = LanguageAlignedTrackSelectionModule(cfg["model"]).to(device)
     if world > 1:  # identical initial weights on every rank
@@ -143,6 +143,13 @@ def train(cfg):
                 f.write(line + "\n")
             torch.save(module.state_dict(), os.path.join(cfg["results"]["output_dir"], f"epoch_{epoch + 1}.pth"))
     if world > 1:
+        # every rank stepped on the same averaged gradient: the weights must be identical everywhere
+        import hashlib
+
+        h = hashlib.sha256()
+        for t in module.state_dict().values():
+            h.update(t.detach().cpu().numpy().tobytes())
+        print(f"[rank {rank}] weights sha256 {h.hexdigest()[:16]}", flush=True)
         torch.distributed.destroy_process_group()
 
 
