@@ -268,6 +268,7 @@ void sola_gn_set_variant(int v);
 void sola_bilinear_set_staged(int v);
 void sola_attn_set_variant(int v);
 void sola_attn_set_target_blocks(int v);
+void sola_iou_set_fused(int v);
 extern "C" int sola_tune(const char* key, int value) {
     SOLA_ARG(key, "tune: null key");
     if (!strcmp(key, "gemm_variant")) { sola_gemm_set_variant(value); return SOLA_OK; }
@@ -281,6 +282,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "bilinear_staged")) { sola_bilinear_set_staged(value); return SOLA_OK; }
     if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
+    if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
     sola_set_error("tune: unknown key '%s'", key);
     return SOLA_ERR_ARG;
 }
@@ -856,6 +858,8 @@ extern "C" int64_t sola_rle_string_to_cum(const char* str, int64_t len, uint32_t
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P, int R, int H, int W, int h, int w, long long* inter,
+                           long long* uni, void* scratch, size_t scratch_bytes, hipStream_t s, int* status);
 
 extern "C" size_t sola_mask_iou_scratch_bytes(int P, int R, int H, int W) {
     const size_t words = (size_t)sola_mask_words(H, W);
@@ -871,6 +875,12 @@ extern "C" int sola_mask_iou_matrix(const void* a, const void* b, int elem_type,
         return SOLA_ERR_WORKSPACE;
     }
     SOLA_ARG((reinterpret_cast<uintptr_t>(scratch) & 255) == 0, "mask_iou_matrix: scratch must be 256-byte aligned");
+    {   // P <= 4 uint8 masks at the comparison resolution (the de-dup loop's calls): one memset + one kernel (iou.hip)
+        int st = SOLA_OK;
+        if (launch_mask_iou_fused(a, b, elem_type, P, R, H, W, h, w, reinterpret_cast<long long*>(inter), reinterpret_cast<long long*>(uni),
+                                  scratch, scratch_bytes, as_stream(stream_), &st))
+            return st;
+    }
     const size_t words = (size_t)sola_mask_words(H, W);
     char* base = static_cast<char*>(scratch);
     uint32_t* abits = reinterpret_cast<uint32_t*>(base);

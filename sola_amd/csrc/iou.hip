@@ -195,7 +195,113 @@ __global__ __launch_bounds__(256) void mask_pair_kernel(const PairArgs a) {
     }
 }
 
+// ---- one-launch path for the de-dup loop's real call sizes (generate_tokens_grid.py:266-278: P <= 4 new tracks against
+//      16-64 prompts, uint8 masks already at the comparison resolution) ---------------------------------------------------
+// The three-kernel path above costs five launches (two area memsets, two packs, one pair kernel): ~25 us of kernels inside
+// ~45 us of wall time for 10-35 MB of masks.  Here block (chunk, r) reads its 32 KiB slice of prompt r and of the P track
+// masks (the tracks are re-read once per prompt, from L2: P * 518 KB stay resident), packs both to bits in registers and
+// counts popc(A & B), |A|, |B| without ever writing the bit planes; per-prompt totals are integer atomics (order-free, so
+// the result is still exact) and the last block of a prompt writes inter / union.  One memset + one kernel.
+struct FusedArgs {
+    const uint8_t *a, *b;
+    long long hw, words;
+    int P, R, chunks;
+    unsigned long long* acc;  // [R][9]: inter[4], areaA[4], areaB
+    unsigned* done;           // [R]
+    long long *inter, *uni;
+};
+constexpr int FUSED_MAXP = 4;
+
+__global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs a) {
+    __shared__ int red[4][2 * FUSED_MAXP + 1];
+    __shared__ int is_last;
+    constexpr int IT = 4;
+    const int r = blockIdx.y;
+    const uint4* bsrc = reinterpret_cast<const uint4*>(a.b + (long long)r * a.hw);
+    const long long w0 = (long long)blockIdx.x * (256 * IT) + threadIdx.x;
+    int cnt[2 * FUSED_MAXP + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * FUSED_MAXP + 1; ++j) cnt[j] = 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const long long w = w0 + it * 256;
+        if (w >= a.words) continue;
+        const unsigned wb = pack16(bsrc[2 * w]) | (pack16(bsrc[2 * w + 1]) << 16);
+        cnt[2 * FUSED_MAXP] += __popc(wb);
+#pragma unroll
+        for (int p = 0; p < FUSED_MAXP; ++p) {
+            if (p < a.P) {
+                const uint4* asrc = reinterpret_cast<const uint4*>(a.a + (long long)p * a.hw);
+                const unsigned wa = pack16(asrc[2 * w]) | (pack16(asrc[2 * w + 1]) << 16);
+                cnt[p] += __popc(wa & wb);
+                cnt[FUSED_MAXP + p] += __popc(wa);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * FUSED_MAXP + 1; ++j) {
+        int c = cnt[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = c;
+    }
+    __syncthreads();
+    unsigned long long* acc = a.acc + (long long)r * (2 * FUSED_MAXP + 1);
+    if (threadIdx.x < 2 * FUSED_MAXP + 1) {
+        const int j = threadIdx.x;
+        const int tot = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        if (tot) atomicAdd(&acc[j], (unsigned long long)tot);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&a.done[r], 1u) == (unsigned)(a.chunks - 1);
+    __syncthreads();
+    if (is_last && threadIdx.x < a.P) {
+        __threadfence();
+        const int p = threadIdx.x;
+        const long long in = (long long)atomicAdd(&acc[p], 0ull);
+        const long long aa = (long long)atomicAdd(&acc[FUSED_MAXP + p], 0ull);
+        const long long ab = (long long)atomicAdd(&acc[2 * FUSED_MAXP], 0ull);
+        a.inter[(long long)p * a.R + r] = in;
+        a.uni[(long long)p * a.R + r] = aa + ab - in;  // sum(A + B) - inter (seg_utils.py:133-134)
+    }
+}
+
 }  // namespace
+
+size_t mask_iou_fused_scratch_bytes(int R) { return (size_t)R * ((2 * FUSED_MAXP + 1) * 8 + 4) + 64; }
+
+int g_iou_fused = 1;  // sola_tune "iou_fused": 0 forces the pack + pair path (A/B, tests)
+void sola_iou_set_fused(int v) { g_iou_fused = v; }
+
+// true if the call was served by the fused kernel
+bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P, int R, int H, int W, int h, int w, long long* inter,
+                           long long* uni, void* scratch, size_t scratch_bytes, hipStream_t s, int* status) {
+    *status = SOLA_OK;
+    const long long hw = (long long)H * W;
+    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || R > 65535 ||
+        (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) || scratch_bytes < mask_iou_fused_scratch_bytes(R))
+        return false;
+    FusedArgs a;
+    a.a = static_cast<const uint8_t*>(am); a.b = static_cast<const uint8_t*>(bm);
+    a.hw = hw; a.words = hw / 32; a.P = P; a.R = R;
+    a.chunks = (int)((a.words + 1023) / 1024);
+    a.acc = static_cast<unsigned long long*>(scratch);
+    a.done = reinterpret_cast<unsigned*>(a.acc + (size_t)R * (2 * FUSED_MAXP + 1));
+    a.inter = inter; a.uni = uni;
+    if (hipMemsetAsync(scratch, 0, mask_iou_fused_scratch_bytes(R), s) != hipSuccess) {
+        sola_set_error("mask_iou_matrix: hipMemsetAsync failed");
+        *status = SOLA_ERR_HIP;
+        return true;
+    }
+    SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)(P + R) * hw);
+    hipLaunchKernelGGL(mask_iou_fused_u8_kernel, dim3(a.chunks, R), dim3(256), 0, s, a);
+    if (hipGetLastError() != hipSuccess) {
+        sola_set_error("mask_iou_matrix: fused kernel launch failed");
+        *status = SOLA_ERR_HIP;
+    }
+    return true;
+}
 
 int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
                      long long* area, hipStream_t s) {

@@ -57,6 +57,9 @@ def pair_counts(a_bits, a_area, b_bits, b_area, T=1, a_frame=None):
     return inter, union
 
 
+_IOU_SCRATCH = {}
+
+
 def mask_iou_matrix(A, B):
     """A [P,H,W], B [R,h,w] (resampled to H x W) -> (inter, union) int64 [P,R] in one library call."""
     A, B = _prep(A), _prep(B)
@@ -65,12 +68,17 @@ def mask_iou_matrix(A, B):
     P, H, W = A.shape
     R, h, w = B.shape
     dev = A.device
-    inter = torch.empty((P, R), device=dev, dtype=torch.int64)
-    union = torch.empty((P, R), device=dev, dtype=torch.int64)
+    out = torch.empty((2, P, R), device=dev, dtype=torch.int64)  # one allocation for both count matrices
+    inter, union = out[0], out[1]
     nb = lib().sola_mask_iou_scratch_bytes(P, R, H, W)
-    scratch = torch.empty(nb, device=dev, dtype=torch.uint8)
+    # the scratch is reused from call to call (same stream: the calls are ordered): the de-dup loop calls this once per SAM2
+    # iteration with 10-35 MB of masks, where an allocation costs as much as the kernel
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    scratch = _IOU_SCRATCH.get(key)
+    if scratch is None or scratch.numel() < nb:
+        scratch = _IOU_SCRATCH[key] = torch.empty(nb, device=dev, dtype=torch.uint8)
     check(lib().sola_mask_iou_matrix(ptr(A), ptr(B), _elem_type(A), P, R, H, W, h, w, ptr(inter), ptr(union),
-                                     ptr(scratch), nb, current_stream(dev)), "sola_mask_iou_matrix")
+                                     ptr(scratch), scratch.numel(), current_stream(dev)), "sola_mask_iou_matrix")
     return inter, union
 
 

@@ -107,3 +107,32 @@ def test_full_size_properties():
     assert inter[0, 0] == union[0, 0] == area_b[0]  # IoU(A,A) = 1
     assert torch.all(inter <= torch.minimum(area_a[:, None], area_b[None, :]))
     assert inter[1, 1] == A[1].sum()  # A[1] is a subset of B[1]
+
+
+@pytest.mark.parametrize("P,R,H,W", [(4, 16, 540, 960), (1, 1, 540, 960), (3, 64, 540, 960), (4, 7, 64, 96), (2, 5, 960, 540), (4, 300, 128, 256)])
+def test_fused_one_launch_path_equals_pack_and_pair(P, R, H, W):
+    """uint8 masks at the comparison resolution with P <= 4 (the de-dup loop's calls) take the fused kernel; its counts are
+    the oracle's and the three-kernel path's, including empty masks and a mask equal to its partner."""
+    from sola_amd import _lib
+
+    rng = np.random.default_rng(P * 1000 + R)
+    A = (rng.uniform(size=(P, H, W)) < 0.3).astype(np.uint8)
+    B = (rng.uniform(size=(R, H, W)) < 0.5).astype(np.uint8) * rng.integers(1, 255, size=(R, H, W)).astype(np.uint8)  # any non-zero byte counts
+    B[0] = 0
+    if R > 2:
+        B[2] = A[0]
+    A[P - 1, : H // 2] = 0
+    ri, ru = iou_oracle.iou_matrix(A, (B != 0).astype(np.uint8))
+    outs = []
+    for fused in (1, 0):
+        _lib.check(_lib.lib().sola_tune(b"iou_fused", fused), "sola_tune")
+        inter, union = seg_utils.mask_iou_matrix(cuda(A), cuda(B))
+        outs.append((inter.cpu().numpy(), union.cpu().numpy()))
+    _lib.check(_lib.lib().sola_tune(b"iou_fused", 1), "sola_tune")
+    for inter, union in outs:
+        np.testing.assert_array_equal(inter, ri)
+        np.testing.assert_array_equal(union, ru)
+    # repeated calls reuse the scratch: the self-zeroing must hold
+    for _ in range(3):
+        inter, union = seg_utils.mask_iou_matrix(cuda(A), cuda(B))
+        np.testing.assert_array_equal(inter.cpu().numpy(), ri)
