@@ -198,78 +198,120 @@ __global__ __launch_bounds__(256) void mask_pair_kernel(const PairArgs a) {
 // ---- one-launch path for the de-dup loop's real call sizes (generate_tokens_grid.py:266-278: P <= 4 new tracks against
 //      16-64 prompts, uint8 masks already at the comparison resolution) ---------------------------------------------------
 // The three-kernel path above costs five launches (two area memsets, two packs, one pair kernel): ~25 us of kernels inside
-// ~45 us of wall time for 10-35 MB of masks.  Here block (chunk, r) reads its 32 KiB slice of prompt r and of the P track
-// masks (the tracks are re-read once per prompt, from L2: P * 518 KB stay resident), packs both to bits in registers and
-// counts popc(A & B), |A|, |B| without ever writing the bit planes; per-prompt totals are integer atomics (order-free, so
-// the result is still exact) and the last block of a prompt writes inter / union.  One memset + one kernel.
+// ~45 us of wall time for 10-35 MB of masks.  Here block (chunk, prompt group) packs its 8 KiB slice of the P track masks
+// to bits ONCE (registers), then streams the same slice of up to 16 prompts, eight in flight at a time, and counts
+// popc(A & B), |B| (and |A|) without ever writing a bit plane; per-block counts go to a small partial table and the last
+// block to finish (one atomic counter) folds them in index order and writes inter / union.  Every mask byte is read once
+// from HBM (the tracks again per prompt group, from L2).  One 64-byte memset + one kernel; integer sums, exact.
 struct FusedArgs {
     const uint8_t *a, *b;
     long long hw, words;
-    int P, R, chunks;
-    unsigned long long* acc;  // [R][9]: inter[4], areaA[4], areaB
-    unsigned* done;           // [R]
+    int P, R, chunks, groups;
+    unsigned* part;   // [chunks][R][P + 1]: inter[p] ..., |B_r| ; then [chunks][P]: |A_p|
+    unsigned* done;   // 1 counter (zeroed by the caller)
     long long *inter, *uni;
 };
 constexpr int FUSED_MAXP = 4;
+constexpr int FUSED_RG = 16;  // prompts per block
+constexpr int FUSED_RB = 8;   // prompts in flight
 
 __global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs a) {
-    __shared__ int red[4][2 * FUSED_MAXP + 1];
+    __shared__ int red[4][FUSED_RB][FUSED_MAXP + 1];
+    __shared__ int reda[4][FUSED_MAXP];
     __shared__ int is_last;
-    constexpr int IT = 4;
-    const int r = blockIdx.y;
-    const uint4* bsrc = reinterpret_cast<const uint4*>(a.b + (long long)r * a.hw);
-    const long long w0 = (long long)blockIdx.x * (256 * IT) + threadIdx.x;
-    int cnt[2 * FUSED_MAXP + 1];
+    const int chunk = blockIdx.x, grp = blockIdx.y;
+    const long long w = (long long)chunk * 256 + threadIdx.x;
+    const bool ok = w < a.words;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P1 = a.P + 1;
+    unsigned wa[FUSED_MAXP];
 #pragma unroll
-    for (int j = 0; j < 2 * FUSED_MAXP + 1; ++j) cnt[j] = 0;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const long long w = w0 + it * 256;
-        if (w >= a.words) continue;
-        const unsigned wb = pack16(bsrc[2 * w]) | (pack16(bsrc[2 * w + 1]) << 16);
-        cnt[2 * FUSED_MAXP] += __popc(wb);
+    for (int p = 0; p < FUSED_MAXP; ++p) {
+        wa[p] = 0u;
+        if (p < a.P && ok) {
+            const uint4* src = reinterpret_cast<const uint4*>(a.a + (long long)p * a.hw);
+            wa[p] = pack16(src[2 * w]) | (pack16(src[2 * w + 1]) << 16);
+        }
+    }
+    if (grp == 0) {  // |A_p| of this slice, once
 #pragma unroll
         for (int p = 0; p < FUSED_MAXP; ++p) {
-            if (p < a.P) {
-                const uint4* asrc = reinterpret_cast<const uint4*>(a.a + (long long)p * a.hw);
-                const unsigned wa = pack16(asrc[2 * w]) | (pack16(asrc[2 * w + 1]) << 16);
-                cnt[p] += __popc(wa & wb);
-                cnt[FUSED_MAXP + p] += __popc(wa);
+            int c = __popc(wa[p]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == 0) reda[wave][p] = c;
+        }
+    }
+    const int r0 = grp * FUSED_RG, r1 = min(a.R, r0 + FUSED_RG);
+    for (int rb = r0; rb < r1; rb += FUSED_RB) {
+        uint4 lo[FUSED_RB], hi[FUSED_RB];
+#pragma unroll
+        for (int j = 0; j < FUSED_RB; ++j) {
+            const int r = min(rb + j, a.R - 1);
+            const uint4* src = reinterpret_cast<const uint4*>(a.b + (long long)r * a.hw);
+            lo[j] = ok ? src[2 * w] : make_uint4(0u, 0u, 0u, 0u);
+            hi[j] = ok ? src[2 * w + 1] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();  // the previous batch's partials have been consumed
+#pragma unroll
+        for (int j = 0; j < FUSED_RB; ++j) {
+            const unsigned wb = pack16(lo[j]) | (pack16(hi[j]) << 16);
+            int c[FUSED_MAXP + 1];
+#pragma unroll
+            for (int p = 0; p < FUSED_MAXP; ++p) c[p] = __popc(wa[p] & wb);
+            c[FUSED_MAXP] = __popc(wb);
+#pragma unroll
+            for (int q = 0; q < FUSED_MAXP + 1; ++q) {
+                int v = c[q];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) red[wave][j][q] = v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < FUSED_RB * (FUSED_MAXP + 1)) {
+            const int j = threadIdx.x / (FUSED_MAXP + 1), q = threadIdx.x - j * (FUSED_MAXP + 1);
+            const int r = rb + j;
+            if (r < r1 && (q < a.P || q == FUSED_MAXP)) {
+                const unsigned tot = (unsigned)(red[0][j][q] + red[1][j][q] + red[2][j][q] + red[3][j][q]);
+                a.part[((long long)chunk * a.R + r) * P1 + (q == FUSED_MAXP ? a.P : q)] = tot;
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 2 * FUSED_MAXP + 1; ++j) {
-        int c = cnt[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = c;
+    if (grp == 0) {
+        __syncthreads();
+        if (threadIdx.x < a.P)
+            a.part[(long long)a.chunks * a.R * P1 + (long long)chunk * a.P + threadIdx.x] =
+                (unsigned)(reda[0][threadIdx.x] + reda[1][threadIdx.x] + reda[2][threadIdx.x] + reda[3][threadIdx.x]);
     }
-    __syncthreads();
-    unsigned long long* acc = a.acc + (long long)r * (2 * FUSED_MAXP + 1);
-    if (threadIdx.x < 2 * FUSED_MAXP + 1) {
-        const int j = threadIdx.x;
-        const int tot = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-        if (tot) atomicAdd(&acc[j], (unsigned long long)tot);
-    }
+    // ---- the last block folds the partials (release: every thread's stores, then the counter; acquire on the reader's side)
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(&a.done[r], 1u) == (unsigned)(a.chunks - 1);
+    if (threadIdx.x == 0) is_last = atomicAdd(a.done, 1u) == (unsigned)(a.chunks * a.groups - 1);
     __syncthreads();
-    if (is_last && threadIdx.x < a.P) {
-        __threadfence();
-        const int p = threadIdx.x;
-        const long long in = (long long)atomicAdd(&acc[p], 0ull);
-        const long long aa = (long long)atomicAdd(&acc[FUSED_MAXP + p], 0ull);
-        const long long ab = (long long)atomicAdd(&acc[2 * FUSED_MAXP], 0ull);
-        a.inter[(long long)p * a.R + r] = in;
-        a.uni[(long long)p * a.R + r] = aa + ab - in;  // sum(A + B) - inter (seg_utils.py:133-134)
+    if (!is_last) return;
+    __threadfence();
+    const volatile unsigned* part = a.part;
+    for (int i = threadIdx.x; i < a.P * a.R; i += 256) {
+        const int p = i / a.R, r = i - p * a.R;
+        long long in = 0, ab = 0, aa = 0;
+        for (int ch = 0; ch < a.chunks; ++ch) {
+            in += part[((long long)ch * a.R + r) * P1 + p];
+            ab += part[((long long)ch * a.R + r) * P1 + a.P];
+            aa += part[(long long)a.chunks * a.R * P1 + (long long)ch * a.P + p];
+        }
+        a.inter[i] = in;
+        a.uni[i] = aa + ab - in;  // sum(A + B) - inter (seg_utils.py:133-134)
     }
 }
 
 }  // namespace
 
-size_t mask_iou_fused_scratch_bytes(int R) { return (size_t)R * ((2 * FUSED_MAXP + 1) * 8 + 4) + 64; }
+static size_t fused_part_words(int P, int R, int chunks) { return (size_t)chunks * R * (P + 1) + (size_t)chunks * P; }
+size_t mask_iou_fused_scratch_bytes(int P, int R, long long words) {
+    const int chunks = (int)((words + 255) / 256);
+    return 64 + fused_part_words(P, R, chunks) * 4;
+}
 
 int g_iou_fused = 1;  // sola_tune "iou_fused": 0 forces the pack + pair path (A/B, tests)
 void sola_iou_set_fused(int v) { g_iou_fused = v; }
@@ -279,23 +321,25 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
                            long long* uni, void* scratch, size_t scratch_bytes, hipStream_t s, int* status) {
     *status = SOLA_OK;
     const long long hw = (long long)H * W;
-    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || R > 65535 ||
-        (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) || scratch_bytes < mask_iou_fused_scratch_bytes(R))
+    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || R > 16 * 65535 ||
+        (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) ||
+        scratch_bytes < mask_iou_fused_scratch_bytes(P, R, hw / 32))
         return false;
     FusedArgs a;
     a.a = static_cast<const uint8_t*>(am); a.b = static_cast<const uint8_t*>(bm);
     a.hw = hw; a.words = hw / 32; a.P = P; a.R = R;
-    a.chunks = (int)((a.words + 1023) / 1024);
-    a.acc = static_cast<unsigned long long*>(scratch);
-    a.done = reinterpret_cast<unsigned*>(a.acc + (size_t)R * (2 * FUSED_MAXP + 1));
+    a.chunks = (int)((a.words + 255) / 256);
+    a.groups = (R + FUSED_RG - 1) / FUSED_RG;
+    a.done = static_cast<unsigned*>(scratch);
+    a.part = a.done + 16;
     a.inter = inter; a.uni = uni;
-    if (hipMemsetAsync(scratch, 0, mask_iou_fused_scratch_bytes(R), s) != hipSuccess) {
+    if (hipMemsetAsync(scratch, 0, 64, s) != hipSuccess) {
         sola_set_error("mask_iou_matrix: hipMemsetAsync failed");
         *status = SOLA_ERR_HIP;
         return true;
     }
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)(P + R) * hw);
-    hipLaunchKernelGGL(mask_iou_fused_u8_kernel, dim3(a.chunks, R), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mask_iou_fused_u8_kernel, dim3(a.chunks, a.groups), dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) {
         sola_set_error("mask_iou_matrix: fused kernel launch failed");
         *status = SOLA_ERR_HIP;

@@ -330,12 +330,22 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             spans.append((key, off, p.numel(), tuple(p.shape)))
             off += (p.numel() + 63) // 64 * 64
         self._grad_arena = torch.zeros(off, device=dev, dtype=torch.float32)
-        self._grad_views = {key: self._grad_arena[o:o + n].view(shape) for key, o, n, shape in spans}
+        self._grad_spans = {key: (o, n, shape) for key, o, n, shape in spans}
         bounds = [starts[b] for b in range(nb)] + [off]
         self._grad_buckets = [(bounds[b], bounds[b + 1]) for b in range(nb)]
-        for key, g in self._grad_views.items():
-            check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
+        self._bind_grad_arena()
         self._grad_ctx = self._ctx
+
+    def _grad_view(self, key):
+        """A NEW tensor object over the parameter's slot of the arena.  autograd's AccumulateGrad adopts an incoming gradient
+        without copying only if nobody else holds that tensor object, so the views are made per backward and not kept."""
+        o, n, shape = self._grad_spans[key]
+        return self._grad_arena[o:o + n].view(shape)
+
+    def _bind_grad_arena(self):
+        for key in self._grad_spans:
+            g = self._grad_view(key)
+            check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
         self._grad_bound = "arena"
 
     def grad_buckets(self):
@@ -364,10 +374,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             self._grad_bound = "fresh"
         else:
             if self._grad_bound != "arena":
-                for key, g in self._grad_views.items():
-                    check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
-                self._grad_bound = "arena"
-            grads = [self._grad_views[key] for key in named]
+                self._bind_grad_arena()
+            grads = [self._grad_view(key) for key in named]
         nbytes = lib().sola_backward_workspace_bytes(self._ctx, B, N, T, L)
         if self._bwd_ws is None or self._bwd_ws.numel() < nbytes or self._bwd_ws.device != dev:
             self._bwd_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
