@@ -207,23 +207,29 @@ struct FusedArgs {
     const uint8_t *a, *b;
     long long hw, words;
     int P, R, chunks, groups;
-    unsigned* part;   // [chunks][R][P + 1]: inter[p] ..., |B_r| ; then [chunks][P]: |A_p|
-    unsigned* done;   // 1 counter (zeroed by the caller)
+    unsigned* acc;    // [R][5]: inter[p] (p < 4), |B_r| ; then [4]: |A_p|   (zeroed by the caller, with `done`)
+    unsigned* done;   // 1 counter
     long long *inter, *uni;
 };
 constexpr int FUSED_MAXP = 4;
 constexpr int FUSED_RG = 16;  // prompts per block
 constexpr int FUSED_RB = 8;   // prompts in flight
 
+// sum over the 64 lanes of two 16-bit counts packed in one word (each total < 2^16)
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs a) {
-    __shared__ int red[4][FUSED_RB][FUSED_MAXP + 1];
-    __shared__ int reda[4][FUSED_MAXP];
+    __shared__ unsigned red[4][FUSED_RB][3];
+    __shared__ unsigned reda[4][2];
     __shared__ int is_last;
     const int chunk = blockIdx.x, grp = blockIdx.y;
     const long long w = (long long)chunk * 256 + threadIdx.x;
     const bool ok = w < a.words;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int P1 = a.P + 1;
     unsigned wa[FUSED_MAXP];
 #pragma unroll
     for (int p = 0; p < FUSED_MAXP; ++p) {
@@ -234,13 +240,9 @@ __global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs 
         }
     }
     if (grp == 0) {  // |A_p| of this slice, once
-#pragma unroll
-        for (int p = 0; p < FUSED_MAXP; ++p) {
-            int c = __popc(wa[p]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            if (lane == 0) reda[wave][p] = c;
-        }
+        const unsigned s01 = wave_sum_u32(__popc(wa[0]) | (__popc(wa[1]) << 16));
+        const unsigned s23 = wave_sum_u32(__popc(wa[2]) | (__popc(wa[3]) << 16));
+        if (lane == 0) { reda[wave][0] = s01; reda[wave][1] = s23; }
     }
     const int r0 = grp * FUSED_RG, r1 = min(a.R, r0 + FUSED_RG);
     for (int rb = r0; rb < r1; rb += FUSED_RB) {
@@ -252,54 +254,53 @@ __global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs 
             lo[j] = ok ? src[2 * w] : make_uint4(0u, 0u, 0u, 0u);
             hi[j] = ok ? src[2 * w + 1] : make_uint4(0u, 0u, 0u, 0u);
         }
-        __syncthreads();  // the previous batch's partials have been consumed
+        __syncthreads();  // the previous batch's sums have been consumed
 #pragma unroll
         for (int j = 0; j < FUSED_RB; ++j) {
             const unsigned wb = pack16(lo[j]) | (pack16(hi[j]) << 16);
-            int c[FUSED_MAXP + 1];
-#pragma unroll
-            for (int p = 0; p < FUSED_MAXP; ++p) c[p] = __popc(wa[p] & wb);
-            c[FUSED_MAXP] = __popc(wb);
-#pragma unroll
-            for (int q = 0; q < FUSED_MAXP + 1; ++q) {
-                int v = c[q];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (lane == 0) red[wave][j][q] = v;
-            }
+            const unsigned s01 = wave_sum_u32(__popc(wa[0] & wb) | (__popc(wa[1] & wb) << 16));
+            const unsigned s23 = wave_sum_u32(__popc(wa[2] & wb) | (__popc(wa[3] & wb) << 16));
+            const unsigned sb = wave_sum_u32(__popc(wb));
+            if (lane == 0) { red[wave][j][0] = s01; red[wave][j][1] = s23; red[wave][j][2] = sb; }
         }
         __syncthreads();
-        if (threadIdx.x < FUSED_RB * (FUSED_MAXP + 1)) {
-            const int j = threadIdx.x / (FUSED_MAXP + 1), q = threadIdx.x - j * (FUSED_MAXP + 1);
+        if (threadIdx.x < FUSED_RB * 5) {
+            const int j = threadIdx.x / 5, q = threadIdx.x - j * 5;
             const int r = rb + j;
-            if (r < r1 && (q < a.P || q == FUSED_MAXP)) {
-                const unsigned tot = (unsigned)(red[0][j][q] + red[1][j][q] + red[2][j][q] + red[3][j][q]);
-                a.part[((long long)chunk * a.R + r) * P1 + (q == FUSED_MAXP ? a.P : q)] = tot;
+            if (r < r1 && (q < a.P || q == 4)) {
+                unsigned tot = 0;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    const unsigned v = q == 4 ? red[wv][j][2] : red[wv][j][q >> 1];
+                    tot += q == 4 ? v : ((q & 1) ? v >> 16 : v & 0xffffu);
+                }
+                if (tot) atomicAdd(&a.acc[r * 5 + q], tot);
             }
         }
     }
     if (grp == 0) {
         __syncthreads();
-        if (threadIdx.x < a.P)
-            a.part[(long long)a.chunks * a.R * P1 + (long long)chunk * a.P + threadIdx.x] =
-                (unsigned)(reda[0][threadIdx.x] + reda[1][threadIdx.x] + reda[2][threadIdx.x] + reda[3][threadIdx.x]);
+        if (threadIdx.x < a.P) {
+            unsigned tot = 0;
+            for (int wv = 0; wv < 4; ++wv) {
+                const unsigned v = reda[wv][threadIdx.x >> 1];
+                tot += (threadIdx.x & 1) ? v >> 16 : v & 0xffffu;
+            }
+            if (tot) atomicAdd(&a.acc[a.R * 5 + threadIdx.x], tot);
+        }
     }
-    // ---- the last block folds the partials (release: every thread's stores, then the counter; acquire on the reader's side)
+    // ---- the last block to finish writes the matrices (release: the adds above, then the counter; acquire on the other side)
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) is_last = atomicAdd(a.done, 1u) == (unsigned)(a.chunks * a.groups - 1);
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    const volatile unsigned* part = a.part;
     for (int i = threadIdx.x; i < a.P * a.R; i += 256) {
         const int p = i / a.R, r = i - p * a.R;
-        long long in = 0, ab = 0, aa = 0;
-        for (int ch = 0; ch < a.chunks; ++ch) {
-            in += part[((long long)ch * a.R + r) * P1 + p];
-            ab += part[((long long)ch * a.R + r) * P1 + a.P];
-            aa += part[(long long)a.chunks * a.R * P1 + (long long)ch * a.P + p];
-        }
+        const long long in = __hip_atomic_load(&a.acc[r * 5 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long ab = __hip_atomic_load(&a.acc[r * 5 + 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long aa = __hip_atomic_load(&a.acc[a.R * 5 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.inter[i] = in;
         a.uni[i] = aa + ab - in;  // sum(A + B) - inter (seg_utils.py:133-134)
     }
@@ -307,10 +308,9 @@ __global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs 
 
 }  // namespace
 
-static size_t fused_part_words(int P, int R, int chunks) { return (size_t)chunks * R * (P + 1) + (size_t)chunks * P; }
 size_t mask_iou_fused_scratch_bytes(int P, int R, long long words) {
-    const int chunks = (int)((words + 255) / 256);
-    return 64 + fused_part_words(P, R, chunks) * 4;
+    (void)P; (void)words;
+    return 64 + ((size_t)R * 5 + 4) * 4;
 }
 
 int g_iou_fused = 1;  // sola_tune "iou_fused": 0 forces the pack + pair path (A/B, tests)
@@ -321,7 +321,8 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
                            long long* uni, void* scratch, size_t scratch_bytes, hipStream_t s, int* status) {
     *status = SOLA_OK;
     const long long hw = (long long)H * W;
-    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || R > 16 * 65535 ||
+    // masks of up to 2^32 - 1 pixels keep every count inside 32 bits; a 256-word slice keeps the packed wave sums inside 16
+    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || hw > 0xffffffffll || R > 16 * 65535 ||
         (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) ||
         scratch_bytes < mask_iou_fused_scratch_bytes(P, R, hw / 32))
         return false;
@@ -331,9 +332,9 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
     a.chunks = (int)((a.words + 255) / 256);
     a.groups = (R + FUSED_RG - 1) / FUSED_RG;
     a.done = static_cast<unsigned*>(scratch);
-    a.part = a.done + 16;
+    a.acc = a.done + 16;
     a.inter = inter; a.uni = uni;
-    if (hipMemsetAsync(scratch, 0, 64, s) != hipSuccess) {
+    if (hipMemsetAsync(scratch, 0, mask_iou_fused_scratch_bytes(P, R, a.words), s) != hipSuccess) {
         sola_set_error("mask_iou_matrix: hipMemsetAsync failed");
         *status = SOLA_ERR_HIP;
         return true;

@@ -122,8 +122,14 @@ def allreduce_gradient_arena(module, world=None, average=True, overlap=True):
                     flat.div_(world)
     if overlap:
         main.wait_stream(side)
+    # A parameter that also receives gradient from outside the network - negative_token.weight feeds the alignment loss
+    # directly (train.py:92) - gets the SUM of both paths from autograd in a tensor of its own, not in its arena slot:
+    # those few (128 KB) take a plain all-reduce on the caller's stream.
+    stragglers = [p for key, p in module.named_parameters()
+                  if p.grad is not None and p.grad.data_ptr() != module._grad_view(key).data_ptr()]
+    n_extra = allreduce_gradients(stragglers, world, average=average) if stragglers else 0
     module._last_grad_sq = None  # (the in-place collective also bumped the arena's version counter, which every view shares)
-    return len(buckets)
+    return len(buckets) + n_extra
 
 
 def gather_scores(local, rank, world):

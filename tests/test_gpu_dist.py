@@ -59,10 +59,12 @@ def _worker(rank, world, port, q, overlap):
         inp = synth.make_inputs(cfg, 2, 6, 16, 5, seed=10 * step + rank)  # every rank its own samples
         opt.zero_grad(set_to_none=True)
         _loss(m, inp).backward()
-        # autograd adopted the arena views without a copy: every p.grad lives in the arena
-        assert m._grads_in_arena and all(p.grad.data_ptr() == m._grad_view(k).data_ptr() for k, p in m.named_parameters())
+        # autograd adopted the arena views without a copy: every p.grad lives in the arena, except the negative tokens', which
+        # autograd sums with the alignment loss's direct contribution into a tensor of its own
+        outside = [k for k, p in m.named_parameters() if p.grad.data_ptr() != m._grad_view(k).data_ptr()]
+        assert m._grads_in_arena and outside == ["negative_token.weight"], outside
         n = sdist.allreduce_gradient_arena(m, world, overlap=overlap)
-        assert n == cfg["n_layers"] + 1
+        assert n == cfg["n_layers"] + 2  # the arena's buckets + one small collective for the straggler
         gnd = m.get_grad_norm_dict()
         m.clip_grad_norm_(0.5 * gnd["total_grad_norm"])  # always clips: the clip factor must be identical on both ranks
         opt.step()
