@@ -355,6 +355,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "train_split_min_rows": precision 1 in training takes the split-f16 GEMMs from this many token rows (B*N*T') on, default 1024
  * (below that the step is launch-bound and the cast launches cost more than the GEMMs gain); tests set 0;
  * "gemm_ablate": measurement only, 4 = no epilogue (results are then WRONG);
+ * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for
+ * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
  * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
  * "attn_target_blocks").  Except under gemm_ablate, results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);

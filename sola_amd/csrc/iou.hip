@@ -322,7 +322,11 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
     *status = SOLA_OK;
     const long long hw = (long long)H * W;
     // masks of up to 2^32 - 1 pixels keep every count inside 32 bits; a 256-word slice keeps the packed wave sums inside 16
-    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || hw > 0xffffffffll || R > 16 * 65535 ||
+    // Measured (tools/iou_probe.py, P=4, 540x960): R=16 18.6 us per call fused vs 25.3 us pack + pair; R=64 30.6 vs 25.8; R=256
+    // 125 vs 40 (the per-block wave reductions grow with R while the pack + pair path amortises its launches): fused up to
+    // 32 prompts (g_iou_fused == 2 forces it for any R: tests).
+    if (!g_iou_fused || (R > 32 && g_iou_fused != 2) || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 ||
+        hw > 0xffffffffll || R > 16 * 65535 ||
         (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) ||
         scratch_bytes < mask_iou_fused_scratch_bytes(P, R, hw / 32))
         return false;
