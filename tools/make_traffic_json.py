@@ -2,7 +2,7 @@
 """profiles/<tag>_summary.md (profiles/summarize_rocprof.py output) -> profiles/r01_traffic.json: HBM bytes per launch
 (FETCH_SIZE x2 + WRITE_SIZE) and rocprofv3 average duration per kernel, plus the name of the GEMM instantiation that
 takes the largest share of the step.  bench.py reads it for the `traffic` field when its batch matches.
-usage: make_traffic_json.py profiles/r01_glds_b256_summary.md 256"""
+usage: make_traffic_json.py profiles/r02_summary.md 256 [profiles/r02_traffic.json]"""
 import json, sys
 rows, share = {}, {}
 for line in open(sys.argv[1]):
@@ -24,5 +24,5 @@ out = {"source": f"{sys.argv[1]}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZ
                  f"--cpu-seconds 0` (batch {sys.argv[2]}); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B "
                  "request), WRITE_SIZE raw; bytes per launch, mean over the launches of the kernel",
        "batch": int(sys.argv[2]), "dominant_gemm": "gemm_split256 (all 256x256 launches)" if p256 else (max(gemms, key=lambda k: share[k]) if gemms else None), "kernels": rows}
-json.dump(out, open("profiles/r01_traffic.json", "w"), indent=1)
+json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_traffic.json", "w"), indent=1)
 print(out["dominant_gemm"], rows.get(out["dominant_gemm"]))
