@@ -76,6 +76,12 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  *   1  split-f16: every operand value x is carried as (f16 hi, f16 lo) with hi + lo = x to 22 bits, in the same 4 bytes,
  *      and each product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation - 3/16 of the f32
  *      matrix-pipe time (gfx950 has no xf32/TF32).  Softmax, GroupNorm statistics, score head and losses stay f32.
+ *   2  16-bit activation STORAGE (sola_forward only; BASELINE configs C2 / C4 name bf16 / fp16 runs of this path): every
+ *      activation between two kernels is a plain f16 (2 bytes per element), every product of the convs / projections /
+ *      attention ONE f16 MFMA with f32 accumulation; softmax, GroupNorm statistics, biases, score head, losses stay f32.
+ *      f16 rather than bf16: 11 significant bits for the same bytes, its range covered by the scales + guard below.  A
+ *      reduced-precision mode (logits within ~3e-2 at magnitude 10), never the default; needs object_token_dim and
+ *      lang_token_dim %% 64 == 0.  sola_forward_train / sola_forward_ragged run exact f32 under it.
  * In training (sola_forward_train / sola_backward) precision 1 runs every GEMM of the step (forward, dX and dW of the
  * projections and convs) on split-f16 casts of the f32 activations / gradients, from 1024 token rows on; attention and
  * GroupNorm backward and everything saved for the backward stay f32. */
@@ -110,6 +116,17 @@ int sola_gemm_nt_split(const float* dev_a_sp, int lda, const float* dev_w_sp, co
 int sola_gemm_nt_split_scaled(const float* dev_a_sp, int lda, const float* dev_w_sp, const float* dev_bias, const float* dev_r,
                               int ldr, int r_is_split, float* dev_c, int ldc, int c_is_split, int M, int N, int K,
                               float out_scale, const float* dev_out_scale, void* stream);
+
+/* Building blocks of precision 2 (16-bit activation storage), exposed for the parity tests: f32 rows -> _Float16 rows (fixed
+ * power-of-two scale, or data-dependent with dev_scal as for sola_cast_sp16_auto); C = out_scale * (A W^T) + bias (+ R) on
+ * _Float16 A [M,K] / W [N,K] / R with f32 accumulation, C written as _Float16 or f32 (K %% 64 == 0, lda %% 16 == 0; pitches in
+ * elements); softmax(q k^T scale) v on _Float16 q / k / v / o with the addressing of sola_attention. */
+int sola_cast_f16(const float* dev_in, int ld_in, void* dev_out, int ld_out, int64_t rows, int K, float scale, float* dev_scal, void* stream);
+int sola_gemm_nt_f16(const void* dev_a_h, int lda, const void* dev_w_h, const float* dev_bias, const void* dev_r_h, int ldr,
+                     void* dev_c, int ldc, int c_is_f16, int M, int N, int K, float out_scale, void* stream);
+int sola_attention_f16(const void* dev_q, int ldq, const void* dev_k, int ldk, const void* dev_v, int ldv, void* dev_o, int ldo,
+                       int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
+                       int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, void* stream);
 
 /* ---- forward: replaces LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162) ------------------ */
 size_t sola_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);

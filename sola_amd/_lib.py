@@ -65,6 +65,9 @@ SIGNATURES = {
     "sola_gemm_nt_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "sola_cast_sp16_auto": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp]),
     "sola_gemm_nt_split_scaled": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "sola_cast_f16": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp, _vp]),
+    "sola_gemm_nt_f16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "sola_attention_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "sola_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sola_ragged_workspace_bytes": (_sz, [_vp, C.POINTER(SolaRaggedBatch)]),

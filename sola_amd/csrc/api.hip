@@ -314,8 +314,8 @@ extern "C" int sola_workspace_tap(const SolaCtx* c, const char* name, size_t* of
 }
 
 extern "C" int sola_set_precision(SolaCtx* c, int precision) {
-    SOLA_ARG(c && (precision == 0 || precision == 1), "set_precision: 0 (f32) or 1 (split-f16)");
-    if (precision == 1 && !c->lin16_buf) {
+    SOLA_ARG(c && precision >= 0 && precision <= 2, "set_precision: 0 (f32), 1 (split-f16) or 2 (f16 storage)");
+    if (precision >= 1 && !c->lin16_buf) {
         const size_t D = c->cfg.lang_token_dim;
         size_t ws_total = 0;
         for (int i = 0; i < 6; ++i) ws_total += (size_t)c->conv[i].cout * c->conv[i].cin * c->conv[i].k;
@@ -351,6 +351,30 @@ extern "C" int sola_gemm_nt_split(const float* a_sp, int lda, const float* w_sp,
     return launch_gemm(gd, as_stream(stream_));
 }
 
+// ---- 16-bit storage mode building blocks (tests) ----------------------------------------------------------------
+int launch_attention_f16(const AttnDesc& d, hipStream_t s);
+extern "C" int sola_cast_f16(const float* in, int ld_in, void* out, int ld_out, int64_t rows, int K, float scale, float* dev_scal, void* stream_) {
+    return launch_cast_f16(in, ld_in, out, ld_out, rows, K, scale, dev_scal, as_stream(stream_));
+}
+extern "C" int sola_gemm_nt_f16(const void* a_h, int lda, const void* w_h, const float* bias, const void* r_h, int ldr, void* cmat, int ldc,
+                                int c_is_f16, int M, int N, int K, float out_scale, void* stream_) {
+    SOLA_ARG(a_h && w_h && cmat, "gemm_nt_f16: null argument");
+    GemmDesc gd{};
+    gd.nprob = 1;
+    gd.p[0] = GemmProblem{static_cast<const float*>(a_h), static_cast<const float*>(w_h), bias, static_cast<const float*>(r_h), static_cast<float*>(cmat)};
+    gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
+    gd.arith = 2; gd.out_scale = out_scale; gd.r_f16 = r_h ? 1 : 0; gd.c_f16 = c_is_f16;
+    return launch_gemm(gd, as_stream(stream_));
+}
+extern "C" int sola_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int G, int H,
+                                  int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_rs,
+                                  int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, void* stream_) {
+    SOLA_ARG(q && k && v && o, "attention_f16: null argument");
+    AttnDesc d{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(o), ldq, ldk, ldv, ldo,
+               G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, nullptr};
+    return launch_attention_f16(d, as_stream(stream_));
+}
+
 extern "C" int sola_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int K, float* scal, void* stream_) {
     return launch_cast_sp16_auto(in, ld_in, out, ld_out, rows, K, scal, as_stream(stream_));
 }
@@ -383,8 +407,10 @@ int sola_split_guard_tripped(SolaCtx* c, hipStream_t s, bool* tripped) {
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
-    if (c && c->precision == 1) {
-        SOLA_TRY(sola_forward_fast_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s));
+    if (c && c->precision >= 1) {
+        const int prec = c->precision;
+        if (prec == 2) SOLA_TRY(sola_forward_f16_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s));
+        else SOLA_TRY(sola_forward_fast_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s));
         bool tripped = false;
         SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
         if (!tripped) return SOLA_OK;
@@ -393,7 +419,7 @@ extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int
         c->split_fallbacks += 1;
         c->precision = 0;
         const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
-        c->precision = 1;
+        c->precision = prec;
         return st;
     }
     return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);

@@ -1,0 +1,245 @@
+// Attention core of the 16-bit storage mode (sola_set_precision(ctx, 2)): q, k, v and the output are plain _Float16
+// matrices (2 bytes per element: half the HBM traffic of the f32 / split-f16 kernels of attn.hip, which this kernel is
+// otherwise a restatement of), products run on v_mfma_f32_16x16x16_f16 with f32 accumulation, softmax in f32.
+//
+// Same single [B, N, T', D] layout and the same (outer, inner, row) / unit-table addressing as attn.hip.  One wave owns a
+// 16-query tile:
+//   S^T = K Q^T : A = K rows (one 8-byte LDS read per 16-wide head-dim chunk), B = Q (registers); lane (c16, g4) ends with
+//                 the scores of query c16 against keys 4*g4 + {0..3} of the tile: a softmax row lives in one 16-lane column;
+//   O^T = V^T P^T: A = V^T (four 2-byte LDS reads down a column of the row-major tile), B = P straight from the score
+//                 registers; lane ends with o[q = c16][16c + 4*g4 + {0..3}]: one 8-byte store per chunk.
+// K/V tiles are 64 keys x head_dim halfs (pitch + 8 halfs: conflict-free for both read patterns on the 64-bank LDS), 34 KB
+// per block at head_dim 128, so four 4-wave blocks share a CU and cover each other's memory latency; longer key sequences
+// take further tiles with an online softmax.  Sequences of at most 16 steps (motion attention over T') use one wave per
+// (group, head) unit with a private 16-row tile, four units per block, no block-level synchronisation.
+#include "kernels.h"
+
+namespace {
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+
+struct AttnHArgs {
+    const _Float16 *q, *k, *v;
+    _Float16* o;
+    int ldq, ldk, ldv, ldo;  // halfs
+    int G, H, Sq, Sk, inner, nqb;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+    int* guard;
+    const int4 *q_units, *k_units;
+};
+
+struct GeoH { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
+__device__ __forceinline__ GeoH geo_h(const AttnHArgs& a, int grp) {
+    GeoH g;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        g.q0 = __builtin_amdgcn_readfirstlane(qu.x); g.q_rs = __builtin_amdgcn_readfirstlane(qu.y); g.Sq = __builtin_amdgcn_readfirstlane(qu.z);
+        g.k0 = __builtin_amdgcn_readfirstlane(ku.x); g.k_rs = __builtin_amdgcn_readfirstlane(ku.y); g.Sk = __builtin_amdgcn_readfirstlane(ku.z);
+    } else {
+        g.q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        g.k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        g.q_rs = a.q_rs; g.k_rs = a.k_rs; g.Sq = a.Sq; g.Sk = a.Sk;
+    }
+    return g;
+}
+
+// WPU = wave per unit (sequences of <= 16 steps): the block's four waves serve four different (group, head) units
+template <int DH, bool WPU>
+__global__ __launch_bounds__(256) void attn_fwd_f16_kernel(const AttnHArgs a) {
+    constexpr int NC = DH / 16;        // 16-wide head-dim chunks
+    constexpr int LD = DH + 8;         // tile pitch in halfs
+    constexpr int H8 = DH / 8;         // 16-byte pieces per row
+    constexpr int TROWS = WPU ? 16 : 64;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+
+    long long unit;
+    int qb = 0;
+    if (WPU) {
+        unit = (long long)blockIdx.x * 4 + wave;
+        if (unit >= (long long)a.G * a.H) return;  // whole waves leave; this mode has no block-level sync
+    } else {
+        unit = blockIdx.x / a.nqb;
+        qb = blockIdx.x - (int)unit * a.nqb;
+    }
+    const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
+    const GeoH g = geo_h(a, grp);
+    _Float16* Ks = smem_h + (WPU ? wave * 2 * TROWS * LD : 0);
+    _Float16* Vs = Ks + TROWS * LD;
+
+    const int qi = qb * 64 + (WPU ? 0 : wave * 16) + c16;
+    const bool q_ok = qi < g.Sq;
+    if (!WPU && qb * 64 >= g.Sq) return;  // ragged: this unit has fewer q-blocks than the largest one (block-uniform)
+    // Q fragment: d = 16c + 4*g4 .. +3
+    half4v qf[NC];
+    {
+        const _Float16* qp = a.q + (g.q0 + (long long)qi * g.q_rs) * a.ldq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (q_ok) qf[c] = *reinterpret_cast<const half4v*>(qp + c * 16);
+            else qf[c] = half4v{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+        }
+    }
+    f32x4 oacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt0 = 0; kt0 < g.Sk; kt0 += TROWS) {
+        const int nrows = min(TROWS, g.Sk - kt0);
+        const int nrows16 = (nrows + 15) & ~15;
+        if (!WPU && kt0 > 0) __syncthreads();  // the previous tile has been consumed by every wave
+        // stage K and V rows (16 bytes per lane), rows past the sequence zero-filled
+        {
+            const int nthr = WPU ? 64 : 256, t0 = WPU ? lane : tid;
+            for (int idx = t0; idx < nrows16 * H8; idx += nthr) {
+                const int r = idx / H8, c8 = idx - r * H8;
+                half8v kv, vv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kv[j] = (_Float16)0; vv[j] = (_Float16)0; }
+                if (r < nrows) {
+                    const long long row = g.k0 + (long long)(kt0 + r) * g.k_rs;
+                    kv = *reinterpret_cast<const half8v*>(a.k + row * a.ldk + h * DH + c8 * 8);
+                    vv = *reinterpret_cast<const half8v*>(a.v + row * a.ldv + h * DH + c8 * 8);
+                }
+                *reinterpret_cast<half8v*>(&Ks[r * LD + c8 * 8]) = kv;
+                *reinterpret_cast<half8v*>(&Vs[r * LD + c8 * 8]) = vv;
+            }
+        }
+        if (WPU) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+        const int ntile = nrows16 >> 4;
+        f32x4 sc[TROWS / 16];
+#pragma unroll
+        for (int t = 0; t < TROWS / 16; ++t) {
+            if (t < ntile) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const _Float16* kp = &Ks[(t * 16 + c16) * LD + 4 * g4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const half4v kf = *reinterpret_cast<const half4v*>(kp + c * 16);
+                    if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc0, 0, 0, 0);
+                }
+                const int key0 = kt0 + t * 16 + 4 * g4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < g.Sk) ? (acc0[r] + acc1[r]) * a.scale : -INFINITY;
+            } else {
+                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        // online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TROWS / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < TROWS / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[t][r] = __expf(sc[t][r] - m_new);
+                rs += sc[t][r];
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+        // O^T += V^T P^T
+#pragma unroll
+        for (int t = 0; t < TROWS / 16; ++t) {
+            if (t < ntile) {
+                half4v pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pf[r] = (_Float16)sc[t][r];
+                const _Float16* vp = &Vs[(t * 16 + 4 * g4) * LD + c16];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    half4v vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vf[j] = vp[j * LD + c * 16];
+                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, oacc[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (q_ok) {
+        const float inv = 1.f / l_run;
+        _Float16* op = a.o + (g.q0 + (long long)qi * g.q_rs) * a.ldo + h * DH + 4 * g4;
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            half4v o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = oacc[c][j] * inv;
+                o4[j] = (_Float16)v;
+                m = fmaxf(m, fabsf(v));
+            }
+            *reinterpret_cast<half4v*>(op + c * 16) = o4;
+        }
+        if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+    }
+}
+
+template <int DH>
+int launch_h(const AttnHArgs& a0, hipStream_t s) {
+    AttnHArgs a = a0;
+    constexpr int LD = DH + 8;
+    const long long units = (long long)a.G * a.H;
+    if (a.Sq <= 16 && a.Sk <= 16) {
+        a.nqb = 1;
+        const size_t lds = (size_t)4 * 2 * 16 * LD * sizeof(_Float16);
+        hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
+    } else {
+        a.nqb = (a.Sq + 63) / 64;
+        SOLA_ARG(units * a.nqb < (1ll << 31), "attention (f16): grid too large");
+        const size_t lds = (size_t)2 * 64 * LD * sizeof(_Float16);
+        hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, false>), dim3((unsigned)(units * a.nqb)), dim3(256), lds, s, a);
+    }
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+}  // namespace
+
+// AttnDesc with q / k / v / o pointing at _Float16 matrices and ld* counting halfs
+int launch_attention_f16(const AttnDesc& d, hipStream_t s) {
+    SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention (f16): bad sizes");
+    SOLA_ARG(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 4 == 0, "attention (f16): row pitches must be multiples of 8 halfs");
+    SOLA_ARG(!d.lse && !d.drop.enabled, "attention (f16): inference only (no log-sum-exp output, no dropout)");
+    AttnHArgs a;
+    a.q = reinterpret_cast<const _Float16*>(d.q); a.k = reinterpret_cast<const _Float16*>(d.k);
+    a.v = reinterpret_cast<const _Float16*>(d.v); a.o = reinterpret_cast<_Float16*>(d.o);
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale; a.guard = d.guard;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 2.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    switch (d.DH) {
+        case 128: return launch_h<128>(a, s);
+        case 64: return launch_h<64>(a, s);
+        case 32: return launch_h<32>(a, s);
+        case 16: return launch_h<16>(a, s);
+        default: sola_set_error("attention (f16): head_dim %d unsupported (16/32/64/128)", d.DH); return SOLA_ERR_ARG;
+    }
+}

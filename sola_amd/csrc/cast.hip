@@ -146,6 +146,43 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_multi_kernel(const MultiAr
     }
 }
 
+// ---- f32 -> plain f16 rows (the 16-bit storage mode): 8 values per thread, 16-byte stores --------------------------------
+// SCALED: the power-of-two scale comes from the amax slot (cast_sp16_auto_kernel's rule), else from the argument
+template <bool SCALED>
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long rows,
+                                                       int blocks_per_row, int ld_in, int ld_out, float scale_arg, float* __restrict__ scal) {
+    float scale = scale_arg;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (SCALED) {
+        scale = auto_scale(reinterpret_cast<const unsigned*>(scal)[0]);
+        if (i == 0) scal[1] = 1.f / scale;
+    }
+    if (i >= rows * blocks_per_row) return;
+    const long long r = i / blocks_per_row;
+    const int b = (int)(i - r * blocks_per_row);
+    const float4 v0 = *reinterpret_cast<const float4*>(in + r * ld_in + b * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(in + r * ld_in + b * 8 + 4);
+    half8 h;
+    h[0] = (_Float16)(v0.x * scale); h[1] = (_Float16)(v0.y * scale); h[2] = (_Float16)(v0.z * scale); h[3] = (_Float16)(v0.w * scale);
+    h[4] = (_Float16)(v1.x * scale); h[5] = (_Float16)(v1.y * scale); h[6] = (_Float16)(v1.z * scale); h[7] = (_Float16)(v1.w * scale);
+    *reinterpret_cast<half8*>(out + r * ld_out + b * 8) = h;
+}
+__global__ __launch_bounds__(256) void cast_f16_auto_multi_kernel(const MultiArgs a, float* __restrict__ scal, long long n8) {
+    const float* in = a.in[blockIdx.z];
+    _Float16* out = reinterpret_cast<_Float16*>(a.out[blockIdx.z]);
+    float* sc = scal + 2 * blockIdx.z;
+    const float scale = auto_scale(reinterpret_cast<const unsigned*>(sc)[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[1] = 1.f / scale;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const float4 v0 = *reinterpret_cast<const float4*>(in + i * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(in + i * 8 + 4);
+        half8 h;
+        h[0] = (_Float16)(v0.x * scale); h[1] = (_Float16)(v0.y * scale); h[2] = (_Float16)(v0.z * scale); h[3] = (_Float16)(v0.w * scale);
+        h[4] = (_Float16)(v1.x * scale); h[5] = (_Float16)(v1.y * scale); h[6] = (_Float16)(v1.z * scale); h[7] = (_Float16)(v1.w * scale);
+        *reinterpret_cast<half8*>(out + i * 8) = h;
+    }
+}
+
 // one block per GroupNorm: rms over the channels of sqrt(gamma^2 + beta^2) = the rms of that norm's output
 constexpr int NORM_MAX = 32;
 struct NormArgs {
@@ -176,6 +213,41 @@ int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n
         hipLaunchKernelGGL(amax_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, reinterpret_cast<unsigned*>(scal + 2 * i0), elems / 4);
         SOLA_LAUNCH_CHECK();
         hipLaunchKernelGGL(cast_sp16_auto_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, scal + 2 * i0, elems / 8);
+        SOLA_LAUNCH_CHECK();
+    }
+    return SOLA_OK;
+}
+
+int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_f16: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
+    const long long n = rows * (K / 8);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (scal ? 10.0 : 6.0) * rows * K);
+    if (scal) {
+        SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
+                           reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
+        SOLA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, 1.f, scal);
+    } else {
+        hipLaunchKernelGGL(cast_f16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, scale, nullptr);
+    }
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && scal && n > 0 && rows > 0 && K > 0 && K % 8 == 0, "cast_f16_auto_multi: n=%d rows=%d K=%d", n, rows, K);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 10.0 * n * rows * K);
+    SOLA_HIP(hipMemsetAsync(scal, 0, (size_t)2 * n * sizeof(float), s));
+    const long long elems = (long long)rows * K;
+    const unsigned blocks = (unsigned)std::min<long long>(1024, (elems / 8 + 255) / 256);
+    for (int i0 = 0; i0 < n; i0 += MULTI_MAX) {
+        const int nn = std::min(MULTI_MAX, n - i0);
+        MultiArgs a;
+        for (int i = 0; i < MULTI_MAX; ++i) { a.in[i] = i < nn ? in[i0 + i] : nullptr; a.out[i] = i < nn ? static_cast<float*>(out[i0 + i]) : nullptr; }
+        hipLaunchKernelGGL(amax_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, reinterpret_cast<unsigned*>(scal + 2 * i0), elems / 4);
+        SOLA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cast_f16_auto_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, scal + 2 * i0, elems / 8);
         SOLA_LAUNCH_CHECK();
     }
     return SOLA_OK;

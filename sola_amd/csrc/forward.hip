@@ -33,7 +33,7 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
     p.add("pe", p.Tp, D);
     p.add("lang", (int64_t)B * p.W, D);
     p.add("lbar", B, D);
-    if (!train && c->precision == 1) {  // split-f16 copies of the three f32-born GEMM inputs (forward_fast.hip)
+    if (!train && c->precision >= 1) {  // split-f16 (or f16) copies of the three f32-born GEMM inputs (forward_fast.hip, forward_f16.hip)
         p.add("obj_sp", R * T, c->cfg.object_token_dim);
         p.add("conv5_sp", p.M, D);
         p.add("lang_sp", (int64_t)B * p.W, D);

@@ -37,7 +37,13 @@ int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
                 in.push_back(w);
                 out.push_back(c->lin16_buf + ((size_t)(l * 3 + a) * 4 + j) * D * D);
             }
-    SOLA_TRY(launch_cast_sp16_auto_multi(in.data(), out.data(), (int)in.size(), D, D, c->scal_pair(2), s));
+    if (c->precision == 2) {  // 16-bit storage mode: plain f16 copies (same per-matrix scales), packed in the first half of the buffer
+        std::vector<void*> outh;
+        for (size_t i = 0; i < out.size(); ++i) outh.push_back(reinterpret_cast<_Float16*>(c->lin16_buf) + i * (size_t)D * D);
+        SOLA_TRY(launch_cast_f16_auto_multi(in.data(), outh.data(), (int)in.size(), D, D, c->scal_pair(2), s));
+    } else {
+        SOLA_TRY(launch_cast_sp16_auto_multi(in.data(), out.data(), (int)in.size(), D, D, c->scal_pair(2), s));
+    }
     std::vector<NormPair> norms;
     for (int i = 0; i < 5; ++i) {
         const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);

@@ -427,6 +427,14 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
+    if (d.arith == 2) {  // plain f16 operands: direct-to-LDS kernels for every grid size
+        SOLA_ARG(gemm_split_glds_supported(d) && d.ksplit <= 1, "f16 gemm: K %% 64, row pitch %% 16 (Cin %% 64 for convs) required; K=%d lda=%d Cin=%d", d.K, d.lda, d.Cin);
+        SOLA_ARG(!d.c_f16 || (d.N % 4 == 0 && d.ldc % 4 == 0), "f16 gemm: f16 output needs N %% 4 == 0 and ldc %% 4 == 0");
+        SOLA_ARG(!d.p[0].R || !d.r_f16 || d.ldr % 4 == 0, "f16 gemm: f16 residual needs ldr %% 4 == 0");
+        SolaProfScope prof(gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
+                           2.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
+        return launch_gemm_split_glds(d, s);
+    }
     const bool glds = d.arith == 1 && (big || g_gemm_glds_force || d.ksplit > 1) && g_gemm_glds && gemm_split_glds_supported(d);
     const int cat = d.arith == 1 ? (glds && gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT)
                                  : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL);

@@ -44,6 +44,7 @@ struct GldsArgs {
     float out_scale;
     const float* out_scale_dev;
     int r_sp16, c_sp16;
+    int r_f16, c_f16;  // PURE kernels: residual / output stored as _Float16 (ldr / ldc in halfs)
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
     int* guard;  // c_sp16: range guard word (GemmDesc::guard), null = unchecked
 };
@@ -71,7 +72,11 @@ __device__ __forceinline__ int conv_tap_bits(int t0, int T_in) {
     return bits;
 }
 
-template <int MI, int WAVES_M, int WAVES_N, bool CONV>
+// PURE = plain f16 operands (GemmDesc::arith 2): the same 128-byte tile rows now hold 64 consecutive halfs instead of 32
+// (hi, lo) pairs, so nothing about the DMA, the swizzle or the fragment reads changes - a "hi" chunk is simply halfs
+// 16j..16j+7 of the row and the "lo" chunk halfs 16j+8..16j+15 - and a product is hi*hi + lo*lo (two consecutive k-chunks,
+// the same permutation of k on both operands) instead of lo*hi + hi*lo + hi*hi: a third of the MFMAs for twice the k.
+template <int MI, int WAVES_M, int WAVES_N, bool CONV, bool PURE = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_kernel(const GldsArgs a) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     constexpr int STAGES = 2;
@@ -204,9 +209,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                if constexpr (PURE) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                }
             }
     };
 
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     Frags f0, f1;
     load_frags(lds, 0, f0);
     issue(1);
-    constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;  // fragment reads and MFMAs of one half
+    constexpr int NRD = 2 * MI + 4, NMF = (PURE ? 4 : 6) * MI;  // fragment reads and MFMAs of one half
     constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;  // one DMA piece behind every DMA_GAP MFMAs of the second half
     for (int kt = 0; kt < nk; ++kt) {
         // Each half = one MFMA batch with the NEXT half's fragment reads issued right behind its first MFMA.  The compiler
@@ -293,7 +303,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
             if (m >= a.M) continue;
             float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
             if (pr.R) {
-                if (a.r_sp16) {
+                if (a.r_f16) {
+                    const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) v[e] += (float)rb[e];
+                } else if (a.r_sp16) {
                     // 4 consecutive columns sit in one 8-wide block: hi[4] and lo[4] are two aligned 8-byte loads
                     const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
                     if (n + 3 < a.N) {
@@ -314,7 +329,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
                         if (n + e < a.N) v[e] += pr.R[(long long)m * a.ldr + n + e];
                 }
             }
-            if (a.c_sp16) {
+            if (a.c_f16) {
+                if (n >= a.N) continue;  // N % 4 == 0: the four columns are in range together
+                half4 hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * a.ldc + n) = hh;
+                guard_sp16x4(a.guard, v);
+            } else if (a.c_sp16) {
                 if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
                 // 4 consecutive columns of one 8-wide block: hi[4] and lo[4] leave as two aligned 8-byte stores
                 _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
@@ -355,7 +377,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 // RMODE: 0 = no residual, 1 = f32 residual, 2 = split-f16 residual; CSP: the output is written as split-f16 pairs.  They are
 // compile-time so that the epilogue is straight-line code (with run-time flags the residual registers of the fast path
 // flow through phi nodes the register allocator keeps - and spills - across the whole tile loop).
-template <bool CONV, int RMODE, bool CSP>
+// PURE (see above): RMODE 3 = f16 residual, CSP = 2 writes C as plain f16.
+template <bool CONV, int RMODE, int CSP, bool PURE = false>
 __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
     constexpr int MI = 4, WAVES_N = 4, GBM = 256, GBN = 256, NWAVE = 8;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
@@ -492,9 +515,14 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                if constexpr (PURE) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                }
             }
     };
 
@@ -507,7 +535,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");  // k-tile 0 is the older half of what is in flight
     __syncthreads();
     int stage = 0;
-    constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;
+    constexpr int NRD = 2 * MI + 4, NMF = (PURE ? 4 : 6) * MI;
     constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
     for (; tile < total; tile += gridDim.x) {
         int z, ks, m0, n0;
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
             // epilogue's stores: naming the store count (32 float4 or 64 half4 stores per wave; the counter is in order)
             // waits for the DMA without waiting for the stores to be acknowledged.
             if (decltype(first)::value && prev_fast) {
-                if (CSP) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                if (CSP == 1) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -618,7 +646,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     for (int sp = 0; sp < RB * 4; ++sp) {
                         const int st = b * RB + (sp >> 2), pass = sp & 3;  // strip 0..7 = (i, hf)
                         const int m = m0 + wr_e * 128 + (st >> 1) * 32 + (st & 1) * 16 + pass * 4 + rsub;
-                        if (RMODE == 2) {
+                        if (RMODE == 3) {  // four halfs = 8 bytes
+                            const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n);
+                            rbuf[sp] = f32x4{h.x, h.y, 0.f, 0.f};
+                        } else if (RMODE == 2) {
                             const char* rb = reinterpret_cast<const char*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4) * 2;
                             const float2 h = *reinterpret_cast<const float2*>(rb), l = *reinterpret_cast<const float2*>(rb + 16);
                             rbuf[sp] = f32x4{h.x, h.y, l.x, l.y};
@@ -649,7 +680,11 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                         float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
                         if (RMODE) {
                             const f32x4 rv = rbuf[sl * 4 + pass];
-                            if (RMODE == 2) {
+                            if (RMODE == 3) {
+                                const half4 hh = __builtin_bit_cast(half4, float2{rv[0], rv[1]});
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)hh[e];
+                            } else if (RMODE == 2) {
                                 const half4 hh = __builtin_bit_cast(half4, float2{rv[0], rv[1]}), ll = __builtin_bit_cast(half4, float2{rv[2], rv[3]});
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += (float)hh[e] + (float)ll[e];
@@ -658,7 +693,13 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                                 for (int e = 0; e < 4; ++e) v[e] += rv[e];
                             }
                         }
-                        if (CSP) {
+                        if (CSP == 2) {
+                            half4 hh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+                            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = hh;
+                            guard_sp16x4(a.guard, v);
+                        } else if (CSP == 1) {
                             _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                             half4 hh, ll;
 #pragma unroll
@@ -701,7 +742,12 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     if (m >= a.M) continue;
                     float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
                     if (RMODE) {
-                        if (RMODE == 2) {
+                        if (RMODE == 3) {
+                            const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < a.N) v[e] += (float)rb[e];
+                        } else if (RMODE == 2) {
                             const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
                             if (n + 3 < a.N) {
                                 const half4 hh = *reinterpret_cast<const half4*>(rb), ll = *reinterpret_cast<const half4*>(rb + 8);
@@ -721,7 +767,14 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                                 if (n + e < a.N) v[e] += pr.R[(long long)m * a.ldr + n + e];
                         }
                     }
-                    if (CSP) {
+                    if (CSP == 2) {
+                        if (n >= a.N) continue;  // N % 4 == 0: the four columns are in range together
+                        half4 hh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+                        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = hh;
+                        guard_sp16x4(a.guard, v);
+                    } else if (CSP == 1) {
                         if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
                         _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                         half4 hh, ll;
@@ -748,12 +801,16 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 }  // namespace
 
 bool gemm_split_glds_supported(const GemmDesc& d) {
+    if (d.arith == 2) {  // plain f16 rows: sizes in halfs, two per 4-byte unit
+        if (d.K % (2 * GBK) != 0 || d.conv == 2) return false;
+        return d.conv == 1 ? d.Cin % (2 * GBK) == 0 : d.lda % 16 == 0;
+    }
     if (d.arith != 1 || d.K % GBK != 0 || d.conv == 2) return false;
     if (d.conv == 1) return d.Cin % GBK == 0;
     return d.lda % 8 == 0;
 }
 
-template <int MI, int WAVES_M, int WAVES_N, bool CONV>
+template <int MI, int WAVES_M, int WAVES_N, bool CONV, bool PURE = false>
 static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     a.tiles_m = (M + GBM - 1) / GBM;
@@ -763,11 +820,11 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV, PURE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
-    hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
+    hipLaunchKernelGGL((gemm_nt_split_glds_kernel<MI, WAVES_M, WAVES_N, CONV, PURE>), dim3(a.tiles_m * a.tiles_n, 1, nprob),
                        dim3(WAVES_M * WAVES_N * 64), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -776,7 +833,7 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 
-template <bool CONV, int RMODE, bool CSP>
+template <bool CONV, int RMODE, int CSP, bool PURE = false>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
@@ -786,28 +843,38 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const int n_cu = sola_cu_count();
     const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
-    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE>), dim3(grid), dim3(512), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
 template <bool CONV>
 static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
-    if (a.ksplit > 1) return launch_persist_t<CONV, 0, false>(a, M, N, nprob, s);  // partial sums: f32, no residual
+    if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);  // partial sums: f32, no residual
     const int rmode = !a.p[0].R ? 0 : (a.r_sp16 ? 2 : 1);
     if (a.c_sp16) {
-        if (CONV || rmode == 0) return launch_persist_t<CONV, 0, true>(a, M, N, nprob, s);
-        return rmode == 2 ? launch_persist_t<false, 2, true>(a, M, N, nprob, s) : launch_persist_t<false, 1, true>(a, M, N, nprob, s);
+        if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 1>(a, M, N, nprob, s);
+        return rmode == 2 ? launch_persist_t<false, 2, 1>(a, M, N, nprob, s) : launch_persist_t<false, 1, 1>(a, M, N, nprob, s);
     }
-    if (CONV || rmode == 0) return launch_persist_t<CONV, 0, false>(a, M, N, nprob, s);
-    return rmode == 2 ? launch_persist_t<false, 2, false>(a, M, N, nprob, s) : launch_persist_t<false, 1, false>(a, M, N, nprob, s);
+    if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);
+    return rmode == 2 ? launch_persist_t<false, 2, 0>(a, M, N, nprob, s) : launch_persist_t<false, 1, 0>(a, M, N, nprob, s);
+}
+// plain f16 operands (16-bit storage mode): C is f16 (or f32 for tests), the residual f16
+template <bool CONV>
+static int launch_persist_pure(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    const bool has_r = a.p[0].R != nullptr;
+    if (a.c_f16) {
+        if (CONV || !has_r) return launch_persist_t<CONV, 0, 2, true>(a, M, N, nprob, s);
+        return launch_persist_t<false, 3, 2, true>(a, M, N, nprob, s);
+    }
+    return launch_persist_t<CONV, 0, 0, true>(a, M, N, nprob, s);
 }
 
 // the persistent kernel takes residual / no residual from the launch, so every problem of the launch must agree
@@ -815,6 +882,14 @@ static bool persist_uniform(const GldsArgs& a, int conv) {
     for (int i = 1; i < a.nprob; ++i)
         if ((a.p[i].R != nullptr) != (a.p[0].R != nullptr)) return false;
     return !(conv && a.p[0].R);
+}
+
+template <bool CONV>
+static int launch_shape_pure(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
+    const bool r_ok = !a.p[0].R || (a.r_f16 && a.c_f16 && !CONV);  // the persistent kernel's residual mode of this arithmetic
+    if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV) && r_ok) return launch_persist_pure<CONV>(a, M, N, nprob, s);
+    if (shape == 4) return launch_glds<4, 2, 4, CONV, true>(a, M, N, nprob, s);
+    return launch_glds<2, 2, 2, CONV, true>(a, M, N, nprob, s);
 }
 
 template <bool CONV>
@@ -835,6 +910,11 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     for (int i = 0; i < 3; ++i) a.p[i] = d.p[i < d.nprob ? i : 0];
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
+    a.r_f16 = a.c_f16 = 0;
+    if (d.arith == 2) {  // plain f16 operand rows: the kernels address A and W in 4-byte units of two halfs
+        a.K = d.K / 2; a.lda = d.lda / 2; a.Cin = d.Cin / 2;
+        a.r_f16 = d.r_f16; a.c_f16 = d.c_f16;
+    }
     a.rowmap = d.conv == 1 ? d.rowmap : nullptr;
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;
     a.out_scale_dev = d.out_scale_dev;
@@ -842,11 +922,12 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.c_sp16 = d.c_sp16;
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
-    a.guard = d.c_sp16 ? d.guard : nullptr;
+    a.guard = (d.c_sp16 || d.c_f16) ? d.guard : nullptr;
     a.ksplit = d.ksplit > 1 ? d.ksplit : 1;
-    a.kper = d.K / GBK / a.ksplit;
+    a.kper = a.K / GBK / a.ksplit;
     a.part = d.splitk_ws;
     const int shape = gemm_split_glds_shape(d);
+    if (d.arith == 2) return d.conv == 1 ? launch_shape_pure<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape_pure<false>(a, shape, d.M, d.N, d.nprob, s);
     return d.conv == 1 ? launch_shape<true>(a, shape, d.M, d.N, d.nprob, s) : launch_shape<false>(a, shape, d.M, d.N, d.nprob, s);
 }
 

@@ -24,7 +24,10 @@ struct GemmDesc {
     // source row rowmap[m].x (the row of tap 0, may lie outside the sequence) and bit kk of rowmap[m].y says whether tap kk
     // is inside the sequence (else it reads zeros).  T_in / T_out / stride / pad are then unused.
     const int2* rowmap;
-    int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate)
+    int arith;        // 0: f32 operands (exact f32 MFMA); 1: split-f16 operands (3 x f16 MFMA, f32 accumulate);
+                      // 2: plain f16 operands (the 16-bit storage mode: ONE f16 MFMA per product, f32 accumulate).  A and W
+                      //    then hold _Float16 rows and K, lda, Cin count halfs (K % 64 == 0, lda % 16 == 0, Cin % 64 == 0);
+                      //    direct-to-LDS kernels only
     float out_scale;  // arith 1: multiplier undoing the power-of-two weight pre-scale (0 = 1)
     int ksplit;  // arith 1, direct-to-LDS kernels: > 1 cuts the reduction into that many ranges, one work item each (few output
                  // tiles, long K: weight gradients); needs splitk_ws of nprob * ksplit * M * N floats and K % (32 * ksplit) == 0
@@ -32,6 +35,7 @@ struct GemmDesc {
                                  // data-dependent scale launch_cast_sp16_auto gave the A operand)
     int r_sp16;       // arith 1: the residual R is split-f16
     int c_sp16;       // arith 1: write C as split-f16 pairs (N % 8 == 0), e.g. q/k/v for the split attention kernel
+    int r_f16, c_f16; // arith 2: R / C are _Float16 matrices (ldr / ldc count halfs then; N % 4 == 0, pitches % 4 == 0)
     // optional scratch for the two-pass split-K of small grids (fewer 64x64 tiles than CUs): S partial sums per problem,
     // [nprob][S][M][N] f32, reduced in a fixed order (deterministic).  Null = never split.
     float* splitk_ws;
@@ -190,6 +194,7 @@ struct GroupNormDesc {
     // optional, ragged batches: instance i covers the tokens units[i] = (first row, row stride, token count, pe row) instead
     // of the strided pattern above; ntok is then the LARGEST token count (it selects the kernel shape)
     const int4* units;
+    int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices (statistics stay f32)
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
@@ -207,6 +212,10 @@ int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, lo
 // The same for up to 64 equally shaped matrices in three launches (the projection weights): in[i] [rows][K] -> out[i], scale pair
 // of matrix i at scal + 2 * i
 int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n, int rows, int K, float* scal, hipStream_t s);
+// f32 rows -> plain _Float16 rows (16-bit storage mode).  scal != null: data-dependent power-of-two scale as above (scal[1]
+// receives its inverse), else the fixed `scale`.  ld_out counts halfs.
+int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s);
+int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s);
 // Weight-time range check of the split-f16 activations: a GroupNorm output has E[y^2] = gamma^2 + beta^2 per channel (its
 // input is normalised), so the magnitude of every tensor the norms emit is known from the weights alone.  Sets bit 1 of
 // *guard when the rms of any (gamma, beta) pair lies outside [2^-6, 2^9] - where the fixed-scale split-f16 activations would

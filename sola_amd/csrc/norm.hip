@@ -77,7 +77,18 @@ struct GnArgs {
     int out_sp16;     // write y / y2 as split-f16 pairs (cast.hip) instead of f32
     int* guard;       // out_sp16: range guard word (GroupNormDesc::guard), null = unchecked
     const int4* units;  // ragged batches: (first row, row stride, token count, pe row) per instance (GroupNormDesc::units)
+    int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices with the same element offsets
 };
+
+typedef _Float16 half4n __attribute__((ext_vector_type(4)));
+// four consecutive channels starting at element offset `off` of x
+__device__ __forceinline__ float4 gn_load(const GnArgs& a, long long off) {
+    if (a.in_f16) {
+        const half4n h = *reinterpret_cast<const half4n*>(reinterpret_cast<const _Float16*>(a.x) + off);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    return *reinterpret_cast<const float4*>(a.x + off);
+}
 
 // The token set of instance `inst`: first row, row stride, token count and the positional-encoding row of the y + pe output.
 struct GnUnit { long long row0, tok_stride; int ntok, pe_row; };
@@ -114,6 +125,18 @@ __device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, c
         o.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? o.y * a.drop.scale : 0.f;
         o.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? o.z * a.drop.scale : 0.f;
         o.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? o.w * a.drop.scale : 0.f;
+    }
+    if (a.out_f16) {  // plain f16 output (8-byte stores); the range guard as for the split pairs
+        if (off < 0) return;
+        half4n h;
+        h[0] = (_Float16)o.x; h[1] = (_Float16)o.y; h[2] = (_Float16)o.z; h[3] = (_Float16)o.w;
+        *reinterpret_cast<half4n*>(reinterpret_cast<_Float16*>(a.y) + off) = h;
+        if (a.y2) {
+            h[0] = (_Float16)(o.x + pe.x); h[1] = (_Float16)(o.y + pe.y); h[2] = (_Float16)(o.z + pe.z); h[3] = (_Float16)(o.w + pe.w);
+            *reinterpret_cast<half4n*>(reinterpret_cast<_Float16*>(a.y2) + off) = h;
+        }
+        if (a.guard && !(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))) < 65000.f)) atomicOr(a.guard, 1);
+        return;
     }
     if (a.out_sp16) {
         // split-f16 output for the 3 x f16 MFMA GEMMs: lanes c4 and c4^1 hold the two halves of an 8-channel block
@@ -169,14 +192,14 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     float s = 0.f;
     if (active)
         for (int t = tl; t < ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
+            const float4 v = gn_load(a, (row0 + (long long)t * tok_stride) * a.C + ch);
             s += (v.x + v.y) + (v.z + v.w);
         }
     const float mean = block_sum_256(s, red) / cnt;
     float q = 0.f;
     if (active)
         for (int t = tl; t < ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
+            const float4 v = gn_load(a, (row0 + (long long)t * tok_stride) * a.C + ch);
             const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch);
     for (int t = tl; t < ntok; t += tpp) {
         const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-        gn_apply_store(a, off, *reinterpret_cast<const float4*>(a.x + off), mean, rstd, ga, be, pe, c4);
+        gn_apply_store(a, off, gn_load(a, off), mean, rstd, ga, be, pe, c4);
     }
 }
 
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, lon
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
-        v[r] = t < ntok ? *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[r] = t < ntok ? gn_load(a, (row0 + (long long)t * tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
     }
     const float mean = (WAVE ? wave_sum(s) : block_sum_256(s, red)) / cnt;
@@ -362,7 +385,9 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     GnArgs a;
     a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = d.out_sp16 ? d.guard : nullptr; a.units = d.units;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = (d.out_sp16 || d.out_f16) ? d.guard : nullptr; a.units = d.units;
+    a.in_f16 = d.in_f16; a.out_f16 = d.out_f16;
+    SOLA_ARG(!(d.out_f16 && d.out_sp16), "group_norm: one output format at a time");
     SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);

@@ -89,7 +89,9 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self.attention_dropout_p = 0.1  # tools/attention.py:12 (hard-coded in the reference)
         # inference arithmetic of the convs / projections: "f32" (exact f32 MFMA) or "f16x3" (split-f16 operands, three
         # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers every GEMM of the
-        # step, forward and backward (attention and GroupNorm backward stay f32)
+        # step, forward and backward (attention and GroupNorm backward stay f32); "f16" = 16-bit activation STORAGE for the
+        # uniform inference forward (plain f16 between kernels, one f16 MFMA per product, f32 accumulate / softmax / statistics;
+        # a reduced-precision mode with a stated tolerance - training and ragged calls run exact f32 under it)
         self.precision = os.environ.get("SOLA_PRECISION", "f32")  # the entry points take it from the environment
         self._ctx_precision = None
         # "f16x3" inference calls are range-guarded: a value outside the split-f16 pairs' range (or GroupNorm weights that
@@ -157,10 +159,10 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # weight changes; "always" / "cached" force either behaviour (bench.py uses "always")
         every = self.training if self.ws_policy == "auto" else self.ws_policy == "always"
         check(lib().sola_set_ws_policy(self._ctx, 1 if every else 0), "sola_set_ws_policy")
-        if self.precision not in ("f32", "f16x3"):
-            raise SolaError(f"precision must be 'f32' or 'f16x3', got {self.precision!r}")
+        if self.precision not in ("f32", "f16x3", "f16"):
+            raise SolaError(f"precision must be 'f32', 'f16x3' or 'f16', got {self.precision!r}")
         if self._ctx_precision != self.precision:
-            check(lib().sola_set_precision(self._ctx, 1 if self.precision == "f16x3" else 0), "sola_set_precision")
+            check(lib().sola_set_precision(self._ctx, {"f32": 0, "f16x3": 1, "f16": 2}[self.precision]), "sola_set_precision")
             self._ctx_precision = self.precision
         if self._ctx_guard != bool(self.split_guard):
             check(lib().sola_set_split_guard(self._ctx, 1 if self.split_guard else 0), "sola_set_split_guard")
