@@ -29,6 +29,7 @@ The ONE JSON line carries the driver's contract plus (rank 0; the legs after the
   stress_T128_N128    BASELINE config C4 (T=128, N=128): value + roofline + roofline_attention
   ragged              sola_forward_ragged on a MeViS-like mix (N 8..80, T 20..200, L 4..24): one expression per video, and
                       four expressions per video (the text-independent half runs once per video)
+  f16_storage_mode    the 16-bit activation storage mode at the headline shape and at C4 (reduced precision, stated tolerance)
   iou                 the mask-IoU de-dup predicate at its real call sizes (P=4 x R=16/64/256 at 540x960): HBM roofline + CPU
   training_step       one optimizer step at up to 64 samples, both precisions, with the per-kernel breakdown
   cpu_baseline        the PyTorch-CPU oracle (a port of the reference path) timed on this box's host cores
@@ -293,6 +294,53 @@ def stress_leg(cfg, m, dev, precision, steps):
     return out
 
 
+def f16_storage_leg(cfg, m, dev, steps):
+    """The 16-bit activation storage mode (module.precision = "f16"; BASELINE configs C2 / C4 name bf16 / fp16 runs): the same
+    step at the headline shape and at C4, with the largest logit difference from the exact-f32 mode on the batch.  A
+    reduced-precision mode (tolerance stated in tests/test_gpu_f16.py): reported beside the headline, never as it."""
+    from sola_amd import ops, synth
+    from sola_amd.loss import track_selection_losses
+
+    out = {"what": "plain f16 between kernels (2 B per activation element), one f16 MFMA per product, f32 accumulate / softmax / statistics; "
+                   "device-side scales + range guard with exact-f32 repeat",
+           "tolerance": "logits within 1.5 % rms and 0.5 max of the reference (tests/test_gpu_f16.py)"}
+    sync = lambda: torch.cuda.synchronize(dev)
+    keep = m.precision
+    for tag, (B, N, T, L) in (("NS_T32_N64", (256, 64, 32, 16)), ("C4_T128_N128", (32, 128, 128, 16))):
+        c = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(cfg, B, N, T, L, seed=1000).items()}
+
+        def step():
+            with torch.no_grad():
+                sm, st = m(c["object_tokens"], c["lang_tokens"])
+                track_selection_losses(sm, st, c["labels"], c["pos_tokens"], m.negative_token.weight, POS_W, TEMP, ALIGN_W)
+                ops.select(sm, 0.5)
+            return sm
+
+        m.precision = "f32"
+        ref = step()
+        m.precision = "f16"
+        dt, prof = profiled(step, steps, sync)
+        sm = step()
+        fl = synth.flops_per_sample(cfg, N, T, L)
+        a = prof["attn"]
+        g = prof["gemm_split256"]
+        alg = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        out[tag] = {"value": round(B / dt, 1), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3), "model_tflops": round(B / dt * fl["total"] / 1e12, 1),
+                    "max_abs_logit_diff_vs_f32_mode": float((sm - ref).abs().max()),
+                    "rms_logit_diff_vs_f32_mode": float((sm - ref).pow(2).mean().sqrt()), "calls_repeated_in_f32": m.split_fallbacks()[0],
+                    "roofline": {"kernel": "gemm_nt_split_glds_persist_kernel<*, PURE> (f16 operands, one v_mfma_f32_32x32x16_f16 per product)",
+                                 "bound": "mfma", "achieved": round(alg, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(alg / F16_MFMA_PEAK_TFLOPS, 4)},
+                    "roofline_attention": {"kernel": "attn_fwd_f16_kernel", "bound": "hbm", "achieved": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "what": "algorithmic bytes at 2 B per element"},
+                    "kernel_ms_per_step": kernel_ms(prof, steps)}
+        del c
+        torch.cuda.empty_cache()
+    m.precision = keep
+    return out
+
+
 def ragged_leg(cfg, m, dev, steps, uniform_model_tflops):
     """sola_forward_ragged + sola_loss_ragged + sola_select on a MeViS-like mix of shapes (N in [8,80] tracks, T in [20,200]
     frames, L in [4,24] text tokens; seeded), 128 samples per launch: (a) one expression per video, (b) four expressions per
@@ -544,6 +592,7 @@ def main():
             out["stress_T128_N128"] = stress_leg(cfg, m, dev, args.precision, k)
             out["ragged"] = ragged_leg(cfg, m, dev, k, out["model_tflops"])
             out["iou"] = iou_leg(dev, args.cpu_seconds)
+            out["f16_storage_mode"] = f16_storage_leg(cfg, m, dev, k)
         if world == 1 and args.train_steps > 0:
             out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps)
         if world == 1 and args.cpu_seconds > 0:
