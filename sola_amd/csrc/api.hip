@@ -323,8 +323,8 @@ extern "C" int sola_set_precision(SolaCtx* c, int precision) {
         SOLA_HIP(hipMalloc(&c->ws16_buf, ws_total * sizeof(float)));
         SOLA_HIP(hipMalloc(&c->lin16_buf, (size_t)c->cfg.n_layers * 12 * D * D * sizeof(float)));
         const size_t n_pairs = 2 + (size_t)c->cfg.n_layers * 12;
-        SOLA_HIP(hipMalloc(&c->scal_buf, (2 * n_pairs + 2) * sizeof(float)));
-        SOLA_HIP(hipMemset(c->scal_buf, 0, (2 * n_pairs + 2) * sizeof(float)));
+        SOLA_HIP(hipMalloc(&c->scal_buf, (2 * n_pairs + 2 + 4) * sizeof(float)));
+        SOLA_HIP(hipMemset(c->scal_buf, 0, (2 * n_pairs + 2 + 4) * sizeof(float)));
         c->guard = reinterpret_cast<int*>(c->scal_buf + 2 * n_pairs);
         SOLA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->guard_host), 2 * sizeof(int), hipHostMallocDefault));
         c->guard_host[0] = c->guard_host[1] = 0;

@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256) void amax_colsum_kernel(const float* __restric
 }
 
 // scale = 2^(13 - floor(log2(amax))): the largest magnitude lands in [2^13, 2^14), far from the f16 overflow at 65504
-__device__ __forceinline__ float auto_scale(unsigned amax_bits) {
+__device__ __forceinline__ float auto_scale(unsigned amax_bits, int target = 13) {
     const int e = (int)(amax_bits >> 23) - 127;  // floor(log2(amax)) for normal floats
     if (amax_bits == 0u) return 1.f;
-    const int k = min(max(13 - e, -100), 100);
+    const int k = min(max(target - e, -100), 100);
     return __uint_as_float((unsigned)(k + 127) << 23);
 }
 
@@ -150,12 +150,16 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_multi_kernel(const MultiAr
 // SCALED: the power-of-two scale comes from the amax slot (cast_sp16_auto_kernel's rule), else from the argument
 template <bool SCALED>
 __global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long rows,
-                                                       int blocks_per_row, int ld_in, int ld_out, float scale_arg, float* __restrict__ scal) {
+                                                       int blocks_per_row, int ld_in, int ld_out, float scale_arg, float* __restrict__ scal,
+                                                       int target, float* __restrict__ scale_out) {
     float scale = scale_arg;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (SCALED) {
-        scale = auto_scale(reinterpret_cast<const unsigned*>(scal)[0]);
-        if (i == 0) scal[1] = 1.f / scale;
+        scale = auto_scale(reinterpret_cast<const unsigned*>(scal)[0], target);
+        if (i == 0) {
+            scal[1] = 1.f / scale;
+            if (scale_out) *scale_out = scale;
+        }
     }
     if (i >= rows * blocks_per_row) return;
     const long long r = i / blocks_per_row;
@@ -218,7 +222,8 @@ int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n
     return SOLA_OK;
 }
 
-int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s) {
+int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s,
+                    int target_exp, float* scale_out) {
     SOLA_ARG(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_f16: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
     const long long n = rows * (K / 8);
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, (scal ? 10.0 : 6.0) * rows * K);
@@ -227,9 +232,11 @@ int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long
         hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
                            reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
         SOLA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, 1.f, scal);
+        hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, 1.f, scal,
+                           target_exp, scale_out);
     } else {
-        hipLaunchKernelGGL(cast_f16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, scale, nullptr);
+        hipLaunchKernelGGL(cast_f16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, scale, nullptr,
+                           0, nullptr);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;

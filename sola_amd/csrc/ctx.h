@@ -75,6 +75,7 @@ struct SolaCtx {
     bool bucket_recorded = false;
     int n_buckets() const { return cfg.n_layers + 1; }
     float* scal_pair(int i) const { return scal_buf + 2 * i; }
+    float* scal_extra(int i) const { return scal_buf + 2 * (2 + (size_t)cfg.n_layers * 12) + 2 + i; }  // 4 spare device floats behind the guard words
     const float* lin_inv_scale(int layer, int attn, int proj) const { return scal_buf + 2 * (2 + (layer * 3 + attn) * 4 + proj) + 1; }
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
     // the seed used by the last sola_forward_train is kept for sola_backward

@@ -63,7 +63,11 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
     SOLA_HIP(hipMemsetAsync(c->guard, 0, sizeof(int), s));
 
     // ---- encoder
-    SOLA_TRY(launch_cast_f16(obj, d_in, buf("obj_sp"), d_in, (long long)R * T, d_in, 1.f, c->scal_pair(0), s));
+    // The caller's tokens: largest magnitude -> [2^6, 2^7).  conv0's output STAYS in those scaled units (its standardised
+    // weights have a gain of sqrt(k*cin) = 28: tokens at 1e3 would leave the f16 range if the scale were undone here, tokens
+    // at 1e-5 would sink into subnormals): the bias is multiplied by the scale in conv0's epilogue and the first GroupNorm
+    // multiplies by the inverse while it reads, so its statistics (and eps) see the true values.
+    SOLA_TRY(launch_cast_f16(obj, d_in, buf("obj_sp"), d_in, (long long)R * T, d_in, 1.f, c->scal_pair(0), s, 6, c->scal_extra(0)));
     const float* x = buf("obj_sp");
     int t_in = T;
     for (int i = 0; i < 6; ++i) {
@@ -78,7 +82,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
         gd.arith = 2; gd.out_scale = 1.f; gd.c_f16 = 1; gd.guard = c->guard;
-        if (i == 0) gd.out_scale_dev = c->scal_pair(0) + 1;
+        if (i == 0) gd.bias_scale_dev = c->scal_extra(0);
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
@@ -88,6 +92,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
             nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
             nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
             nd.in_f16 = 1; nd.out_f16 = 1; nd.guard = c->guard;
+            if (i == 0) nd.in_scale_dev = c->scal_pair(0) + 1;
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
         }
@@ -95,7 +100,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
     }
     SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
     SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
-    SOLA_TRY(launch_cast_f16(buf("lang"), D, buf("lang_sp"), D, (long long)B * Wn, D, 1.f, c->scal_pair(1), s));
+    SOLA_TRY(launch_cast_f16(buf("lang"), D, buf("lang_sp"), D, (long long)B * Wn, D, 1.f, c->scal_pair(1), s, 6));
 
     const float scale = 1.0f / sqrtf((float)DH);
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, int layer, int attn, int nprob, int rows, float* o0,

@@ -45,6 +45,7 @@ struct GldsArgs {
     const float* out_scale_dev;
     int r_sp16, c_sp16;
     int r_f16, c_f16;  // PURE kernels: residual / output stored as _Float16 (ldr / ldc in halfs)
+    const float* bias_scale_dev;  // optional device multiplier of the bias (GemmDesc::bias_scale_dev)
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
     int* guard;  // c_sp16: range guard word (GemmDesc::guard), null = unchecked
 };
@@ -277,10 +278,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     const bool vec_ok = (a.ldc & 3) == 0 && n + 3 < a.N && (!pr.R || a.r_sp16 || (a.ldr & 3) == 0);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pr.bias) {
-        bv.x = n < a.N ? pr.bias[n] : 0.f;
-        bv.y = n + 1 < a.N ? pr.bias[n + 1] : 0.f;
-        bv.z = n + 2 < a.N ? pr.bias[n + 2] : 0.f;
-        bv.w = n + 3 < a.N ? pr.bias[n + 3] : 0.f;
+        const float bsc = a.bias_scale_dev ? *a.bias_scale_dev : 1.f;
+        bv.x = n < a.N ? pr.bias[n] * bsc : 0.f;
+        bv.y = n + 1 < a.N ? pr.bias[n + 1] * bsc : 0.f;
+        bv.z = n + 2 < a.N ? pr.bias[n + 2] * bsc : 0.f;
+        bv.w = n + 3 < a.N ? pr.bias[n + 3] * bsc : 0.f;
     }
 #pragma unroll
     for (int h = 0; h < MI / 2; ++h) {
@@ -625,10 +627,11 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         const bool vec_ok = (ldc & 3) == 0 && n + 3 < a.N && (RMODE != 1 || (a.ldr & 3) == 0);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pr.bias) {
-            bv.x = n < a.N ? pr.bias[n] : 0.f;
-            bv.y = n + 1 < a.N ? pr.bias[n + 1] : 0.f;
-            bv.z = n + 2 < a.N ? pr.bias[n + 2] : 0.f;
-            bv.w = n + 3 < a.N ? pr.bias[n + 3] : 0.f;
+            const float bsc = a.bias_scale_dev ? *a.bias_scale_dev : 1.f;
+            bv.x = n < a.N ? pr.bias[n] * bsc : 0.f;
+            bv.y = n + 1 < a.N ? pr.bias[n + 1] * bsc : 0.f;
+            bv.z = n + 2 < a.N ? pr.bias[n + 2] * bsc : 0.f;
+            bv.w = n + 3 < a.N ? pr.bias[n + 3] * bsc : 0.f;
         }
         // Interior tiles (every row and column in range, 16-byte aligned rows) take a straight-line path: no per-lane
         // predicates, so the number of stores a wave issues is known (see the relaxed wait at the next tile's first
@@ -911,6 +914,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.r_f16 = a.c_f16 = 0;
+    a.bias_scale_dev = d.bias_scale_dev;
     if (d.arith == 2) {  // plain f16 operand rows: the kernels address A and W in 4-byte units of two halfs
         a.K = d.K / 2; a.lda = d.lda / 2; a.Cin = d.Cin / 2;
         a.r_f16 = d.r_f16; a.c_f16 = d.c_f16;

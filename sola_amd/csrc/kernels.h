@@ -36,6 +36,8 @@ struct GemmDesc {
     int r_sp16;       // arith 1: the residual R is split-f16
     int c_sp16;       // arith 1: write C as split-f16 pairs (N % 8 == 0), e.g. q/k/v for the split attention kernel
     int r_f16, c_f16; // arith 2: R / C are _Float16 matrices (ldr / ldc count halfs then; N % 4 == 0, pitches % 4 == 0)
+    const float* bias_scale_dev;  // direct-to-LDS kernels, optional: the bias is multiplied by this device scalar (an output kept in
+                                  // the units of a scaled input: conv0 of the 16-bit storage mode)
     // optional scratch for the two-pass split-K of small grids (fewer 64x64 tiles than CUs): S partial sums per problem,
     // [nprob][S][M][N] f32, reduced in a fixed order (deterministic).  Null = never split.
     float* splitk_ws;
@@ -195,6 +197,7 @@ struct GroupNormDesc {
     // of the strided pattern above; ntok is then the LARGEST token count (it selects the kernel shape)
     const int4* units;
     int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices (statistics stay f32)
+    const float* in_scale_dev;  // optional: x is multiplied by this device scalar while it is read (an input stored in scaled units)
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
@@ -214,7 +217,9 @@ int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, lo
 int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n, int rows, int K, float* scal, hipStream_t s);
 // f32 rows -> plain _Float16 rows (16-bit storage mode).  scal != null: data-dependent power-of-two scale as above (scal[1]
 // receives its inverse), else the fixed `scale`.  ld_out counts halfs.
-int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s);
+// target_exp: the largest magnitude lands in [2^target_exp, 2^(target_exp+1)); scale_out (optional, device): receives the scale itself
+int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s,
+                    int target_exp = 13, float* scale_out = nullptr);
 int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s);
 // Weight-time range check of the split-f16 activations: a GroupNorm output has E[y^2] = gamma^2 + beta^2 per channel (its
 // input is normalised), so the magnitude of every tensor the norms emit is known from the weights alone.  Sets bit 1 of

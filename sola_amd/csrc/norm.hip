@@ -78,16 +78,24 @@ struct GnArgs {
     int* guard;       // out_sp16: range guard word (GroupNormDesc::guard), null = unchecked
     const int4* units;  // ragged batches: (first row, row stride, token count, pe row) per instance (GroupNormDesc::units)
     int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices with the same element offsets
+    const float* in_scale_dev;  // optional multiplier applied to x while reading (GroupNormDesc::in_scale_dev)
 };
 
 typedef _Float16 half4n __attribute__((ext_vector_type(4)));
 // four consecutive channels starting at element offset `off` of x
 __device__ __forceinline__ float4 gn_load(const GnArgs& a, long long off) {
+    float4 v;
     if (a.in_f16) {
         const half4n h = *reinterpret_cast<const half4n*>(reinterpret_cast<const _Float16*>(a.x) + off);
-        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+        v = *reinterpret_cast<const float4*>(a.x + off);
     }
-    return *reinterpret_cast<const float4*>(a.x + off);
+    if (a.in_scale_dev) {
+        const float sc = *a.in_scale_dev;
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    }
+    return v;
 }
 
 // The token set of instance `inst`: first row, row stride, token count and the positional-encoding row of the y + pe output.
@@ -386,7 +394,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     a.x = d.x; a.y = d.y; a.y2 = d.y2; a.pe = d.pe; a.gamma = d.gamma; a.beta = d.beta;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = (d.out_sp16 || d.out_f16) ? d.guard : nullptr; a.units = d.units;
-    a.in_f16 = d.in_f16; a.out_f16 = d.out_f16;
+    a.in_f16 = d.in_f16; a.out_f16 = d.out_f16; a.in_scale_dev = d.in_scale_dev;
     SOLA_ARG(!(d.out_f16 && d.out_sp16), "group_norm: one output format at a time");
     SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
