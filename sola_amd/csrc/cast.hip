@@ -32,6 +32,20 @@ __global__ __launch_bounds__(256) void cast_sp16_kernel(const float* __restrict_
     o[1] = lo;
 }
 
+// block-wide max -> ONE atomic per block (a launch over 0.5 GB has 65 K blocks: an atomic per wave queued 260 K updates on one
+// address and took as long as the read itself)
+__device__ __forceinline__ void block_amax_commit(float m, unsigned* out) {
+    __shared__ float bmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) bmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
+        if (m > 0.f && m <= 3.0e38f) atomicMax(out, __float_as_uint(m));
+    }
+}
+
 // max |x| of a strided matrix as float bits (non-negative floats order like their bit patterns).  A thread owns one float4
 // column of a 64-row slab: coalesced row reads, no index arithmetic in the loop, one atomic per wave.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ in, unsigned* __restrict__ out, long long rows, int f4_per_row, int ld_in) {
@@ -47,9 +61,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ in,
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(out, __float_as_uint(m));
+    block_amax_commit(m, out);
 }
 
 // amax_kernel that also leaves the column sums of every 64-row slab in part[slab][cols] (bias gradients: the second, tiny
@@ -71,9 +83,7 @@ __global__ __launch_bounds__(256) void amax_colsum_kernel(const float* __restric
         }
         *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * f4_per_row + c) * 4) = sum;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(out, __float_as_uint(m));
+    block_amax_commit(m, out);
 }
 
 // scale = 2^(13 - floor(log2(amax))): the largest magnitude lands in [2^13, 2^14), far from the f16 overflow at 65504
@@ -120,9 +130,7 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const MultiArgs a, unsi
         const float4 v = *reinterpret_cast<const float4*>(in + i * 4);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(scal + 2 * blockIdx.z, __float_as_uint(m));
+    block_amax_commit(m, scal + 2 * blockIdx.z);
 }
 __global__ __launch_bounds__(256) void cast_sp16_auto_multi_kernel(const MultiArgs a, float* __restrict__ scal, long long n8) {
     const float* in = a.in[blockIdx.z];
@@ -208,7 +216,7 @@ int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 12.0 * n * rows * K);
     SOLA_HIP(hipMemsetAsync(scal, 0, (size_t)2 * n * sizeof(float), s));
     const long long elems = (long long)rows * K;
-    const unsigned blocks = (unsigned)std::min<long long>(1024, (elems / 8 + 255) / 256);
+    const unsigned blocks = (unsigned)std::min<long long>(128, (elems / 8 + 255) / 256);
     for (int i0 = 0; i0 < n; i0 += MULTI_MAX) {
         const int nn = std::min(MULTI_MAX, n - i0);
         MultiArgs a;
