@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__
     float scale = scale_arg;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (SCALED) {
+        // scale_arg > 0 caps the data-dependent scale (an output kept in the scaled units also carries scale * bias)
         scale = auto_scale(reinterpret_cast<const unsigned*>(scal)[0], target);
+        if (scale_arg > 0.f) scale = fminf(scale, scale_arg);
         if (i == 0) {
             scal[1] = 1.f / scale;
             if (scale_out) *scale_out = scale;
@@ -240,8 +242,8 @@ int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long
         hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
                            reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
         SOLA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, 1.f, scal,
-                           target_exp, scale_out);
+        hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out,
+                           scale_out ? scale : 0.f, scal, target_exp, scale_out);
     } else {
         hipLaunchKernelGGL(cast_f16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, scale, nullptr,
                            0, nullptr);

@@ -67,7 +67,9 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
     // weights have a gain of sqrt(k*cin) = 28: tokens at 1e3 would leave the f16 range if the scale were undone here, tokens
     // at 1e-5 would sink into subnormals): the bias is multiplied by the scale in conv0's epilogue and the first GroupNorm
     // multiplies by the inverse while it reads, so its statistics (and eps) see the true values.
-    SOLA_TRY(launch_cast_f16(obj, d_in, buf("obj_sp"), d_in, (long long)R * T, d_in, 1.f, c->scal_pair(0), s, 6, c->scal_extra(0)));
+    // The scale is capped at 2^8: conv0's bias rides along multiplied by it (tokens of 1e-5 would ask for 2^21 and carry a
+    // bias of 0.03 to 75 000); below the cap the smallest token entries lose some of their 11 bits to f16 subnormals.
+    SOLA_TRY(launch_cast_f16(obj, d_in, buf("obj_sp"), d_in, (long long)R * T, d_in, 256.f, c->scal_pair(0), s, 6, c->scal_extra(0)));
     const float* x = buf("obj_sp");
     int t_in = T;
     for (int i = 0; i < 6; ++i) {
