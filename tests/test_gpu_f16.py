@@ -162,5 +162,7 @@ def test_f16_mode_unsupported_config_is_an_error():
 
     m = build("f16", synth.SMALL_MODEL_CFG)  # object_token_dim 32: not a multiple of 64
     inp = synth.make_inputs(synth.SMALL_MODEL_CFG, 1, 4, 8, 3, 0)
-    with pytest.raises(SolaError, match="multiples of 64"):
+    with pytest.raises(SolaError, match="multiples of 64"), torch.no_grad():
         m(cuda(inp["object_tokens"]), cuda(inp["lang_tokens"]))
+    sm, _ = m(cuda(inp["object_tokens"]), cuda(inp["lang_tokens"]))  # with autograd on this is a training forward: exact f32 under this mode
+    assert sm.requires_grad and torch.isfinite(sm).all()
