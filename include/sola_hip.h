@@ -374,6 +374,7 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "gemm_ablate": measurement only, 4 = no epilogue (results are then WRONG);
  * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for
  * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
+ * "pack_resample_lds": nearest-resampling mask pack, 1 (default) = source rows staged through LDS / 0 = per-pixel gather;
  * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
  * "attn_target_blocks").  Except under gemm_ablate, results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);

@@ -88,6 +88,67 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const PackArgs a) {
     }
 }
 
+// Nearest-resample pack (generate_tokens_grid.py:271-272: prompt masks of another resolution): the generic kernel above
+// walks 16 destination pixels per lane with a source-index computation and a scattered byte load for each (20 % of the HBM
+// peak at 720x1280 -> 540x960).  Here a block owns RPB destination rows of one mask: their source rows are read ONCE with
+// coalesced 4-byte loads into LDS as {0,1} bytes (only the rows ATen's rule selects are touched at all), and every lane then
+// gathers the 32 pixels of one destination word from LDS with the column rule evaluated in registers.  Needs W % 32 == 0.
+constexpr int RS_RPB = 8, RS_MAXW = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs a) {
+    __shared__ uint8_t rows[RS_RPB][RS_MAXW];
+    __shared__ int red[4];
+    const int n = blockIdx.y, y0 = blockIdx.x * RS_RPB;
+    const T* src = reinterpret_cast<const T*>(a.src) + (long long)n * a.hw_src;
+    const bool vec4 = (a.w & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) * 1) % (4 * sizeof(T)) == 0) && ((a.hw_src * (long long)sizeof(T)) % (4 * sizeof(T)) == 0);
+    for (int r = 0; r < RS_RPB; ++r) {
+        const int y = y0 + r;
+        if (y >= a.H) break;
+        const int sy = a.h == a.H ? y : min((int)floorf((float)y * a.sy), a.h - 1);  // ATen nearest, fp32 product
+        const T* row = src + (long long)sy * a.w;
+        if (vec4) {
+            for (int i = threadIdx.x * 4; i < a.w; i += 1024) {
+                if constexpr (sizeof(T) == 1) {
+                    const unsigned v = *reinterpret_cast<const unsigned*>(row + i);
+                    // byte != 0 -> 1, four at a time
+                    const unsigned nz = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;
+                    *reinterpret_cast<unsigned*>(&rows[r][i]) = nz;
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(row + i);
+                    *reinterpret_cast<unsigned*>(&rows[r][i]) = (v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 0x100u : 0u) | (v.z != 0.f ? 0x10000u : 0u) | (v.w != 0.f ? 0x1000000u : 0u);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < a.w; i += 256) rows[r][i] = is_set(row[i]) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const int wpr = a.W >> 5;
+    int cnt = 0;
+    for (int idx = threadIdx.x; idx < RS_RPB * wpr; idx += 256) {
+        const int r = idx / wpr, j = idx - r * wpr;
+        const int y = y0 + r;
+        if (y >= a.H) break;
+        unsigned bits = 0;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) {
+            const int x = 32 * j + b;
+            const int sx = a.w == a.W ? x : min((int)floorf((float)x * a.sx), a.w - 1);
+            bits |= (unsigned)rows[r][sx] << b;
+        }
+        a.bits[(long long)n * a.words + (long long)y * wpr + j] = bits;
+        cnt += __popc(bits);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = red[0] + red[1] + red[2] + red[3];
+        if (tot) atomicAdd(&a.area[n], (unsigned long long)tot);
+    }
+}
+
 // Streaming fast path for the common case (uint8 masks already at the comparison resolution, 32-byte aligned rows of
 // H*W % 32 == 0 pixels): a lane packs one whole 32-bit word from 32 bytes, four words per lane with all eight 16-byte
 // loads in flight before the first use, one area atomic per 32 KiB of mask.
@@ -352,6 +413,9 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
     return true;
 }
 
+int g_pack_resample_lds = 1;  // sola_tune "pack_resample_lds": 0 = the generic per-pixel kernel for resampled packs (A/B, tests)
+void sola_pack_set_resample_lds(int v) { g_pack_resample_lds = v; }
+
 int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
                      long long* area, hipStream_t s) {
     SOLA_ARG(n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "mask_pack: bad sizes");
@@ -370,6 +434,10 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, src_bytes + (double)n * a.words * 4);
     if (elem_type == 0 && a.identity && a.HW % 32 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0)
         hipLaunchKernelGGL(mask_pack_u8_stream_kernel, dim3((unsigned)((a.words + 1023) / 1024), n), dim3(256), 0, s, a);
+    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && elem_type == 0)
+        hipLaunchKernelGGL(mask_pack_resample_kernel<uint8_t>, dim3((unsigned)((H + RS_RPB - 1) / RS_RPB), n), dim3(256), 0, s, a);
+    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && elem_type == 1)
+        hipLaunchKernelGGL(mask_pack_resample_kernel<float>, dim3((unsigned)((H + RS_RPB - 1) / RS_RPB), n), dim3(256), 0, s, a);
     else if (elem_type == 0)
         hipLaunchKernelGGL(mask_pack_kernel<uint8_t>, dim3(blocks, n), dim3(256), 0, s, a);
     else

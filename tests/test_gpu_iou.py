@@ -136,3 +136,24 @@ def test_fused_one_launch_path_equals_pack_and_pair(P, R, H, W):
     for _ in range(3):
         inter, union = seg_utils.mask_iou_matrix(cuda(A), cuda(B))
         np.testing.assert_array_equal(inter.cpu().numpy(), ri)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("h,w,H,W", [(720, 1280, 540, 960), (480, 854, 540, 960), (1080, 1920, 540, 960), (100, 37, 64, 96), (270, 480, 540, 960),
+                                     (33, 4100, 40, 64)])
+def test_lds_staged_resample_pack_equals_per_pixel_pack(dtype, h, w, H, W):
+    """The LDS-staged nearest-resample pack (rows of any alignment, uint8 and float32 sources, sources wider than its LDS rows
+    fall back) writes the bits and areas of the per-pixel kernel, which the ATen index maps of the fixture pin."""
+    from sola_amd import _lib
+
+    rng = np.random.default_rng(h + w)
+    src = ((rng.uniform(size=(3, h, w)) < 0.4) * rng.integers(1, 200, size=(3, h, w))).astype(dtype)
+    outs = []
+    for lds in (1, 0):
+        _lib.check(_lib.lib().sola_tune(b"pack_resample_lds", lds), "sola_tune")
+        bits, area = seg_utils.pack_masks(cuda(src), (H, W))
+        outs.append((bits.clone(), area.clone()))
+    _lib.check(_lib.lib().sola_tune(b"pack_resample_lds", 1), "sola_tune")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = iou_oracle.nearest_resize((src != 0).astype(np.uint8), H, W)
+    np.testing.assert_array_equal(outs[0][1].cpu().numpy(), ref.reshape(3, -1).sum(axis=1))
