@@ -89,75 +89,87 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const PackArgs a) {
 }
 
 // Nearest-resample pack (generate_tokens_grid.py:271-272: prompt masks of another resolution): the generic kernel above
-// walks 16 destination pixels per lane with a source-index computation and a scattered byte load for each (20 % of the HBM
-// peak at 720x1280 -> 540x960).  Here a block owns RPB destination rows of one mask: their source rows are read ONCE with
-// coalesced 4-byte loads into LDS as {0,1} bytes (only the rows ATen's rule selects are touched at all), and every lane then
-// gathers the 32 pixels of one destination word from LDS with the column rule evaluated in registers.  Needs W % 32 == 0.
-constexpr int RS_RPB = 8, RS_MAXW = 4096;
+// walks 16 destination pixels per lane with a source-index computation and a scattered byte load for each (17-24 % of the
+// HBM peak at 720x1280 / 1080x1920 -> 540x960).  Here a block owns RPB destination rows of one mask:
+//   1. their source rows (only the rows ATen's rule selects are touched at all) are read ONCE with 16-byte loads, several in
+//      flight per lane, thresholded and written to LDS as BITS (40 words for a 1280-pixel row);
+//   2. a lane builds one destination word from the (at most four) consecutive source words its 32 pixels fall into: four
+//      LDS reads per word instead of one per pixel (the per-pixel byte gather from LDS was latency-bound at the same 160 us
+//      as the gather from HBM), the column rule and the bit select run in registers.
+// Needs W % 32 == 0 and a horizontal scale of at most 3 (a word's 32 pixels then span < 128 source pixels).
+constexpr int RS_RPB = 8, RS_MAXW = 4096, RS_WORDS = RS_MAXW / 32 + 4;
+__device__ __forceinline__ unsigned pack16(const uint4 v);
 template <typename T>
 __global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs a) {
-    __shared__ uint8_t rows[RS_RPB][RS_MAXW];
+    __shared__ unsigned sbits[RS_RPB][RS_WORDS];
     __shared__ int red[4];
     const int n = blockIdx.y, y0 = blockIdx.x * RS_RPB;
     const T* src = reinterpret_cast<const T*>(a.src) + (long long)n * a.hw_src;
-    const bool vec4 = (a.w & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) * 1) % (4 * sizeof(T)) == 0) && ((a.hw_src * (long long)sizeof(T)) % (4 * sizeof(T)) == 0);
     const int nrows = min(RS_RPB, a.H - y0);
-    if (vec4) {
-        // all rows of the block as ONE index space, eight independent loads in flight per lane (a row-by-row loop paid one
-        // full memory latency per row: 8 x 1.5 us per block, 160 us per 256 masks whatever the bytes)
-        const int w4 = a.w >> 2, total = nrows * w4;
-        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 256) {
-            unsigned val[8];
+    const int sw = (a.w + 31) >> 5;  // source words per row
+    // rows made of whole, 16-byte aligned 32-pixel groups: vector loads
+    const bool vec = (a.w & 31) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ((a.hw_src * (long long)sizeof(T)) & 15) == 0;
+    const int total = nrows * sw;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 2 * 256) {
+        unsigned word[2] = {0u, 0u};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = e0 + q * 256;
-                val[q] = 0u;
-                if (e < total) {
-                    const int r = e / w4, i = (e - r * w4) * 4;
-                    const int y = y0 + r;
-                    const int sy = a.h == a.H ? y : min((int)floorf((float)y * a.sy), a.h - 1);  // ATen nearest, fp32 product
-                    const T* row = src + (long long)sy * a.w;
-                    if constexpr (sizeof(T) == 1) {
-                        const unsigned v = *reinterpret_cast<const unsigned*>(row + i);
-                        val[q] = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;  // byte != 0 -> 1, four at a time
-                    } else {
-                        const float4 v = *reinterpret_cast<const float4*>(row + i);
-                        val[q] = (v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 0x100u : 0u) | (v.z != 0.f ? 0x10000u : 0u) | (v.w != 0.f ? 0x1000000u : 0u);
+        for (int q = 0; q < 2; ++q) {
+            const int e = e0 + q * 256;
+            if (e >= total) continue;
+            const int r = e / sw, jw = e - r * sw;
+            const int y = y0 + r;
+            const int sy = a.h == a.H ? y : min((int)floorf((float)y * a.sy), a.h - 1);  // ATen nearest, fp32 product
+            const T* p = src + (long long)sy * a.w + jw * 32;
+            if (vec) {
+                if constexpr (sizeof(T) == 1) {
+                    const uint4 lo = reinterpret_cast<const uint4*>(p)[0], hi = reinterpret_cast<const uint4*>(p)[1];
+                    word[q] = pack16(lo) | (pack16(hi) << 16);
+                } else {
+                    unsigned wv = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 v = reinterpret_cast<const float4*>(p)[k];
+                        wv |= ((v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 2u : 0u) | (v.z != 0.f ? 4u : 0u) | (v.w != 0.f ? 8u : 0u)) << (4 * k);
                     }
+                    word[q] = wv;
                 }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = e0 + q * 256;
-                if (e < total) {
-                    const int r = e / w4, i = (e - r * w4) * 4;
-                    *reinterpret_cast<unsigned*>(&rows[r][i]) = val[q];
-                }
+            } else {
+                unsigned wv = 0;
+                const int lim = min(32, a.w - jw * 32);
+                for (int k = 0; k < lim; ++k) wv |= (is_set(p[k]) ? 1u : 0u) << k;
+                word[q] = wv;
             }
         }
-    } else {
-        for (int r = 0; r < nrows; ++r) {
-            const int y = y0 + r;
-            const int sy = a.h == a.H ? y : min((int)floorf((float)y * a.sy), a.h - 1);
-            const T* row = src + (long long)sy * a.w;
-            for (int i = threadIdx.x; i < a.w; i += 256) rows[r][i] = is_set(row[i]) ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = e0 + q * 256;
+            if (e < total) {
+                const int r = e / sw;
+                sbits[r][e - r * sw] = word[q];
+            }
         }
     }
+    if (threadIdx.x < RS_RPB * 4) sbits[threadIdx.x >> 2][sw + (threadIdx.x & 3)] = 0u;  // the window may run past the row's last word
     __syncthreads();
     const int wpr = a.W >> 5;
     int cnt = 0;
-    for (int idx = threadIdx.x; idx < RS_RPB * wpr; idx += 256) {
+    for (int idx = threadIdx.x; idx < nrows * wpr; idx += 256) {
         const int r = idx / wpr, j = idx - r * wpr;
-        const int y = y0 + r;
-        if (y >= a.H) break;
+        const int x0 = 32 * j;
+        const int s0 = a.w == a.W ? x0 : min((int)floorf((float)x0 * a.sx), a.w - 1);
+        const int wb = s0 >> 5;
+        const unsigned w0 = sbits[r][wb], w1 = sbits[r][wb + 1], w2 = sbits[r][wb + 2], w3 = sbits[r][wb + 3];
         unsigned bits = 0;
-#pragma unroll 8
+#pragma unroll
         for (int b = 0; b < 32; ++b) {
-            const int x = 32 * j + b;
+            const int x = x0 + b;
             const int sx = a.w == a.W ? x : min((int)floorf((float)x * a.sx), a.w - 1);
-            bits |= (unsigned)rows[r][sx] << b;
+            const int k = sx - (wb << 5);  // 0 .. 127
+            const unsigned t0 = (k & 32) ? w1 : w0, t1 = (k & 32) ? w3 : w2;
+            const unsigned t = (k & 64) ? t1 : t0;
+            bits |= ((t >> (k & 31)) & 1u) << b;
         }
-        a.bits[(long long)n * a.words + (long long)y * wpr + j] = bits;
+        a.bits[(long long)n * a.words + (long long)(y0 + r) * wpr + j] = bits;
         cnt += __popc(bits);
     }
 #pragma unroll
@@ -455,9 +467,9 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, src_bytes + (double)n * a.words * 4);
     if (elem_type == 0 && a.identity && a.HW % 32 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0)
         hipLaunchKernelGGL(mask_pack_u8_stream_kernel, dim3((unsigned)((a.words + 1023) / 1024), n), dim3(256), 0, s, a);
-    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && elem_type == 0)
+    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && w <= 3 * W && elem_type == 0)
         hipLaunchKernelGGL(mask_pack_resample_kernel<uint8_t>, dim3((unsigned)((H + RS_RPB - 1) / RS_RPB), n), dim3(256), 0, s, a);
-    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && elem_type == 1)
+    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && w <= 3 * W && elem_type == 1)
         hipLaunchKernelGGL(mask_pack_resample_kernel<float>, dim3((unsigned)((H + RS_RPB - 1) / RS_RPB), n), dim3(256), 0, s, a);
     else if (elem_type == 0)
         hipLaunchKernelGGL(mask_pack_kernel<uint8_t>, dim3(blocks, n), dim3(256), 0, s, a);
