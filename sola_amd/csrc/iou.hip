@@ -8,6 +8,8 @@
 //                  1 bit/pixel together with its area (popcount).  Pure HBM-bound byte streaming.
 //   2. mask_pair : inter[p,r] = popcount(Abits & Bbits) over 1/8-size L2-resident bit rows; union = |A|+|B|-inter.
 // Counts are int64 and order-independent (integer adds), so results are bit-exact and deterministic.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -103,8 +105,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs a) {
     __shared__ unsigned sbits[RS_RPB][RS_WORDS];
     __shared__ int red[4];
-    const int n = blockIdx.y, y0 = blockIdx.x * RS_RPB;
+    const int n = blockIdx.y;
     const T* src = reinterpret_cast<const T*>(a.src) + (long long)n * a.hw_src;
+    int cnt = 0;
+    // A block walks row chunks blockIdx.x, + gridDim.x, ... and adds its pixel count to the mask's area ONCE: one 64-bit
+    // atomic per 8-row chunk (17 K of them at 256 masks, eight masks to a cache line) serialised in L2 and was the whole
+    // 160 us of this kernel - and of the per-pixel kernel before it.
+    for (int y0 = blockIdx.x * RS_RPB; y0 < a.H; y0 += gridDim.x * RS_RPB) {
+    if (y0 != (int)blockIdx.x * RS_RPB) __syncthreads();  // the previous chunk's LDS rows have been consumed
     const int nrows = min(RS_RPB, a.H - y0);
     const int sw = (a.w + 31) >> 5;  // source words per row
     // rows made of whole, 16-byte aligned 32-pixel groups: vector loads
@@ -152,7 +160,6 @@ __global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs 
     if (threadIdx.x < RS_RPB * 4) sbits[threadIdx.x >> 2][sw + (threadIdx.x & 3)] = 0u;  // the window may run past the row's last word
     __syncthreads();
     const int wpr = a.W >> 5;
-    int cnt = 0;
     for (int idx = threadIdx.x; idx < nrows * wpr; idx += 256) {
         const int r = idx / wpr, j = idx - r * wpr;
         const int x0 = 32 * j;
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs 
         }
         a.bits[(long long)n * a.words + (long long)(y0 + r) * wpr + j] = bits;
         cnt += __popc(bits);
+    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -446,6 +454,12 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
     return true;
 }
 
+// blocks per mask of the resample pack: enough of them to fill the chip when there are few masks, few area atomics when many
+static unsigned resample_blocks(int H, int n) {
+    const int chunks = (H + RS_RPB - 1) / RS_RPB;
+    return (unsigned)std::max(1, std::min(chunks, std::max(4, 2048 / n)));
+}
+
 int g_pack_resample_lds = 1;  // sola_tune "pack_resample_lds": 0 = the generic per-pixel kernel for resampled packs (A/B, tests)
 void sola_pack_set_resample_lds(int v) { g_pack_resample_lds = v; }
 
@@ -468,9 +482,9 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
     if (elem_type == 0 && a.identity && a.HW % 32 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0)
         hipLaunchKernelGGL(mask_pack_u8_stream_kernel, dim3((unsigned)((a.words + 1023) / 1024), n), dim3(256), 0, s, a);
     else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && w <= 3 * W && elem_type == 0)
-        hipLaunchKernelGGL(mask_pack_resample_kernel<uint8_t>, dim3((unsigned)((H + RS_RPB - 1) / RS_RPB), n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(mask_pack_resample_kernel<uint8_t>, dim3(resample_blocks(H, n), n), dim3(256), 0, s, a);
     else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && w <= 3 * W && elem_type == 1)
-        hipLaunchKernelGGL(mask_pack_resample_kernel<float>, dim3((unsigned)((H + RS_RPB - 1) / RS_RPB), n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(mask_pack_resample_kernel<float>, dim3(resample_blocks(H, n), n), dim3(256), 0, s, a);
     else if (elem_type == 0)
         hipLaunchKernelGGL(mask_pack_kernel<uint8_t>, dim3(blocks, n), dim3(256), 0, s, a);
     else
