@@ -108,23 +108,6 @@ __global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs 
     const int n = blockIdx.y;
     const T* src = reinterpret_cast<const T*>(a.src) + (long long)n * a.hw_src;
     int cnt = 0;
-    // The column rule depends on the destination word only, and a thread keeps the same word (and row slot) in every chunk
-    // when a chunk's words fit one pass of the block: its 32 source offsets are computed ONCE, packed four to a register.
-    const int wpr0 = a.W >> 5;
-    const bool fixed = RS_RPB * wpr0 <= 256;
-    int my_wb = 0;
-    unsigned kpack[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    if (fixed && (int)threadIdx.x < RS_RPB * wpr0) {
-        const int j = threadIdx.x % wpr0, x0 = 32 * j;
-        const int s0 = a.w == a.W ? x0 : min((int)floorf((float)x0 * a.sx), a.w - 1);
-        my_wb = s0 >> 5;
-#pragma unroll
-        for (int b = 0; b < 32; ++b) {
-            const int x = x0 + b;
-            const int sx = a.w == a.W ? x : min((int)floorf((float)x * a.sx), a.w - 1);
-            kpack[b >> 2] |= (unsigned)(sx - (my_wb << 5)) << (8 * (b & 3));
-        }
-    }
     // A block walks row chunks blockIdx.x, + gridDim.x, ... and adds its pixel count to the mask's area ONCE: one 64-bit
     // atomic per 8-row chunk (17 K of them at 256 masks, eight masks to a cache line) serialised in L2 and was the whole
     // 160 us of this kernel - and of the per-pixel kernel before it.
@@ -180,23 +163,15 @@ __global__ __launch_bounds__(256) void mask_pack_resample_kernel(const PackArgs 
     for (int idx = threadIdx.x; idx < nrows * wpr; idx += 256) {
         const int r = idx / wpr, j = idx - r * wpr;
         const int x0 = 32 * j;
-        int wb = my_wb;
-        if (!fixed) {
-            const int s0 = a.w == a.W ? x0 : min((int)floorf((float)x0 * a.sx), a.w - 1);
-            wb = s0 >> 5;
-        }
+        const int s0 = a.w == a.W ? x0 : min((int)floorf((float)x0 * a.sx), a.w - 1);
+        const int wb = s0 >> 5;
         const unsigned w0 = sbits[r][wb], w1 = sbits[r][wb + 1], w2 = sbits[r][wb + 2], w3 = sbits[r][wb + 3];
         unsigned bits = 0;
 #pragma unroll
         for (int b = 0; b < 32; ++b) {
-            int k;  // 0 .. 127: offset of the source pixel inside the four-word window
-            if (fixed) {
-                k = (int)((kpack[b >> 2] >> (8 * (b & 3))) & 0xffu);
-            } else {
-                const int x = x0 + b;
-                const int sx = a.w == a.W ? x : min((int)floorf((float)x * a.sx), a.w - 1);
-                k = sx - (wb << 5);
-            }
+            const int x = x0 + b;
+            const int sx = a.w == a.W ? x : min((int)floorf((float)x * a.sx), a.w - 1);
+            const int k = sx - (wb << 5);  // 0 .. 127
             const unsigned t0 = (k & 32) ? w1 : w0, t1 = (k & 32) ? w3 : w2;
             const unsigned t = (k & 64) ? t1 : t0;
             bits |= ((t >> (k & 31)) & 1u) << b;
