@@ -460,7 +460,17 @@ static unsigned resample_blocks(int H, int n) {
     return (unsigned)std::max(1, std::min(chunks, std::max(4, 2048 / n)));
 }
 
-int g_pack_resample_lds = 1;  // sola_tune "pack_resample_lds": 0 = the generic per-pixel kernel for resampled packs (A/B, tests)
+int g_pack_resample_lds = 1;
+// Measured (tools/pack_probe.py, -> 540x960): 720x1280 uint8 168 -> 133 us (22 % of the HBM peak on the whole source, of which
+// only 3 rows in 4 are read), 1080x1920 uint8 273 -> 151 us (44 %), float32 158 -> 67 us (44 %) and 483 -> 85 us (78 %); rows
+// that are not whole aligned 32-pixel groups (480x854) stage pixel by pixel and are slower than the gather kernel: they keep
+// it (2 = this kernel for every width: tests).
+static bool resample_lds_ok(const void* masks, int elem_type, int h, int w, int W) {
+    if (!g_pack_resample_lds || W % 32 != 0 || w > RS_MAXW || w > 3 * W) return false;
+    if (g_pack_resample_lds == 2) return true;
+    const size_t es = elem_type ? 4 : 1;
+    return w % 32 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0 && ((size_t)h * w * es) % 16 == 0;
+}  // sola_tune "pack_resample_lds": 0 = the generic per-pixel kernel for resampled packs (A/B, tests)
 void sola_pack_set_resample_lds(int v) { g_pack_resample_lds = v; }
 
 int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
@@ -481,9 +491,9 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, src_bytes + (double)n * a.words * 4);
     if (elem_type == 0 && a.identity && a.HW % 32 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0)
         hipLaunchKernelGGL(mask_pack_u8_stream_kernel, dim3((unsigned)((a.words + 1023) / 1024), n), dim3(256), 0, s, a);
-    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && w <= 3 * W && elem_type == 0)
+    else if (!a.identity && resample_lds_ok(masks, elem_type, h, w, W) && elem_type == 0)
         hipLaunchKernelGGL(mask_pack_resample_kernel<uint8_t>, dim3(resample_blocks(H, n), n), dim3(256), 0, s, a);
-    else if (!a.identity && g_pack_resample_lds && W % 32 == 0 && w <= RS_MAXW && w <= 3 * W && elem_type == 1)
+    else if (!a.identity && resample_lds_ok(masks, elem_type, h, w, W) && elem_type == 1)
         hipLaunchKernelGGL(mask_pack_resample_kernel<float>, dim3(resample_blocks(H, n), n), dim3(256), 0, s, a);
     else if (elem_type == 0)
         hipLaunchKernelGGL(mask_pack_kernel<uint8_t>, dim3(blocks, n), dim3(256), 0, s, a);
