@@ -269,6 +269,7 @@ void sola_bilinear_set_staged(int v);
 void sola_attn_set_variant(int v);
 void sola_attn_set_target_blocks(int v);
 void sola_iou_set_fused(int v);
+void sola_attn_set_split_min_keys(int v);
 void sola_pack_set_resample_lds(int v);
 extern "C" int sola_tune(const char* key, int value) {
     SOLA_ARG(key, "tune: null key");
@@ -284,6 +285,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
     if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "pack_resample_lds")) { sola_pack_set_resample_lds(value); return SOLA_OK; }
     sola_set_error("tune: unknown key '%s'", key);
     return SOLA_ERR_ARG;

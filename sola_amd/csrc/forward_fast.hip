@@ -66,6 +66,9 @@ int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
     return SOLA_OK;
 }
 
+int g_attn_split_min_keys = 64;  // sola_tune "attn_split_min_keys": units with more keys than this take the split-f16 MFMA shape
+void sola_attn_set_split_min_keys(int v) { g_attn_split_min_keys = v; }
+
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                            float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s) {
     SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
@@ -209,8 +212,8 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
     // q/k/v leave the projection GEMM already split when the attention that reads them runs the split-f16 MFMA shape.
     // Measured (tools/attn_probe.py): with <= 64 keys per unit the exact-f32 MFMA kernel is as fast or faster (the kernel
     // is then bound by latency and LDS traffic, not by the matrix pipe); with 65..128 keys the split shape wins by 14 %.
-    const int obj_sp = (N > 64 && DH % 16 == 0) ? 1 : 0;
-    const int o2l_sp = (Wn > 64 && DH % 16 == 0) ? 1 : 0;
+    const int obj_sp = (N > g_attn_split_min_keys && N > 16 && DH % 16 == 0) ? 1 : 0;
+    const int o2l_sp = (Wn > g_attn_split_min_keys && DH % 16 == 0) ? 1 : 0;
 
     const float* xin = buf("conv5_sp");  // split-f16 A operand of the layer
     const float* xres = conv5_split ? buf("conv5_sp") : buf("conv5");  // residual of the first sub-block
@@ -230,7 +233,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         SOLA_TRY(out_proj(l, 0, xres, xres_sp));
         SOLA_TRY(gn(lp, 0, x_obj, x_pe, 1, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
         // (ii) motion attention (module.py:38-43)
-        const int mot_sp = (Tp > 64 && DH % 16 == 0) ? 1 : 0;
+        const int mot_sp = (Tp > g_attn_split_min_keys && Tp > 16 && DH % 16 == 0) ? 1 : 0;
         SOLA_TRY(linear3(x_pe, x_pe, x_obj, l, 1, 3, M, q, k, v, 0, mot_sp));
         SOLA_TRY(attention(q, k, v, B * N, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, mot_sp));
         SOLA_TRY(out_proj(l, 1, x_obj, 1));
