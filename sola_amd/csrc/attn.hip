@@ -46,6 +46,7 @@ struct AttnArgs {
     int in_sp16;      // shared: q, k, v are split-f16 rows (the SPLIT kernel shape)
     int* guard;       // o_sp16: range guard word (AttnDesc::guard), null = unchecked
     const int4 *q_units, *k_units;  // ragged batches: per-group (first row, row stride, length, -) (AttnDesc::q_units)
+    int tile_rows;    // shared, restaged (multi-tile) path: keys per K/V tile, 64 or 32
 };
 
 // Geometry of one group: first rows, row strides and lengths of its query and key sequences.  With unit tables the values
@@ -129,8 +130,8 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
 
 // NW = waves per block of the shared mode (4: 64-query blocks, K/V tiles of up to 64 rows, two blocks per CU; 8: 128-query
 // blocks and a resident K/V tile of up to 128 rows for units of 65..128 keys, one block per CU).  The packed mode uses 4.
-template <int DH, bool PACKED, int NW, bool SPLIT>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs a) {
+template <int DH, bool PACKED, int NW, bool SPLIT, int MINB = 2>
+__global__ __launch_bounds__(NW * 64, MINB) void attn_fwd_f32_kernel(const AttnArgs a) {
     constexpr int NT = NW * 64;
     constexpr int NC = DH / 16;   // 16-wide head-dim chunks
     constexpr int LDK = DH + LDK_PAD;  // K pitch: ds_read_b128, 16 key rows per 16-lane group -> 16 distinct 16-B slots of the 64-bank line needs pitch = 4 (mod 64)
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
 #pragma unroll
             for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             float m_run = -INFINITY, l_run = 0.f;
-            for (int kt0 = 0; kt0 < cur.Sk; kt0 += 64) {
-                const int nrows = min(64, cur.Sk - kt0);
+            for (int kt0 = 0; kt0 < cur.Sk; kt0 += a.tile_rows) {
+                const int nrows = min(a.tile_rows, cur.Sk - kt0);
                 const int nrows16 = (nrows + 15) & ~15;
                 if (!single_tile) {
                     __syncthreads();  // the previous tile has been consumed by every wave
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                         sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                     }
                 }
-                if (kt0 + 64 >= cur.Sk) {  // q is dead for this q-block: fetch the next fragment into the same registers
+                if (kt0 + a.tile_rows >= cur.Sk) {  // q is dead for this q-block: fetch the next fragment into the same registers
                     if (qb + a.qsplit < cur.nqb) load_q(cur, qb + a.qsplit, qf);
                     else if (has_next) load_q(nxt, nxt.qs, qf);
                 }
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_f32_kernel(const AttnArgs
                         for (int r = 0; r < 4; ++r)
                             sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
                 }
-                if (single_tile && has_next && qb + a.qsplit >= cur.nqb && kt0 + 64 >= cur.Sk) {
+                if (single_tile && has_next && qb + a.qsplit >= cur.nqb && kt0 + a.tile_rows >= cur.Sk) {
                     // last QK^T of this unit is done: Ks can take the next unit's K, and its V starts to travel
                     __syncthreads();
                     commit(true);
@@ -505,16 +506,16 @@ int g_attn_target_blocks = 512;  // resident-K/V mode: blocks per launch (measur
 int g_attn_resident_blocks = 512;  // shared mode: grid size cap (2 blocks per CU x 256 CUs)
 int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
 
-template <int DH, int NW, bool SPLIT>
+template <int DH, int NW, bool SPLIT, int MINB = 2>
 static int launch_shared(const AttnArgs& a, long long blocks, size_t lds, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW, SPLIT>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel<DH, false, NW, SPLIT, MINB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once.done(dev);
     }
-    hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false, NW, SPLIT>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_fwd_f32_kernel<DH, false, NW, SPLIT, MINB>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
     return SOLA_OK;
 }
 
@@ -566,6 +567,7 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
         SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
         const long long resident = wide ? g_attn_resident_blocks / 2 : g_attn_resident_blocks;
         if (g_attn_variant != 0 && blocks > resident) blocks = resident;
+        a.tile_rows = 64;
         const size_t lds = (size_t)a.kv_rows * row_bytes;
         if (a.in_sp16) {
             if (wide) SOLA_TRY((launch_shared<DH, 8, true>(a, blocks, lds, s)));
@@ -584,9 +586,13 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
 void sola_attn_set_variant(int v) { g_attn_variant = v; }
 void sola_attn_set_target_blocks(int v) { g_attn_target_blocks = v; }
 
+bool attention_simple_supported(const AttnDesc& d);
+int launch_attention_simple(const AttnDesc& d, hipStream_t s);
+
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
+    if (g_attn_variant == 2 && attention_simple_supported(d)) return launch_attention_simple(d, s);  // high-occupancy shape (attn_simple.hip)
     AttnArgs a;
     a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
     a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
@@ -600,7 +606,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     a.in_sp16 = d.in_sp16;
     a.guard = d.o_sp16 ? d.guard : nullptr;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
-    a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4;
+    a.kv_rows = 64; a.qsplit = 1; a.sp_log2 = 4; a.tile_rows = 64;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     switch (d.DH) {

@@ -1,0 +1,205 @@
+// High-occupancy shape of the exact-f32 attention core (inference; sola_tune "attn_variant" 2).
+//
+// attn.hip's shared mode keeps a whole 64-key K/V tile pair in LDS (68 KB) and 256 VGPRs per lane for its register
+// prefetch of the next unit: two 4-wave blocks per CU, and a unit's phases (stage, QK^T, softmax, PV, store) largely
+// serialise - it reaches 3.5 TB/s where a plain copy with the same access pattern reaches 5.3-5.9 (tools/micro/strided_bw).
+// This shape trades the hand-rolled pipeline for occupancy: K/V tiles of TK = 32 keys (34 KB), no cross-unit state, ~100
+// VGPRs, so four to five blocks share a CU and cover each other's latency; longer key sequences take further tiles with
+// the online softmax.  Same arithmetic (v_mfma_f32_16x16x4_f32, S^T = K Q^T / O^T = V^T P^T register layout), same
+// addressing (strided groups or unit tables), f32 or split-f16 output.
+#include "kernels.h"
+
+namespace {
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+struct AttnSArgs {
+    const float *q, *k, *v;
+    float* o;
+    int ldq, ldk, ldv, ldo;
+    int G, H, Sq, Sk, inner, nqb;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+    int o_sp16;
+    int* guard;
+    const int4 *q_units, *k_units;
+};
+
+template <int DH, int TK>
+__global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnSArgs a) {
+    constexpr int NC = DH / 16;
+    constexpr int LDK = DH + 4, LDV = DH + 4;
+    constexpr int F4 = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_s[];
+    float* Ks = smem_s;
+    float* Vs = smem_s + TK * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const long long unit = blockIdx.x / a.nqb;
+    const int qb = blockIdx.x - (int)unit * a.nqb;
+    const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = __builtin_amdgcn_readfirstlane(qu.x); q_rs = __builtin_amdgcn_readfirstlane(qu.y); Sq = __builtin_amdgcn_readfirstlane(qu.z);
+        k0 = __builtin_amdgcn_readfirstlane(ku.x); k_rs = __builtin_amdgcn_readfirstlane(ku.y); Sk = __builtin_amdgcn_readfirstlane(ku.z);
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    if (qb * 64 >= Sq) return;  // ragged: fewer q-blocks than the largest unit (block-uniform)
+    const int qi = qb * 64 + wave * 16 + c16;
+    const bool q_ok = qi < Sq;
+    float4 qf[NC];
+    {
+        const float* qp = a.q + (q0 + (long long)qi * q_rs) * a.ldq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qf[c] = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 oacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int kt0 = 0; kt0 < Sk; kt0 += TK) {
+        const int nrows = min(TK, Sk - kt0);
+        const int nrows16 = (nrows + 15) & ~15;
+        if (kt0 > 0) __syncthreads();
+        for (int idx = tid; idx < nrows16 * F4; idx += 256) {
+            const int r = idx / F4, c4 = idx - r * F4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (r < nrows) {
+                const long long row = k0 + (long long)(kt0 + r) * k_rs;
+                kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(&Ks[r * LDK + c4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
+        }
+        __syncthreads();
+        const int ntile = nrows16 >> 4;
+        f32x4 sc[TK / 16];
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t) {
+            if (t < ntile) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const float* kp = &Ks[(t * 16 + c16) * LDK + 4 * g4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
+                    if (c & 1) {
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a1, 0, 0, 0);
+                    } else {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, a0, 0, 0, 0);
+                    }
+                }
+                const int key0 = kt0 + t * 16 + 4 * g4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
+            } else {
+                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[t][r] = __expf(sc[t][r] - m_new);
+                rs += sc[t][r];
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t) {
+            if (t < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* vp = &Vs[(t * 16 + 4 * g4 + r) * LDV + c16];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[c * 16], sc[t][r], oacc[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!q_ok) return;
+    const float inv = 1.f / l_run;
+    float* op = a.o + (q0 + (long long)qi * q_rs) * a.ldo + h * DH;
+    if (!a.o_sp16) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        return;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        half4v hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = oacc[c][j] * inv;
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+            m = fmaxf(m, fabsf(v));
+        }
+        char* dst = reinterpret_cast<char*>(op + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+        *reinterpret_cast<half4v*>(dst) = hi;
+        *reinterpret_cast<half4v*>(dst + 16) = lo;
+    }
+    if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+}
+
+template <int DH>
+int launch_s(const AttnSArgs& a0, hipStream_t s) {
+    AttnSArgs a = a0;
+    constexpr int TK = 32;
+    a.nqb = (a.Sq + 63) / 64;
+    const long long blocks = (long long)a.G * a.H * a.nqb;
+    SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+    const size_t lds = (size_t)2 * TK * (DH + 4) * sizeof(float);
+    hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, TK>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+}  // namespace
+
+// inference shapes only: f32 q / k / v, no log-sum-exp, no dropout, more than 16 keys or queries
+bool attention_simple_supported(const AttnDesc& d) {
+    return !d.lse && !d.drop.enabled && !d.in_sp16 && (d.Sq > 16 || d.Sk > 16) && (d.DH == 128 || d.DH == 64);
+}
+
+int launch_attention_simple(const AttnDesc& d, hipStream_t s) {
+    AttnSArgs a;
+    a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    return d.DH == 128 ? launch_s<128>(a, s) : launch_s<64>(a, s);
+}
