@@ -504,7 +504,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void attn_fwd_f32_kernel(const AttnA
 
 int g_attn_target_blocks = 512;  // resident-K/V mode: blocks per launch (measured flat from 256 to 1024, worse above)
 int g_attn_resident_blocks = 512;  // shared mode: grid size cap (2 blocks per CU x 256 CUs)
-int g_attn_variant = 1;  // 1: packed short sequences + q-block loop over resident K/V; 0: one unit per wave / one q-block per block
+int g_attn_variant = 1;  // 1 (default): packed short sequences, high-occupancy shape for units of <= 128 queries, q-block loop over
+                         // resident K/V otherwise; 0: one unit per wave / one q-block per block (baseline); 2: high-occupancy shape
+                         // wherever it applies; 3: never the high-occupancy shape (A/B)
 
 template <int DH, int NW, bool SPLIT, int MINB = 2>
 static int launch_shared(const AttnArgs& a, long long blocks, size_t lds, hipStream_t s) {
@@ -592,7 +594,11 @@ int launch_attention_simple(const AttnDesc& d, hipStream_t s);
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
-    if (g_attn_variant == 2 && attention_simple_supported(d)) return launch_attention_simple(d, s);  // high-occupancy shape (attn_simple.hip)
+    // High-occupancy shape (attn_simple.hip) where a unit has at most two 64-query blocks and at most 128 keys - the
+    // inter-object attention: measured 278 vs 308 us at N = 64, 399 vs 452 us at N = 128 (tools/attn_probe.py, B = 256 / 32).
+    // With many q-blocks per unit (object -> language: 206 vs 237 us) the resident-K/V loop of this file wins and stays.
+    if (attention_simple_supported(d) && (g_attn_variant == 2 || (g_attn_variant == 1 && d.Sq <= 128 && d.Sk <= 128)))
+        return launch_attention_simple(d, s);
     AttnArgs a;
     a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
     a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;

@@ -13,7 +13,7 @@ m = m.cuda().eval(); m.precision = "f16x3"; m.ws_policy = "always"
 B, N, T, L = 256, 64, 32, 16
 inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, N, T, L, 1000).items()}
 ref = None
-for mk, var in ((64, 1), (64, 2), (64, 1), (64, 2)):
+for mk, var in ((64, 3), (64, 1), (64, 3), (64, 1)):
     _lib.check(_lib.lib().sola_tune(b"attn_split_min_keys", mk), "tune")
     _lib.check(_lib.lib().sola_tune(b"attn_variant", var), "tune")
     with torch.no_grad():
