@@ -86,9 +86,13 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 struct HL4 { half4v hi, lo; };
 __device__ __forceinline__ HL4 split4(float x, float y, float z, float w) {
     HL4 r;
-    r.hi[0] = (_Float16)x; r.hi[1] = (_Float16)y; r.hi[2] = (_Float16)z; r.hi[3] = (_Float16)w;
-    r.lo[0] = (_Float16)(x - (float)r.hi[0]); r.lo[1] = (_Float16)(y - (float)r.hi[1]);
-    r.lo[2] = (_Float16)(z - (float)r.hi[2]); r.lo[3] = (_Float16)(w - (float)r.hi[3]);
+    const float in[4] = {x, y, z, w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 h1, l1;
+        split_f16(in[j], h1, l1);
+        r.hi[j] = h1; r.lo[j] = l1;
+    }
     return r;
 }
 __device__ __forceinline__ f32x4 mfma3(const HL4& a, const HL4& b, f32x4 c) {
@@ -117,8 +121,9 @@ __device__ __forceinline__ void store_o(float* op, int g4, const f32x4 (&oacc)[N
         half4v hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            hi[j] = (_Float16)v[j];
-            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+            _Float16 h1, l1;
+            split_f16(v[j], h1, l1);
+            hi[j] = h1; lo[j] = l1;
             m = fmaxf(m, fabsf(v[j]));
         }
         char* dst = reinterpret_cast<char*>(op + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float v = oacc[c][j] * inv;
-            hi[j] = (_Float16)v;
-            lo[j] = (_Float16)(v - (float)hi[j]);
+            _Float16 h1, l1;
+            split_f16(v, h1, l1);
+            hi[j] = h1; lo[j] = l1;
             m = fmaxf(m, fabsf(v));
         }
         char* dst = reinterpret_cast<char*>(op + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);

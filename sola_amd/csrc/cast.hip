@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void cast_sp16_kernel(const float* __restrict_
     half8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        hi[j] = (_Float16)v[j];
-        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        _Float16 h1, l1;
+        split_f16(v[j], h1, l1);
+        hi[j] = h1; lo[j] = l1;
     }
     half8* o = reinterpret_cast<half8*>(out + r * ld_out + b * 8);
     o[0] = hi;
@@ -108,8 +109,9 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_kernel(const float* __rest
     half8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        hi[j] = (_Float16)v[j];
-        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        _Float16 h1, l1;
+        split_f16(v[j], h1, l1);
+        hi[j] = h1; lo[j] = l1;
     }
     half8* o = reinterpret_cast<half8*>(out + r * ld_out + b * 8);
     o[0] = hi;
@@ -145,8 +147,9 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_multi_kernel(const MultiAr
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            hi[j] = (_Float16)v[j];
-            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+            _Float16 h1, l1;
+            split_f16(v[j], h1, l1);
+            hi[j] = h1; lo[j] = l1;
         }
         half8* o = reinterpret_cast<half8*>(out + i * 8);
         o[0] = hi;

@@ -45,6 +45,19 @@ struct SolaProfScope {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// x -> (hi, lo) with hi = f16(x), lo = f16(x - hi): the split-f16 pair.  The value is pinned in a register first: without
+// that the compiler may fuse the conversion with the FMA that produced x (v_fma_mixlo_f16: ONE rounding from the exact
+// product) for the hi half and subtract the separately rounded f32 for the lo half; where x sits exactly between two f16
+// values the two disagree on hi and the stored lo gets the wrong sign - an error of 2^-12 |x| on ~1 element in 50 000
+// (found by tests/test_gpu_fast.py::test_split_attention_kernel_vs_float64 after an unrelated change to the store pattern).
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    asm volatile("" : "+v"(x));
+    hi = (_Float16)x;
+    float hf = (float)hi;
+    asm volatile("" : "+v"(hf));
+    lo = (_Float16)(x - hf);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -306,9 +306,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
                     }
                     if (a.c_sp16) {  // element n of block n/8: hi[n%8] | lo[n%8]
                         _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7));
-                        const _Float16 hi = (_Float16)v;
+                        _Float16 hi, lo;
+                        split_f16(v, hi, lo);
                         cb[n & 7] = hi;
-                        cb[8 + (n & 7)] = (_Float16)(v - (float)hi);
+                        cb[8 + (n & 7)] = lo;
                         guard_sp16(a.guard, fabsf(v));
                     } else {
                         pr.C[(long long)m * a.ldc + n] = v;
@@ -352,9 +353,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
         _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const _Float16 hi = (_Float16)v[e];
+            _Float16 hi, lo;
+            split_f16(v[e], hi, lo);
             cb[e] = hi;
-            cb[8 + e] = (_Float16)(v[e] - (float)hi);
+            cb[8 + e] = lo;
         }
         guard_sp16(a.guard, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     } else {

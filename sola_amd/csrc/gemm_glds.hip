@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
                 _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
                 half4 hh, ll;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
                 *reinterpret_cast<half4*>(cb) = hh;
                 *reinterpret_cast<half4*>(cb + 8) = ll;
                 guard_sp16x4(a.guard, v);
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                             half4 hh, ll;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                            for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
                             *reinterpret_cast<half4*>(cb) = hh;
                             *reinterpret_cast<half4*>(cb + 8) = ll;
                             guard_sp16x4(a.guard, v);
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                         _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                         half4 hh, ll;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                        for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
                         *reinterpret_cast<half4*>(cb) = hh;
                         *reinterpret_cast<half4*>(cb + 8) = ll;
                         guard_sp16x4(a.guard, v);

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = tile[8 * b + e][c];
-            hi[e] = (_Float16)v;
-            lo[e] = (_Float16)(v - (float)hi[e]);
+            _Float16 h1, l1;
+            split_f16(v, h1, l1);
+            hi[e] = h1; lo[e] = l1;
         }
         half8* o = reinterpret_cast<half8*>(out + (long long)(c0 + c) * ld_out + r0 + 8 * b);
         o[0] = hi;

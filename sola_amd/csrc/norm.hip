@@ -156,7 +156,7 @@ __device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, c
             const float v8[8] = {o.x, o.y, o.z, o.w, n.x, n.y, n.z, n.w};
             half8 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v8[j]; lo[j] = (_Float16)(v8[j] - (float)hi[j]); }
+            for (int j = 0; j < 8; ++j) { _Float16 h1, l1; split_f16(v8[j], h1, l1); hi[j] = h1; lo[j] = l1; }
             half8* dst = reinterpret_cast<half8*>(a.y + off);
             dst[0] = hi; dst[1] = lo;
             if (a.guard) {  // |y + pe| <= |y| + 1: one test covers both outputs (NaN fails the comparison too)
@@ -168,7 +168,7 @@ __device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, c
             if (a.y2) {
                 const float w8[8] = {o2.x, o2.y, o2.z, o2.w, n2.x, n2.y, n2.z, n2.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)w8[j]; lo[j] = (_Float16)(w8[j] - (float)hi[j]); }
+                for (int j = 0; j < 8; ++j) { _Float16 h1, l1; split_f16(w8[j], h1, l1); hi[j] = h1; lo[j] = l1; }
                 half8* dst2 = reinterpret_cast<half8*>(a.y2 + off);
                 dst2[0] = hi; dst2[1] = lo;
             }

@@ -13,3 +13,11 @@ print("max err", float(e.max()), "by column mod 16:", [float(e[:, i::16].max()) 
 raw = ops.attention_split(qs, ks, vs, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp), out_split=True)
 h = raw.view(torch.float16).reshape(-1, D // 8, 16)
 print("row0 block0 hi", h[0, 0, :8].tolist(), "lo", h[0, 0, 8:].tolist(), "f32", a[0, :8].tolist())
+idx = torch.nonzero(e > 1e-5)
+print("n bad", idx.shape[0], "of", e.numel())
+hh = raw.view(torch.float16).reshape(a.shape[0], D // 8, 2, 8)
+for r, c in idx[:6].tolist():
+    print("row", r, "col", c, "f32", float(a[r, c]), "hi", float(hh[r, c // 8, 0, c % 8]), "lo", float(hh[r, c // 8, 1, c % 8]), "g4", (c % 16) // 4, "j", c % 4,
+          "head", c // 128)
+rows = sorted(set(i[0] for i in idx.tolist()))
+print("bad rows", rows[:20], "...")
