@@ -51,11 +51,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // values the two disagree on hi and the stored lo gets the wrong sign - an error of 2^-12 |x| on ~1 element in 50 000
 // (found by tests/test_gpu_fast.py::test_split_attention_kernel_vs_float64 after an unrelated change to the store pattern).
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    asm volatile("" : "+v"(x));
+    asm volatile("" : "+v"(x));  // opaque from here on: both halves derive from this one f32
     hi = (_Float16)x;
-    float hf = (float)hi;
-    asm volatile("" : "+v"(hf));
-    lo = (_Float16)(x - hf);
+    lo = (_Float16)(x - (float)hi);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
