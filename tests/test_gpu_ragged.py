@@ -177,3 +177,34 @@ def test_ragged_is_deterministic_and_independent_of_batch_composition(full):
     torch.testing.assert_close(c[2], a[1], rtol=0, atol=2e-4)
     torch.testing.assert_close(c[0], a[2], rtol=0, atol=2e-4)
     assert torch.equal(c[1], c[3])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15])
+def test_random_ragged_batches_equal_per_sample(small, seed):
+    """Seeded random batches: 1..12 videos of N in [1,40] tracks x T in [1,70] frames, S in [V,3V] samples assigned to random
+    videos (some videos serve several expressions, some none), L in [1,20]: every sample equals its own one-sample call."""
+    cfg = synth.SMALL_MODEL_CFG
+    rng = np.random.Generator(np.random.PCG64(seed))
+    V = int(rng.integers(1, 13))
+    shapes = [(int(rng.integers(1, 41)), int(rng.integers(1, 71))) for _ in range(V)]
+    S = int(rng.integers(V, 3 * V + 1))
+    sample_video = [int(v) for v in rng.integers(0, V, size=S)]
+    lens = [int(v) for v in rng.integers(1, 21, size=S)]
+    videos, texts = make_videos(cfg, shapes, seed * 7), make_texts(cfg, lens, seed * 7 + 1)
+    sms, sts = small.forward_ragged(videos, texts, sample_video)
+    ref = per_sample(small, videos, texts, sample_video)
+    for i, ((rsm, rst), sm, st) in enumerate(zip(ref, sms, sts)):
+        torch.testing.assert_close(sm, rsm, rtol=0, atol=2e-4, msg=lambda s, i=i: f"seed {seed} sample {i} video {shapes[sample_video[i]]} L {lens[i]}: {s}")
+        torch.testing.assert_close(st, rst, rtol=0, atol=2e-4, msg=lambda s, i=i: f"seed {seed} sample {i}: {s}")
+
+
+def test_ragged_under_the_16_bit_storage_mode_runs_exact_f32():
+    """precision "f16" covers the uniform forward; ragged calls under it take the exact-f32 kernels (documented), not a
+    half-converted path."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    m16, m32 = build(cfg, "f16"), build(cfg, "f32")
+    videos, texts = make_videos(cfg, [(9, 24), (20, 40)], 21), make_texts(cfg, [5, 8, 3], 22)
+    a, _ = m16.forward_ragged(videos, texts, [0, 1, 1])
+    b, _ = m32.forward_ragged(videos, texts, [0, 1, 1])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
