@@ -602,7 +602,10 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     // High-occupancy shape (attn_simple.hip) where a unit has at most two 64-query blocks and at most 128 keys - the
     // inter-object attention: measured 278 vs 308 us at N = 64, 399 vs 452 us at N = 128 (tools/attn_probe.py, B = 256 / 32).
     // With many q-blocks per unit (object -> language: 206 vs 237 us) the resident-K/V loop of this file wins and stays.
-    if (attention_simple_supported(d) && (g_attn_variant == 2 || (g_attn_variant == 1 && d.Sq <= 128 && d.Sk <= 128)))
+    // Ragged batches take it for every shape: its q-blocks are independent blocks, so units of very different lengths
+    // balance over the chip (the resident-K/V loop walks a unit's q-blocks inside one block: 1 to 31 of them per unit in
+    // the object -> language attention of a MeViS-like mix).
+    if (attention_simple_supported(d) && (g_attn_variant == 2 || (g_attn_variant == 1 && ((d.Sq <= 128 && d.Sk <= 128) || d.q_units))))
         return launch_attention_simple(d, s);
     AttnArgs a;
     a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
