@@ -595,10 +595,14 @@ void sola_attn_set_target_blocks(int v) { g_attn_target_blocks = v; }
 
 bool attention_simple_supported(const AttnDesc& d);
 int launch_attention_simple(const AttnDesc& d, hipStream_t s);
+bool attention_small_supported(const AttnDesc& d);
+int launch_attention_small(const AttnDesc& d, hipStream_t s);
 
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
+    // Sequences of <= 4 steps (motion attention at T <= 32): the register-only streaming shape (attn_simple.hip)
+    if (g_attn_variant == 1 && attention_small_supported(d)) return launch_attention_small(d, s);
     // High-occupancy shape (attn_simple.hip) where a unit has at most two 64-query blocks and at most 128 keys - the
     // inter-object attention: measured 278 vs 308 us at N = 64, 399 vs 452 us at N = 128 (tools/attn_probe.py, B = 256 / 32).
     // With many q-blocks per unit (object -> language: 206 vs 237 us) the resident-K/V loop of this file wins and stays.

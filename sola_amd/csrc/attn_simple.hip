@@ -171,6 +171,94 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
     if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
 }
 
+// ---- sequences of at most 4 steps (motion attention over T' = ceil(T/8): 4 at the headline shape) -----------------------
+// A (track, head) unit is 4 rows of q, k, v in and 4 rows of o out - 8 KB of traffic for 4 K multiply-adds: pure streaming.
+// The packed MFMA shape of attn.hip stages K/V through 67 KB of LDS (two blocks per CU) and reaches 45 % of the HBM peak
+// where a copy with this access pattern reaches 66-74 % (tools/micro/strided_bw).  Here half a wave owns a unit: lane c holds
+// float4 chunk c of every row (rows are 32 chunks = one 512-byte head slice, so every load and store is a coalesced 512
+// bytes), the TT x TT scores are per-lane partial dot products all-reduced over the 32 lanes, softmax and P V run in
+// registers.  No LDS, ~100 VGPRs, any occupancy the registers allow.
+template <int TT>
+__global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnSArgs a) {
+    constexpr int DH = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, hw = lane >> 5;
+    const long long unit = ((long long)blockIdx.x * 4 + wave) * 2 + hw;
+    const long long n_units = (long long)a.G * a.H;
+    const bool live = unit < n_units;
+    const long long uu = live ? unit : 0;
+    const int grp = (int)(uu / a.H), h = (int)(uu - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = qu.x; q_rs = qu.y; Sq = qu.z; k0 = ku.x; k_rs = ku.y; Sk = ku.z;
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    if (!live) { Sq = 0; Sk = 0; }
+    float4 qv[TT], kv[TT], vv[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        qv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.q + (q0 + (long long)t * q_rs) * a.ldq + h * DH + 4 * c) : z;
+        kv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.k + (k0 + (long long)t * k_rs) * a.ldk + h * DH + 4 * c) : z;
+        vv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.v + (k0 + (long long)t * k_rs) * a.ldv + h * DH + 4 * c) : z;
+    }
+    float sc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float p = (qv[i].x * kv[j].x + qv[i].y * kv[j].y) + (qv[i].z * kv[j].z + qv[i].w * kv[j].w);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);  // stays inside the 32-lane half
+            sc[i][j] = p * a.scale;
+        }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        if (i >= Sq) break;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) mx = j < Sk ? fmaxf(mx, sc[i][j]) : mx;
+        float den = 0.f, pj[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            pj[j] = j < Sk ? __expf(sc[i][j] - mx) : 0.f;
+            den += pj[j];
+        }
+        const float inv = 1.f / den;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const float w = pj[j] * inv;
+            o.x += w * vv[j].x; o.y += w * vv[j].y; o.z += w * vv[j].z; o.w += w * vv[j].w;
+        }
+        float* op = a.o + (q0 + (long long)i * q_rs) * a.ldo + h * DH;
+        if (!a.o_sp16) {
+            *reinterpret_cast<float4*>(op + 4 * c) = o;
+        } else {
+            // floats 4c .. 4c+3 are one half of the 8-wide block c >> 1: hi4 at 8 * (c & 1), lo4 sixteen bytes behind
+            const float v4[4] = {o.x, o.y, o.z, o.w};
+            half4v hi, lo;
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 h1, l1;
+                split_f16(v4[j], h1, l1);
+                hi[j] = h1; lo[j] = l1;
+                m = fmaxf(m, fabsf(v4[j]));
+            }
+            char* dst = reinterpret_cast<char*>(op + 8 * (c >> 1)) + 8 * (c & 1);
+            *reinterpret_cast<half4v*>(dst) = hi;
+            *reinterpret_cast<half4v*>(dst + 16) = lo;
+            if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+        }
+    }
+}
+
 template <int DH>
 int launch_s(const AttnSArgs& a0, hipStream_t s) {
     AttnSArgs a = a0;
@@ -185,6 +273,37 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
 }
 
 }  // namespace
+
+// sequences of <= 4 steps at head_dim 128, inference (no log-sum-exp, no dropout), f32 q / k / v
+bool attention_small_supported(const AttnDesc& d) {
+    return !d.lse && !d.drop.enabled && !d.in_sp16 && d.Sq <= 4 && d.Sk <= 4 && d.DH == 128;
+}
+
+static AttnSArgs make_sargs(const AttnDesc& d) {
+    AttnSArgs a;
+    a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    return a;
+}
+
+int launch_attention_small(const AttnDesc& d, hipStream_t s) {
+    const AttnSArgs a = make_sargs(d);
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    const long long units = (long long)d.G * d.H;
+    const unsigned blocks = (unsigned)((units + 7) / 8);
+    const int need = d.Sq > d.Sk ? d.Sq : d.Sk;
+    if (need <= 1) hipLaunchKernelGGL((attn_fwd_small_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (need <= 2) hipLaunchKernelGGL((attn_fwd_small_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_small_kernel<4>), dim3(blocks), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 // inference shapes only: f32 q / k / v, no log-sum-exp, no dropout, more than 16 keys or queries
 bool attention_simple_supported(const AttnDesc& d) {
