@@ -270,9 +270,12 @@ void sola_attn_set_variant(int v);
 void sola_attn_set_target_blocks(int v);
 void sola_iou_set_fused(int v);
 void sola_attn_set_split_min_keys(int v);
+void sola_attn_set_splitm(int v);
 void sola_pack_set_resample_lds(int v);
+static int g_stage_split_math = 0;
 extern "C" int sola_tune(const char* key, int value) {
     SOLA_ARG(key, "tune: null key");
+    if (!strcmp(key, "attn_stage_split_math")) { g_stage_split_math = value != 0; return SOLA_OK; }
     if (!strcmp(key, "gemm_variant")) { sola_gemm_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
@@ -286,6 +289,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
     if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "pack_resample_lds")) { sola_pack_set_resample_lds(value); return SOLA_OK; }
     sola_set_error("tune: unknown key '%s'", key);
     return SOLA_ERR_ARG;
@@ -771,6 +775,7 @@ extern "C" int sola_attention(const float* q, int ldq, const float* k, int ldk, 
     SOLA_ARG(q && k && v && o, "attention: null argument");
     AttnDesc d{q, k, v, o, ldq, ldk, ldv, ldo, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, lse};
     d.drop = g_stage_drop;
+    d.split_math = g_stage_split_math;  // sola_tune "attn_stage_split_math" (tests): the split precision mode's arithmetic
     return launch_attention(d, as_stream(stream_));
 }
 

@@ -590,6 +590,8 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
 
 }  // namespace
 
+int g_attn_splitm = 1;  // sola_tune "attn_splitm": 0 = exact-f32 MFMA attention also in the split precision mode (A/B)
+void sola_attn_set_splitm(int v) { g_attn_splitm = v; }
 void sola_attn_set_variant(int v) { g_attn_variant = v; }
 void sola_attn_set_target_blocks(int v) { g_attn_target_blocks = v; }
 
@@ -597,12 +599,17 @@ bool attention_simple_supported(const AttnDesc& d);
 int launch_attention_simple(const AttnDesc& d, hipStream_t s);
 bool attention_small_supported(const AttnDesc& d);
 int launch_attention_small(const AttnDesc& d, hipStream_t s);
+bool attention_splitm_supported(const AttnDesc& d);
+int launch_attention_splitm(const AttnDesc& d, hipStream_t s);
+extern int g_attn_splitm;
 
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
     // Sequences of <= 4 steps (motion attention at T <= 32): the register-only streaming shape (attn_simple.hip)
     if (g_attn_variant == 1 && attention_small_supported(d)) return launch_attention_small(d, s);
+    // split precision mode: f16-MFMA triples instead of the exact-f32 MFMA for every longer shape (attn_simple.hip)
+    if (g_attn_variant == 1 && g_attn_splitm && attention_splitm_supported(d)) return launch_attention_splitm(d, s);
     // High-occupancy shape (attn_simple.hip) where a unit has at most two 64-query blocks and at most 128 keys - the
     // inter-object attention: measured 278 vs 308 us at N = 64, 399 vs 452 us at N = 128 (tools/attn_probe.py, B = 256 / 32).
     // With many q-blocks per unit (object -> language: 206 vs 237 us) the resident-K/V loop of this file wins and stays.

@@ -259,6 +259,190 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnSArgs a) 
     }
 }
 
+// ---- split-f16 products on f32 inputs (the split precision mode) -----------------------------------------------------------
+// The exact-f32 MFMA (v_mfma_f32_16x16x4_f32: 32 cycles for 2 K flops) makes the shapes above co-bound by the matrix pipe:
+// the object -> language attention needs 94 us of it per launch next to 114 us of HBM time at the practical rate, and the two
+// do not overlap well at two to four waves per SIMD (measured 204 us = their sum).  In the split precision mode every other
+// contraction already runs as hi*hi + hi*lo + lo*hi on f16 MFMAs (22-bit products), and so can these: the K/V tile is
+// converted to (hi, lo) halfs while it is staged - K row-major, V TRANSPOSED ([d][key]) so that both MFMA A-fragments are
+// single 8-byte LDS reads - Q and P are split in registers, and a product costs 3 x 8 cycles instead of 4 x 32.  The halved
+// tile (38 KB for 32 keys) keeps four blocks per CU.  Same block decomposition, addressing and online softmax as above.
+__device__ __forceinline__ void split4h(const float4 v, half4v& hi, half4v& lo) {
+    const float in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 h1, l1;
+        split_f16(in[j], h1, l1);
+        hi[j] = h1; lo[j] = l1;
+    }
+}
+__device__ __forceinline__ f32x4 mfma3h(const half4v ah, const half4v al, const half4v bh, const half4v bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+}
+
+template <int DH, int TK>
+__global__ __launch_bounds__(256, 4) void attn_fwd_splitm_kernel(const AttnSArgs a) {
+    constexpr int NC = DH / 16;
+    constexpr int LDK = DH + 8;   // halfs: K rows, 8-byte fragment reads conflict-free (row pitch = 4 banks mod 64)
+    constexpr int LDT = TK + 8;   // halfs: V^T rows (one per head dim), pitch 20 dwords at TK = 32
+    constexpr int F4 = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_m[];
+    _Float16* Kh = smem_m;
+    _Float16* Kl = Kh + TK * LDK;
+    _Float16* Vh = Kl + TK * LDK;   // [DH][LDT]
+    _Float16* Vl = Vh + DH * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const long long unit = blockIdx.x / a.nqb;
+    const int qb = blockIdx.x - (int)unit * a.nqb;
+    const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = __builtin_amdgcn_readfirstlane(qu.x); q_rs = __builtin_amdgcn_readfirstlane(qu.y); Sq = __builtin_amdgcn_readfirstlane(qu.z);
+        k0 = __builtin_amdgcn_readfirstlane(ku.x); k_rs = __builtin_amdgcn_readfirstlane(ku.y); Sk = __builtin_amdgcn_readfirstlane(ku.z);
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    if (qb * 64 >= Sq) return;
+    const int qi = qb * 64 + wave * 16 + c16;
+    const bool q_ok = qi < Sq;
+    half4v qh[NC], ql[NC];
+    {
+        const float* qp = a.q + (q0 + (long long)qi * q_rs) * a.ldq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 v = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            split4h(v, qh[c], ql[c]);
+        }
+    }
+    f32x4 oacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int kt0 = 0; kt0 < Sk; kt0 += TK) {
+        const int nrows = min(TK, Sk - kt0);
+        const int nrows16 = (nrows + 15) & ~15;
+        if (kt0 > 0) __syncthreads();
+        for (int idx = tid; idx < nrows16 * F4; idx += 256) {
+            const int r = idx / F4, c4 = idx - r * F4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (r < nrows) {
+                const long long row = k0 + (long long)(kt0 + r) * k_rs;
+                kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+            }
+            half4v hi, lo;
+            split4h(kv, hi, lo);
+            *reinterpret_cast<half4v*>(&Kh[r * LDK + c4 * 4]) = hi;
+            *reinterpret_cast<half4v*>(&Kl[r * LDK + c4 * 4]) = lo;
+            split4h(vv, hi, lo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Vh[(c4 * 4 + j) * LDT + r] = hi[j];
+                Vl[(c4 * 4 + j) * LDT + r] = lo[j];
+            }
+        }
+        __syncthreads();
+        const int ntile = nrows16 >> 4;
+        f32x4 sc[TK / 16];
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t) {
+            if (t < ntile) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const int ko = (t * 16 + c16) * LDK + 4 * g4;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const half4v kh = *reinterpret_cast<const half4v*>(&Kh[ko + c * 16]);
+                    const half4v kl = *reinterpret_cast<const half4v*>(&Kl[ko + c * 16]);
+                    if (c & 1) a1 = mfma3h(kh, kl, qh[c], ql[c], a1);
+                    else a0 = mfma3h(kh, kl, qh[c], ql[c], a0);
+                }
+                const int key0 = kt0 + t * 16 + 4 * g4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
+            } else {
+                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[t][r] = __expf(sc[t][r] - m_new);
+                rs += sc[t][r];
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t) {
+            if (t < ntile) {
+                half4v ph, pl;
+                split4h(make_float4(sc[t][0], sc[t][1], sc[t][2], sc[t][3]), ph, pl);
+                const int vo = c16 * LDT + t * 16 + 4 * g4;  // V^T row d = 16c + c16, keys 16t + 4*g4 .. +3
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const half4v vh = *reinterpret_cast<const half4v*>(&Vh[vo + c * 16 * LDT]);
+                    const half4v vl = *reinterpret_cast<const half4v*>(&Vl[vo + c * 16 * LDT]);
+                    oacc[c] = mfma3h(vh, vl, ph, pl, oacc[c]);
+                }
+            }
+        }
+    }
+    if (!q_ok) return;
+    const float inv = 1.f / l_run;
+    float* op = a.o + (q0 + (long long)qi * q_rs) * a.ldo + h * DH;
+    if (!a.o_sp16) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        return;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        half4v hi, lo;
+        const float4 v = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        split4h(v, hi, lo);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        char* dst = reinterpret_cast<char*>(op + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+        *reinterpret_cast<half4v*>(dst) = hi;
+        *reinterpret_cast<half4v*>(dst + 16) = lo;
+    }
+    if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+}
+
+int launch_splitm(const AttnSArgs& a0, hipStream_t s) {
+    AttnSArgs a = a0;
+    constexpr int DH = 128, TK = 32;
+    a.nqb = (a.Sq + 63) / 64;
+    const long long blocks = (long long)a.G * a.H * a.nqb;
+    SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+    const size_t lds = ((size_t)2 * TK * (DH + 8) + (size_t)2 * DH * (TK + 8)) * sizeof(_Float16);
+    hipLaunchKernelGGL((attn_fwd_splitm_kernel<DH, TK>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 template <int DH>
 int launch_s(const AttnSArgs& a0, hipStream_t s) {
     AttnSArgs a = a0;
@@ -311,15 +495,19 @@ bool attention_simple_supported(const AttnDesc& d) {
 }
 
 int launch_attention_simple(const AttnDesc& d, hipStream_t s) {
-    AttnSArgs a;
-    a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o;
-    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
-    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
-    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
-    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
-    a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
-    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    const AttnSArgs a = make_sargs(d);
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     return d.DH == 128 ? launch_s<128>(a, s) : launch_s<64>(a, s);
+}
+
+// f32 q / k / v with the products evaluated as split-f16 triples (AttnDesc::split_math; head_dim 128, inference)
+bool attention_splitm_supported(const AttnDesc& d) {
+    return d.split_math && !d.lse && !d.drop.enabled && !d.in_sp16 && (d.Sq > 4 || d.Sk > 4) && d.DH == 128;
+}
+int launch_attention_splitm(const AttnDesc& d, hipStream_t s) {
+    const AttnSArgs a = make_sargs(d);
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    return launch_splitm(a, s);
 }

@@ -207,6 +207,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         ad.o_sp16 = 1;
         ad.in_sp16 = in_sp16;
         ad.guard = c->guard;
+        ad.split_math = 1;
         return launch_attention(ad, s);
     };
     // q/k/v leave the projection GEMM already split when the attention that reads them runs the split-f16 MFMA shape.

@@ -460,6 +460,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         ad.o_sp16 = sp ? 1 : 0;
         ad.in_sp16 = in_sp16;
         ad.guard = guard;
+        ad.split_math = sp ? 1 : 0;
         ad.q_units = qu; ad.k_units = ku;
         return launch_attention(ad, s);
     };

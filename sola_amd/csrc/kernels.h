@@ -102,6 +102,9 @@ struct AttnDesc {
     // optional, ragged batches: group g attends q_units[g] = (first row, row stride, Sq_g, -) over k_units[g] = (first row,
     // row stride, Sk_g, -); Sq / Sk are then the LARGEST lengths (they select the kernel shape and size the LDS)
     const int4 *q_units, *k_units;
+    // f32 q / k / v, but the caller's arithmetic is the split-f16 mode's: QK^T and PV may be evaluated as hi*hi + hi*lo + lo*hi
+    // on f16 MFMAs (22-bit products, f32 accumulate and softmax) instead of the exact-f32 MFMA (attn_simple.hip)
+    int split_math;
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 

@@ -170,3 +170,36 @@ def test_select_threshold():
     prob, pred = ops.select(cuda(x), 0.5)
     np.testing.assert_array_equal(pred.cpu().numpy(), sola_oracle.select(x).numpy())
     np.testing.assert_allclose(prob.cpu().numpy(), 1 / (1 + np.exp(-x.astype(np.float64))), atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,Tp", [(1, 64, 4), (2, 80, 1), (1, 130, 2), (1, 20, 25), (1, 7, 16)])
+def test_attention_split_math_on_f32_inputs(B, N, Tp):
+    """The split precision mode's attention (attn_fwd_splitm_kernel): f32 q / k / v, K and V converted to (hi, lo) halfs while
+    staged (V transposed), Q and P split in registers, products as f16-MFMA triples.  f32-class error against float64 in all
+    three layouts, including the online-softmax rescale over several 32-key tiles."""
+    from sola_amd import _lib
+
+    H, D = 8, 1024
+    rng = np.random.default_rng(N * Tp + 7)
+    q, k, v = (rnd(rng, B, N, Tp, D) for _ in range(3))
+    k[0, N // 2, 0] = 3.0 * q[0, 1, 0]  # a dominant key in a later tile: forces the rescale
+    q64, k64, v64 = (t.astype(np.float64) for t in (q, k, v))
+    qc, kc, vc = (cuda(t).reshape(B * N * Tp, D) for t in (q, k, v))
+    _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 1), "sola_tune")
+    try:
+        tr = lambda t: np.transpose(t, (0, 2, 1, 3)).reshape(B * Tp, N, D)
+        ref = _attn_ref(tr(q64), tr(k64), tr(v64), H).reshape(B, Tp, N, D).transpose(0, 2, 1, 3)
+        got = ops.attention(qc, kc, vc, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp))
+        assert_close(got.reshape(B, N, Tp, D), ref, rel=2e-5, name="obj attention (split math)")
+        if Tp > 4:
+            fl = lambda t: t.reshape(B * N, Tp, D)
+            ref = _attn_ref(fl(q64), fl(k64), fl(v64), H).reshape(B, N, Tp, D)
+            got = ops.attention(qc, kc, vc, B * N, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1))
+            assert_close(got.reshape(B, N, Tp, D), ref, rel=2e-5, name="motion attention (split math)")
+        for Wn in (48, 37, 70):
+            lk, lv = rnd(rng, B, Wn, D), rnd(rng, B, Wn, D)
+            ref = _attn_ref(q64.reshape(B, N * Tp, D), lk.astype(np.float64), lv.astype(np.float64), H).reshape(B, N, Tp, D)
+            got = ops.attention(qc, cuda(lk).reshape(B * Wn, D), cuda(lv).reshape(B * Wn, D), B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1))
+            assert_close(got.reshape(B, N, Tp, D), ref, rel=2e-5, name=f"o2l attention (split math) W={Wn}")
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 0), "sola_tune")

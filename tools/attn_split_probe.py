@@ -13,9 +13,9 @@ m = m.cuda().eval(); m.precision = "f16x3"; m.ws_policy = "always"
 B, N, T, L = 256, 64, 32, 16
 inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, N, T, L, 1000).items()}
 ref = None
-for mk, var in ((64, 3), (64, 1), (64, 3), (64, 1)):
+for mk, var in ((64, 0), (64, 1), (64, 0), (64, 1)):  # var: attn_splitm off / on
     _lib.check(_lib.lib().sola_tune(b"attn_split_min_keys", mk), "tune")
-    _lib.check(_lib.lib().sola_tune(b"attn_variant", var), "tune")
+    _lib.check(_lib.lib().sola_tune(b"attn_splitm", var), "tune")
     with torch.no_grad():
         for _ in range(3): sm, _ = m(inp["object_tokens"], inp["lang_tokens"])
         torch.cuda.synchronize()
@@ -26,5 +26,5 @@ for mk, var in ((64, 3), (64, 1), (64, 3), (64, 1)):
         dt = (time.perf_counter() - t0) / 10
     p = _lib.profile_read(True); _lib.profile_enable(False)
     if ref is None: ref = sm.clone()
-    print(json.dumps({"attn_split_min_keys": mk, "attn_variant": var, "ms_per_forward": round(dt * 1e3, 3), "attn_ms": round(p["attn"]["ms"] / 10, 3), "attn_launches": p["attn"]["launches"] // 10,
+    print(json.dumps({"attn_split_min_keys": mk, "attn_splitm": var, "ms_per_forward": round(dt * 1e3, 3), "attn_ms": round(p["attn"]["ms"] / 10, 3), "attn_launches": p["attn"]["launches"] // 10,
                       "gemm_ms": round(p["gemm_split256"]["ms"] / 10, 3), "max_diff_vs_first": float((sm - ref).abs().max())}))
