@@ -22,6 +22,22 @@ __global__ __launch_bounds__(256) void copy_units(const f4* __restrict__ in, f4*
         }
     }
 }
+// the attention core's mix: three input streams (q, k, v) of the same shape, one output stream
+__global__ __launch_bounds__(256) void add3_units(const f4* __restrict__ a, const f4* __restrict__ b, const f4* __restrict__ c, f4* __restrict__ out,
+                                                  long long n_units, int slices, int rows_per_unit, int row_stride, int piece_f4, int row_f4) {
+    for (long long u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const long long grp = u / slices;
+        const int sl = (int)(u - grp * slices);
+        const long long row0 = grp / row_stride * ((long long)rows_per_unit * row_stride) + grp % row_stride;
+        const int total = rows_per_unit * piece_f4;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int r = i / piece_f4, cc = i - r * piece_f4;
+            const long long off = (row0 + (long long)r * row_stride) * row_f4 + sl * piece_f4 + cc;
+            out[off] = a[off] + b[off] + c[off];
+        }
+    }
+}
 int main() {
     const long long rows = 65536LL * 4;  // 1 GiB of 4 KiB rows
     const int row_f4 = 256;
@@ -45,5 +61,25 @@ int main() {
                 printf("row stride %d rows, piece %4d B, %4d blocks: %7.1f us  %5.2f TB/s (read + write)\n", row_stride, piece, blocks, best * 1e3,
                        bytes / (best * 1e-3) / 1e12);
             }
+    {   // 3 reads : 1 write, 512-byte head slices, row stride 4 (the inter-object attention at T' = 4)
+        const long long rows3 = 65536LL;  // 256 MiB per tensor, 1 GiB moved: the headline launch
+        f4 *b, *c;
+        hipMalloc(&b, rows3 * row_f4 * 16); hipMalloc(&c, rows3 * row_f4 * 16);
+        hipMemset(b, 1, rows3 * row_f4 * 16); hipMemset(c, 1, rows3 * row_f4 * 16);
+        for (int row_stride : {1, 4})
+            for (int blocks : {1024, 2048, 8192}) {
+                const int piece_f4 = 32, slices = 8, rpu = 64;
+                const long long n_units = rows3 / rpu * slices;
+                float best = 1e9;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(add3_units, dim3(blocks), dim3(256), 0, 0, in, b, c, out, n_units, slices, rpu, row_stride, piece_f4, row_f4);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+                }
+                const double bytes = 4.0 * rows3 * row_f4 * 16;
+                printf("3 in + 1 out, row stride %d, 512 B pieces, %4d blocks: %7.1f us  %5.2f TB/s\n", row_stride, blocks, best * 1e3, bytes / (best * 1e-3) / 1e12);
+            }
+    }
     return 0;
 }
