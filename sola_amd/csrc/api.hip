@@ -271,6 +271,10 @@ void sola_attn_set_target_blocks(int v);
 void sola_iou_set_fused(int v);
 void sola_attn_set_split_min_keys(int v);
 void sola_attn_set_splitm(int v);
+void sola_attn_set_reg(int v);
+void sola_attn_set_reg_minw(int v);
+void sola_attn_set_res(int v);
+void sola_attn_set_res_tiles(int v);
 void sola_pack_set_resample_lds(int v);
 static int g_stage_split_math = 0;
 extern "C" int sola_tune(const char* key, int value) {
@@ -290,6 +294,10 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_reg_minw")) { sola_attn_set_reg_minw(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_res")) { sola_attn_set_res(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_res_tiles")) { sola_attn_set_res_tiles(value); return SOLA_OK; }
     if (!strcmp(key, "pack_resample_lds")) { sola_pack_set_resample_lds(value); return SOLA_OK; }
     sola_set_error("tune: unknown key '%s'", key);
     return SOLA_ERR_ARG;

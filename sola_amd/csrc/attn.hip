@@ -590,7 +590,8 @@ int launch_dh(const AttnArgs& a0, hipStream_t s) {
 
 }  // namespace
 
-int g_attn_splitm = 1;  // sola_tune "attn_splitm": 0 = exact-f32 MFMA attention also in the split precision mode (A/B)
+int g_attn_splitm = 0;  // sola_tune "attn_splitm": 1 = f16-MFMA triples on f32 inputs in the split precision mode (measured slower:
+                        // 1.49 vs 1.39 ms of attention per 256-sample step - every wave re-converts the K/V fragments it reads)
 void sola_attn_set_splitm(int v) { g_attn_splitm = v; }
 void sola_attn_set_variant(int v) { g_attn_variant = v; }
 void sola_attn_set_target_blocks(int v) { g_attn_target_blocks = v; }
@@ -601,6 +602,10 @@ bool attention_small_supported(const AttnDesc& d);
 int launch_attention_small(const AttnDesc& d, hipStream_t s);
 bool attention_splitm_supported(const AttnDesc& d);
 int launch_attention_splitm(const AttnDesc& d, hipStream_t s);
+bool attention_reg_supported(const AttnDesc& d);
+int launch_attention_reg(const AttnDesc& d, hipStream_t s);
+bool attention_res_supported(const AttnDesc& d);
+int launch_attention_res(const AttnDesc& d, hipStream_t s);
 extern int g_attn_splitm;
 
 int launch_attention(const AttnDesc& d, hipStream_t s) {
@@ -608,6 +613,10 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
     // Sequences of <= 4 steps (motion attention at T <= 32): the register-only streaming shape (attn_simple.hip)
     if (g_attn_variant == 1 && attention_small_supported(d)) return launch_attention_small(d, s);
+    // register-only shape (attn_reg.hip): every wave on its own 16-query tile, operands straight from global memory
+    if (g_attn_variant == 1 && attention_reg_supported(d)) return launch_attention_reg(d, s);
+    // few keys, many queries (object -> language): K/V resident in LDS, 8-wave blocks streaming 16-query tiles (attn_res.hip)
+    if (g_attn_variant == 1 && attention_res_supported(d)) return launch_attention_res(d, s);
     // split precision mode: f16-MFMA triples instead of the exact-f32 MFMA for every longer shape (attn_simple.hip)
     if (g_attn_variant == 1 && g_attn_splitm && attention_splitm_supported(d)) return launch_attention_splitm(d, s);
     // High-occupancy shape (attn_simple.hip) where a unit has at most two 64-query blocks and at most 128 keys - the

@@ -1,0 +1,225 @@
+// Few keys, many queries (object -> language: N*T' = 256 ... 2048 tokens against L + 32 <= 64 text tokens,
+// module/module.py:46-48): the unit's K and V (48 x 512 B each) are staged ONCE into LDS by an 8-wave block and stay there;
+// every wave then streams 16-query tiles - Q straight from global memory in the MFMA operand layout, K / V fragments from
+// LDS, O stored from registers - with nothing between the tiles but the loads themselves: no barrier after the staging one,
+// no cross-unit state, ~110 VGPRs.  Two blocks (16 waves) share a CU, so four waves per SIMD take turns on the matrix pipe
+// (82 us of exact-f32 MFMA per launch at the headline batch against ~115 us of HBM time at the practical rate) and cover each
+// other's Q-load latency.  attn.hip's resident-K/V loop does the same arithmetic with 256 VGPRs (it carries the next unit's
+// K/V through registers) at two 4-wave blocks per CU: 212 us per launch, 38 % of the HBM peak.
+// Same register layout as attn.hip (S^T = K Q^T, O^T = V^T P^T, v_mfma_f32_16x16x4_f32), strided groups or unit tables,
+// f32 or split-f16 output, optional log-sum-exp.  head_dim 128, at most 64 keys.  tools/attention.py:66-72.
+#include "kernels.h"
+
+namespace {
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+struct AttnQArgs {
+    const float *q, *k, *v;
+    float* o;
+    float* lse;
+    int ldq, ldk, ldv, ldo;
+    int G, H, Sq, Sk, inner, nchunk, tiles_per_wave;
+    long long q_outer, q_inner, q_rs;
+    long long k_outer, k_inner, k_rs;
+    float scale;
+    int o_sp16;
+    int* guard;
+    const int4 *q_units, *k_units;
+};
+
+constexpr int RES_NW = 8;           // waves per block
+constexpr int RES_LD = 128 + 4;     // LDS row pitch in floats: 528 B = 16 B past two bank rows, so the 16 keys of a ds_read_b128
+                                    // (K fragment) and the 4 keys of a ds_read_b32 (V^T fragment, keys 4 apart) hit distinct banks
+
+template <int NT>  // key tiles of 16: Sk <= 16 NT
+__device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, const float* Vs, const float* qp, float* op, float* lsep,
+                                         int Sk, int x, int g4, bool q_ok) {
+    // (requesting the next tile's Q rows into these registers right after the last QK^T MFMA, and the first tile's before the
+    // K/V staging, measured SLOWER - 217 vs 182 us per launch: the block's 16 waves per CU already cover the latency and the
+    // longer live ranges cost spills at 128 VGPRs)
+    float4 qf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + 16 * i);
+    f32x4 sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* kr = Ks + (16 * t + x) * RES_LD + 4 * g4;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const float4 k0 = *reinterpret_cast<const float4*>(kr + 16 * i);
+            const float4 k1 = *reinterpret_cast<const float4*>(kr + 16 * i + 16);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[i].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[i + 1].x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[i].y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[i + 1].y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[i].z, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[i + 1].z, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[i].w, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[i + 1].w, a1, 0, 0, 0);
+        }
+        const int key0 = 16 * t + 4 * g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[t][r] = __expf(sc[t][r] - mx);
+            rs += sc[t][r];
+        }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    f32x4 oacc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = Vs + (16 * t + 4 * g4 + r) * RES_LD + x;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * c], sc[t][r], oacc[c], 0, 0, 0);
+        }
+    if (!q_ok) return;
+    if (lsep && g4 == 0) *lsep = mx + logf(rs);
+    const float inv = 1.f / rs;
+    if (!a.o_sp16) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            *reinterpret_cast<float4*>(op + 16 * c + 4 * g4) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        return;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        half4v hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = oacc[c][j] * inv;
+            _Float16 h1, l1;
+            split_f16(v, h1, l1);
+            hi[j] = h1; lo[j] = l1;
+            m = fmaxf(m, fabsf(v));
+        }
+        char* dst = reinterpret_cast<char*>(op + 16 * c + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+        *reinterpret_cast<half4v*>(dst) = hi;
+        *reinterpret_cast<half4v*>(dst + 16) = lo;
+    }
+    if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+}
+
+__global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_f32_res_kernel(const AttnQArgs a) {
+    constexpr int DH = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem_r[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 15, g4 = lane >> 4;
+    // consecutive logical blocks (the chunks of a unit, the heads of a group) on one XCD; gridDim.x % 8 == 0
+    const unsigned lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long long unit = lb / a.nchunk;
+    if (unit >= (long long)a.G * a.H) return;
+    const int chunk = (int)(lb - unit * a.nchunk);
+    const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = __builtin_amdgcn_readfirstlane(qu.x); q_rs = __builtin_amdgcn_readfirstlane(qu.y); Sq = __builtin_amdgcn_readfirstlane(qu.z);
+        k0 = __builtin_amdgcn_readfirstlane(ku.x); k_rs = __builtin_amdgcn_readfirstlane(ku.y); Sk = __builtin_amdgcn_readfirstlane(ku.z);
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    const int qchunk = RES_NW * 16 * a.tiles_per_wave;
+    const int qbeg = chunk * qchunk;
+    if (qbeg >= Sq || Sk <= 0) return;  // block-uniform
+    const int rows = (Sk + 15) & ~15;
+    float* Ks = smem_r;
+    float* Vs = smem_r + rows * RES_LD;
+    // stage K and V: 32 float4 per row; rows past Sk are zero (a NaN there would survive the multiplication by p = 0)
+    for (int e = tid; e < rows * 32; e += RES_NW * 64) {
+        const int r = e >> 5, c = e & 31;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (r < Sk) {
+            kv = *reinterpret_cast<const float4*>(a.k + (k0 + (long long)r * k_rs) * a.ldk + h * DH + 4 * c);
+            vv = *reinterpret_cast<const float4*>(a.v + (k0 + (long long)r * k_rs) * a.ldv + h * DH + 4 * c);
+        }
+        *reinterpret_cast<float4*>(Ks + r * RES_LD + 4 * c) = kv;
+        *reinterpret_cast<float4*>(Vs + r * RES_LD + 4 * c) = vv;
+    }
+    __syncthreads();
+    const int nt = rows >> 4;
+    for (int j = 0; j < a.tiles_per_wave; ++j) {
+        const int qt0 = qbeg + (j * RES_NW + wave) * 16;  // the block's waves take neighbouring tiles
+        if (qt0 >= Sq) break;
+        const int qi = qt0 + x;
+        const bool q_ok = qi < Sq;
+        const long long qrow = q0 + (long long)(q_ok ? qi : Sq - 1) * q_rs;
+        const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
+        float* op = a.o + qrow * a.ldo + h * DH;
+        float* lsep = a.lse ? a.lse + qrow * a.H + h : nullptr;
+        if (nt == 3) res_tile<3>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
+        else if (nt == 4) res_tile<4>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
+        else if (nt == 2) res_tile<2>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
+        else res_tile<1>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
+    }
+}
+
+}  // namespace
+
+int g_attn_res = 1;              // sola_tune "attn_res": 0 = never this shape (A/B), 2 = also for ragged batches
+int g_attn_res_tiles = 0;        // 16-query tiles per wave and block (a block covers 8 x 16 x this many queries of a unit); 0 = up to
+                                 // 4, the chunks of a unit made equal (256 queries: one block of 2 tiles per wave; 320: 3; 2048: 4 blocks of 4)
+void sola_attn_set_res(int v) { g_attn_res = v; }
+void sola_attn_set_res_tiles(int v) { g_attn_res_tiles = v < 0 ? 0 : v; }
+
+// f32 q / k / v at head_dim 128, no dropout, at most 64 keys and enough queries per unit to pay for staging K/V
+bool attention_res_supported(const AttnDesc& d) {
+    if (d.q_units && g_attn_res != 2) return false;  // ragged batches: see attention_reg_supported
+    return g_attn_res && !d.drop.enabled && !d.in_sp16 && d.DH == 128 && d.Sk <= 64 && d.Sq >= 128;
+}
+
+int launch_attention_res(const AttnDesc& d, hipStream_t s) {
+    AttnQArgs a;
+    a.q = d.q; a.k = d.k; a.v = d.v; a.o = d.o; a.lse = d.lse;
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    if (g_attn_res_tiles > 0) {
+        a.tiles_per_wave = g_attn_res_tiles;
+    } else {
+        const int per_tile = RES_NW * 16, nch = (d.Sq + 4 * per_tile - 1) / (4 * per_tile);
+        a.tiles_per_wave = (d.Sq + per_tile * nch - 1) / (per_tile * nch);
+    }
+    const int qchunk = RES_NW * 16 * a.tiles_per_wave;
+    a.nchunk = (d.Sq + qchunk - 1) / qchunk;
+    const long long blocks = ((long long)d.G * d.H * a.nchunk + 7) / 8 * 8;
+    SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+    const size_t lds = (size_t)2 * ((d.Sk + 15) & ~15) * RES_LD * sizeof(float);
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(2 * 64 * RES_LD * sizeof(float))));
+        once.done(dev);
+    }
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    hipLaunchKernelGGL(attn_fwd_f32_res_kernel, dim3((unsigned)blocks), dim3(RES_NW * 64), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import sola_oracle  # noqa: E402
-from sola_amd import ops  # noqa: E402
+from sola_amd import _lib, ops  # noqa: E402
 
 
 def cuda(x):
@@ -117,9 +117,19 @@ def _attn_ref(q, k, v, H):
     return (p @ vh).transpose(0, 2, 1, 3).reshape(G, Sq, D)
 
 
+@pytest.fixture(params=[1, 0, 2], ids=["reg-auto", "reg-off", "reg-forced"])
+def attn_reg_mode(request):
+    """sola_tune attn_reg: 1 = default routing (register-only shape up to its key limit), 0 = LDS shapes only, 2 = register-only
+    shape for every key count (online softmax over 64-key passes)."""
+    _lib.check(_lib.lib().sola_tune(b"attn_reg", request.param), "sola_tune")
+    yield request.param
+    _lib.check(_lib.lib().sola_tune(b"attn_reg", 1), "sola_tune")
+
+
 @pytest.mark.parametrize("B,N,Tp,D", [(2, 5, 3, 128), (1, 64, 4, 1024), (2, 80, 1, 1024), (1, 7, 16, 128), (1, 130, 2, 128),
-                                      (1, 20, 25, 128), (2, 16, 4, 256), (1, 9, 5, 512)])
-def test_attention_three_layouts(B, N, Tp, D):
+                                      (1, 20, 25, 128), (2, 16, 4, 256), (1, 9, 5, 512), (1, 130, 2, 1024), (1, 20, 25, 1024),
+                                      (2, 7, 16, 1024), (1, 33, 3, 1024)])
+def test_attention_three_layouts(B, N, Tp, D, attn_reg_mode):
     H = 8
     rng = np.random.default_rng(N * Tp + D)
     q, k, v = (rnd(rng, B, N, Tp, D) for _ in range(3))
@@ -144,9 +154,10 @@ def test_attention_three_layouts(B, N, Tp, D):
         assert_close(got.reshape(B, N, Tp, D), ref, name=f"o2l attention W={Wn}")
 
 
-def test_attention_online_softmax_rescale():
+@pytest.mark.parametrize("D", [128, 1024])
+def test_attention_online_softmax_rescale(D, attn_reg_mode):
     """Force the running-max rescale: one key in a later 64-key tile dominates (cdna guide rule 26)."""
-    H, D, Sq, Sk = 8, 128, 20, 200
+    H, Sq, Sk = 8, 20, 200
     rng = np.random.default_rng(5)
     q, k, v = rnd(rng, 1, Sq, D), rnd(rng, 1, Sk, D), rnd(rng, 1, Sk, D)
     k[0, 150] = 6.0 * q[0, 3]  # spikes query 3 in the third tile
