@@ -2,7 +2,7 @@
 // module/module.py:46-48): the unit's K and V (48 x 512 B each) are staged ONCE into LDS by an 8-wave block and stay there;
 // every wave then streams 16-query tiles - Q straight from global memory in the MFMA operand layout, K / V fragments from
 // LDS, O stored from registers - with nothing between the tiles but the loads themselves: no barrier after the staging one,
-// no cross-unit state, ~110 VGPRs.  Two blocks (16 waves) share a CU, so four waves per SIMD take turns on the matrix pipe
+// no cross-unit state, ~120 VGPRs.  Two blocks (16 waves) share a CU, so four waves per SIMD take turns on the matrix pipe
 // (82 us of exact-f32 MFMA per launch at the headline batch against ~115 us of HBM time at the practical rate) and cover each
 // other's Q-load latency.  attn.hip's resident-K/V loop does the same arithmetic with 256 VGPRs (it carries the next unit's
 // K/V through registers) at two 4-wave blocks per CU: 212 us per launch, 38 % of the HBM peak.
@@ -28,19 +28,12 @@ struct AttnQArgs {
     const int4 *q_units, *k_units;
 };
 
-constexpr int RES_NW = 8;           // waves per block
 constexpr int RES_LD = 128 + 4;     // LDS row pitch in floats: 528 B = 16 B past two bank rows, so the 16 keys of a ds_read_b128
                                     // (K fragment) and the 4 keys of a ds_read_b32 (V^T fragment, keys 4 apart) hit distinct banks
 
 template <int NT>  // key tiles of 16: Sk <= 16 NT
-__device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, const float* Vs, const float* qp, float* op, float* lsep,
+__device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, const float* Vs, const float4 (&qf)[8], float* op, float* lsep,
                                          int Sk, int x, int g4, bool q_ok) {
-    // (requesting the next tile's Q rows into these registers right after the last QK^T MFMA, and the first tile's before the
-    // K/V staging, measured SLOWER - 217 vs 182 us per launch: the block's 16 waves per CU already cover the latency and the
-    // longer live ranges cost spills at 128 VGPRs)
-    float4 qf[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + 16 * i);
     f32x4 sc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -119,7 +112,10 @@ __device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, co
     if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
 }
 
-__global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_f32_res_kernel(const AttnQArgs a) {
+// NW waves per block, compiled for MINW waves per SIMD.  PF: the Q rows of a wave's next tile are requested into a second
+// register set before the current tile is computed (needs the 168 VGPRs of MINW = 3; at 128 it spills and loses).
+template <int NW, int MINW, bool PF>
+__global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_f32_res_kernel(const AttnQArgs a) {
     constexpr int DH = 128;
     extern __shared__ __attribute__((aligned(16))) float smem_r[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,14 +137,27 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_f32_res_kernel(const 
         k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
         q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
     }
-    const int qchunk = RES_NW * 16 * a.tiles_per_wave;
+    const int qchunk = NW * 16 * a.tiles_per_wave;
     const int qbeg = chunk * qchunk;
     if (qbeg >= Sq || Sk <= 0) return;  // block-uniform
+    // tile j of this wave: the block's waves take neighbouring tiles
+    auto tile_live = [&](int j) { return j < a.tiles_per_wave && qbeg + (j * NW + wave) * 16 < Sq; };  // wave-uniform
+    auto q_row = [&](int j) {
+        const int qi = qbeg + (j * NW + wave) * 16 + x;
+        return q0 + (long long)(qi < Sq ? qi : Sq - 1) * q_rs;
+    };
+    auto load_q = [&](float4 (&qf)[8], int j) {
+        const float* qp = a.q + q_row(j) * a.ldq + h * DH + 4 * g4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + 16 * i);
+    };
+    float4 qA[8], qB[8];
+    if (PF && tile_live(0)) load_q(qA, 0);  // travels while K/V are staged
     const int rows = (Sk + 15) & ~15;
     float* Ks = smem_r;
     float* Vs = smem_r + rows * RES_LD;
     // stage K and V: 32 float4 per row; rows past Sk are zero (a NaN there would survive the multiplication by p = 0)
-    for (int e = tid; e < rows * 32; e += RES_NW * 64) {
+    for (int e = tid; e < rows * 32; e += NW * 64) {
         const int r = e >> 5, c = e & 31;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (r < Sk) {
@@ -160,34 +169,72 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_f32_res_kernel(const 
     }
     __syncthreads();
     const int nt = rows >> 4;
-    for (int j = 0; j < a.tiles_per_wave; ++j) {
-        const int qt0 = qbeg + (j * RES_NW + wave) * 16;  // the block's waves take neighbouring tiles
-        if (qt0 >= Sq) break;
-        const int qi = qt0 + x;
-        const bool q_ok = qi < Sq;
-        const long long qrow = q0 + (long long)(q_ok ? qi : Sq - 1) * q_rs;
-        const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
+    auto compute = [&](const float4 (&qf)[8], int j) {
+        const int qi = qbeg + (j * NW + wave) * 16 + x;
+        const long long qrow = q_row(j);
         float* op = a.o + qrow * a.ldo + h * DH;
         float* lsep = a.lse ? a.lse + qrow * a.H + h : nullptr;
-        if (nt == 3) res_tile<3>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
-        else if (nt == 4) res_tile<4>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
-        else if (nt == 2) res_tile<2>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
-        else res_tile<1>(a, Ks, Vs, qp, op, lsep, Sk, x, g4, q_ok);
+        const bool q_ok = qi < Sq;
+        if (nt == 3) res_tile<3>(a, Ks, Vs, qf, op, lsep, Sk, x, g4, q_ok);
+        else if (nt == 4) res_tile<4>(a, Ks, Vs, qf, op, lsep, Sk, x, g4, q_ok);
+        else if (nt == 2) res_tile<2>(a, Ks, Vs, qf, op, lsep, Sk, x, g4, q_ok);
+        else res_tile<1>(a, Ks, Vs, qf, op, lsep, Sk, x, g4, q_ok);
+    };
+    if (PF) {
+        for (int j = 0; tile_live(j); j += 2) {
+            if (tile_live(j + 1)) load_q(qB, j + 1);
+            compute(qA, j);
+            if (!tile_live(j + 1)) break;
+            if (tile_live(j + 2)) load_q(qA, j + 2);
+            compute(qB, j + 1);
+        }
+    } else {
+        for (int j = 0; tile_live(j); ++j) {
+            load_q(qA, j);
+            compute(qA, j);
+        }
     }
 }
 
 }  // namespace
 
 int g_attn_res = 1;              // sola_tune "attn_res": 0 = never this shape (A/B), 2 = also for ragged batches
-int g_attn_res_tiles = 0;        // 16-query tiles per wave and block (a block covers 8 x 16 x this many queries of a unit); 0 = up to
-                                 // 4, the chunks of a unit made equal (256 queries: one block of 2 tiles per wave; 320: 3; 2048: 4 blocks of 4)
+int g_attn_res_tiles = 0;        // 16-query tiles per wave and block; 0 = up to 4, the chunks of a unit made equal
+int g_attn_res_shape = 0;        // 0 = auto, 1 = 8 waves / 128 VGPRs / no prefetch, 2 = 4 waves / 168 VGPRs / next-tile prefetch
 void sola_attn_set_res(int v) { g_attn_res = v; }
 void sola_attn_set_res_tiles(int v) { g_attn_res_tiles = v < 0 ? 0 : v; }
+void sola_attn_set_res_shape(int v) { g_attn_res_shape = v; }
 
 // f32 q / k / v at head_dim 128, no dropout, at most 64 keys and enough queries per unit to pay for staging K/V
 bool attention_res_supported(const AttnDesc& d) {
     if (d.q_units && g_attn_res != 2) return false;  // ragged batches: see attention_reg_supported
     return g_attn_res && !d.drop.enabled && !d.in_sp16 && d.DH == 128 && d.Sk <= 64 && d.Sq >= 128;
+}
+
+template <int NW, int MINW, bool PF>
+static int launch_res(AttnQArgs a, const AttnDesc& d, hipStream_t s) {
+    const int max_tiles = PF ? 8 : 4;
+    if (g_attn_res_tiles > 0) {
+        a.tiles_per_wave = g_attn_res_tiles;
+    } else {
+        const int per_tile = NW * 16, nch = (d.Sq + max_tiles * per_tile - 1) / (max_tiles * per_tile);
+        a.tiles_per_wave = (d.Sq + per_tile * nch - 1) / (per_tile * nch);
+    }
+    const int qchunk = NW * 16 * a.tiles_per_wave;
+    a.nchunk = (d.Sq + qchunk - 1) / qchunk;
+    const long long blocks = ((long long)d.G * d.H * a.nchunk + 7) / 8 * 8;
+    SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+    const size_t lds = (size_t)2 * ((d.Sk + 15) & ~15) * RES_LD * sizeof(float);
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_res_kernel<NW, MINW, PF>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * RES_LD * sizeof(float))));
+        once.done(dev);
+    }
+    hipLaunchKernelGGL((attn_fwd_f32_res_kernel<NW, MINW, PF>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
 }
 
 int launch_attention_res(const AttnDesc& d, hipStream_t s) {
@@ -199,27 +246,11 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
-    if (g_attn_res_tiles > 0) {
-        a.tiles_per_wave = g_attn_res_tiles;
-    } else {
-        const int per_tile = RES_NW * 16, nch = (d.Sq + 4 * per_tile - 1) / (4 * per_tile);
-        a.tiles_per_wave = (d.Sq + per_tile * nch - 1) / (per_tile * nch);
-    }
-    const int qchunk = RES_NW * 16 * a.tiles_per_wave;
-    a.nchunk = (d.Sq + qchunk - 1) / qchunk;
-    const long long blocks = ((long long)d.G * d.H * a.nchunk + 7) / 8 * 8;
-    SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
-    const size_t lds = (size_t)2 * ((d.Sk + 15) & ~15) * RES_LD * sizeof(float);
-    static DeviceOnce once;
-    int dev;
-    if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(2 * 64 * RES_LD * sizeof(float))));
-        once.done(dev);
-    }
+    a.tiles_per_wave = 1; a.nchunk = 1;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
-    hipLaunchKernelGGL(attn_fwd_f32_res_kernel, dim3((unsigned)blocks), dim3(RES_NW * 64), lds, s, a);
-    SOLA_LAUNCH_CHECK();
-    return SOLA_OK;
+    // measured at 256 samples (256 queries x 48 keys per unit, tools/attn_probe3.py): 8 waves without prefetch 183 us, three
+    // 4-wave blocks per CU with the next tile's Q prefetched 191 us, attn.hip's resident loop 206 us
+    if (g_attn_res_shape == 2) return launch_res<4, 3, true>(a, d, s);
+    return launch_res<8, 4, false>(a, d, s);
 }

@@ -3,7 +3,8 @@ import collections, csv, glob, re, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(gemm_\w+(<[^>]*>)?)", r["Kernel_Name"])
+        pat = sys.argv[2] if len(sys.argv) > 2 else "gemm"
+        m = re.search(r"(" + pat + r"_\w+(<[^>]*>)?)", r["Kernel_Name"])
         if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)
