@@ -222,7 +222,7 @@ def cpu_baseline(cfg, sd, N, T, L, budget_s):
 
 def training_leg(cfg, sd, dev, B, N, T, L, steps):
     """Outside the timed region, rank 0 at N=1 only: one optimizer step of the same network (sola_forward_train + losses +
-    sola_backward + gradient norms / clip + AdamW) at up to 64 samples, exact f32 and with the split-f16 GEMMs."""
+    sola_backward + gradient norms / clip + AdamW) at up to 64 samples: exact f32, split-f16 GEMMs, f16-operand GEMMs."""
     from sola_amd import synth
     from sola_amd.loss import track_selection_losses
     from sola_amd.module import LanguageAlignedTrackSelectionModule
@@ -247,21 +247,25 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
            "what": "forward_train + BCE/alignment losses + backward + clip + AdamW; dropout on, one GPU",
            "gflop_per_sample_fwd_bwd": round(3 * fl["total"] / 1e9, 2)}
     sync = lambda: torch.cuda.synchronize(dev)
-    for prec in ("f32", "f16x3"):
+    for prec in ("f32", "f16x3", "f16"):
         m.precision = prec
         dt = timed(step, steps, sync)
         _dtp, prof = profiled(step, max(2, steps // 2), sync, warmup=0)
         kms = kernel_ms(prof, max(2, steps // 2))
-        gk = "gemm_split256" if prec == "f16x3" else "gemm128"
+        gk = "gemm128" if prec == "f32" else "gemm_split256"
         g = prof[gk]
         alg = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        peak = F16_MFMA_PEAK_TFLOPS if prec == "f16x3" else F32_MFMA_PEAK_TFLOPS
+        peak = F32_MFMA_PEAK_TFLOPS if prec == "f32" else F16_MFMA_PEAK_TFLOPS
         res[prec] = {"value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "model_tflops": round(3 * fl["total"] * B / dt / 1e12, 1),
                      "kernel_ms_per_step": kms,
                      "roofline": {"kernel": gk + " (forward, dX and dW GEMMs of the step)", "bound": "mfma", "achieved": round(alg, 2),
                                   "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
                                   **({"achieved_executed": round(3 * alg, 2), "frac_executed": round(3 * alg / peak, 4)} if prec == "f16x3" else {}),
                                   "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2)}}
+        if prec == "f16":
+            res[prec]["what"] = ("mixed precision (BASELINE config C2): every GEMM of the step on plain f16 casts of the f32 activations / "
+                                 "gradients, f32 accumulation, ONE MFMA per product; everything else f32.  Reduced precision: losses within "
+                                 "1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py)")
     del m, opt
     torch.cuda.empty_cache()
     return res

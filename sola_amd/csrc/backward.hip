@@ -64,7 +64,7 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
     a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, (size_t)p.B * p.Tp)), (int)D) / sizeof(float) + 64);
-    if (c->precision == 1 && p.M >= g_train_split_min_rows) {  // split-f16 dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
+    if (c->precision >= 1 && p.M >= g_train_split_min_rows) {  // split-f16 / f16-operand dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
         a.add("scal", 64);
@@ -132,7 +132,20 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     float* tn = ar.get("tn");
     const size_t tn_bytes = ar.total - ar.off.at("tn");  // upper bound; launch_gemm_tn checks its own need
     float* wt = ar.get("wt");
-    const bool split = c->precision == 1 && ar.off.count("dy_sp") != 0;
+    // split: every GEMM of the backward on f16 MFMAs - (hi, lo) operand pairs, three products (precision 1), or plain f16
+    // operands, one product (precision 2: "pure"; mixed precision - activations, gradients and accumulation stay f32)
+    const bool split = c->precision >= 1 && ar.off.count("dy_sp") != 0;
+    const bool pure = c->precision == 2;
+    const int lowp_arith = pure ? 2 : 1;
+    auto cast_scaled = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
+        return pure ? launch_cast_f16_scaled(in, ld, out, K, rows, K, scal, s) : launch_cast_sp16_scaled(in, ld, out, K, rows, K, scal, s);
+    };
+    auto cast_auto = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
+    };
+    auto cast_fixed = [&](const float* in, int ld, float* out, long long rows, int K, float scale) -> int {
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
+    };
 
     // ---- helpers ----------------------------------------------------------------------------------------------
     // dW[N_out, K_in] = dY^T X, db = colsum(dY)
@@ -167,7 +180,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in, float* sc = nullptr, bool db_done = false) -> int {
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
-            d.scal = sc;
+            d.scal = sc; d.pure = pure;
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
@@ -189,15 +202,15 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         d.nprob = 1;
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
         d.M = rows; d.N = k_in; d.K = n_cat; d.lda = ldy; d.ldr = k_in; d.ldc = k_in;
-        if (split && n_cat % 32 == 0 && ldy % 4 == 0) {
-            // split-f16: dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal
-            // range), the transposed weights with the fixed 2^6; the epilogue undoes both
+        if (split && n_cat % (pure ? 64 : 32) == 0 && ldy % 4 == 0) {
+            // dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal range), the
+            // transposed weights with the fixed 2^6; the epilogue undoes both
             float* scal = sc ? sc : ar.get("scal");
-            if (sc) SOLA_TRY(launch_cast_sp16_scaled(dY, ldy, ar.get("dy_sp"), n_cat, rows, n_cat, scal, s));
-            else SOLA_TRY(launch_cast_sp16_auto(dY, ldy, ar.get("dy_sp"), n_cat, rows, n_cat, scal, s));
-            SOLA_TRY(launch_cast_sp16(wt, n_cat, ar.get("wt_sp"), n_cat, k_in, n_cat, kLinScale, s));
+            if (sc) SOLA_TRY(cast_scaled(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
+            else SOLA_TRY(cast_auto(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
+            SOLA_TRY(cast_fixed(wt, n_cat, ar.get("wt_sp"), k_in, n_cat, kLinScale));
             d.p[0].A = ar.get("dy_sp"); d.p[0].W = ar.get("wt_sp");
-            d.lda = n_cat; d.arith = 1; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
+            d.lda = n_cat; d.arith = lowp_arith; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
         }
         return launch_gemm(d, s);
     };
@@ -385,7 +398,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes(rows, g.cout, g.k * g.cin, 1)) {
             SOLA_TRY(stats(dy, g.cout, rows, g.cout, 8, &scc));
             GemmTnSplitDesc d{};
-            d.scal = scc;
+            d.scal = scc; d.pure = pure;
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
@@ -409,14 +422,15 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             // split-f16: z[(r,to)][kk*cin+ci] = sum_co dY[(r,to)][co] w_std[co][kk*cin+ci] in ONE NT GEMM over the output steps (a
             // strided conv's gather form would multiply zeros for every skipped step), then the k taps are gathered into dX
             float* scal = scc ? scc : ar.get("scal");
-            if (scc) SOLA_TRY(launch_cast_sp16_scaled(dy, g.cout, ar.get("dy_sp"), g.cout, rows, g.cout, scal, s));
-            else SOLA_TRY(launch_cast_sp16_auto(dy, g.cout, ar.get("dy_sp"), g.cout, rows, g.cout, scal, s));
-            SOLA_TRY(launch_cast_sp16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
+            if (scc) SOLA_TRY(cast_scaled(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
+            else SOLA_TRY(cast_auto(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
+            if (pure) SOLA_TRY(launch_cast_f16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
+            else SOLA_TRY(launch_cast_sp16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
             GemmDesc d{};
             d.nprob = 1;
             d.p[0] = GemmProblem{ar.get("dy_sp"), ar.get("wt_sp"), nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
             d.M = rows; d.N = g.k * g.cin; d.K = g.cout; d.lda = g.cout; d.ldc = g.k * g.cin;
-            d.arith = 1; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
+            d.arith = lowp_arith; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
             SOLA_TRY(launch_gemm(d, s));
             if (g.k > 1) SOLA_TRY(launch_col2im(ar.get("zcol"), dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s));
         } else {

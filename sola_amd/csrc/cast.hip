@@ -255,6 +255,17 @@ int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long
     return SOLA_OK;
 }
 
+// the cast half of launch_cast_f16 with a data-dependent scale: scal[0] already holds max|in| (launch_amax_colsum)
+int launch_cast_f16_scaled(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && scal && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_f16_scaled: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
+    const long long n = rows * (K / 8);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 6.0 * rows * K);
+    hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out,
+                       0.f, scal, 13, nullptr);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s) {
     SOLA_ARG(in && out && scal && n > 0 && rows > 0 && K > 0 && K % 8 == 0, "cast_f16_auto_multi: n=%d rows=%d K=%d", n, rows, K);
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 10.0 * n * rows * K);

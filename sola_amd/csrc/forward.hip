@@ -38,7 +38,7 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
         p.add("conv5_sp", p.M, D);
         p.add("lang_sp", (int64_t)B * p.W, D);
     }
-    if (train && c->precision == 1 && p.M >= g_train_split_min_rows) {
+    if (train && c->precision >= 1 && p.M >= g_train_split_min_rows) {
         // split-f16 training forward: every GEMM input is cast into one of two scratch buffers right before its launch
         // (the f32 activations stay where the backward reads them)
         int64_t amax = std::max<int64_t>(R * T * c->cfg.object_token_dim, std::max<int64_t>((int64_t)p.M * D, (int64_t)B * p.W * D));
@@ -97,7 +97,17 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     // training forward in the split-f16 mode (sola_set_precision 1): the same GEMM kernels as forward_fast.hip on casts of
     // the f32 activations, everything the backward reads stays f32
     // (from ~1024 token rows on: below that the step is launch-bound and the extra cast launches cost more than the GEMMs gain)
-    const bool split = train && c->precision == 1 && D % 32 == 0 && c->cfg.object_token_dim % 32 == 0 && p.M >= g_train_split_min_rows;
+    // precision 2 ("pure"): the same structure with plain f16 GEMM operands, ONE MFMA per product - mixed-precision training:
+    // activations, statistics, softmax, accumulation and everything the backward reads stay f32
+    const bool pure = c->precision == 2;
+    const bool split = train && c->precision >= 1 && D % (pure ? 64 : 32) == 0 && c->cfg.object_token_dim % (pure ? 64 : 32) == 0 && p.M >= g_train_split_min_rows;
+    const int lowp_arith = pure ? 2 : 1;
+    auto cast_auto = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
+    };
+    auto cast_fixed = [&](const float* in, int ld, float* out, long long rows, int K, float scale) -> int {
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
+    };
 
     // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
     if (c->ws_dirty || c->ws_every_forward || train) {
@@ -110,7 +120,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         if (split)
             for (int i = 0; i < 6; ++i) {
                 const int kc = c->conv[i].k * c->conv[i].cin;
-                SOLA_TRY(launch_cast_sp16(c->ws_buf + c->ws_off[i], kc, c->ws16_buf + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, s));
+                float* dst = pure ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(c->ws16_buf) + c->ws_off[i]) : c->ws16_buf + c->ws_off[i];
+                SOLA_TRY(cast_fixed(c->ws_buf + c->ws_off[i], kc, dst, c->conv[i].cout, kc, 1.f));
             }
         c->ws_dirty = false;
     }
@@ -121,7 +132,10 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             if (attn.size() >= strlen(kAttnLong[a]) && attn.compare(attn.size() - strlen(kAttnLong[a]), std::string::npos, kAttnLong[a]) == 0) a3 = a;
         return (l * 3 + a3) * 4 + proj;
     };
-    auto lin16 = [&](const std::string& attn, int proj) -> const float* { return c->lin16_buf + (size_t)lin_idx(attn, proj) * D * D; };
+    auto lin16 = [&](const std::string& attn, int proj) -> const float* {  // split pairs: D*D floats per matrix; plain f16: D*D halfs
+        return pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->lin16_buf) + (size_t)lin_idx(attn, proj) * D * D)
+                    : c->lin16_buf + (size_t)lin_idx(attn, proj) * D * D;
+    };
     auto lin_inv = [&](const std::string& attn, int proj) -> const float* { return c->scal_buf + 2 * (2 + lin_idx(attn, proj)) + 1; };
     if (split) SOLA_TRY(sola_refresh_lin16(c, s));
     float* const sp_a = split ? buf("sp_a") : nullptr;
@@ -141,15 +155,16 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
-        if (split && g.cin % 32 == 0) {
+        if (split && g.cin % (pure ? 64 : 32) == 0) {
             if (i == 0) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip)
-                SOLA_TRY(launch_cast_sp16_auto(x, g.cin, sp_a, g.cin, (long long)R * t_in, g.cin, c->scal_pair(0), s));
+                SOLA_TRY(cast_auto(x, g.cin, sp_a, (long long)R * t_in, g.cin, c->scal_pair(0)));
                 gd.out_scale_dev = c->scal_pair(0) + 1;
             } else {
-                SOLA_TRY(launch_cast_sp16(x, g.cin, sp_a, g.cin, (long long)R * t_in, g.cin, 1.f, s));
+                SOLA_TRY(cast_fixed(x, g.cin, sp_a, (long long)R * t_in, g.cin, 1.f));
             }
-            gd.p[0].A = sp_a; gd.p[0].W = c->ws16_buf + c->ws_off[i];
-            gd.arith = 1; gd.out_scale = 1.f;
+            gd.p[0].A = sp_a;
+            gd.p[0].W = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->ws16_buf) + c->ws_off[i]) : c->ws16_buf + c->ws_off[i];
+            gd.arith = lowp_arith; gd.out_scale = 1.f;
         }
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
@@ -197,14 +212,14 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                 if (at < 0) {
                     at = nsrc++;
                     src[at] = as[j];
-                    if (a_scal) SOLA_TRY(launch_cast_sp16_auto(as[j], D, dst[at], D, rows, D, a_scal, s));
-                    else SOLA_TRY(launch_cast_sp16(as[j], D, dst[at], D, rows, D, 1.f, s));
+                    if (a_scal) SOLA_TRY(cast_auto(as[j], D, dst[at], rows, D, a_scal));
+                    else SOLA_TRY(cast_fixed(as[j], D, dst[at], rows, D, 1.f));
                 }
                 gd.p[j].A = dst[at];
                 gd.p[j].W = lin16(attn, first_proj + j);
                 gd.p[j].scale_dev = lin_inv(attn, first_proj + j);
             }
-            gd.arith = 1; gd.out_scale = 1.f;
+            gd.arith = lowp_arith; gd.out_scale = 1.f;
             if (a_scal) gd.out_scale_dev = a_scal + 1;
         }
         return launch_gemm(gd, s);
@@ -216,9 +231,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split) {
-            SOLA_TRY(launch_cast_sp16(ao, D, sp_a, D, M, D, 1.f, s));
+            SOLA_TRY(cast_fixed(ao, D, sp_a, M, D, 1.f));
             gd.p[0].A = sp_a; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
-            gd.arith = 1; gd.out_scale = 1.f;
+            gd.arith = lowp_arith; gd.out_scale = 1.f;
         }
         return launch_gemm(gd, s);
     };

@@ -420,8 +420,8 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.rowmap = d.conv == 1 ? d.rowmap : nullptr;
     a.tiles_m = a.tiles_n = a.xcd_remap = 0;
-    a.out_scale = d.arith == 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
-    a.out_scale_dev = d.arith == 1 ? d.out_scale_dev : nullptr;
+    a.out_scale = d.arith >= 1 && d.out_scale != 0.f ? d.out_scale : 1.f;
+    a.out_scale_dev = d.arith >= 1 ? d.out_scale_dev : nullptr;
     a.r_sp16 = d.r_sp16;
     a.c_sp16 = d.arith == 1 ? d.c_sp16 : 0;
     a.ksplit = 1; a.kt_per = 0; a.part = nullptr;
@@ -430,11 +430,23 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs
     if (d.arith == 2) {  // plain f16 operands: direct-to-LDS kernels for every grid size
-        SOLA_ARG(gemm_split_glds_supported(d) && d.ksplit <= 1, "f16 gemm: K %% 64, row pitch %% 16 (Cin %% 64 for convs) required; K=%d lda=%d Cin=%d", d.K, d.lda, d.Cin);
+        SOLA_ARG(gemm_split_glds_supported(d), "f16 gemm: K %% 64, row pitch %% 16 (Cin %% 64 for convs) required; K=%d lda=%d Cin=%d", d.K, d.lda, d.Cin);
         SOLA_ARG(!d.c_f16 || (d.N % 4 == 0 && d.ldc % 4 == 0), "f16 gemm: f16 output needs N %% 4 == 0 and ldc %% 4 == 0");
         SOLA_ARG(!d.p[0].R || !d.r_f16 || d.ldr % 4 == 0, "f16 gemm: f16 residual needs ldr %% 4 == 0");
-        SolaProfScope prof(gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
+        SolaProfScope prof(d.ksplit > 1 || gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                            2.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
+        if (d.ksplit > 1) {  // weight gradients (gemm_tn_split.hip): K ranges as work items of the persistent kernel + ordered reduce
+            SOLA_ARG(d.splitk_ws && d.K % (64 * d.ksplit) == 0 && d.K / 64 / d.ksplit >= 2 && d.N % 4 == 0 && d.ldc % 4 == 0 && !d.c_f16 &&
+                         d.splitk_bytes >= (size_t)d.nprob * d.ksplit * d.M * d.N * sizeof(float),
+                     "f16 gemm: split-K over %d ranges needs K %% (64 * ksplit) == 0 (K=%d) and a scratch of nprob*ksplit*M*N floats", d.ksplit, d.K);
+            a.ksplit = d.ksplit;
+            a.part = d.splitk_ws;
+            SOLA_TRY(launch_gemm_split_glds(d, s));
+            const long long quads = (long long)a.M * (a.N >> 2);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256), 1, d.nprob), dim3(256), 0, s, a);
+            SOLA_LAUNCH_CHECK();
+            return SOLA_OK;
+        }
         return launch_gemm_split_glds(d, s);
     }
     const bool glds = d.arith == 1 && (big || g_gemm_glds_force || d.ksplit > 1) && g_gemm_glds && gemm_split_glds_supported(d);

@@ -869,14 +869,17 @@ static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);
     return rmode == 2 ? launch_persist_t<false, 2, 0>(a, M, N, nprob, s) : launch_persist_t<false, 1, 0>(a, M, N, nprob, s);
 }
-// plain f16 operands (16-bit storage mode): C is f16 (or f32 for tests), the residual f16
+// plain f16 operands: C and the residual f16 (16-bit storage mode, inference) or both f32 (f16-operand training: the
+// activations stay f32, only the GEMM inputs are cast); split-K partial sums are always f32 without residual
 template <bool CONV>
 static int launch_persist_pure(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0, true>(a, M, N, nprob, s);
     const bool has_r = a.p[0].R != nullptr;
     if (a.c_f16) {
         if (CONV || !has_r) return launch_persist_t<CONV, 0, 2, true>(a, M, N, nprob, s);
         return launch_persist_t<false, 3, 2, true>(a, M, N, nprob, s);
     }
+    if (has_r && !CONV) return launch_persist_t<false, 1, 0, true>(a, M, N, nprob, s);
     return launch_persist_t<CONV, 0, 0, true>(a, M, N, nprob, s);
 }
 
@@ -889,7 +892,9 @@ static bool persist_uniform(const GldsArgs& a, int conv) {
 
 template <bool CONV>
 static int launch_shape_pure(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
-    const bool r_ok = !a.p[0].R || (a.r_f16 && a.c_f16 && !CONV);  // the persistent kernel's residual mode of this arithmetic
+    if (a.ksplit > 1) return launch_persist_pure<CONV>(a, M, N, nprob, s);
+    // the persistent kernel's residual modes of this arithmetic: f16 residual into an f16 output, f32 into f32
+    const bool r_ok = !a.p[0].R || (!CONV && ((a.r_f16 && a.c_f16) || (!a.r_f16 && !a.c_f16)));
     if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV) && r_ok) return launch_persist_pure<CONV>(a, M, N, nprob, s);
     if (shape == 4) return launch_glds<4, 2, 4, CONV, true>(a, M, N, nprob, s);
     return launch_glds<2, 2, 2, CONV, true>(a, M, N, nprob, s);

@@ -25,6 +25,8 @@ __device__ __forceinline__ float auto_scale_t(unsigned amax_bits) {  // as cast.
 // `rows` up to ld_out are written as zeros.  Tile = 128 rows x 64 columns through LDS.
 // With conv_T_out > 0 the input is the implicit im2col of a channels-last conv for ONE tap: row m = (r, to) reads source row
 // r * conv_T_in + to * conv_stride + conv_toff (tap - pad), zeros outside [0, conv_T_in).
+// PURE: the output is plain _Float16 ([cols][ld_out halfs]) for the one-MFMA-per-product GEMM (GemmDesc::arith 2).
+template <bool PURE>
 __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                                           int ld_in, long long ld_out, float* __restrict__ scal, int conv_T_in,
                                                           int conv_T_out, int conv_stride, int conv_toff) {
@@ -79,12 +81,17 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
         for (int e = 0; e < 8; ++e) {
             const float v = tile[8 * b + e][c];
             _Float16 h1, l1;
-            split_f16(v, h1, l1);
+            if (PURE) { h1 = (_Float16)v; l1 = (_Float16)0.f; }
+            else split_f16(v, h1, l1);
             hi[e] = h1; lo[e] = l1;
         }
-        half8* o = reinterpret_cast<half8*>(out + (long long)(c0 + c) * ld_out + r0 + 8 * b);
-        o[0] = hi;
-        o[1] = lo;
+        if (PURE) {
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(out) + (long long)(c0 + c) * ld_out + r0 + 8 * b) = hi;
+        } else {
+            half8* o = reinterpret_cast<half8*>(out + (long long)(c0 + c) * ld_out + r0 + 8 * b);
+            o[0] = hi;
+            o[1] = lo;
+        }
     }
 }
 
@@ -111,18 +118,20 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z
     *reinterpret_cast<float4*>(dx + i * 4) = acc;
 }
 
-int cast_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
+int cast_t(bool pure, const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
            int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0) {
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * cols);
-    hipLaunchKernelGGL(cast_sp16_t_kernel, dim3((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64)), dim3(256), 0, s, in, out, rows,
-                       cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (pure ? 6.0 : 8.0) * rows * cols);
+    const dim3 grid((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64));
+    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff);
+    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
-void geometry(int M, int& ksplit, long long& Mp) {
+void geometry(int M, int& ksplit, long long& Mp, bool pure = false) {
     ksplit = M >= 8192 ? 16 : (M >= 2048 ? 8 : (M >= 512 ? 4 : 2));
-    const long long q = 64LL * ksplit;  // every range at least two 32-wide k-tiles; a multiple of the 128-row cast tile
+    // every range at least two k-tiles (32 pairs or 64 halfs wide); a multiple of the 128-row cast tile
+    const long long q = (pure ? 128LL : 64LL) * ksplit;
     Mp = (M + q - 1) / q * q;
 }
 
@@ -130,7 +139,12 @@ void geometry(int M, int& ksplit, long long& Mp) {
 
 int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
     SOLA_ARG(in && out && rows > 0 && cols > 0 && ld_out % 128 == 0 && ld_out >= rows, "cast_sp16_t: rows=%d ld_out=%lld", rows, ld_out);
-    return cast_t(in, ld_in, out, ld_out, rows, cols, scal, s);
+    return cast_t(false, in, ld_in, out, ld_out, rows, cols, scal, s);
+}
+
+int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
+    SOLA_ARG(in && out && rows > 0 && cols > 0 && ld_out % 128 == 0 && ld_out >= rows, "cast_f16_t: rows=%d ld_out=%lld", rows, ld_out);
+    return cast_t(true, in, ld_in, static_cast<float*>(out), ld_out, rows, cols, scal, s);
 }
 
 int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s) {
@@ -146,7 +160,7 @@ bool gemm_tn_split_supported(int M, int N, int K) { return N % 8 == 0 && K % 8 =
 
 size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob) {
     int ks; long long Mp;
-    geometry(M, ks, Mp);
+    geometry(M, ks, Mp, true);  // the f16-operand layout pads the rows further; sized for either
     const size_t el = (size_t)nprob * N * Mp + (size_t)nprob * K * Mp + (size_t)nprob * ks * N * K + 64;
     return el * sizeof(float);
 }
@@ -157,7 +171,10 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     SOLA_ARG(!d.conv || (d.Cin > 0 && d.K % d.Cin == 0 && d.T_out > 0 && d.M % d.T_out == 0), "gemm_tn_split: conv geometry K=%d Cin=%d", d.K, d.Cin);
     SOLA_ARG(d.scratch_bytes >= gemm_tn_split_scratch_bytes(d.M, d.N, d.K, d.nprob), "gemm_tn_split: scratch too small");
     int ks; long long Mp;
-    geometry(d.M, ks, Mp);
+    const bool pure = d.pure != 0;
+    geometry(d.M, ks, Mp, pure);
+    // transposed operands: rows of Mp split-f16 pairs (4 bytes per element) or Mp halfs (2 bytes); the buffers are sized for pairs
+    const long long rowf = pure ? Mp / 2 : Mp;  // floats per transposed row
     float* at = d.scratch;
     float* xt = at + (size_t)d.nprob * d.N * Mp;
     float* slabs = xt + (size_t)d.nprob * d.K * Mp;
@@ -169,25 +186,27 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     const float* xt_of[3] = {nullptr, nullptr, nullptr};
     int n_xt = 0;
     for (int j = 0; j < d.nprob; ++j) {
-        SOLA_TRY(cast_t(d.A[j], d.lda, at + (size_t)j * d.N * Mp, Mp, d.M, d.N, scal, s));
+        SOLA_TRY(cast_t(pure, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s));
         for (int e = 0; e < j; ++e)
             if (d.B[e] == d.B[j]) xt_of[j] = xt_of[e];
         if (!xt_of[j]) {
-            float* dst = xt + (size_t)n_xt++ * d.K * Mp;
+            float* dst = xt + (size_t)n_xt++ * d.K * rowf;
             if (d.conv) {  // rows [kk*Cin, (kk+1)*Cin) of X^T = tap kk of the implicit im2col
                 for (int kk = 0; kk < d.K / d.Cin; ++kk)
-                    SOLA_TRY(cast_t(d.B[j], d.ldb, dst + (size_t)kk * d.Cin * Mp, Mp, d.M, d.Cin, nullptr, s, d.T_in, d.T_out, d.stride, kk - d.pad));
+                    SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst + (size_t)kk * d.Cin * rowf, Mp, d.M, d.Cin, d.scal_b, s, d.T_in, d.T_out, d.stride, kk - d.pad));
             } else {
-                SOLA_TRY(cast_t(d.B[j], d.ldb, dst, Mp, d.M, d.K, nullptr, s));
+                SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst, Mp, d.M, d.K, d.scal_b, s));
             }
             xt_of[j] = dst;
         }
     }
     GemmDesc g{};
     g.nprob = d.nprob;
-    for (int j = 0; j < d.nprob; ++j) g.p[j] = GemmProblem{at + (size_t)j * d.N * Mp, xt_of[j], nullptr, nullptr, d.C[j]};
+    for (int j = 0; j < d.nprob; ++j) g.p[j] = GemmProblem{at + (size_t)j * d.N * rowf, xt_of[j], nullptr, nullptr, d.C[j]};
     g.M = d.N; g.N = d.K; g.K = (int)Mp; g.lda = (int)Mp; g.ldr = 0; g.ldc = d.K;
-    g.arith = 1; g.out_scale = 1.f; g.out_scale_dev = scal + 1;
+    g.arith = pure ? 2 : 1; g.out_scale = 1.f; g.out_scale_dev = scal + 1;
+    if (d.scal_b)  // the activations' own scale (the caller's tokens): every problem shares it
+        for (int j = 0; j < d.nprob; ++j) g.p[j].scale_dev = d.scal_b + 1;
     g.ksplit = ks; g.splitk_ws = slabs; g.splitk_bytes = (size_t)d.nprob * ks * d.N * d.K * sizeof(float);
     return launch_gemm(g, s);
 }

@@ -67,6 +67,9 @@ struct GemmTnSplitDesc {
     int nprob, M, N, K, lda, ldb;
     int conv, T_in, T_out, stride, pad, Cin;  // conv = 1: B is the channels-last conv input [R*T_in, Cin], K = k*Cin (implicit im2col)
     float* scal;  // optional device pair with scal[0] = max|A| over all problems already computed (else found here)
+    float* scal_b;  // optional device pair with scal_b[0] = max|B| already computed: B is cast with that power-of-two scale too
+                    // (activations whose magnitude the caller does not control: the object tokens); null = B is cast unscaled
+    int pure;     // 1: plain f16 transposed operands and ONE f16 MFMA per product (training with f16 GEMM operands), else split-f16
     float* scratch;
     size_t scratch_bytes;
 };
@@ -224,6 +227,9 @@ int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n
 int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s,
                     int target_exp = 13, float* scale_out = nullptr);
 int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s);
+int launch_cast_f16_scaled(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
+// transposing cast to plain f16: in [rows][cols] f32 -> out [cols][ld_out halfs] (ld_out % 128 == 0, zero-filled past rows)
+int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s);
 // Weight-time range check of the split-f16 activations: a GroupNorm output has E[y^2] = gamma^2 + beta^2 per channel (its
 // input is normalised), so the magnitude of every tensor the norms emit is known from the weights alone.  Sets bit 1 of
 // *guard when the rms of any (gamma, beta) pair lies outside [2^-6, 2^9] - where the fixed-scale split-f16 activations would
