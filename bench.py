@@ -230,7 +230,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
     m = LanguageAlignedTrackSelectionModule(cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     m = m.to(dev).train()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5, fused=True)  # as train.py
     inp = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(cfg, B, N, T, L, 1).items()}
 
     def step():

@@ -268,6 +268,101 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     }
 }
 
+// ---- sequences of at most 4 steps (motion attention over T' = 4 at the headline shape): ONE pass -------------------------
+// A (track, head) unit is 4 rows each of q, k, v, o, dO in and of dQ, dK, dV out - pure streaming.  The two-pass kernels above
+// pad it to a 16 x 16 tile, stage it through LDS per wave and read q, k, v, dO twice: 406 us per launch pair at 64 samples
+// where the traffic (8 tensors once) takes ~110 us.  Here, as in attn_fwd_small_kernel, half a wave owns a unit: lane c holds
+// float4 chunk c of every row, the TT x TT scores S = q k^T, dP = dO v^T and D = dO . o are per-lane partial dot products
+// all-reduced over the 32 lanes (DPP, common.h), P is recomputed from the saved log-sum-exp, dS = P o (dP - D), and dQ, dK, dV
+// are TT x TT combinations of the rows in registers.  Dropout on P as in the forward (same counter-based mask).
+template <int TT>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a) {
+    constexpr int DH = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, hw = lane >> 5;
+    const long long unit = ((long long)blockIdx.x * 4 + wave) * 2 + hw;
+    const long long n_units = (long long)a.G * a.H;
+    const bool live = unit < n_units;
+    const long long uu = live ? unit : 0;
+    const int grp = (int)(uu / a.H), h = (int)(uu - (long long)grp * a.H);
+    const long long q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+    const long long k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const int Sq = live ? a.Sq : 0, Sk = live ? a.Sk : 0;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 qv[TT], kv[TT], vv[TT], gv[TT];
+    float dsum[TT], lse[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const long long qr = q0 + (long long)t * a.q_rs, kr = k0 + (long long)t * a.k_rs;
+        qv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.q + qr * a.ldq + h * DH + 4 * c) : z;
+        gv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.dout + qr * a.ldo + h * DH + 4 * c) : z;
+        const float4 ov = t < Sq ? *reinterpret_cast<const float4*>(a.o + qr * a.ldo + h * DH + 4 * c) : z;
+        kv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.k + kr * a.ldk + h * DH + 4 * c) : z;
+        vv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.v + kr * a.ldv + h * DH + 4 * c) : z;
+        lse[t] = t < Sq ? a.lse[qr * a.H + h] : 0.f;
+        dsum[t] = half_sum32((ov.x * gv[t].x + ov.y * gv[t].y) + (ov.z * gv[t].z + ov.w * gv[t].w));  // D[i] = dO[i] . O[i]
+        if (t < Sq && c == 0) a.dvec[qr * a.H + h] = dsum[t];
+    }
+    float pd[TT][TT], ds[TT][TT];  // P after dropout (the weights of V in the forward), dS
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const float sp = (qv[i].x * kv[j].x + qv[i].y * kv[j].y) + (qv[i].z * kv[j].z + qv[i].w * kv[j].w);
+            const float dp = (gv[i].x * vv[j].x + gv[i].y * vv[j].y) + (gv[i].z * vv[j].z + gv[i].w * vv[j].w);
+            const float sc = half_sum32(sp) * a.scale;
+            float dpr = half_sum32(dp);
+            const bool ok = i < Sq && j < Sk;
+            const float p = ok ? __expf(sc - lse[i]) : 0.f;
+            float pw = p;
+            if (a.drop.enabled) {
+                const bool keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + i) * a.Sk + j);
+                pw = keep ? p * a.drop.scale : 0.f;
+                dpr = keep ? dpr * a.drop.scale : 0.f;
+            }
+            pd[i][j] = pw;
+            ds[i][j] = p * (dpr - dsum[i]);
+        }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        if (i >= Sq) break;
+        float4 dq = z;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const float w = ds[i][j] * a.scale;
+            dq.x += w * kv[j].x; dq.y += w * kv[j].y; dq.z += w * kv[j].z; dq.w += w * kv[j].w;
+        }
+        *reinterpret_cast<float4*>(a.dq + (q0 + (long long)i * a.q_rs) * a.ld_dq + h * DH + 4 * c) = dq;
+    }
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        if (j >= Sk) break;
+        float4 dk = z, dv = z;
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const float w = ds[i][j] * a.scale, pw = pd[i][j];
+            dk.x += w * qv[i].x; dk.y += w * qv[i].y; dk.z += w * qv[i].z; dk.w += w * qv[i].w;
+            dv.x += pw * gv[i].x; dv.y += pw * gv[i].y; dv.z += pw * gv[i].z; dv.w += pw * gv[i].w;
+        }
+        const long long kr = k0 + (long long)j * a.k_rs;
+        *reinterpret_cast<float4*>(a.dk + kr * a.ld_dk + h * DH + 4 * c) = dk;
+        *reinterpret_cast<float4*>(a.dv + kr * a.ld_dv + h * DH + 4 * c) = dv;
+    }
+}
+
+int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels for every shape (A/B)
+
+static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
+    const long long units = (long long)a.G * a.H;
+    const unsigned blocks = (unsigned)((units + 7) / 8);
+    const int need = a.Sq > a.Sk ? a.Sq : a.Sk;
+    if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_small_kernel<4>), dim3(blocks), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 template <int DH>
 int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * 2 * 16 * (DH + 4) * sizeof(float);
@@ -295,6 +390,8 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
 
 }  // namespace
 
+void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
+
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");
     AttnBwdArgs a;
@@ -309,6 +406,7 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.drop = d.drop;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
+    if (g_attn_bwd_small && d.DH == 128 && d.Sq <= 4 && d.Sk <= 4) return launch_bwd_small(a, s);
     switch (d.DH) {
         case 128: return launch_bwd_dh<128>(a, s);
         case 64: return launch_bwd_dh<64>(a, s);

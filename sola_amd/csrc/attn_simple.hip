@@ -212,10 +212,8 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnSArgs a) 
     for (int i = 0; i < TT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
-            float p = (qv[i].x * kv[j].x + qv[i].y * kv[j].y) + (qv[i].z * kv[j].z + qv[i].w * kv[j].w);
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);  // stays inside the 32-lane half
-            sc[i][j] = p * a.scale;
+            const float p = (qv[i].x * kv[j].x + qv[i].y * kv[j].y) + (qv[i].z * kv[j].z + qv[i].w * kv[j].w);
+            sc[i][j] = half_sum32(p) * a.scale;  // DPP + one permlane swap; stays inside the 32-lane half
         }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {

@@ -66,6 +66,26 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Sum over the 32-lane half of the wave a lane belongs to, the same value in all of its lanes.  DPP adds inside the 16-lane rows
+// (swap pairs, swap quad halves, mirror the 8-lane halves, mirror the row: after each step the sum is uniform over twice as many
+// lanes and both partners add the same two numbers, so every lane ends with the bit-identical result), then one
+// v_permlane16_swap across the row pair.  VALU only: __shfl_xor would be five ds_bpermute_b32 through the LDS crossbar.
+#define SOLA_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
+__device__ __forceinline__ float half_sum32(float v) {
+    v = SOLA_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
+    v = SOLA_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
+    v = SOLA_DPP_ADD(v, 0x141);  // row_half_mirror
+    v = SOLA_DPP_ADD(v, 0x140);  // row_mirror
+    // the swap exchanges the odd rows of its first operand with the even rows of its second: given two copies of v it leaves
+    // (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3).  Inline asm: inside these kernels hipcc 7.2 folds the two
+    // results of __builtin_amdgcn_permlane16_swap(u, u) into ONE register (v_add v, v, v: twice the first row pair's partner-
+    // less sum; an opaque copy of the operand does not stop it).  s_nop 1: a VALU result needs two wait states before a
+    // permlane reads it, and the hazard recogniser does not look inside asm.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // Sum over a 256-thread block; every thread gets the result. `red` is >= 4 floats of LDS; deterministic order.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);

@@ -156,7 +156,8 @@ def _attn_t(q, k, v, H):
     return (p @ vh).permute(0, 2, 1, 3).reshape(G, Sq, D)
 
 
-@pytest.mark.parametrize("B,N,Tp,D", [(2, 5, 3, 128), (1, 64, 4, 1024), (1, 7, 16, 128), (1, 20, 25, 128), (2, 16, 4, 256), (1, 130, 2, 128)])
+@pytest.mark.parametrize("B,N,Tp,D", [(2, 5, 3, 128), (1, 64, 4, 1024), (1, 7, 16, 128), (1, 20, 25, 128), (2, 16, 4, 256), (1, 130, 2, 128),
+                                      (2, 9, 2, 1024), (1, 12, 3, 1024)])
 def test_attention_backward_three_layouts(B, N, Tp, D):
     H = 8
     rng = np.random.default_rng(N * Tp + D)

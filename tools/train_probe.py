@@ -9,7 +9,7 @@ cfg = synth.DEFAULT_MODEL_CFG
 m = LanguageAlignedTrackSelectionModule(cfg)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()}, strict=True)
 m = m.cuda().train()
-opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+opt = torch.optim.AdamW(m.parameters(), lr=1e-5, fused=True)
 inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, 64, 32, 16, 1).items()}
 def step():
     opt.zero_grad(set_to_none=True)
