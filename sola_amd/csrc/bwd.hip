@@ -122,6 +122,124 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
     }
 }
 
+// Register-resident shape (as norm.hip's group_norm_reg_kernel): x and dy of the whole unit are read ONCE into 2 R float4 per
+// lane, the statistics, the two gradient means and the per-channel partials all come from the registers, dx is written
+// straight out - 8 + 4 bytes per element of traffic instead of four reads of x and two of dy through L2 (the three-pass
+// kernel above: 78-133 us per launch at 64 samples where the forward's register kernels take 19-55).
+//   WAVE = true : one wave per unit (encoder norms and the motion norm, units of <= 4 KiB), four units per block, shuffles only;
+//   WAVE = false: one block per unit (the inter-object norm: 32 KiB, R = 8).
+template <int R, bool WAVE>
+__global__ __launch_bounds__(256) void group_norm_bwd_reg_kernel(const GnBwdArgs a, long long n_units, int groups) {
+    __shared__ float red[4];
+    __shared__ float part[WAVE ? 1 : 256 * 8];
+    const int f4 = a.cg >> 2;
+    const int nthr = WAVE ? 64 : 256;
+    const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+    const long long unit = WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
+    if (WAVE && unit >= n_units) return;  // a whole wave leaves; the WAVE shape has no block-level sync
+    const int inst = (int)(unit / groups), g = (int)(unit - (long long)inst * groups);
+    const int tpp = nthr / f4;
+    const int tl = tid / f4, c4 = tid - tl * f4;
+    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const int ch = g * a.cg + c4 * 4;
+    const float cnt = (float)a.ntok * (float)a.cg;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xv[R], dv[R];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+        xv[r] = t < a.ntok ? *reinterpret_cast<const float4*>(a.x + off) : z;
+        dv[r] = t < a.ntok ? *reinterpret_cast<const float4*>(a.dy + off) : z;
+        if (a.dy2 && t < a.ntok) {
+            const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
+            dv[r].x += e.x; dv[r].y += e.y; dv[r].z += e.z; dv[r].w += e.w;
+        }
+        s += (xv[r].x + xv[r].y) + (xv[r].z + xv[r].w);
+    }
+    const float mean = (WAVE ? wave_sum(s) : block_sum_256(s, red)) / cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tl + r * tpp < a.ntok) {
+            const float d0 = xv[r].x - mean, d1 = xv[r].y - mean, d2 = xv[r].z - mean, d3 = xv[r].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float var = (WAVE ? wave_sum(q) : block_sum_256(q, red)) / cnt;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    float s1 = 0.f, s2 = 0.f;
+    float4 dgam = z, dbet = z;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        if (t < a.ntok) {
+            const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+            const float4 xh = make_float4((xv[r].x - mean) * rstd, (xv[r].y - mean) * rstd, (xv[r].z - mean) * rstd, (xv[r].w - mean) * rstd);
+            float4 d = dv[r];
+            if (a.drop.enabled) {  // y = dropout(lrelu(gn(x))): the mask is regenerated from the element index
+                d.x = dropout_keep(a.drop, (unsigned long long)off) ? d.x * a.drop.scale : 0.f;
+                d.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? d.y * a.drop.scale : 0.f;
+                d.z = dropout_keep(a.drop, (unsigned long long)off + 2) ? d.z * a.drop.scale : 0.f;
+                d.w = dropout_keep(a.drop, (unsigned long long)off + 3) ? d.w * a.drop.scale : 0.f;
+            }
+            if (a.leaky) {
+                if (xh.x * ga.x + be.x < 0.f) d.x *= a.slope;
+                if (xh.y * ga.y + be.y < 0.f) d.y *= a.slope;
+                if (xh.z * ga.z + be.z < 0.f) d.z *= a.slope;
+                if (xh.w * ga.w + be.w < 0.f) d.w *= a.slope;
+            }
+            dgam.x += d.x * xh.x; dgam.y += d.y * xh.y; dgam.z += d.z * xh.z; dgam.w += d.w * xh.w;
+            dbet.x += d.x; dbet.y += d.y; dbet.z += d.z; dbet.w += d.w;
+            const float g0 = d.x * ga.x, g1 = d.y * ga.y, g2 = d.z * ga.z, g3 = d.w * ga.w;
+            s1 += (g0 + g1) + (g2 + g3);
+            s2 += (g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w);
+            xv[r] = xh;                            // kept for the dx pass
+            dv[r] = make_float4(g0, g1, g2, g3);   // dy' * gamma
+        }
+    }
+    const float m1 = (WAVE ? wave_sum(s1) : block_sum_256(s1, red)) / cnt;
+    const float m2 = (WAVE ? wave_sum(s2) : block_sum_256(s2, red)) / cnt;
+    // per-channel partials: add up the token lanes that share a channel quad (fixed order)
+    const long long po = (long long)inst * a.C + g * a.cg + c4 * 4;
+    if (WAVE) {
+        float acc[8] = {dgam.x, dgam.y, dgam.z, dgam.w, dbet.x, dbet.y, dbet.z, dbet.w};
+        for (int o = f4; o < 64; o <<= 1)  // lanes tl differ in the bits above log2(f4); f4 is a power of two here
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (tl == 0) {
+            *reinterpret_cast<float4*>(a.dgp + po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(a.dbp + po) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    } else {
+        float* pp = &part[threadIdx.x * 8];
+        pp[0] = dgam.x; pp[1] = dgam.y; pp[2] = dgam.z; pp[3] = dgam.w;
+        pp[4] = dbet.x; pp[5] = dbet.y; pp[6] = dbet.z; pp[7] = dbet.w;
+        __syncthreads();
+        if (threadIdx.x < f4) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < tpp; ++sl) {
+                const float* src = &part[(sl * f4 + threadIdx.x) * 8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += src[j];
+            }
+            *reinterpret_cast<float4*>(a.dgp + po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(a.dbp + po) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        if (t < a.ntok) {
+            const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+            *reinterpret_cast<float4*>(a.dx + off) = make_float4(rstd * (dv[r].x - m1 - xv[r].x * m2), rstd * (dv[r].y - m1 - xv[r].y * m2),
+                                                                 rstd * (dv[r].z - m1 - xv[r].z * m2), rstd * (dv[r].w - m1 - xv[r].w * m2));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight-standardisation backward (module/ws.py:9-13): w_hat = c / (sigma + eps), c = w - mean(w),
 // sigma = sqrt(sum c^2 / (n-1)).  dc = g / s - (sum g w_hat) c / (s (n-1) sigma);  dw = dc - mean(dc)
@@ -376,6 +494,9 @@ __global__ __launch_bounds__(256) void neg_token_grad_kernel(const float* __rest
 
 }  // namespace
 
+int g_gn_bwd_reg = 1;  // sola_tune "gn_bwd_reg": 0 = three-pass kernel for every shape (A/B)
+void sola_gn_set_bwd_reg(int v) { g_gn_bwd_reg = v; }
+
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.groups > 0 && d.C % d.groups == 0, "group_norm_bwd: C=%d groups=%d", d.C, d.groups);
     const int cg = d.C / d.groups;
@@ -387,7 +508,24 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop;
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
-    hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+    const int f4 = cg / 4;
+    const bool pow2 = (f4 & (f4 - 1)) == 0;
+    const long long n_units = (long long)d.n_inst * d.groups;
+    const int rw = pow2 && f4 <= 64 ? (d.ntok + 64 / f4 - 1) / (64 / f4) : 1 << 30;    // float4 per lane and tensor, one wave per unit
+    const int rb = pow2 && f4 <= 256 ? (d.ntok + 256 / f4 - 1) / (256 / f4) : 1 << 30;  // ... one block per unit
+    if (g_gn_bwd_reg && rw <= 4 && n_units < (1ll << 31)) {
+        const dim3 grid((unsigned)((n_units + 3) / 4));
+        if (rw == 1) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<1, true>), grid, dim3(256), 0, s, a, n_units, d.groups);
+        else if (rw == 2) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<2, true>), grid, dim3(256), 0, s, a, n_units, d.groups);
+        else hipLaunchKernelGGL((group_norm_bwd_reg_kernel<4, true>), grid, dim3(256), 0, s, a, n_units, d.groups);
+    } else if (g_gn_bwd_reg && rb <= 8 && n_units < (1ll << 31)) {
+        const dim3 grid((unsigned)n_units);
+        if (rb <= 2) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<2, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
+        else if (rb <= 4) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<4, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
+        else hipLaunchKernelGGL((group_norm_bwd_reg_kernel<8, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
+    } else {
+        hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+    }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
