@@ -160,7 +160,8 @@ def attn_roofline(prof):
     if a["ms"] <= 0:
         return None
     gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
-    return {"kernel": "attn_fwd_f32_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"kernel": "attention core, all launches of a step: attn_fwd_f32_simple_kernel (inter-object), attn_fwd_small_kernel / attn_fwd_f32_reg_kernel "
+                      "(motion), attn_fwd_f32_res_kernel (object->language); exact f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
             "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 2)}
 
@@ -563,9 +564,9 @@ def main():
                     roofline["traffic_kernel"] = gk
                     roofline["traffic"] = kk[gk]["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = tr["source"]
-                ak = [kk[k]["hbm_bytes_per_launch"] for k in ("attn_fwd_f32_kernel<128, false, 4, false>", "attn_fwd_f32_kernel<128, true, 4, false>") if k in kk]
-                if roofline_attn and len(ak) == 2:
-                    roofline_attn["traffic"] = int((2 * ak[0] + ak[1]) / 3)  # obj + o2l (shared K/V) and motion (packed) launches
+                ak = [(kk[k]["hbm_bytes_per_launch"], kk[k]["calls"]) for k in kk if k.startswith("attn_fwd")]
+                if roofline_attn and ak:  # launch-weighted mean over the attention kernels of the profiled run
+                    roofline_attn["traffic"] = int(sum(b * c for b, c in ak) / sum(c for _, c in ak))
                 if exact and exact.get("roofline") and "gemm_nt_f32_kernel<128, 128, 0, 0>" in kk:
                     exact["roofline"]["traffic"] = kk["gemm_nt_f32_kernel<128, 128, 0, 0>"]["hbm_bytes_per_launch"]
             break

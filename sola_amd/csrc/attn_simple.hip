@@ -238,7 +238,10 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnSArgs a) 
         if (!a.o_sp16) {
             *reinterpret_cast<float4*>(op + 4 * c) = o;
         } else {
-            // floats 4c .. 4c+3 are one half of the 8-wide block c >> 1: hi4 at 8 * (c & 1), lo4 sixteen bytes behind
+            // floats 4c .. 4c+3 are one half of the 8-wide block c >> 1 = 32 bytes [hi8 | lo8].  The lane pair (c, c ^ 1) trades
+            // halves (two DPP moves each way) so that the even lane writes the 16 bytes of hi8 and the odd lane the 16 bytes of
+            // lo8 - one 16-byte store per lane instead of two 8-byte ones (which reached HBM as 366 MiB of WRITE_SIZE per launch
+            // for 256 MiB of output: half-written 32-byte sectors)
             const float v4[4] = {o.x, o.y, o.z, o.w};
             half4v hi, lo;
             float m = 0.f;
@@ -249,9 +252,14 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnSArgs a) 
                 hi[j] = h1; lo[j] = l1;
                 m = fmaxf(m, fabsf(v4[j]));
             }
-            char* dst = reinterpret_cast<char*>(op + 8 * (c >> 1)) + 8 * (c & 1);
-            *reinterpret_cast<half4v*>(dst) = hi;
-            *reinterpret_cast<half4v*>(dst + 16) = lo;
+            const int2 hw2 = __builtin_bit_cast(int2, hi), lw2 = __builtin_bit_cast(int2, lo);
+            const bool odd = c & 1;
+            const int sx = odd ? hw2.x : lw2.x, sy = odd ? hw2.y : lw2.y;  // what the partner needs: its lo8 needs my lo4, its hi8 my hi4
+            const int rx = __builtin_amdgcn_update_dpp(0, sx, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]: lane c <- lane c ^ 1
+            const int ry = __builtin_amdgcn_update_dpp(0, sy, 0xB1, 0xF, 0xF, false);
+            // even lane: [my hi4 | partner's hi4] at block + 0;  odd lane: [partner's lo4 | my lo4] at block + 16
+            const int4 piece = odd ? make_int4(rx, ry, lw2.x, lw2.y) : make_int4(hw2.x, hw2.y, rx, ry);
+            *reinterpret_cast<int4*>(reinterpret_cast<char*>(op + 8 * (c >> 1)) + (odd ? 16 : 0)) = piece;
             if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
         }
     }

@@ -9,7 +9,9 @@ repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="--steps 10 --warmup 2 --cpu-seconds 0 $*"
+# the headline leg only (split-f16 steps + the exact-f32 leg): the stress / ragged / IoU / 16-bit / training legs would mix other shapes
+# into the per-kernel means
+args="--steps 10 --warmup 2 --cpu-seconds 0 --extra-legs 0 --train-steps 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats -- python3 "$repo/bench.py" $args > "$out/bench_under_rocprof.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out" -o pmc_fetch -- python3 "$repo/bench.py" $args > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out" -o pmc_write -- python3 "$repo/bench.py" $args > "$out/pmc_write.log" 2>&1
