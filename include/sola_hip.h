@@ -81,10 +81,13 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  *      attention ONE f16 MFMA with f32 accumulation; softmax, GroupNorm statistics, biases, score head, losses stay f32.
  *      f16 rather than bf16: 11 significant bits for the same bytes, its range covered by the scales + guard below.  A
  *      reduced-precision mode (logits within ~3e-2 at magnitude 10), never the default; needs object_token_dim and
- *      lang_token_dim %% 64 == 0.  sola_forward_train / sola_forward_ragged run exact f32 under it.
+ *      lang_token_dim %% 64 == 0.  sola_forward_ragged runs exact f32 under it.
  * In training (sola_forward_train / sola_backward) precision 1 runs every GEMM of the step (forward, dX and dW of the
  * projections and convs) on split-f16 casts of the f32 activations / gradients, from 1024 token rows on; attention and
- * GroupNorm backward and everything saved for the backward stay f32. */
+ * GroupNorm backward and everything saved for the backward stay f32.  Precision 2 in training is MIXED precision (BASELINE
+ * config C2): the same step with plain-f16 casts and ONE f16 MFMA per product (f32 accumulation, per-tensor power-of-two
+ * scales); activations, statistics, softmax, saved tensors and master weights stay f32.  Reduced precision with a stated
+ * tolerance: losses within 1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py). */
 int sola_set_precision(SolaCtx* ctx, int precision);
 /* Range handling of precision 1 in sola_forward / sola_forward_ragged.  The split-f16 pairs keep 22 significant bits for
  * every value within 2^-16 of its tensor's largest, on top of a per-tensor power-of-two scale:

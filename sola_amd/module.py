@@ -91,7 +91,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers every GEMM of the
         # step, forward and backward (attention and GroupNorm backward stay f32); "f16" = 16-bit activation STORAGE for the
         # uniform inference forward (plain f16 between kernels, one f16 MFMA per product, f32 accumulate / softmax / statistics;
-        # a reduced-precision mode with a stated tolerance - training and ragged calls run exact f32 under it)
+        # a reduced-precision mode with a stated tolerance; ragged calls run exact f32 under it; in TRAINING it is mixed
+        # precision: every GEMM of the step on plain-f16 casts, one MFMA per product, everything else f32)
         self.precision = os.environ.get("SOLA_PRECISION", "f32")  # the entry points take it from the environment
         self._ctx_precision = None
         # "f16x3" inference calls are range-guarded: a value outside the split-f16 pairs' range (or GroupNorm weights that
