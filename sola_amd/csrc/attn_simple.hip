@@ -24,6 +24,7 @@ struct AttnSArgs {
     int o_sp16;
     int* guard;
     const int4 *q_units, *k_units;
+    int xcd_remap;
 };
 
 template <int DH, int TK>
@@ -36,8 +37,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
     float* Vs = smem_s + TK * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
-    const long long unit = blockIdx.x / a.nqb;
-    const int qb = blockIdx.x - (int)unit * a.nqb;
+    // a.xcd_remap (grid % 8 == 0): consecutive logical blocks - the heads of a group, the q-blocks of a unit - share an XCD's L2
+    const unsigned lb = a.xcd_remap ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const long long unit = lb / a.nqb;
+    const int qb = (int)(lb - unit * a.nqb);
     const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
     long long q0, k0, q_rs, k_rs;
     int Sq, Sk;
@@ -449,6 +452,8 @@ int launch_splitm(const AttnSArgs& a0, hipStream_t s) {
     return SOLA_OK;
 }
 
+int g_attn_simple_remap = 0;  // sola_tune "attn_simple_remap": XCD-contiguous block order; measured no gain (273.8 vs 275.8 us at 64 tracks, 392 vs 400 at 128)
+
 template <int DH>
 int launch_s(const AttnSArgs& a0, hipStream_t s) {
     AttnSArgs a = a0;
@@ -456,6 +461,7 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
     a.nqb = (a.Sq + 63) / 64;
     const long long blocks = (long long)a.G * a.H * a.nqb;
     SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+    a.xcd_remap = (g_attn_simple_remap && blocks % 8 == 0) ? 1 : 0;
     const size_t lds = (size_t)2 * TK * (DH + 4) * sizeof(float);
     hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, TK>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
@@ -463,6 +469,8 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
 }
 
 }  // namespace
+
+void sola_attn_set_simple_remap(int v) { g_attn_simple_remap = v; }
 
 // sequences of <= 4 steps at head_dim 128, inference (no log-sum-exp, no dropout), f32 q / k / v
 bool attention_small_supported(const AttnDesc& d) {
@@ -478,6 +486,7 @@ static AttnSArgs make_sargs(const AttnDesc& d) {
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    a.xcd_remap = 0;
     return a;
 }
 
