@@ -108,6 +108,19 @@ def test_all_golden_cases_in_one_ragged_batch(full, full_golden):
         assert int(sm.argmax()) == garg
 
 
+def test_golden_ragged_batch_with_the_register_and_resident_attention_shapes(full, full_golden):
+    """Default routing keeps ragged batches on the high-occupancy LDS shape (measured faster on mixed unit sizes); the
+    resident-K/V (attn_res.hip) and register-only (attn_reg.hip) shapes read the same unit tables - forced here."""
+    from sola_amd import _lib
+    try:
+        _lib.check(_lib.lib().sola_tune(b"attn_res", 2), "tune")
+        _lib.check(_lib.lib().sola_tune(b"attn_reg", 2), "tune")
+        test_all_golden_cases_in_one_ragged_batch(full, full_golden)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"attn_res", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"attn_reg", 1), "tune")
+
+
 def test_small_golden_cases_in_one_ragged_batch(small, small_golden):
     cfg = synth.SMALL_MODEL_CFG
     videos, texts, gold = [], [], []
