@@ -83,6 +83,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._ctx = None
         self._ctx_device = None
         self._bound = {}      # key -> (data_ptr, version)
+        self._weights_touched = False
         self._workspace = None
         self._last_shape = None
         self.ws_policy = "auto"
@@ -140,9 +141,20 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         except Exception:
             pass
 
+    def weights_changed(self):
+        """Tell the library that parameter VALUES changed in place without torch noticing (e.g. an update through ``p.data``
+        or a fused optimizer kernel - neither bumps ``Tensor._version``): cached derived copies (standardised conv weights,
+        split-f16 / f16 copies of the projection matrices and their scales) are rebuilt on the next call."""
+        self._weights_touched = True
+
     def _bind_weights(self):
         """Hand the library the current device pointer of every state_dict tensor; flag in-place updates."""
-        changed = False
+        # A training forward is followed by an optimizer step.  ``Tensor._version`` cannot be trusted to show it:
+        # torch.optim.AdamW(fused=True) updates the parameters without bumping it (the split-f16 copies of the projection
+        # weights then go stale: an 80-step run diverged to a loss of 70 where exact f32 reached 1.0 - tools/train_converge.py).
+        # So every call after a training forward (and after weights_changed()) rebuilds the derived copies.
+        changed = bool(getattr(self, "_weights_touched", False))
+        self._weights_touched = False
         for key, t in self.state_dict(keep_vars=True).items():
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise SolaError(f"{key}: expected a contiguous float32 tensor")
@@ -289,6 +301,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         lang = lang_tokens.detach().to(torch.float32).contiguous()
         self._ensure_ctx(dev)
         self._bind_weights()
+        self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
         if self.training and (self.dropout_p > 0 or self.attention_dropout_p > 0):
             # a fresh mask seed per step from torch's (seedable) CPU generator, like nn.Dropout under set_seed(42)
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())

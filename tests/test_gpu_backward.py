@@ -384,6 +384,50 @@ def test_f16_operand_training_vs_exact_f32(full_model, full_golden):
     assert gnd["total_grad_norm"] == pytest.approx(gref["total_grad_norm"], rel=5e-2)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_training_run_tracks_exact_f32_across_optimizer_steps(fused):
+    """Several optimizer steps, not one: the reduced-precision modes keep derived copies of the weights (split-f16 / f16
+    projection matrices + scales) that must follow every update.  torch.optim.AdamW(fused=True) changes the parameters
+    without bumping Tensor._version - a run that trusted the version counter used the INITIAL projection weights in every
+    forward and diverged (loss 8 -> 70 in 50 steps where exact f32 reached 1.0; profiles/r02_train_converge.log is the fixed
+    behaviour).  12 steps each: the eval-mode exact-f32 loss of every mode must have dropped by a third and end within 15 %
+    of the exact-f32 run's."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    B, N, T, L = 8, 40, 32, 10  # 1280 token rows: above the size gate of the split kernels
+    sd = synth.make_state_dict(cfg, 42)
+    batches = [{k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, N, T, L, 700 + i).items()} for i in range(2)]
+
+    def loss_of(m, inp):
+        sm, st = m(inp["object_tokens"], inp["lang_tokens"])
+        neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+        return track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
+
+    def eval_loss(m):
+        m.eval(); m.precision = "f32"
+        with torch.no_grad():
+            return sum(float(loss_of(m, b)[0]) for b in batches) / len(batches)
+
+    final = {}
+    for prec in ("f32", "f16x3", "f16"):
+        m = LanguageAlignedTrackSelectionModule(cfg)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        m = m.cuda()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=fused)
+        start = eval_loss(m)
+        torch.manual_seed(5)  # the dropout seeds of the steps
+        for it in range(12):
+            m.train(); m.precision = prec
+            opt.zero_grad(set_to_none=True)
+            loss_of(m, batches[it % 2])[0].backward()
+            m.clip_grad_norm_(1.0)
+            opt.step()
+        final[prec] = eval_loss(m)
+        assert final[prec] < 0.67 * start, (prec, start, final[prec])
+        del m, opt
+    for prec in ("f16x3", "f16"):
+        assert abs(final[prec] - final["f32"]) <= 0.15 * final["f32"], final
+
+
 def test_small_gradients_vs_oracle_autograd(small_model):
     """Every parameter gradient against float64 autograd through the oracle on a case with no fixture."""
     m, sd = small_model
