@@ -64,6 +64,9 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
     a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, (size_t)p.B * p.Tp)), (int)D) / sizeof(float) + 64);
+    // few-sample regime (the reference trains at batch size 1): the dX GEMMs have fewer 64x64 tiles than the chip has CUs; scratch
+    // for their deterministic two-pass split-K, as the forward has (42-136 us per dX GEMM without it, 64 blocks on 256 CUs)
+    if (M <= 8192) a.add("splitk", (size_t)8192 * 4096);
     if (c->precision >= 1 && p.M >= g_train_split_min_rows) {  // split-f16 / f16-operand dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
@@ -132,6 +135,8 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     float* tn = ar.get("tn");
     const size_t tn_bytes = ar.total - ar.off.at("tn");  // upper bound; launch_gemm_tn checks its own need
     float* wt = ar.get("wt");
+    float* const splitk_ws = ar.off.count("splitk") ? ar.get("splitk") : nullptr;
+    const size_t splitk_bytes = splitk_ws ? (size_t)8192 * 4096 * sizeof(float) : 0;
     // split: every GEMM of the backward on f16 MFMAs - (hi, lo) operand pairs, three products (precision 1), or plain f16
     // operands, one product (precision 2: "pure"; mixed precision - activations, gradients and accumulation stay f32)
     const bool split = c->precision >= 1 && ar.off.count("dy_sp") != 0;
@@ -202,6 +207,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         d.nprob = 1;
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
         d.M = rows; d.N = k_in; d.K = n_cat; d.lda = ldy; d.ldr = k_in; d.ldc = k_in;
+        d.splitk_ws = splitk_ws; d.splitk_bytes = splitk_bytes;
         if (split && n_cat % (pure ? 64 : 32) == 0 && ldy % 4 == 0) {
             // dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal range), the
             // transposed weights with the fixed 2^6; the epilogue undoes both
@@ -443,6 +449,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             d.p[0] = GemmProblem{dy, wt, nullptr, nullptr, dact};
             d.M = R * t_in; d.N = g.cin; d.K = g.k * g.cout; d.lda = g.cout; d.ldc = g.cin;
             d.conv = g.k > 1 ? 2 : 0; d.T_in = p.Tl[i]; d.T_out = t_in; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cout;
+            d.splitk_ws = splitk_ws; d.splitk_bytes = splitk_bytes;
             SOLA_TRY(launch_gemm(d, s));
         }
         }
