@@ -268,6 +268,252 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     }
 }
 
+// ---- block-shared staging (round 2) --------------------------------------------------------------------------------------
+// The two kernels above give every WAVE its own LDS slice and stage the streamed side (K/V rows for dQ, Q/dO rows for dK/dV)
+// per wave, 16 rows at a time, between two block barriers: the four waves of a unit each read the unit's whole K and V (or
+// Q and dO) through L2, and no load overlaps a MFMA.  Here a BLOCK owns (unit, 64 queries) for dQ or (unit, 64 keys) for
+// dK/dV: the 16-row tile of the streamed side is staged ONCE per block by all 256 threads into one of two LDS buffers, the
+// next tile travels in registers while the current one is multiplied (one barrier per tile), the arithmetic is unchanged.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_blk_kernel(const AttnBwdArgs a) {
+    constexpr int NC = DH / 16, LD = DH + 4, F4 = DH / 4, PT = 2 * 16 * F4 / 256;  // float4 per thread and tile (K + V)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int nqc = (a.Sq + 63) / 64;
+    const long long gh = blockIdx.x / nqc;
+    const int qc = (int)(blockIdx.x - gh * nqc);
+    const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
+    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const int qi = qc * 64 + wave * 16 + c16;
+    const bool q_ok = qi < a.Sq;
+    const long long qrow = qrow0 + (long long)(q_ok ? qi : 0) * a.q_rs;
+
+    float4 qf[NC], dof[NC];
+    float dsum = 0.f;
+    {
+        const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
+        const float* op = a.o + qrow * a.ldo + h * DH + 4 * g4;
+        const float* gp = a.dout + qrow * a.ldo + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 qv = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : z;
+            const float4 ov = q_ok ? *reinterpret_cast<const float4*>(op + c * 16) : z;
+            const float4 gv = q_ok ? *reinterpret_cast<const float4*>(gp + c * 16) : z;
+            qf[c] = make_float4(qv.x * a.scale, qv.y * a.scale, qv.z * a.scale, qv.w * a.scale);
+            dof[c] = gv;
+            dsum += (ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w);
+        }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);  // D[q] for the lane's column
+    const float lse_q = q_ok ? a.lse[qrow * a.H + h] : 0.f;
+    if (q_ok && g4 == 0) a.dvec[qrow * a.H + h] = dsum;
+
+    f32x4 dqacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dqacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: element e = tid + 256 j of a tile -> (which = K / V, row, float4 column)
+    float4 st[PT];
+    auto fetch = [&](int kt0) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int e = tid + 256 * j, which = e / (16 * F4), r = (e % (16 * F4)) / F4, c4 = e % F4;
+            st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kt0 + r < a.Sk) {
+                const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
+                st[j] = which ? *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4)
+                              : *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+            }
+        }
+    };
+    auto stash = [&](float* buf) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int e = tid + 256 * j, which = e / (16 * F4), r = (e % (16 * F4)) / F4, c4 = e % F4;
+            *reinterpret_cast<float4*>(&buf[(which * 16 + r) * LD + c4 * 4]) = st[j];
+        }
+    };
+    fetch(0);
+    int it = 0;
+    for (int kt0 = 0; kt0 < a.Sk; kt0 += 16, ++it) {
+        float* Ks = smem + (it & 1) * 2 * 16 * LD;
+        float* Vs = Ks + 16 * LD;
+        stash(Ks);
+        __syncthreads();
+        if (kt0 + 16 < a.Sk) fetch(kt0 + 16);
+        // S^T[key][q] and dP^T[key][q]: A = K / V rows (b128), B = q / dO fragments
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+        const float* kp = &Ks[c16 * LD + 4 * g4];
+        const float* vp = &Vs[c16 * LD + 4 * g4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + c * 16);
+            const float4 vf = *reinterpret_cast<const float4*>(vp + c * 16);
+            f32x4& ss = (c & 1) ? s1 : s0;
+            f32x4& pp = (c & 1) ? p1 : p0;
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, dof[c].x, pp, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, dof[c].y, pp, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, dof[c].z, pp, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, dof[c].w, pp, 0, 0, 0);
+        }
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool kok = kt0 + 4 * g4 + r < a.Sk;
+            const float p = (kok && q_ok) ? __expf((s0[r] + s1[r]) - lse_q) : 0.f;
+            float dp = p0[r] + p1[r];
+            if (a.drop.enabled)  // O = (P o mask / (1-p)) V: dP = (dO V^T) o mask / (1-p); D = dO . O is unchanged
+                dp = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk + kt0 + 4 * g4 + r)
+                         ? dp * a.drop.scale : 0.f;
+            ds[r] = p * (dp - dsum);
+        }
+        // dQ^T[d][q] += sum_key K[key][d] * dS^T[key][q]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* kr = &Ks[(4 * g4 + r) * LD + c16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dqacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[c * 16], ds[r], dqacc[c], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        float* dp = a.dq + qrow * a.ld_dq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(dp + c * 16) = make_float4(dqacc[c][0] * a.scale, dqacc[c][1] * a.scale,
+                                                                  dqacc[c][2] * a.scale, dqacc[c][3] * a.scale);
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdArgs a) {
+    constexpr int NC = DH / 16, LD = DH + 4, F4 = DH / 4, PT = 2 * 16 * F4 / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int nkc = (a.Sk + 63) / 64;
+    const long long gh = blockIdx.x / nkc;
+    const int kc = (int)(blockIdx.x - gh * nkc);
+    const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
+    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const int kj = kc * 64 + wave * 16 + c16;
+    const bool k_ok = kj < a.Sk;
+    const long long krow = krow0 + (long long)(k_ok ? kj : 0) * a.k_rs;
+
+    float4 kf[NC], vf[NC];
+    {
+        const float* kp = a.k + krow * a.ldk + h * DH + 4 * g4;
+        const float* vp = a.v + krow * a.ldv + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 kv = k_ok ? *reinterpret_cast<const float4*>(kp + c * 16) : z;
+            kf[c] = make_float4(kv.x * a.scale, kv.y * a.scale, kv.z * a.scale, kv.w * a.scale);
+            vf[c] = k_ok ? *reinterpret_cast<const float4*>(vp + c * 16) : z;
+        }
+    }
+    f32x4 dkacc[NC], dvacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 st[PT];
+    auto fetch = [&](int qt0) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int e = tid + 256 * j, which = e / (16 * F4), r = (e % (16 * F4)) / F4, c4 = e % F4;
+            st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qt0 + r < a.Sq) {
+                const long long row = qrow0 + (long long)(qt0 + r) * a.q_rs;
+                st[j] = which ? *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4)
+                              : *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
+            }
+        }
+    };
+    auto stash = [&](float* buf) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int e = tid + 256 * j, which = e / (16 * F4), r = (e % (16 * F4)) / F4, c4 = e % F4;
+            *reinterpret_cast<float4*>(&buf[(which * 16 + r) * LD + c4 * 4]) = st[j];
+        }
+    };
+    fetch(0);
+    int it = 0;
+    for (int qt0 = 0; qt0 < a.Sq; qt0 += 16, ++it) {
+        float* Qs = smem + (it & 1) * 2 * 16 * LD;
+        float* Gs = Qs + 16 * LD;  // dO rows
+        stash(Qs);
+        __syncthreads();
+        if (qt0 + 16 < a.Sq) fetch(qt0 + 16);
+        // S[q][key] and dP[q][key]: A = Q / dO rows (b128), B = k / v fragments; lane gets q = 4*g4 + r, key = c16
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+        const float* qp = &Qs[c16 * LD + 4 * g4];
+        const float* gp = &Gs[c16 * LD + 4 * g4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 qv = *reinterpret_cast<const float4*>(qp + c * 16);
+            const float4 gv = *reinterpret_cast<const float4*>(gp + c * 16);
+            f32x4& ss = (c & 1) ? s1 : s0;
+            f32x4& pp = (c & 1) ? p1 : p0;
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, pp, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[c].y, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, vf[c].y, pp, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kf[c].z, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.z, vf[c].z, pp, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kf[c].w, ss, 0, 0, 0);
+            pp = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, pp, 0, 0, 0);
+        }
+        float pr[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt0 + 4 * g4 + r;
+            const bool ok = k_ok && q < a.Sq;
+            float lse = 0.f, dv = 0.f;
+            if (ok) {
+                const long long row = qrow0 + (long long)q * a.q_rs;
+                lse = a.lse[row * a.H + h];
+                dv = a.dvec[row * a.H + h];
+            }
+            pr[r] = ok ? __expf((s0[r] + s1[r]) - lse) : 0.f;
+            const float dp = p0[r] + p1[r];
+            float keep = 1.f;
+            if (a.drop.enabled)
+                keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + q) * a.Sk + kj) ? a.drop.scale : 0.f;
+            ds[r] = pr[r] * (dp * keep - dv);
+            pr[r] *= keep;  // dV uses the dropped probabilities
+        }
+        // dV^T[d][key] += sum_q dO[q][d] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* gr = &Gs[(4 * g4 + r) * LD + c16];
+            const float* qr = &Qs[(4 * g4 + r) * LD + c16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                dvacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[c * 16], pr[r], dvacc[c], 0, 0, 0);
+                dkacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[c * 16], ds[r], dkacc[c], 0, 0, 0);
+            }
+        }
+    }
+    if (k_ok) {
+        float* dkp = a.dk + krow * a.ld_dk + h * DH + 4 * g4;
+        float* dvp = a.dv + krow * a.ld_dv + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            *reinterpret_cast<float4*>(dkp + c * 16) = make_float4(dkacc[c][0] * a.scale, dkacc[c][1] * a.scale,
+                                                                   dkacc[c][2] * a.scale, dkacc[c][3] * a.scale);
+            *reinterpret_cast<float4*>(dvp + c * 16) = make_float4(dvacc[c][0], dvacc[c][1], dvacc[c][2], dvacc[c][3]);
+        }
+    }
+}
+
 // ---- sequences of at most 4 steps (motion attention over T' = 4 at the headline shape): ONE pass -------------------------
 // A (track, head) unit is 4 rows each of q, k, v, o, dO in and of dQ, dK, dV out - pure streaming.  The two-pass kernels above
 // pad it to a 16 x 16 tile, stage it through LDS per wave and read q, k, v, dO twice: 406 us per launch pair at 64 samples
@@ -350,6 +596,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
     }
 }
 
+int g_attn_bwd_blk = 1;    // sola_tune "attn_bwd_blk": 0 = per-wave staging (the round-1 kernels) for every shape (A/B)
 int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels for every shape (A/B)
 
 static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
@@ -376,13 +623,43 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
         once.done(dev);
     }
     AttnBwdArgs a = a0;
-    a.ntile = (a.Sq + 15) / 16;
-    long long units = (long long)a.G * a.H * a.ntile;
-    SOLA_ARG((units + 3) / 4 < (1ll << 31), "attention backward: grid too large");
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
-    SOLA_LAUNCH_CHECK();
+    bool done_dq = false;
+    if constexpr (DH == 128) if (g_attn_bwd_blk) {  // block-shared double-buffered staging (dvec is written by the dQ pass, read by the dK/dV pass)
+        constexpr size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
+        const long long bq = (long long)a.G * a.H * ((a.Sq + 63) / 64), bk = (long long)a.G * a.H * ((a.Sk + 63) / 64);
+        SOLA_ARG(bq < (1ll << 31) && bk < (1ll << 31), "attention backward: grid too large");
+        // a block of the shared-staging shape serves 64 queries (dQ) / 64 keys (dK, dV) of one unit: with one 16-row tile per
+        // unit three of its four waves would idle (16-step motion attention: 278 us per-wave vs 369 us), so those keep the
+        // per-wave kernels, where a block is four units
+        if (a.Sq > 16) {
+            hipLaunchKernelGGL((attn_bwd_dq_blk_kernel<DH>), dim3((unsigned)bq), dim3(256), lds2, s, a);
+            SOLA_LAUNCH_CHECK();
+            done_dq = true;
+        }
+        if (a.Sk > 16) {
+            if (!done_dq) {  // the dK/dV pass reads dvec = dO . O, which the dQ pass writes
+                a.ntile = (a.Sq + 15) / 16;
+                const long long u = (long long)a.G * a.H * a.ntile;
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3((unsigned)((u + 3) / 4)), dim3(256), lds, s, a);
+                SOLA_LAUNCH_CHECK();
+                done_dq = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dkv_blk_kernel<DH>), dim3((unsigned)bk), dim3(256), lds2, s, a);
+            SOLA_LAUNCH_CHECK();
+            return SOLA_OK;
+        }
+    }
+    long long units;
+    if (!done_dq) {
+        a.ntile = (a.Sq + 15) / 16;
+        units = (long long)a.G * a.H * a.ntile;
+        SOLA_ARG((units + 3) / 4 < (1ll << 31), "attention backward: grid too large");
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
+        SOLA_LAUNCH_CHECK();
+    }
     a.ntile = (a.Sk + 15) / 16;
     units = (long long)a.G * a.H * a.ntile;
+    SOLA_ARG((units + 3) / 4 < (1ll << 31), "attention backward: grid too large");
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -391,6 +668,7 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
 }  // namespace
 
 void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
+void sola_attn_set_bwd_blk(int v) { g_attn_bwd_blk = v; }
 
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");
