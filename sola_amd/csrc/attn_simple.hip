@@ -27,7 +27,9 @@ struct AttnSArgs {
     int xcd_remap;
 };
 
-template <int DH, int TK>
+// DB: two LDS stages of TK keys; the next tile's K/V rows travel in registers while the current tile is multiplied and there
+// is ONE barrier per tile (the shape that took the attention backward from 460 to 299 us, attn_bwd.hip).
+template <int DH, int TK, bool DB = false>
 __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnSArgs a) {
     constexpr int NC = DH / 16;
     constexpr int LDK = DH + 4, LDV = DH + 4;
@@ -66,9 +68,36 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
 #pragma unroll
     for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    for (int kt0 = 0; kt0 < Sk; kt0 += TK) {
+    constexpr int PT = DB ? 2 * TK * F4 / 256 : 1;  // float4 per thread and tile (K + V) of the prefetch
+    float4 st[PT];
+    auto fetch = [&](int kt0) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int e = tid + 256 * j, which = e / (TK * F4), r = (e % (TK * F4)) / F4, c4 = e % F4;
+            st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kt0 + r < Sk) {
+                const long long row = k0 + (long long)(kt0 + r) * k_rs;
+                st[j] = which ? *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4)
+                              : *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+            }
+        }
+    };
+    if (DB) fetch(0);
+    int it = 0;
+    for (int kt0 = 0; kt0 < Sk; kt0 += TK, ++it) {
         const int nrows = min(TK, Sk - kt0);
         const int nrows16 = (nrows + 15) & ~15;
+        if (DB) {
+            Ks = smem_s + (it & 1) * 2 * TK * LDK;
+            Vs = Ks + TK * LDK;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int e = tid + 256 * j, which = e / (TK * F4), r = (e % (TK * F4)) / F4, c4 = e % F4;
+                *reinterpret_cast<float4*>(&(which ? Vs : Ks)[r * LDK + c4 * 4]) = st[j];
+            }
+            __syncthreads();
+            if (kt0 + TK < Sk) fetch(kt0 + TK);
+        } else {
         if (kt0 > 0) __syncthreads();
         for (int idx = tid; idx < nrows16 * F4; idx += 256) {
             const int r = idx / F4, c4 = idx - r * F4;
@@ -82,6 +111,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
             *reinterpret_cast<float4*>(&Vs[r * LDV + c4 * 4]) = vv;
         }
         __syncthreads();
+        }
         const int ntile = nrows16 >> 4;
         f32x4 sc[TK / 16];
 #pragma unroll
@@ -452,6 +482,7 @@ int launch_splitm(const AttnSArgs& a0, hipStream_t s) {
     return SOLA_OK;
 }
 
+int g_attn_simple_db = 1;  // sola_tune "attn_simple_db": 1 = double-buffered 16-key stages with register prefetch
 int g_attn_simple_remap = 0;  // sola_tune "attn_simple_remap": XCD-contiguous block order; measured no gain (273.8 vs 275.8 us at 64 tracks, 392 vs 400 at 128)
 
 template <int DH>
@@ -462,6 +493,12 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
     const long long blocks = (long long)a.G * a.H * a.nqb;
     SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
     a.xcd_remap = (g_attn_simple_remap && blocks % 8 == 0) ? 1 : 0;
+    if (g_attn_simple_db) {  // two stages of 16 keys: the same LDS footprint (34 KB), next tile prefetched in registers
+        const size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
+        hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, 16, true>), dim3((unsigned)blocks), dim3(256), lds2, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
     const size_t lds = (size_t)2 * TK * (DH + 4) * sizeof(float);
     hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, TK>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
@@ -471,6 +508,7 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
 }  // namespace
 
 void sola_attn_set_simple_remap(int v) { g_attn_simple_remap = v; }
+void sola_attn_set_simple_db(int v) { g_attn_simple_db = v; }
 
 // sequences of <= 4 steps at head_dim 128, inference (no log-sum-exp, no dropout), f32 q / k / v
 bool attention_small_supported(const AttnDesc& d) {
