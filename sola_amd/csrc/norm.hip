@@ -277,6 +277,103 @@ __global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, lon
     }
 }
 
+// Large units (the object->language norm of a long video: N*T' = 2048 tokens x 128 channels = 1 MiB per unit; ragged batches
+// whose largest sample has more than 256 tokens): one block per unit walks the unit three times out of L2 and a launch has only
+// instances x groups blocks (256 at T = 128, N = 128, 32 samples: one block per CU, ~0.5 ms per launch where the traffic takes
+// 0.11).  Here a unit is cut into slices of 32 float4 per thread (256 tokens at 128 channels per group, a FIXED size, so a
+// sample's result does not depend on what else is in the batch) and two launches cover (unit, slice):
+//   stats : the slice is read once into registers -> (mean_i, M2_i = sum (x - mean_i)^2) -> a slot in scratch;
+//   apply : the slots of the unit are combined in slice order (Chan: M2 = sum M2_i + sum n_i (mean_i - mean)^2), then the
+//           slice is read again, normalised and stored (same epilogue as every other shape).
+// No inter-block waiting.  Traffic 2 reads + 1 write, from (units x slices) blocks.
+constexpr int GNC_R = 32;
+struct GncGeo { long long row0, tok_stride; int ntok, pe_row, g, inst, t0, tl, c4, tpp, nslice; };
+__device__ __forceinline__ GncGeo gnc_geo(const GnArgs& a, int S) {
+    GncGeo q;
+    const long long unit = blockIdx.x / S;
+    const int sl = (int)(blockIdx.x - unit * S);
+    const int f4 = a.cg >> 2;
+    q.inst = (int)(unit / a.groups); q.g = (int)(unit - (long long)q.inst * a.groups);
+    const GnUnit un = gn_unit(a, q.inst);
+    q.row0 = un.row0; q.tok_stride = un.tok_stride; q.ntok = un.ntok; q.pe_row = un.pe_row;
+    q.tpp = 256 / f4;
+    q.tl = threadIdx.x / f4; q.c4 = threadIdx.x - q.tl * f4;
+    const int ts = q.tpp * GNC_R;  // tokens per slice
+    q.nslice = (q.ntok + ts - 1) / ts;
+    q.t0 = sl < q.nslice ? sl * ts : -1;
+    return q;
+}
+__global__ __launch_bounds__(256) void group_norm_slice_stats_kernel(const GnArgs a, int S, float2* __restrict__ slots) {
+    __shared__ float red[4];
+    const GncGeo q = gnc_geo(a, S);
+    if (q.t0 < 0) return;  // block-uniform: this unit has fewer slices
+    const int ch = q.g * a.cg + q.c4 * 4;
+    float4 v[GNC_R];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < GNC_R; ++r) {
+        const int t = q.t0 + q.tl + r * q.tpp;
+        v[r] = t < q.ntok ? gn_load(a, (q.row0 + (long long)t * q.tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+    }
+    const int ntok_i = min(q.ntok - q.t0, q.tpp * GNC_R);
+    const float mean = block_sum_256(s, red) / ((float)ntok_i * (float)a.cg);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < GNC_R; ++r)
+        if (q.t0 + q.tl + r * q.tpp < q.ntok) {
+            const float d0 = v[r].x - mean, d1 = v[r].y - mean, d2 = v[r].z - mean, d3 = v[r].w - mean;
+            m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    m2 = block_sum_256(m2, red);
+    if (q.nslice > 1) {  // block-uniform
+        if (threadIdx.x == 0) slots[blockIdx.x] = make_float2(mean, m2);
+        return;
+    }
+    // a unit that fits one slice (the short samples of a ragged batch) is finished here, from the registers
+    const float rstd = 1.0f / sqrtf(m2 / ((float)ntok_i * (float)a.cg) + a.eps);
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)q.pe_row * a.C + ch);
+#pragma unroll
+    for (int r = 0; r < GNC_R; ++r) {
+        const int t = q.t0 + q.tl + r * q.tpp;
+        const long long off = t < q.ntok ? (q.row0 + (long long)t * q.tok_stride) * a.C + ch : -1;
+        gn_apply_store(a, off, v[r], mean, rstd, ga, be, pe, q.c4);
+    }
+}
+__global__ __launch_bounds__(256) void group_norm_slice_apply_kernel(const GnArgs a, int S, const float2* __restrict__ slots) {
+    const GncGeo q = gnc_geo(a, S);
+    if (q.t0 < 0 || q.nslice == 1) return;  // one-slice units were finished by the stats launch
+    const int ts = q.tpp * GNC_R;
+    const long long unit = blockIdx.x / S;
+    // combine the unit's slices in index order (every block of the unit computes the same numbers)
+    float mean = 0.f;
+    const float ntot = (float)q.ntok * (float)a.cg;
+    for (int i = 0; i < q.nslice; ++i) mean += slots[unit * S + i].x * ((float)min(q.ntok - i * ts, ts) * (float)a.cg / ntot);
+    float m2 = 0.f;
+    for (int i = 0; i < q.nslice; ++i) {
+        const float2 sm = slots[unit * S + i];
+        const float d = sm.x - mean;
+        m2 += sm.y + (float)min(q.ntok - i * ts, ts) * (float)a.cg * d * d;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / ntot + a.eps);  // biased variance, as nn.GroupNorm
+    const int ch = q.g * a.cg + q.c4 * 4;
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)q.pe_row * a.C + ch);
+#pragma unroll 4
+    for (int r = 0; r < GNC_R; ++r) {
+        const int t = q.t0 + q.tl + r * q.tpp;
+        // out-of-range token slots still take part in the split-f16 shuffles; off < 0 marks "do not store"
+        const long long off = t < q.ntok ? (q.row0 + (long long)t * q.tok_stride) * a.C + ch : -1;
+        const float4 v = off >= 0 ? gn_load(a, off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gn_apply_store(a, off, v, mean, rstd, ga, be, pe, q.c4);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void pos_encoding_kernel(const float* __restrict__ gauss, int half, int t_len, float max_len, float* pe) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,6 +479,25 @@ int launch_ws_standardize(const WsLayer* layers, int n_layers, hipStream_t s) {
 }
 
 int g_gn_variant = 1;  // 0 = always the three-pass kernel (A/B), 1 = register-resident shapes where the unit fits
+int g_gn_slices = 1;   // sola_tune "gn_slices": 0 = three-pass kernel for units that do not fit the registers (A/B)
+void sola_gn_set_slices(int v) { g_gn_slices = v; }
+// Per-device scratch of the sliced shape (slots of 8 bytes per (unit, slice) block): allocated on first use, grown when a
+// launch needs more; never during stream capture (the launch then takes the three-pass kernel).
+static float2* gn_slice_scratch(size_t bytes, hipStream_t s) {
+    static float2* buf[64] = {nullptr};
+    static size_t cap[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return nullptr;
+    if (cap[dev] >= bytes) return buf[dev];
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    // a previous launch on another stream may still read the old buffer: wait for the device before replacing it
+    if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
+    const size_t want = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+    if (hipMalloc(&buf[dev], want) != hipSuccess) { buf[dev] = nullptr; return nullptr; }
+    cap[dev] = want;
+    return buf[dev];
+}
 void sola_gn_set_variant(int v) { g_gn_variant = v; }
 
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
@@ -415,6 +531,19 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
         else if (rb <= 8) hipLaunchKernelGGL((group_norm_reg_kernel<8, false>), grid, dim3(256), 0, s, a, n_units);
         else if (rb <= 16) hipLaunchKernelGGL((group_norm_reg_kernel<16, false>), grid, dim3(256), 0, s, a, n_units);
         else hipLaunchKernelGGL((group_norm_reg_kernel<32, false>), grid, dim3(256), 0, s, a, n_units);
+    } else if (g_gn_variant != 0 && g_gn_slices && 256 % f4 == 0 && n_units < (1ll << 24)) {
+        // units of more than 32 float4 per thread: (unit, slice) blocks, two launches (stats, apply)
+        const int ts = (256 / f4) * GNC_R;
+        const int S = (d.ntok + ts - 1) / ts;
+        const long long blocks = n_units * S;
+        float2* slots = gn_slice_scratch((size_t)blocks * sizeof(float2), s);
+        if (slots && blocks < (1ll << 31)) {
+            hipLaunchKernelGGL(group_norm_slice_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, S, slots);
+            SOLA_LAUNCH_CHECK();
+            hipLaunchKernelGGL(group_norm_slice_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, S, slots);
+        } else {
+            hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+        }
     } else {
         hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
     }

@@ -78,7 +78,8 @@ def _gn_ref(x, gamma, beta, groups):
                                          torch.tensor(beta, dtype=torch.float64), groups).numpy()
 
 
-@pytest.mark.parametrize("B,N,Tp,C", [(2, 5, 3, 128), (1, 64, 4, 1024), (2, 3, 1, 64), (1, 7, 25, 512)])
+@pytest.mark.parametrize("B,N,Tp,C", [(2, 5, 3, 128), (1, 64, 4, 1024), (2, 3, 1, 64), (1, 7, 25, 512), (2, 75, 8, 1024), (1, 300, 7, 512),
+                                      (1, 128, 16, 1024)])  # the last three: units beyond the register shapes (sliced, two launches)
 def test_group_norm_addressing(B, N, Tp, C):
     """The four instance layouts used by the path, all on an [B,N,T',C] tensor."""
     rng = np.random.default_rng(C + N)

@@ -16,5 +16,5 @@ for tag, res, reg in (("lds", 1, 1), ("res", 2, 1), ("res+reg", 2, 2), ("lds", 1
     _lib.check(_lib.lib().sola_tune(b"attn_res", res), "tune"); _lib.check(_lib.lib().sola_tune(b"attn_reg", reg), "tune")
     r = bench.ragged_leg(cfg, m, torch.device("cuda", 0), 6, 288.0)
     for k in ("one_expression_per_video", "four_expressions_per_video"):
-        print(tag, k, json.dumps({kk: r[k][kk] for kk in ("value", "ms_per_launch")}), "attn", r[k]["kernel_ms_per_launch"]["attn"])
+        print(tag, k, json.dumps({kk: r[k][kk] for kk in ("value", "ms_per_launch")}), "attn", r[k]["kernel_ms_per_launch"]["attn"], "gn", r[k]["kernel_ms_per_launch"]["group_norm"])
 _lib.lib().sola_tune(b"attn_res", 1); _lib.lib().sola_tune(b"attn_reg", 1)
