@@ -276,6 +276,7 @@ void sola_attn_set_reg_minw(int v);
 void sola_attn_set_res(int v);
 void sola_attn_set_res_tiles(int v);
 void sola_attn_set_res_shape(int v);
+void sola_attn_set_res_splitm(int v);
 void sola_attn_set_bwd_small(int v);
 void sola_attn_set_bwd_blk(int v);
 void sola_gn_set_bwd_reg(int v);
@@ -306,6 +307,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_res")) { sola_attn_set_res(value); return SOLA_OK; }
     if (!strcmp(key, "attn_res_tiles")) { sola_attn_set_res_tiles(value); return SOLA_OK; }
     if (!strcmp(key, "attn_res_shape")) { sola_attn_set_res_shape(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_res_splitm")) { sola_attn_set_res_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_small")) { sola_attn_set_bwd_small(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_blk")) { sola_attn_set_bwd_blk(value); return SOLA_OK; }
     if (!strcmp(key, "gn_bwd_reg")) { sola_gn_set_bwd_reg(value); return SOLA_OK; }

@@ -112,6 +112,180 @@ __device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, co
     if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
 }
 
+// ---- the same shape in the split precision mode's arithmetic (AttnDesc::split_math) -----------------------------------------
+// The exact-f32 MFMA makes this shape co-bound by the matrix pipe (82 us of v_mfma_f32_16x16x4_f32 per launch at the headline
+// batch next to ~115 us of HBM time; measured 163-182 us).  In the split precision mode every dense contraction already runs
+// as hi*hi + hi*lo + lo*hi on f16 MFMAs (22-bit products), and here the conversion is cheap because K and V are staged ONCE
+// per block for 256 ... 2048 queries: while staging, K becomes (hi, lo) f16 rows and V becomes (hi, lo) TRANSPOSED f16 rows
+// ([dh][key], so both MFMA A-fragments are 8-byte LDS reads); per 16-query tile Q (32 values per lane) and P (12) are split
+// in registers.  3 x v_mfma_f32_16x16x16_f16 per 16-deep product step: 144 MFMAs of 8 cycles per tile instead of 192 of 32.
+// (attn_simple.hip's first attempt converted K/V per 64-query block and every wave re-split the fragments it read: slower.)
+typedef _Float16 half4r __attribute__((ext_vector_type(4)));
+struct HL4r { half4r hi, lo; };
+__device__ __forceinline__ HL4r split4r(float x, float y, float z, float w, float& amax) {
+    HL4r r;
+    const float in[4] = {x, y, z, w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 h1, l1;
+        split_f16(in[j], h1, l1);
+        r.hi[j] = h1; r.lo[j] = l1;
+        amax = fmaxf(amax, fabsf(in[j]));
+    }
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma3r(const HL4r& a, const HL4r& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.hi, c, 0, 0, 0);
+}
+constexpr int SM_KP = 136;  // K row pitch in halfs: 272 B = 16 B past a bank row, the 8-byte fragment reads of 16 keys x 2 k-groups tile the banks
+constexpr int SM_VP = 72;   // V^T row pitch in halfs: 144 B = 9 x 16 B (odd), up to 64 keys per row
+
+template <int NT>
+__device__ __forceinline__ void sm_tile(const AttnQArgs& a, const _Float16* Kh, const _Float16* Kl, const _Float16* Vh, const _Float16* Vl,
+                                        const float4 (&qf)[8], float* op, float* lsep, int Sk, int x, int g4, bool q_ok, float& amax) {
+    HL4r q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = split4r(qf[i].x, qf[i].y, qf[i].z, qf[i].w, amax);
+    f32x4 sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ko = (16 * t + x) * SM_KP + 4 * g4;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            HL4r k0, k1;
+            k0.hi = *reinterpret_cast<const half4r*>(Kh + ko + 16 * i); k0.lo = *reinterpret_cast<const half4r*>(Kl + ko + 16 * i);
+            k1.hi = *reinterpret_cast<const half4r*>(Kh + ko + 16 * i + 16); k1.lo = *reinterpret_cast<const half4r*>(Kl + ko + 16 * i + 16);
+            a0 = mfma3r(k0, q[i], a0);
+            a1 = mfma3r(k1, q[i + 1], a1);
+        }
+        const int key0 = 16 * t + 4 * g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float rs = 0.f;
+    HL4r p[NT];
+    float dummy = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[t][r] = __expf(sc[t][r] - mx);
+            rs += sc[t][r];
+        }
+        p[t] = split4r(sc[t][0], sc[t][1], sc[t][2], sc[t][3], dummy);
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    f32x4 oacc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int vo = (16 * c + x) * SM_VP + 16 * t + 4 * g4;
+            HL4r v;
+            v.hi = *reinterpret_cast<const half4r*>(Vh + vo); v.lo = *reinterpret_cast<const half4r*>(Vl + vo);
+            oacc[c] = mfma3r(v, p[t], oacc[c]);
+        }
+    if (!q_ok) return;
+    if (lsep && g4 == 0) *lsep = mx + logf(rs);
+    const float inv = 1.f / rs;
+    if (!a.o_sp16) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            *reinterpret_cast<float4*>(op + 16 * c + 4 * g4) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const HL4r o = split4r(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv, amax);
+        char* dst = reinterpret_cast<char*>(op + 16 * c + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+        *reinterpret_cast<half4r*>(dst) = o.hi;
+        *reinterpret_cast<half4r*>(dst + 16) = o.lo;
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void attn_fwd_sm_res_kernel(const AttnQArgs a) {
+    constexpr int DH = 128, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem_r[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 15, g4 = lane >> 4;
+    const unsigned lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long long unit = lb / a.nchunk;
+    if (unit >= (long long)a.G * a.H) return;
+    const int chunk = (int)(lb - unit * a.nchunk);
+    const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = __builtin_amdgcn_readfirstlane(qu.x); q_rs = __builtin_amdgcn_readfirstlane(qu.y); Sq = __builtin_amdgcn_readfirstlane(qu.z);
+        k0 = __builtin_amdgcn_readfirstlane(ku.x); k_rs = __builtin_amdgcn_readfirstlane(ku.y); Sk = __builtin_amdgcn_readfirstlane(ku.z);
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    const int qchunk = NW * 16 * a.tiles_per_wave;
+    const int qbeg = chunk * qchunk;
+    if (qbeg >= Sq || Sk <= 0) return;  // block-uniform
+    const int rows = (Sk + 15) & ~15;
+    _Float16* Kh = reinterpret_cast<_Float16*>(smem_r);
+    _Float16* Kl = Kh + rows * SM_KP;
+    _Float16* Vh = Kl + rows * SM_KP;      // V^T: [dh][key]
+    _Float16* Vl = Vh + DH * SM_VP;
+    float amax = 0.f;
+    // stage + convert: 32 float4 per row; rows past Sk are zero (a NaN there would survive the multiplication by p = 0)
+    for (int e = tid; e < rows * 32; e += NW * 64) {
+        const int r = e >> 5, c = e & 31;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (r < Sk) {
+            kv = *reinterpret_cast<const float4*>(a.k + (k0 + (long long)r * k_rs) * a.ldk + h * DH + 4 * c);
+            vv = *reinterpret_cast<const float4*>(a.v + (k0 + (long long)r * k_rs) * a.ldv + h * DH + 4 * c);
+        }
+        const HL4r kk = split4r(kv.x, kv.y, kv.z, kv.w, amax), vs = split4r(vv.x, vv.y, vv.z, vv.w, amax);
+        *reinterpret_cast<half4r*>(Kh + r * SM_KP + 4 * c) = kk.hi;
+        *reinterpret_cast<half4r*>(Kl + r * SM_KP + 4 * c) = kk.lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Vh[(4 * c + j) * SM_VP + r] = vs.hi[j];
+            Vl[(4 * c + j) * SM_VP + r] = vs.lo[j];
+        }
+    }
+    __syncthreads();
+    const int nt = rows >> 4;
+    for (int j = 0; j < a.tiles_per_wave; ++j) {
+        const int qt0 = qbeg + (j * NW + wave) * 16;  // the block's waves take neighbouring tiles
+        if (qt0 >= Sq) break;
+        const int qi = qt0 + x;
+        const bool q_ok = qi < Sq;
+        const long long qrow = q0 + (long long)(q_ok ? qi : Sq - 1) * q_rs;
+        const float* qp = a.q + qrow * a.ldq + h * DH + 4 * g4;
+        float4 qf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + 16 * i);
+        float* op = a.o + qrow * a.ldo + h * DH;
+        float* lsep = a.lse ? a.lse + qrow * a.H + h : nullptr;
+        if (nt == 3) sm_tile<3>(a, Kh, Kl, Vh, Vl, qf, op, lsep, Sk, x, g4, q_ok, amax);
+        else if (nt == 4) sm_tile<4>(a, Kh, Kl, Vh, Vl, qf, op, lsep, Sk, x, g4, q_ok, amax);
+        else if (nt == 2) sm_tile<2>(a, Kh, Kl, Vh, Vl, qf, op, lsep, Sk, x, g4, q_ok, amax);
+        else sm_tile<1>(a, Kh, Kl, Vh, Vl, qf, op, lsep, Sk, x, g4, q_ok, amax);
+    }
+    // anything that left the f16 range (q, k, v or the output pairs; NaN fails the comparison too): the forward repeats in f32
+    if (a.guard && !(amax < 65000.f)) atomicOr(a.guard, 1);
+}
+
 // NW waves per block, compiled for MINW waves per SIMD.  PF: the Q rows of a wave's next tile are requested into a second
 // register set before the current tile is computed (needs the 168 VGPRs of MINW = 3; at 128 it spills and loses).
 template <int NW, int MINW, bool PF>
@@ -200,10 +374,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_f32_res_kernel(const A
 
 int g_attn_res = 1;              // sola_tune "attn_res": 0 = never this shape (A/B), 2 = also for ragged batches
 int g_attn_res_tiles = 0;        // 16-query tiles per wave and block; 0 = up to 4, the chunks of a unit made equal
+int g_attn_res_splitm = 0;      // sola_tune "attn_res_splitm": 1 = f16-MFMA triples when the caller's arithmetic is the split mode's.  Measured:
+                                // 181 -> 175 us at 256 x 48, 163 -> 165 us at 2048 x 48 - removing 3/4 of the matrix-pipe time buys almost
+                                // nothing, so the pipe is not what bounds this shape (its 64-byte pieces per row and instruction are); off
 int g_attn_res_shape = 0;        // 0 = auto, 1 = 8 waves / 128 VGPRs / no prefetch, 2 = 4 waves / 168 VGPRs / next-tile prefetch
 void sola_attn_set_res(int v) { g_attn_res = v; }
 void sola_attn_set_res_tiles(int v) { g_attn_res_tiles = v < 0 ? 0 : v; }
 void sola_attn_set_res_shape(int v) { g_attn_res_shape = v; }
+void sola_attn_set_res_splitm(int v) { g_attn_res_splitm = v; }
 
 // f32 q / k / v at head_dim 128, no dropout, at most 64 keys and enough queries per unit to pay for staging K/V
 bool attention_res_supported(const AttnDesc& d) {
@@ -251,6 +429,30 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     // measured at 256 samples (256 queries x 48 keys per unit, tools/attn_probe3.py): 8 waves without prefetch 183 us, three
     // 4-wave blocks per CU with the next tile's Q prefetched 191 us, attn.hip's resident loop 206 us
+    if (d.split_math && g_attn_res_splitm) {  // the split precision mode's arithmetic (f16 MFMA triples, K/V converted once per block)
+        a.guard = d.guard;
+        a.tiles_per_wave = g_attn_res_tiles > 0 ? g_attn_res_tiles : 0;
+        if (a.tiles_per_wave == 0) {
+            const int per_tile = 8 * 16, nch = (d.Sq + 4 * per_tile - 1) / (4 * per_tile);
+            a.tiles_per_wave = (d.Sq + per_tile * nch - 1) / (per_tile * nch);
+        }
+        const int qchunk = 8 * 16 * a.tiles_per_wave;
+        a.nchunk = (d.Sq + qchunk - 1) / qchunk;
+        const long long blocks = ((long long)d.G * d.H * a.nchunk + 7) / 8 * 8;
+        SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+        const int rows = (d.Sk + 15) & ~15;
+        const size_t lds = ((size_t)2 * rows * SM_KP + (size_t)2 * 128 * SM_VP) * sizeof(_Float16);
+        static DeviceOnce once;
+        int dev;
+        if (once.needed(&dev)) {
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_sm_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(((size_t)2 * 64 * SM_KP + (size_t)2 * 128 * SM_VP) * sizeof(_Float16))));
+            once.done(dev);
+        }
+        hipLaunchKernelGGL(attn_fwd_sm_res_kernel, dim3((unsigned)blocks), dim3(512), lds, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
     if (g_attn_res_shape == 2) return launch_res<4, 3, true>(a, d, s);
     return launch_res<8, 4, false>(a, d, s);
 }

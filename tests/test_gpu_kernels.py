@@ -198,6 +198,8 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
     q64, k64, v64 = (t.astype(np.float64) for t in (q, k, v))
     qc, kc, vc = (cuda(t).reshape(B * N * Tp, D) for t in (q, k, v))
     _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 1), "sola_tune")
+    _lib.check(_lib.lib().sola_tune(b"attn_splitm", 1), "sola_tune")      # both split-math shapes are off by default (measured slower /
+    _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 1), "sola_tune")  # no faster than exact f32): forced here
     try:
         tr = lambda t: np.transpose(t, (0, 2, 1, 3)).reshape(B * Tp, N, D)
         ref = _attn_ref(tr(q64), tr(k64), tr(v64), H).reshape(B, Tp, N, D).transpose(0, 2, 1, 3)
@@ -215,3 +217,5 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
             assert_close(got.reshape(B, N, Tp, D), ref, rel=2e-5, name=f"o2l attention (split math) W={Wn}")
     finally:
         _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 0), "sola_tune")
+        _lib.check(_lib.lib().sola_tune(b"attn_splitm", 0), "sola_tune")
+        _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 0), "sola_tune")
