@@ -224,16 +224,33 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     }
 }
 
+// Sum over a block of NTHR threads (NTHR / 64 waves); every thread gets the result; fixed combination order.
+template <int NTHR>
+__device__ __forceinline__ float block_sum_n(float v, float* red) {
+    if (NTHR == 256) return block_sum_256(v, red);
+    v = wave_sum(v);
+    __syncthreads();  // protect `red` from a previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTHR / 64; ++i) t += red[i];
+    return t;
+}
+
 // Register-resident shape: the whole unit is read ONCE into R float4 per lane, mean and the centred second moment are
 // taken from the registers, and the result is written straight out - one HBM read + one write, no re-read.
 //   WAVE = true : one wave per unit (units of <= 64*4*R floats: the encoder norms and the motion norm, 1-4 KiB each),
 //                 four units per block, shuffle reductions only;
 //   WAVE = false: one block per unit (the inter-object norm, 32 KiB, R = 8; the object->language norm, 128 KiB, R = 32).
-template <int R, bool WAVE>
-__global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, long long n_units) {
-    __shared__ float red[4];
+//                 NTHR = 1024 for the largest units: 16 waves share a 128 KiB unit at 8 float4 per lane instead of 4 waves at 32 -
+//                 more loads in flight per unit and twice the waves per CU (173 -> ~100 us per launch at 256 samples: the
+//                 256-thread shape moved 515 MB at 3.0 TB/s where the small-unit shapes reach 5.4-5.8).
+template <int R, bool WAVE, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void group_norm_reg_kernel(const GnArgs a, long long n_units) {
+    __shared__ float red[NTHR / 64];
     const int f4 = a.cg >> 2;
-    const int nthr = WAVE ? 64 : 256;
+    const int nthr = WAVE ? 64 : NTHR;
     const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
     const long long unit = WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
     if (WAVE && unit >= n_units) return;  // a whole wave leaves; the WAVE shape has no block-level sync
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, lon
         v[r] = t < ntok ? gn_load(a, (row0 + (long long)t * tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
     }
-    const float mean = (WAVE ? wave_sum(s) : block_sum_256(s, red)) / cnt;
+    const float mean = (WAVE ? wave_sum(s) : block_sum_n<NTHR>(s, red)) / cnt;
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void group_norm_reg_kernel(const GnArgs a, lon
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     }
-    const float var = (WAVE ? wave_sum(q) : block_sum_256(q, red)) / cnt;  // biased, as nn.GroupNorm
+    const float var = (WAVE ? wave_sum(q) : block_sum_n<NTHR>(q, red)) / cnt;  // biased, as nn.GroupNorm
     const float rstd = 1.0f / sqrtf(var + a.eps);
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
@@ -479,6 +496,8 @@ int launch_ws_standardize(const WsLayer* layers, int n_layers, hipStream_t s) {
 }
 
 int g_gn_variant = 1;  // 0 = always the three-pass kernel (A/B), 1 = register-resident shapes where the unit fits
+int g_gn_wide = 1;     // sola_tune "gn_wide": 1024-thread blocks for units of 64-128 KiB (A/B)
+void sola_gn_set_wide(int v) { g_gn_wide = v; }
 int g_gn_slices = 1;   // sola_tune "gn_slices": 0 = three-pass kernel for units that do not fit the registers (A/B)
 void sola_gn_set_slices(int v) { g_gn_slices = v; }
 // Per-device scratch of the sliced shape (slots of 8 bytes per (unit, slice) block): allocated on first use, grown when a
@@ -529,8 +548,12 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
         if (rb <= 2) hipLaunchKernelGGL((group_norm_reg_kernel<2, false>), grid, dim3(256), 0, s, a, n_units);
         else if (rb <= 4) hipLaunchKernelGGL((group_norm_reg_kernel<4, false>), grid, dim3(256), 0, s, a, n_units);
         else if (rb <= 8) hipLaunchKernelGGL((group_norm_reg_kernel<8, false>), grid, dim3(256), 0, s, a, n_units);
-        else if (rb <= 16) hipLaunchKernelGGL((group_norm_reg_kernel<16, false>), grid, dim3(256), 0, s, a, n_units);
-        else hipLaunchKernelGGL((group_norm_reg_kernel<32, false>), grid, dim3(256), 0, s, a, n_units);
+        else if (rb <= 16 || !g_gn_wide || 1024 % f4 != 0) {
+            if (rb <= 16) hipLaunchKernelGGL((group_norm_reg_kernel<16, false>), grid, dim3(256), 0, s, a, n_units);
+            else hipLaunchKernelGGL((group_norm_reg_kernel<32, false>), grid, dim3(256), 0, s, a, n_units);
+        } else {
+            hipLaunchKernelGGL((group_norm_reg_kernel<8, false, 1024>), grid, dim3(1024), 0, s, a, n_units);  // rb in (16, 32]: 8 per lane at 1024 threads
+        }
     } else if (g_gn_variant != 0 && g_gn_slices && 256 % f4 == 0 && n_units < (1ll << 24)) {
         // units of more than 32 float4 per thread: (unit, slice) blocks, two launches (stats, apply)
         const int ts = (256 / f4) * GNC_R;
