@@ -128,12 +128,25 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
 // kernel above: 78-133 us per launch at 64 samples where the forward's register kernels take 19-55).
 //   WAVE = true : one wave per unit (encoder norms and the motion norm, units of <= 4 KiB), four units per block, shuffles only;
 //   WAVE = false: one block per unit (the inter-object norm: 32 KiB, R = 8).
-template <int R, bool WAVE>
-__global__ __launch_bounds__(256) void group_norm_bwd_reg_kernel(const GnBwdArgs a, long long n_units, int groups) {
-    __shared__ float red[4];
-    __shared__ float part[WAVE ? 1 : 256 * 8];
+//   NTHR = 1024 (block shape only): the 128 KiB object->language units at 8 float4 per lane and tensor (norm.hip's wide shape).
+template <int NTHR>
+__device__ __forceinline__ float bwd_block_sum(float v, float* red) {
+    if (NTHR == 256) return block_sum_256(v, red);
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTHR / 64; ++i) t += red[i];
+    return t;
+}
+template <int R, bool WAVE, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArgs a, long long n_units, int groups) {
+    __shared__ float red[NTHR / 64];
+    __shared__ float part[WAVE ? 1 : NTHR * 8];
     const int f4 = a.cg >> 2;
-    const int nthr = WAVE ? 64 : 256;
+    const int nthr = WAVE ? 64 : NTHR;
     const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
     const long long unit = WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
     if (WAVE && unit >= n_units) return;  // a whole wave leaves; the WAVE shape has no block-level sync
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256) void group_norm_bwd_reg_kernel(const GnBwdArgs
         }
         s += (xv[r].x + xv[r].y) + (xv[r].z + xv[r].w);
     }
-    const float mean = (WAVE ? wave_sum(s) : block_sum_256(s, red)) / cnt;
+    const float mean = (WAVE ? wave_sum(s) : bwd_block_sum<NTHR>(s, red)) / cnt;
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void group_norm_bwd_reg_kernel(const GnBwdArgs
             const float d0 = xv[r].x - mean, d1 = xv[r].y - mean, d2 = xv[r].z - mean, d3 = xv[r].w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
-    const float var = (WAVE ? wave_sum(q) : block_sum_256(q, red)) / cnt;
+    const float var = (WAVE ? wave_sum(q) : bwd_block_sum<NTHR>(q, red)) / cnt;
     const float rstd = 1.0f / sqrtf(var + a.eps);
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
@@ -200,8 +213,8 @@ __global__ __launch_bounds__(256) void group_norm_bwd_reg_kernel(const GnBwdArgs
             dv[r] = make_float4(g0, g1, g2, g3);   // dy' * gamma
         }
     }
-    const float m1 = (WAVE ? wave_sum(s1) : block_sum_256(s1, red)) / cnt;
-    const float m2 = (WAVE ? wave_sum(s2) : block_sum_256(s2, red)) / cnt;
+    const float m1 = (WAVE ? wave_sum(s1) : bwd_block_sum<NTHR>(s1, red)) / cnt;
+    const float m2 = (WAVE ? wave_sum(s2) : bwd_block_sum<NTHR>(s2, red)) / cnt;
     // per-channel partials: add up the token lanes that share a channel quad (fixed order)
     const long long po = (long long)inst * a.C + g * a.cg + c4 * 4;
     if (WAVE) {
@@ -523,6 +536,8 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
         if (rb <= 2) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<2, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
         else if (rb <= 4) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<4, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
         else hipLaunchKernelGGL((group_norm_bwd_reg_kernel<8, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
+    } else if (g_gn_bwd_reg && rb <= 32 && pow2 && f4 <= 256 && 1024 % f4 == 0 && n_units < (1ll << 31)) {
+        hipLaunchKernelGGL((group_norm_bwd_reg_kernel<8, false, 1024>), dim3((unsigned)n_units), dim3(1024), 0, s, a, n_units, d.groups);
     } else {
         hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
     }
