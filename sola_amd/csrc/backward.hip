@@ -10,6 +10,8 @@
 #include "ctx.h"
 
 extern int g_train_split_min_rows;
+int g_bwd_dual_cast = 1;  // sola_tune "bwd_dual_cast": the transposing cast of a gradient matrix also writes its row-major cast (A/B)
+void sola_set_bwd_dual_cast(int v) { g_bwd_dual_cast = v; }
 
 namespace {
 
@@ -182,14 +184,20 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     };
     struct WG { const float* dY; const float* X; float* dW; float* db; };
     // sc: scale slot from stats() over a matrix containing every dY of the call; db_done: the bias gradients were taken from it
-    auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in, float* sc = nullptr, bool db_done = false) -> int {
+    // dy_rm_done (optional, out): the call also left the ROW-MAJOR cast of the whole [rows][ldy] gradient matrix behind g[0].dY in
+    // "dy_sp" (same scale): the dX GEMMs of the same matrix then skip their own cast (grad_x's `cast_done`)
+    auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in, float* sc = nullptr, bool db_done = false,
+                           bool* dy_rm_done = nullptr) -> int {
+        if (dy_rm_done) *dy_rm_done = false;
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
             d.scal = sc; d.pure = pure;
+            if (dy_rm_done && sc && g_bwd_dual_cast) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy; }
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             if (d.scratch_bytes >= gemm_tn_split_scratch_bytes(rows, n_out, k_in, n)) {
+                if (dy_rm_done) *dy_rm_done = gemm_tn_split_writes_rm(d);
                 SOLA_TRY(launch_gemm_tn_split(d, s));
                 float* cs = ar.get("colsum");
                 const size_t csb = ar.total - ar.off.at("colsum");  // upper bound; launch_colsum uses what it needs
@@ -202,7 +210,9 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         return SOLA_OK;
     };
     // dX[rows, k_in] = dY[rows, n_cat] * Wcat (+ R), where wt holds Wcat^T as [k_in][n_cat]
-    auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX, float* sc = nullptr) -> int {
+    // cast_done: "dy_sp" already holds the row-major cast of the [rows][ldy] matrix that dY - col_off starts (grad_w_many)
+    auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX, float* sc = nullptr,
+                      bool cast_done = false, int col_off = 0) -> int {
         GemmDesc d{};
         d.nprob = 1;
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
@@ -212,11 +222,18 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             // dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal range), the
             // transposed weights with the fixed 2^6; the epilogue undoes both
             float* scal = sc ? sc : ar.get("scal");
-            if (sc) SOLA_TRY(cast_scaled(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
-            else SOLA_TRY(cast_auto(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
+            if (cast_done && sc) {
+                d.p[0].A = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(ar.get("dy_sp")) + col_off) : ar.get("dy_sp") + col_off;
+                d.lda = ldy;
+            } else {
+                if (sc) SOLA_TRY(cast_scaled(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
+                else SOLA_TRY(cast_auto(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
+                d.p[0].A = ar.get("dy_sp");
+                d.lda = n_cat;
+            }
             SOLA_TRY(cast_fixed(wt, n_cat, ar.get("wt_sp"), k_in, n_cat, kLinScale));
-            d.p[0].A = ar.get("dy_sp"); d.p[0].W = ar.get("wt_sp");
-            d.lda = n_cat; d.arith = lowp_arith; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
+            d.p[0].W = ar.get("wt_sp");
+            d.arith = lowp_arith; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
         }
         return launch_gemm(d, s);
     };
@@ -276,9 +293,10 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             SOLA_TRY(stats(dres, D, M, D, 2, &sc));
             if (sc) SOLA_TRY(bias_from_stats(0, D, G(an + ".out_proj.bias")));
             const WG wo[1] = {{dres, ab(a, "attn"), G(an + ".out_proj.weight"), G(an + ".out_proj.bias")}};
-            SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D, sc, sc != nullptr));
+            bool rm;
+            SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D, sc, sc != nullptr, &rm));
             SOLA_TRY(transpose_into(W(an + ".out_proj.weight"), D, D, D, 0));
-            return grad_x(dres, D, M, D, D, nullptr, dattn, sc);
+            return grad_x(dres, D, M, D, D, nullptr, dattn, sc, rm);
         };
 
         // (iii) object -> language: x_o2l = GN2(x_mot + attn(q(x_mot), k(lang), v(lang)) Wo)
@@ -297,7 +315,8 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             SOLA_TRY(stats(dqkv, 3 * D, M, D, 4, &scq));
             if (scq) SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
             const WG wq[1] = {{dqkv, x_mot, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")}};
-            SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr));
+            bool rmq;
+            SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr, &rmq));
             SOLA_TRY(stats(dlkv, 2 * D, B * Wn, 2 * D, 6, &sckv));
             if (sckv) {
                 SOLA_TRY(bias_from_stats(0, D, G(an + ".k_proj.bias")));
@@ -307,7 +326,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
                                {dlkv + D, fb("lang"), G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
             SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, B * Wn, D, D, sckv, sckv != nullptr));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, D, 0));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur], scq));  // d x_mot = dres + dq Wq
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur], scq, rmq));  // d x_mot = dres + dq Wq
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 2 * D, D));
             SOLA_TRY(grad_x(dlkv, 2 * D, B * Wn, 2 * D, D, dlang_init ? dlang : nullptr, dlang, sckv));  // accumulate over layers
@@ -337,12 +356,13 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             const WG w3[3] = {{dqkv, x_pe, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")},
                               {dqkv + D, x_pe, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                               {dqkv + 2 * D, x_obj, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
-            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr));
+            bool rm3;
+            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr, &rm3));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, D));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad, sc3));  // d(x_obj + pe) = dq Wq + dk Wk
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad, sc3, rm3, 0));  // d(x_obj + pe) = dq Wq + dk Wk
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, D, 0));
-            SOLA_TRY(grad_x(dqkv + 2 * D, 3 * D, M, D, D, dres, gbuf[1 - cur], sc3));  // d x_obj (direct) = dres + dv Wv
+            SOLA_TRY(grad_x(dqkv + 2 * D, 3 * D, M, D, D, dres, gbuf[1 - cur], sc3, rm3, 2 * D));  // d x_obj (direct) = dres + dv Wv
             cur = 1 - cur;
         }
         // (i) inter-object: x_obj = GN0(xin + attn(q,k,v(xin)) Wo); x_obj also feeds x_obj + pe
@@ -366,11 +386,12 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             const WG w3[3] = {{dqkv, xin, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")},
                               {dqkv + D, xin, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                               {dqkv + 2 * D, xin, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
-            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr));
+            bool rm3;
+            SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr, &rm3));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 3 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 3 * D, D));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 3 * D, 2 * D));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur], sc3));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur], sc3, rm3, 0));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
             cur = 1 - cur;
         }
         if (l > 0) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final

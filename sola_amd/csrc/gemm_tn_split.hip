@@ -29,7 +29,8 @@ __device__ __forceinline__ float auto_scale_t(unsigned amax_bits) {  // as cast.
 template <bool PURE>
 __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                                           int ld_in, long long ld_out, float* __restrict__ scal, int conv_T_in,
-                                                          int conv_T_out, int conv_stride, int conv_toff) {
+                                                          int conv_T_out, int conv_stride, int conv_toff, float* __restrict__ out_rm,
+                                                          long long ld_rm) {
     __shared__ float tile[128][65];
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
@@ -65,6 +66,28 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) tile[r][c4 + e] = v[e] * scale;
+            if (out_rm && r0 + r < rows) {  // the row-major cast of the same values (vec path guaranteed by the launcher)
+                const long long col = c0 + c4;
+                if (PURE) {
+                    typedef _Float16 half4t __attribute__((ext_vector_type(4)));
+                    half4t h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)(v[e] * scale);
+                    *reinterpret_cast<half4t*>(reinterpret_cast<_Float16*>(out_rm) + (long long)(r0 + r) * ld_rm + col) = h;
+                } else {  // 8-value blocks [hi8 | lo8]: this thread owns half a block
+                    typedef _Float16 half4t __attribute__((ext_vector_type(4)));
+                    half4t hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 h1, l1;
+                        split_f16(v[e] * scale, h1, l1);
+                        hi[e] = h1; lo[e] = l1;
+                    }
+                    char* dst = reinterpret_cast<char*>(out_rm + (long long)(r0 + r) * ld_rm + (col & ~7ll)) + 8 * ((col >> 2) & 1);
+                    *reinterpret_cast<half4t*>(dst) = hi;
+                    *reinterpret_cast<half4t*>(dst + 16) = lo;
+                }
+            }
         }
     }
     __syncthreads();
@@ -119,11 +142,11 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z
 }
 
 int cast_t(bool pure, const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
-           int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0) {
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (pure ? 6.0 : 8.0) * rows * cols);
+           int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0, float* out_rm = nullptr, long long ld_rm = 0) {
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, ((pure ? 6.0 : 8.0) + (out_rm ? (pure ? 2.0 : 4.0) : 0.0)) * rows * cols);
     const dim3 grid((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64));
-    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff);
-    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff);
+    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm);
+    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -158,6 +181,16 @@ int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, i
 
 bool gemm_tn_split_supported(int M, int N, int K) { return N % 8 == 0 && K % 8 == 0 && M >= 64; }
 
+// the row-major copy is written by the 16-byte-load path of the cast only: whole 64-column tiles, aligned slices
+bool gemm_tn_split_writes_rm(const GemmTnSplitDesc& d) {
+    if (!d.a_rm || d.N % 64 != 0 || d.lda % 4 != 0 || d.a_rm_ld % 8 != 0) return false;
+    for (int j = 0; j < d.nprob; ++j) {
+        const long long off = d.A[j] - d.A[0];
+        if (off < 0 || off % 8 != 0 || off + d.N > d.a_rm_ld) return false;
+    }
+    return true;
+}
+
 size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob) {
     int ks; long long Mp;
     geometry(M, ks, Mp, true);  // the f16-operand layout pads the rows further; sized for either
@@ -183,10 +216,17 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
         for (int j = 0; j < d.nprob; ++j) SOLA_TRY(launch_amax_accumulate(d.A[j], d.lda, d.M, d.N, scal, s));
     }
+    const bool rm = gemm_tn_split_writes_rm(d);
     const float* xt_of[3] = {nullptr, nullptr, nullptr};
     int n_xt = 0;
     for (int j = 0; j < d.nprob; ++j) {
-        SOLA_TRY(cast_t(pure, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s));
+        if (rm) {  // + the row-major cast of the same gradient matrix (the dX GEMM's operand): one read of dY for both
+            const long long off = d.A[j] - d.A[0];
+            float* dst = pure ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(d.a_rm) + off) : d.a_rm + off;
+            SOLA_TRY(cast_t(pure, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s, 0, 0, 1, 0, dst, d.a_rm_ld));
+        } else {
+            SOLA_TRY(cast_t(pure, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s));
+        }
         for (int e = 0; e < j; ++e)
             if (d.B[e] == d.B[j]) xt_of[j] = xt_of[e];
         if (!xt_of[j]) {

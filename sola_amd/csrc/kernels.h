@@ -70,6 +70,12 @@ struct GemmTnSplitDesc {
     float* scal_b;  // optional device pair with scal_b[0] = max|B| already computed: B is cast with that power-of-two scale too
                     // (activations whose magnitude the caller does not control: the object tokens); null = B is cast unscaled
     int pure;     // 1: plain f16 transposed operands and ONE f16 MFMA per product (training with f16 GEMM operands), else split-f16
+    // optional: the transposing cast of A also writes the ROW-MAJOR cast of A (same scale, the format of launch_cast_f16_scaled /
+    // launch_cast_sp16_scaled) - the operand of the dX GEMM that consumes the same gradient matrix - so dY is read once for both.
+    // a_rm addresses the value (row 0, column of A[0]); problem j lands at column A[j] - A[0]; a_rm_ld = row pitch in values.
+    // Needs N % 64 == 0 and column offsets % 8 == 0 (else ignored: check gemm_tn_split_writes_rm()).
+    float* a_rm;
+    int a_rm_ld;
     float* scratch;
     size_t scratch_bytes;
 };
@@ -79,6 +85,7 @@ int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out,
 // dx[(r, ti)][ci] = sum over taps of z[(r, to)][kk*cin + ci] (the scatter of a transposed conv, as a gather)
 int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s);
 bool gemm_tn_split_supported(int M, int N, int K);
+bool gemm_tn_split_writes_rm(const GemmTnSplitDesc& d);
 size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob);
 int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s);
 size_t gemm_tn_scratch_bytes(int M, int N, int K);
