@@ -379,7 +379,16 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
  * "pack_resample_lds": nearest-resampling mask pack, 1 (default) = source rows staged through LDS / 0 = per-pixel gather;
  * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
- * "attn_target_blocks").  Except under gemm_ablate, results are identical across variants up to f32 summation order. */
+ * "attn_target_blocks";
+ * attention forward shapes (round 2): "attn_reg" 0 / 1 (default: 5..16-step and 65..96-key units) / 2 (wherever it can run) =
+ * register-only MFMA shape; "attn_res" 0 / 1 (default: >= 128 queries against <= 64 keys, uniform batches) / 2 (ragged batches
+ * too) = resident-K/V shape, "attn_res_tiles", "attn_res_shape", "attn_res_splitm"; "attn_simple_db" 1 (default) = double-
+ * buffered 16-key stages in the high-occupancy shape; "attn_simple_remap"; "attn_splitm", "attn_stage_split_math" (tests);
+ * attention backward: "attn_bwd_small" 1 (default) = one-pass kernel for <= 4 steps, "attn_bwd_blk" 1 (default) = block-shared
+ * double-buffered staging (bit-identical to 0); GroupNorm: "gn_wide" 1024-thread shape for 64-128 KiB units, "gn_slices"
+ * two-launch sliced shape for larger units, "gn_bwd_reg" register-resident backward; "bwd_dual_cast" 1 (default) = the
+ * transposing cast of a gradient matrix also writes its row-major cast).
+ * Except under gemm_ablate, results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
 int sola_profile_enable(int enable);
 /* Synchronises the recorded events and returns, per category: launches, total milliseconds, algorithmic flops,
