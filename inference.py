@@ -21,7 +21,7 @@ import torch
 from sola_amd import dist as sdist
 from sola_amd import ops
 from sola_amd.config import load_configs
-from sola_amd.data import make_ragged_batches
+from sola_amd.data import DevicePrefetcher, make_ragged_batches
 from sola_amd.module import LanguageAlignedTrackSelectionModule
 from sola_amd.text import TextEncoder
 
@@ -41,9 +41,10 @@ def inference(cfg):
     out_dir = cfg["results"]["test_output_dir"]
     n_selected = n_tracks = n_samples = n_videos = n_calls = 0
     t_score = 0.0
-    for batch in batches:
+    t_wall0 = time.perf_counter()
+    for batch in DevicePrefetcher(batches, device):  # the next batch's tokens are copied to the GPU while this one is scored
         t0 = time.perf_counter()
-        videos = [v.to(device, non_blocking=True) for v in batch["videos"]]
+        videos = batch["videos"]
         texts, _pos = text.encode_ragged([s["expression"] for s in batch["samples"]])
         module.forward_ragged(videos, texts, batch["sample_video"])
         flat, _tok, _offs, counts = module.last_ragged
@@ -71,8 +72,10 @@ def inference(cfg):
                 os.makedirs(os.path.join(out_dir, vid), exist_ok=True)
                 np.save(os.path.join(out_dir, vid, f"{eid}_pred.npy"), p)
     rate = n_samples / t_score if t_score > 0 else 0.0
+    wall = n_samples / max(time.perf_counter() - t_wall0, 1e-9)
     print(f"[rank {rank}] selected {n_selected} of {n_tracks} tracks over {n_samples} samples / {n_videos} video passes in {n_calls} "
-          f"ragged calls ({rate:.1f} samples/s incl. text encoding and host copies; text encoder: {text.kind}); outputs in {out_dir}")
+          f"ragged calls ({rate:.1f} samples/s scoring incl. text encoding and the decision copy, token upload prefetched; "
+          f"{wall:.1f} samples/s wall incl. dataset reads and output files; text encoder: {text.kind}); outputs in {out_dir}")
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -52,10 +52,8 @@ class TextEncoder:
             lens = enc["attention_mask"].sum(1).tolist()
             toks = [tok[b, :int(n)] for b, n in enumerate(lens)]
         else:
-            toks = []
-            for e in expressions:
-                t, _ = self.encode([e])
-                toks.append(t[0])
+            tok, _ = self.encode(list(expressions))  # one padded host array + ONE copy; every expression keeps its own length
+            toks = [tok[b, :len(e.lower().split()) + 2] for b, e in enumerate(expressions)]
         pos = torch.stack([t.mean(0) for t in toks], 0)
         return toks, pos
 
@@ -72,10 +70,14 @@ class TextEncoder:
         L = max(len(w) for w in words)
         tok = np.zeros((len(words), L, self.dim), dtype=np.float32)
         mask = np.zeros((len(words), L, 1), dtype=np.float32)
+        cache = self.__dict__.setdefault("_word_cache", {})  # a word's stand-in vector is a pure function of the word
         for b, ws in enumerate(words):
             for i, w in enumerate(ws):
-                seed = int.from_bytes(hashlib.sha256(w.encode()).digest()[:8], "little")
-                tok[b, i] = np.random.Generator(np.random.PCG64(seed)).standard_normal(self.dim) * 0.5
+                vec = cache.get(w)
+                if vec is None:
+                    seed = int.from_bytes(hashlib.sha256(w.encode()).digest()[:8], "little")
+                    vec = cache[w] = (np.random.Generator(np.random.PCG64(seed)).standard_normal(self.dim) * 0.5).astype(np.float32)
+                tok[b, i] = vec
                 mask[b, i] = 1.0
         pos = (tok * mask).sum(1, keepdims=True) / np.maximum(mask.sum(1, keepdims=True), 1e-9)
         return torch.from_numpy(tok).to(self.device), torch.from_numpy(pos).to(self.device)

@@ -19,7 +19,7 @@ import torch
 
 from sola_amd import dist as sdist
 from sola_amd.config import load_configs
-from sola_amd.data import make_loader, make_ragged_batches
+from sola_amd.data import make_loader, make_ragged_batches, DevicePrefetcher
 from sola_amd.loss import track_selection_losses, track_selection_losses_ragged
 from sola_amd.module import LanguageAlignedTrackSelectionModule
 from sola_amd.text import TextEncoder
@@ -83,8 +83,8 @@ def run_split_ragged(module, text, batches, tcfg, device, world=1):
     counts4 = torch.zeros(4, device=device)  # TP FP FN TN
     bce_eval = torch.zeros(1, device=device)
     n = 0
-    for batch in batches:
-        videos = [v.to(device, non_blocking=True) for v in batch["videos"]]
+    for batch in DevicePrefetcher(batches, device):  # the next batch's tokens are uploaded while this one is scored
+        videos = batch["videos"]
         texts, pos = text.encode_ragged([s["expression"] for s in batch["samples"]])
         module.forward_ragged(videos, texts, batch["sample_video"])
         flat, tok, offs, counts = module.last_ragged
