@@ -204,7 +204,7 @@ class SyntheticTracks(torch.utils.data.Dataset):
             tok = last[1]
         else:
             vrng = np.random.Generator(np.random.PCG64(self.seed * 1000003 + 7 * vid + 1))  # tokens belong to the VIDEO
-            tok = torch.from_numpy(vrng.standard_normal((N, T, self.d)).astype(np.float32))
+            tok = torch.from_numpy(vrng.standard_normal((N, T, self.d), dtype=np.float32))  # drawn as f32: half the host time
             self._last_video = (vid, tok)
         rng = np.random.Generator(np.random.PCG64(self.seed * 1000003 + 1000 * idx + 3))
         iou = torch.from_numpy(np.where(rng.uniform(size=N) < 0.2, 0.9, 0.1).astype(np.float32))
@@ -344,6 +344,10 @@ def make_loader(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, 
     ds = make_dataset(cfg_dataset, split, synthetic, model_cfg)
     # training shards are padded to equal length: one gradient all-reduce per step must meet its peers on every rank
     sub = torch.utils.data.Subset(ds, shard_indices(len(ds), rank, world, pad=(split == "train")))
-    loader = torch.utils.data.DataLoader(sub, batch_size=sc.get("batch_size", 1), shuffle=(split == "train"),
-                                         num_workers=0 if use_syn else int(cfg_dataset.get("num_workers", 0)), pin_memory=True, collate_fn=collate)
+    # worker processes also for the synthetic stand-in: drawing a sample's tokens on the host (numpy, 0.5 M normals at 64 x 32
+    # tracks x frames) is ~5 ms, 40x the GPU time of the sample at 64 samples per step (tools/train_rate.sh)
+    nw = int(cfg_dataset.get("num_workers", 0))
+    loader = torch.utils.data.DataLoader(sub, batch_size=sc.get("batch_size", 1), shuffle=(split == "train"), num_workers=nw,
+                                         pin_memory=True, collate_fn=collate, persistent_workers=nw > 0,
+                                         prefetch_factor=4 if nw > 0 else None)
     return loader, ds

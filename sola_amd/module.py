@@ -409,22 +409,34 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         return flat.reshape(rows.value, cols.value).clone()
 
     # ------------------------------------------------------------------------------------------ a7
-    def get_grad_norm_dict(self):
-        """module/module.py:164-199 with one device reduction per group and a single host sync."""
+    def _grad_groups(self):
         groups = [("short_motion_encoder", list(self.short_motion_encoder.parameters()))]
         groups += [(f"scmola_layer_{i}", list(layer.parameters())) for i, layer in enumerate(self.object_lang_align_layers)]
         groups.append(("negative_token", list(self.negative_token.parameters())))
+        return groups
+
+    def _grad_sq_device(self):
+        """Per-group sums of squares of the gradients + their total as device doubles (one multi-tensor launch, NO host
+        sync); None when there are no gradients."""
+        groups = self._grad_groups()
         tensors, group_ids = [], []
         for gi, (_name, params) in enumerate(groups):
             for p in params:
                 if p.grad is not None:
                     tensors.append(p.grad)
                     group_ids.append(gi)
-        n_groups = len(groups)
         if not tensors:
+            return None
+        return self._grad_sqnorms(tensors, group_ids, len(groups))
+
+    def get_grad_norm_dict(self):
+        """module/module.py:164-199 with one device reduction per group and a single host sync."""
+        groups = self._grad_groups()
+        n_groups = len(groups)
+        sq = self._grad_sq_device()
+        if sq is None:
             vals = [0.0] * n_groups
         else:
-            sq = self._grad_sqnorms(tensors, group_ids, n_groups)
             # device doubles, reused by clip_grad_norm_ without another reduction - but only for these very gradient
             # values: the tag is every gradient's (storage, version), so an all-reduce, unscale, accumulation or a new
             # backward in between makes clip_grad_norm_ reduce again instead of clipping with a stale norm
@@ -461,17 +473,20 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm) (train.py:121-122) as one in-place multi-tensor
-        launch driven by the device-side total from the last get_grad_norm_dict(); no host sync."""
+        launch: the total norm is reduced on the device (or taken from a get_grad_norm_dict() of these very gradients) and
+        the kernel itself decides whether to scale - the reference's ``if total_grad_norm > clip`` without a host sync."""
         grads = [p.grad for p in self.parameters() if p.grad is not None]
         if not grads:
             return
         cached = getattr(self, "_last_grad_sq", None)
-        if cached is None or cached[1] != self._grad_tag(grads):
-            self.get_grad_norm_dict()
+        if cached is not None and cached[1] == self._grad_tag(grads):
+            sq = cached[0]
+        else:
+            sq = self._grad_sq_device()  # reduced on the device; the clip kernel reads the total there: no host sync
         n = len(grads)
         dev = grads[0].device
         ptrs = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
         numel = (C.c_int64 * n)(*[g.numel() for g in grads])
-        total = self._last_grad_sq[0][-1:]
+        total = sq[-1:]
         check(lib().sola_grad_clip(ptrs, numel, n, ptr(total), float(max_norm), current_stream(dev)), "sola_grad_clip")
         self._last_grad_sq = None
