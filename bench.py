@@ -267,6 +267,23 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
             res[prec]["what"] = ("mixed precision (BASELINE config C2): every GEMM of the step on plain f16 casts of the f32 activations / "
                                  "gradients, f32 accumulation, ONE MFMA per product; everything else f32.  Reduced precision: losses within "
                                  "1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py)")
+    # the reference's own regime: ONE sample per optimizer step (configs/mevis/default.yaml:37 batch_size 1), which is also what
+    # train.py runs on variable-shape data (sola_forward_train takes one uniform batch)
+    inp1 = {k: v[:1].contiguous() for k, v in inp.items()}
+
+    def step1():
+        opt.zero_grad(set_to_none=True)
+        sm, st = m(inp1["object_tokens"], inp1["lang_tokens"])
+        neg = m.negative_token.weight.clone().unsqueeze(0)
+        loss3 = track_selection_losses(sm, st, inp1["labels"], inp1["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
+        loss3[0].backward()
+        m.clip_grad_norm_(1.0)
+        opt.step()
+
+    m.precision = "f32"
+    dt1 = timed(step1, max(steps, 10), sync)
+    res["one_sample_per_step"] = {"value": round(1.0 / dt1, 1), "ms_per_step": round(dt1 * 1e3, 3), "precision": "f32",
+                                  "what": "the reference's training batch size; below 1024 token rows every precision mode runs the exact-f32 kernels"}
     del m, opt
     torch.cuda.empty_cache()
     return res

@@ -155,6 +155,28 @@ def test_attention_three_layouts(B, N, Tp, D, attn_reg_mode):
         assert_close(got.reshape(B, N, Tp, D), ref, name=f"o2l attention W={Wn}")
 
 
+@pytest.mark.parametrize("G,Sq,Sk", [(3, 130, 5), (2, 300, 64), (1, 128, 1), (4, 17, 33), (2, 200, 49), (1, 1000, 16), (5, 16, 16), (2, 65, 96),
+                                      (1, 129, 97)])
+def test_attention_cross_shapes(G, Sq, Sk, attn_reg_mode):
+    """Queries and keys of different counts from different matrices (the object->language pattern) at head_dim 128, through
+    whatever shape the routing / the forced register-only mode picks: ragged tails of the 16-row tiles, one key, 64 keys
+    exactly (four key tiles of the resident shape), more keys than it takes."""
+    H, D = 8, 1024
+    rng = np.random.default_rng(Sq * 131 + Sk)
+    q, k, v = rnd(rng, G, Sq, D), rnd(rng, G, Sk, D), rnd(rng, G, Sk, D)
+    ref = _attn_ref(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), H)
+    got, lse = ops.attention(cuda(q).reshape(G * Sq, D), cuda(k).reshape(G * Sk, D), cuda(v).reshape(G * Sk, D), G, H, Sq, Sk, 1,
+                             (Sq, 0, 1), (Sk, 0, 1), return_lse=True)
+    assert_close(got.reshape(G, Sq, D), ref, name=f"cross attention {Sq}x{Sk}")
+    # the log-sum-exp the backward reads
+    dh = D // H
+    s64 = np.einsum("gqhd,gkhd->ghqk", q.astype(np.float64).reshape(G, Sq, H, dh), k.astype(np.float64).reshape(G, Sk, H, dh)) / math.sqrt(dh)
+    lref = np.log(np.exp(s64 - s64.max(-1, keepdims=True)).sum(-1)) + s64.max(-1)
+    np.testing.assert_allclose(lse.cpu().numpy().reshape(G, Sq, H), lref.transpose(0, 2, 1), rtol=0, atol=2e-4)
+    got2 = ops.attention(cuda(q).reshape(G * Sq, D), cuda(k).reshape(G * Sk, D), cuda(v).reshape(G * Sk, D), G, H, Sq, Sk, 1, (Sq, 0, 1), (Sk, 0, 1))
+    assert_close(got2.reshape(G, Sq, D), ref, name=f"cross attention {Sq}x{Sk} (no lse)")
+
+
 @pytest.mark.parametrize("D", [128, 1024])
 def test_attention_online_softmax_rescale(D, attn_reg_mode):
     """Force the running-max rescale: one key in a later 64-key tile dominates (cdna guide rule 26)."""
