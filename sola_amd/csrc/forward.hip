@@ -31,6 +31,9 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
     // single-sample regime: scratch for the two-pass split-K of the GEMMs whose grid is smaller than the chip (gemm.hip)
     if ((long long)B * N * p.Tp <= 8192) p.add("splitk", 8192, 4096);
     p.add("pe", p.Tp, D);
+    // slots of the sliced GroupNorm shape (8 bytes per (unit, slice); units of more than 256 tokens at 128 channels per group):
+    // bounded by rows / 11 entries over every norm of the path
+    p.add("gn_slots", std::max<int64_t>(R * T, (int64_t)p.M) / 4 + 1024, 1);
     p.add("lang", (int64_t)B * p.W, D);
     p.add("lbar", B, D);
     if (!train && c->precision >= 1) {  // split-f16 (or f16) copies of the three f32-born GEMM inputs (forward_fast.hip, forward_f16.hip)
@@ -170,6 +173,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
             GroupNormDesc nd{};
+            nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);
             nd.x = buf("conv" + std::to_string(i)); nd.y = buf("act" + std::to_string(i)); nd.y2 = nullptr; nd.pe = nullptr;
             nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
             nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
@@ -240,6 +244,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,
                   long long outer, long long inner_stride, long long tok_stride, int ntok) -> int {
         GroupNormDesc nd{};
+            nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);
         nd.x = res; nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
         nd.gamma = W(lp + "norm." + std::to_string(idx) + ".weight");
         nd.beta = W(lp + "norm." + std::to_string(idx) + ".bias");

@@ -89,6 +89,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
             GroupNormDesc nd{};
+            nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);
             nd.x = buf("conv" + std::to_string(i)); nd.y = buf("act" + std::to_string(i));
             nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
             nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
@@ -132,6 +133,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
     auto gn = [&](const std::string& lp, int idx, float* y, float* y2, int f16_out, int n_inst, int inner, long long outer,
                   long long inner_stride, long long tok_stride, int ntok) -> int {
         GroupNormDesc nd{};
+            nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);
         nd.x = buf("res"); nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
         nd.gamma = W(lp + "norm." + std::to_string(idx) + ".weight");
         nd.beta = W(lp + "norm." + std::to_string(idx) + ".bias");

@@ -183,6 +183,16 @@ struct RagPlan {
     }
 };
 
+// slots of the sliced GroupNorm shape: a launch has (instances x 8 groups x slices of the LONGEST unit) blocks of 8 bytes; the
+// object->language norm has one instance per sample (up to maxRowsSample tokens), the encoder norms one per track (up to
+// maxT[1] tokens); slices are at least 128 tokens
+size_t rag_gn_slots_bytes(const RagShape& r) {
+    const size_t a = (size_t)r.S * ((size_t)r.maxRowsSample / 128 + 1);
+    const size_t b = (size_t)r.NT * ((size_t)r.maxT[1] / 128 + 1);
+    const size_t t = (size_t)std::max(r.sumTpV, r.sumTpS) * ((size_t)r.maxN / 128 + 1);  // inter-object norm: one instance per (sample, t')
+    return 8 * 8 * std::max(a, std::max(b, t)) + 4096;
+}
+
 RagPlan rag_plan(const SolaCtx* c, const RagShape& r) {
     RagPlan p;
     const size_t D = c->cfg.lang_token_dim, f = sizeof(float);
@@ -205,6 +215,7 @@ RagPlan rag_plan(const SolaCtx* c, const RagShape& r) {
     const size_t Mmax = (size_t)std::max(r.Mv, r.Ms);
     if (Mmax <= 8192) p.add("splitk", (size_t)8192 * 4096 * f);
     p.add("pe", (size_t)r.maxT[6] * D * f);
+    p.add("gn_slots", rag_gn_slots_bytes(r));  // sliced GroupNorm shape: 8 B per (unit, slice)
     p.add("lang", (size_t)r.LW * D * f);
     if (sp) p.add("lang_sp", (size_t)r.LW * D * f);
     p.add("lbar", (size_t)r.S * D * f);
@@ -308,6 +319,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
     const int V = r.V, S = r.S;
     float* const splitk_ws = p.off.count("splitk") ? buf("splitk") : nullptr;
     const size_t splitk_bytes = splitk_ws ? (size_t)8192 * 4096 * sizeof(float) : 0;
+    const size_t gn_slots_bytes = rag_gn_slots_bytes(r);
 
     // ---- descriptors -> device, unit tables
     const int32_t* trk_off_dev = nullptr;
@@ -401,6 +413,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
             GroupNormDesc nd{};
+            nd.slice_ws = raw("gn_slots"); nd.slice_ws_bytes = gn_slots_bytes;
             nd.x = buf("conv" + std::to_string(i)); nd.y = buf("act" + std::to_string(i));
             nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
             nd.n_inst = r.NT; nd.inner = 1; nd.tok_stride = 1;
@@ -447,6 +460,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
     auto gn = [&](int layer, int idx, float* y, float* y2, int out_sp16, const int4* units, int n_inst, int max_tok) -> int {
         const std::string lp = "object_lang_align_layers." + std::to_string(layer) + ".norm." + std::to_string(idx);
         GroupNormDesc nd{};
+            nd.slice_ws = raw("gn_slots"); nd.slice_ws_bytes = gn_slots_bytes;
         nd.x = buf("res"); nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
         nd.gamma = W(lp + ".weight"); nd.beta = W(lp + ".bias");
         nd.n_inst = n_inst; nd.inner = 1; nd.tok_stride = 1; nd.units = units; nd.ntok = max_tok;

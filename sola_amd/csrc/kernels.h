@@ -211,6 +211,11 @@ struct GroupNormDesc {
     const int4* units;
     int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices (statistics stay f32)
     const float* in_scale_dev;  // optional: x is multiplied by this device scalar while it is read (an input stored in scaled units)
+    // optional scratch of the sliced shape (units beyond the register shapes): 8 bytes per (unit, 256-token slice); the forward
+    // orchestrators pass a piece of the caller's workspace (concurrent calls on one device must not share it); null = a
+    // per-device buffer owned by the library (the stage entry point: one stream at a time)
+    void* slice_ws;
+    size_t slice_ws_bytes;
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);

@@ -559,7 +559,8 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
         const int ts = (256 / f4) * GNC_R;
         const int S = (d.ntok + ts - 1) / ts;
         const long long blocks = n_units * S;
-        float2* slots = gn_slice_scratch((size_t)blocks * sizeof(float2), s);
+        float2* slots = (d.slice_ws && d.slice_ws_bytes >= (size_t)blocks * sizeof(float2)) ? static_cast<float2*>(d.slice_ws)
+                                                                                         : gn_slice_scratch((size_t)blocks * sizeof(float2), s);
         if (slots && blocks < (1ll << 31)) {
             hipLaunchKernelGGL(group_norm_slice_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, S, slots);
             SOLA_LAUNCH_CHECK();
