@@ -21,7 +21,7 @@ void sola_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sola_last_error(void) { return g_err; }
-extern "C" const char* sola_version(void) { return "sola_hip 0.5 (gfx950; f32 and range-guarded split-f16 MFMA forward and backward, ragged batches, mask IoU + masklet rows)"; }
+extern "C" const char* sola_version(void) { return "sola_hip 0.6 (gfx950; f32, range-guarded split-f16 and f16-operand MFMA forward and backward, ragged batches, mask IoU + masklet rows)"; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // event profiler: start/stop HIP events on the launch stream around every kernel launch while enabled
