@@ -357,9 +357,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_f32_res_kernel(const A
     if (PF) {
         for (int j = 0; tile_live(j); j += 2) {
             if (tile_live(j + 1)) load_q(qB, j + 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the tile's MFMAs (the scheduler sinks loads to their uses)
             compute(qA, j);
             if (!tile_live(j + 1)) break;
             if (tile_live(j + 2)) load_q(qA, j + 2);
+            __builtin_amdgcn_sched_barrier(0);
             compute(qB, j + 1);
         }
     } else {
@@ -427,8 +429,12 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     a.tiles_per_wave = 1; a.nchunk = 1;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
-    // measured at 256 samples (256 queries x 48 keys per unit, tools/attn_probe3.py): 8 waves without prefetch 183 us, three
-    // 4-wave blocks per CU with the next tile's Q prefetched 191 us, attn.hip's resident loop 206 us
+    // measured at 256 samples (256 queries x 48 keys per unit, tools/attn_probe3.py): 8 waves without prefetch 180-183 us, three
+    // 4-wave blocks per CU with the next tile's Q prefetched (pinned in front of the MFMAs by sched_barrier) 191-193 us,
+    // attn.hip's resident loop 205 us.  Also measured without effect: staggered block starts (0-8 us), f16-MFMA triples (175 us:
+    // a quarter of the matrix-pipe time), and a plain copy with this kernel's 16-rows-x-64-bytes instruction footprint runs at
+    // 5.2-5.8 TB/s (tools/micro/strided_bw) - so neither the pipe, nor the bytes in flight, nor the access pattern, nor
+    // phase-locking explains the 3.6 TB/s; a per-phase timeline of the kernel is the next measurement
     if (d.split_math && g_attn_res_splitm) {  // the split precision mode's arithmetic (f16 MFMA triples, K/V converted once per block)
         a.guard = d.guard;
         a.tiles_per_wave = g_attn_res_tiles > 0 ? g_attn_res_tiles : 0;

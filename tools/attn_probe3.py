@@ -16,12 +16,12 @@ cases = {
     f"motion (Sq=Sk={Tp})": (lambda: ops.attention(q, k, v, B * N, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1)), 4 * M * D * 4),
     f"o2l (Sq={N * Tp},Sk=48)": (lambda: ops.attention(q, lk, lv, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1)), (2 * M + 2 * B * Wn) * D * 4),
 }
-modes = [("lds", 0, 0, 0), ("res", 0, 1, 1), ("res split-math", 0, 1, 7)]
+modes = [("lds", 0, 0, 0), ("res8", 0, 1, 1), ("res4 prefetch", 0, 1, 2)]
 for name, (fn, nbytes) in cases.items():
     best, outs = {}, {}
     for rnd in range(3):
         for mname, reg, minw, shape in modes:
-            lib.sola_tune(b"attn_reg", reg); lib.sola_tune(b"attn_res", 1 if minw else 0); lib.sola_tune(b"attn_res_tiles", 0 if minw <= 1 else minw); lib.sola_tune(b"attn_res_shape", 1); lib.sola_tune(b"attn_stage_split_math", 1 if shape == 7 else 0)
+            lib.sola_tune(b"attn_reg", reg); lib.sola_tune(b"attn_res", 1 if minw else 0); lib.sola_tune(b"attn_res_tiles", 0 if minw <= 1 else minw); lib.sola_tune(b"attn_res_shape", shape)
             o = fn(); torch.cuda.synchronize()
             outs[mname] = o
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +29,6 @@ for name, (fn, nbytes) in cases.items():
             for _ in range(20): fn()
             e1.record(); torch.cuda.synchronize()
             best[mname] = min(best.get(mname, 1e9), e0.elapsed_time(e1) / 20)
-    lib.sola_tune(b"attn_reg", 1); lib.sola_tune(b"attn_res", 1); lib.sola_tune(b"attn_res_tiles", 0); lib.sola_tune(b"attn_res_shape", 0); lib.sola_tune(b"attn_stage_split_math", 0)
-    diff = max(float((outs[m] - outs["lds"]).abs().max()) for m, _, _, _ in modes)
+    lib.sola_tune(b"attn_reg", 1); lib.sola_tune(b"attn_res", 1); lib.sola_tune(b"attn_res_tiles", 0); lib.sola_tune(b"attn_res_shape", 0)
+    diff = max(float((outs[m] - outs[modes[0][0]]).abs().max()) for m, _, _, _ in modes)
     print(f"{name:24s} " + "  ".join(f"{m}: {best[m]*1e3:7.1f} us ({nbytes/best[m]/1e6/8000*100:4.1f}%)" for m, _, _, _ in modes) + f"  maxdiff {diff:.1e}")
