@@ -434,7 +434,11 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     // attn.hip's resident loop 205 us.  Also measured without effect: staggered block starts (0-8 us), f16-MFMA triples (175 us:
     // a quarter of the matrix-pipe time), and a plain copy with this kernel's 16-rows-x-64-bytes instruction footprint runs at
     // 5.2-5.8 TB/s (tools/micro/strided_bw) - so neither the pipe, nor the bytes in flight, nor the access pattern, nor
-    // phase-locking explains the 3.6 TB/s; a per-phase timeline of the kernel is the next measurement
+    // phase-locking explains the 3.6 TB/s.  A per-phase timeline (wall_clock64 stamps per wave, 256 samples) reads: 7.0 us to the
+    // staging barrier, 4.7 us for the first tile's Q rows, 9.3 us of MFMA phase, 1.4 us of store drain, then 2.5 + 6.3 + 1.0 us
+    // for the second tile - about half of a 32 us block is memory latency under load.  Acting on it did not pay: requesting
+    // the first tile's Q rows before the staging 183 -> 197 us (the K/V loads queue behind them), all staging loads in front of
+    // the first LDS write 183 -> 183 us
     if (d.split_math && g_attn_res_splitm) {  // the split precision mode's arithmetic (f16 MFMA triples, K/V converted once per block)
         a.guard = d.guard;
         a.tiles_per_wave = g_attn_res_tiles > 0 ? g_attn_res_tiles : 0;
