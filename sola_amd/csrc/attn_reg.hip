@@ -255,6 +255,9 @@ void sola_attn_set_reg_minw(int v) { g_attn_reg_minw = v; }
 // re-reads the unit's K and V from L2 with one tile of prefetch, which two waves per SIMD do not cover.
 bool attention_reg_supported(const AttnDesc& d) {
     if (!g_attn_reg || d.drop.enabled || d.in_sp16 || d.DH != 128 || (d.Sq <= 4 && d.Sk <= 4)) return false;
+    // the kernel addresses a unit's key rows with 32-bit byte offsets from the unit's first row
+    const long long ld = d.ldk > d.ldv ? d.ldk : d.ldv;
+    if (!d.q_units && (long long)d.Sk * d.k_rs * ld * 4 >= (1ll << 32)) return false;
     if (g_attn_reg == 2) return true;
     // ragged batches (unit tables) mix unit sizes in one launch: measured slower there (attention of the 128-sample MeViS-like
     // bench batch 2.73 -> 3.02 ms with this shape and attn_res.hip routed in), so they keep the high-occupancy LDS shape
