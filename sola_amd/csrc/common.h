@@ -86,6 +86,14 @@ __device__ __forceinline__ float half_sum32(float v) {
     return a + b;
 }
 
+// Sum over the whole wave without the LDS crossbar: half_sum32, then one v_permlane32_swap across the halves.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = half_sum32(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // (lo, lo) and (hi, hi) of two copies
+    return a + b;
+}
+
 // Sum over a 256-thread block; every thread gets the result. `red` is >= 4 floats of LDS; deterministic order.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);

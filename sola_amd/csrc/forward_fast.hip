@@ -141,8 +141,25 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         if (i == 0) gd.out_scale_dev = c->scal_pair(0) + 1;
         gd.guard = c->guard;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
-        SOLA_TRY(launch_gemm(gd, s));
+        // conv0-2 at GPU-filling batches: the norm behind the conv (64 channels per group, 16 / 8 / 4 tokens per instance) is
+        // applied in the GEMM's epilogue and the activation written as split-f16 pairs directly (gemm_glds.hip, GNF)
+        bool fused_norm = false;
         if (i < 5) {
+            GemmDesc probe = gd;
+            probe.c_sp16 = 1;
+            if (gemm_gn_fusable(probe, g.cout / c->cfg.n_groups, p.Tl[i])) {
+                const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
+                gd.c_sp16 = 1;
+                gd.p[0].C = buf("act" + std::to_string(i));
+                gd.gn_gamma = W(np + ".weight"); gd.gn_beta = W(np + ".bias");
+                gd.gn_tokens = p.Tl[i]; gd.gn_eps = 1e-5f; gd.gn_slope = 0.01f;
+                fused_norm = true;
+            }
+        }
+        SOLA_TRY(launch_gemm(gd, s));
+        if (fused_norm) {
+            x = buf("act" + std::to_string(i));
+        } else if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
             GroupNormDesc nd{};
             nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);

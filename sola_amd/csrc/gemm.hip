@@ -484,6 +484,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
         return SOLA_OK;
     }
     if (glds) return launch_gemm_split_glds(d, s);
+    SOLA_ARG(!d.gn_gamma, "gemm: the fused GroupNorm epilogue needs the persistent direct-to-LDS kernel (check gemm_gn_fusable)");
     if (d.arith == 1) {
         SOLA_ARG(d.K % 16 == 0 && (d.conv ? d.Cin % 8 == 0 : d.lda % 8 == 0), "split-f16 gemm: K %% 16 and row pitch %% 8 required");
         if (big) return pipe ? launch_tile<128, 128, 1, 1>(a, d.nprob, s) : launch_tile<128, 128, 0, 1>(a, d.nprob, s);

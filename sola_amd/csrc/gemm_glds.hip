@@ -48,6 +48,11 @@ struct GldsArgs {
     const float* bias_scale_dev;  // optional device multiplier of the bias (GemmDesc::bias_scale_dev)
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
     int* guard;  // c_sp16: range guard word (GemmDesc::guard), null = unchecked
+    // GNF instantiation of the persistent kernel: GroupNorm (64 channels per group = a wave's 64 output columns, instances of
+    // gn_tokens = 4 / 8 / 16 consecutive rows) + LeakyReLU applied to the tile in the epilogue (GemmDesc::gn_gamma)
+    const float *gn_gamma, *gn_beta;
+    int gn_tokens;
+    float gn_eps, gn_slope;
 };
 
 __device__ __forceinline__ void guard_sp16x4(int* guard, const float (&v)[4]) {
@@ -380,7 +385,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 // compile-time so that the epilogue is straight-line code (with run-time flags the residual registers of the fast path
 // flow through phi nodes the register allocator keeps - and spills - across the whole tile loop).
 // PURE (see above): RMODE 3 = f16 residual, CSP = 2 writes C as plain f16.
-template <bool CONV, int RMODE, int CSP, bool PURE = false>
+// GNF (with CSP = 1, RMODE = 0, every tile interior): the norm that follows an encoder conv is applied HERE.  A GroupNorm
+// instance of conv0-2 is 16 / 8 / 4 consecutive token rows x 64 channels, and a 16-row epilogue strip of a wave is 16 rows x its
+// 64 output columns: whole instances, already in the wave's registers.  Per strip: the four passes' values are kept, the sums
+// per pass are reduced over the wave (DPP + permlane swaps, no LDS), combined to the instance means by the token count, the
+// centred squares likewise, then (v - mean) * rstd * gamma + beta, LeakyReLU, split-f16 store - the GroupNorm launch and its
+// read of the f32 conv output disappear (norm.hip's register shapes moved 8 bytes per element for them).
+template <bool CONV, int RMODE, int CSP, bool PURE = false, bool GNF = false>
 __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
     constexpr int MI = 4, WAVES_N = 4, GBM = 256, GBN = 256, NWAVE = 8;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
@@ -633,6 +644,11 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
             bv.z = n + 2 < a.N ? pr.bias[n + 2] * bsc : 0.f;
             bv.w = n + 3 < a.N ? pr.bias[n + 3] * bsc : 0.f;
         }
+        float4 gnw = make_float4(1.f, 1.f, 1.f, 1.f), gnb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GNF) {
+            gnw = *reinterpret_cast<const float4*>(a.gn_gamma + n);
+            gnb = *reinterpret_cast<const float4*>(a.gn_beta + n);
+        }
         // Interior tiles (every row and column in range, 16-byte aligned rows) take a straight-line path: no per-lane
         // predicates, so the number of stores a wave issues is known (see the relaxed wait at the next tile's first
         // k-tile), and the residual is fetched four strips ahead (64 registers; the fragment registers are dead here).
@@ -675,6 +691,58 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if constexpr (GNF) {
+                        float vv[4][4], sp[4];
+#pragma unroll
+                        for (int pass = 0; pass < 4; ++pass) {
+                            const int row = pass * 4 + rsub;
+                            const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
+                            vv[pass][0] = t.x * osc + bv.x; vv[pass][1] = t.y * osc + bv.y; vv[pass][2] = t.z * osc + bv.z; vv[pass][3] = t.w * osc + bv.w;
+                            sp[pass] = wave_sum_dpp((vv[pass][0] + vv[pass][1]) + (vv[pass][2] + vv[pass][3]));
+                        }
+                        // instance of a pass: 4 rows (one pass), 8 rows (passes 2u, 2u+1) or the whole strip
+                        const int tl = a.gn_tokens;
+                        const float cnt = (float)tl * 64.f;
+                        float mean[4], rstd[4];
+                        {
+                            const float s01 = sp[0] + sp[1], s23 = sp[2] + sp[3], sall = s01 + s23;
+                            mean[0] = (tl == 4 ? sp[0] : tl == 8 ? s01 : sall) / cnt;
+                            mean[1] = (tl == 4 ? sp[1] : tl == 8 ? s01 : sall) / cnt;
+                            mean[2] = (tl == 4 ? sp[2] : tl == 8 ? s23 : sall) / cnt;
+                            mean[3] = (tl == 4 ? sp[3] : tl == 8 ? s23 : sall) / cnt;
+                        }
+#pragma unroll
+                        for (int pass = 0; pass < 4; ++pass) {
+                            const float d0 = vv[pass][0] - mean[pass], d1 = vv[pass][1] - mean[pass], d2 = vv[pass][2] - mean[pass], d3 = vv[pass][3] - mean[pass];
+                            sp[pass] = wave_sum_dpp((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                        }
+                        {
+                            const float s01 = sp[0] + sp[1], s23 = sp[2] + sp[3], sall = s01 + s23;
+                            rstd[0] = 1.0f / sqrtf((tl == 4 ? sp[0] : tl == 8 ? s01 : sall) / cnt + a.gn_eps);
+                            rstd[1] = 1.0f / sqrtf((tl == 4 ? sp[1] : tl == 8 ? s01 : sall) / cnt + a.gn_eps);
+                            rstd[2] = 1.0f / sqrtf((tl == 4 ? sp[2] : tl == 8 ? s23 : sall) / cnt + a.gn_eps);
+                            rstd[3] = 1.0f / sqrtf((tl == 4 ? sp[3] : tl == 8 ? s23 : sall) / cnt + a.gn_eps);
+                        }
+                        const float gw[4] = {gnw.x, gnw.y, gnw.z, gnw.w}, gb[4] = {gnb.x, gnb.y, gnb.z, gnb.w};
+#pragma unroll
+                        for (int pass = 0; pass < 4; ++pass) {
+                            const int row = pass * 4 + rsub;
+                            const int m = m0 + wr_e * 128 + i * 32 + hf * 16 + row;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float y = (vv[pass][e] - mean[pass]) * rstd[pass] * gw[e] + gb[e];
+                                v[e] = y >= 0.f ? y : y * a.gn_slope;
+                            }
+                            _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
+                            half4 hh, ll;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
+                            *reinterpret_cast<half4*>(cb) = hh;
+                            *reinterpret_cast<half4*>(cb + 8) = ll;
+                            guard_sp16x4(a.guard, v);
+                        }
+                    } else
 #pragma unroll
                     for (int pass = 0; pass < 4; ++pass) {
                         const int row = pass * 4 + rsub;
@@ -833,10 +901,12 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     return SOLA_OK;
 }
 
+int g_gemm_gn_fuse = 1;  // sola_tune "gemm_gn_fuse": 0 = never apply the encoder norms in the GEMM epilogue (A/B)
+void sola_gemm_set_gn_fuse(int v) { g_gemm_gn_fuse = v; }
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 
-template <bool CONV, int RMODE, int CSP, bool PURE = false>
+template <bool CONV, int RMODE, int CSP, bool PURE = false, bool GNF = false>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
@@ -846,14 +916,14 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const int n_cu = sola_cu_count();
     const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
-    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNF>), dim3(grid), dim3(512), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -861,6 +931,7 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
 template <bool CONV>
 static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);  // partial sums: f32, no residual
+    if (a.gn_gamma) return launch_persist_t<CONV, 0, 1, false, true>(a, M, N, nprob, s);  // conditions checked by gemm_gn_fusable()
     const int rmode = !a.p[0].R ? 0 : (a.r_sp16 ? 2 : 1);
     if (a.c_sp16) {
         if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 1>(a, M, N, nprob, s);
@@ -908,10 +979,18 @@ static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStre
     return launch_glds<2, 2, 2, CONV>(a, M, N, nprob, s);
 }
 
-extern int g_gemm_glds;
-int gemm_split_glds_shape(const GemmDesc& d);
 int g_gemm_ablate = 0;
 void sola_gemm_set_ablate(int v) { g_gemm_ablate = v; }
+
+extern int g_gemm_glds;
+int gemm_split_glds_shape(const GemmDesc& d);
+// The fused-GroupNorm epilogue exists for the persistent 256x256 kernel only, on interior tiles: split-f16 arithmetic and
+// output, one problem, no residual, M and N multiples of 256, 64 channels per group (a wave's columns), 4 / 8 / 16 tokens.
+bool gemm_gn_fusable(const GemmDesc& d, int channels_per_group, int tokens) {
+    return g_gemm_gn_fuse && g_gemm_persist && d.arith == 1 && d.nprob == 1 && !d.p[0].R && d.ksplit <= 1 && d.M % 256 == 0 && d.N % 256 == 0 &&
+           d.K / GBK >= 2 && channels_per_group == 64 && (tokens == 4 || tokens == 8 || tokens == 16) && (d.ldc & 7) == 0 &&
+           gemm_split_glds_supported(d) && gemm_split_glds_shape(d) == 4;
+}
 
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     GldsArgs a;
@@ -932,6 +1011,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
     a.guard = (d.c_sp16 || d.c_f16) ? d.guard : nullptr;
+    a.gn_gamma = d.gn_gamma; a.gn_beta = d.gn_beta; a.gn_tokens = d.gn_tokens; a.gn_eps = d.gn_eps; a.gn_slope = d.gn_slope;
     a.ksplit = d.ksplit > 1 ? d.ksplit : 1;
     a.kper = a.K / GBK / a.ksplit;
     a.part = d.splitk_ws;

@@ -45,8 +45,14 @@ struct GemmDesc {
     // arith 1 with c_sp16, optional: device word that gets bit 0 set when a value written as split-f16 is not finite or
     // beyond the f16 range (|v| >= 65000): the inference forward then repeats the call on the exact-f32 kernels
     int* guard;
+    // arith 1, optional (check gemm_gn_fusable first): GroupNorm + LeakyReLU of the output applied in the epilogue - instances of
+    // gn_tokens (4 / 8 / 16) consecutive rows x 64 channels - and C written as split-f16 pairs (c_sp16 must be 1)
+    const float *gn_gamma, *gn_beta;
+    int gn_tokens;
+    float gn_eps, gn_slope;
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
+bool gemm_gn_fusable(const GemmDesc& d, int channels_per_group, int tokens);
 
 // ---- weight-gradient GEMM + helpers (gemm_tn.hip) ----------------------------------------------------------------
 struct GemmTnDesc {
