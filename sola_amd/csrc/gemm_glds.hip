@@ -52,7 +52,7 @@ struct GldsArgs {
     // gn_tokens = 4 / 8 / 16 consecutive rows) + LeakyReLU applied to the tile in the epilogue (GemmDesc::gn_gamma)
     const float *gn_gamma, *gn_beta;
     int gn_tokens;
-    float gn_eps, gn_slope;
+    float gn_eps, gn_slope, gn_icnt;  // gn_icnt = 1 / (gn_tokens * 64)
 };
 
 __device__ __forceinline__ void guard_sp16x4(int* guard, const float (&v)[4]) {
@@ -385,18 +385,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 // compile-time so that the epilogue is straight-line code (with run-time flags the residual registers of the fast path
 // flow through phi nodes the register allocator keeps - and spills - across the whole tile loop).
 // PURE (see above): RMODE 3 = f16 residual, CSP = 2 writes C as plain f16.
-// GNF (with CSP = 1, RMODE = 0, every tile interior): the norm that follows an encoder conv is applied HERE.  A GroupNorm
-// instance of conv0-2 is 16 / 8 / 4 consecutive token rows x 64 channels, and a 16-row epilogue strip of a wave is 16 rows x its
-// 64 output columns: whole instances, already in the wave's registers.  Per strip: the four passes' values are kept, the sums
-// per pass are reduced over the wave (DPP + permlane swaps, no LDS), combined to the instance means by the token count, the
-// centred squares likewise, then (v - mean) * rstd * gamma + beta, LeakyReLU, split-f16 store - the GroupNorm launch and its
-// read of the f32 conv output disappear (norm.hip's register shapes moved 8 bytes per element for them).
-template <bool CONV, int RMODE, int CSP, bool PURE = false, bool GNF = false>
+// GNT != 0 (with CSP = 1, RMODE = 0, every tile interior): the norm that follows an encoder conv is applied HERE.  A GroupNorm
+// instance of conv0-2 is GNT = 16 / 8 / 4 consecutive token rows x 64 channels, and a 16-row epilogue strip of a wave is 16 rows x
+// its 64 output columns: whole instances, already in the wave's registers.  Per strip: shifted sums and sums of squares per
+// instance, reduced over the wave (DPP + permlane swaps, no LDS), then (v - mean) * rstd * gamma + beta, LeakyReLU, split-f16
+// store - the GroupNorm launch and its read of the f32 conv output disappear (norm.hip's register shapes moved 8 bytes per
+// element for them).  GNT is a template parameter: the eight unrolled strips carry one variant of the statistics, not three.
+template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0>
 __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
     constexpr int MI = 4, WAVES_N = 4, GBM = 256, GBN = 256, NWAVE = 8;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
     constexpr int APW = GBM / 8 / NWAVE, WPW = GBN / 8 / NWAVE;
     constexpr int STRIP_ROWS = 16;
+    constexpr bool GNF = GNT != 0;  // GNT = rows per GroupNorm instance (4 / 8 / 16), 0 = no norm in the epilogue
     constexpr int RB = 4;  // strips per residual batch (16 registers each)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -657,6 +658,15 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         const bool interior = m0 + GBM <= a.M && n0 + GBN <= a.N && (ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
         prev_fast = interior;
         if (interior) {
+            // Range guard of the split / f16 outputs: one flag per lane for the whole tile, checked once behind the last strip.  A
+            // check per store (an exec-masked region in front of every pass) cost 32 branches per tile, and the packed-f32
+            // subtract that followed the exec restore lost its low half in lanes 48..63 about five times per 65536 strips
+            // (measured on the fused-norm epilogue: the element left the epilogue uncentred).
+            unsigned long long out_of_range = 0;  // lane mask, kept in scalar registers
+            auto note_range = [&](const float (&v)[4]) {
+                const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));  // drops NaNs
+                out_of_range |= __builtin_amdgcn_ballot_w64(!(m < 65000.f) || __builtin_isunordered(v[0], v[1]) || __builtin_isunordered(v[2], v[3]));
+            };
 #pragma unroll
             for (int b = 0; b < 8 / RB; ++b) {
                 f32x4 rbuf[RB * 4];
@@ -692,36 +702,31 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if constexpr (GNF) {
-                        float vv[4][4], sp[4];
+                        // instances of GNT rows: NI per strip, PPI passes each.  One pass over the values: sums of (v - k) and
+                        // (v - k)^2 with k = a value of the instance itself (lane 0's first element: mean - k is a few standard
+                        // deviations at most, so s2 / n - (s1 / n)^2 loses a digit, not the result), two INDEPENDENT wave
+                        // reductions per instance - the two-pass form was one dependent chain of reduce, divide, reduce, sqrt,
+                        // divide per strip with two waves per SIMD to hide it.
+                        constexpr int NI = 16 / GNT, PPI = 4 / NI;
+                        float d[4][4], s1[NI], s2[NI], mu[NI], rs[NI];
+#pragma unroll
+                        for (int u = 0; u < NI; ++u) s1[u] = s2[u] = 0.f;
+                        float kk = 0.f;
 #pragma unroll
                         for (int pass = 0; pass < 4; ++pass) {
-                            const int row = pass * 4 + rsub;
+                            const int row = pass * 4 + rsub, u = pass / PPI;
                             const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
-                            vv[pass][0] = t.x * osc + bv.x; vv[pass][1] = t.y * osc + bv.y; vv[pass][2] = t.z * osc + bv.z; vv[pass][3] = t.w * osc + bv.w;
-                            sp[pass] = wave_sum_dpp((vv[pass][0] + vv[pass][1]) + (vv[pass][2] + vv[pass][3]));
-                        }
-                        // instance of a pass: 4 rows (one pass), 8 rows (passes 2u, 2u+1) or the whole strip
-                        const int tl = a.gn_tokens;
-                        const float cnt = (float)tl * 64.f;
-                        float mean[4], rstd[4];
-                        {
-                            const float s01 = sp[0] + sp[1], s23 = sp[2] + sp[3], sall = s01 + s23;
-                            mean[0] = (tl == 4 ? sp[0] : tl == 8 ? s01 : sall) / cnt;
-                            mean[1] = (tl == 4 ? sp[1] : tl == 8 ? s01 : sall) / cnt;
-                            mean[2] = (tl == 4 ? sp[2] : tl == 8 ? s23 : sall) / cnt;
-                            mean[3] = (tl == 4 ? sp[3] : tl == 8 ? s23 : sall) / cnt;
+                            const float v0 = t.x * osc + bv.x, v1 = t.y * osc + bv.y, v2 = t.z * osc + bv.z, v3 = t.w * osc + bv.w;
+                            if (pass % PPI == 0) kk = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v0)));
+                            d[pass][0] = v0 - kk; d[pass][1] = v1 - kk; d[pass][2] = v2 - kk; d[pass][3] = v3 - kk;
+                            s1[u] += (d[pass][0] + d[pass][1]) + (d[pass][2] + d[pass][3]);
+                            s2[u] += (d[pass][0] * d[pass][0] + d[pass][1] * d[pass][1]) + (d[pass][2] * d[pass][2] + d[pass][3] * d[pass][3]);
                         }
 #pragma unroll
-                        for (int pass = 0; pass < 4; ++pass) {
-                            const float d0 = vv[pass][0] - mean[pass], d1 = vv[pass][1] - mean[pass], d2 = vv[pass][2] - mean[pass], d3 = vv[pass][3] - mean[pass];
-                            sp[pass] = wave_sum_dpp((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-                        }
-                        {
-                            const float s01 = sp[0] + sp[1], s23 = sp[2] + sp[3], sall = s01 + s23;
-                            rstd[0] = 1.0f / sqrtf((tl == 4 ? sp[0] : tl == 8 ? s01 : sall) / cnt + a.gn_eps);
-                            rstd[1] = 1.0f / sqrtf((tl == 4 ? sp[1] : tl == 8 ? s01 : sall) / cnt + a.gn_eps);
-                            rstd[2] = 1.0f / sqrtf((tl == 4 ? sp[2] : tl == 8 ? s23 : sall) / cnt + a.gn_eps);
-                            rstd[3] = 1.0f / sqrtf((tl == 4 ? sp[3] : tl == 8 ? s23 : sall) / cnt + a.gn_eps);
+                        for (int u = 0; u < NI; ++u) {
+                            const float m1 = wave_sum_dpp(s1[u]) * a.gn_icnt, m2 = wave_sum_dpp(s2[u]) * a.gn_icnt;  // 1 / (GNT * 64): a power of two
+                            mu[u] = m1;
+                            rs[u] = __builtin_amdgcn_rsqf(fmaxf(m2 - m1 * m1, 0.f) + a.gn_eps);
                         }
                         const float gw[4] = {gnw.x, gnw.y, gnw.z, gnw.w}, gb[4] = {gnb.x, gnb.y, gnb.z, gnb.w};
 #pragma unroll
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float y = (vv[pass][e] - mean[pass]) * rstd[pass] * gw[e] + gb[e];
+                                const float y = (d[pass][e] - mu[pass / PPI]) * rs[pass / PPI] * gw[e] + gb[e];
                                 v[e] = y >= 0.f ? y : y * a.gn_slope;
                             }
                             _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
                             *reinterpret_cast<half4*>(cb) = hh;
                             *reinterpret_cast<half4*>(cb + 8) = ll;
-                            guard_sp16x4(a.guard, v);
+                            note_range(v);
                         }
                     } else
 #pragma unroll
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 #pragma unroll
                             for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
                             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = hh;
-                            guard_sp16x4(a.guard, v);
+                            note_range(v);
                         } else if (CSP == 1) {
                             _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                             half4 hh, ll;
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
                             *reinterpret_cast<half4*>(cb) = hh;
                             *reinterpret_cast<half4*>(cb + 8) = ll;
-                            guard_sp16x4(a.guard, v);
+                            note_range(v);
                         } else {
                             *reinterpret_cast<float4*>(pr.C + (long long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                         }
@@ -786,6 +791,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+            if (CSP != 0 && a.guard && out_of_range != 0 && lane_e == 0) atomicOr(a.guard, 1);
             continue;
         }
 #pragma unroll
@@ -906,7 +912,7 @@ void sola_gemm_set_gn_fuse(int v) { g_gemm_gn_fuse = v; }
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 
-template <bool CONV, int RMODE, int CSP, bool PURE = false, bool GNF = false>
+template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
@@ -916,14 +922,14 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNF>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const int n_cu = sola_cu_count();
     const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
-    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNF>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT>), dim3(grid), dim3(512), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -931,7 +937,11 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
 template <bool CONV>
 static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);  // partial sums: f32, no residual
-    if (a.gn_gamma) return launch_persist_t<CONV, 0, 1, false, true>(a, M, N, nprob, s);  // conditions checked by gemm_gn_fusable()
+    if (a.gn_gamma) {  // conditions checked by gemm_gn_fusable()
+        if (a.gn_tokens == 16) return launch_persist_t<CONV, 0, 1, false, 16>(a, M, N, nprob, s);
+        if (a.gn_tokens == 8) return launch_persist_t<CONV, 0, 1, false, 8>(a, M, N, nprob, s);
+        return launch_persist_t<CONV, 0, 1, false, 4>(a, M, N, nprob, s);
+    }
     const int rmode = !a.p[0].R ? 0 : (a.r_sp16 ? 2 : 1);
     if (a.c_sp16) {
         if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 1>(a, M, N, nprob, s);
@@ -1012,6 +1022,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.ablate = g_gemm_ablate;
     a.guard = (d.c_sp16 || d.c_f16) ? d.guard : nullptr;
     a.gn_gamma = d.gn_gamma; a.gn_beta = d.gn_beta; a.gn_tokens = d.gn_tokens; a.gn_eps = d.gn_eps; a.gn_slope = d.gn_slope;
+    a.gn_icnt = d.gn_tokens > 0 ? 1.0f / (64.0f * (float)d.gn_tokens) : 0.f;
     a.ksplit = d.ksplit > 1 ? d.ksplit : 1;
     a.kper = a.K / GBK / a.ksplit;
     a.part = d.splitk_ws;

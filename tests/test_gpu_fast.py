@@ -299,9 +299,49 @@ def test_split_gemm_auto_scaled_operand(M, N, K, mag):
     assert np.abs(got - ref).max() <= max(4 * np.abs(f32 - ref).max(), 2e-6 * np.abs(ref).max())
 
 
+def test_fused_norm_epilogue_is_repeatable_and_matches_the_unfused_activations():
+    """The fused conv + GroupNorm + LeakyReLU epilogue at the headline shape, 12 forwards: every encoder activation it writes
+    (act0..act2, split-f16 pairs) is bit-identical from run to run and within 2e-5 of the separate launches.  Regression test
+    for two faults of earlier versions of the epilogue that showed up as a handful of wrong rows per launch, different ones
+    each run ("fused norm"): a packed-f32 subtract behind a per-store exec-masked range check that left one
+    element of a strip's last row uncentred, and SLP-vectorised statistics that returned garbage rows; tools/gnf_stress.py
+    is the longer version."""
+    from sola_amd import _lib
+    cfg = synth.DEFAULT_MODEL_CFG
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()})
+    m = m.cuda().eval(); m.precision = "f16x3"
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, 128, 64, 32, 16, 31).items()}
+    names = ("act0", "act1", "act2")
+
+    def unsplit(t):  # [rows, C] floats holding [hi8|lo8] halfs per 8 values
+        h = t.view(torch.float16).reshape(t.shape[0], -1, 2, 8).float()
+        return (h[:, :, 0, :] + h[:, :, 1, :]).reshape(t.shape[0], -1)
+
+    def run(fuse):
+        _lib.check(_lib.lib().sola_tune(b"gemm_gn_fuse", fuse), "tune")
+        with torch.no_grad():
+            m(inp["object_tokens"], inp["lang_tokens"])
+        torch.cuda.synchronize()
+        return {nm: m.workspace_tap(nm) for nm in names}
+
+    try:
+        ref = run(0)
+        first = run(1)
+        for nm in names:
+            assert float((unsplit(first[nm]) - unsplit(ref[nm])).abs().max()) <= 2e-5, nm
+        for _ in range(11):
+            t = run(1)
+            for nm in names:
+                assert torch.equal(t[nm].view(torch.int32), first[nm].view(torch.int32)), nm
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"gemm_gn_fuse", 1), "tune")
+    assert m.split_fallbacks()[1] == 0
+
+
 def test_norm_fused_into_the_conv_epilogue_matches_the_separate_launch():
     """At GPU-filling batches the first three encoder norms (64 channels per group) are applied in the conv GEMM's epilogue
-    (gemm_glds.hip, GNF).  128 samples of the headline shape: conv0 / conv1 / conv2 all qualify; the logits must agree with the
+    (gemm_glds.hip, GNT).  128 samples of the headline shape: conv0 / conv1 / conv2 all qualify; the logits must agree with the
     same forward running the separate GroupNorm launches (sola_tune gemm_gn_fuse 0) to f32 summation noise, decisions equal."""
     from sola_amd import _lib
     cfg = synth.DEFAULT_MODEL_CFG

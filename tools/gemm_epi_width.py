@@ -1,0 +1,26 @@
+"""Epilogue cost of the persistent split-f16 GEMM by output format: f32 rows (32 float4 stores per wave and tile) against
+split-f16 pairs (64 half4 stores), each with and without the epilogue (sola_tune "gemm_ablate" 4)."""
+import sys, torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from sola_amd import ops, _lib
+lib = _lib.lib()
+for (M, N, K) in [(65536, 1024, 1024), (131072, 512, 768), (65536, 1024, 3072)]:
+    x = torch.randn(M, K, device="cuda"); wt = torch.randn(N, K, device="cuda") * 0.03
+    a = ops.cast_sp16(x); w = ops.cast_sp16(wt, 64.0); b = torch.randn(N, device="cuda")
+    r32 = torch.randn(M, N, device="cuda"); rsp = ops.cast_sp16(r32)
+    for name, kw in (("f32 out", dict()), ("split out", dict(out_split=True)), ("f32 out + f32 residual", dict(residual=r32)),
+                     ("split out + split residual", dict(residual=rsp, residual_is_split=True, out_split=True))):
+        row = []
+        for ab in (0, 4):
+            lib.sola_tune(b"gemm_ablate", ab)
+            best = 1e9
+            for rnd in range(3):
+                ops.gemm_nt_split(a, w, b, out_scale=1 / 64, **kw); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): ops.gemm_nt_split(a, w, b, out_scale=1 / 64, **kw)
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 10)
+            row.append(best * 1e3)
+        print(f"M={M} N={N} K={K} {name:28s}: full {row[0]:7.1f} us   no epilogue {row[1]:7.1f} us   epilogue {row[0] - row[1]:6.1f} us ({(row[0] - row[1]) / row[0] * 100:.0f} %)")
+lib.sola_tune(b"gemm_ablate", 0)
