@@ -135,7 +135,8 @@ def gemm_roofline(prof, precision, step_s, steps):
             return None
         alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
         name = ("gemm_nt_split_glds_persist_kernel<conv, residual, split-out> (persistent 256x256x32 blocks, 8 waves of 128x64, "
-                "split-f16 operands, 3 x v_mfma_f32_32x32x16_f16 per product, direct-to-LDS staging; all instantiations of a step)") \
+                "split-f16 operands, 3 x v_mfma_f32_32x32x16_f16 per product, direct-to-LDS staging; all plain-GEMM instantiations of a step - "
+                "the launches that also apply GroupNorm + LeakyReLU in the epilogue are timed apart, kernel_ms_per_step.gemm_split256_gn)") \
             if g is g256 else "gemm_nt_split_glds_kernel<2,2,2,*> / gemm_nt_f32_kernel<64,64,1,1> (128x128 and 64x64 split-f16 blocks)"
         return {"kernel": name, "bound": "mfma", "achieved": round(alg, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(alg / F16_MFMA_PEAK_TFLOPS, 4), "frac_algorithmic": round(alg / F16_MFMA_PEAK_TFLOPS, 4),
@@ -144,7 +145,9 @@ def gemm_roofline(prof, precision, step_s, steps):
                         "products the kernel issues per algorithmic product (hi*hi + hi*lo + lo*hi)",
                 "algorithmic_vs_f32_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 3), "traffic": None,
                 "launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
-                "share_of_step_time": round(g["ms"] * 1e-3 / (step_s * steps), 4)}
+                "share_of_step_time": round(g["ms"] * 1e-3 / (step_s * steps), 4),
+                "fused_norm_launches": {"launches": prof["gemm_split256_gn"]["launches"], "ms_per_step": round(prof["gemm_split256_gn"]["ms"] / steps, 4),
+                                        "algorithmic_tflops": round(prof["gemm_split256_gn"]["flops"] / max(prof["gemm_split256_gn"]["ms"] * 1e-3, 1e-12) / 1e12, 2)}}
     g = prof["gemm128"] if prof["gemm128"]["ms"] >= prof["gemm64"]["ms"] else prof["gemm64"]
     if g["ms"] <= 0:
         return None

@@ -367,14 +367,18 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_ATTN_BWD = 10, /* attn_bwd_* kernels */
        SOLA_PROF_GEMM_SPLIT = 11, /* split-f16 GEMMs other than the 256x256 shape (128x128 glds blocks, 64x64 small grids) */
        SOLA_PROF_GEMM_SPLIT256 = 12, /* gemm_nt_split_glds_persist_kernel<*> (and the one-tile <4,2,4,*> kernel): 256x256 blocks, split-f16, 3 x f16 MFMA */
-       SOLA_PROF_NCAT = 13 };
+       SOLA_PROF_GEMM_SPLIT256_GN = 13, /* the same kernel with GroupNorm + LeakyReLU applied in the epilogue (encoder conv0-2): its time includes the norm */
+       SOLA_PROF_NCAT = 14 };
 /* Kernel-schedule switches for within-process A/B measurements ("gemm_variant": 0 simple / 1 mid-tile staging;
  * "gemm_glds": split-f16 GEMM staging, 0 registers / 1 direct-to-LDS 128x128 blocks / 4 256x256 blocks / 3 auto;
  * "gemm_persist": 256x256 shape, 1 persistent kernel (default) / 0 one tile per block; "gemm_glds_force": tests only, take the
  * direct-to-LDS kernels for grids of any size; "gemm_splitk", "bilinear_staged";
  * "train_split_min_rows": precision 1 in training takes the split-f16 GEMMs from this many token rows (B*N*T') on, default 1024
  * (below that the step is launch-bound and the cast launches cost more than the GEMMs gain); tests set 0;
- * "gemm_ablate": measurement only, 4 = no epilogue (results are then WRONG);
+ * "gemm_ablate": measurement only (results are then WRONG), bits: 4 = no epilogue, 8 = interior epilogue without its global
+ * stores, 16 = without its LDS transpose;
+ * "gemm_gn_fuse": 1 (default) = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM
+ * epilogue (batches whose conv outputs fill 256-row tiles, 64 channels per group), 0 = separate GroupNorm launches;
  * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for
  * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
  * "pack_resample_lds": nearest-resampling mask pack, 1 (default) = source rows staged through LDS / 0 = per-pixel gather;

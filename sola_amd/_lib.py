@@ -123,7 +123,7 @@ SIGNATURES = {
 }
 
 PROF_CATEGORIES = ["gemm128", "attn", "group_norm", "ws_standardize", "head_loss", "misc", "iou_pack", "iou_pair", "gemm64", "gemm_tn", "attn_bwd", "gemm_split",
-                   "gemm_split256"]
+                   "gemm_split256", "gemm_split256_gn"]
 
 _lib = None
 

@@ -450,7 +450,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
         return launch_gemm_split_glds(d, s);
     }
     const bool glds = d.arith == 1 && (big || g_gemm_glds_force || d.ksplit > 1) && g_gemm_glds && gemm_split_glds_supported(d);
-    const int cat = d.arith == 1 ? (glds && gemm_split_glds_shape(d) == 4 ? SOLA_PROF_GEMM_SPLIT256 : SOLA_PROF_GEMM_SPLIT)
+    const int cat = d.arith == 1 ? (glds && gemm_split_glds_shape(d) == 4 ? (d.gn_gamma ? SOLA_PROF_GEMM_SPLIT256_GN : SOLA_PROF_GEMM_SPLIT256) : SOLA_PROF_GEMM_SPLIT)
                                  : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL);
     SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));

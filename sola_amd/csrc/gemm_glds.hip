@@ -656,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
         // vmcnt is one in-order counter for loads and stores: a residual load issued between stores would have to wait for
         // the acknowledgement of every store before it, so the loads of a batch are issued together, in front of its stores.
         const bool interior = m0 + GBM <= a.M && n0 + GBN <= a.N && (ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
-        prev_fast = interior;
+        prev_fast = interior && !(a.ablate & 24);
         if (interior) {
             // Range guard of the split / f16 outputs: one flag per lane for the whole tile, checked once behind the last strip.  A
             // check per store (an exec-masked region in front of every pass) cost 32 branches per tile, and the packed-f32
@@ -690,6 +690,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
 #pragma unroll
                 for (int sl = 0; sl < RB; ++sl) {
                     const int st = b * RB + sl, i = st >> 1, hf = st & 1;
+                    if (!(a.ablate & 16))
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -752,7 +753,9 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                     for (int pass = 0; pass < 4; ++pass) {
                         const int row = pass * 4 + rsub;
                         const int m = m0 + wr_e * 128 + i * 32 + hf * 16 + row;
-                        const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
+                        float4 t;
+                        if (a.ablate & 16) t = make_float4(acc[i][0][hf * 8 + pass], acc[i][0][hf * 8 + 4 + pass], acc[i][1][hf * 8 + pass], acc[i][1][hf * 8 + 4 + pass]);
+                        else t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
                         float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
                         if (RMODE) {
                             const f32x4 rv = rbuf[sl * 4 + pass];
@@ -773,6 +776,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             half4 hh;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+                            if (a.ablate & 8) asm volatile("" ::"v"(hh)); else
                             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = hh;
                             note_range(v);
                         } else if (CSP == 1) {
@@ -780,10 +784,12 @@ __global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const G
                             half4 hh, ll;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
+                            if (a.ablate & 8) asm volatile("" ::"v"(hh), "v"(ll)); else {
                             *reinterpret_cast<half4*>(cb) = hh;
-                            *reinterpret_cast<half4*>(cb + 8) = ll;
+                            *reinterpret_cast<half4*>(cb + 8) = ll; }
                             note_range(v);
                         } else {
+                            if (a.ablate & 8) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); else
                             *reinterpret_cast<float4*>(pr.C + (long long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     }

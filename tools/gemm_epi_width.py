@@ -11,7 +11,7 @@ for (M, N, K) in [(65536, 1024, 1024), (131072, 512, 768), (65536, 1024, 3072)]:
     for name, kw in (("f32 out", dict()), ("split out", dict(out_split=True)), ("f32 out + f32 residual", dict(residual=r32)),
                      ("split out + split residual", dict(residual=rsp, residual_is_split=True, out_split=True))):
         row = []
-        for ab in (0, 4):
+        for ab in (0, 4, 8, 16, 24):
             lib.sola_tune(b"gemm_ablate", ab)
             best = 1e9
             for rnd in range(3):
@@ -22,5 +22,5 @@ for (M, N, K) in [(65536, 1024, 1024), (131072, 512, 768), (65536, 1024, 3072)]:
                 e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 10)
             row.append(best * 1e3)
-        print(f"M={M} N={N} K={K} {name:28s}: full {row[0]:7.1f} us   no epilogue {row[1]:7.1f} us   epilogue {row[0] - row[1]:6.1f} us ({(row[0] - row[1]) / row[0] * 100:.0f} %)")
+        print(f"M={M} N={N} K={K} {name:28s}: full {row[0]:7.1f} us  no epilogue {row[1]:7.1f}  no stores {row[2]:7.1f}  no LDS transpose {row[3]:7.1f}  neither {row[4]:7.1f}")
 lib.sola_tune(b"gemm_ablate", 0)
