@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=5, help="steps of the training_step leg (rank 0, N=1, outside the timed region; 0 = skip)")
     ap.add_argument("--extra-legs", type=int, default=1, help="0 skips the stress / ragged / iou legs (profiling runs)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="sola_tune switch for A/B measurements (reported in config.tune; not the default line)")
     ap.add_argument("--cached-ws", action="store_true", help="inference mode: standardise conv weights once (not the headline)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("SOLA_PRECISION", "f16x3"),
                     help="arithmetic of the convs/projections: exact f32 MFMA, or split-f16 operands (3 f16 MFMAs per product, "
@@ -492,6 +493,9 @@ def main():
     from sola_amd.loss import track_selection_losses
     from sola_amd.module import LanguageAlignedTrackSelectionModule
 
+    for kv in args.tune:  # A/B measurements only; the line says so (config.tune)
+        key, val = kv.split("=")
+        _lib.check(_lib.lib().sola_tune(key.encode(), int(val)), f"sola_tune {kv}")
     cfg = synth.DEFAULT_MODEL_CFG
     B, N, T, L = args.batch, args.tracks, args.frames, args.text_len
     sd = synth.make_state_dict(cfg, 42)
@@ -603,7 +607,8 @@ def main():
                                    + ("conv weights standardised once (inference cache)" if args.cached_ws
                                       else "conv weights re-standardised every step"),
                        "batch_per_gpu": B, "tracks": N, "frames": T, "text_len": L, "sharding": f"per-sample x{world}",
-                       "collective_backend": backend_name, "world_size_reported_by_backend": world if world > 1 else None},
+                       "collective_backend": backend_name, "world_size_reported_by_backend": world if world > 1 else None,
+                       **({"tune": args.tune} if args.tune else {})},
             "gflop_per_sample": round(fl["total"] / 1e9, 3),
             "model_tflops": round(value * fl["total"] / 1e12, 2),
             "roofline": roofline, "roofline_attention": roofline_attn, "kernel_ms_per_step": kernel_ms(prof, args.steps),
