@@ -13,7 +13,14 @@ for line in open(sys.argv[1]):
 gemms = [k for k in rows if k.startswith("gemm_nt_split")]  # the exact-f32 leg of the same run is not the headline
 # bench.py's roofline line covers every 256x256 launch of a step (its own profiler category); those are the instantiations
 # of the persistent kernel, so their launch-weighted mean is the per-launch traffic / duration that goes with it
-p256 = [k for k in rows if k.startswith("gemm_nt_split_glds_persist_kernel") or k.startswith("gemm_nt_split_glds_kernel<4")]
+# (the instantiations that also apply GroupNorm in the epilogue - last template argument 16 / 8 / 4 - are a category of their own)
+fused = [k for k in rows if k.startswith("gemm_nt_split_glds_persist_kernel") and not k.rstrip().endswith(", 0>")]
+p256 = [k for k in rows if (k.startswith("gemm_nt_split_glds_persist_kernel") and k not in fused) or k.startswith("gemm_nt_split_glds_kernel<4")]
+if fused:
+    calls = sum(rows[k]["calls"] for k in fused)
+    rows["gemm_split256_gn (conv + GroupNorm launches)"] = {
+        "hbm_bytes_per_launch": int(sum(rows[k]["hbm_bytes_per_launch"] * rows[k]["calls"] for k in fused) / calls),
+        "rocprof_avg_us": round(sum(rows[k]["rocprof_avg_us"] * rows[k]["calls"] for k in fused) / calls, 1), "calls": calls, "instantiations": fused}
 if p256:
     calls = sum(rows[k]["calls"] for k in p256)
     rows["gemm_split256 (all 256x256 launches)"] = {
