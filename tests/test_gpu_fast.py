@@ -339,6 +339,42 @@ def test_fused_norm_epilogue_is_repeatable_and_matches_the_unfused_activations()
     assert m.split_fallbacks()[1] == 0
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16"])
+def test_forward_and_gradients_repeat_bit_for_bit(precision):
+    """No kernel of the path uses float atomics: logits, tokens and every gradient of a training step repeat bit for bit from
+    run to run in every precision mode (tools/repeat_stress.py is the long version, with the ragged forward)."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    sd = synth.make_state_dict(cfg, 42)
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m = m.cuda().eval(); m.precision = precision
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, 128, 64, 32, 16, 31).items()}
+    first = None
+    for _ in range(5):
+        with torch.no_grad():
+            sm, st = m(inp["object_tokens"], inp["lang_tokens"])
+        cur = (sm.view(torch.int32).clone(), st.view(torch.int32).clone())
+        if first is None:
+            first = cur
+        assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])
+    from sola_amd.loss import track_selection_losses
+    B = 16
+    tinp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, 64, 32, 16, 1).items()}
+    m.train()
+    first = None
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = None
+        torch.manual_seed(11)  # the dropout seed of the step is drawn from torch's generator
+        sm, st = m(tinp["object_tokens"], tinp["lang_tokens"])
+        neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+        track_selection_losses(sm, st, tinp["labels"], tinp["pos_tokens"], neg, 1.5, 0.07, 0.3)[0].backward()
+        cur = [p.grad.view(torch.int32).clone() for p in m.parameters() if p.grad is not None]
+        if first is None:
+            first = cur
+        assert all(torch.equal(a, b) for a, b in zip(cur, first))
+
+
 def test_norm_fused_into_the_conv_epilogue_matches_the_separate_launch():
     """At GPU-filling batches the first three encoder norms (64 channels per group) are applied in the conv GEMM's epilogue
     (gemm_glds.hip, GNT).  128 samples of the headline shape: conv0 / conv1 / conv2 all qualify; the logits must agree with the
