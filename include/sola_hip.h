@@ -377,6 +377,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * (below that the step is launch-bound and the cast launches cost more than the GEMMs gain); tests set 0;
  * "gemm_ablate": measurement only (results are then WRONG), bits: 4 = no epilogue, 8 = interior epilogue without its global
  * stores, 16 = without its LDS transpose;
+ * "gemm_nw4", "gemm_pp": experimental four-wave shapes of the persistent split-f16 GEMM (256x128 tiles, one wave per SIMD; gemm_pp with
+ * two accumulator sets and the epilogue drained under the next tile), bit-identical to the default, 0 (default) = off;
  * "gemm_gn_fuse": 1 (default) = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM
  * epilogue (batches whose conv outputs fill 256-row tiles, 64 channels per group), 0 = separate GroupNorm launches;
  * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for

@@ -391,9 +391,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 // instance, reduced over the wave (DPP + permlane swaps, no LDS), then (v - mean) * rstd * gamma + beta, LeakyReLU, split-f16
 // store - the GroupNorm launch and its read of the f32 conv output disappear (norm.hip's register shapes moved 8 bytes per
 // element for them).  GNT is a template parameter: the eight unrolled strips carry one variant of the statistics, not three.
-template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0>
-__global__ __launch_bounds__(512) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
-    constexpr int MI = 4, WAVES_N = 4, GBM = 256, GBN = 256, NWAVE = 8;
+template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
+    // NW = 8: 256x256 tiles, 2 x 4 waves, two waves per SIMD.  NW = 4 (experiment, sola_tune "gemm_nw4"): 256x128 tiles, 2 x 2 waves, one
+    // wave per SIMD and up to 512 registers each
+    constexpr int MI = 4, WAVES_N = NW / 2, GBM = 256, GBN = WAVES_N * 64, NWAVE = NW;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
     constexpr int APW = GBM / 8 / NWAVE, WPW = GBN / 8 / NWAVE;
     constexpr int STRIP_ROWS = 16;
@@ -893,6 +895,382 @@ bool gemm_split_glds_supported(const GemmDesc& d) {
     return d.lda % 8 == 0;
 }
 
+// Ping-pong variant (sola_tune "gemm_pp"; plain launches without residual whose tiles are all interior and K >= 352): 256x128
+// tiles, four waves = ONE per SIMD with up to 512 registers, TWO accumulator sets.  The epilogue of a tile does not run behind
+// its k-loop: its eight strips are drained one per k-tile under the first eight k-tiles of the block's NEXT tile (LDS transpose
+// and conversion between that k-tile's MFMAs, the strip's stores behind the k-tile's last DMA piece, so the next k-tile's wait
+// names them - vmcnt(stores per strip) - instead of waiting for their acknowledgement).  Same fragments, same accumulation
+// order and the same epilogue arithmetic as the kernel above: results are bit-identical.
+template <bool CONV, int CSP>
+__global__ __launch_bounds__(256) void gemm_nt_split_glds_pp_kernel(const GldsArgs a) {
+    constexpr int RMODE = 0, GNT = 0, NW = 4;
+    constexpr bool PURE = false;
+    constexpr int MI = 4, WAVES_N = NW / 2, GBM = 256, GBN = WAVES_N * 64, NWAVE = NW;
+    constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
+    constexpr int APW = GBM / 8 / NWAVE, WPW = GBN / 8 / NWAVE;
+    constexpr int STRIP_ROWS = 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int ks_n = a.ksplit > 1 ? a.ksplit : 1;
+    const int nk = a.ksplit > 1 ? a.kper : a.K / GBK;
+
+    // Tile order: the problems of a launch (q/k/v projections of the same rows) are the innermost index next to the column
+    // tile, so the nprob * tiles_n tiles that read one 256-row block of A run back to back on one XCD and A comes from HBM once.
+    // The k ranges of a split-K launch are further "problems" in that order.
+    const int tiles_row = a.tiles_n * a.nprob * ks_n;
+    const int total = a.tiles_m * tiles_row;
+    auto decode = [&](int tile, int& z, int& ks, int& m0, int& n0) {
+        int rt, c;
+        if (a.xcd_remap) {
+            const int x = tile & 7, j = tile >> 3;
+            rt = x + 8 * (j / tiles_row);
+            c = j % tiles_row;
+        } else {
+            rt = tile / tiles_row;
+            c = tile % tiles_row;
+        }
+        const int zz = c / a.tiles_n;
+        z = zz / ks_n;
+        ks = zz - z * ks_n;
+        m0 = rt * GBM;
+        n0 = (c - zz * a.tiles_n) * GBN;
+    };
+
+    // ---- DMA stream state (same piece layout as the kernel above)
+    const int lrow = lane >> 3, chunk = lane & 7;
+    const char* a_ptr0;  // piece 0's running source pointer; pieces 1.. are a_ptr0 + a_d[i] (rows of a tile ascend in memory)
+    const char* w_ptr0;
+    int a_d[APW], w_d[WPW];
+    int a_t0[APW];
+    int conv_kk = 0, conv_c = 0;
+    int dma_kt = 0;  // next k-tile of the DMA stream within its tile
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    auto setup_dma = [&](int tile) {
+        int z, ks, m0, n0;
+        decode(tile, z, ks, m0, n0);
+        const int k0 = ks * nk * GBK;  // first reduction index of this work item
+        const float* A = a.p[z].A + k0;
+        const float* Wt = a.p[z].W + k0;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int r = (wave * APW + i) * 8 + lrow;
+            const int col_bytes = (chunk ^ ((r >> 1) & 7)) * 16;
+            const int m = min(m0 + r, a.M - 1);
+            const char* p;
+            if (CONV) {
+                if (a.rowmap) {
+                    const int2 rm = a.rowmap[m];
+                    a_t0[i] = rm.y;
+                    p = reinterpret_cast<const char*>(A) + (long long)rm.x * a.Cin * 4 + col_bytes;
+                } else {
+                    const int rr = m / a.T_out, to = m - rr * a.T_out;
+                    const int t0 = to * a.stride - a.pad;
+                    a_t0[i] = conv_tap_bits(t0, a.T_in);
+                    p = reinterpret_cast<const char*>(A) + ((long long)rr * a.T_in + t0) * a.Cin * 4 + col_bytes;
+                }
+            } else {
+                a_t0[i] = 0;
+                p = reinterpret_cast<const char*>(A + (long long)m * a.lda) + col_bytes;
+            }
+            if (i == 0) a_ptr0 = p;
+            a_d[i] = (int)(p - a_ptr0);
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int r = (wave * WPW + i) * 8 + lrow;
+            const int n = min(n0 + r, a.N - 1);
+            const char* p = reinterpret_cast<const char*>(Wt + (long long)n * a.K) + (chunk ^ ((r >> 1) & 7)) * 16;
+            if (i == 0) w_ptr0 = p;
+            w_d[i] = (int)(p - w_ptr0);
+        }
+        conv_kk = CONV ? k0 / a.Cin : 0;
+        conv_c = CONV ? k0 - conv_kk * a.Cin : 0;
+        dma_kt = 0;
+    };
+    auto issue = [&](int stage) {
+        char* sbase = lds + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const char* src = a_ptr0 + a_d[i];
+            if (CONV) src = ((a_t0[i] >> conv_kk) & 1) ? src : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr0 + w_d[i]), (lptr_t)(sbase + GBM * ROWB + (wave * WPW + i) * 1024), 16, 0, 0);
+        }
+        // past the last k-tile of the last tile the stream re-reads that k-tile (see the one-tile kernel)
+        const bool more = dma_kt + 1 < nk;
+        const int adv = more ? GBK * 4 : 0;
+        a_ptr0 += adv;
+        w_ptr0 += adv;
+        if (CONV) {  // branch-free: a branch here would split the basic block the DMA is interleaved in
+            conv_c += more ? GBK : 0;
+            const bool wrap = conv_c == a.Cin;
+            conv_c = wrap ? 0 : conv_c;
+            conv_kk += wrap ? 1 : 0;
+        }
+        ++dma_kt;
+    };
+
+    const int fr = lane & 31, fh = lane >> 5, key = (lane >> 1) & 7;
+    const int a_frag = (wr * MI * 32 + fr) * ROWB, w_frag = GBM * ROWB + (wc * 64 + fr) * ROWB;
+    struct Frags { half8 ah[MI], al[MI], bh[2], bl[2]; };
+    auto load_frags = [&](const char* sbase, int s16, Frags& f) {
+        const int hi_off = (((s16 * 2 + fh) * 2) ^ key) << 4;
+        const int lo_off = hi_off ^ 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* q = sbase + w_frag + j * 32 * ROWB;
+            f.bh[j] = *reinterpret_cast<const half8*>(q + hi_off);
+            f.bl[j] = *reinterpret_cast<const half8*>(q + lo_off);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const char* p = sbase + a_frag + i * 32 * ROWB;
+            f.ah[i] = *reinterpret_cast<const half8*>(p + hi_off);
+            f.al[i] = *reinterpret_cast<const half8*>(p + lo_off);
+        }
+    };
+    f32x16 acc[2][MI][2];  // accumulator sets of the tile in flight and of the tile being drained
+    auto mfmas = [&](auto pc, const Frags& f) {
+        constexpr int P = decltype(pc)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (PURE) {
+                    acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[P][i][j], 0, 0, 0);
+                    acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[P][i][j], 0, 0, 0);
+                } else {
+                    acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[P][i][j], 0, 0, 0);
+                    acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[P][i][j], 0, 0, 0);
+                    acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[P][i][j], 0, 0, 0);
+                }
+            }
+    };
+
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    setup_dma(tile);
+    issue(0);
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");
+    __syncthreads();
+    int stage = 0;
+    constexpr int NRD = 2 * MI + 4, NMF = 6 * MI;
+    constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
+    constexpr int NST = CSP == 1 ? 8 : 4;  // global stores per strip and wave
+
+    // Lane coordinates of the epilogue are re-derived from an opaque copy of the thread id inside every strip: derived once, the
+    // compiler hoists the addresses of all eight strips out of the tile loop and keeps them - spilled - across the k-loops.
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: costs no vector register across the k-loops
+#define PP_LANE_COORDS                                                                                   \
+    int le = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));                    \
+    asm volatile("" : "+v"(le));                                                                         \
+    const int lane_e = le, wave_e = wave_s;                                                              \
+    const int fh_e = lane_e >> 5;                                                                        \
+    float* strip = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave_e * (STRIP_ROWS * 64);         \
+    const int col_l = lane_e & 31;                                                                       \
+    const int c4 = lane_e & 15, rsub = lane_e >> 4;                                                      \
+    const int wr_e = wave_e / WAVES_N, wc_e = wave_e % WAVES_N;                                          \
+    (void)fh_e; (void)strip; (void)col_l; (void)c4; (void)rsub; (void)wr_e; (void)wc_e;
+
+    // the tile whose accumulators wait to be drained
+    float* pend_C = nullptr;
+    float pend_osc = 1.f;
+    float4 pend_bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    int pend_m0 = 0, pend_n = 0;
+    unsigned long long out_of_range = 0;
+
+    // one strip (16 rows x this wave's 64 columns) of accumulator set Q: LDS transpose + conversion (part 1), stores (part 2)
+    f32x4 sv[4];
+    auto strip_compute = [&](auto qc, auto stc) {
+        constexpr int Q = decltype(qc)::value, st = decltype(stc)::value, i = st >> 1, hf = st & 1;
+        PP_LANE_COORDS
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * fh_e;
+                const int col = (j * 32 + col_l) ^ (fh_e << 5);
+                strip[row * 64 + col] = acc[Q][i][j][hf * 8 + q];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is written (in-order LDS queue; wave-private region)
+        __builtin_amdgcn_wave_barrier();
+        // The four reads go through inline asm with their own lgkmcnt wait: in front of a compiler-visible LDS read the waitcnt pass
+        // puts vmcnt(0) here (LDS-DMA pieces and the previous strip's stores are in flight) - exactly the wait this kernel avoids.
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 4 + rsub;
+            const unsigned addr = (unsigned)(uintptr_t)(lptr_t)&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(sv[pass]) : "v"(addr) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])::"memory");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            sv[pass][0] = sv[pass][0] * pend_osc + pend_bv.x; sv[pass][1] = sv[pass][1] * pend_osc + pend_bv.y;
+            sv[pass][2] = sv[pass][2] * pend_osc + pend_bv.z; sv[pass][3] = sv[pass][3] * pend_osc + pend_bv.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto strip_store = [&](auto stc) {
+        constexpr int st = decltype(stc)::value, i = st >> 1, hf = st & 1;
+        PP_LANE_COORDS
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int m = pend_m0 + wr_e * 128 + i * 32 + hf * 16 + pass * 4 + rsub;
+            if (CSP == 1) {
+                _Float16* cb = reinterpret_cast<_Float16*>(pend_C + (long long)m * a.ldc + (pend_n & ~7)) + (pend_n & 4);
+                half4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(sv[pass][e], h1, l1); hh[e] = h1; ll[e] = l1; }
+                *reinterpret_cast<half4*>(cb) = hh;
+                *reinterpret_cast<half4*>(cb + 8) = ll;
+                const float mx = fmaxf(fmaxf(fabsf(sv[pass][0]), fabsf(sv[pass][1])), fmaxf(fabsf(sv[pass][2]), fabsf(sv[pass][3])));
+                out_of_range |= __builtin_amdgcn_ballot_w64(!(mx < 65000.f) || __builtin_isunordered(sv[pass][0], sv[pass][1]) || __builtin_isunordered(sv[pass][2], sv[pass][3]));
+            } else {
+                *reinterpret_cast<float4*>(pend_C + (long long)m * a.ldc + pend_n) = make_float4(sv[pass][0], sv[pass][1], sv[pass][2], sv[pass][3]);
+            }
+        }
+    };
+    auto flush_guard = [&]() {
+        if (CSP == 1 && a.guard && out_of_range != 0 && (tid & 63) == 0) atomicOr(a.guard, 1);
+        out_of_range = 0;
+    };
+
+    Frags f0, f1;
+    // one k-tile of the tile accumulating into set P; ST >= 0: strip ST of set P ^ 1 is drained under it; RELAX: the previous
+    // k-tile ended with NST stores, which the wait for this k-tile's DMA may leave in flight
+    auto ktile = [&](auto pc, auto stc, auto relaxc) {
+        constexpr int P = decltype(pc)::value, ST = decltype(stc)::value;  // ST = 0..8: stores of strip ST - 1, transpose of strip ST
+        constexpr bool STORES = ST >= 1 && ST <= 8, COMPUTE = ST >= 0 && ST <= 7;
+        load_frags(lds + stage * STAGE_BYTES, 1, f1);
+        mfmas(pc, f0);
+        if constexpr (STORES) strip_store(std::integral_constant<int, STORES ? ST - 1 : 0>{});
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        if constexpr (STORES) {  // the previous strip's stores, one per two MFMAs (a wave stuck at a full memory queue issues no MFMAs)
+#pragma unroll
+            for (int g = 0; g < NST; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - 2 * NST, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this strip's transpose through LDS behind the half's last MFMA issue (it runs under that MFMA and the barrier wait)
+        if constexpr (COMPUTE) strip_compute(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, COMPUTE ? ST : 0>{});
+        if constexpr (decltype(relaxc)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);
+        issue(stage);
+        mfmas(pc, f1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+        for (int g = 0; g < NDMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage ^= 1;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using NoStrip = std::integral_constant<int, -1>;
+    // one tile into accumulator set P; DRAIN: the other set holds the previous tile (strips under k-tiles 0..7)
+    auto run_tile = [&](auto pc, auto drainc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr bool DRAIN = decltype(drainc)::value;
+        int z, ks, m0, n0;
+        decode(tile, z, ks, m0, n0);
+        const int next = tile + gridDim.x;
+        const bool has_next = next < total;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[P][i][j][r] = 0.f;
+        load_frags(lds + stage * STAGE_BYTES, 0, f0);
+        if constexpr (DRAIN) {
+            ktile(pc, std::integral_constant<int, 0>{}, std::false_type{});
+            ktile(pc, std::integral_constant<int, 1>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 2>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 3>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 4>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 5>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 6>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 7>{}, std::true_type{});
+            ktile(pc, std::integral_constant<int, 8>{}, std::true_type{});
+            flush_guard();
+        } else {
+            for (int q = 0; q < 9; ++q) ktile(pc, NoStrip{}, std::false_type{});
+        }
+        int kt = 9;  // nk >= 11 (checked by the launcher)
+        for (; kt < nk - 2; ++kt) ktile(pc, NoStrip{}, std::false_type{});
+        if (has_next) setup_dma(next);
+        for (; kt < nk; ++kt) ktile(pc, NoStrip{}, std::false_type{});
+        // this tile's accumulators now wait for the next tile's k-loop (or the drain below)
+        const GemmProblem pr = a.p[z];
+        pend_C = pr.C;
+        pend_osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
+        pend_m0 = m0;
+        {
+            PP_LANE_COORDS
+            pend_n = n0 + wc_e * 64 + c4 * 4;
+        }
+        pend_bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr.bias) {
+            const float bsc = a.bias_scale_dev ? *a.bias_scale_dev : 1.f;
+            const float4 b4 = *reinterpret_cast<const float4*>(pr.bias + pend_n);
+            pend_bv = make_float4(b4.x * bsc, b4.y * bsc, b4.z * bsc, b4.w * bsc);
+        }
+    };
+    auto drain = [&](auto qc) {  // behind the block's last tile
+        strip_compute(qc, std::integral_constant<int, 0>{}); strip_store(std::integral_constant<int, 0>{});
+        strip_compute(qc, std::integral_constant<int, 1>{}); strip_store(std::integral_constant<int, 1>{});
+        strip_compute(qc, std::integral_constant<int, 2>{}); strip_store(std::integral_constant<int, 2>{});
+        strip_compute(qc, std::integral_constant<int, 3>{}); strip_store(std::integral_constant<int, 3>{});
+        strip_compute(qc, std::integral_constant<int, 4>{}); strip_store(std::integral_constant<int, 4>{});
+        strip_compute(qc, std::integral_constant<int, 5>{}); strip_store(std::integral_constant<int, 5>{});
+        strip_compute(qc, std::integral_constant<int, 6>{}); strip_store(std::integral_constant<int, 6>{});
+        strip_compute(qc, std::integral_constant<int, 7>{}); strip_store(std::integral_constant<int, 7>{});
+        flush_guard();
+    };
+    if (a.ablate & 4) {  // measurement: k-loops only, nothing is drained or stored
+        for (; tile < total; tile += gridDim.x) run_tile(I0{}, std::false_type{});
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[0][i][j][r];
+        if (keep == 12345.678f) a.p[0].C[tid] = keep;  // keeps the MFMAs alive
+        return;
+    }
+#undef PP_LANE_COORDS_UNUSED
+    run_tile(I0{}, std::false_type{});
+    tile += gridDim.x;
+    for (;;) {
+        if (tile >= total) { drain(I0{}); return; }
+        run_tile(I1{}, std::true_type{});
+        tile += gridDim.x;
+        if (tile >= total) { drain(I1{}); return; }
+        run_tile(I0{}, std::true_type{});
+        tile += gridDim.x;
+    }
+}
+
 template <int MI, int WAVES_M, int WAVES_N, bool CONV, bool PURE = false>
 static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
@@ -915,33 +1293,65 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
 
 int g_gemm_gn_fuse = 1;  // sola_tune "gemm_gn_fuse": 0 = never apply the encoder norms in the GEMM epilogue (A/B)
 void sola_gemm_set_gn_fuse(int v) { g_gemm_gn_fuse = v; }
+int g_gemm_pp = 0;  // experiment (sola_tune "gemm_pp"): 1 = ping-pong kernel where it applies
+int g_gemm_nw4 = 0;  // experiment (sola_tune "gemm_nw4"): plain f32-output launches on 256x128 tiles with four waves, one per SIMD
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 
-template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0>
+template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0, int NW = 8>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    constexpr int GBN = NW / 2 * 64;
     a.tiles_m = (M + 255) / 256;
-    a.tiles_n = (N + 255) / 256;
+    a.tiles_n = (N + GBN - 1) / GBN;
     a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
     a.nprob = nprob;
-    constexpr size_t lds = (size_t)2 * 512 * ROWB + 8 * 16 * 64 * 4;  // two stages + eight epilogue strips = 160 KiB
+    constexpr size_t lds = (size_t)2 * (256 + GBN) * ROWB + NW * 16 * 64 * 4;  // two stages + one epilogue strip per wave (160 KiB at NW = 8)
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const int n_cu = sola_cu_count();
     const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
-    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
+
+template <bool CONV, int CSP>
+static int launch_pp_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    a.tiles_m = M / 256;
+    a.tiles_n = N / 128;
+    a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
+    a.nprob = nprob;
+    constexpr size_t lds = (size_t)2 * (256 + 128) * ROWB + 4 * 16 * 64 * 4;
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_pp_kernel<CONV, CSP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done(dev);
+    }
+    const int n_cu = sola_cu_count();
+    const int total = a.tiles_m * a.tiles_n * nprob;
+    const int grid = total < n_cu ? total : n_cu;
+    hipLaunchKernelGGL((gemm_nt_split_glds_pp_kernel<CONV, CSP>), dim3(grid), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+// the ping-pong kernel takes launches without residual / norm / split-K whose tiles are all interior and whose k-loop is long
+// enough to drain eight strips under it
+static bool pp_applies(const GldsArgs& a, int M, int N) {
+    return g_gemm_pp && !a.p[0].R && !a.gn_gamma && a.ksplit <= 1 && M % 256 == 0 && N % 128 == 0 && (a.ldc & 3) == 0 && a.K / GBK >= 11 &&
+           (!a.p[0].bias || (reinterpret_cast<uintptr_t>(a.p[0].bias) & 15) == 0);
+}
+
 template <bool CONV>
 static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    if (pp_applies(a, M, N)) return a.c_sp16 ? launch_pp_t<CONV, 1>(a, M, N, nprob, s) : launch_pp_t<CONV, 0>(a, M, N, nprob, s);
     if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);  // partial sums: f32, no residual
     if (a.gn_gamma) {  // conditions checked by gemm_gn_fusable()
         if (a.gn_tokens == 16) return launch_persist_t<CONV, 0, 1, false, 16>(a, M, N, nprob, s);
@@ -953,6 +1363,7 @@ static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
         if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 1>(a, M, N, nprob, s);
         return rmode == 2 ? launch_persist_t<false, 2, 1>(a, M, N, nprob, s) : launch_persist_t<false, 1, 1>(a, M, N, nprob, s);
     }
+    if (g_gemm_nw4 && !CONV && rmode == 0 && a.ksplit <= 1) return launch_persist_t<false, 0, 0, false, 0, 4>(a, M, N, nprob, s);  // experiment
     if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);
     return rmode == 2 ? launch_persist_t<false, 2, 0>(a, M, N, nprob, s) : launch_persist_t<false, 1, 0>(a, M, N, nprob, s);
 }

@@ -241,3 +241,32 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
         _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 0), "sola_tune")
         _lib.check(_lib.lib().sola_tune(b"attn_splitm", 0), "sola_tune")
         _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 0), "sola_tune")
+
+
+@pytest.mark.parametrize("key", ["gemm_nw4", "gemm_pp"])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_experimental_four_wave_gemm_kernels_are_bit_identical(key, out_split):
+    """The two experimental shapes of the persistent split-f16 GEMM (sola_tune gemm_nw4: 256x128 tiles, four waves, one per SIMD;
+    gemm_pp: the same with two accumulator sets, a tile's epilogue drained under the next tile's k-loop - DESIGN.md 5) keep the
+    fragment layout and accumulation order of the default kernel: same bits, with bias, in both output formats."""
+    from sola_amd import _lib
+    lib = _lib.lib()
+    torch.manual_seed(3)
+    outs = {}
+    try:
+        _lib.check(lib.sola_tune(b"gemm_glds", 4), "tune")  # the 256x256 family whatever the grid
+        for M, N, K in ((65536, 512, 768), (16384, 1024, 1024)):  # 4 and 2 tiles per CU: the draining k-tiles and the final drain both run
+            x = torch.randn(M, K, device="cuda"); wt = torch.randn(N, K, device="cuda") * 0.03; b = torch.randn(N, device="cuda")
+            a, w = ops.cast_sp16(x), ops.cast_sp16(wt, 64.0)
+            for on in (0, 1):
+                _lib.check(lib.sola_tune(key.encode(), on), "tune")
+                _lib.check(lib.sola_tune(b"gemm_glds_force", 1), "tune")
+                _lib.profile_enable(True)
+                outs[on] = ops.gemm_nt_split(a, w, b, out_scale=1 / 64, out_split=out_split).clone()
+            assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (M, N, K)
+        assert _lib.profile_read(reset=True)["gemm_split256"]["launches"] == 4  # all four launches took the 256-row kernels
+    finally:
+        _lib.profile_enable(False)
+        _lib.check(lib.sola_tune(key.encode(), 0), "tune")
+        _lib.check(lib.sola_tune(b"gemm_glds_force", 0), "tune")
+        _lib.check(lib.sola_tune(b"gemm_glds", 3), "tune")
