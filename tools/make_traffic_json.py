@@ -13,8 +13,11 @@ for line in open(sys.argv[1]):
 gemms = [k for k in rows if k.startswith("gemm_nt_split")]  # the exact-f32 leg of the same run is not the headline
 # bench.py's roofline line covers every 256x256 launch of a step (its own profiler category); those are the instantiations
 # of the persistent kernel, so their launch-weighted mean is the per-launch traffic / duration that goes with it
-# (the instantiations that also apply GroupNorm in the epilogue - last template argument 16 / 8 / 4 - are a category of their own)
-fused = [k for k in rows if k.startswith("gemm_nt_split_glds_persist_kernel") and not k.rstrip().endswith(", 0>")]
+# (the instantiations that also apply GroupNorm in the epilogue - template argument GNT = 16 / 8 / 4 - are a category of their own)
+def _gnt(name):  # <CONV, RMODE, CSP, PURE, GNT, NW>: rows per GroupNorm instance of the epilogue, 0 = none
+    args = name[name.index("<") + 1:name.rindex(">")].split(",")
+    return int(args[4]) if len(args) > 4 else 0
+fused = [k for k in rows if k.startswith("gemm_nt_split_glds_persist_kernel") and _gnt(k) != 0]
 p256 = [k for k in rows if (k.startswith("gemm_nt_split_glds_persist_kernel") and k not in fused) or k.startswith("gemm_nt_split_glds_kernel<4")]
 if fused:
     calls = sum(rows[k]["calls"] for k in fused)
