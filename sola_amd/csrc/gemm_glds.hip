@@ -903,7 +903,7 @@ bool gemm_split_glds_supported(const GemmDesc& d) {
 // order and the same epilogue arithmetic as the kernel above: results are bit-identical.
 template <bool CONV, int CSP>
 __global__ __launch_bounds__(256) void gemm_nt_split_glds_pp_kernel(const GldsArgs a) {
-    constexpr int RMODE = 0, GNT = 0, NW = 4;
+    constexpr int NW = 4;
     constexpr bool PURE = false;
     constexpr int MI = 4, WAVES_N = NW / 2, GBM = 256, GBN = WAVES_N * 64, NWAVE = NW;
     constexpr int STAGE_BYTES = (GBM + GBN) * ROWB;
