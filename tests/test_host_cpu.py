@@ -136,3 +136,17 @@ def test_text_encoder_stand_in_needs_explicit_opt_in(monkeypatch):
     monkeypatch.setenv("SOLA_ALLOW_TEXT_STANDIN", "1")
     with pytest.warns(UserWarning):
         assert TextEncoder("no-such-org/no-such-model", 64, "cpu").kind == "hashed-standin"
+
+
+def test_build_recipe_keeps_the_flags_the_kernels_were_validated_with():
+    """gemm_glds.hip must be compiled without the SLP vectoriser (its packed-f32 code made the fused GroupNorm epilogue return wrong
+    rows nondeterministically - DESIGN.md 5); the recipe and the profiler categories the bench relies on are pinned here."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mk = open(os.path.join(root, "sola_amd", "csrc", "Makefile")).read()
+    assert re.search(r"^FLAGS_gemm_glds\s*=.*-fno-slp-vectorize", mk, re.M)
+    assert "$(FLAGS_$*)" in mk and "--offload-arch=$(ARCH)" in mk and re.search(r"^ARCH\s*\?=\s*gfx950", mk, re.M)
+    from sola_amd import _lib
+    hdr = open(os.path.join(root, "include", "sola_hip.h")).read()
+    n_cat = int(re.search(r"SOLA_PROF_NCAT\s*=\s*(\d+)", hdr).group(1))
+    assert n_cat == len(_lib.PROF_CATEGORIES) and _lib.PROF_CATEGORIES[-1] == "gemm_split256_gn"
