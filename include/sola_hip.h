@@ -246,6 +246,33 @@ int sola_forward_train(SolaCtx* ctx, const float* dev_object_tokens, const float
                        void* dev_workspace, size_t workspace_bytes, void* stream);
 int sola_backward(SolaCtx* ctx, const float* dev_d_score_map, const float* dev_d_score_tokens,
                   const void* dev_forward_workspace, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* ---- ragged training step: many (video, expression) samples of DIFFERENT shapes per optimizer step -------------------------
+ * The reference trains at batch size 1 (configs/mevis/default.yaml:37; train.py:62-137: one forward, one backward, one AdamW
+ * step per sample) because every sample has its own N tracks, T frames and L text tokens (dataloader.py:119-163,187-199).
+ * sola_forward_train_ragged / sola_backward_ragged run the same step over a SolaRaggedBatch: token rows concatenated without
+ * padding (layouts as sola_forward_ragged), every GEMM of the forward and backward over all rows at once, every shape-dependent
+ * kernel (conv windows and their transposes, GroupNorm and its backward, the three attentions and their backward, score head)
+ * reading per-unit tables built on the device.  One sample per video, in order (n_samples == n_videos, sample_video[i] == i):
+ * under training-mode dropout each sample has its own masks, so nothing is shared between the expressions of a video.
+ * The parameter gradients sola_backward_ragged leaves are the SUM over the samples of what one-sample calls produce for the
+ * same upstream d(score_map) / d(score_tokens) (weighting per sample is the caller's, through those: sola_loss_backward_ragged
+ * takes one upstream triple per sample).  The workspace holds the unit tables: hand the SAME workspace to sola_backward_ragged. */
+size_t sola_train_ragged_workspace_bytes(const SolaCtx* ctx, const SolaRaggedBatch* batch);
+size_t sola_backward_ragged_workspace_bytes(const SolaCtx* ctx, const SolaRaggedBatch* batch);
+int sola_forward_train_ragged(SolaCtx* ctx, const float* dev_object_tokens, const float* dev_lang_tokens, const SolaRaggedBatch* batch,
+                              float* dev_score_map, float* dev_score_tokens, void* dev_workspace, size_t workspace_bytes, void* stream);
+int sola_backward_ragged(SolaCtx* ctx, const float* dev_d_score_map, const float* dev_d_score_tokens,
+                         const void* dev_forward_workspace, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* Backward of sola_loss_ragged: dev_g3 [n_samples, 3] = upstream gradients of every sample's {total, bce, alignment} (the mean
+ * of the per-sample totals - train.py:113 averaged over the batch - is g3[b] = {1/n_samples, 0, 0}).  Outputs as
+ * sola_loss_backward over the concatenated tracks; d_neg [n_samples, n_neg, D], or [n_neg, D] summed over the samples when
+ * neg_batch_stride == 0.  Scratch: total_tracks*n_neg floats (+ n_samples*n_neg*D for shared negatives). */
+int sola_loss_backward_ragged(const float* dev_score_map, const float* dev_score_tokens, const float* dev_labels,
+                              const float* dev_pos_tokens, const float* dev_neg_tokens, int64_t neg_batch_stride, int n_samples,
+                              const int32_t* dev_track_offsets, int max_tracks, int64_t total_tracks, int D, int n_neg,
+                              float positive_weight, float temperature, float alignment_weight, const float* dev_g3,
+                              float* dev_d_score_map, float* dev_d_score_tokens, float* dev_d_neg, void* dev_scratch,
+                              size_t scratch_bytes, void* stream);
 /* Gradient buckets for multi-GPU training (train.py under torchrun: one RCCL all-reduce of the gradient per step, the only
  * collective of the path).  sola_backward finishes the parameters' gradients in a fixed order: alignment layer n-1, ...,
  * layer 1, then layer 0 together with negative_token.weight (which collects contributions from every layer), then the

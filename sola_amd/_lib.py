@@ -73,6 +73,11 @@ SIGNATURES = {
     "sola_ragged_workspace_bytes": (_sz, [_vp, C.POINTER(SolaRaggedBatch)]),
     "sola_forward_ragged": (_i, [_vp, _vp, _vp, C.POINTER(SolaRaggedBatch), _vp, _vp, _vp, _sz, _vp]),
     "sola_loss_ragged": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _i, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "sola_train_ragged_workspace_bytes": (_sz, [_vp, C.POINTER(SolaRaggedBatch)]),
+    "sola_backward_ragged_workspace_bytes": (_sz, [_vp, C.POINTER(SolaRaggedBatch)]),
+    "sola_forward_train_ragged": (_i, [_vp, _vp, _vp, C.POINTER(SolaRaggedBatch), _vp, _vp, _vp, _sz, _vp]),
+    "sola_backward_ragged": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sola_loss_backward_ragged": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _i, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sola_workspace_tap": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_i64)]),
     "sola_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "sola_select": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),

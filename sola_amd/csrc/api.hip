@@ -8,7 +8,7 @@
 #include <exception>
 #include <mutex>
 
-#include "ctx.h"
+#include "ragged.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // errors
@@ -543,6 +543,34 @@ extern "C" int sola_forward_train(SolaCtx* c, const float* obj, const float* lan
     return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_), true);
 }
 
+// ---- ragged training step: many samples of different (N, T, L) per optimizer step (train.py:62-137 runs ONE per step) --------
+extern "C" size_t sola_train_ragged_workspace_bytes(const SolaCtx* c, const SolaRaggedBatch* batch) {
+    if (!c || !batch) return 0;
+    try {
+        RagShape r;
+        if (rag_shape(c, batch, r) != SOLA_OK) return 0;
+        return make_plan_ragged(c, r, true).total;
+    } catch (const std::exception& e) {
+        sola_set_error("train_ragged_workspace_bytes: %s", e.what());
+        return 0;
+    }
+}
+
+extern "C" int sola_forward_train_ragged(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch,
+                                         float* score_map, float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
+    SOLA_ARG(c && batch, "forward_train_ragged: null argument");
+    try {  // the host-side plan allocates; nothing may throw across the ABI
+        RagShape r;
+        SOLA_TRY(rag_shape(c, batch, r));
+        SOLA_ARG(r.identity, "forward_train_ragged: one sample per video, in order (n_samples == n_videos, sample_video[i] == i): "
+                             "every training sample runs its own encoder pass under its own dropout masks");
+        return sola_forward_impl(c, obj, lang, 0, 0, 0, 0, score_map, score_tokens, workspace, ws_bytes, as_stream(stream_), true, &r);
+    } catch (const std::exception& e) {
+        sola_set_error("forward_train_ragged: %s", e.what());
+        return SOLA_ERR_ARG;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // losses / selection
 // ---------------------------------------------------------------------------------------------------------------
@@ -590,6 +618,34 @@ extern "C" int sola_loss_backward(const float* score_map, const float* score_tok
     d.d_neg = shared ? stage : d_neg;
     SOLA_TRY(launch_loss_bwd(d, as_stream(stream_)));
     if (shared) return launch_neg_token_grad(nullptr, nullptr, stage, d_neg, B, 0, n_neg, D, as_stream(stream_));
+    return SOLA_OK;
+}
+
+extern "C" int sola_loss_backward_ragged(const float* score_map, const float* score_tokens, const float* labels, const float* pos,
+                                         const float* neg, int64_t neg_batch_stride, int n_samples, const int32_t* dev_track_offsets,
+                                         int max_tracks, int64_t total_tracks, int D, int n_neg, float pw, float temperature, float aw,
+                                         const float* g3, float* d_score_map, float* d_score_tokens, float* d_neg, void* scratch,
+                                         size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(score_map && score_tokens && labels && pos && neg && g3 && d_score_map && d_score_tokens && scratch && dev_track_offsets,
+             "loss_backward_ragged: null argument");
+    SOLA_ARG(n_samples > 0 && max_tracks > 0 && total_tracks > 0 && D > 0 && n_neg > 0, "loss_backward_ragged: bad sizes");
+    const bool shared = neg_batch_stride == 0 && d_neg != nullptr;
+    const size_t coef_floats = ((size_t)total_tracks * n_neg + 63) & ~(size_t)63;
+    const size_t need = (coef_floats + (shared ? (size_t)n_samples * n_neg * D : 0)) * sizeof(float);
+    if (scratch_bytes < need) {
+        sola_set_error("loss_backward_ragged: scratch %zu bytes < required %zu", scratch_bytes, need);
+        return SOLA_ERR_WORKSPACE;
+    }
+    float* stage = static_cast<float*>(scratch) + coef_floats;
+    LossBwdDesc d{};
+    d.score_map = score_map; d.score_tokens = score_tokens; d.labels = labels; d.pos = pos; d.neg = neg;
+    d.neg_batch_stride = neg_batch_stride; d.B = n_samples; d.N = max_tracks; d.D = D; d.n_neg = n_neg;
+    d.pos_w = pw; d.temp_scale = expf(temperature); d.align_w = aw; d.g3 = g3;
+    d.d_score = d_score_map; d.d_tok = d_score_tokens; d.coef = static_cast<float*>(scratch);
+    d.d_neg = shared ? stage : d_neg;
+    d.trk_off = dev_track_offsets; d.total_tracks = total_tracks;
+    SOLA_TRY(launch_loss_bwd(d, as_stream(stream_)));
+    if (shared) return launch_neg_token_grad(nullptr, nullptr, stage, d_neg, n_samples, 0, n_neg, D, as_stream(stream_));
     return SOLA_OK;
 }
 

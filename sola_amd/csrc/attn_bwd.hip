@@ -23,7 +23,26 @@ struct AttnBwdArgs {
     long long k_outer, k_inner, k_rs;
     float scale;
     DropoutCfg drop;
+    // ragged batches (AttnBwdDesc::q_units): group g has q_units[g] = (first row, row stride, Sq_g, -), k_units[g] likewise; Sq / Sk
+    // are then the LARGEST lengths: they size the grids and - in the per-wave kernels, whose four waves serve different units
+    // between shared block barriers - the loop trip counts; rows past a unit's own length are masked
+    const int4 *q_units, *k_units;
 };
+
+struct BwdGeo { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
+__device__ __forceinline__ BwdGeo bwd_geo(const AttnBwdArgs& a, int grp) {
+    BwdGeo g;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        g.q0 = qu.x; g.q_rs = qu.y; g.Sq = qu.z;
+        g.k0 = ku.x; g.k_rs = ku.y; g.Sk = ku.z;
+    } else {
+        g.q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        g.k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        g.q_rs = a.q_rs; g.k_rs = a.k_rs; g.Sq = a.Sq; g.Sk = a.Sk;
+    }
+    return g;
+}
 
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
@@ -39,11 +58,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     const int qt = unit_ok ? (int)(unit % a.ntile) : 0;
     const long long gh = unit_ok ? unit / a.ntile : 0;
     const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
-    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const BwdGeo geo = bwd_geo(a, grp);
+    const long long qrow0 = geo.q0, krow0 = geo.k0;
     const int qi = qt * 16 + c16;
-    const bool q_ok = unit_ok && qi < a.Sq;
-    const long long qrow = qrow0 + (long long)qi * a.q_rs;
+    const bool q_ok = unit_ok && qi < geo.Sq;
+    const long long qrow = qrow0 + (long long)(q_ok ? qi : 0) * geo.q_rs;
 
     float4 qf[NC], dof[NC];
     float dsum = 0.f;
@@ -72,14 +91,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     for (int c = 0; c < NC; ++c) dqacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt0 = 0; kt0 < a.Sk; kt0 += 16) {
-        const int nrows = min(16, a.Sk - kt0);
+        const int nrows = min(16, geo.Sk - kt0);
         __syncthreads();
         if (unit_ok) {
             for (int idx = lane; idx < 16 * F4; idx += 64) {
                 const int r = idx / F4, c4 = idx - r * F4;
                 float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
                 if (r < nrows) {
-                    const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
+                    const long long row = krow0 + (long long)(kt0 + r) * geo.k_rs;
                     kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
                     vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
                 }
@@ -119,11 +138,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool kok = kt0 + 4 * g4 + r < a.Sk;
+            const bool kok = kt0 + 4 * g4 + r < geo.Sk;
             const float p = (kok && q_ok) ? __expf((s0[r] + s1[r]) - lse_q) : 0.f;
             float dp = p0[r] + p1[r];
             if (a.drop.enabled)  // O = (P o mask / (1-p)) V: dP = (dO V^T) o mask / (1-p); D = dO . O is unchanged
-                dp = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk + kt0 + 4 * g4 + r)
+                dp = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * geo.Sq + qi) * geo.Sk + kt0 + 4 * g4 + r)
                          ? dp * a.drop.scale : 0.f;
             ds[r] = p * (dp - dsum);
         }
@@ -158,11 +177,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     const int kt = unit_ok ? (int)(unit % a.ntile) : 0;
     const long long gh = unit_ok ? unit / a.ntile : 0;
     const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
-    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const BwdGeo geo = bwd_geo(a, grp);
+    const long long qrow0 = geo.q0, krow0 = geo.k0;
     const int kj = kt * 16 + c16;
-    const bool k_ok = unit_ok && kj < a.Sk;
-    const long long krow = krow0 + (long long)kj * a.k_rs;
+    const bool k_ok = unit_ok && kj < geo.Sk;
+    const long long krow = krow0 + (long long)(k_ok ? kj : 0) * geo.k_rs;
 
     float4 kf[NC], vf[NC];
     {
@@ -181,14 +200,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int qt0 = 0; qt0 < a.Sq; qt0 += 16) {
-        const int nrows = min(16, a.Sq - qt0);
+        const int nrows = min(16, geo.Sq - qt0);
         __syncthreads();
         if (unit_ok) {
             for (int idx = lane; idx < 16 * F4; idx += 64) {
                 const int r = idx / F4, c4 = idx - r * F4;
                 float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
                 if (r < nrows) {
-                    const long long row = qrow0 + (long long)(qt0 + r) * a.q_rs;
+                    const long long row = qrow0 + (long long)(qt0 + r) * geo.q_rs;
                     qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
                     gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
                 }
@@ -229,10 +248,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt0 + 4 * g4 + r;
-            const bool ok = k_ok && q < a.Sq;
+            const bool ok = k_ok && q < geo.Sq;
             float lse = 0.f, dv = 0.f;
             if (ok) {
-                const long long row = qrow0 + (long long)q * a.q_rs;
+                const long long row = qrow0 + (long long)q * geo.q_rs;
                 lse = a.lse[row * a.H + h];
                 dv = a.dvec[row * a.H + h];
             }
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
             float dp = p0[r] + p1[r];
             float keep = 1.f;
             if (a.drop.enabled)
-                keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + q) * a.Sk + kj) ? a.drop.scale : 0.f;
+                keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * geo.Sq + q) * geo.Sk + kj) ? a.drop.scale : 0.f;
             ds[r] = pr[r] * (dp * keep - dv);
             pr[r] *= keep;  // dV uses the dropped probabilities
         }
@@ -284,11 +303,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_blk_kernel(const AttnBwdArgs 
     const long long gh = blockIdx.x / nqc;
     const int qc = (int)(blockIdx.x - gh * nqc);
     const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
-    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const BwdGeo geo = bwd_geo(a, grp);
+    if (qc * 64 >= geo.Sq) return;  // ragged: the grid follows the longest unit (the whole block leaves together)
+    const long long qrow0 = geo.q0, krow0 = geo.k0;
     const int qi = qc * 64 + wave * 16 + c16;
-    const bool q_ok = qi < a.Sq;
-    const long long qrow = qrow0 + (long long)(q_ok ? qi : 0) * a.q_rs;
+    const bool q_ok = qi < geo.Sq;
+    const long long qrow = qrow0 + (long long)(q_ok ? qi : 0) * geo.q_rs;
 
     float4 qf[NC], dof[NC];
     float dsum = 0.f;
@@ -323,8 +343,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_blk_kernel(const AttnBwdArgs 
         for (int j = 0; j < PT; ++j) {
             const int e = tid + 256 * j, which = e / (16 * F4), r = (e % (16 * F4)) / F4, c4 = e % F4;
             st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kt0 + r < a.Sk) {
-                const long long row = krow0 + (long long)(kt0 + r) * a.k_rs;
+            if (kt0 + r < geo.Sk) {
+                const long long row = krow0 + (long long)(kt0 + r) * geo.k_rs;
                 st[j] = which ? *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4)
                               : *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
             }
@@ -339,12 +359,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_blk_kernel(const AttnBwdArgs 
     };
     fetch(0);
     int it = 0;
-    for (int kt0 = 0; kt0 < a.Sk; kt0 += 16, ++it) {
+    for (int kt0 = 0; kt0 < geo.Sk; kt0 += 16, ++it) {
         float* Ks = smem + (it & 1) * 2 * 16 * LD;
         float* Vs = Ks + 16 * LD;
         stash(Ks);
         __syncthreads();
-        if (kt0 + 16 < a.Sk) fetch(kt0 + 16);
+        if (kt0 + 16 < geo.Sk) fetch(kt0 + 16);
         // S^T[key][q] and dP^T[key][q]: A = K / V rows (b128), B = q / dO fragments
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
         const float* kp = &Ks[c16 * LD + 4 * g4];
@@ -367,11 +387,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_blk_kernel(const AttnBwdArgs 
         float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool kok = kt0 + 4 * g4 + r < a.Sk;
+            const bool kok = kt0 + 4 * g4 + r < geo.Sk;
             const float p = (kok && q_ok) ? __expf((s0[r] + s1[r]) - lse_q) : 0.f;
             float dp = p0[r] + p1[r];
             if (a.drop.enabled)  // O = (P o mask / (1-p)) V: dP = (dO V^T) o mask / (1-p); D = dO . O is unchanged
-                dp = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + qi) * a.Sk + kt0 + 4 * g4 + r)
+                dp = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * geo.Sq + qi) * geo.Sk + kt0 + 4 * g4 + r)
                          ? dp * a.drop.scale : 0.f;
             ds[r] = p * (dp - dsum);
         }
@@ -402,11 +422,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
     const long long gh = blockIdx.x / nkc;
     const int kc = (int)(blockIdx.x - gh * nkc);
     const int h = (int)(gh % a.H), grp = (int)(gh / a.H);
-    const long long qrow0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-    const long long krow0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+    const BwdGeo geo = bwd_geo(a, grp);
+    if (kc * 64 >= geo.Sk) return;  // ragged: the grid follows the longest unit
+    const long long qrow0 = geo.q0, krow0 = geo.k0;
     const int kj = kc * 64 + wave * 16 + c16;
-    const bool k_ok = kj < a.Sk;
-    const long long krow = krow0 + (long long)(k_ok ? kj : 0) * a.k_rs;
+    const bool k_ok = kj < geo.Sk;
+    const long long krow = krow0 + (long long)(k_ok ? kj : 0) * geo.k_rs;
 
     float4 kf[NC], vf[NC];
     {
@@ -430,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
         for (int j = 0; j < PT; ++j) {
             const int e = tid + 256 * j, which = e / (16 * F4), r = (e % (16 * F4)) / F4, c4 = e % F4;
             st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qt0 + r < a.Sq) {
-                const long long row = qrow0 + (long long)(qt0 + r) * a.q_rs;
+            if (qt0 + r < geo.Sq) {
+                const long long row = qrow0 + (long long)(qt0 + r) * geo.q_rs;
                 st[j] = which ? *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4)
                               : *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
             }
@@ -446,12 +467,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
     };
     fetch(0);
     int it = 0;
-    for (int qt0 = 0; qt0 < a.Sq; qt0 += 16, ++it) {
+    for (int qt0 = 0; qt0 < geo.Sq; qt0 += 16, ++it) {
         float* Qs = smem + (it & 1) * 2 * 16 * LD;
         float* Gs = Qs + 16 * LD;  // dO rows
         stash(Qs);
         __syncthreads();
-        if (qt0 + 16 < a.Sq) fetch(qt0 + 16);
+        if (qt0 + 16 < geo.Sq) fetch(qt0 + 16);
         // S[q][key] and dP[q][key]: A = Q / dO rows (b128), B = k / v fragments; lane gets q = 4*g4 + r, key = c16
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
         const float* qp = &Qs[c16 * LD + 4 * g4];
@@ -475,10 +496,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt0 + 4 * g4 + r;
-            const bool ok = k_ok && q < a.Sq;
+            const bool ok = k_ok && q < geo.Sq;
             float lse = 0.f, dv = 0.f;
             if (ok) {
-                const long long row = qrow0 + (long long)q * a.q_rs;
+                const long long row = qrow0 + (long long)q * geo.q_rs;
                 lse = a.lse[row * a.H + h];
                 dv = a.dvec[row * a.H + h];
             }
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
             const float dp = p0[r] + p1[r];
             float keep = 1.f;
             if (a.drop.enabled)
-                keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + q) * a.Sk + kj) ? a.drop.scale : 0.f;
+                keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * geo.Sq + q) * geo.Sk + kj) ? a.drop.scale : 0.f;
             ds[r] = pr[r] * (dp * keep - dv);
             pr[r] *= keep;  // dV uses the dropped probabilities
         }
@@ -531,15 +552,15 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
     const bool live = unit < n_units;
     const long long uu = live ? unit : 0;
     const int grp = (int)(uu / a.H), h = (int)(uu - (long long)grp * a.H);
-    const long long q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
-    const long long k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
-    const int Sq = live ? a.Sq : 0, Sk = live ? a.Sk : 0;
+    const BwdGeo geo = bwd_geo(a, grp);
+    const long long q0 = geo.q0, k0 = geo.k0;
+    const int Sq = live ? geo.Sq : 0, Sk = live ? geo.Sk : 0;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 qv[TT], kv[TT], vv[TT], gv[TT];
     float dsum[TT], lse[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        const long long qr = q0 + (long long)t * a.q_rs, kr = k0 + (long long)t * a.k_rs;
+        const long long qr = q0 + (long long)t * geo.q_rs, kr = k0 + (long long)t * geo.k_rs;
         qv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.q + qr * a.ldq + h * DH + 4 * c) : z;
         gv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.dout + qr * a.ldo + h * DH + 4 * c) : z;
         const float4 ov = t < Sq ? *reinterpret_cast<const float4*>(a.o + qr * a.ldo + h * DH + 4 * c) : z;
@@ -562,7 +583,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             const float p = ok ? __expf(sc - lse[i]) : 0.f;
             float pw = p;
             if (a.drop.enabled) {
-                const bool keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * a.Sq + i) * a.Sk + j);
+                const bool keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * geo.Sq + i) * geo.Sk + j);
                 pw = keep ? p * a.drop.scale : 0.f;
                 dpr = keep ? dpr * a.drop.scale : 0.f;
             }
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             const float w = ds[i][j] * a.scale;
             dq.x += w * kv[j].x; dq.y += w * kv[j].y; dq.z += w * kv[j].z; dq.w += w * kv[j].w;
         }
-        *reinterpret_cast<float4*>(a.dq + (q0 + (long long)i * a.q_rs) * a.ld_dq + h * DH + 4 * c) = dq;
+        *reinterpret_cast<float4*>(a.dq + (q0 + (long long)i * geo.q_rs) * a.ld_dq + h * DH + 4 * c) = dq;
     }
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             dk.x += w * qv[i].x; dk.y += w * qv[i].y; dk.z += w * qv[i].z; dk.w += w * qv[i].w;
             dv.x += pw * gv[i].x; dv.y += pw * gv[i].y; dv.z += pw * gv[i].z; dv.w += pw * gv[i].w;
         }
-        const long long kr = k0 + (long long)j * a.k_rs;
+        const long long kr = k0 + (long long)j * geo.k_rs;
         *reinterpret_cast<float4*>(a.dk + kr * a.ld_dk + h * DH + 4 * c) = dk;
         *reinterpret_cast<float4*>(a.dv + kr * a.ld_dv + h * DH + 4 * c) = dv;
     }
@@ -682,6 +703,7 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale;
     a.drop = d.drop;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
     if (g_attn_bwd_small && d.DH == 128 && d.Sq <= 4 && d.Sk <= 4) return launch_bwd_small(a, s);

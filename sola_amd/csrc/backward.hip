@@ -7,7 +7,7 @@
 
 #include <algorithm>
 
-#include "ctx.h"
+#include "ragged.h"
 
 extern int g_train_split_min_rows;
 int g_bwd_dual_cast = 1;  // sola_tune "bwd_dual_cast": the transposing cast of a gradient matrix also writes its row-major cast (A/B)
@@ -27,11 +27,34 @@ struct Arena {
     float* get(const std::string& name) const { return reinterpret_cast<float*>(base + off.at(name)); }
 };
 
-Arena make_arena(const SolaCtx* c, const Plan& p) {
+// row counts the arena is sized by: a uniform (B, N, T, L) batch or the concatenated rows of a ragged one
+struct BwdSizes {
+    size_t M, BW, R, S, inst_bt;  // layer rows, text ++ negative rows, tracks, samples, inter-object GroupNorm instances (sum of T')
+    size_t rows[7];               // token rows per encoder level (0 = the object tokens)
+    bool rag;
+};
+BwdSizes sizes_of(const Plan& p) {
+    BwdSizes z{};
+    z.M = p.M; z.BW = (size_t)p.B * p.W; z.R = (size_t)p.B * p.N; z.S = p.B; z.inst_bt = (size_t)p.B * p.Tp;
+    z.rows[0] = z.R * p.T;
+    for (int i = 0; i < 6; ++i) z.rows[i + 1] = z.R * p.Tl[i];
+    z.rag = false;
+    return z;
+}
+template <class RagLike>  // RagShape (before the forward) or RagTables (after it): the same extent fields
+BwdSizes sizes_of_ragged(const RagLike& r) {
+    BwdSizes z{};
+    z.M = (size_t)r.Ms; z.BW = (size_t)r.LW; z.R = (size_t)r.NT; z.S = (size_t)r.S; z.inst_bt = (size_t)r.sumTpS;
+    for (int j = 0; j < 7; ++j) z.rows[j] = (size_t)r.rows[j];
+    z.rag = true;
+    return z;
+}
+
+Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
     Arena a;
     a.base = nullptr;
-    const size_t D = c->cfg.lang_token_dim, H = c->cfg.num_heads, M = p.M, BW = (size_t)p.B * p.W;
-    const size_t R = (size_t)p.B * p.N;
+    const size_t D = c->cfg.lang_token_dim, H = c->cfg.num_heads, M = z.M, BW = z.BW;
+    const size_t R = z.R;
     a.add("g0", M * D);
     a.add("g1", M * D);
     a.add("e", M * D);       // d(x + pe)
@@ -42,19 +65,17 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("dlang", BW * D);
     a.add("dvec", M * H);
     a.add("dlbar_part", R * D);
-    a.add("dlbar", (size_t)p.B * D);
+    a.add("dlbar", z.S * D);
     // GroupNorm partials are [n_inst][C]; n_inst is B*N (per track), B*T' (per time step) or B
-    size_t enc_max = 0, ws_total = 0, wt_max = 3 * D * D, tn_max = 0, inst_c_max = std::max(R, (size_t)p.B * p.Tp) * D;
-    int t_in = p.T;
+    size_t enc_max = 0, ws_total = 0, wt_max = 3 * D * D, tn_max = 0, inst_c_max = std::max(R, z.inst_bt) * D;
     for (int i = 0; i < 6; ++i) {
         const ConvGeom& g = c->conv[i];
-        enc_max = std::max(enc_max, R * p.Tl[i] * (size_t)g.cout);
-        enc_max = std::max(enc_max, R * (size_t)t_in * g.cin);
+        enc_max = std::max(enc_max, z.rows[i + 1] * (size_t)g.cout);
+        enc_max = std::max(enc_max, z.rows[i] * (size_t)g.cin);
         ws_total += (size_t)g.cout * g.cin * g.k;
         wt_max = std::max(wt_max, (size_t)g.cout * g.cin * g.k);
-        tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)(R * p.Tl[i]), g.cout, g.k * g.cin));
+        tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)z.rows[i + 1], g.cout, g.k * g.cin));
         inst_c_max = std::max(inst_c_max, R * (size_t)g.cout);
-        t_in = p.Tl[i];
     }
     tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)M, (int)D, (int)D));
     tn_max = std::max(tn_max, gemm_tn_scratch_bytes((int)BW, (int)D, (int)D));
@@ -65,31 +86,33 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
     a.add("tn", tn_max / sizeof(float) + 64);
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
-    a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, (size_t)p.B * p.Tp)), (int)D) / sizeof(float) + 64);
+    a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, z.inst_bt)), (int)D) / sizeof(float) + 64);
     // few-sample regime (the reference trains at batch size 1): the dX GEMMs have fewer 64x64 tiles than the chip has CUs; scratch
     // for their deterministic two-pass split-K, as the forward has (42-136 us per dX GEMM without it, 64 blocks on 256 CUs)
     if (M <= 8192) a.add("splitk", (size_t)8192 * 4096);
-    if (c->precision >= 1 && p.M >= g_train_split_min_rows) {  // split-f16 / f16-operand dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
+    const bool lowp = c->precision >= 1 && (long long)M >= g_train_split_min_rows;
+    {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather: the split-f16 / f16 modes, and every ragged batch
+        // (the f32 path's transposed-conv gather needs one sequence length)
+        size_t zmax = 0;
+        for (int i = 1; i < 6; ++i) zmax = std::max(zmax, z.rows[i + 1] * (size_t)c->conv[i].k * c->conv[i].cin);
+        if (lowp || z.rag) a.add("zcol", zmax);
+    }
+    if (lowp) {  // split-f16 / f16-operand dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
         a.add("scal", 64);
         {   // per-64-row-slab column sums of a gradient matrix (launch_amax_colsum): bias gradients without a second read
             size_t cp = std::max((M / 64 + 1) * 3 * D, (BW / 64 + 1) * 2 * D);
-            for (int i = 0; i < 6; ++i) cp = std::max(cp, (R * p.Tl[i] / 64 + 1) * (size_t)c->conv[i].cout);
+            for (int i = 0; i < 6; ++i) cp = std::max(cp, (z.rows[i + 1] / 64 + 1) * (size_t)c->conv[i].cout);
             a.add("cpart", cp);
-        }
-        {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather
-            size_t zmax = 0;
-            for (int i = 1; i < 6; ++i) zmax = std::max(zmax, R * p.Tl[i] * (size_t)c->conv[i].k * c->conv[i].cin);
-            a.add("zcol", zmax);
         }
         // split-f16 weight gradients of the projections (gemm_tn_split.hip): transposed operands + partial sums
         if (gemm_tn_split_supported((int)M, (int)D, (int)D)) {
             size_t need = gemm_tn_split_scratch_bytes((int)M, (int)D, (int)D, 3);
             if (gemm_tn_split_supported((int)BW, (int)D, (int)D)) need = std::max(need, gemm_tn_split_scratch_bytes((int)BW, (int)D, (int)D, 2));
             for (int i = 0; i < 6; ++i)
-                if (gemm_tn_split_supported((int)(R * p.Tl[i]), c->conv[i].cout, c->conv[i].k * c->conv[i].cin))
-                    need = std::max(need, gemm_tn_split_scratch_bytes((int)(R * p.Tl[i]), c->conv[i].cout, c->conv[i].k * c->conv[i].cin, 1));
+                if (gemm_tn_split_supported((int)z.rows[i + 1], c->conv[i].cout, c->conv[i].k * c->conv[i].cin))
+                    need = std::max(need, gemm_tn_split_scratch_bytes((int)z.rows[i + 1], c->conv[i].cout, c->conv[i].k * c->conv[i].cin, 1));
             a.add("tns", need / sizeof(float) + 64);
         }
     }
@@ -98,27 +121,49 @@ Arena make_arena(const SolaCtx* c, const Plan& p) {
 
 }  // namespace
 
-size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p) { return make_arena(c, p).total; }
+size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p) { return make_arena(c, sizes_of(p)).total; }
 
 extern "C" size_t sola_backward_workspace_bytes(const SolaCtx* c, int B, int N, int T, int L) {
     if (!c || B <= 0 || N <= 0 || T <= 0 || L < 1) return 0;
     return sola_backward_scratch_bytes(c, make_plan(c, B, N, T, L, true));
 }
 
-extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* d_score_tokens, const void* fwd_workspace,
-                             void* scratch, size_t scratch_bytes, void* stream_) {
+extern "C" size_t sola_backward_ragged_workspace_bytes(const SolaCtx* c, const SolaRaggedBatch* batch) {
+    if (!c || !batch) return 0;
+    try {
+        RagShape r;
+        if (rag_shape(c, batch, r) != SOLA_OK) return 0;
+        return make_arena(c, sizes_of_ragged(r)).total;
+    } catch (const std::exception& e) {
+        sola_set_error("backward_ragged_workspace_bytes: %s", e.what());
+        return 0;
+    }
+}
+
+// want_rag: the caller is sola_backward_ragged (the last forward must have been sola_forward_train_ragged, in this workspace)
+static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_score_tokens, const void* fwd_workspace,
+                         void* scratch, size_t scratch_bytes, void* stream_, bool want_rag) {
     SOLA_ARG(c && d_score_map && d_score_tokens && fwd_workspace && scratch, "backward: null argument");
     const Plan& p = c->last;
     if (!p.train || p.M == 0) {
-        sola_set_error("backward: the last forward on this context was not sola_forward_train");
+        sola_set_error("backward: the last forward on this context was not sola_forward_train%s", want_rag ? "_ragged" : "");
         return SOLA_ERR_STATE;
     }
+    if (p.rag != want_rag) {
+        sola_set_error("backward: the last training forward was %s - call %s", p.rag ? "ragged" : "uniform", p.rag ? "sola_backward_ragged" : "sola_backward");
+        return SOLA_ERR_STATE;
+    }
+    if (p.rag && fwd_workspace != c->last_ws) {
+        sola_set_error("backward_ragged: not the workspace of the last sola_forward_train_ragged (its unit tables live there)");
+        return SOLA_ERR_STATE;
+    }
+    const RagTables* const rt = p.rag ? &c->last_rag : nullptr;
     for (const Weight& w : c->weights)
         if (!w.grad && w.name != "positional_encoding_gaussian_matrix") {
             sola_set_error("backward: no gradient buffer registered for '%s'", w.name.c_str());
             return SOLA_ERR_WEIGHT;
         }
-    Arena ar = make_arena(c, p);
+    Arena ar = make_arena(c, rt ? sizes_of_ragged(*rt) : sizes_of(p));
     if (scratch_bytes < ar.total) {
         sola_set_error("backward: scratch %zu bytes < required %zu", scratch_bytes, ar.total);
         return SOLA_ERR_WORKSPACE;
@@ -132,7 +177,10 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     auto G = [&](const std::string& name) { return ctx_grad(c, name); };
     const int B = p.B, N = p.N, Tp = p.Tp, M = p.M, Wn = p.W, L = p.L;
     const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
-    const int R = B * N;
+    const int R = rt ? rt->NT : B * N;                    // tracks
+    const int BW = rt ? (int)rt->LW : B * Wn;             // text ++ negative rows
+    const int n_bt = rt ? rt->sumTpS : B * Tp;            // inter-object units (one per sample and encoded step)
+    const int max_rows_smp = rt ? rt->maxRowsSample : N * Tp;
     const float scale = 1.0f / sqrtf((float)DH);
     float* tn = ar.get("tn");
     const size_t tn_bytes = ar.total - ar.off.at("tn");  // upper bound; launch_gemm_tn checks its own need
@@ -242,9 +290,10 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     };
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
-                      int leaky, const DropoutCfg* drop) -> int {
+                      int leaky, const DropoutCfg* drop, const int4* units = nullptr) -> int {
         GroupNormBwdDesc d{};
         if (drop) d.drop = *drop;
+        d.units = units;
         d.x = xpre; d.dy = dy; d.dy2 = dy2; d.gamma = W(wname + ".weight"); d.beta = W(wname + ".bias"); d.dx = dx;
         d.dgamma_part = ar.get("gpart"); d.dbeta_part = ar.get("bpart");
         d.n_inst = n_inst; d.inner = inner; d.outer_stride = outer; d.inner_stride = inner_stride; d.tok_stride = tok_stride;
@@ -269,8 +318,10 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     c->bucket_recorded = false;
     {
         HeadBwdDesc d{fb(last), fb("lbar"), d_score_map, d_score_tokens, gbuf[cur], ar.get("dlbar_part"), B, N, Tp, D};
+        if (rt) { d.B = 1; d.N = R; d.units = rt->u_strk; }
         SOLA_TRY(launch_score_head_bwd(d, s));
-        SOLA_TRY(launch_colsum(ar.get("dlbar_part"), ar.get("dlbar"), B, N, D, D, 1.f, 0, nullptr, 0, s));
+        if (rt) SOLA_TRY(launch_segsum_rows(ar.get("dlbar_part"), ar.get("dlbar"), rt->trk_off, B, D, s));
+        else SOLA_TRY(launch_colsum(ar.get("dlbar_part"), ar.get("dlbar"), B, N, D, D, 1.f, 0, nullptr, 0, s));
     }
     float* dres = ar.get("dres");
     float* dattn = ar.get("dattn");
@@ -302,12 +353,13 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         // (iii) object -> language: x_o2l = GN2(x_mot + attn(q(x_mot), k(lang), v(lang)) Wo)
         {
             const std::string an = lp + "object2lang_attn";
-            SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, N * Tp, D,
-                            c->cfg.n_groups_module, 0, nullptr));
+            SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, max_rows_smp, D,
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr));
             SOLA_TRY(out_proj_bwd(2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
-                           B, H, DH, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
+                           B, H, DH, max_rows_smp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
+            if (rt) { ad.q_units = rt->u_smp; ad.k_units = rt->u_langk; }
             ad.drop = c->attn_drop(l, 2);
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
@@ -317,31 +369,32 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             const WG wq[1] = {{dqkv, x_mot, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")}};
             bool rmq;
             SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr, &rmq));
-            SOLA_TRY(stats(dlkv, 2 * D, B * Wn, 2 * D, 6, &sckv));
+            SOLA_TRY(stats(dlkv, 2 * D, BW, 2 * D, 6, &sckv));
             if (sckv) {
                 SOLA_TRY(bias_from_stats(0, D, G(an + ".k_proj.bias")));
                 SOLA_TRY(bias_from_stats(D, D, G(an + ".v_proj.bias")));
             }
             const WG wkv[2] = {{dlkv, fb("lang"), G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                                {dlkv + D, fb("lang"), G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
-            SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, B * Wn, D, D, sckv, sckv != nullptr));
+            SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, BW, D, D, sckv, sckv != nullptr));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, D, 0));
             SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur], scq, rmq));  // d x_mot = dres + dq Wq
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 2 * D, D));
-            SOLA_TRY(grad_x(dlkv, 2 * D, B * Wn, 2 * D, D, dlang_init ? dlang : nullptr, dlang, sckv));  // accumulate over layers
+            SOLA_TRY(grad_x(dlkv, 2 * D, BW, 2 * D, D, dlang_init ? dlang : nullptr, dlang, sckv));  // accumulate over layers
             dlang_init = true;
             cur = 1 - cur;
         }
         // (ii) motion: x_mot = GN1(x_obj + attn(q(x_obj+pe), k(x_obj+pe), v(x_obj)) Wo)
         {
             const std::string an = lp + "motion_attn";
-            SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, B * N, 1, Tp, 0, 1, Tp, D,
-                            c->cfg.n_groups_module, 0, nullptr));
+            SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, R, 1, Tp, 0, 1, Tp, D,
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr));
             SOLA_TRY(out_proj_bwd(1));
             AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
-                           B * N, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
+                           R, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
+            if (rt) ad.q_units = rt->u_strk;
             ad.drop = c->attn_drop(l, 1);
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
@@ -368,12 +421,13 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         // (i) inter-object: x_obj = GN0(xin + attn(q,k,v(xin)) Wo); x_obj also feeds x_obj + pe
         {
             const std::string an = lp + "obj_attn";
-            SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, D,
-                            c->cfg.n_groups_module, 0, nullptr));
+            SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr));
             SOLA_TRY(out_proj_bwd(0));
             AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
-                           B * Tp, H, DH, N, N, Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
+                           n_bt, H, DH, N, N, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
+            if (rt) ad.q_units = rt->u_st;
             ad.drop = c->attn_drop(l, 0);
             SOLA_TRY(launch_attention_bwd(ad, s));
             float* sc3;
@@ -398,7 +452,8 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     }
 
     // ---- negative tokens: rows L.. of d(lang ++ neg) from the k/v projections + the mean-over-W of the score head
-    SOLA_TRY(launch_neg_token_grad(dlang, ar.get("dlbar"), nullptr, G("negative_token.weight"), B, L, c->cfg.n_negative, D, s));
+    SOLA_TRY(launch_neg_token_grad(dlang, ar.get("dlbar"), nullptr, G("negative_token.weight"), B, L, c->cfg.n_negative, D, s,
+                                   rt ? rt->u_lang : nullptr));
     SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1], s));  // layer 0 + negative tokens
 
     // ---- encoder ----------------------------------------------------------------------------------------------
@@ -417,7 +472,9 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         const ConvGeom& g = c->conv[i];
         const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
         const int t_in = i == 0 ? p.T : p.Tl[i - 1];
-        const int rows = R * p.Tl[i];
+        const int rows = rt ? (int)rt->rows[i + 1] : R * p.Tl[i];
+        const long long rows_in = rt ? rt->rows[i] : (long long)R * t_in;
+        const int2* const rowmap = (rt && g.k > 1) ? rt->rowmap[i] : nullptr;
         const float* x_in = i == 0 ? nullptr : fb("act" + std::to_string(i - 1));
         // dW_std[cout][k*cin] = dY^T im2col(x_in), db
         float* scc = nullptr;  // scale slot of this layer's dY (shared by its dW and dX GEMMs)
@@ -429,6 +486,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
+            d.rowmap = rowmap;
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
             if (scc) SOLA_TRY(bias_from_stats(0, g.cout, G(cp + ".bias")));
@@ -438,6 +496,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             d.A = dy; d.B = i == 0 ? c->last_obj : x_in; d.C = dwstd + ws_off[i]; d.bias_grad = G(cp + ".bias");
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
+            d.rowmap = rowmap;
             d.scratch = tn; d.scratch_bytes = tn_bytes;
             SOLA_TRY(launch_gemm_tn(d, s));
         }
@@ -445,7 +504,11 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         // d act_{i-1}[(r, ti)][ci] = sum_{kk, co} dY[(r, to)][co] w_std[co][kk][ci]: the NT kernel with the transposed-conv
         // gather over dY and the weights re-laid-out to [cin][kk*cout + co]
         float* dact = enc[0];
-        if (split && g.cout % 128 == 0 && g.cin % 8 == 0 && (size_t)rows * g.cout <= std::max((size_t)M, (size_t)B * Wn) * 3 * D) {
+        auto col2im = [&](const float* zc) -> int {
+            if (rt) return launch_col2im_ragged(zc, dact, rows_in, rt->imap[i - 1], g.cin, g.k, g.stride, g.pad, s);
+            return launch_col2im(zc, dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s);
+        };
+        if (split && g.cout % 128 == 0 && g.cin % 8 == 0 && (size_t)rows * g.cout <= std::max((size_t)M, (size_t)BW) * 3 * D) {
             // split-f16: z[(r,to)][kk*cin+ci] = sum_co dY[(r,to)][co] w_std[co][kk*cin+ci] in ONE NT GEMM over the output steps (a
             // strided conv's gather form would multiply zeros for every skipped step), then the k taps are gathered into dX
             float* scal = scc ? scc : ar.get("scal");
@@ -459,7 +522,18 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
             d.M = rows; d.N = g.k * g.cin; d.K = g.cout; d.lda = g.cout; d.ldc = g.k * g.cin;
             d.arith = lowp_arith; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
             SOLA_TRY(launch_gemm(d, s));
-            if (g.k > 1) SOLA_TRY(launch_col2im(ar.get("zcol"), dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s));
+            if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
+        } else if (rt) {
+            // ragged, exact f32: the same decomposition - z = dY W over the OUTPUT rows (a plain GEMM on the concatenated rows, half
+            // the products of the gather form for the stride-2 convs), then the taps are gathered per sequence
+            SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i], wt, g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0, s));  // wt [k*cin][cout]
+            GemmDesc d{};
+            d.nprob = 1;
+            d.p[0] = GemmProblem{dy, wt, nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
+            d.M = rows; d.N = g.k * g.cin; d.K = g.cout; d.lda = g.cout; d.ldc = g.k * g.cin;
+            d.splitk_ws = splitk_ws; d.splitk_bytes = splitk_bytes;
+            SOLA_TRY(launch_gemm(d, s));
+            if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
         } else {
         for (int kk = 0; kk < g.k; ++kk)
             SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, wt, g.cout, g.cin, g.k * g.cin,
@@ -478,7 +552,7 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
         const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i - 1]);
         const DropoutCfg edrop = c->enc_drop(i - 1);
         SOLA_TRY(gn_bwd(fb("conv" + std::to_string(i - 1)), dact, nullptr, np, enc[1], R, 1, t_in, 0, 1, t_in, g.cin,
-                        c->cfg.n_groups, 1, &edrop));
+                        c->cfg.n_groups, 1, &edrop, rt ? rt->u_lvl[i] : nullptr));
         dy = enc[1];  // dact (enc[0]) is consumed; the next stage's dX may overwrite it, its GN backward overwrites enc[1]
     }
     // weight-standardisation backward for all six convs
@@ -493,6 +567,26 @@ extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* 
     SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers], s));  // encoder
     c->bucket_recorded = true;
     return SOLA_OK;
+}
+
+extern "C" int sola_backward(SolaCtx* c, const float* d_score_map, const float* d_score_tokens, const void* fwd_workspace,
+                             void* scratch, size_t scratch_bytes, void* stream_) {
+    try {
+        return backward_impl(c, d_score_map, d_score_tokens, fwd_workspace, scratch, scratch_bytes, stream_, false);
+    } catch (const std::exception& e) {
+        sola_set_error("backward: %s", e.what());
+        return SOLA_ERR_ARG;
+    }
+}
+
+extern "C" int sola_backward_ragged(SolaCtx* c, const float* d_score_map, const float* d_score_tokens, const void* fwd_workspace,
+                                    void* scratch, size_t scratch_bytes, void* stream_) {
+    try {
+        return backward_impl(c, d_score_map, d_score_tokens, fwd_workspace, scratch, scratch_bytes, stream_, true);
+    } catch (const std::exception& e) {
+        sola_set_error("backward_ragged: %s", e.what());
+        return SOLA_ERR_ARG;
+    }
 }
 
 extern "C" int sola_grad_bucket_count(const SolaCtx* c) { return c ? c->n_buckets() : 0; }

@@ -18,7 +18,22 @@ struct GnBwdArgs {
     float eps, slope;
     int leaky;
     DropoutCfg drop;
+    const int4* units;  // ragged batches: (first row, row stride, token count, -) per instance (GroupNormBwdDesc::units)
 };
+
+// token set of instance `inst` (norm.hip: gn_unit)
+struct GnBwdUnit { long long row0, tok_stride; int ntok; };
+__device__ __forceinline__ GnBwdUnit gn_bwd_unit(const GnBwdArgs& a, int inst) {
+    GnBwdUnit u;
+    if (a.units) {
+        const int4 d = a.units[inst];
+        u.row0 = d.x; u.tok_stride = d.y; u.ntok = d.z;
+    } else {
+        u.row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+        u.tok_stride = a.tok_stride; u.ntok = a.ntok;
+    }
+    return u;
+}
 
 __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) {
     __shared__ float red[4];
@@ -28,22 +43,24 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
     const int tpp = 256 / lpt;
     const int tl = threadIdx.x / lpt;
     const int c4 = threadIdx.x - tl * lpt;
-    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const GnBwdUnit un = gn_bwd_unit(a, inst);
+    const long long row0 = un.row0, tok_stride = un.tok_stride;
+    const int ntok = un.ntok;
     const int ch = g * a.cg + c4 * 4;
     const bool active = tl < tpp;
-    const float cnt = (float)a.ntok * (float)a.cg;
+    const float cnt = (float)ntok * (float)a.cg;
 
     float s = 0.f;
     if (active)
-        for (int t = tl; t < a.ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+        for (int t = tl; t < ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
             s += (v.x + v.y) + (v.z + v.w);
         }
     const float mean = block_sum_256(s, red) / cnt;
     float q = 0.f;
     if (active)
-        for (int t = tl; t < a.ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * a.tok_stride) * a.C + ch);
+        for (int t = tl; t < ntok; t += tpp) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
             const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -78,8 +95,8 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
     float s1 = 0.f, s2 = 0.f;
     float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
     if (active)
-        for (int t = tl; t < a.ntok; t += tpp) {
-            const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+        for (int t = tl; t < ntok; t += tpp) {
+            const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
             const float4 v = *reinterpret_cast<const float4*>(a.x + off);
             const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
             const float4 d = grad_in(off, xh);
@@ -108,8 +125,8 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
         *reinterpret_cast<float4*>(a.dbp + o) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     if (!active) return;
-    for (int t = tl; t < a.ntok; t += tpp) {
-        const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+    for (int t = tl; t < ntok; t += tpp) {
+        const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
         const float4 v = *reinterpret_cast<const float4*>(a.x + off);
         const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
         const float4 d = grad_in(off, xh);
@@ -153,19 +170,21 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
     const int inst = (int)(unit / groups), g = (int)(unit - (long long)inst * groups);
     const int tpp = nthr / f4;
     const int tl = tid / f4, c4 = tid - tl * f4;
-    const long long row0 = (long long)(inst / a.inner) * a.outer_stride + (long long)(inst % a.inner) * a.inner_stride;
+    const GnBwdUnit un = gn_bwd_unit(a, inst);
+    const long long row0 = un.row0, tok_stride = un.tok_stride;
+    const int ntok = un.ntok;
     const int ch = g * a.cg + c4 * 4;
-    const float cnt = (float)a.ntok * (float)a.cg;
+    const float cnt = (float)ntok * (float)a.cg;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 xv[R], dv[R];
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
-        const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
-        xv[r] = t < a.ntok ? *reinterpret_cast<const float4*>(a.x + off) : z;
-        dv[r] = t < a.ntok ? *reinterpret_cast<const float4*>(a.dy + off) : z;
-        if (a.dy2 && t < a.ntok) {
+        const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
+        xv[r] = t < ntok ? *reinterpret_cast<const float4*>(a.x + off) : z;
+        dv[r] = t < ntok ? *reinterpret_cast<const float4*>(a.dy + off) : z;
+        if (a.dy2 && t < ntok) {
             const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
             dv[r].x += e.x; dv[r].y += e.y; dv[r].z += e.z; dv[r].w += e.w;
         }
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (tl + r * tpp < a.ntok) {
+        if (tl + r * tpp < ntok) {
             const float d0 = xv[r].x - mean, d1 = xv[r].y - mean, d2 = xv[r].z - mean, d3 = xv[r].w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -188,8 +207,8 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
-        if (t < a.ntok) {
-            const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+        if (t < ntok) {
+            const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
             const float4 xh = make_float4((xv[r].x - mean) * rstd, (xv[r].y - mean) * rstd, (xv[r].z - mean) * rstd, (xv[r].w - mean) * rstd);
             float4 d = dv[r];
             if (a.drop.enabled) {  // y = dropout(lrelu(gn(x))): the mask is regenerated from the element index
@@ -245,8 +264,8 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
-        if (t < a.ntok) {
-            const long long off = (row0 + (long long)t * a.tok_stride) * a.C + ch;
+        if (t < ntok) {
+            const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
             *reinterpret_cast<float4*>(a.dx + off) = make_float4(rstd * (dv[r].x - m1 - xv[r].x * m2), rstd * (dv[r].y - m1 - xv[r].y * m2),
                                                                  rstd * (dv[r].z - m1 - xv[r].z * m2), rstd * (dv[r].w - m1 - xv[r].w * m2));
         }
@@ -326,6 +345,7 @@ struct HeadBwdArgs {
     const float *x, *lbar, *d_score, *d_tok;
     float *dx, *dlbar_part;
     int N, Tp, D;
+    const int4* units;  // ragged batches: (first row, -, T', sample) per track (HeadBwdDesc::units); Tp = the largest T'
 };
 
 __global__ __launch_bounds__(256) void score_head_bwd_kernel(const HeadBwdArgs a) {
@@ -334,15 +354,21 @@ __global__ __launch_bounds__(256) void score_head_bwd_kernel(const HeadBwdArgs a
     float* aw = sh;             // softmax weights a_t
     float* da = sh + tp4;       // da_t, then dlogit_t
     float* red = sh + 2 * tp4;  // 4
-    const int bn = blockIdx.x, b = bn / a.N;
+    const int bn = blockIdx.x;
+    int b = bn / a.N, Tp = a.Tp;
+    long long row0 = (long long)bn * a.Tp;
+    if (a.units) {
+        const int4 u = a.units[bn];
+        row0 = u.x; Tp = u.z; b = u.w;
+    }
     const int d4n = a.D >> 2;
-    const float4* xb = reinterpret_cast<const float4*>(a.x + (long long)bn * a.Tp * a.D);
+    const float4* xb = reinterpret_cast<const float4*>(a.x + row0 * a.D);
     const float4* lb = reinterpret_cast<const float4*>(a.lbar + (long long)b * a.D);
     const float4* dt = reinterpret_cast<const float4*>(a.d_tok + (long long)bn * a.D);
     const float ds = a.d_score[bn];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // logits_t = x_t . lbar ; da_t = dtok . x_t with dtok = d_tok + ds * lbar
-    for (int t = wave; t < a.Tp; t += 4) {
+    for (int t = wave; t < Tp; t += 4) {
         float s = 0.f, u = 0.f;
         for (int i = lane; i < d4n; i += 64) {
             const float4 xv = xb[(long long)t * d4n + i], lv = lb[i], gv = dt[i];
@@ -355,25 +381,25 @@ __global__ __launch_bounds__(256) void score_head_bwd_kernel(const HeadBwdArgs a
     }
     __syncthreads();
     float mx = -INFINITY;
-    for (int t = 0; t < a.Tp; ++t) mx = fmaxf(mx, aw[t]);
+    for (int t = 0; t < Tp; ++t) mx = fmaxf(mx, aw[t]);
     float den = 0.f;
-    for (int t = 0; t < a.Tp; ++t) den += expf(aw[t] - mx);
+    for (int t = 0; t < Tp; ++t) den += expf(aw[t] - mx);
     float sada = 0.f;
-    for (int t = 0; t < a.Tp; ++t) sada += (expf(aw[t] - mx) / den) * da[t];
+    for (int t = 0; t < Tp; ++t) sada += (expf(aw[t] - mx) / den) * da[t];
     __syncthreads();
-    for (int t = threadIdx.x; t < a.Tp; t += 256) {
+    for (int t = threadIdx.x; t < Tp; t += 256) {
         const float w = expf(aw[t] - mx) / den;
         aw[t] = w;
         da[t] = w * (da[t] - sada);  // dlogit_t
     }
     __syncthreads();
-    float4* dxo = reinterpret_cast<float4*>(a.dx + (long long)bn * a.Tp * a.D);
+    float4* dxo = reinterpret_cast<float4*>(a.dx + row0 * a.D);
     float4* dlb = reinterpret_cast<float4*>(a.dlbar_part + (long long)bn * a.D);
     for (int i = threadIdx.x; i < d4n; i += 256) {
         const float4 lv = lb[i], gv = dt[i];
         const float4 dtok = make_float4(gv.x + ds * lv.x, gv.y + ds * lv.y, gv.z + ds * lv.z, gv.w + ds * lv.w);
         float4 tok = make_float4(0.f, 0.f, 0.f, 0.f), acc = tok;
-        for (int t = 0; t < a.Tp; ++t) {
+        for (int t = 0; t < Tp; ++t) {
             const float w = aw[t], dl = da[t];
             const float4 xv = xb[(long long)t * d4n + i];
             tok.x += w * xv.x; tok.y += w * xv.y; tok.z += w * xv.z; tok.w += w * xv.w;
@@ -396,6 +422,7 @@ struct LossBwdArgs {
     float pos_w, temp_scale, align_w;
     const float* g3;
     float *d_score, *d_tok, *coef;
+    const int32_t* trk_off;  // ragged batches (LossBwdDesc::trk_off): tracks of sample b = trk_off[b] .. trk_off[b + 1], g3 is [B][3]
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -405,7 +432,20 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossBwdArgs a) {
     float* negl = sh;  // [n_neg] logits, then coefficients
     float* red = sh + ((a.n_neg + 3) & ~3);
     float* sc = red + 4;  // [2]: dpos coefficient
-    const int bn = blockIdx.x, b = bn / a.N;
+    const int bn = blockIdx.x;
+    int b = bn / a.N, count = a.B * a.N;  // the means run over all B*N tracks, or - ragged - over the sample's own
+    const float* g3 = a.g3;
+    if (a.trk_off) {
+        int lo = 0, hi = a.B - 1;  // largest b with trk_off[b] <= bn
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.trk_off[mid] <= bn) lo = mid;
+            else hi = mid - 1;
+        }
+        b = lo;
+        count = a.trk_off[b + 1] - a.trk_off[b];
+        g3 = a.g3 + 3 * b;
+    }
     const int d4n = a.D >> 2;
     const float4* tok = reinterpret_cast<const float4*>(a.score_tokens + (long long)bn * a.D);
     const float4* pos = reinterpret_cast<const float4*>(a.pos + (long long)b * a.D);
@@ -429,11 +469,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossBwdArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float bn_count = (float)a.B * (float)a.N;
+        const float bn_count = (float)count;
         const float y = a.labels[bn], x = a.score_map[bn];
         const float w = y > 0.f ? a.pos_w : 1.f;
-        const float cb = a.g3[0] + a.g3[1];               // d total / d bce
-        const float ca = a.g3[0] * a.align_w + a.g3[2];   // d total / d align
+        const float cb = g3[0] + g3[1];               // d total / d bce
+        const float ca = g3[0] * a.align_w + g3[2];   // d total / d align
         a.d_score[bn] = cb * w * (sigmoidf_(x) - y) / bn_count;
         int arg = 0;
         float best = negl[0];
@@ -464,14 +504,17 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossBwdArgs a) {
 
 // d_neg[b][m][:] = sum_n coef[b,n,m] * tok[b,n,:]
 __global__ __launch_bounds__(256) void loss_dneg_kernel(const float* __restrict__ coef, const float* __restrict__ tok,
-                                                        float* __restrict__ d_neg, int N, int D, int n_neg) {
+                                                        float* __restrict__ d_neg, int N, int D, int n_neg,
+                                                        const int32_t* __restrict__ trk_off) {
     const int b = blockIdx.x / n_neg, m = blockIdx.x % n_neg;
     const int d4n = D >> 2;
+    const long long first = trk_off ? trk_off[b] : (long long)b * N;
+    if (trk_off) N = trk_off[b + 1] - trk_off[b];
     for (int i = threadIdx.x; i < d4n; i += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int n = 0; n < N; ++n) {
-            const float cf = coef[((long long)b * N + n) * n_neg + m];
-            const float4 v = reinterpret_cast<const float4*>(tok + ((long long)b * N + n) * D)[i];
+            const float cf = coef[(first + n) * n_neg + m];
+            const float4 v = reinterpret_cast<const float4*>(tok + (first + n) * D)[i];
             acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
         }
         reinterpret_cast<float4*>(d_neg + ((long long)b * n_neg + m) * D)[i] = acc;
@@ -481,15 +524,22 @@ __global__ __launch_bounds__(256) void loss_dneg_kernel(const float* __restrict_
 // d_negw[m][:] = sum_b ( d_lang[b, L+m, :] + dlbar[b, :] / W + d_neg_align[b, m, :] )
 __global__ __launch_bounds__(256) void neg_token_grad_kernel(const float* __restrict__ d_lang, const float* __restrict__ dlbar,
                                                              const float* __restrict__ d_neg_align, float* __restrict__ out,
-                                                             int B, int L, int n_neg, int D) {
+                                                             int B, int L, int n_neg, int D, const int4* __restrict__ units) {
     const int m = blockIdx.x;
-    const int W = L + n_neg;
-    const float invw = 1.f / (float)W;
+    int W = L + n_neg;
+    float invw = 1.f / (float)W;
     for (int i = threadIdx.x; i < (D >> 2); i += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int b = 0; b < B; ++b) {
+            long long neg_row = (long long)b * W + L + m;
+            if (units) {  // ragged: sample b has units[b] = (-, L_b, first row of its text ++ negatives, W_b)
+                const int4 u = units[b];
+                neg_row = (long long)u.z + u.y + m;
+                W = u.w;
+                invw = 1.f / (float)W;
+            }
             if (d_lang) {
-                const float4 v = reinterpret_cast<const float4*>(d_lang + ((long long)b * W + L + m) * D)[i];
+                const float4 v = reinterpret_cast<const float4*>(d_lang + neg_row * D)[i];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             if (dlbar) {
@@ -505,7 +555,30 @@ __global__ __launch_bounds__(256) void neg_token_grad_kernel(const float* __rest
     }
 }
 
+// out[seg][c] = sum of in[r][c] over r in [off[seg], off[seg + 1]): the per-sample sums of the per-track partials of a ragged
+// batch (fixed order)
+__global__ __launch_bounds__(256) void segsum_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          const int32_t* __restrict__ off, int cols) {
+    const int seg = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = off[seg], r1 = off[seg + 1];
+    float s0 = 0.f, s1 = 0.f;
+    int r = r0;
+    for (; r + 1 < r1; r += 2) { s0 += in[(long long)r * cols + c]; s1 += in[(long long)(r + 1) * cols + c]; }
+    if (r < r1) s0 += in[(long long)r * cols + c];
+    out[(long long)seg * cols + c] = s0 + s1;
+}
+
 }  // namespace
+
+int launch_segsum_rows(const float* in, float* out, const int32_t* off, int segments, int cols, hipStream_t s) {
+    SOLA_ARG(in && out && off && segments > 0 && segments <= 65535 && cols > 0, "segsum_rows: bad arguments");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 0);
+    hipLaunchKernelGGL(segsum_rows_kernel, dim3((cols + 255) / 256, segments), dim3(256), 0, s, in, out, off, cols);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 int g_gn_bwd_reg = 1;  // sola_tune "gn_bwd_reg": 0 = three-pass kernel for every shape (A/B)
 void sola_gn_set_bwd_reg(int v) { g_gn_bwd_reg = v; }
@@ -518,7 +591,7 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     GnBwdArgs a;
     a.x = d.x; a.dy = d.dy; a.dy2 = d.dy2; a.gamma = d.gamma; a.beta = d.beta; a.dx = d.dx; a.dgp = d.dgamma_part; a.dbp = d.dbeta_part;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
-    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop;
+    a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.units = d.units;
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
     const int f4 = cg / 4;
@@ -567,7 +640,7 @@ int launch_ws_backward(const WsBwdLayer* layers, int n_layers, hipStream_t s) {
 
 int launch_score_head_bwd(const HeadBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.Tp > 0, "score_head_bwd: bad sizes");
-    HeadBwdArgs a{d.x, d.lbar, d.d_score, d.d_tok, d.dx, d.dlbar_part, d.N, d.Tp, d.D};
+    HeadBwdArgs a{d.x, d.lbar, d.d_score, d.d_tok, d.dx, d.dlbar_part, d.N, d.Tp, d.D, d.units};
     const size_t lds = (2 * (((size_t)d.Tp + 3) & ~(size_t)3) + 4) * sizeof(float);
     SOLA_ARG(lds <= 60000, "score_head_bwd: T'=%d too long", d.Tp);
     const double elems = (double)d.B * d.N * d.Tp * d.D;
@@ -580,23 +653,25 @@ int launch_score_head_bwd(const HeadBwdDesc& d, hipStream_t s) {
 int launch_loss_bwd(const LossBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.D % 4 == 0 && d.B > 0 && d.N > 0 && d.n_neg > 0 && d.n_neg < 8192, "loss_bwd: bad sizes");
     LossBwdArgs a{d.score_map, d.score_tokens, d.labels, d.pos, d.neg, d.neg_batch_stride, d.B, d.N, d.D, d.n_neg,
-                  d.pos_w, d.temp_scale, d.align_w, d.g3, d.d_score, d.d_tok, d.coef};
+                  d.pos_w, d.temp_scale, d.align_w, d.g3, d.d_score, d.d_tok, d.coef, d.trk_off};
     const size_t lds = ((((size_t)d.n_neg + 3) & ~(size_t)3) + 8) * sizeof(float);
     SolaProfScope prof(SOLA_PROF_HEAD, s, 4.0 * d.B * d.N * (double)d.D * (d.n_neg + 1), 8.0 * d.B * d.N * (double)d.D);
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(d.B * d.N), dim3(256), lds, s, a);
+    // ragged: d.N = the largest track count (unused by the kernels), the grid covers the concatenated tracks
+    const unsigned n_trk = d.trk_off ? (unsigned)d.total_tracks : (unsigned)(d.B * d.N);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(n_trk), dim3(256), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (d.d_neg) {
-        hipLaunchKernelGGL(loss_dneg_kernel, dim3(d.B * d.n_neg), dim3(256), 0, s, d.coef, d.score_tokens, d.d_neg, d.N, d.D, d.n_neg);
+        hipLaunchKernelGGL(loss_dneg_kernel, dim3(d.B * d.n_neg), dim3(256), 0, s, d.coef, d.score_tokens, d.d_neg, d.N, d.D, d.n_neg, d.trk_off);
         SOLA_LAUNCH_CHECK();
     }
     return SOLA_OK;
 }
 
 int launch_neg_token_grad(const float* d_lang, const float* dlbar, const float* d_neg_align, float* d_negw, int B, int L,
-                          int n_neg, int D, hipStream_t s) {
+                          int n_neg, int D, hipStream_t s, const int4* units) {
     SOLA_ARG(d_negw && B > 0 && n_neg > 0 && D % 4 == 0, "neg_token_grad: bad arguments");
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 12.0 * B * n_neg * (double)D);
-    hipLaunchKernelGGL(neg_token_grad_kernel, dim3(n_neg), dim3(256), 0, s, d_lang, dlbar, d_neg_align, d_negw, B, L, n_neg, D);
+    hipLaunchKernelGGL(neg_token_grad_kernel, dim3(n_neg), dim3(256), 0, s, d_lang, dlbar, d_neg_align, d_negw, B, L, n_neg, D, units);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

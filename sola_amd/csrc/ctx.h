@@ -23,6 +23,7 @@ struct Plan {
     int B = 0, N = 0, T = 0, L = 0, W = 0, Tp = 0, M = 0;
     int Tl[6] = {0};
     bool train = false;
+    bool rag = false;  // ragged training batch: B = samples, N / T / L / W / Tl / Tp = the LARGEST extents, M = all layer rows
     std::unordered_map<std::string, Buf> bufs;
     size_t total = 0;
     size_t add(const std::string& name, int64_t rows, int64_t cols) {
@@ -31,6 +32,28 @@ struct Plan {
         total += (((size_t)rows * (size_t)cols * sizeof(float)) + 255) & ~(size_t)255;
         return off;
     }
+};
+
+// Ragged batches (ragged.h): device tables (pointers into the caller's workspace) + the host-side extents the launchers need.
+// The context keeps the set of the last ragged training forward for its backward.
+struct RagTables {
+    const int4* u_lvl[7] = {nullptr};   // [NT] per encoder level: (first row, 1, T_level, video) of every track
+    const int2* rowmap[5] = {nullptr};  // conv l, per OUTPUT row (level l + 1): (source row of tap 0, tap-validity bits)
+    const int4* imap[5] = {nullptr};    // training only: conv l + 1's INPUT rows (level l + 1, l = 0..4): (first output row of the
+                                        // row's sequence, T_out, step ti inside the sequence, -) - the col2im gather of the conv dX
+    const int4* u_vt = nullptr;         // [sum T'_v]  (first row, T'_v, N_v, t')  inter-object units per video
+    const int4* u_st = nullptr;         // [sum T'_i]  ... per sample
+    const int4* u_strk = nullptr;       // [sum N_i]   (first row, 1, T', sample)  tracks of the samples
+    const int4* u_smp = nullptr;        // [S]         (first row, 1, N*T', sample)
+    const int4* u_lang = nullptr;       // [S]         (first input text row, L, first lang_cat row, W)
+    const int4* u_langk = nullptr;      // [S]         (first lang_cat row, 1, W, 0)
+    const int4* u_gather = nullptr;     // [S]         (first sample row, first video row at T', rows, 0)
+    const int32_t* trk_off = nullptr;   // [S + 1]     first track of every sample
+    // host-side extents
+    int V = 0, S = 0, NT = 0, sumNS = 0, sumTpV = 0, sumTpS = 0;
+    int maxN = 0, maxT[7] = {0}, maxW = 0, maxRowsSample = 0;
+    long long rows[7] = {0}, Mv = 0, Ms = 0, LW = 0, Lin = 0;
+    bool identity = false;
 };
 
 struct SolaRagStage;  // pinned staging ring of the ragged forward's descriptor upload (forward_ragged.hip)
@@ -48,6 +71,8 @@ struct SolaCtx {
     bool ws_every_forward = true;
     Plan last;                // plan of the last forward (taps, backward)
     const float* last_obj = nullptr;  // input of the last training forward (conv0's weight gradient reads it)
+    RagTables last_rag;               // last.rag: the unit tables that forward left in its workspace
+    const void* last_ws = nullptr;    // workspace of the last forward (sola_backward_ragged checks it gets the same one)
     // inference precision: 0 = exact f32 MFMA; 1 = split-f16 operands, 3 x f16 MFMA with f32 accumulation (cast.hip).
     // ctx-owned split-f16 copies of the weights: standardised conv weights (same offsets as ws_buf) and the
     // 12 * n_layers linear weights pre-scaled by 64 (index (layer * 3 + attn) * 4 + proj, D*D floats each).
@@ -109,9 +134,11 @@ inline std::string abuf(bool train, int layer, const char* attn, const char* wha
     return "l" + std::to_string(layer) + "_" + attn + "_" + what;
 }
 
+struct RagShape;
 Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train);
+Plan make_plan_ragged(const SolaCtx* c, const RagShape& r, bool train);
 int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
-                      float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train);
+                      float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train, const RagShape* rs = nullptr);
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                            float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s);
 int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,

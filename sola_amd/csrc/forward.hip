@@ -6,10 +6,73 @@
 
 #include <algorithm>
 
-#include "ctx.h"
+#include "ragged.h"
 
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
+
+// Workspace layout shared by the uniform and the ragged plans: only the row counts differ.
+namespace {
+struct PlanSizes {
+    int64_t rows0;      // object-token rows (level 0)
+    int64_t rows[6];    // token rows behind each conv
+    int64_t M, BW;      // layer rows, text ++ negative rows
+    int64_t S;          // samples
+    int64_t gn_slots;   // floats of the sliced GroupNorm shape's scratch
+    size_t tables;      // ragged: bytes of the descriptor / unit-table region (0 = uniform batch)
+};
+void plan_fill(Plan& p, const SolaCtx* c, const PlanSizes& z, bool train) {
+    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads;
+    if (z.tables) p.add("tables", (int64_t)((z.tables + 3) / 4), 1);
+    for (int i = 0; i < 6; ++i) {
+        p.add("conv" + std::to_string(i), z.rows[i], c->conv[i].cout);
+        if (i < 5) p.add("act" + std::to_string(i), z.rows[i], c->conv[i].cout);
+    }
+    // single-sample regime: scratch for the two-pass split-K of the GEMMs whose grid is smaller than the chip (gemm.hip)
+    if (z.M <= 8192) p.add("splitk", 8192, 4096);
+    p.add("pe", p.Tp, D);
+    // slots of the sliced GroupNorm shape (8 bytes per (unit, slice); units of more than 256 tokens at 128 channels per group):
+    // bounded by rows / 11 entries over every norm of the path
+    p.add("gn_slots", z.gn_slots, 1);
+    p.add("lang", z.BW, D);
+    p.add("lbar", z.S, D);
+    if (!train && c->precision >= 1) {  // split-f16 (or f16) copies of the three f32-born GEMM inputs (forward_fast.hip, forward_f16.hip)
+        p.add("obj_sp", z.rows0, c->cfg.object_token_dim);
+        p.add("conv5_sp", z.M, D);
+        p.add("lang_sp", z.BW, D);
+    }
+    if (train && c->precision >= 1 && z.M >= g_train_split_min_rows) {
+        // split-f16 training forward: every GEMM input is cast into one of two scratch buffers right before its launch
+        // (the f32 activations stay where the backward reads them)
+        int64_t amax = std::max<int64_t>(z.rows0 * c->cfg.object_token_dim, std::max<int64_t>(z.M * D, z.BW * D));
+        for (int i = 0; i < 5; ++i) amax = std::max<int64_t>(amax, z.rows[i] * c->conv[i].cout);
+        p.add("sp_a", amax, 1);
+        p.add("sp_b", z.M, D);
+    }
+    const int n_sets = train ? c->cfg.n_layers : 1;
+    for (int l = 0; l < n_sets; ++l)
+        for (int a = 0; a < (train ? 3 : 1); ++a) {
+            p.add(abuf(train, l, kAttnShort[a], "q"), z.M, D);
+            if (!train || a < 2) {
+                p.add(abuf(train, l, kAttnShort[a], "k"), z.M, D);
+                p.add(abuf(train, l, kAttnShort[a], "v"), z.M, D);
+            }
+            p.add(abuf(train, l, kAttnShort[a], "attn"), z.M, D);
+            p.add(abuf(train, l, kAttnShort[a], "res"), z.M, D);
+            if (train) p.add(abuf(train, l, kAttnShort[a], "lse"), z.M, H);
+            if (!train || a == 2) {
+                p.add(abuf(train, l, kAttnShort[a], "lk"), z.BW, D);
+                p.add(abuf(train, l, kAttnShort[a], "lv"), z.BW, D);
+            }
+        }
+    for (int l = 0; l < c->cfg.n_layers; ++l) {
+        p.add("l" + std::to_string(l) + "_obj", z.M, D);
+        p.add("l" + std::to_string(l) + "_xpe", z.M, D);
+        p.add("l" + std::to_string(l) + "_motion", z.M, D);
+        p.add("l" + std::to_string(l) + "_o2l", z.M, D);
+    }
+}
+}  // namespace
 
 Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
     Plan p;
@@ -22,68 +85,49 @@ Plan make_plan(const SolaCtx* c, int B, int N, int T, int L, bool train) {
     }
     p.Tp = p.Tl[5];
     p.M = B * N * p.Tp;
-    const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads;
     const int64_t R = (int64_t)B * N;
-    for (int i = 0; i < 6; ++i) {
-        p.add("conv" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
-        if (i < 5) p.add("act" + std::to_string(i), R * p.Tl[i], c->conv[i].cout);
-    }
-    // single-sample regime: scratch for the two-pass split-K of the GEMMs whose grid is smaller than the chip (gemm.hip)
-    if ((long long)B * N * p.Tp <= 8192) p.add("splitk", 8192, 4096);
-    p.add("pe", p.Tp, D);
-    // slots of the sliced GroupNorm shape (8 bytes per (unit, slice); units of more than 256 tokens at 128 channels per group):
-    // bounded by rows / 11 entries over every norm of the path
-    p.add("gn_slots", std::max<int64_t>(R * T, (int64_t)p.M) / 4 + 1024, 1);
-    p.add("lang", (int64_t)B * p.W, D);
-    p.add("lbar", B, D);
-    if (!train && c->precision >= 1) {  // split-f16 (or f16) copies of the three f32-born GEMM inputs (forward_fast.hip, forward_f16.hip)
-        p.add("obj_sp", R * T, c->cfg.object_token_dim);
-        p.add("conv5_sp", p.M, D);
-        p.add("lang_sp", (int64_t)B * p.W, D);
-    }
-    if (train && c->precision >= 1 && p.M >= g_train_split_min_rows) {
-        // split-f16 training forward: every GEMM input is cast into one of two scratch buffers right before its launch
-        // (the f32 activations stay where the backward reads them)
-        int64_t amax = std::max<int64_t>(R * T * c->cfg.object_token_dim, std::max<int64_t>((int64_t)p.M * D, (int64_t)B * p.W * D));
-        for (int i = 0; i < 5; ++i) amax = std::max<int64_t>(amax, R * p.Tl[i] * c->conv[i].cout);
-        p.add("sp_a", amax, 1);
-        p.add("sp_b", (int64_t)p.M, D);
-    }
-    const int n_sets = train ? c->cfg.n_layers : 1;
-    for (int l = 0; l < n_sets; ++l)
-        for (int a = 0; a < (train ? 3 : 1); ++a) {
-            p.add(abuf(train, l, kAttnShort[a], "q"), p.M, D);
-            if (!train || a < 2) {
-                p.add(abuf(train, l, kAttnShort[a], "k"), p.M, D);
-                p.add(abuf(train, l, kAttnShort[a], "v"), p.M, D);
-            }
-            p.add(abuf(train, l, kAttnShort[a], "attn"), p.M, D);
-            p.add(abuf(train, l, kAttnShort[a], "res"), p.M, D);
-            if (train) p.add(abuf(train, l, kAttnShort[a], "lse"), p.M, H);
-            if (!train || a == 2) {
-                p.add(abuf(train, l, kAttnShort[a], "lk"), (int64_t)B * p.W, D);
-                p.add(abuf(train, l, kAttnShort[a], "lv"), (int64_t)B * p.W, D);
-            }
-        }
-    for (int l = 0; l < c->cfg.n_layers; ++l) {
-        p.add("l" + std::to_string(l) + "_obj", p.M, D);
-        p.add("l" + std::to_string(l) + "_xpe", p.M, D);
-        p.add("l" + std::to_string(l) + "_motion", p.M, D);
-        p.add("l" + std::to_string(l) + "_o2l", p.M, D);
-    }
+    PlanSizes z{};
+    z.rows0 = R * T;
+    for (int i = 0; i < 6; ++i) z.rows[i] = R * p.Tl[i];
+    z.M = p.M; z.BW = (int64_t)B * p.W; z.S = B;
+    z.gn_slots = std::max<int64_t>(R * T, (int64_t)p.M) / 4 + 1024;
+    plan_fill(p, c, z, train);
     return p;
 }
 
+// Plan of a ragged TRAINING batch (sola_forward_train_ragged): the same buffers over the concatenated rows, plus the table
+// region.  B = samples; N, T, L, W, Tl, Tp hold the LARGEST extents (they only select kernel shapes); M = all layer rows.
+Plan make_plan_ragged(const SolaCtx* c, const RagShape& r, bool train) {
+    Plan p;
+    p.rag = true;
+    p.B = r.S; p.N = r.maxN; p.T = r.maxT[0]; p.L = r.maxW - c->cfg.n_negative; p.train = train;
+    p.W = r.maxW;
+    for (int i = 0; i < 6; ++i) p.Tl[i] = r.maxT[i + 1];
+    p.Tp = r.maxT[6];
+    p.M = (int)r.Ms;
+    PlanSizes z{};
+    z.rows0 = r.rows[0];
+    for (int i = 0; i < 6; ++i) z.rows[i] = r.rows[i + 1];
+    z.M = r.Ms; z.BW = r.LW; z.S = r.S;
+    z.gn_slots = (int64_t)(rag_gn_slots_bytes(r) / 4 + 64);
+    z.tables = rag_tables_bytes(r, train);
+    plan_fill(p, c, z, train);
+    return p;
+}
+
+// rs != null: a ragged TRAINING batch (sola_forward_train_ragged) - the token rows of all samples concatenated, every shape-
+// dependent kernel reads the unit tables built here (ragged.h); B, N, T, L are then ignored.
 int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
-                      float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train) {
+                      float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train, const RagShape* rs) {
     SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
-    SOLA_ARG(B > 0 && N > 0 && T > 0 && L >= 1, "forward: bad sizes B=%d N=%d T=%d L=%d", B, N, T, L);
+    if (rs) SOLA_ARG(train && rs->identity, "forward: a ragged training batch has one sample per video (sample_video[i] == i)");
+    else SOLA_ARG(B > 0 && N > 0 && T > 0 && L >= 1, "forward: bad sizes B=%d N=%d T=%d L=%d", B, N, T, L);
     for (const Weight& w : c->weights)
         if (!w.ptr) {
             sola_set_error("forward: weight '%s' has not been set", w.name.c_str());
             return SOLA_ERR_WEIGHT;
         }
-    Plan p = make_plan(c, B, N, T, L, train);
+    Plan p = rs ? make_plan_ragged(c, *rs, train) : make_plan(c, B, N, T, L, train);
     if (ws_bytes < p.total) {
         sola_set_error("forward: workspace %zu bytes < required %zu", ws_bytes, p.total);
         return SOLA_ERR_WORKSPACE;
@@ -96,7 +140,12 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     auto W = [&](const std::string& name) { return ctx_weight(c, name); };
     const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H;
     const int Tp = p.Tp, M = p.M, Wn = p.W;
-    const int R = B * N;
+    if (rs) { B = rs->S; N = rs->maxN; T = rs->maxT[0]; }
+    const int R = rs ? rs->NT : B * N;
+    RagTables rt;  // ragged: unit tables in the workspace (they stay valid for sola_backward_ragged)
+    if (rs) SOLA_TRY(rag_build_tables(c, *rs, base + p.bufs.at("tables").off, true, &rt, s));
+    auto level_rows = [&](int lvl) -> long long { return rs ? rs->rows[lvl] : (long long)R * (lvl == 0 ? T : p.Tl[lvl - 1]); };
+    const long long text_rows = rs ? rs->LW : (long long)B * Wn;
     // training forward in the split-f16 mode (sola_set_precision 1): the same GEMM kernels as forward_fast.hip on casts of
     // the f32 activations, everything the backward reads stays f32
     // (from ~1024 token rows on: below that the step is launch-bound and the extra cast launches cost more than the GEMMs gain)
@@ -153,17 +202,18 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         GemmDesc gd{};
         gd.nprob = 1;
         gd.p[0] = GemmProblem{x, c->ws_buf + c->ws_off[i], W(cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
-        gd.M = R * p.Tl[i]; gd.N = g.cout; gd.K = g.k * g.cin;
+        gd.M = (int)level_rows(i + 1); gd.N = g.cout; gd.K = g.k * g.cin;
         gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
         gd.conv = g.k > 1 ? 1 : 0;
         gd.T_in = t_in; gd.T_out = p.Tl[i]; gd.stride = g.stride; gd.pad = g.pad; gd.Cin = g.cin;
+        if (rs && gd.conv) { gd.rowmap = rt.rowmap[i]; gd.T_in = 1; gd.T_out = 1; }
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split && g.cin % (pure ? 64 : 32) == 0) {
             if (i == 0) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip)
-                SOLA_TRY(cast_auto(x, g.cin, sp_a, (long long)R * t_in, g.cin, c->scal_pair(0)));
+                SOLA_TRY(cast_auto(x, g.cin, sp_a, level_rows(i), g.cin, c->scal_pair(0)));
                 gd.out_scale_dev = c->scal_pair(0) + 1;
             } else {
-                SOLA_TRY(cast_fixed(x, g.cin, sp_a, (long long)R * t_in, g.cin, 1.f));
+                SOLA_TRY(cast_fixed(x, g.cin, sp_a, level_rows(i), g.cin, 1.f));
             }
             gd.p[0].A = sp_a;
             gd.p[0].W = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->ws16_buf) + c->ws_off[i]) : c->ws16_buf + c->ws_off[i];
@@ -178,6 +228,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             nd.gamma = W(np + ".weight"); nd.beta = W(np + ".bias");
             nd.n_inst = R; nd.inner = 1; nd.outer_stride = p.Tl[i]; nd.inner_stride = 0; nd.tok_stride = 1;
             nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
+            if (rs) nd.units = rt.u_lvl[i + 1];
             if (train) nd.drop = c->enc_drop(i);
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
@@ -189,7 +240,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
 
     // a3: positional table; text tokens ++ negative tokens and their mean (module/module.py:143-147)
     SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
-    SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
+    if (rs) SOLA_TRY(launch_lang_concat_ragged(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, rt.u_lang, c->cfg.n_negative, D, s));
+    else SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
 
     // a5: alignment layers (module/module.py:22-52)
     const float scale = 1.0f / sqrtf((float)DH);
@@ -242,7 +294,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         return launch_gemm(gd, s);
     };
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,
-                  long long outer, long long inner_stride, long long tok_stride, int ntok) -> int {
+                  long long outer, long long inner_stride, long long tok_stride, int ntok, const int4* units = nullptr) -> int {
         GroupNormDesc nd{};
             nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);
         nd.x = res; nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
@@ -251,6 +303,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         nd.n_inst = n_inst; nd.inner = inner; nd.outer_stride = outer; nd.inner_stride = inner_stride;
         nd.tok_stride = tok_stride; nd.ntok = ntok; nd.C = D; nd.groups = c->cfg.n_groups_module;
         nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0;
+        nd.units = units;
         return launch_group_norm(nd, s);
     };
     const float* xin = buf("conv5");
@@ -268,40 +321,49 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         {
             AttnDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), D, D, D, D, B * Tp, H, DH, N, N, Tp,
                         (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale, lse(0)};
+            if (rs) { ad.G = rt.sumTpS; ad.inner = 1; ad.q_units = rt.u_st; }
             if (train) ad.drop = c->attn_drop(l, 0);
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
-        SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
+        if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st));
+        else SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
         // (ii) motion attention over T' per track, PE on q and k only: module.py:38-43
         SOLA_TRY(linear3(x_pe, x_pe, x_obj, lp + "motion_attn", 3, M, ab(1, "q"), ab(1, "k"), ab(1, "v"), 0));
         {
             AttnDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), D, D, D, D, B * N, H, DH, Tp, Tp, 1,
                         (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale, lse(1)};
+            if (rs) { ad.G = rt.sumNS; ad.q_units = rt.u_strk; }
             if (train) ad.drop = c->attn_drop(l, 1);
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
-        SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp));
+        if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk));
+        else SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp));
         // (iii) object -> language cross attention: module.py:46-50
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, lp + "object2lang_attn", 1, M, ab(2, "q"), nullptr, nullptr, 0));
-        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, B * Wn, ab(2, "lk"), ab(2, "lv"), nullptr, 1,
+        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, (int)text_rows, ab(2, "lk"), ab(2, "lv"), nullptr, 1,
                          split ? c->scal_pair(1) : nullptr));
         {
             AttnDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
                         (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale, lse(2)};
+            if (rs) { ad.Sq = rt.maxRowsSample; ad.q_units = rt.u_smp; ad.k_units = rt.u_langk; }
             if (train) ad.drop = c->attn_drop(l, 2);
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));
-        SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp));
+        if (rs) SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, 0, 0, 1, rt.maxRowsSample, rt.u_smp));
+        else SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp));
         xin = x_o2l;
     }
 
     // a6: score head (module/module.py:152-160)
     HeadDesc hd{xin, buf("lbar"), score_map, score_tokens, B, N, Tp, D};
+    if (rs) { hd.B = 1; hd.N = rt.sumNS; hd.units = rt.u_strk; }
     SOLA_TRY(launch_score_head(hd, s));
     c->last = p;
+    c->last_rag = rt;
+    c->last_ws = workspace;
     c->last_obj = train ? obj : nullptr;
     return SOLA_OK;
 }

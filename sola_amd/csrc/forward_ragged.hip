@@ -19,7 +19,7 @@
 
 #include <algorithm>
 
-#include "ctx.h"
+#include "ragged.h"
 
 namespace {
 
@@ -40,6 +40,7 @@ struct RagDev {
     int4* u_lang;     // [S]         (first input text row, L, first lang_cat row, W)
     int4* u_langk;    // [S]         (first lang_cat row, 1, W, 0)
     int4* u_gather;   // [S]         (first sample row, first video row at T', rows, 0)
+    int4* imap[5];    // training: [rows of level l + 1] (first output row of the sequence under conv l + 1, T_out, ti, 0); null = not built
 };
 
 // largest i in [0, n) with pre[i] <= x (pre ascending, pre[0] = 0)
@@ -53,7 +54,8 @@ __device__ __forceinline__ int seg_of(const int* pre, int n, int x) {
     return lo;
 }
 
-// blockIdx.y = section: 0..6 level tables, 7..11 row maps, 12 (video, t') units, 13 (sample, t') units, 14 sample tracks, 15 samples
+// blockIdx.y = section: 0..6 level tables, 7..11 row maps, 12 (video, t') units, 13 (sample, t') units, 14 sample tracks, 15 samples,
+// 16..20 (training) input-row maps of convs 1..5
 __global__ __launch_bounds__(256) void ragged_plan_kernel(const RagDev p) {
     const int sec = blockIdx.y;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x;; i += (long long)gridDim.x * 256) {
@@ -91,6 +93,16 @@ __global__ __launch_bounds__(256) void ragged_plan_kernel(const RagDev p) {
             const int v = p.sVid[sidx];
             const int Tp = p.vT[6 * p.V + v];
             p.u_strk[i] = make_int4(p.sRow0[sidx] + ((int)i - p.sTrk0[sidx]) * Tp, 1, Tp, sidx);
+        } else if (sec >= 16) {
+            const int l = sec - 16 + 1;  // conv l reads level l and writes level l + 1: this is the table of its INPUT rows
+            if (!p.imap[l - 1]) return;
+            const int* pre = p.vRow0 + l * (p.V + 1);
+            if (i >= pre[p.V]) return;
+            const int v = seg_of(pre, p.V, (int)i);
+            const int local = (int)i - pre[v];
+            const int T_in = p.vT[l * p.V + v], T_out = p.vT[(l + 1) * p.V + v];
+            const int n = local / T_in, ti = local - n * T_in;
+            p.imap[l - 1][i] = make_int4(p.vRow0[(l + 1) * (p.V + 1) + v] + n * T_out, T_out, ti, 0);
         } else {
             if (i >= p.S) return;
             const int v = p.sVid[i];
@@ -104,18 +116,9 @@ __global__ __launch_bounds__(256) void ragged_plan_kernel(const RagDev p) {
     }
 }
 
-// ---- host-side shape bookkeeping ---------------------------------------------------------------------------------
-struct RagShape {
-    int V = 0, S = 0;
-    std::vector<int> vN, vT[7], vRow0[7], vTrk0, vTp0;
-    std::vector<int> sVid, sL, sLin0, sLrow0, sTrk0, sRow0, sTp0;
-    long long rows[7] = {0};  // token rows per level over the videos
-    int NT = 0, maxN = 0, maxT[7] = {0}, maxW = 0;
-    long long Mv = 0, Ms = 0, LW = 0, Lin = 0;
-    int maxRowsSample = 0, sumTpV = 0, sumTpS = 0, sumNS = 0;
-    bool identity = false;  // one sample per video, in order: the per-sample rows ARE the per-video rows
-};
+}  // namespace
 
+// ---- host-side shape bookkeeping ---------------------------------------------------------------------------------
 int rag_shape(const SolaCtx* c, const SolaRaggedBatch* b, RagShape& r) {
     SOLA_ARG(b && b->n_videos > 0 && b->n_samples > 0 && b->video_tracks && b->video_frames && b->sample_video && b->sample_text_len,
              "ragged batch: null or empty descriptor");
@@ -170,6 +173,8 @@ int rag_shape(const SolaCtx* c, const SolaRaggedBatch* b, RagShape& r) {
     return SOLA_OK;
 }
 
+namespace {
+
 size_t blob_ints(const RagShape& r) { return (size_t)r.V * 8 + (size_t)(r.V + 1) * 9 + (size_t)r.S * 2 + (size_t)(r.S + 1) * 5; }
 
 struct RagPlan {
@@ -183,6 +188,8 @@ struct RagPlan {
     }
 };
 
+}  // namespace
+
 // slots of the sliced GroupNorm shape: a launch has (instances x 8 groups x slices of the LONGEST unit) blocks of 8 bytes; the
 // object->language norm has one instance per sample (up to maxRowsSample tokens), the encoder norms one per track (up to
 // maxT[1] tokens); slices are at least 128 tokens
@@ -193,20 +200,13 @@ size_t rag_gn_slots_bytes(const RagShape& r) {
     return 8 * 8 * std::max(a, std::max(b, t)) + 4096;
 }
 
+namespace {
+
 RagPlan rag_plan(const SolaCtx* c, const RagShape& r) {
     RagPlan p;
     const size_t D = c->cfg.lang_token_dim, f = sizeof(float);
     const bool sp = c->precision == 1;
-    p.add("blob", blob_ints(r) * sizeof(int));
-    for (int j = 0; j < 7; ++j) p.add("u_lvl" + std::to_string(j), (size_t)r.NT * sizeof(int4));
-    for (int l = 0; l < 5; ++l) p.add("rowmap" + std::to_string(l), (size_t)r.rows[l + 1] * sizeof(int2));
-    p.add("u_vt", (size_t)r.sumTpV * sizeof(int4));
-    p.add("u_st", (size_t)r.sumTpS * sizeof(int4));
-    p.add("u_strk", (size_t)r.sumNS * sizeof(int4));
-    p.add("u_smp", (size_t)r.S * sizeof(int4));
-    p.add("u_lang", (size_t)r.S * sizeof(int4));
-    p.add("u_langk", (size_t)r.S * sizeof(int4));
-    p.add("u_gather", (size_t)r.S * sizeof(int4));
+    p.add("tables", rag_tables_bytes(r, false));
     for (int i = 0; i < 6; ++i) {
         p.add("conv" + std::to_string(i), (size_t)r.rows[i + 1] * c->conv[i].cout * f);
         if (i < 5) p.add("act" + std::to_string(i), (size_t)r.rows[i + 1] * c->conv[i].cout * f);
@@ -283,6 +283,83 @@ static int stage_slot(SolaCtx* c, size_t ints, int** host, hipEvent_t* ev) {
     return SOLA_OK;
 }
 
+namespace {
+size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+// walks the table region in a fixed order; `visit(name index, bytes)` returns nothing, offsets accumulate
+struct TableLayout {
+    size_t blob, u_lvl[7], rowmap[5], imap[5], u_vt, u_st, u_strk, u_smp, u_lang, u_langk, u_gather, total;
+};
+TableLayout table_layout(const RagShape& r, bool train) {
+    TableLayout t{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+    t.blob = take(blob_ints(r) * sizeof(int));
+    for (int j = 0; j < 7; ++j) t.u_lvl[j] = take((size_t)r.NT * sizeof(int4));
+    for (int l = 0; l < 5; ++l) t.rowmap[l] = take((size_t)r.rows[l + 1] * sizeof(int2));
+    for (int l = 0; l < 5; ++l) t.imap[l] = train ? take((size_t)r.rows[l + 1] * sizeof(int4)) : 0;
+    t.u_vt = take((size_t)r.sumTpV * sizeof(int4));
+    t.u_st = take((size_t)r.sumTpS * sizeof(int4));
+    t.u_strk = take((size_t)r.sumNS * sizeof(int4));
+    t.u_smp = take((size_t)r.S * sizeof(int4));
+    t.u_lang = take((size_t)r.S * sizeof(int4));
+    t.u_langk = take((size_t)r.S * sizeof(int4));
+    t.u_gather = take((size_t)r.S * sizeof(int4));
+    t.total = o;
+    return t;
+}
+}  // namespace
+
+size_t rag_tables_bytes(const RagShape& r, bool train) { return table_layout(r, train).total; }
+
+int rag_build_tables(SolaCtx* c, const RagShape& r, char* base, bool train, RagTables* out, hipStream_t s) {
+    SOLA_ARG(c && base && out && (reinterpret_cast<uintptr_t>(base) & 255) == 0, "ragged tables: bad arguments");
+    const TableLayout t = table_layout(r, train);
+    int* host;
+    hipEvent_t ev;
+    SOLA_TRY(stage_slot(c, blob_ints(r), &host, &ev));
+    int* w = host;
+    int* const blob = reinterpret_cast<int*>(base + t.blob);
+    auto put = [&](const std::vector<int>& v) { const int* at = blob + (w - host); memcpy(w, v.data(), v.size() * sizeof(int)); w += v.size(); return at; };
+    RagDev dv{};
+    dv.vN = put(r.vN);
+    dv.vT = blob + (w - host);
+    for (int j = 0; j < 7; ++j) put(r.vT[j]);
+    dv.vRow0 = blob + (w - host);
+    for (int j = 0; j < 7; ++j) put(r.vRow0[j]);
+    dv.vTrk0 = put(r.vTrk0); dv.vTp0 = put(r.vTp0);
+    dv.sVid = put(r.sVid); dv.sL = put(r.sL); dv.sLin0 = put(r.sLin0); dv.sLrow0 = put(r.sLrow0);
+    dv.sTrk0 = put(r.sTrk0); dv.sRow0 = put(r.sRow0); dv.sTp0 = put(r.sTp0);
+    SOLA_HIP(hipMemcpyAsync(blob, host, (size_t)(w - host) * sizeof(int), hipMemcpyHostToDevice, s));
+    SOLA_HIP(hipEventRecord(ev, s));
+    dv.V = r.V; dv.S = r.S; dv.NT = r.NT; dv.n_neg = c->cfg.n_negative;
+    for (int l = 0; l < 5; ++l) { dv.stride[l] = c->conv[l].stride; dv.pad[l] = c->conv[l].pad; dv.k[l] = c->conv[l].k; }
+    auto t4 = [&](size_t off) { return reinterpret_cast<int4*>(base + off); };
+    for (int j = 0; j < 7; ++j) dv.u_lvl[j] = t4(t.u_lvl[j]);
+    for (int l = 0; l < 5; ++l) dv.rowmap[l] = reinterpret_cast<int2*>(base + t.rowmap[l]);
+    for (int l = 0; l < 5; ++l) dv.imap[l] = train ? t4(t.imap[l]) : nullptr;
+    dv.u_vt = t4(t.u_vt); dv.u_st = t4(t.u_st); dv.u_strk = t4(t.u_strk); dv.u_smp = t4(t.u_smp);
+    dv.u_lang = t4(t.u_lang); dv.u_langk = t4(t.u_langk); dv.u_gather = t4(t.u_gather);
+    long long biggest = std::max<long long>(r.NT, r.rows[1]);
+    biggest = std::max<long long>(biggest, std::max<long long>(r.sumNS, std::max(r.sumTpS, r.sumTpV)));
+    const unsigned bx = (unsigned)std::min<long long>(2048, (biggest + 255) / 256);
+    {
+        SolaProfScope prof(SOLA_PROF_MISC, s, 0, 0);
+        hipLaunchKernelGGL(ragged_plan_kernel, dim3(bx, train ? 21 : 16), dim3(256), 0, s, dv);
+        SOLA_LAUNCH_CHECK();
+    }
+    RagTables& o = *out;
+    for (int j = 0; j < 7; ++j) o.u_lvl[j] = dv.u_lvl[j];
+    for (int l = 0; l < 5; ++l) { o.rowmap[l] = dv.rowmap[l]; o.imap[l] = dv.imap[l]; }
+    o.u_vt = dv.u_vt; o.u_st = dv.u_st; o.u_strk = dv.u_strk; o.u_smp = dv.u_smp;
+    o.u_lang = dv.u_lang; o.u_langk = dv.u_langk; o.u_gather = dv.u_gather;
+    o.trk_off = dv.sTrk0;
+    o.V = r.V; o.S = r.S; o.NT = r.NT; o.sumNS = r.sumNS; o.sumTpV = r.sumTpV; o.sumTpS = r.sumTpS;
+    o.maxN = r.maxN; o.maxW = r.maxW; o.maxRowsSample = r.maxRowsSample;
+    for (int j = 0; j < 7; ++j) { o.maxT[j] = r.maxT[j]; o.rows[j] = r.rows[j]; }
+    o.Mv = r.Mv; o.Ms = r.Ms; o.LW = r.LW; o.Lin = r.Lin; o.identity = r.identity;
+    return SOLA_OK;
+}
+
 size_t sola_ragged_workspace_bytes_impl(const SolaCtx* c, const SolaRaggedBatch* b) {
     RagShape r;
     if (!c || rag_shape(c, b, r) != SOLA_OK) return 0;
@@ -313,48 +390,26 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
     char* base = static_cast<char*>(workspace);
     auto raw = [&](const std::string& name) { return base + p.off.at(name); };
     auto buf = [&](const std::string& name) { return reinterpret_cast<float*>(raw(name)); };
-    auto tab4 = [&](const std::string& name) { return reinterpret_cast<int4*>(raw(name)); };
     auto W = [&](const std::string& name) { return ctx_weight(c, name); };
     const int D = c->cfg.lang_token_dim, H = c->cfg.num_heads, DH = D / H, d_in = c->cfg.object_token_dim;
-    const int V = r.V, S = r.S;
+    const int S = r.S;
     float* const splitk_ws = p.off.count("splitk") ? buf("splitk") : nullptr;
     const size_t splitk_bytes = splitk_ws ? (size_t)8192 * 4096 * sizeof(float) : 0;
     const size_t gn_slots_bytes = rag_gn_slots_bytes(r);
 
     // ---- descriptors -> device, unit tables
-    const int32_t* trk_off_dev = nullptr;
-    {
-        int* host;
-        hipEvent_t ev;
-        SOLA_TRY(stage_slot(c, blob_ints(r), &host, &ev));
-        int* w = host;
-        auto put = [&](const std::vector<int>& v) { const int* at = reinterpret_cast<int*>(raw("blob")) + (w - host); memcpy(w, v.data(), v.size() * sizeof(int)); w += v.size(); return at; };
-        RagDev dv{};
-        dv.vN = put(r.vN);
-        dv.vT = reinterpret_cast<int*>(raw("blob")) + (w - host);
-        for (int j = 0; j < 7; ++j) put(r.vT[j]);
-        dv.vRow0 = reinterpret_cast<int*>(raw("blob")) + (w - host);
-        for (int j = 0; j < 7; ++j) put(r.vRow0[j]);
-        dv.vTrk0 = put(r.vTrk0); dv.vTp0 = put(r.vTp0);
-        dv.sVid = put(r.sVid); dv.sL = put(r.sL); dv.sLin0 = put(r.sLin0); dv.sLrow0 = put(r.sLrow0);
-        dv.sTrk0 = put(r.sTrk0); dv.sRow0 = put(r.sRow0); dv.sTp0 = put(r.sTp0);
-        trk_off_dev = dv.sTrk0;
-        SOLA_HIP(hipMemcpyAsync(raw("blob"), host, (size_t)(w - host) * sizeof(int), hipMemcpyHostToDevice, s));
-        SOLA_HIP(hipEventRecord(ev, s));
-        dv.V = V; dv.S = S; dv.NT = r.NT; dv.n_neg = c->cfg.n_negative;
-        for (int l = 0; l < 5; ++l) { dv.stride[l] = c->conv[l].stride; dv.pad[l] = c->conv[l].pad; dv.k[l] = c->conv[l].k; }
-        for (int j = 0; j < 7; ++j) dv.u_lvl[j] = tab4("u_lvl" + std::to_string(j));
-        for (int l = 0; l < 5; ++l) dv.rowmap[l] = reinterpret_cast<int2*>(raw("rowmap" + std::to_string(l)));
-        dv.u_vt = tab4("u_vt"); dv.u_st = tab4("u_st"); dv.u_strk = tab4("u_strk"); dv.u_smp = tab4("u_smp");
-        dv.u_lang = tab4("u_lang"); dv.u_langk = tab4("u_langk"); dv.u_gather = tab4("u_gather");
-        long long biggest = std::max<long long>(r.NT, r.rows[1]);
-        biggest = std::max<long long>(biggest, std::max<long long>(r.sumNS, std::max(r.sumTpS, r.sumTpV)));
-        const unsigned bx = (unsigned)std::min<long long>(2048, (biggest + 255) / 256);
-        SolaProfScope prof(SOLA_PROF_MISC, s, 0, 0);
-        hipLaunchKernelGGL(ragged_plan_kernel, dim3(bx, 16), dim3(256), 0, s, dv);
-        SOLA_LAUNCH_CHECK();
-    }
-    (void)trk_off_dev;
+    RagTables rt;
+    SOLA_TRY(rag_build_tables(c, r, raw("tables"), false, &rt, s));
+    auto tab4 = [&](const std::string& name) -> const int4* {
+        if (name == "u_vt") return rt.u_vt;
+        if (name == "u_st") return rt.u_st;
+        if (name == "u_strk") return rt.u_strk;
+        if (name == "u_smp") return rt.u_smp;
+        if (name == "u_lang") return rt.u_lang;
+        if (name == "u_langk") return rt.u_langk;
+        if (name == "u_gather") return rt.u_gather;
+        return rt.u_lvl[name.back() - '0'];  // "u_lvl<j>"
+    };
 
     // ---- weights
     if (c->ws_dirty || c->ws_every_forward) {
@@ -403,7 +458,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
         gd.conv = g.k > 1 ? 1 : 0;
         gd.Cin = g.cin; gd.stride = g.stride; gd.pad = g.pad; gd.T_in = 1; gd.T_out = 1;
-        if (gd.conv) gd.rowmap = reinterpret_cast<const int2*>(raw("rowmap" + std::to_string(i)));
+        if (gd.conv) gd.rowmap = rt.rowmap[i];
         if (sp) {
             gd.arith = 1; gd.out_scale = 1.f; gd.c_sp16 = last_sp ? 1 : 0; gd.guard = guard;
             if (i == 0) gd.out_scale_dev = c->scal_pair(0) + 1;

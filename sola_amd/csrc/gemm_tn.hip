@@ -18,6 +18,7 @@ struct TnArgs {
     float* Pb;       // optional [splits][N]: column sums of A (bias gradient), written by the tk == 0 blocks
     int M, N, K, lda, ldb;
     int conv, T_in, T_out, stride, pad, Cin;  // conv gather on B (same convention as the NT kernel's mode 1)
+    const int2* rowmap;  // conv, ragged batches: row m reads tap kk from source row rowmap[m].x + kk when bit kk of rowmap[m].y is set
     int tiles_n, tiles_k, m_per_split;
 };
 
@@ -55,7 +56,11 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             bool ok = mok && k0 + lcol < a.K;
             const float* src;
-            if (a.conv) {
+            if (a.conv && a.rowmap) {
+                const int2 rm = a.rowmap[mok ? m : 0];
+                ok = ok && ((rm.y >> kk) & 1);
+                src = a.B + ((long long)rm.x + kk) * a.Cin + ci;
+            } else if (a.conv) {
                 const int r = m / a.T_out;
                 const int to = m - r * a.T_out;
                 const int ti = to * a.stride - a.pad + kk;
@@ -230,6 +235,7 @@ int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
     TnArgs a;
     a.A = d.A; a.B = d.B; a.P = d.scratch; a.Pb = nullptr; a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
+    a.rowmap = d.conv ? d.rowmap : nullptr;
     a.tiles_n = (d.N + TB - 1) / TB;
     a.tiles_k = (d.K + TB - 1) / TB;
     const size_t need = gemm_tn_scratch_bytes(d.M, d.N, d.K);

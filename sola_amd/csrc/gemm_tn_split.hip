@@ -23,6 +23,7 @@ __device__ __forceinline__ float auto_scale_t(unsigned amax_bits) {  // as cast.
 
 // in [rows][cols] f32 (pitch ld_in) -> out [cols][ld_out] split-f16, out[c][8b..8b+7] = scale * in[8b..8b+7][c]; rows beyond
 // `rows` up to ld_out are written as zeros.  Tile = 128 rows x 64 columns through LDS.
+// With rowmap != null (ragged batches) row m reads source row rowmap[m].x + tap, zeros where bit `tap` of rowmap[m].y is clear.
 // With conv_T_out > 0 the input is the implicit im2col of a channels-last conv for ONE tap: row m = (r, to) reads source row
 // r * conv_T_in + to * conv_stride + conv_toff (tap - pad), zeros outside [0, conv_T_in).
 // PURE: the output is plain _Float16 ([cols][ld_out halfs]) for the one-MFMA-per-product GEMM (GemmDesc::arith 2).
@@ -30,7 +31,7 @@ template <bool PURE>
 __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                                           int ld_in, long long ld_out, float* __restrict__ scal, int conv_T_in,
                                                           int conv_T_out, int conv_stride, int conv_toff, float* __restrict__ out_rm,
-                                                          long long ld_rm) {
+                                                          long long ld_rm, const int2* __restrict__ rowmap, int tap) {
     __shared__ float tile[128][65];
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
@@ -48,7 +49,11 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             long long src = r0 + r;
             bool ok = r0 + r < rows;
-            if (conv_T_out > 0 && ok) {
+            if (rowmap && ok) {  // ragged batches: tap `tap` of output row m lives at source row rowmap[m].x + tap (GemmDesc::rowmap)
+                const int2 rm = rowmap[r0 + r];
+                ok = (rm.y >> tap) & 1;
+                src = (long long)rm.x + tap;
+            } else if (conv_T_out > 0 && ok) {
                 const int m = r0 + r, rr = m / conv_T_out, tt = (m - rr * conv_T_out) * conv_stride + conv_toff;
                 ok = (unsigned)tt < (unsigned)conv_T_in;
                 src = (long long)rr * conv_T_in + tt;
@@ -141,12 +146,32 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z
     *reinterpret_cast<float4*>(dx + i * 4) = acc;
 }
 
+// ragged batches: input row i of the conv has imap[i] = (first output row of its sequence, T_out, step ti, -)
+__global__ __launch_bounds__(256) void col2im_ragged_kernel(const float* __restrict__ z, float* __restrict__ dx, long long n4,
+                                                            const int4* __restrict__ imap, int cin4, int k, int stride, int pad) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % cin4);
+    const int4 im = imap[i / cin4];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kk = 0; kk < k; ++kk) {
+        const int u = im.z + pad - kk;
+        if (u < 0 || u % stride) continue;
+        const int to = u / stride;
+        if (to >= im.y) continue;
+        const float4 v = *reinterpret_cast<const float4*>(z + (((long long)im.x + to) * k + kk) * (long long)(cin4 * 4) + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = acc;
+}
+
 int cast_t(bool pure, const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
-           int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0, float* out_rm = nullptr, long long ld_rm = 0) {
+           int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0, float* out_rm = nullptr, long long ld_rm = 0,
+           const int2* rowmap = nullptr, int tap = 0) {
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, ((pure ? 6.0 : 8.0) + (out_rm ? (pure ? 2.0 : 4.0) : 0.0)) * rows * cols);
     const dim3 grid((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64));
-    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm);
-    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm);
+    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap);
+    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -179,6 +204,15 @@ int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, i
     return SOLA_OK;
 }
 
+int launch_col2im_ragged(const float* z, float* dx, long long rows_in, const int4* imap, int cin, int k, int stride, int pad, hipStream_t s) {
+    SOLA_ARG(z && dx && imap && cin % 4 == 0 && k >= 1 && stride >= 1 && rows_in > 0, "col2im_ragged: cin=%d k=%d stride=%d", cin, k, stride);
+    const long long n4 = rows_in * (cin / 4);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (rows_in * (double)k * cin / stride + rows_in * (double)cin));
+    hipLaunchKernelGGL(col2im_ragged_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, imap, cin / 4, k, stride, pad);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 bool gemm_tn_split_supported(int M, int N, int K) { return N % 8 == 0 && K % 8 == 0 && M >= 64; }
 
 // the row-major copy is written by the 16-byte-load path of the cast only: whole 64-column tiles, aligned slices
@@ -201,7 +235,7 @@ size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob) {
 int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3 && d.scratch, "gemm_tn_split: nprob %d", d.nprob);
     SOLA_ARG(gemm_tn_split_supported(d.M, d.N, d.K) && d.lda % 4 == 0, "gemm_tn_split: M=%d N=%d K=%d lda=%d", d.M, d.N, d.K, d.lda);
-    SOLA_ARG(!d.conv || (d.Cin > 0 && d.K % d.Cin == 0 && d.T_out > 0 && d.M % d.T_out == 0), "gemm_tn_split: conv geometry K=%d Cin=%d", d.K, d.Cin);
+    SOLA_ARG(!d.conv || (d.Cin > 0 && d.K % d.Cin == 0 && (d.rowmap || (d.T_out > 0 && d.M % d.T_out == 0))), "gemm_tn_split: conv geometry K=%d Cin=%d", d.K, d.Cin);
     SOLA_ARG(d.scratch_bytes >= gemm_tn_split_scratch_bytes(d.M, d.N, d.K, d.nprob), "gemm_tn_split: scratch too small");
     int ks; long long Mp;
     const bool pure = d.pure != 0;
@@ -233,7 +267,8 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             float* dst = xt + (size_t)n_xt++ * d.K * rowf;
             if (d.conv) {  // rows [kk*Cin, (kk+1)*Cin) of X^T = tap kk of the implicit im2col
                 for (int kk = 0; kk < d.K / d.Cin; ++kk)
-                    SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst + (size_t)kk * d.Cin * rowf, Mp, d.M, d.Cin, d.scal_b, s, d.T_in, d.T_out, d.stride, kk - d.pad));
+                    SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst + (size_t)kk * d.Cin * rowf, Mp, d.M, d.Cin, d.scal_b, s, d.T_in, d.T_out, d.stride, kk - d.pad,
+                                    nullptr, 0, d.rowmap, kk));
             } else {
                 SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst, Mp, d.M, d.K, d.scal_b, s));
             }

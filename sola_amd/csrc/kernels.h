@@ -64,6 +64,7 @@ struct GemmTnDesc {
     int conv, T_in, T_out, stride, pad, Cin;
     float* scratch;
     size_t scratch_bytes;
+    const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap (T_in / T_out / stride / pad are then unused)
 };
 // Split-f16 version (gemm_tn_split.hip): up to three problems dW_j = A_j^T B_j sharing M, N, K and the pitches
 struct GemmTnSplitDesc {
@@ -84,12 +85,15 @@ struct GemmTnSplitDesc {
     int a_rm_ld;
     float* scratch;
     size_t scratch_bytes;
+    const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap
 };
 // in [rows][cols] f32 -> out [cols][ld_out] split-f16 (rows rows..ld_out zero-filled; ld_out % 128 == 0); scal: optional
 // device pair as for launch_cast_sp16_auto with scal[0] = max|in| already there
 int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s);
 // dx[(r, ti)][ci] = sum over taps of z[(r, to)][kk*cin + ci] (the scatter of a transposed conv, as a gather)
 int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s);
+// ragged batches: input row i has imap[i] = (first output row of its sequence, T_out, step ti inside the sequence, -)
+int launch_col2im_ragged(const float* z, float* dx, long long rows_in, const int4* imap, int cin, int k, int stride, int pad, hipStream_t s);
 bool gemm_tn_split_supported(int M, int N, int K);
 bool gemm_tn_split_writes_rm(const GemmTnSplitDesc& d);
 size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob);
@@ -134,6 +138,9 @@ struct AttnBwdDesc {
     long long k_outer, k_inner, k_rs;
     float scale;
     DropoutCfg drop;
+    // optional, ragged batches: as AttnDesc::q_units / k_units (per-group (first row, row stride, length, -)); Sq / Sk are then
+    // the LARGEST lengths
+    const int4 *q_units, *k_units;
 };
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);
 
@@ -152,6 +159,9 @@ struct GroupNormBwdDesc {
     float eps, slope;
     int leaky;
     DropoutCfg drop;
+    // optional, ragged batches: instance i covers units[i] = (first row, row stride, token count, -) (GroupNormDesc::units);
+    // ntok is then the LARGEST token count (it selects the kernel shape)
+    const int4* units;
 };
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
 struct WsBwdLayer {
@@ -166,6 +176,7 @@ struct HeadBwdDesc {
     float* dx;          // [B, N, Tp, D]
     float* dlbar_part;  // [B*N, D]
     int B, N, Tp, D;
+    const int4* units;  // optional, ragged batches: as HeadDesc::units (B*N = number of tracks, Tp = the largest T')
 };
 int launch_score_head_bwd(const HeadBwdDesc& d, hipStream_t s);
 struct LossBwdDesc {
@@ -178,11 +189,18 @@ struct LossBwdDesc {
     float* d_tok;     // [B*N, D]
     float* coef;      // [B*N, n_neg] scratch
     float* d_neg;     // [B, n_neg, D]
+    // optional, ragged batches: sample b owns the tracks trk_off[b] .. trk_off[b + 1] (device, B + 1 entries) of the concatenated
+    // arrays (total_tracks of them), every mean runs over the sample's own tracks and g3 is [B][3] (one upstream triple per sample)
+    const int32_t* trk_off;
+    long long total_tracks;
 };
 int launch_loss_bwd(const LossBwdDesc& d, hipStream_t s);
 // d_negw[m] = sum_b (d_lang[b, L+m] + dlbar[b] / W) (+ d_neg_align[b, m]); also used to fold dlbar into d_lang rows
+// units (optional, ragged batches): sample b has units[b] = (-, L_b, first row of its text ++ negatives in d_lang, W_b)
 int launch_neg_token_grad(const float* d_lang, const float* dlbar, const float* d_neg_align, float* d_negw, int B, int L,
-                          int n_neg, int D, hipStream_t s);
+                          int n_neg, int D, hipStream_t s, const int4* units = nullptr);
+// out[seg] = sum of the rows off[seg] .. off[seg + 1] of in [*, cols] (per-sample sums over a ragged batch's tracks)
+int launch_segsum_rows(const float* in, float* out, const int32_t* off, int segments, int cols, hipStream_t s);
 
 // ---- multi-tensor gradient statistics (optim.hip) ---------------------------------------------------------------
 size_t mt_sqnorm_scratch_bytes(int n, const long long* numel);

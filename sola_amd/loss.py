@@ -81,15 +81,8 @@ def weighted_bce_with_logits(score_logits, labels, positive_weight=1.5):
     return loss3[1]
 
 
-@torch.no_grad()
-def track_selection_losses_ragged(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets, counts,
-                                  positive_weight=1.5, temperature=0.07, alignment_weight=0.3, return_argmax=False):
-    """``track_selection_losses`` for the flat outputs of ``forward_ragged``: every sample gets its OWN means over its own
-    tracks - what train.py:98-113 / evaluator.py:88-112 compute at the reference's batch size of 1 (sola_loss_ragged).
-
-    score_map [sum N_i], score_tokens [sum N_i, D], labels [sum N_i]; pos_tokens [S, D] (or [S,1,D]); neg_tokens a shared
-    [n_neg, D] table or [S, n_neg, D]; track_offsets int32 [S+1] on the device; counts = python list of N_i.
-    Returns float32 [S, 3] = {total, bce, alignment} per sample (and int32 [sum N_i] hardest-negative indices)."""
+def _loss_forward_ragged(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets, counts, positive_weight,
+                         temperature, alignment_weight, return_argmax):
     require_cuda(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets)
     S = len(counts)
     total = int(score_map.numel())
@@ -114,4 +107,27 @@ def track_selection_losses_ragged(score_map, score_tokens, labels, pos_tokens, n
                                  max(counts), total, D, n_neg, float(positive_weight), float(temperature),
                                  float(alignment_weight), ptr(loss3), ptr(argmax), ptr(scratch), scratch.numel() * 4,
                                  current_stream(dev)), "sola_loss_ragged")
+    return loss3, argmax
+
+
+def track_selection_losses_ragged(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets, counts,
+                                  positive_weight=1.5, temperature=0.07, alignment_weight=0.3, return_argmax=False):
+    """``track_selection_losses`` for the flat outputs of ``forward_ragged``: every sample gets its OWN means over its own
+    tracks - what train.py:98-113 / evaluator.py:88-112 compute at the reference's batch size of 1 (sola_loss_ragged).
+
+    score_map [sum N_i], score_tokens [sum N_i, D], labels [sum N_i]; pos_tokens [S, D] (or [S,1,D]); neg_tokens a shared
+    [n_neg, D] table or [S, n_neg, D]; track_offsets int32 [S+1] on the device; counts = python list of N_i.
+    Returns float32 [S, 3] = {total, bce, alignment} per sample (and int32 [sum N_i] hardest-negative indices).
+    Differentiable with respect to score_map, score_tokens and neg_tokens (sola_loss_backward_ragged): ``loss[:, 0].mean()`` is
+    the batch objective whose gradient is the average of the reference's per-sample (batch-size-1) gradients."""
+    needs_grad = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (score_map, score_tokens, neg_tokens))
+    if needs_grad and not return_argmax:
+        from .autograd import _LossesRagged
+
+        return _LossesRagged.apply(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets.contiguous(), list(counts),
+                                   positive_weight, temperature, alignment_weight)
+    with torch.no_grad():
+        loss3, argmax = _loss_forward_ragged(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets, counts,
+                                             positive_weight, temperature, alignment_weight, return_argmax)
     return (loss3, argmax) if return_argmax else loss3

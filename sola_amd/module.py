@@ -232,19 +232,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         return score_map, score_tokens
 
     # ------------------------------------------------------------------------------------------ ragged batches
-    @torch.no_grad()
-    def forward_ragged(self, object_tokens, lang_tokens, sample_video=None):
-        """Score many (video, expression) samples of different shapes in ONE pass (sola_forward_ragged).
-
-        object_tokens : list of V tensors [N_v, T_v, d] - one per VIDEO (object set)
-        lang_tokens   : list of S tensors [L_i, D]      - one per SAMPLE
-        sample_video  : list of S video indices (default: sample i scores video i, S == V)
-
-        Everything that does not depend on the text (encoder, layer 0's inter-object and motion sub-blocks) runs once per
-        video and is shared by the samples that refer to it; inference.py:44-58 recomputes it per expression.
-        Returns ``(score_maps, score_tokens)``: lists of S tensors [N_i] and [N_i, D] (views of two flat buffers, also
-        available as ``self.last_ragged``: flat score_map, flat score_tokens, int32 track offsets on the device).
-        Inference only (no autograd).  Each sample's result equals ``self(obj[None], lang[None])`` up to f32 summation order."""
+    def _ragged_inputs(self, object_tokens, lang_tokens, sample_video):
         V, S = len(object_tokens), len(lang_tokens)
         if V < 1 or S < 1:
             raise SolaError("forward_ragged: need at least one video and one sample")
@@ -265,14 +253,58 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         for v in sample_video:
             if not 0 <= int(v) < V:
                 raise SolaError(f"forward_ragged: sample_video entry {v} out of range")
-        dev = object_tokens[0].device
-        obj = torch.cat([t.reshape(-1, d) for t in object_tokens], 0).to(torch.float32).contiguous()
-        lang = torch.cat(list(lang_tokens), 0).to(torch.float32).contiguous()
+        return [int(v) for v in sample_video]
+
+    @staticmethod
+    def _ragged_batch_struct(object_tokens, lang_tokens, sample_video):
+        V, S = len(object_tokens), len(lang_tokens)
         vN = (C.c_int32 * V)(*[int(t.shape[0]) for t in object_tokens])
         vT = (C.c_int32 * V)(*[int(t.shape[1]) for t in object_tokens])
         sV = (C.c_int32 * S)(*[int(v) for v in sample_video])
         sL = (C.c_int32 * S)(*[int(t.shape[0]) for t in lang_tokens])
         batch = SolaRaggedBatch(V, vN, vT, S, sV, sL)
+        batch._keep = (vN, vT, sV, sL)  # the struct only holds pointers
+        return batch
+
+    def forward_ragged(self, object_tokens, lang_tokens, sample_video=None, differentiable=None):
+        """Score many (video, expression) samples of different shapes in ONE pass.
+
+        object_tokens : list of V tensors [N_v, T_v, d] - one per VIDEO (object set)
+        lang_tokens   : list of S tensors [L_i, D]      - one per SAMPLE
+        sample_video  : list of S video indices (default: sample i scores video i, S == V)
+
+        Inference (``eval()`` mode or ``torch.no_grad()``; ``differentiable=False``; sola_forward_ragged): everything
+        that does not depend on the text (encoder, layer 0's inter-object and motion sub-blocks) runs once per video and is
+        shared by the samples that refer to it; inference.py:44-58 recomputes it per expression.
+        Training (``train()`` mode with grad enabled, or ``differentiable=True`` - e.g. gradients in eval mode, dropout off;
+        sola_forward_train_ragged / sola_backward_ragged): the whole training step of train.py:62-137 over
+        a batch of variable-shape samples; every sample runs its own encoder pass under its own dropout masks (a video referred
+        to by several samples is repeated), the returned tensors are differentiable with respect to the parameters.
+        Returns ``(score_maps, score_tokens)``: lists of S tensors [N_i] and [N_i, D] (views of two flat buffers, also
+        available as ``self.last_ragged``: flat score_map, flat score_tokens, int32 track offsets on the device, counts).
+        Each sample's result equals ``self(obj[None], lang[None])`` up to f32 summation order."""
+        sample_video = self._ragged_inputs(object_tokens, lang_tokens, sample_video)
+        if differentiable is None:
+            differentiable = torch.is_grad_enabled() and self.training
+        if differentiable:
+            if not torch.is_grad_enabled():
+                raise SolaError("forward_ragged(differentiable=True) under torch.no_grad()")
+            from .autograd import track_selection_forward_ragged  # backward kernels
+            objs = [object_tokens[v] for v in sample_video]
+            score_map, score_tokens = track_selection_forward_ragged(self, objs, list(lang_tokens))
+            counts = self.last_ragged[3]
+            self.last_ragged = (score_map, score_tokens, self.last_ragged[2], counts)
+            return list(torch.split(score_map, counts)), list(torch.split(score_tokens, counts))
+        with torch.no_grad():
+            return self._forward_ragged_impl(object_tokens, lang_tokens, sample_video)
+
+    def _forward_ragged_impl(self, object_tokens, lang_tokens, sample_video):
+        S = len(lang_tokens)
+        d, D = self.object_token_dim, self.lang_token_dim
+        dev = object_tokens[0].device
+        obj = torch.cat([t.reshape(-1, d) for t in object_tokens], 0).to(torch.float32).contiguous()
+        lang = torch.cat(list(lang_tokens), 0).to(torch.float32).contiguous()
+        batch = self._ragged_batch_struct(object_tokens, lang_tokens, sample_video)
         self._ensure_ctx(dev)
         self._bind_weights()
         nbytes = lib().sola_ragged_workspace_bytes(self._ctx, C.byref(batch))
@@ -302,14 +334,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._ensure_ctx(dev)
         self._bind_weights()
         self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
-        if self.training and (self.dropout_p > 0 or self.attention_dropout_p > 0):
-            # a fresh mask seed per step from torch's (seedable) CPU generator, like nn.Dropout under set_seed(42)
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-            check(lib().sola_set_dropout(self._ctx, float(self.dropout_p), float(self.attention_dropout_p), seed), "sola_set_dropout")
-        else:
-            seed = 0
-            check(lib().sola_set_dropout(self._ctx, 0.0, 0.0, 0), "sola_set_dropout")
-        self._last_dropout_seed = seed
+        self._set_step_dropout()
         nbytes = lib().sola_train_workspace_bytes(self._ctx, B, N, T, L)
         if self._train_ws is None or self._train_ws.numel() < nbytes or self._train_ws.device != dev:
             self._train_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
@@ -321,6 +346,52 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._train_shape = (B, N, T, L)
         self._train_generation += 1
         self._workspace = self._train_ws  # workspace_tap reads the arena of the last forward
+        return score_map, score_tokens
+
+    def _set_step_dropout(self):
+        if self.training and (self.dropout_p > 0 or self.attention_dropout_p > 0):
+            # a fresh mask seed per step from torch's (seedable) CPU generator, like nn.Dropout under set_seed(42)
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            check(lib().sola_set_dropout(self._ctx, float(self.dropout_p), float(self.attention_dropout_p), seed), "sola_set_dropout")
+        else:
+            seed = 0
+            check(lib().sola_set_dropout(self._ctx, 0.0, 0.0, 0), "sola_set_dropout")
+        self._last_dropout_seed = seed
+
+    def _forward_train_ragged_impl(self, object_tokens, lang_tokens):
+        """sola_forward_train_ragged: one sample per entry of the two lists ([N_i, T_i, d], [L_i, D]); activations and the
+        unit tables are kept in the workspace for sola_backward_ragged."""
+        S = len(lang_tokens)
+        d, D = self.object_token_dim, self.lang_token_dim
+        dev = object_tokens[0].device
+        obj = torch.cat([t.detach().reshape(-1, d) for t in object_tokens], 0).to(torch.float32).contiguous()
+        lang = torch.cat([t.detach() for t in lang_tokens], 0).to(torch.float32).contiguous()
+        batch = self._ragged_batch_struct(object_tokens, lang_tokens, list(range(S)))
+        self._ensure_ctx(dev)
+        self._bind_weights()
+        self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
+        self._set_step_dropout()
+        nbytes = lib().sola_train_ragged_workspace_bytes(self._ctx, C.byref(batch))
+        if nbytes == 0:
+            raise SolaError("forward_ragged (training): invalid batch description: " + (lib().sola_last_error() or b"").decode())
+        if self._train_ws is None or self._train_ws.numel() < nbytes or self._train_ws.device != dev:
+            self._train_ws = None  # release before allocating the larger arena
+            self._train_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        counts = [int(t.shape[0]) for t in object_tokens]
+        total = sum(counts)
+        score_map = torch.empty(total, device=dev, dtype=torch.float32)
+        score_tokens = torch.empty((total, D), device=dev, dtype=torch.float32)
+        check(lib().sola_forward_train_ragged(self._ctx, ptr(obj), ptr(lang), C.byref(batch), ptr(score_map), ptr(score_tokens),
+                                              ptr(self._train_ws), self._train_ws.numel(), current_stream(dev)),
+              "sola_forward_train_ragged")
+        self._train_inputs = (obj, lang)  # the conv0 weight gradient re-reads the tokens
+        self._train_shape = ("ragged", batch, total)
+        self._train_generation += 1
+        self._workspace = self._train_ws
+        offs = [0]
+        for n in counts:
+            offs.append(offs[-1] + n)
+        self.last_ragged = (score_map, score_tokens, torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True), counts)
         return score_map, score_tokens
 
     def _grad_layout(self):
@@ -369,11 +440,17 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         return [self._grad_arena[a:b] for a, b in self._grad_buckets]
 
     def _backward_impl(self, d_score_map, d_score_tokens):
-        B, N, T, L = self._train_shape
+        ragged = self._train_shape[0] == "ragged"
         dev = self._train_ws.device
         D = self.lang_token_dim
-        d_sm = torch.zeros((B, N), device=dev) if d_score_map is None else d_score_map.to(torch.float32).contiguous()
-        d_st = torch.zeros((B, N, D), device=dev) if d_score_tokens is None else d_score_tokens.to(torch.float32).contiguous()
+        if ragged:
+            _tag, batch, total = self._train_shape
+            sm_shape, st_shape = (total,), (total, D)
+        else:
+            B, N, T, L = self._train_shape
+            sm_shape, st_shape = (B, N), (B, N, D)
+        d_sm = torch.zeros(sm_shape, device=dev) if d_score_map is None else d_score_map.to(torch.float32).contiguous()
+        d_st = torch.zeros(st_shape, device=dev) if d_score_tokens is None else d_score_tokens.to(torch.float32).contiguous()
         named = dict(self.named_parameters())
         self._grad_layout()
         lo, hi = self._grad_arena.data_ptr(), self._grad_arena.data_ptr() + 4 * self._grad_arena.numel()
@@ -392,11 +469,16 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             if self._grad_bound != "arena":
                 self._bind_grad_arena()
             grads = [self._grad_view(key) for key in named]
-        nbytes = lib().sola_backward_workspace_bytes(self._ctx, B, N, T, L)
+        if ragged:
+            nbytes = lib().sola_backward_ragged_workspace_bytes(self._ctx, C.byref(batch))
+        else:
+            nbytes = lib().sola_backward_workspace_bytes(self._ctx, B, N, T, L)
         if self._bwd_ws is None or self._bwd_ws.numel() < nbytes or self._bwd_ws.device != dev:
+            self._bwd_ws = None
             self._bwd_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        check(lib().sola_backward(self._ctx, ptr(d_sm), ptr(d_st), ptr(self._train_ws), ptr(self._bwd_ws),
-                                  self._bwd_ws.numel(), current_stream(dev)), "sola_backward")
+        fn = lib().sola_backward_ragged if ragged else lib().sola_backward
+        check(fn(self._ctx, ptr(d_sm), ptr(d_st), ptr(self._train_ws), ptr(self._bwd_ws), self._bwd_ws.numel(),
+                 current_stream(dev)), "sola_backward_ragged" if ragged else "sola_backward")
         self._grads_in_arena = not aliased
         return grads
 

@@ -152,6 +152,52 @@ def gen_model_golden():
     print("full_golden.npz", os.path.getsize(os.path.join(HERE, "full_golden.npz")) / 1e6, "MB")
 
 
+RAGGED_SMALL_SHAPES = [(8, 8, 5), (5, 20, 6), (16, 32, 9), (3, 1, 4), (7, 33, 16), (1, 9, 1), (20, 200, 7), (70, 17, 40), (2, 64, 3), (11, 130, 12)]
+RAGGED_FULL_SHAPES = [(8, 8, 16), (64, 32, 16), (16, 32, 9), (3, 1, 4), (80, 32, 11), (7, 33, 24), (12, 150, 5)]
+
+
+def gen_ragged_train_golden():
+    """The reference's training step at its batch size of 1 (configs/mevis/default.yaml:37; train.py:62-117), run over samples
+    of DIFFERENT (N, T, L) with the gradients ACCUMULATED (no zero_grad in between): the sum of the per-sample gradients, which
+    is what one ragged step of the build (sola_forward_train_ragged / sola_backward_ragged) must produce for loss = sum of the
+    per-sample totals.  Small configuration: the summed gradient in full; default configuration (33 M parameters): its
+    per-parameter norms and the first 256 elements of every tensor."""
+    store = {}
+    for tag, cfg, shapes, seed0 in (("small", synth.SMALL_MODEL_CFG, RAGGED_SMALL_SHAPES, 300),
+                                    ("full", synth.DEFAULT_MODEL_CFG, RAGGED_FULL_SHAPES, 400)):
+        m, _ = build_reference(cfg, seed=42)
+        m.zero_grad(set_to_none=True)
+        align_fn = AlignmentLoss(positive_weight=POS_W, temperature=TEMP)
+        store[f"{tag}.shapes"] = np.array(shapes, dtype=np.int32)
+        store[f"{tag}.seed0"] = np.array(seed0, dtype=np.int32)
+        losses = []
+        for i, (N, T, L) in enumerate(shapes):
+            inp = synth.make_inputs(cfg, 1, N, T, L, seed0 + i)
+            obj, lang = torch.from_numpy(inp["object_tokens"]), torch.from_numpy(inp["lang_tokens"])
+            labels, pos = torch.from_numpy(inp["labels"]), torch.from_numpy(inp["pos_tokens"])
+            score_map, score_tokens = m(obj, lang)
+            neg = m.negative_token.weight.clone().unsqueeze(0).repeat(1, 1, 1)  # train.py:92
+            weight = torch.ones_like(labels)
+            weight[labels > 0] = POS_W
+            bce = F.binary_cross_entropy_with_logits(input=score_map, target=labels, weight=weight)
+            align = align_fn(object_tokens=score_tokens, labels=labels, pos_tokens=pos, neg_tokens=neg)
+            total = bce + align * ALIGN_W
+            total.backward()  # accumulates into .grad
+            losses.append([total.item(), bce.item(), align.item()])
+            store[f"{tag}.s{i}.score_map"] = score_map.detach().numpy()[0]
+            print(tag, "sample", i, (N, T, L), "loss", losses[-1])
+        store[f"{tag}.loss"] = np.array(losses, dtype=np.float64)
+        for k, p in m.named_parameters():
+            g = p.grad.detach()
+            if tag == "small":
+                store[f"{tag}.gradsum.{k}"] = g.numpy().copy()
+            else:
+                store[f"{tag}.gradsum_norm.{k}"] = np.array(float(g.double().norm()))
+                store[f"{tag}.gradsum_head.{k}"] = g.reshape(-1)[:256].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "ragged_train_golden.npz"), **store)
+    print("ragged_train_golden.npz", os.path.getsize(os.path.join(HERE, "ragged_train_golden.npz")) / 1e6, "MB")
+
+
 def gen_range_golden():
     """Reference outputs for inputs away from N(0,1) and weights away from the default-init scale (the range cases of the
     split-f16 mode): full configuration at the headline shape, outputs only."""
@@ -296,3 +342,5 @@ if __name__ == "__main__":
         gen_model_golden()
     if which in ("all", "range"):
         gen_range_golden()
+    if which in ("all", "ragged_train"):
+        gen_ragged_train_golden()

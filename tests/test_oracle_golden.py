@@ -163,3 +163,29 @@ def test_range_cases_vs_reference():
     for v in ("lin_outliers", "gamma_div256", "gamma_x300"):
         sd = sola_oracle.to_torch_state(synth.make_state_dict_variant(cfg, 42, v))
         check(sd, 1.0, 1.0, g[f"w.{v}.score_map"], g[f"w.{v}.score_tokens"], f"weights {v}", g[f"w.{v}.cond"])
+
+
+def test_accumulated_gradients_of_mixed_shape_samples_small():
+    """tests/golden/ragged_train_golden.npz (gen_golden.py ragged_train): the reference stepped one sample at a time over ten
+    samples of different (N, T, L) with the gradients accumulated.  The oracle, differentiated by autograd, must reproduce the
+    per-sample losses and the summed gradient - it is the checker of the ragged training step on the GPU."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ragged_train_golden.npz"), allow_pickle=False)
+    cfg = synth.SMALL_MODEL_CFG
+    sd = {k: torch.tensor(v, requires_grad=(k != "positional_encoding_gaussian_matrix")) for k, v in synth.make_state_dict(cfg, 42).items()}
+    seed0 = int(g["small.seed0"])
+    for i, (N, T, L) in enumerate(g["small.shapes"]):
+        inp = synth.make_inputs(cfg, 1, int(N), int(T), int(L), seed0 + i)
+        sm, st = sola_oracle.forward(sd, cfg, inp["object_tokens"], inp["lang_tokens"])
+        ls = sola_oracle.losses(sm, st, inp["labels"], inp["pos_tokens"], sd["negative_token.weight"].unsqueeze(0), POS_W, TEMP, ALIGN_W)
+        np.testing.assert_allclose([float(ls[k].detach()) for k in ("total", "bce", "align")], g["small.loss"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(sm.detach().numpy()[0], g[f"small.s{i}.score_map"], rtol=0, atol=1e-4)
+        ls["total"].backward()  # accumulates
+    total = float(np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in g.files if k.startswith("small.gradsum."))))
+    for k, t in sd.items():
+        if not t.requires_grad:
+            continue
+        ref = g["small.gradsum." + k]
+        err = float(np.abs(t.grad.numpy() - ref).max())
+        assert err <= 1e-3 * float(np.abs(ref).max()) + 1e-6 * total, (k, err, float(np.abs(ref).max()))
