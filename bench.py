@@ -31,7 +31,8 @@ The ONE JSON line carries the driver's contract plus (rank 0; the legs after the
                       four expressions per video (the text-independent half runs once per video)
   f16_storage_mode    the 16-bit activation storage mode at the headline shape and at C4 (reduced precision, stated tolerance)
   iou                 the mask-IoU de-dup predicate at its real call sizes (P=4 x R=16/64/256 at 540x960): HBM roofline + CPU
-  training_step       one optimizer step at up to 64 samples, both precisions, with the per-kernel breakdown
+  training_step       one optimizer step at up to 64 samples, three precisions, with the per-kernel breakdown; .ragged = the same
+                      step over 64 samples of DIFFERENT shapes (the MeViS-like mix); .one_sample_per_step = the reference's regime
   cpu_baseline        the PyTorch-CPU oracle (a port of the reference path) timed on this box's host cores
 """
 import argparse
@@ -284,6 +285,40 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
         m.clip_grad_norm_(1.0)
         opt.step()
 
+    # variable-shape samples in ONE step (sola_forward_train_ragged / sola_backward_ragged): the MeViS-like mix of the ragged
+    # inference leg (N~U[8,80], T~U[20,200], L~U[4,24]); objective = mean of the per-sample totals
+    from sola_amd.loss import track_selection_losses_ragged
+
+    S = 64
+    smp = synth.make_ragged_samples(cfg, S, 2024, dev)
+    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    rlabels = torch.cat([x["labels"] for x in smp])
+    rpos = torch.stack([x["pos"] for x in smp])
+    rflops = sum(synth.flops_per_sample(cfg, int(o.shape[0]), int(o.shape[1]), int(t.shape[0]))["total"] for o, t in zip(objs, langs))
+
+    def step_ragged():
+        opt.zero_grad(set_to_none=True)
+        m.forward_ragged(objs, langs)
+        flat, tok, offs, counts = m.last_ragged
+        loss = track_selection_losses_ragged(flat, tok, rlabels, rpos, m.negative_token.weight, offs, counts, POS_W, TEMP, ALIGN_W)
+        loss[:, 0].mean().backward()
+        m.clip_grad_norm_(1.0)
+        opt.step()
+
+    rag = {"samples_per_step": S, "shapes": "N~U[8,80], T~U[20,200], L~U[4,24], seed 2024", "unit": "samples/s",
+           "object_token_rows": int(sum(o.shape[0] * o.shape[1] for o in objs)),
+           "gflop_per_sample_fwd_bwd": round(3 * rflops / S / 1e9, 2),
+           "what": "one optimizer step over 64 samples of different shapes: sola_forward_train_ragged + per-sample losses + "
+                   "sola_backward_ragged + clip + AdamW; dropout on; a sample of this mix costs "
+                   f"{rflops / S / fl['total']:.2f}x the headline shape's FLOPs"}
+    for prec in ("f32", "f16x3", "f16"):
+        m.precision = prec
+        dtr = timed(step_ragged, max(2, steps // 2), sync)
+        _d, profr = profiled(step_ragged, 2, sync, warmup=0)
+        rag[prec] = {"value": round(S / dtr, 1), "ms_per_step": round(dtr * 1e3, 3), "model_tflops": round(3 * rflops / dtr / 1e12, 1),
+                     "kernel_ms_per_step": kernel_ms(profr, 2)}
+    res["ragged"] = rag
+    del smp, objs, langs
     m.precision = "f32"
     dt1 = timed(step1, max(steps, 10), sync)
     res["one_sample_per_step"] = {"value": round(1.0 / dt1, 1), "ms_per_step": round(dt1 * 1e3, 3), "precision": "f32",

@@ -101,7 +101,10 @@ int sola_set_precision(SolaCtx* ctx, int precision);
  * result computed outside the format's range.  enable = 0 keeps the call fully asynchronous (also while the stream is
  * being captured into a graph, where the check is skipped automatically); the words can then be read with
  * sola_split_fallback_count: *count = calls repeated in f32 so far, *last_guard = guard bits of the last checked call
- * (bit 0: a value left the f16 range, bit 1: GroupNorm weights outside the covered magnitude). */
+ * (bit 0: a value left the f16 range, bit 1: GroupNorm weights outside the covered magnitude).  Once bit 1 has been seen for the
+ * current weights, further calls skip the split pass and run the exact-f32 kernels directly (one line on stderr says so) until a
+ * weight changes.  The guard words, their pinned host copy and the precision switch of the repeat belong to the CONTEXT: a
+ * context serves one stream / one host thread at a time (use one context per stream for concurrent calls). */
 int sola_set_split_guard(SolaCtx* ctx, int enable);
 int sola_split_fallback_count(const SolaCtx* ctx, int64_t* count, int32_t* last_guard);
 /* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
@@ -406,8 +409,10 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * stores, 16 = without its LDS transpose;
  * "gemm_nw4", "gemm_pp": experimental four-wave shapes of the persistent split-f16 GEMM (256x128 tiles, one wave per SIMD; gemm_pp with
  * two accumulator sets and the epilogue drained under the next tile), bit-identical to the default, 0 (default) = off;
- * "gemm_gn_fuse": 1 (default) = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM
- * epilogue (batches whose conv outputs fill 256-row tiles, 64 channels per group), 0 = separate GroupNorm launches;
+ * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose
+ * conv outputs fill 256-row tiles, 64 channels per group; ~2 % of the headline step), 0 (default since round 3: the epilogue had two
+ * nondeterministic faults in development whose root cause was never established - contained and stress-tested, but opt-in) =
+ * separate GroupNorm launches;
  * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for
  * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
  * "pack_resample_lds": nearest-resampling mask pack, 1 (default) = source rows staged through LDS / 0 = per-pixel gather;

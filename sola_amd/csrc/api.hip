@@ -442,12 +442,29 @@ int sola_split_guard_tripped(SolaCtx* c, hipStream_t s, bool* tripped) {
     SOLA_HIP(hipMemcpyAsync(c->guard_host, c->guard, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     SOLA_HIP(hipStreamSynchronize(s));
     *tripped = (c->guard_host[0] | c->guard_host[1]) != 0;
+    if (!c->guard_host[1]) c->weight_range_bad = false;  // the current weights are fine (again)
+    if (c->guard_host[1] && !c->weight_range_bad) {
+        // the WEIGHTS put a GroupNorm's output outside the split-f16 pairs' range: every call would run the split pass and then
+        // the exact-f32 repeat (2x the cost) until the weights change - remember it and go straight to f32 from the next call on
+        c->weight_range_bad = true;
+        fprintf(stderr, "sola_hip: GroupNorm weights outside the range of the split-f16 activations (rms of (gamma, beta) not in "
+                        "[2^-6, 2^9]): precision 1 calls run on the exact-f32 kernels until the weights change\n");
+    }
     return SOLA_OK;
 }
+// precision 1 only: the weight-time guard bit is known to be set for the current weights -> skip the split pass
+static bool split_known_out_of_range(const SolaCtx* c) { return c->precision == 1 && c->split_guard && c->weight_range_bad && !c->lin16_dirty; }
 
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
+    if (c && split_known_out_of_range(c)) {
+        c->split_fallbacks += 1;
+        c->precision = 0;
+        const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
+        c->precision = 1;
+        return st;
+    }
     if (c && c->precision >= 1) {
         const int prec = c->precision;
         if (prec == 2) SOLA_TRY(sola_forward_f16_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s));
@@ -488,6 +505,13 @@ extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* la
                                    float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
     try {  // the host-side plan allocates; nothing may throw across the ABI
+        if (c && split_known_out_of_range(c)) {
+            c->split_fallbacks += 1;
+            c->precision = 0;
+            const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
+            c->precision = 1;
+            return st;
+        }
         SOLA_TRY(sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s));
         if (c->precision != 1) return SOLA_OK;
         bool tripped = false;

@@ -82,7 +82,9 @@ __device__ __forceinline__ float half_sum32(float v) {
     // less sum; an opaque copy of the operand does not stop it).  s_nop 1: a VALU result needs two wait states before a
     // permlane reads it, and the hazard recogniser does not look inside asm.
     float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    // ... and a trailing s_nop 1: no wait-state rule is published for a VALU reading a swap's results, the compiler pads one state
+    // behind an asm statement and cannot see what the statement wrote; two more states cost nothing measurable here
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return a + b;
 }
 
@@ -90,7 +92,7 @@ __device__ __forceinline__ float half_sum32(float v) {
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     v = half_sum32(v);
     float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // (lo, lo) and (hi, hi) of two copies
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));  // (lo, lo) and (hi, hi) of two copies
     return a + b;
 }
 

@@ -91,6 +91,7 @@ struct SolaCtx {
     int* guard_host = nullptr;      // pinned, 2 ints
     bool split_guard = true;        // sola_set_split_guard
     long long split_fallbacks = 0;  // calls that were repeated in exact f32
+    bool weight_range_bad = false;  // the weight-time guard bit was seen set for the current weights: precision 1 goes straight to f32
     SolaRagStage* rag_stage = nullptr;
     // Gradient buckets of sola_backward, in the order their gradients become final: layer n-1, ..., layer 1, layer 0 (+ the
     // negative tokens, whose gradient collects contributions from every layer), encoder.  An event is recorded on the

@@ -1291,7 +1291,12 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     return SOLA_OK;
 }
 
-int g_gemm_gn_fuse = 1;  // sola_tune "gemm_gn_fuse": 0 = never apply the encoder norms in the GEMM epilogue (A/B)
+// sola_tune "gemm_gn_fuse": 1 = encoder conv0-2 apply their GroupNorm + LeakyReLU in the GEMM epilogue.  OFF by default (round 3): the
+// fused epilogue showed two nondeterministic corruption faults during development whose cause was never pinned to an instruction
+// (DESIGN.md 5); they are contained (no packed-f32 code: -fno-slp-vectorize + tests/test_host_cpu.py's disassembly check; no exec
+// change in the interior epilogue; the repeatability stress in the GPU suite), but a ~2 % step-time gain does not justify shipping an
+// unexplained fault's containment as the default.
+int g_gemm_gn_fuse = 0;
 void sola_gemm_set_gn_fuse(int v) { g_gemm_gn_fuse = v; }
 int g_gemm_pp = 0;  // experiment (sola_tune "gemm_pp"): 1 = ping-pong kernel where it applies
 int g_gemm_nw4 = 0;  // experiment (sola_tune "gemm_nw4"): plain f32-output launches on 256x128 tiles with four waves, one per SIMD

@@ -6,6 +6,10 @@
 // All reductions are wave-shuffle + LDS trees with a fixed order (deterministic, no atomics).
 #include <algorithm>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "kernels.h"
 
 namespace {
@@ -500,22 +504,27 @@ int g_gn_wide = 1;     // sola_tune "gn_wide": 1024-thread blocks for units of 6
 void sola_gn_set_wide(int v) { g_gn_wide = v; }
 int g_gn_slices = 1;   // sola_tune "gn_slices": 0 = three-pass kernel for units that do not fit the registers (A/B)
 void sola_gn_set_slices(int v) { g_gn_slices = v; }
-// Per-device scratch of the sliced shape (slots of 8 bytes per (unit, slice) block): allocated on first use, grown when a
-// launch needs more; never during stream capture (the launch then takes the three-pass kernel).
+// Library-owned scratch of the sliced shape for callers that pass none (the per-stage entry point; the forward orchestrators hand
+// over a piece of the caller's workspace): one buffer per (device, stream), so launches on different streams never share slots - a
+// stream's launches are ordered among themselves - and a mutex around the table.  Allocated on first use, grown when a launch
+// needs more (after that STREAM has drained: nobody else uses the buffer); never during stream capture (the launch then takes the
+// three-pass kernel).
 static float2* gn_slice_scratch(size_t bytes, hipStream_t s) {
-    static float2* buf[64] = {nullptr};
-    static size_t cap[64] = {0};
+    struct Slot { float2* buf = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Slot> table;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return nullptr;
-    if (cap[dev] >= bytes) return buf[dev];
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Slot& sl = table[std::make_pair(dev, s)];
+    if (sl.cap >= bytes) return sl.buf;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    // a previous launch on another stream may still read the old buffer: wait for the device before replacing it
-    if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
+    if (sl.buf) { (void)hipStreamSynchronize(s); (void)hipFree(sl.buf); sl.buf = nullptr; sl.cap = 0; }
     const size_t want = std::max<size_t>(bytes * 2, (size_t)1 << 20);
-    if (hipMalloc(&buf[dev], want) != hipSuccess) { buf[dev] = nullptr; return nullptr; }
-    cap[dev] = want;
-    return buf[dev];
+    if (hipMalloc(&sl.buf, want) != hipSuccess) { sl.buf = nullptr; return nullptr; }
+    sl.cap = want;
+    return sl.buf;
 }
 void sola_gn_set_variant(int v) { g_gn_variant = v; }
 

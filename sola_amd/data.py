@@ -267,11 +267,23 @@ class DevicePrefetcher:
         q = queue.Queue(maxsize=self.depth)
         stream = _t.cuda.Stream(device=self.device)
         done = object()
+        stop = threading.Event()
+
+        def put(item):  # never blocks for good: a consumer that left (break / exception) sets `stop`
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def work():
             try:
                 _t.cuda.set_device(self.device)
                 for b in self.batches:
+                    if stop.is_set():
+                        return
                     with _t.cuda.stream(stream):
                         vids = []
                         for v in b["videos"]:
@@ -279,25 +291,36 @@ class DevicePrefetcher:
                             vids.append(v.to(self.device, non_blocking=True))
                         ev = _t.cuda.Event()
                         ev.record(stream)
-                    q.put((dict(b, videos=vids), ev))
-                q.put(done)
+                    if not put((dict(b, videos=vids), ev)):
+                        return
+                put(done)
             except BaseException as e:  # surface loader errors in the consumer
-                q.put(e)
+                put(e)
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        while True:
-            item = q.get()
-            if item is done:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            b, ev = item
-            _t.cuda.current_stream(self.device).wait_event(ev)
-            for v in b["videos"]:
-                v.record_stream(_t.cuda.current_stream(self.device))
-            yield b
-        th.join()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                b, ev = item
+                _t.cuda.current_stream(self.device).wait_event(ev)
+                for v in b["videos"]:
+                    v.record_stream(_t.cuda.current_stream(self.device))
+                yield b
+        finally:
+            # the consumer may leave early (break, an exception in its loop body, generator close): release the worker, drop the
+            # batches it already uploaded (a 128-sample batch is ~160 MB of device + pinned memory) and join it
+            stop.set()
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            th.join(timeout=30)
 
 
 def make_ragged_batches(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, model_cfg=None):
@@ -311,6 +334,20 @@ def make_ragged_batches(cfg_dataset: dict, split: str, rank=0, world=1, syntheti
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     idx = list(range(lo, hi)) if world > 1 else shard_indices(n, 0, 1)
     return RaggedBatcher(ds, idx, int(cfg_dataset.get("ragged_max_samples", 128)), int(cfg_dataset.get("ragged_max_rows", 1 << 20))), ds
+
+
+def make_ragged_train_batches(cfg_dataset: dict, rank=0, world=1, synthetic=None, model_cfg=None, samples_per_step=64, epoch=0):
+    """Ragged TRAINING batches of one epoch for this rank: the train split shuffled with a seed every rank derives from the
+    epoch, sharded i % world == rank with the short shards padded (every rank must issue the same number of optimizer steps:
+    each ends in one gradient all-reduce), cut into batches of exactly ``samples_per_step`` samples (the last one shorter) -
+    bounded by the sample count only, so all ranks see the same number of batches."""
+    from .dist import shard_indices
+
+    ds = make_dataset(cfg_dataset, "train", synthetic, model_cfg)
+    n = len(ds)
+    order = np.random.Generator(np.random.PCG64(1234567 + int(epoch))).permutation(n).tolist()
+    mine = [order[i] for i in shard_indices(n, rank, world, pad=True)]
+    return RaggedBatcher(ds, mine, int(samples_per_step), max_rows=1 << 62), ds
 
 
 def collate(batch):

@@ -86,8 +86,8 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, average=True)
 
 def allreduce_gradient_arena(module, world=None, average=True, overlap=True):
     """The training step's one collective, in place and overlapped: the module keeps all gradients in ONE flat arena laid
-    out in the order sola_backward finishes them (layer n-1 ... layer 0 + negative tokens, encoder: n_layers + 1 buckets of
-    30-50 MB at the default size - xGMI is point-to-point, so few large messages).  Called right after ``loss.backward()``
+    out in the order sola_backward finishes them (layer n-1 ... layer 0, encoder: n_layers + 1 buckets of 30-50 MB at the
+    default size; negative_token.weight, whose gradient autograd completes later on the caller's stream, sits behind them - xGMI is point-to-point, so few large messages).  Called right after ``loss.backward()``
     has ENQUEUED the backward, it makes a side stream wait (device-side) for each bucket's completion event and issues that
     bucket's all-reduce there, so the layer buckets travel while the encoder's backward still runs; the caller's stream
     then waits for the side stream.  Every rank issues the same collectives in the same order.  Returns their number.
@@ -122,12 +122,17 @@ def allreduce_gradient_arena(module, world=None, average=True, overlap=True):
                     flat.div_(world)
     if overlap:
         main.wait_stream(side)
-    # A parameter that also receives gradient from outside the network - negative_token.weight feeds the alignment loss
-    # directly (train.py:92) - gets the SUM of both paths from autograd in a tensor of its own, not in its arena slot:
-    # those few (128 KB) take a plain all-reduce on the caller's stream.
-    stragglers = [p for key, p in module.named_parameters()
-                  if p.grad is not None and p.grad.data_ptr() != module._grad_view(key).data_ptr()]
-    n_extra = allreduce_gradients(stragglers, world, average=average) if stragglers else 0
+    # Parameters with a gradient path outside the network - negative_token.weight feeds the alignment loss directly
+    # (train.py:92) - live behind the last bucket, outside every bucket's range (module._grad_layout): autograd adds the loss's
+    # gradient to that slot on the caller's stream after the backward, possibly into a tensor of its own.  Whatever tensor
+    # holds the parameter's gradient now is reduced HERE, on the caller's stream, behind that add (128 KB).
+    tail = set(getattr(module, "_grad_tail", []))
+    named = dict(module.named_parameters())
+    extra = [named[k] for k in tail if named[k].grad is not None]
+    # ... and anything else autograd moved out of its arena slot (a parameter used twice)
+    extra += [p for key, p in named.items() if key not in tail and p.grad is not None
+              and p.grad.data_ptr() != module._grad_view(key).data_ptr()]
+    n_extra = allreduce_gradients(extra, world, average=average) if extra else 0
     module._last_grad_sq = None  # (the in-place collective also bumped the arena's version counter, which every view shares)
     return len(buckets) + n_extra
 

@@ -404,12 +404,19 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         if getattr(self, "_grad_arena", None) is not None and self._grad_arena.device == dev and self._grad_ctx is self._ctx:
             return
         nb = lib().sola_grad_bucket_count(self._ctx)
+        # Parameters that ALSO receive gradient from outside the network go behind the last bucket, outside every bucket's flat
+        # range: negative_token.weight feeds the alignment loss directly (train.py:92), so autograd ADDS the loss's gradient to
+        # this slot on the caller's stream after the whole backward - an in-place collective on a side stream must never cover
+        # the slot (it raced with that add: ranks could disagree on whether the add saw the slot before or after the collective,
+        # and every rank then ended with the same WRONG gradient).  The tail is reduced on the caller's stream
+        # (sola_amd/dist.py: allreduce_gradient_arena).
+        tail_keys = {"negative_token.weight"}
         order = []
         for key, p in named:
             b = lib().sola_grad_bucket_of(self._ctx, key.encode())
             if b < 0:
                 check(b, f"sola_grad_bucket_of({key})")
-            order.append((b, len(order), key, p))
+            order.append((nb if key in tail_keys else b, len(order), key, p))
         order.sort(key=lambda t: (t[0], t[1]))
         off, spans, starts = 0, [], {}
         for b, _i, key, p in order:
@@ -418,8 +425,9 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             off += (p.numel() + 63) // 64 * 64
         self._grad_arena = torch.zeros(off, device=dev, dtype=torch.float32)
         self._grad_spans = {key: (o, n, shape) for key, o, n, shape in spans}
-        bounds = [starts[b] for b in range(nb)] + [off]
+        bounds = [starts[b] for b in range(nb)] + [starts.get(nb, off)]
         self._grad_buckets = [(bounds[b], bounds[b + 1]) for b in range(nb)]
+        self._grad_tail = sorted(tail_keys & set(self._grad_spans))
         self._bind_grad_arena()
         self._grad_ctx = self._ctx
 

@@ -159,6 +159,28 @@ def make_inputs(cfg, B, N, T, L, seed=0, pos_rate=0.2):
     return {"object_tokens": obj, "lang_tokens": lang, "labels": labels, "pos_tokens": pos}
 
 
+def make_ragged_samples(cfg, n_samples, seed=2024, device=None, n_range=(8, 80), t_range=(20, 200), l_range=(4, 24), pos_rate=0.2):
+    """A MeViS-like mix of variable-shape samples (every real sample has its own N tracks, T frames, L text tokens:
+    dataloader.py:119-163, 187-199): N ~ U[8,80], T ~ U[20,200], L ~ U[4,24], seeded.  Returns a list of dicts of torch
+    tensors {obj [N,T,d], lang [L,D], labels [N], pos [D]} (pos = mean of the text tokens, train.py:86-90)."""
+    import torch
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, D = cfg["object_token_dim"], cfg["lang_token_dim"]
+    out = []
+    for _ in range(n_samples):
+        N, T, L = (int(rng.integers(lo, hi + 1)) for lo, hi in (n_range, t_range, l_range))
+        obj = rng.standard_normal(size=(N, T, d)).astype(np.float32)
+        lang = rng.standard_normal(size=(L, D)).astype(np.float32)
+        labels = (rng.uniform(size=N) < pos_rate).astype(np.float32)
+        pos = lang.astype(np.float64).mean(axis=0).astype(np.float32)
+        smp = {"obj": torch.from_numpy(obj), "lang": torch.from_numpy(lang), "labels": torch.from_numpy(labels), "pos": torch.from_numpy(pos)}
+        if device is not None:
+            smp = {k: v.to(device) for k, v in smp.items()}
+        out.append(smp)
+    return out
+
+
 def t_out_lengths(T):
     """Frame count after each encoder conv (three stride-2 k=3 p=1 convs, then stride 1)."""
     lens = []

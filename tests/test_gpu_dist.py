@@ -63,6 +63,11 @@ def _worker(rank, world, port, q, overlap):
         # autograd sums with the alignment loss's direct contribution into a tensor of its own
         outside = [k for k, p in m.named_parameters() if p.grad.data_ptr() != m._grad_view(k).data_ptr()]
         assert m._grads_in_arena and outside == ["negative_token.weight"], outside
+        # ... and its arena slot lies outside every bucket's flat range: the overlapped in-place collectives on the side stream
+        # never touch memory that autograd's add on the main stream reads (that was a race)
+        o, cnt, _shape = m._grad_spans["negative_token.weight"]
+        assert all(not (a < o + cnt and o < b) for a, b in m._grad_buckets), (o, cnt, m._grad_buckets)
+        assert m._grad_buckets[-1][1] <= o
         n = sdist.allreduce_gradient_arena(m, world, overlap=overlap)
         assert n == cfg["n_layers"] + 2  # the arena's buckets + one small collective for the straggler
         gnd = m.get_grad_norm_dict()
@@ -148,3 +153,13 @@ def test_train_py_two_ranks_odd_sample_count(tmp_path):
     shas = [ln.split()[-1] for ln in r.stdout.splitlines() if "weights sha256" in ln]
     assert len(shas) == 2 and shas[0] == shas[1], r.stdout[-1500:]
     assert "EPOCH 1" in r.stdout
+    # the same with RAGGED optimizer steps: 9 variable-shape samples on 2 ranks, 4 samples per step -> 5 per rank (padded shard)
+    # = two steps per rank, each ending in the gradient all-reduce
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), "--config", "mevis/default", "--synthetic", "true",
+                        "--synthetic_samples", "9", "--synthetic_ragged", "true", "--samples_per_step", "4", "--n_epochs_override", "1"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    shas = [ln.split()[-1] for ln in r.stdout.splitlines() if "weights sha256" in ln]
+    assert len(shas) == 2 and shas[0] == shas[1], r.stdout[-1500:]
+    assert "4 samples per step" in r.stdout

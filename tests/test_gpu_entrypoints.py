@@ -61,6 +61,26 @@ def test_train_eval_inference_roundtrip(tmp_path):
         np.testing.assert_array_equal(preds["one"][k], preds["many"][k], err_msg=k)
 
 
+def test_train_on_ragged_batches(tmp_path):
+    """train.py --samples_per_step 8 on a mix of shapes (N in [8,80], T in [20,200]): three ragged optimizer steps per epoch
+    over 20 samples (8 + 8 + 4), the validation pass, a finite checkpoint that moved."""
+    os.makedirs(tmp_path / "configs" / "mevis")
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "mevis", "default.yaml")))
+    cfg["dataset"]["track_root"] = str(tmp_path / "no_such_dir")
+    yaml.safe_dump(cfg, open(tmp_path / "configs" / "mevis" / "default.yaml", "w"))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    args = ["--config", "mevis/default", "--synthetic", "true", "--synthetic_samples", "20", "--synthetic_ragged", "true",
+            "--samples_per_step", "8", "--n_epochs_override", "2"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "EPOCH 2" in r.stdout and "8 samples per step" in r.stdout, r.stdout[-800:]
+    wdir = tmp_path / "SOLA" / "TRAIN" / "default" / "mevis"
+    sd1 = torch.load(wdir / "epoch_1.pth", map_location="cpu", weights_only=True)
+    sd2 = torch.load(wdir / "epoch_2.pth", map_location="cpu", weights_only=True)
+    assert all(torch.isfinite(v).all() for v in sd2.values())
+    assert any(not torch.equal(sd1[k], sd2[k]) for k in sd1)
+
+
 def test_bench_two_ranks_code_path(tmp_path):
     """bench.py under torch.distributed.run with 2 ranks (gloo, both on cuda:0 - RCCL refuses two ranks per device): the
     barrier / max-over-ranks / whole-job aggregation path the driver uses at N > 1 prints one well-formed JSON line."""

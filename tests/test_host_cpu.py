@@ -150,3 +150,34 @@ def test_build_recipe_keeps_the_flags_the_kernels_were_validated_with():
     hdr = open(os.path.join(root, "include", "sola_hip.h")).read()
     n_cat = int(re.search(r"SOLA_PROF_NCAT\s*=\s*(\d+)", hdr).group(1))
     assert n_cat == len(_lib.PROF_CATEGORIES) and _lib.PROF_CATEGORIES[-1] == "gemm_split256_gn"
+
+
+def test_split_gemm_code_object_has_no_packed_f32_and_the_fused_norm_is_opt_in():
+    """the fused conv + GroupNorm epilogue returned nondeterministic wrong rows when the SLP vectoriser packed its
+    statistics into v_pk_*_f32.  Containment is a compiler flag, so the BUILT code object is checked: no packed-f32
+    instruction anywhere in gemm_glds.hip's kernels.  And the fused epilogue is opt-in (sola_tune "gemm_gn_fuse")."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "sola_amd", "csrc", "gemm_glds.hip")).read()
+    assert re.search(r"^int g_gemm_gn_fuse = 0;", src, re.M)
+    obj = os.path.join(root, "build", "obj", "gemm_glds.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("gemm_glds.o not built here (run __graft_entry__.build()) or no llvm-objdump")
+    tmp = tempfile.mkdtemp()
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gemm_glds.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(tmp, "copy.o")], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+                        f"--output={co}", "--unbundle"], check=True)
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kernels = re.findall(r"^[0-9a-f]+ <(\S*gemm_nt_split_glds_persist_kernel\S*)>:", dis, re.M)
+    assert len(kernels) >= 8, kernels
+    assert "v_mfma_f32_32x32x16_f16" in dis.replace("-", "_") or "v_mfma_f32_32x32x16" in dis
+    packed = sorted(set(re.findall(r"\bv_pk_\w+_f32\b", dis)))
+    assert not packed, f"packed-f32 instructions in gemm_glds.hip's code object: {packed}"

@@ -2,8 +2,14 @@
 """Training entry point with the reference's CLI / YAML / checkpoint layout (train.py of cvlab-kaist/SOLA), running
 the track-selection network, its losses, backward, gradient norms and clipping in libsola_hip.so.
 
-    python train.py --config mevis/default [--n_epochs_override 1] [--synthetic true]
+    python train.py --config mevis/default [--n_epochs_override 1] [--synthetic true] [--samples_per_step 64]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config mevis/default
+
+``--samples_per_step K`` (K > 1) trains on ragged batches: K (video, expression) samples of DIFFERENT shapes per optimizer step,
+the step's objective the mean of the per-sample losses (run_train_ragged).  The default, 1, is the reference's loop
+(configs/mevis/default.yaml:37): one sample per step.  Averaging K gradients before one AdamW update is not K batch-1 updates:
+re-tune ``train.lr`` for K > 1 (AdamW's update size is set by lr, not by the gradient scale, so K-fold fewer updates per epoch at
+the reference's lr train K-fold slower per epoch).
 
 One process per GPU; samples are sharded i % world == rank; the only collective is the RCCL all-reduce (average) of
 the 32.98M-element gradient before get_grad_norm_dict()/clipping, so every rank clips and steps identically
@@ -19,7 +25,7 @@ import torch
 
 from sola_amd import dist as sdist
 from sola_amd.config import load_configs
-from sola_amd.data import make_loader, make_ragged_batches, DevicePrefetcher
+from sola_amd.data import make_loader, make_ragged_batches, make_ragged_train_batches, DevicePrefetcher
 from sola_amd.loss import track_selection_losses, track_selection_losses_ragged
 from sola_amd.module import LanguageAlignedTrackSelectionModule
 from sola_amd.text import TextEncoder
@@ -71,6 +77,42 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
     n_tot = max(stats[7], 1.0)
     return {"total": stats[0] / n_tot, "bce": stats[1] / n_tot, "alignment": stats[2] / n_tot, "tp": stats[3], "fp": stats[4],
             "fn": stats[5], "tn": stats[6], "samples_per_s": n_smp / max(time.time() - t_loop, 1e-9)}
+
+
+def run_train_ragged(module, text, batches, tcfg, device, optimizer, world=1):
+    """One epoch of optimizer steps over RAGGED batches: up to ``train.samples_per_step`` (video, expression) samples of
+    different (N, T, L) per step (sola_forward_train_ragged / sola_backward_ragged).  The reference steps once per sample
+    (configs/mevis/default.yaml:37 batch_size 1, train.py:62-137); here a step minimises the MEAN over the batch of the
+    per-sample totals of train.py:98-113 (each a mean over the sample's own tracks), i.e. its gradient is the average of the
+    gradients the reference's next K batch-1 steps would start from, followed by ONE clipped AdamW update instead of K.
+    With world > 1 the ranks' averages are averaged again by the all-reduce (effective batch K x world)."""
+    pw, temp, aw = tcfg["positive_weight"], tcfg["temperature"], tcfg["alignment_weight"]
+    module.train(True)
+    sums = torch.zeros(3, device=device)
+    n = n_smp = 0
+    t_loop = time.time()
+    for batch in DevicePrefetcher(batches, device):  # the next batch's tokens are uploaded while this one trains
+        texts, pos = text.encode_ragged([s["expression"] for s in batch["samples"]])
+        labels = torch.cat([(s["labels"][tcfg["positive_metric"]] > tcfg["positive_threshold"]).float() for s in batch["samples"]]).to(device)
+        module.forward_ragged(batch["videos"], texts, batch["sample_video"])  # train mode + grad enabled: the differentiable path
+        flat, tok, offs, counts = module.last_ragged
+        loss = track_selection_losses_ragged(flat, tok, labels, pos, module.negative_token.weight, offs, counts, pw, temp, aw)
+        optimizer.zero_grad(set_to_none=True)
+        loss[:, 0].mean().backward()
+        sdist.allreduce_gradient_arena(module, world)
+        if tcfg["grad_clip_norm"] > 0:
+            module.clip_grad_norm_(tcfg["grad_clip_norm"])
+        optimizer.step()
+        sums += loss.detach().sum(0)
+        n += len(counts)
+        n_smp += len(counts)
+    stats = torch.cat([sums, torch.zeros(4, device=device), torch.tensor([float(n)], device=device)])
+    if world > 1:
+        torch.distributed.all_reduce(stats)
+    stats = stats.cpu().tolist()  # the loop's only host sync
+    n_tot = max(stats[7], 1.0)
+    return {"total": stats[0] / n_tot, "bce": stats[1] / n_tot, "alignment": stats[2] / n_tot, "tp": 0.0, "fp": 0.0, "fn": 0.0, "tn": 0.0,
+            "samples_per_s": n_smp / max(time.time() - t_loop, 1e-9)}
 
 
 @torch.no_grad()
@@ -130,9 +172,16 @@ def train(cfg):
     optimizer = torch.optim.AdamW(module.parameters(), lr=tcfg["lr"], fused=torch.cuda.is_available())
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=tcfg["lr_factor"], patience=tcfg["lr_patience"])
     n_epochs = int(cfg.get("n_epochs_override", tcfg["n_epochs"]))
+    # --samples_per_step K (default: dataset.train.batch_size = 1, the reference's): K > 1 trains on ragged batches of K
+    # variable-shape samples per optimizer step (run_train_ragged); K = 1 is the reference's loop, one sample per step
+    per_step = int(cfg.get("samples_per_step", tcfg.get("samples_per_step", cfg["dataset"]["train"].get("batch_size", 1))))
     for epoch in range(n_epochs):
         t0 = time.time()
-        tr = run_split(module, text, train_loader, tcfg, device, True, optimizer, world)
+        if per_step > 1:
+            batches, _ = make_ragged_train_batches(cfg["dataset"], rank, world, synthetic, cfg["model"], per_step, epoch)
+            tr = run_train_ragged(module, text, batches, tcfg, device, optimizer, world)
+        else:
+            tr = run_split(module, text, train_loader, tcfg, device, True, optimizer, world)
         va = run_split_ragged(module, text, valid_batches, tcfg, device, world)
         scheduler.step(va["total"])
         if rank == 0:
@@ -140,7 +189,8 @@ def train(cfg):
             rec = va["tp"] / max(va["tp"] + va["fn"], 1.0)
             line = (f"EPOCH {epoch + 1} | train total {tr['total']:.4f} bce {tr['bce']:.4f} align {tr['alignment']:.4f} | "
                     f"valid total {va['total']:.4f} bce {va['bce']:.4f} align {va['alignment']:.4f} | precision {prec:.4f} "
-                    f"recall {rec:.4f} | {time.time() - t0:.1f} s | train {tr['samples_per_s']:.0f} samples/s/rank incl. data + text")
+                    f"recall {rec:.4f} | {time.time() - t0:.1f} s | train {tr['samples_per_s']:.0f} samples/s/rank incl. data + text"
+                    + (f" ({per_step} samples per step)" if per_step > 1 else ""))
             print(line, flush=True)
             with open(os.path.join(cfg["results"]["output_dir"], "log.txt"), "a") as f:
                 f.write(line + "\n")
