@@ -475,7 +475,10 @@ def iou_leg(dev, cpu_seconds):
         if R <= 64:
             ri, ru = iou_oracle.iou_matrix(A, Bm)
             assert np.array_equal(inter.cpu().numpy(), ri) and np.array_equal(union.cpu().numpy(), ru)
-        dt, prof = profiled(lambda: seg_utils.mask_iou_matrix(a, b), 50, sync, warmup=5)
+        # wall time WITHOUT the in-library event profiler (its two event records per launch cost a multi-launch call ~20 us:
+        # round 2 reported 48 us for the three-launch R=64 call that takes 25 us), kernel time from a second, profiled loop
+        dt = timed(lambda: seg_utils.mask_iou_matrix(a, b), 200, sync, warmup=5)
+        _dtp, prof = profiled(lambda: seg_utils.mask_iou_matrix(a, b), 50, sync, warmup=2)
         k_ms = (prof["iou_pack"]["ms"] + prof["iou_pair"]["ms"]) / 50
         nbytes = (P + R) * H * W
         res["cases"].append({"R": R, "pairs": P * R, "call_us_wall": round(dt * 1e6, 1), "kernels_us": round(k_ms * 1e3, 1),

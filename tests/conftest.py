@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The library's default arithmetic is the range-guarded split-f16 mode ("f16x3", sola_amd/module.py).  The parity tests state the
+# mode they test; modules they build without saying so are the exact-f32 baseline.  Entry-point tests (subprocesses) drop this
+# variable again and run the real default.
+os.environ.setdefault("SOLA_PRECISION", "f32")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -145,6 +145,7 @@ def test_train_py_two_ranks_odd_sample_count(tmp_path):
     cfg["dataset"]["track_root"] = str(tmp_path / "no_such_dir")
     yaml.safe_dump(cfg, open(tmp_path / "configs" / "mevis" / "default.yaml", "w"))
     env = dict(os.environ, PYTHONPATH=ROOT, SOLA_DIST_BACKEND="gloo")
+    env.pop("SOLA_PRECISION", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), "--config", "mevis/default", "--synthetic", "true",
                         "--synthetic_samples", "7", "--synthetic_tracks", "8", "--synthetic_frames", "16", "--n_epochs_override", "1"],

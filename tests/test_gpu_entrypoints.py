@@ -19,6 +19,7 @@ def test_train_eval_inference_roundtrip(tmp_path):
     cfg["dataset"]["track_root"] = str(tmp_path / "no_such_dir")
     yaml.safe_dump(cfg, open(tmp_path / "configs" / "mevis" / "default.yaml", "w"))
     env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("SOLA_PRECISION", None)  # the entry points' own default (f16x3)
     common = ["--config", "mevis/default", "--synthetic", "true", "--synthetic_samples", "6", "--synthetic_tracks", "8", "--synthetic_frames", "16"]
 
     def run(script, *extra):
@@ -69,6 +70,7 @@ def test_train_on_ragged_batches(tmp_path):
     cfg["dataset"]["track_root"] = str(tmp_path / "no_such_dir")
     yaml.safe_dump(cfg, open(tmp_path / "configs" / "mevis" / "default.yaml", "w"))
     env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("SOLA_PRECISION", None)  # the entry points' own default (f16x3)
     args = ["--config", "mevis/default", "--synthetic", "true", "--synthetic_samples", "20", "--synthetic_ragged", "true",
             "--samples_per_step", "8", "--n_epochs_override", "2"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
@@ -85,6 +87,7 @@ def test_bench_two_ranks_code_path(tmp_path):
     """bench.py under torch.distributed.run with 2 ranks (gloo, both on cuda:0 - RCCL refuses two ranks per device): the
     barrier / max-over-ranks / whole-job aggregation path the driver uses at N > 1 prints one well-formed JSON line."""
     env = dict(os.environ, PYTHONPATH=ROOT, SOLA_BENCH_BACKEND="gloo")
+    env.pop("SOLA_PRECISION", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--batch", "4", "--cpu-seconds", "0"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)

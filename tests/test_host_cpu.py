@@ -181,3 +181,12 @@ def test_split_gemm_code_object_has_no_packed_f32_and_the_fused_norm_is_opt_in()
     assert "v_mfma_f32_32x32x16_f16" in dis.replace("-", "_") or "v_mfma_f32_32x32x16" in dis
     packed = sorted(set(re.findall(r"\bv_pk_\w+_f32\b", dis)))
     assert not packed, f"packed-f32 instructions in gemm_glds.hip's code object: {packed}"
+
+
+def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
+    """What bench.py's headline measures is what a user of the classes and entry points gets."""
+    monkeypatch.delenv("SOLA_PRECISION", raising=False)
+    m = LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG)
+    assert m.precision == "f16x3" and m.split_guard is True
+    monkeypatch.setenv("SOLA_PRECISION", "f32")
+    assert LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG).precision == "f32"
