@@ -33,6 +33,8 @@ The ONE JSON line carries the driver's contract plus (rank 0; the legs after the
   iou                 the mask-IoU de-dup predicate at its real call sizes (P=4 x R=16/64/256 at 540x960): HBM roofline + CPU
   training_step       one optimizer step at up to 64 samples, three precisions, with the per-kernel breakdown; .ragged = the same
                       step over 64 samples of DIFFERENT shapes (the MeViS-like mix); .one_sample_per_step = the reference's regime
+  training_step_dist  --gpus N > 1 only: the training step on every rank with the gradient all-reduce overlapped / not overlapped /
+                      left out, the all-reduce alone (ms, bus GB/s), and a ragged inference batch per rank
   cpu_baseline        the PyTorch-CPU oracle (a port of the reference path) timed on this box's host cores
 """
 import argparse
@@ -328,6 +330,90 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
     return res
 
 
+def dist_legs(cfg, sd, dev, world, rank, steps):
+    """--gpus N > 1, after the timed region, every rank: (a) the training step with the path's ONE collective - the all-reduce of the
+    131.9 MB gradient arena (train.py under torchrun; SURVEY 8e, BASELINE config C2) - with the per-bucket overlap on and off, and
+    the all-reduce alone; (b) a ragged inference batch per rank (per-video sharding, no collective).  Times are max over ranks."""
+    import torch.distributed as dist
+
+    from sola_amd import dist as sdist
+    from sola_amd import synth
+    from sola_amd.loss import track_selection_losses, track_selection_losses_ragged
+    from sola_amd.module import LanguageAlignedTrackSelectionModule
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_all(fn, n, warmup=2):
+        for _ in range(warmup):
+            fn()
+        dist.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dist.barrier(); torch.cuda.synchronize(dev)
+        return max_over_ranks((time.perf_counter() - t0) / n)
+
+    B, N, T, L = 64, 64, 32, 16
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m = m.to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5, fused=True)
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(cfg, B, N, T, L, 7000 + rank).items()}
+    state = {"overlap": True, "reduce": True}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        sm, st = m(inp["object_tokens"], inp["lang_tokens"])
+        neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+        track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)[0].backward()
+        if state["reduce"]:
+            sdist.allreduce_gradient_arena(m, world, overlap=state["overlap"])
+        m.clip_grad_norm_(1.0)
+        opt.step()
+
+    res = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "precision": m.precision, "samples_per_rank_per_step": B,
+           "what": "forward_train + losses + backward + all-reduce (AVG) of the flat gradient arena + clip + AdamW on every rank; "
+                   "the buckets of the arena are reduced in place on a side stream as sola_backward completes them (overlap) or after it"}
+    for tag, ov, red in (("overlap", True, True), ("no_overlap", False, True), ("no_collective", True, False)):
+        state["overlap"], state["reduce"] = ov, red
+        dt = timed_all(step, steps)
+        res[tag] = {"ms_per_step": round(dt * 1e3, 3), "value": round(world * B / dt, 1), "unit": "samples/s (all ranks)"}
+    flat = torch.cat([b.reshape(-1) for b in m.grad_buckets()]) if getattr(m, "_grad_arena", None) is None else m._grad_arena
+    nbytes = flat.numel() * 4
+
+    def ar():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    dta = timed_all(ar, max(3, steps))
+    res["allreduce_alone"] = {"bytes": int(nbytes), "ms": round(dta * 1e3, 3), "algbw_GBps": round(nbytes / dta / 1e9, 2),
+                              "busbw_GBps": round(2 * (world - 1) / world * nbytes / dta / 1e9, 2),
+                              "exposed_ms_with_overlap": round((res["overlap"]["ms_per_step"] - res["no_collective"]["ms_per_step"]), 3),
+                              "exposed_ms_without_overlap": round((res["no_overlap"]["ms_per_step"] - res["no_collective"]["ms_per_step"]), 3)}
+    del opt
+    # (b) ragged inference, one batch per rank
+    m.eval()
+    S = 64
+    smp = synth.make_ragged_samples(cfg, S, 3000 + rank, dev)
+    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    labels = torch.cat([x["labels"] for x in smp]); pos = torch.stack([x["pos"] for x in smp])
+
+    def rstep():
+        with torch.no_grad():
+            m.forward_ragged(objs, langs)
+            flat_sm, tok, offs, counts = m.last_ragged
+            track_selection_losses_ragged(flat_sm, tok, labels, pos, m.negative_token.weight, offs, counts, POS_W, TEMP, ALIGN_W)
+
+    dtr = timed_all(rstep, steps)
+    res["ragged_inference"] = {"samples_per_rank_per_launch": S, "shapes": "N~U[8,80], T~U[20,200], L~U[4,24], seed 3000 + rank",
+                               "ms_per_launch": round(dtr * 1e3, 3), "value": round(world * S / dtr, 1), "unit": "samples/s (all ranks)"}
+    del m
+    torch.cuda.empty_cache()
+    return res
+
+
 def stress_leg(cfg, m, dev, precision, steps):
     """BASELINE config C4: long-video stress T=128, N=128 (T'=16, 2048 tokens per sample), 32 samples per step."""
     from sola_amd import ops, synth
@@ -592,6 +678,7 @@ def main():
     # transparency leg (after the timed region, N=1 only): the same workload on the exact-f32 MFMA path with its own
     # roofline entries, and the largest difference between the two modes' logits on this batch
     exact = None
+    parity = None
     if args.precision == "f16x3" and world == 1:
         with torch.no_grad():
             sm_split, _ = m(obj, lang)
@@ -600,12 +687,33 @@ def main():
         dt32, prof32 = profiled(step, k, sync)
         with torch.no_grad():
             sm_f32, _ = m(obj, lang)
+        # parity of the benched batch itself: EVERY row of this rank-0 batch against the fp32 PyTorch-CPU oracle, both modes
+        # (~8 s of host time at 256 samples; skipped with --cpu-seconds 0)
+        err = None
+        if args.cpu_seconds > 0 and B * N * T <= 256 * 64 * 32:
+            from oracle import sola_oracle  # checker only
+
+            torch.set_num_threads(min(32, os.cpu_count() or 1))
+            tsd = sola_oracle.to_torch_state(sd)
+            ref = np.concatenate([sola_oracle.forward(tsd, cfg, inp["object_tokens"][b:b + 16], inp["lang_tokens"][b:b + 16])[0].numpy()
+                                  for b in range(0, B, 16)])
+            err = {}
+            for tag, got in (("f16x3", sm_split), ("f32", sm_f32)):
+                e_rows = np.abs(got.cpu().numpy() - ref).max(axis=1)
+                err[tag] = {"max_abs_logit_err_vs_oracle": float(e_rows.max()), "mean_row_max_err": float(e_rows.mean()),
+                            "rows_above_5e-4": int((e_rows > 5e-4).sum()), "rows": int(B),
+                            "selections_equal": bool(np.array_equal(got.cpu().numpy() > 0, ref > 0))}
         exact = {"value": round(B / dt32, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt32, 4), "steps": k, "dtype": "f32",
                  "roofline": gemm_roofline(prof32, "f32", dt32, k), "roofline_attention": attn_roofline(prof32),
                  "kernel_ms_per_step": kernel_ms(prof32, k),
-                 "max_abs_logit_diff_vs_split_mode": float((sm_f32 - sm_split).abs().max())}
+                 "max_abs_logit_diff_vs_split_mode": float((sm_f32 - sm_split).abs().max()),
+                 **({"max_abs_logit_err_vs_oracle": err["f32"]} if err else {})}
+        parity = err["f16x3"] if err else None
         m.precision = args.precision
 
+    dist_res = None
+    if world > 1 and args.train_steps > 0:  # every rank takes part (collectives); reported by rank 0
+        dist_res = dist_legs(cfg, sd, dev, world, rank, max(2, min(args.train_steps, 5)))
     if rank == 0:
         fl = synth.flops_per_sample(cfg, N, T, L)
         step_s = elapsed / args.steps
@@ -653,6 +761,8 @@ def main():
         }
         if args.precision == "f16x3":
             out["split_guard"] = {"enabled": bool(m.split_guard), "calls_repeated_in_f32": fallbacks, "guard_bits_last_call": guard_bits}
+        if parity is not None:  # every row of the timed batch against the fp32 oracle (the headline mode; exact_f32_mode carries its own)
+            out["max_abs_logit_err_vs_oracle"] = parity
         if exact is not None:
             out["exact_f32_mode"] = exact
         if world == 1 and args.extra_legs:
@@ -661,6 +771,8 @@ def main():
             out["ragged"] = ragged_leg(cfg, m, dev, k, out["model_tflops"])
             out["iou"] = iou_leg(dev, args.cpu_seconds)
             out["f16_storage_mode"] = f16_storage_leg(cfg, m, dev, k)
+        if dist_res is not None:
+            out["training_step_dist"] = dist_res
         if world == 1 and args.train_steps > 0:
             out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps)
         if world == 1 and args.cpu_seconds > 0:

@@ -51,7 +51,7 @@ constexpr int LDP = 36;  // LDS row pitch in floats (144 B: 16-byte aligned, con
 //          cost.  Bytes per element, tile staging and LDS layout are identical to ARITH 0 (a k16 MFMA step consumes
 //          two 32-byte blocks; lanes 0-31 take the first, lanes 32-63 the second - exactly the MFMA A/B fragment).
 template <int BM, int BN, int PIPE, int ARITH>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {  // two blocks per CU (their LDS allows exactly that): <= 256 registers
     constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte loads per thread per operand per k-tile
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -174,6 +174,38 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Exact-f32 arithmetic only: the MFMA chain rounds after every product, so one accumulator summed over K = 1024 ... 3072
+    // carries a random walk of ~sqrt(K/2) roundings of the running sum (the 256-sample batch sat 9.9e-4 from the fp32 oracle, the
+    // split-f16 mode - whose f16 MFMA rounds once per 16 products - 4.3e-4).  Two levels instead: `acc` collects FOLD k-tiles (128
+    // values of k), then is added to `outer` and cleared - sqrt(64) + sqrt(K/128) roundings instead of sqrt(K/2), in a fixed order
+    // (deterministic), for 64 extra VGPRs (the kernel runs two waves per SIMD on its LDS footprint: 256 are available) and one
+    // v_add per 32 MFMAs.
+    constexpr int FOLD = 4;
+    f32x16 outer[ARITH == 0 ? TM : 1][ARITH == 0 ? TN : 1];
+    if constexpr (ARITH == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) outer[i][j][r] = 0.f;
+    }
+    auto fold = [&](int done_tiles, bool last) {  // after `done_tiles` k-tiles of this block's range
+        if constexpr (ARITH == 0) {
+            if (last || done_tiles % FOLD == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            outer[i][j][r] += acc[i][j][r];
+                            acc[i][j][r] = last ? outer[i][j][r] : 0.f;
+                        }
+            }
+        }
+    };
+
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) << 2;
     const int nk = (a.K + BK - 1) / BK;
@@ -244,6 +276,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
             const int buf = (kt - ktb) & 1;
             if (kt + 1 < kte) load_tile((kt + 1) * BK);
             compute(buf, 0, BK / 8);
+            fold(kt - ktb + 1, kt + 1 == kte);
             if (kt + 1 < kte) store_tile(buf ^ 1);
             __syncthreads();
         }
@@ -260,6 +293,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs a) {
             if (kt + 1 < kte) store_tile(buf ^ 1);
             if (kt + 2 < kte) load_tile((kt + 2) * BK);
             compute(buf, BK / 16, BK / 8);
+            fold(kt - ktb + 1, kt + 1 == kte);
             __syncthreads();
         }
     }

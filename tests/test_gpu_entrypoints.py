@@ -90,10 +90,17 @@ def test_bench_two_ranks_code_path(tmp_path):
     env.pop("SOLA_PRECISION", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "4", "--cpu-seconds", "0"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+                        "--batch", "4", "--cpu-seconds", "0", "--train-steps", "2"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-1500:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "samples/s"
     assert out["config"]["sharding"] == "per-sample x2" and "roofline" in out and "cpu_baseline" not in out
+    # the multi-rank training leg: the one collective of the path, with and without overlap, and the per-rank ragged inference leg
+    td = out["training_step_dist"]
+    assert td["world_size"] == 2 and td["backend"] == "gloo"
+    for k in ("overlap", "no_overlap", "no_collective"):
+        assert td[k]["value"] > 0 and td[k]["ms_per_step"] > 0
+    assert td["allreduce_alone"]["bytes"] >= 4 * 32_980_000 and td["allreduce_alone"]["busbw_GBps"] > 0
+    assert td["ragged_inference"]["value"] > 0

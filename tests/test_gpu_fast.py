@@ -397,6 +397,6 @@ def test_norm_fused_into_the_conv_epilogue_matches_the_separate_launch():
     assert m.split_fallbacks()[1] == 0
     d_sm = float((outs[1][0] - outs[0][0]).abs().max()); d_st = float((outs[1][1] - outs[0][1]).abs().max())
     # f32 rounding noise reaches the logits amplified ~1000x (the reference itself sits 1e-4 from a float64 evaluation at this
-    # shape): two correct evaluation orders differ by a few 1e-4; the absolute bar is test_batch_256_sampled_rows_vs_oracle
+    # shape): two correct evaluation orders differ by a few 1e-4; the absolute bar is test_batch_256_every_row_vs_oracle
     assert d_sm <= 6e-4 and d_st <= 6e-4, (d_sm, d_st)
     assert torch.equal(outs[1][0] > 0, outs[0][0] > 0) or float((outs[1][0] - outs[0][0]).abs()[(outs[1][0] > 0) != (outs[0][0] > 0)].max()) < 1e-3
