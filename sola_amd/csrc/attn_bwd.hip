@@ -44,7 +44,21 @@ __device__ __forceinline__ BwdGeo bwd_geo(const AttnBwdArgs& a, int grp) {
     return g;
 }
 
-template <int DH>
+// RAG (ragged batches): every wave stages its unit through its OWN LDS slice, so nothing is shared between the waves of a block:
+// the block barriers become wave barriers (a wave's LDS instructions execute in order), a wave whose query tile lies past its
+// unit's length leaves at once, and the key / query loops run to the unit's OWN length instead of the batch's largest.
+template <bool RAG>
+__device__ __forceinline__ void stage_sync() {
+    if constexpr (RAG) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int DH, bool RAG = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     constexpr int NC = DH / 16, LD = DH + 4, F4 = DH / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -62,6 +76,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     const long long qrow0 = geo.q0, krow0 = geo.k0;
     const int qi = qt * 16 + c16;
     const bool q_ok = unit_ok && qi < geo.Sq;
+    if constexpr (RAG) {
+        if (!unit_ok || qt * 16 >= geo.Sq) return;  // the whole wave (its tile is past the unit's queries)
+    }
+    const int sk_loop = RAG ? geo.Sk : a.Sk;
     const long long qrow = qrow0 + (long long)(q_ok ? qi : 0) * geo.q_rs;
 
     float4 qf[NC], dof[NC];
@@ -90,9 +108,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) dqacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt0 = 0; kt0 < a.Sk; kt0 += 16) {
+    for (int kt0 = 0; kt0 < sk_loop; kt0 += 16) {
         const int nrows = min(16, geo.Sk - kt0);
-        __syncthreads();
+        stage_sync<RAG>();
         if (unit_ok) {
             for (int idx = lane; idx < 16 * F4; idx += 64) {
                 const int r = idx / F4, c4 = idx - r * F4;
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
                 *reinterpret_cast<float4*>(&Vs[r * LD + c4 * 4]) = vv;
             }
         }
-        __syncthreads();
+        stage_sync<RAG>();
         // S^T[key][q] and dP^T[key][q]: A = K / V rows (b128), B = q / dO fragments
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
         const float* kp = &Ks[c16 * LD + 4 * g4];
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     }
 }
 
-template <int DH>
+template <int DH, bool RAG = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     constexpr int NC = DH / 16, LD = DH + 4, F4 = DH / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -181,6 +199,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     const long long qrow0 = geo.q0, krow0 = geo.k0;
     const int kj = kt * 16 + c16;
     const bool k_ok = unit_ok && kj < geo.Sk;
+    if constexpr (RAG) {
+        if (!unit_ok || kt * 16 >= geo.Sk) return;
+    }
+    const int sq_loop = RAG ? geo.Sq : a.Sq;
     const long long krow = krow0 + (long long)(k_ok ? kj : 0) * geo.k_rs;
 
     float4 kf[NC], vf[NC];
@@ -199,9 +221,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 #pragma unroll
     for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int qt0 = 0; qt0 < a.Sq; qt0 += 16) {
+    for (int qt0 = 0; qt0 < sq_loop; qt0 += 16) {
         const int nrows = min(16, geo.Sq - qt0);
-        __syncthreads();
+        stage_sync<RAG>();
         if (unit_ok) {
             for (int idx = lane; idx < 16 * F4; idx += 64) {
                 const int r = idx / F4, c4 = idx - r * F4;
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
                 *reinterpret_cast<float4*>(&Gs[r * LD + c4 * 4]) = gv;
             }
         }
-        __syncthreads();
+        stage_sync<RAG>();
         // S[q][key] and dP[q][key]: A = Q / dO rows (b128), B = k / v fragments; lane gets q = 4*g4 + r, key = c16
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
         const float* qp = &Qs[c16 * LD + 4 * g4];
@@ -617,6 +639,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
     }
 }
 
+int g_attn_bwd_rag_wave = 96;  // sola_tune "attn_bwd_rag_wave": ragged batches whose LONGEST unit has at most this many queries and keys take
+                               // the per-wave kernels in their RAG form (0 = never)
 int g_attn_bwd_blk = 1;    // sola_tune "attn_bwd_blk": 0 = per-wave staging (the round-1 kernels) for every shape (A/B)
 int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels for every shape (A/B)
 
@@ -645,6 +669,31 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
     }
     AttnBwdArgs a = a0;
     bool done_dq = false;
+    if (a.q_units && a.Sq <= g_attn_bwd_rag_wave && a.Sk <= g_attn_bwd_rag_wave) {
+        // ragged batch of short units (motion attention over T' <= 25 steps, inter-object attention over N <= 80 tracks): one wave
+        // per 16-row tile, no block-level sync, every wave runs its own unit's trip count.  A 64-row block of the shared-staging
+        // shape would serve one unit of 3..80 rows with one to five of its tiles idle and all of them at the longest unit's pace.
+        static DeviceOnce once_r;
+        int dev_r;
+        if (once_r.needed(&dev_r)) {
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            once_r.done(dev_r);
+        }
+        a.ntile = (a.Sq + 15) / 16;
+        long long u = (long long)a.G * a.H * a.ntile;
+        SOLA_ARG((u + 3) / 4 < (1ll << 31), "attention backward: grid too large");
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, true>), dim3((unsigned)((u + 3) / 4)), dim3(256), lds, s, a);
+        SOLA_LAUNCH_CHECK();
+        a.ntile = (a.Sk + 15) / 16;
+        u = (long long)a.G * a.H * a.ntile;
+        SOLA_ARG((u + 3) / 4 < (1ll << 31), "attention backward: grid too large");
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, true>), dim3((unsigned)((u + 3) / 4)), dim3(256), lds, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
     if constexpr (DH == 128) if (g_attn_bwd_blk) {  // block-shared double-buffered staging (dvec is written by the dQ pass, read by the dK/dV pass)
         constexpr size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
         const long long bq = (long long)a.G * a.H * ((a.Sq + 63) / 64), bk = (long long)a.G * a.H * ((a.Sk + 63) / 64);
@@ -690,6 +739,7 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
 
 void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
 void sola_attn_set_bwd_blk(int v) { g_attn_bwd_blk = v; }
+void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
 
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");

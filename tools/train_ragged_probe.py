@@ -1,7 +1,7 @@
 """Ragged training step (forward_ragged(differentiable) + per-sample losses + backward + clip + AdamW) on a MeViS-like mix of
 shapes (N~U[8,80], T~U[20,200], L~U[4,24], seed 2024), per precision mode, with the in-library per-kernel breakdown.
 
-    python tools/train_ragged_probe.py [samples per step = 64] [modes, comma separated = f32,f16x3,f16]
+    python tools/train_ragged_probe.py [samples per step = 64] [modes, comma separated = f32,f16x3,f16] [tune key=value,...]
 """
 import os
 import sys
@@ -17,6 +17,9 @@ from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f32", "f16x3", "f16"]
+for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 else []):  # sola_tune switches for A/B runs: key=value,...
+    k, v = kv.split("=")
+    _lib.check(_lib.lib().sola_tune(k.encode(), int(v)), kv)
 cfg = synth.DEFAULT_MODEL_CFG
 m = LanguageAlignedTrackSelectionModule(cfg)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()}, strict=True)
