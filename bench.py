@@ -450,7 +450,8 @@ def f16_storage_leg(cfg, m, dev, steps):
 
     out = {"what": "plain f16 between kernels (2 B per activation element), one f16 MFMA per product, f32 accumulate / softmax / statistics; "
                    "device-side scales + range guard with exact-f32 repeat",
-           "tolerance": "logits within 1.5 % rms and 0.5 max of the reference (tests/test_gpu_f16.py)"}
+           "tolerance": "heavy-tailed: logits (magnitude ~10) within 1.5 % rms, at most 0.5 % of them beyond 0.25, none beyond 1.0 "
+                        "(tests/test_gpu_f16.py: every row of three 256-sample batches against the oracle)"}
     sync = lambda: torch.cuda.synchronize(dev)
     keep = m.precision
     for tag, (B, N, T, L) in (("NS_T32_N64", (256, 64, 32, 16)), ("C4_T128_N128", (32, 128, 128, 16))):
@@ -484,6 +485,40 @@ def f16_storage_leg(cfg, m, dev, steps):
                     "kernel_ms_per_step": kernel_ms(prof, steps)}
         del c
         torch.cuda.empty_cache()
+    # the ragged path under the same mode (round 3: inference.py / eval.py call only this path): the MeViS-like mix, four
+    # expressions per video, against the same call in the default split-f16 mode
+    from sola_amd.loss import track_selection_losses_ragged
+
+    rng = np.random.Generator(np.random.PCG64(2024))
+    S, per_video = 128, 4
+    d, D = cfg["object_token_dim"], cfg["lang_token_dim"]
+    shapes = [(int(rng.integers(8, 81)), int(rng.integers(20, 201))) for _ in range(S // per_video)]
+    lens = [int(rng.integers(4, 25)) for _ in range(S)]
+    sample_video = [i // per_video for i in range(S)]
+    videos = [torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)).to(dev) for n, t in shapes]
+    texts = [torch.from_numpy(rng.standard_normal((ln, D)).astype(np.float32)).to(dev) for ln in lens]
+    labels = torch.cat([torch.from_numpy((rng.uniform(size=shapes[v][0]) < 0.2).astype(np.float32)) for v in sample_video]).to(dev)
+    pos = torch.stack([t.mean(0) for t in texts], 0)
+
+    def rstep():
+        m.forward_ragged(videos, texts, sample_video)
+        flat, tok, offs, counts = m.last_ragged
+        track_selection_losses_ragged(flat, tok, labels, pos, m.negative_token.weight, offs, counts, POS_W, TEMP, ALIGN_W)
+        ops.select(flat, 0.5)
+        return flat
+
+    m.precision = "f16x3"
+    dt_ref = timed(rstep, steps, sync)
+    ref = rstep().clone()
+    m.precision = "f16"
+    dt16 = timed(rstep, steps, sync)
+    got = rstep()
+    out["ragged_four_expressions_per_video"] = {
+        "samples_per_launch": S, "value": round(S / dt16, 1), "unit": "samples/s", "ms_per_launch": round(dt16 * 1e3, 3),
+        "split_f16_mode_value": round(S / dt_ref, 1), "max_abs_logit_diff_vs_split_mode": float((got - ref).abs().max()),
+        "rms_logit_diff_vs_split_mode": float((got - ref).pow(2).mean().sqrt()), "calls_repeated_in_f32": m.split_fallbacks()[0]}
+    del videos, texts
+    torch.cuda.empty_cache()
     m.precision = keep
     return out
 

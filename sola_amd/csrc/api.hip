@@ -490,11 +490,12 @@ extern "C" size_t sola_ragged_workspace_bytes(const SolaCtx* c, const SolaRagged
     // the exact-f32 repeat of a guarded split-f16 call runs in the same arena: size it for the larger of the two plans
     try {
         size_t n = sola_ragged_workspace_bytes_impl(c, batch);
-        if (c->precision == 1) {
+        if (c->precision >= 1) {
             SolaCtx* m = const_cast<SolaCtx*>(c);
+            const int prec = c->precision;
             m->precision = 0;
             n = std::max(n, sola_ragged_workspace_bytes_impl(c, batch));
-            m->precision = 1;
+            m->precision = prec;
         }
         return n;
     } catch (const std::exception& e) {
@@ -515,14 +516,15 @@ extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* la
             return st;
         }
         SOLA_TRY(sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s));
-        if (c->precision != 1) return SOLA_OK;
+        if (c->precision < 1) return SOLA_OK;
         bool tripped = false;
         SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
         if (!tripped) return SOLA_OK;
         c->split_fallbacks += 1;
+        const int prec = c->precision;
         c->precision = 0;
         const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
-        c->precision = 1;
+        c->precision = prec;
         return st;
     } catch (const std::exception& e) {
         sola_set_error("forward_ragged: %s", e.what());

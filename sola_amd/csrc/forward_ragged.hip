@@ -21,6 +21,8 @@
 
 #include "ragged.h"
 
+int launch_attention_f16(const AttnDesc& d, hipStream_t s);
+
 namespace {
 
 // ---- device-side plan: unit tables from the compact per-video / per-sample descriptors ---------------------------
@@ -205,7 +207,7 @@ namespace {
 RagPlan rag_plan(const SolaCtx* c, const RagShape& r) {
     RagPlan p;
     const size_t D = c->cfg.lang_token_dim, f = sizeof(float);
-    const bool sp = c->precision == 1;
+    const bool sp = c->precision >= 1;  // split-f16 or plain-f16 copies of the caller's tensors
     p.add("tables", rag_tables_bytes(r, false));
     for (int i = 0; i < 6; ++i) {
         p.add("conv" + std::to_string(i), (size_t)r.rows[i + 1] * c->conv[i].cout * f);
@@ -375,6 +377,12 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
             return SOLA_ERR_WEIGHT;
         }
     const bool sp = c->precision == 1;
+    // precision 2: 16-bit activation STORAGE (forward_f16.hip's arithmetic on the ragged layout): every activation between two
+    // kernels a plain _Float16 in the first half of its f32-sized buffer, one f16 MFMA per product, f32 statistics / softmax
+    const bool h16 = c->precision == 2;
+    if (h16)
+        SOLA_ARG(c->cfg.object_token_dim % 64 == 0 && c->cfg.lang_token_dim % 64 == 0,
+                 "16-bit storage mode needs object_token_dim and lang_token_dim to be multiples of 64");
     if (sp)
         SOLA_ARG(c->cfg.object_token_dim % 8 == 0 && (c->cfg.lang_token_dim / c->cfg.n_groups_module) % 8 == 0 &&
                      (2 * c->cfg.object_token_dim / c->cfg.n_groups) % 8 == 0 && (c->cfg.lang_token_dim / c->cfg.n_groups) % 8 == 0,
@@ -424,16 +432,27 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
                 const int kc = c->conv[i].k * c->conv[i].cin;
                 SOLA_TRY(launch_cast_sp16(c->ws_buf + c->ws_off[i], kc, c->ws16_buf + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, s));
             }
+        if (h16)
+            for (int i = 0; i < 6; ++i) {
+                const int kc = c->conv[i].k * c->conv[i].cin;
+                SOLA_TRY(launch_cast_f16(c->ws_buf + c->ws_off[i], kc, reinterpret_cast<_Float16*>(c->ws16_buf) + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f,
+                                         nullptr, s));
+            }
         c->ws_dirty = false;
     }
-    if (sp) {
+    if (sp || h16) {
         SOLA_TRY(sola_refresh_lin16(c, s));
         SOLA_HIP(hipMemsetAsync(c->guard, 0, sizeof(int), s));
     }
-    int* const guard = sp ? c->guard : nullptr;
+    int* const guard = (sp || h16) ? c->guard : nullptr;
+    auto ws_w = [&](int i) -> const float* {  // standardised conv weights in the mode's operand format
+        if (h16) return reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->ws16_buf) + c->ws_off[i]);
+        return sp ? c->ws16_buf + c->ws_off[i] : c->ws_buf + c->ws_off[i];
+    };
     auto lin_w = [&](int layer, int attn, int proj) -> const float* {
         static const char* pn[4] = {"q_proj", "k_proj", "v_proj", "out_proj"};
         if (sp) return c->lin16_buf + ((size_t)(layer * 3 + attn) * 4 + proj) * D * D;
+        if (h16) return reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->lin16_buf) + ((size_t)(layer * 3 + attn) * 4 + proj) * D * D);
         return W("object_lang_align_layers." + std::to_string(layer) + "." + kAttnLong[attn] + "." + pn[proj] + ".weight");
     };
     auto lin_b = [&](int layer, int attn, int proj) -> const float* {
@@ -447,13 +466,17 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         SOLA_TRY(launch_cast_sp16_auto(obj, d_in, buf("obj_sp"), d_in, r.rows[0], d_in, c->scal_pair(0), s));
         x = buf("obj_sp");
     }
+    if (h16) {  // largest magnitude -> [2^6, 2^7), capped at 2^8; conv0's output stays in the scaled units (forward_f16.hip)
+        SOLA_TRY(launch_cast_f16(obj, d_in, buf("obj_sp"), d_in, r.rows[0], d_in, 256.f, c->scal_pair(0), s, 6, c->scal_extra(0)));
+        x = buf("obj_sp");
+    }
     for (int i = 0; i < 6; ++i) {
         const ConvGeom& g = c->conv[i];
         const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
         const bool last_sp = sp && i == 5;  // conv5 feeds layer 0 as GEMM operand and residual: written as split-f16 pairs
         GemmDesc gd{};
         gd.nprob = 1;
-        gd.p[0] = GemmProblem{x, sp ? c->ws16_buf + c->ws_off[i] : c->ws_buf + c->ws_off[i], W(cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
+        gd.p[0] = GemmProblem{x, ws_w(i), W(cp + ".bias"), nullptr, buf("conv" + std::to_string(i))};
         gd.M = (int)r.rows[i + 1]; gd.N = g.cout; gd.K = g.k * g.cin;
         gd.lda = g.cin; gd.ldr = 0; gd.ldc = g.cout;
         gd.conv = g.k > 1 ? 1 : 0;
@@ -463,7 +486,11 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
             gd.arith = 1; gd.out_scale = 1.f; gd.c_sp16 = last_sp ? 1 : 0; gd.guard = guard;
             if (i == 0) gd.out_scale_dev = c->scal_pair(0) + 1;
         }
-        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (h16) {
+            gd.arith = 2; gd.out_scale = 1.f; gd.c_f16 = 1; gd.guard = guard;
+            if (i == 0) gd.bias_scale_dev = c->scal_extra(0);
+        }
+        gd.splitk_ws = h16 ? nullptr : splitk_ws; gd.splitk_bytes = h16 ? 0 : splitk_bytes;
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
             const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i]);
@@ -475,6 +502,10 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
             nd.units = tab4("u_lvl" + std::to_string(i + 1));
             nd.ntok = r.maxT[i + 1]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
             nd.out_sp16 = sp ? 1 : 0; nd.guard = guard;
+            if (h16) {
+                nd.in_f16 = 1; nd.out_f16 = 1;
+                if (i == 0) nd.in_scale_dev = c->scal_pair(0) + 1;
+            }
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
         }
@@ -487,6 +518,10 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         SOLA_TRY(launch_cast_sp16_auto(buf("lang"), D, buf("lang_sp"), D, r.LW, D, c->scal_pair(1), s));
         lang_in = buf("lang_sp");
     }
+    if (h16) {
+        SOLA_TRY(launch_cast_f16(buf("lang"), D, buf("lang_sp"), D, r.LW, D, 1.f, c->scal_pair(1), s, 6));
+        lang_in = buf("lang_sp");
+    }
 
     const float scale = 1.0f / sqrtf((float)DH);
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, int layer, int attn, int nprob, long long rows, float* o0, float* o1,
@@ -497,22 +532,24 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         gd.nprob = nprob;
         for (int j = 0; j < nprob; ++j)
             gd.p[j] = GemmProblem{as[j], lin_w(layer, attn, first_proj + j), lin_b(layer, attn, first_proj + j), nullptr, os[j],
-                                  sp ? c->lin_inv_scale(layer, attn, first_proj + j) : nullptr};
+                                  (sp || h16) ? c->lin_inv_scale(layer, attn, first_proj + j) : nullptr};
         gd.M = (int)rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = 0; gd.ldc = D;
         if (sp) { gd.arith = 1; gd.out_scale = 1.f; gd.out_scale_dev = a_inv_scale; gd.c_sp16 = out_sp16; gd.guard = guard; }
-        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (h16) { gd.arith = 2; gd.out_scale = 1.f; gd.out_scale_dev = a_inv_scale; gd.c_f16 = 1; gd.guard = guard; }
+        gd.splitk_ws = h16 ? nullptr : splitk_ws; gd.splitk_bytes = h16 ? 0 : splitk_bytes;
         return launch_gemm(gd, s);
     };
     auto out_proj = [&](int layer, int attn, long long rows, const float* resid, int resid_sp16) -> int {
         GemmDesc gd{};
         gd.nprob = 1;
-        gd.p[0] = GemmProblem{buf("attn"), lin_w(layer, attn, 3), lin_b(layer, attn, 3), resid, buf("res"), sp ? c->lin_inv_scale(layer, attn, 3) : nullptr};
+        gd.p[0] = GemmProblem{buf("attn"), lin_w(layer, attn, 3), lin_b(layer, attn, 3), resid, buf("res"), (sp || h16) ? c->lin_inv_scale(layer, attn, 3) : nullptr};
         gd.M = (int)rows; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         if (sp) { gd.arith = 1; gd.out_scale = 1.f; gd.r_sp16 = resid_sp16; }
-        gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (h16) { gd.arith = 2; gd.out_scale = 1.f; gd.r_f16 = 1; gd.c_f16 = 1; gd.guard = guard; }
+        gd.splitk_ws = h16 ? nullptr : splitk_ws; gd.splitk_bytes = h16 ? 0 : splitk_bytes;
         return launch_gemm(gd, s);
     };
-    auto gn = [&](int layer, int idx, float* y, float* y2, int out_sp16, const int4* units, int n_inst, int max_tok) -> int {
+    auto gn = [&](int layer, int idx, float* y, float* y2, int out_sp16, const int4* units, int n_inst, int max_tok, int out_f16 = 1) -> int {
         const std::string lp = "object_lang_align_layers." + std::to_string(layer) + ".norm." + std::to_string(idx);
         GroupNormDesc nd{};
             nd.slice_ws = raw("gn_slots"); nd.slice_ws_bytes = gn_slots_bytes;
@@ -521,6 +558,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         nd.n_inst = n_inst; nd.inner = 1; nd.tok_stride = 1; nd.units = units; nd.ntok = max_tok;
         nd.C = D; nd.groups = c->cfg.n_groups_module; nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0;
         nd.out_sp16 = out_sp16; nd.guard = guard;
+        if (h16) { nd.in_f16 = 1; nd.out_f16 = out_f16; }
         return launch_group_norm(nd, s);
     };
     auto attention = [&](const float* q, const float* k, const float* v, int G, const int4* qu, const int4* ku, int maxSq, int maxSk,
@@ -531,6 +569,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         ad.guard = guard;
         ad.split_math = sp ? 1 : 0;
         ad.q_units = qu; ad.k_units = ku;
+        if (h16) { ad.o_sp16 = 0; ad.in_sp16 = 0; ad.split_math = 0; return launch_attention_f16(ad, s); }
         return launch_attention(ad, s);
     };
     // q/k/v leave the projection already split where the attention runs the split-f16 MFMA shape (forward_fast.hip: units of
@@ -557,7 +596,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
     // ---- from here on rows are per SAMPLE: repeat the video's activations for each of its expressions
     const float* x_mot = buf("v_motion");
     if (!r.identity) {
-        SOLA_TRY(launch_gather_rows(buf("v_motion"), buf("s_motion0"), tab4("u_gather"), S, D, r.Ms, s));
+        SOLA_TRY(launch_gather_rows(buf("v_motion"), buf("s_motion0"), tab4("u_gather"), S, h16 ? D / 2 : D, r.Ms, s));  // f16 rows: D halfs
         x_mot = buf("s_motion0");
     }
     const long long M = r.Ms;
@@ -581,10 +620,10 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         // object -> language attention (module/module.py:46-50)
         float* x_o2l = buf(ls + "_o2l");
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0, o2l_in_sp, nullptr));
-        SOLA_TRY(linear3(lang_in, lang_in, nullptr, l, 2, 2, r.LW, buf("lk"), buf("lv"), nullptr, 1, o2l_in_sp, sp ? c->scal_pair(1) + 1 : nullptr));
+        SOLA_TRY(linear3(lang_in, lang_in, nullptr, l, 2, 2, r.LW, buf("lk"), buf("lv"), nullptr, 1, o2l_in_sp, (sp || h16) ? c->scal_pair(1) + 1 : nullptr));
         SOLA_TRY(attention(q, buf("lk"), buf("lv"), S, tab4("u_smp"), tab4("u_langk"), r.maxRowsSample, r.maxW, o2l_in_sp));
         SOLA_TRY(out_proj(l, 2, M, x_mot, spi));
-        SOLA_TRY(gn(l, 2, x_o2l, nullptr, (sp && !last) ? 1 : 0, tab4("u_smp"), S, r.maxRowsSample));  // the score head reads f32
+        SOLA_TRY(gn(l, 2, x_o2l, nullptr, (sp && !last) ? 1 : 0, tab4("u_smp"), S, r.maxRowsSample, last ? 0 : 1));  // the score head reads f32
         xin = x_o2l;
     }
     HeadDesc hd{xin, buf("lbar"), score_map, score_tokens, 1, r.sumNS, maxTp, D};

@@ -91,8 +91,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # inference arithmetic of the convs / projections: "f32" (exact f32 MFMA) or "f16x3" (split-f16 operands, three
         # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers every GEMM of the
         # step, forward and backward (attention and GroupNorm backward stay f32); "f16" = 16-bit activation STORAGE for the
-        # uniform inference forward (plain f16 between kernels, one f16 MFMA per product, f32 accumulate / softmax / statistics;
-        # a reduced-precision mode with a stated tolerance; ragged calls run exact f32 under it; in TRAINING it is mixed
+        # inference forward, uniform and ragged (plain f16 between kernels, one f16 MFMA per product, f32 accumulate / softmax /
+        # statistics; a reduced-precision mode with a stated tolerance); in TRAINING it is mixed
         # precision: every GEMM of the step on plain-f16 casts, one MFMA per product, everything else f32)
         # Default (round 3): "f16x3", the range-guarded split-f16 mode - what bench.py's headline measures, closer to a float64
         # evaluation than the f32 MFMA chain, and backed by the exact-f32 kernels whenever its guard trips.  The

@@ -24,7 +24,12 @@ from sola_amd import _lib, synth  # noqa: E402
 from sola_amd._lib import check, current_stream, lib, ptr  # noqa: E402
 from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
 
-TOL_LOGIT, TOL_TOKEN, TOL_RMS = 0.5, 0.5, 1.5e-2
+# Stated tolerance of the mode (round 3, from EVERY row of three 256-sample batches against the oracle -
+# test_f16_mode_every_row_of_the_benched_batch; round 2 stated 0.5 from five golden cases and the benched batch itself reached
+# 0.52): the error is heavy-tailed - rms 0.8 % of the logits' rms, 99.5 % of the logits within 0.25, the worst of 16 K logits
+# 0.52-0.69 and of 16.8 M token entries 0.61-0.78 - so the bound has three parts: 1.0 on any logit / token (logit magnitude ~10),
+# 1.5 % rms, at most 0.5 % of the logits beyond 0.25.  Decisions are compared where the reference logit is clear of the bound.
+TOL_LOGIT, TOL_TOKEN, TOL_RMS, TOL_Q, TOL_Q_FRAC = 1.0, 1.0, 1.5e-2, 0.25, 5e-3
 
 
 def cuda(x):
@@ -128,6 +133,26 @@ def test_full_cases_vs_golden_in_f16_mode(full_golden, full_f16, ci):
     assert rms(sm - g["score_map"]) <= TOL_RMS * rms(g["score_map"]) and rms(st - g["score_tokens"]) <= TOL_RMS * rms(g["score_tokens"])
     clear = np.abs(g["score_map"]) > 2 * TOL_LOGIT
     np.testing.assert_array_equal((sm > 0)[clear], (g["score_map"] > 0)[clear])
+
+
+@pytest.mark.parametrize("seed", [1000, 1001, 1002])
+def test_f16_mode_every_row_of_the_benched_batch(full_f16, seed):
+    """The bound is stated for what is benched: all 256 rows of bench.py's batch (seed 1000) and of two more, against the fp32
+    oracle (the five golden cases reach 0.06-0.17; the batch's worst logit is what the stated bound must cover)."""
+    from test_gpu_range import _oracle_rows
+    inp, rsm, rst = _oracle_rows(seed, 256, 64, 32, 16)
+    with torch.no_grad():
+        sm, st = full_f16(cuda(inp["object_tokens"]), cuda(inp["lang_tokens"]))
+    sm, st = sm.cpu().numpy(), st.cpu().numpy()
+    assert full_f16.split_fallbacks() == (0, 0)
+    e_sm, e_st = float(np.abs(sm - rsm).max()), float(np.abs(st - rst).max())
+    rms = lambda x: float(np.sqrt(np.mean(np.square(x.astype(np.float64)))))
+    print(f"f16 storage mode, seed {seed}: worst |logit err| {e_sm:.3f} (rms {rms(sm - rsm) / rms(rsm):.4f} of the logits' rms), worst |token err| {e_st:.3f}")
+    assert e_sm <= TOL_LOGIT and e_st <= TOL_TOKEN, (e_sm, e_st)
+    assert rms(sm - rsm) <= TOL_RMS * rms(rsm) and rms(st - rst) <= TOL_RMS * rms(rst)
+    assert float((np.abs(sm - rsm) > TOL_Q).mean()) <= TOL_Q_FRAC, float((np.abs(sm - rsm) > TOL_Q).mean())
+    clear = np.abs(rsm) > 2 * TOL_LOGIT
+    np.testing.assert_array_equal((sm > 0)[clear], (rsm > 0)[clear])
 
 
 def test_f16_mode_input_scales_and_guard(full_f16):
