@@ -16,7 +16,7 @@ Arithmetic of the convs/projections (98 % of the FLOPs), --precision:
         power-of-two scales for the caller's tokens and every weight matrix and a range guard that repeats a call on the
         exact-f32 kernels if a value leaves the format's range (include/sola_hip.h: sola_set_split_guard; the guard's
         read-back is inside the timed region).  It meets the same parity bar as exact f32 at every input scale
-        (tests/test_gpu_range.py) and is closer to a float64 evaluation than the f32 MFMA path.
+        (tests/test_gpu_range.py: every row of three 256-sample batches in both modes; the two sit in the same error class).
   f32   exact v_mfma_f32_32x32x2_f32.  In the default mode the same workload is also timed on this path after the timed
         region and reported as "exact_f32_mode" with its own roofline entries.
 
