@@ -287,3 +287,59 @@ def test_call_sequence_errors(small):
     torch.testing.assert_close(sms[0], sms[1], rtol=0, atol=0)
     with pytest.raises(SolaError):
         small.forward_ragged([s["obj"]], [s["lang"]], [1])
+
+
+def test_dropout_gradients_of_a_mixed_shape_batch_match_finite_differences(small):
+    """Training mode on a MIXED-shape batch: the dropout masks are functions of (seed, element index / unit index), regenerated by
+    the backward kernels from the unit tables.  With the seed pinned the loss is a smooth function of the parameters, so central
+    differences of the loss must agree with the HIP gradients - for parameters upstream of every dropout site (encoder norms'
+    dropout, the three attentions' dropout on the probabilities)."""
+    cfg = synth.SMALL_MODEL_CFG
+    shapes = [(6, 40, 7), (3, 9, 2), (17, 130, 5), (9, 24, 11)]
+    samples = [sample_inputs(cfg, N, T, L, 900 + i) for i, (N, T, L) in enumerate(shapes)]
+    labels = torch.cat([s["labels"] for s in samples])
+    pos = torch.stack([s["pos"] for s in samples])
+    small.train()
+    try:
+        def loss_value(backward):
+            torch.manual_seed(4321)  # the step's dropout seed is drawn from torch's generator
+            small.zero_grad(set_to_none=True)
+            small.forward_ragged([s["obj"] for s in samples], [s["lang"] for s in samples])
+            assert small._last_dropout_seed != 0
+            flat, tok, offs, counts = small.last_ragged
+            loss = track_selection_losses_ragged(flat, tok, labels, pos, small.negative_token.weight, offs, counts, POS_W, TEMP, ALIGN_W)[:, 0].sum()
+            if backward:
+                loss.backward()
+            return float(loss.detach().double())
+
+        base = loss_value(True)
+        named = dict(small.named_parameters())
+        grads = {k: p.grad.detach().clone() for k, p in named.items()}
+        assert loss_value(False) == base  # same seed -> same masks -> bit-identical loss
+        probes = [("short_motion_encoder.0.bias", (3,)), ("short_motion_encoder.5.weight", (10,)), ("short_motion_encoder.12.bias", (7,)),
+                  ("object_lang_align_layers.0.obj_attn.v_proj.bias", (11,)), ("object_lang_align_layers.0.motion_attn.out_proj.bias", (2,)),
+                  ("object_lang_align_layers.1.object2lang_attn.q_proj.bias", (5,)), ("object_lang_align_layers.1.norm.1.weight", (9,)),
+                  ("negative_token.weight", (1, 4))]
+        bad = {}
+        for key, idx in probes:
+            p = named[key]
+            eps = 2e-2
+            with torch.no_grad():
+                old = float(p[idx])
+                p[idx] = old + eps
+            small.weights_changed()
+            up = loss_value(False)
+            with torch.no_grad():
+                p[idx] = old - eps
+            small.weights_changed()
+            dn = loss_value(False)
+            with torch.no_grad():
+                p[idx] = old
+            small.weights_changed()
+            fd = (up - dn) / (2 * eps)
+            g = float(grads[key][idx])
+            if abs(fd - g) > 3e-2 * max(abs(g), abs(fd)) + 2e-3:
+                bad[key] = (fd, g)
+        assert not bad, f"finite differences vs HIP gradients under dropout: {bad}"
+    finally:
+        small.eval()
