@@ -281,6 +281,7 @@ void sola_attn_set_res_splitm(int v);
 void sola_attn_set_bwd_small(int v);
 void sola_attn_set_bwd_blk(int v);
 void sola_attn_set_bwd_rag_wave(int v);
+void sola_attn_set_simple_train(int v);
 void sola_gn_set_bwd_reg(int v);
 void sola_gn_set_slices(int v);
 void sola_gn_set_wide(int v);
@@ -318,6 +319,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_bwd_small")) { sola_attn_set_bwd_small(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_blk")) { sola_attn_set_bwd_blk(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_rag_wave")) { sola_attn_set_bwd_rag_wave(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_simple_train")) { sola_attn_set_simple_train(value); return SOLA_OK; }
     if (!strcmp(key, "gn_bwd_reg")) { sola_gn_set_bwd_reg(value); return SOLA_OK; }
     if (!strcmp(key, "gn_slices")) { sola_gn_set_slices(value); return SOLA_OK; }
     if (!strcmp(key, "gn_wide")) { sola_gn_set_wide(value); return SOLA_OK; }

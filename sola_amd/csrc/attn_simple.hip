@@ -25,11 +25,17 @@ struct AttnSArgs {
     int* guard;
     const int4 *q_units, *k_units;
     int xcd_remap;
+    float* lse;       // TR instantiation: optional [q rows][H] log-sum-exp of the scaled scores (saved for the backward)
+    DropoutCfg drop;  // TR instantiation: dropout on the probabilities (tools/attention.py:71), same counter-based mask as attn.hip
 };
 
 // DB: two LDS stages of TK keys; the next tile's K/V rows travel in registers while the current tile is multiplied and there
 // is ONE barrier per tile (the shape that took the attention backward from 460 to 299 us, attn_bwd.hip).
-template <int DH, int TK, bool DB = false>
+// TR (round 3): the training forward - log-sum-exp output and dropout on the probabilities - so that sola_forward_train[_ragged]
+// takes this shape too (its q-blocks are independent blocks: units of very different lengths balance over the chip, where
+// attn.hip's shared mode walks a ragged unit's q-blocks inside one block).  A separate instantiation: the inference kernel's
+// registers (126 at four blocks per CU) are untouched.
+template <int DH, int TK, bool DB = false, bool TR = false>
 __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnSArgs a) {
     constexpr int NC = DH / 16;
     constexpr int LDK = DH + 4, LDV = DH + 4;
@@ -164,6 +170,16 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
         m_run = m_new;
 #pragma unroll
         for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+        if constexpr (TR) {
+            if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped (attn.hip)
+                const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * Sq + qi) * Sk;
+#pragma unroll
+                for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < TK / 16; ++t) {
             if (t < ntile) {
@@ -178,6 +194,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
     }
     if (!q_ok) return;
     const float inv = 1.f / l_run;
+    if constexpr (TR) {
+        if (a.lse && g4 == 0) a.lse[(q0 + (long long)qi * q_rs) * a.H + h] = m_run + logf(l_run);
+    }
     float* op = a.o + (q0 + (long long)qi * q_rs) * a.ldo + h * DH;
     if (!a.o_sp16) {
 #pragma unroll
@@ -493,6 +512,12 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
     const long long blocks = (long long)a.G * a.H * a.nqb;
     SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
     a.xcd_remap = (g_attn_simple_remap && blocks % 8 == 0) ? 1 : 0;
+    if (a.lse || a.drop.enabled) {  // training forward
+        const size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
+        hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, 16, true, true>), dim3((unsigned)blocks), dim3(256), lds2, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
     if (g_attn_simple_db) {  // two stages of 16 keys: the same LDS footprint (34 KB), next tile prefetched in registers
         const size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
         hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, 16, true>), dim3((unsigned)blocks), dim3(256), lds2, s, a);
@@ -525,6 +550,8 @@ static AttnSArgs make_sargs(const AttnDesc& d) {
     a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     a.xcd_remap = 0;
+    a.lse = d.lse;
+    a.drop = d.drop;
     return a;
 }
 
@@ -542,10 +569,13 @@ int launch_attention_small(const AttnDesc& d, hipStream_t s) {
     return SOLA_OK;
 }
 
-// inference shapes only: f32 q / k / v, no log-sum-exp, no dropout, more than 16 keys or queries
+// f32 q / k / v, more than 16 keys or queries; with a log-sum-exp output / dropout (training) the TR instantiation, f32 output only
+int g_attn_simple_train = 1;  // sola_tune "attn_simple_train": 0 = the training forward keeps attn.hip's kernels (A/B)
 bool attention_simple_supported(const AttnDesc& d) {
-    return !d.lse && !d.drop.enabled && !d.in_sp16 && (d.Sq > 16 || d.Sk > 16) && (d.DH == 128 || d.DH == 64);
+    if ((d.lse || d.drop.enabled) && (!g_attn_simple_train || d.o_sp16)) return false;
+    return !d.in_sp16 && (d.Sq > 16 || d.Sk > 16) && (d.DH == 128 || d.DH == 64);
 }
+void sola_attn_set_simple_train(int v) { g_attn_simple_train = v; }
 
 int launch_attention_simple(const AttnDesc& d, hipStream_t s) {
     const AttnSArgs a = make_sargs(d);
