@@ -35,12 +35,28 @@ __device__ __forceinline__ GnBwdUnit gn_bwd_unit(const GnBwdArgs& a, int inst) {
     return u;
 }
 
-__global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) {
-    __shared__ float red[4];
-    __shared__ float part[256 * 8];
+template <int NTHR>
+__device__ __forceinline__ float bwd_block_sum(float v, float* red) {
+    if (NTHR == 256) return block_sum_256(v, red);
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTHR / 64; ++i) t += red[i];
+    return t;
+}
+// NTHR = 1024 (round 3): units beyond the register shapes are the object->language norm's (a sample's N*T' tokens x 128 channels: up
+// to 1 MB per (sample, group)); a launch has only samples x groups blocks and its time is the longest block's four walks over
+// its unit - four times the threads move the unit four times as fast (515 -> ~200 us per launch on the MeViS-like mix).
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a) {
+    __shared__ float red[NTHR / 64];
+    __shared__ float part[NTHR * 8];
     const int g = blockIdx.y, inst = blockIdx.x;
     const int lpt = a.cg >> 2;
-    const int tpp = 256 / lpt;
+    const int tpp = NTHR / lpt;
     const int tl = threadIdx.x / lpt;
     const int c4 = threadIdx.x - tl * lpt;
     const GnBwdUnit un = gn_bwd_unit(a, inst);
@@ -56,7 +72,7 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
             const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
             s += (v.x + v.y) + (v.z + v.w);
         }
-    const float mean = block_sum_256(s, red) / cnt;
+    const float mean = bwd_block_sum<NTHR>(s, red) / cnt;
     float q = 0.f;
     if (active)
         for (int t = tl; t < ntok; t += tpp) {
@@ -64,7 +80,7 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
             const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
-    const float var = block_sum_256(q, red) / cnt;
+    const float var = bwd_block_sum<NTHR>(q, red) / cnt;
     const float rstd = 1.0f / sqrtf(var + a.eps);
 
     float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), be = ga;
@@ -106,8 +122,8 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
             s1 += (g0 + g1) + (g2 + g3);
             s2 += (g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w);
         }
-    const float m1 = block_sum_256(s1, red) / cnt;
-    const float m2 = block_sum_256(s2, red) / cnt;
+    const float m1 = bwd_block_sum<NTHR>(s1, red) / cnt;
+    const float m2 = bwd_block_sum<NTHR>(s2, red) / cnt;
     // per-channel partials: reduce the token slots that share a channel quad
     float* pp = &part[threadIdx.x * 8];
     pp[0] = dgam.x; pp[1] = dgam.y; pp[2] = dgam.z; pp[3] = dgam.w;
@@ -146,18 +162,6 @@ __global__ __launch_bounds__(256) void group_norm_bwd_kernel(const GnBwdArgs a) 
 //   WAVE = true : one wave per unit (encoder norms and the motion norm, units of <= 4 KiB), four units per block, shuffles only;
 //   WAVE = false: one block per unit (the inter-object norm: 32 KiB, R = 8).
 //   NTHR = 1024 (block shape only): the 128 KiB object->language units at 8 float4 per lane and tensor (norm.hip's wide shape).
-template <int NTHR>
-__device__ __forceinline__ float bwd_block_sum(float v, float* red) {
-    if (NTHR == 256) return block_sum_256(v, red);
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < NTHR / 64; ++i) t += red[i];
-    return t;
-}
 template <int R, bool WAVE, int NTHR = 256>
 __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArgs a, long long n_units, int groups) {
     __shared__ float red[NTHR / 64];
@@ -609,10 +613,16 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
         if (rb <= 2) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<2, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
         else if (rb <= 4) hipLaunchKernelGGL((group_norm_bwd_reg_kernel<4, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
         else hipLaunchKernelGGL((group_norm_bwd_reg_kernel<8, false>), grid, dim3(256), 0, s, a, n_units, d.groups);
+    } else if (g_gn_bwd_reg && rb <= 16 && pow2 && f4 <= 256 && 512 % f4 == 0 && n_units < (1ll << 31)) {
+        // units of up to twice the 256-thread shape (ragged batches: the inter-object norm over up to 128 tracks): 512 threads at 8
+        // float4 per lane and tensor - the 1024-thread shape leaves most of its lanes idle on them (407 -> ~220 us per launch)
+        hipLaunchKernelGGL((group_norm_bwd_reg_kernel<8, false, 512>), dim3((unsigned)n_units), dim3(512), 0, s, a, n_units, d.groups);
     } else if (g_gn_bwd_reg && rb <= 32 && pow2 && f4 <= 256 && 1024 % f4 == 0 && n_units < (1ll << 31)) {
         hipLaunchKernelGGL((group_norm_bwd_reg_kernel<8, false, 1024>), dim3((unsigned)n_units), dim3(1024), 0, s, a, n_units, d.groups);
+    } else if (g_gn_bwd_reg && (1024 % f4) == 0 && f4 <= 256) {
+        hipLaunchKernelGGL(group_norm_bwd_kernel<1024>, dim3(d.n_inst, d.groups), dim3(1024), 0, s, a);
     } else {
-        hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(group_norm_bwd_kernel<256>, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
