@@ -212,9 +212,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 kv = k_ok ? *reinterpret_cast<const float4*>(kp + c * 16) : z;
+            const float4 kl = *reinterpret_cast<const float4*>(kp + c * 16);  // the row is clamped: load, then zero the VALUE (a select
+            const float4 kv = k_ok ? kl : z;                                  // of POINTERS goes through a scratch copy of z + a flat load)
             kf[c] = make_float4(kv.x * a.scale, kv.y * a.scale, kv.z * a.scale, kv.w * a.scale);
-            vf[c] = k_ok ? *reinterpret_cast<const float4*>(vp + c * 16) : z;
+            const float4 vl = *reinterpret_cast<const float4*>(vp + c * 16);
+            vf[c] = k_ok ? vl : z;
         }
     }
     f32x4 dkacc[NC], dvacc[NC];
@@ -458,9 +460,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 kv = k_ok ? *reinterpret_cast<const float4*>(kp + c * 16) : z;
+            const float4 kl = *reinterpret_cast<const float4*>(kp + c * 16);  // the row is clamped: load, then zero the VALUE (a select
+            const float4 kv = k_ok ? kl : z;                                  // of POINTERS goes through a scratch copy of z + a flat load)
             kf[c] = make_float4(kv.x * a.scale, kv.y * a.scale, kv.z * a.scale, kv.w * a.scale);
-            vf[c] = k_ok ? *reinterpret_cast<const float4*>(vp + c * 16) : z;
+            const float4 vl = *reinterpret_cast<const float4*>(vp + c * 16);
+            vf[c] = k_ok ? vl : z;
         }
     }
     f32x4 dkacc[NC], dvacc[NC];
@@ -582,12 +586,18 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
     float dsum[TT], lse[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        const long long qr = q0 + (long long)t * geo.q_rs, kr = k0 + (long long)t * geo.k_rs;
-        qv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.q + qr * a.ldq + h * DH + 4 * c) : z;
-        gv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.dout + qr * a.ldo + h * DH + 4 * c) : z;
-        const float4 ov = t < Sq ? *reinterpret_cast<const float4*>(a.o + qr * a.ldo + h * DH + 4 * c) : z;
-        kv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.k + kr * a.ldk + h * DH + 4 * c) : z;
-        vv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.v + kr * a.ldv + h * DH + 4 * c) : z;
+        // rows past the unit's length: a CLAMPED row is loaded and the VALUE zeroed (a `cond ? *p : z` makes the compiler select
+        // between the global pointer and a scratch copy of z and load through a flat address - attn_simple.hip)
+        const long long qr = q0 + (long long)(t < Sq ? t : 0) * geo.q_rs, kr = k0 + (long long)(t < Sk ? t : 0) * geo.k_rs;
+        auto ld = [&](const float* p, bool ok) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        };
+        qv[t] = ld(a.q + qr * a.ldq + h * DH + 4 * c, t < Sq);
+        gv[t] = ld(a.dout + qr * a.ldo + h * DH + 4 * c, t < Sq);
+        const float4 ov = ld(a.o + qr * a.ldo + h * DH + 4 * c, t < Sq);
+        kv[t] = ld(a.k + kr * a.ldk + h * DH + 4 * c, t < Sk);
+        vv[t] = ld(a.v + kr * a.ldv + h * DH + 4 * c, t < Sk);
         lse[t] = t < Sq ? a.lse[qr * a.H + h] : 0.f;
         dsum[t] = half_sum32((ov.x * gv[t].x + ov.y * gv[t].y) + (ov.z * gv[t].z + ov.w * gv[t].w));  // D[i] = dO[i] . O[i]
         if (t < Sq && c == 0) a.dvec[qr * a.H + h] = dsum[t];

@@ -252,12 +252,20 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnSArgs a) 
     }
     if (!live) { Sq = 0; Sk = 0; }
     float4 qv[TT], kv[TT], vv[TT];
+    // Rows past the unit's length: load a CLAMPED row and zero the VALUE.  `t < Sq ? *p : z` made the compiler select between the
+    // global pointer and the address of a zero constant it had put into scratch memory, then load through a FLAT address: a
+    // 16-byte scratch store per lane and row (366 MiB of WRITE_SIZE per launch for 256 MiB of output, profiles/r02_summary.md -
+    // WRITE_SIZE itself is exact on this access pattern: profiles/r03_write_size_calibration.txt) and flat instead of global loads.
+    auto ld = [&](const float* base, long long row0, long long rs, int ld_, int t, int n) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (row0 + (long long)(t < n ? t : 0) * rs) * ld_ + h * DH + 4 * c);
+        const bool ok = t < n;
+        return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    };
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        qv[t] = t < Sq ? *reinterpret_cast<const float4*>(a.q + (q0 + (long long)t * q_rs) * a.ldq + h * DH + 4 * c) : z;
-        kv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.k + (k0 + (long long)t * k_rs) * a.ldk + h * DH + 4 * c) : z;
-        vv[t] = t < Sk ? *reinterpret_cast<const float4*>(a.v + (k0 + (long long)t * k_rs) * a.ldv + h * DH + 4 * c) : z;
+        qv[t] = ld(a.q, q0, q_rs, a.ldq, t, Sq);
+        kv[t] = ld(a.k, k0, k_rs, a.ldk, t, Sk);
+        vv[t] = ld(a.v, k0, k_rs, a.ldv, t, Sk);
     }
     float sc[TT][TT];
 #pragma unroll
