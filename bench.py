@@ -748,7 +748,11 @@ def main():
 
     dist_res = None
     if world > 1 and args.train_steps > 0:  # every rank takes part (collectives); reported by rank 0
-        dist_res = dist_legs(cfg, sd, dev, world, rank, max(2, min(args.train_steps, 5)))
+        try:  # a (symmetric) failure of this extra leg must not cost the headline line
+            dist_res = dist_legs(cfg, sd, dev, world, rank, max(2, min(args.train_steps, 5)))
+        except Exception as e:  # noqa: BLE001
+            dist_res = {"error": f"{type(e).__name__}: {e}"[:500]}
+            torch.cuda.synchronize(dev)
     if rank == 0:
         fl = synth.flops_per_sample(cfg, N, T, L)
         step_s = elapsed / args.steps

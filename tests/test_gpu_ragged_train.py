@@ -343,3 +343,19 @@ def test_dropout_gradients_of_a_mixed_shape_batch_match_finite_differences(small
         assert not bad, f"finite differences vs HIP gradients under dropout: {bad}"
     finally:
         small.eval()
+
+
+@pytest.mark.parametrize("shapes", [[(1, 1, 1)], [(1, 9, 1), (130, 24, 3), (5, 300, 7)], [(97, 8, 2), (2, 2, 2), (40, 257, 33)]])
+def test_edge_shapes_equal_one_sample_steps(small, shapes):
+    """One sample of one track, one frame, one text token; more than 96 / 128 tracks (the block-shared attention backward on unit
+    tables instead of the per-wave ragged form; inter-object units past two 64-row blocks); more than 32 encoded steps."""
+    cfg = synth.SMALL_MODEL_CFG
+    samples = [sample_inputs(cfg, N, T, L, 700 + i) for i, (N, T, L) in enumerate(shapes)]
+    ref_sum, ref_loss = None, []
+    for s in samples:
+        l3, g, _ = one_sample_step(small, s)
+        ref_loss.append(l3)
+        ref_sum = g if ref_sum is None else {k: ref_sum[k] + g[k] for k in g}
+    loss, got, _ = ragged_step(small, samples)
+    torch.testing.assert_close(loss, torch.stack(ref_loss), rtol=2e-4, atol=2e-4)
+    assert_grads_close(got, ref_sum, 2e-3, f"edge shapes {shapes}")
