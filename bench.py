@@ -255,7 +255,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
            "what": "forward_train + BCE/alignment losses + backward + clip + AdamW; dropout on, one GPU",
            "gflop_per_sample_fwd_bwd": round(3 * fl["total"] / 1e9, 2)}
     sync = lambda: torch.cuda.synchronize(dev)
-    for prec in ("f32", "f16x3", "f16"):
+    for prec in ("f32", "f16x3", "f16", "bf16"):
         m.precision = prec
         dt = timed(step, steps, sync)
         _dtp, prof = profiled(step, max(2, steps // 2), sync, warmup=0)
@@ -274,6 +274,9 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
             res[prec]["what"] = ("mixed precision (BASELINE config C2): every GEMM of the step on plain f16 casts of the f32 activations / "
                                  "gradients, f32 accumulation, ONE MFMA per product; everything else f32.  Reduced precision: losses within "
                                  "1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py)")
+        if prec == "bf16":
+            res[prec]["what"] = ("the same mixed-precision step with BFLOAT16 GEMM operands (v_mfma_f32_32x32x16_bf16), the format BASELINE "
+                                 "config C2 names; 8 significant bits, tolerance stated in tests/test_gpu_backward.py (LOWP_TRAIN_TOL)")
     # the reference's own regime: ONE sample per optimizer step (configs/mevis/default.yaml:37 batch_size 1), which is also what
     # train.py runs on variable-shape data (sola_forward_train takes one uniform batch)
     inp1 = {k: v[:1].contiguous() for k, v in inp.items()}
@@ -313,7 +316,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
            "what": "one optimizer step over 64 samples of different shapes: sola_forward_train_ragged + per-sample losses + "
                    "sola_backward_ragged + clip + AdamW; dropout on; a sample of this mix costs "
                    f"{rflops / S / fl['total']:.2f}x the headline shape's FLOPs"}
-    for prec in ("f32", "f16x3", "f16"):
+    for prec in ("f32", "f16x3", "f16", "bf16"):
         m.precision = prec
         dtr = timed(step_ragged, max(2, steps // 2), sync)
         _d, profr = profiled(step_ragged, 2, sync, warmup=0)

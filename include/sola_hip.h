@@ -88,7 +88,11 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  * GroupNorm backward and everything saved for the backward stay f32.  Precision 2 in training is MIXED precision (BASELINE
  * config C2): the same step with plain-f16 casts and ONE f16 MFMA per product (f32 accumulation, per-tensor power-of-two
  * scales); activations, statistics, softmax, saved tensors and master weights stay f32.  Reduced precision with a stated
- * tolerance: losses within 1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py). */
+ * tolerance: losses within 1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py).
+ *   3  TRAINING only (sola_forward_train[_ragged] / sola_backward[_ragged]; the inference entry points return SOLA_ERR_ARG):
+ *      the mixed-precision step of precision 2 with BFLOAT16 GEMM operands (v_cvt_pk_bf16_f32 casts, v_mfma_f32_32x32x16_bf16,
+ *      f32 accumulation) - the "bf16 training" BASELINE config C2 names.  8 significant bits instead of 11 for the same MFMA
+ *      rate; the tolerance is stated in tests/test_gpu_backward.py next to the f16 one. */
 int sola_set_precision(SolaCtx* ctx, int precision);
 /* Range handling of precision 1 in sola_forward / sola_forward_ragged.  The split-f16 pairs keep 22 significant bits for
  * every value within 2^-16 of its tensor's largest, on top of a per-tensor power-of-two scale:

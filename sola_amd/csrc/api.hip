@@ -359,7 +359,7 @@ extern "C" int sola_workspace_tap(const SolaCtx* c, const char* name, size_t* of
 }
 
 extern "C" int sola_set_precision(SolaCtx* c, int precision) {
-    SOLA_ARG(c && precision >= 0 && precision <= 2, "set_precision: 0 (f32), 1 (split-f16) or 2 (f16 storage)");
+    SOLA_ARG(c && precision >= 0 && precision <= 3, "set_precision: 0 (f32), 1 (split-f16), 2 (f16 storage / f16 GEMM operands) or 3 (bf16 GEMM operands, training)");
     if (precision >= 1 && !c->lin16_buf) {
         const size_t D = c->cfg.lang_token_dim;
         size_t ws_total = 0;
@@ -462,6 +462,7 @@ static bool split_known_out_of_range(const SolaCtx* c) { return c->precision == 
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
+    SOLA_ARG(!c || c->precision != 3, "forward: precision 3 (bf16 GEMM operands) is a TRAINING mode; inference runs precision 0, 1 or 2");
     if (c && split_known_out_of_range(c)) {
         c->split_fallbacks += 1;
         c->precision = 0;
@@ -509,6 +510,7 @@ extern "C" size_t sola_ragged_workspace_bytes(const SolaCtx* c, const SolaRagged
 extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch, float* score_map,
                                    float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
+    SOLA_ARG(!c || c->precision != 3, "forward_ragged: precision 3 (bf16 GEMM operands) is a TRAINING mode; inference runs precision 0, 1 or 2");
     try {  // the host-side plan allocates; nothing may throw across the ABI
         if (c && split_known_out_of_range(c)) {
             c->split_fallbacks += 1;

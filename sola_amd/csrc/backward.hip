@@ -190,16 +190,17 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     // split: every GEMM of the backward on f16 MFMAs - (hi, lo) operand pairs, three products (precision 1), or plain f16
     // operands, one product (precision 2: "pure"; mixed precision - activations, gradients and accumulation stay f32)
     const bool split = c->precision >= 1 && ar.off.count("dy_sp") != 0;
-    const bool pure = c->precision == 2;
+    const bool pure = c->precision >= 2;
+    const int bf = c->precision == 3 ? 1 : 0;  // bfloat16 GEMM operands
     const int lowp_arith = pure ? 2 : 1;
     auto cast_scaled = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
-        return pure ? launch_cast_f16_scaled(in, ld, out, K, rows, K, scal, s) : launch_cast_sp16_scaled(in, ld, out, K, rows, K, scal, s);
+        return pure ? launch_cast_f16_scaled(in, ld, out, K, rows, K, scal, s, bf) : launch_cast_sp16_scaled(in, ld, out, K, rows, K, scal, s);
     };
     auto cast_auto = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
-        return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s, 13, nullptr, bf) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
     };
     auto cast_fixed = [&](const float* in, int ld, float* out, long long rows, int K, float scale) -> int {
-        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s, 13, nullptr, bf) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
     };
 
     // ---- helpers ----------------------------------------------------------------------------------------------
@@ -239,7 +240,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         if (dy_rm_done) *dy_rm_done = false;
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
-            d.scal = sc; d.pure = pure;
+            d.scal = sc; d.pure = pure ? 1 + bf : 0;
             if (dy_rm_done && sc && g_bwd_dual_cast) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy; }
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
@@ -281,7 +282,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             }
             SOLA_TRY(cast_fixed(wt, n_cat, ar.get("wt_sp"), k_in, n_cat, kLinScale));
             d.p[0].W = ar.get("wt_sp");
-            d.arith = lowp_arith; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
+            d.arith = lowp_arith; d.bf16 = bf; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
         }
         return launch_gemm(d, s);
     };
@@ -482,7 +483,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes(rows, g.cout, g.k * g.cin, 1)) {
             SOLA_TRY(stats(dy, g.cout, rows, g.cout, 8, &scc));
             GemmTnSplitDesc d{};
-            d.scal = scc; d.pure = pure;
+            d.scal = scc; d.pure = pure ? 1 + bf : 0;
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
@@ -514,13 +515,13 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             float* scal = scc ? scc : ar.get("scal");
             if (scc) SOLA_TRY(cast_scaled(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
             else SOLA_TRY(cast_auto(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
-            if (pure) SOLA_TRY(launch_cast_f16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
+            if (pure) SOLA_TRY(launch_cast_f16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s, bf));
             else SOLA_TRY(launch_cast_sp16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));
             GemmDesc d{};
             d.nprob = 1;
             d.p[0] = GemmProblem{ar.get("dy_sp"), ar.get("wt_sp"), nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
             d.M = rows; d.N = g.k * g.cin; d.K = g.cout; d.lda = g.cout; d.ldc = g.k * g.cin;
-            d.arith = lowp_arith; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
+            d.arith = lowp_arith; d.bf16 = bf; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
             SOLA_TRY(launch_gemm(d, s));
             if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
         } else if (rt) {

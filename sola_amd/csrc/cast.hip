@@ -159,10 +159,26 @@ __global__ __launch_bounds__(256) void cast_sp16_auto_multi_kernel(const MultiAr
 
 // ---- f32 -> plain f16 rows (the 16-bit storage mode): 8 values per thread, 16-byte stores --------------------------------
 // SCALED: the power-of-two scale comes from the amax slot (cast_sp16_auto_kernel's rule), else from the argument
+// eight scaled f32 values -> eight 16-bit values: f16, or (bf) bfloat16 - both round to nearest even; the bits travel as a half8
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8 cvt16x8(const float4 v0, const float4 v1, float scale, int bf) {
+    const float x[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
+    if (bf) {
+        bf16x8c b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (__bf16)x[j];
+        return __builtin_bit_cast(half8, b);
+    }
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)x[j];
+    return h;
+}
+
 template <bool SCALED>
 __global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long rows,
                                                        int blocks_per_row, int ld_in, int ld_out, float scale_arg, float* __restrict__ scal,
-                                                       int target, float* __restrict__ scale_out) {
+                                                       int target, float* __restrict__ scale_out, int bf) {
     float scale = scale_arg;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (SCALED) {
@@ -179,12 +195,9 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__
     const int b = (int)(i - r * blocks_per_row);
     const float4 v0 = *reinterpret_cast<const float4*>(in + r * ld_in + b * 8);
     const float4 v1 = *reinterpret_cast<const float4*>(in + r * ld_in + b * 8 + 4);
-    half8 h;
-    h[0] = (_Float16)(v0.x * scale); h[1] = (_Float16)(v0.y * scale); h[2] = (_Float16)(v0.z * scale); h[3] = (_Float16)(v0.w * scale);
-    h[4] = (_Float16)(v1.x * scale); h[5] = (_Float16)(v1.y * scale); h[6] = (_Float16)(v1.z * scale); h[7] = (_Float16)(v1.w * scale);
-    *reinterpret_cast<half8*>(out + r * ld_out + b * 8) = h;
+    *reinterpret_cast<half8*>(out + r * ld_out + b * 8) = cvt16x8(v0, v1, scale, bf);
 }
-__global__ __launch_bounds__(256) void cast_f16_auto_multi_kernel(const MultiArgs a, float* __restrict__ scal, long long n8) {
+__global__ __launch_bounds__(256) void cast_f16_auto_multi_kernel(const MultiArgs a, float* __restrict__ scal, long long n8, int bf) {
     const float* in = a.in[blockIdx.z];
     _Float16* out = reinterpret_cast<_Float16*>(a.out[blockIdx.z]);
     float* sc = scal + 2 * blockIdx.z;
@@ -193,10 +206,7 @@ __global__ __launch_bounds__(256) void cast_f16_auto_multi_kernel(const MultiArg
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         const float4 v0 = *reinterpret_cast<const float4*>(in + i * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(in + i * 8 + 4);
-        half8 h;
-        h[0] = (_Float16)(v0.x * scale); h[1] = (_Float16)(v0.y * scale); h[2] = (_Float16)(v0.z * scale); h[3] = (_Float16)(v0.w * scale);
-        h[4] = (_Float16)(v1.x * scale); h[5] = (_Float16)(v1.y * scale); h[6] = (_Float16)(v1.z * scale); h[7] = (_Float16)(v1.w * scale);
-        *reinterpret_cast<half8*>(out + i * 8) = h;
+        *reinterpret_cast<half8*>(out + i * 8) = cvt16x8(v0, v1, scale, bf);
     }
 }
 
@@ -236,7 +246,7 @@ int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n
 }
 
 int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s,
-                    int target_exp, float* scale_out) {
+                    int target_exp, float* scale_out, int bf16) {
     SOLA_ARG(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_f16: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
     const long long n = rows * (K / 8);
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, (scal ? 10.0 : 6.0) * rows * K);
@@ -246,27 +256,27 @@ int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long
                            reinterpret_cast<unsigned*>(scal), rows, K / 4, ld_in);
         SOLA_LAUNCH_CHECK();
         hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out,
-                           scale_out ? scale : 0.f, scal, target_exp, scale_out);
+                           scale_out ? scale : 0.f, scal, target_exp, scale_out, bf16);
     } else {
         hipLaunchKernelGGL(cast_f16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out, scale, nullptr,
-                           0, nullptr);
+                           0, nullptr, bf16);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
 // the cast half of launch_cast_f16 with a data-dependent scale: scal[0] already holds max|in| (launch_amax_colsum)
-int launch_cast_f16_scaled(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, hipStream_t s) {
+int launch_cast_f16_scaled(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, hipStream_t s, int bf16) {
     SOLA_ARG(in && out && scal && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_f16_scaled: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
     const long long n = rows * (K / 8);
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 6.0 * rows * K);
     hipLaunchKernelGGL(cast_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, static_cast<_Float16*>(out), rows, K / 8, ld_in, ld_out,
-                       0.f, scal, 13, nullptr);
+                       0.f, scal, 13, nullptr, bf16);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
-int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s) {
+int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s, int bf16) {
     SOLA_ARG(in && out && scal && n > 0 && rows > 0 && K > 0 && K % 8 == 0, "cast_f16_auto_multi: n=%d rows=%d K=%d", n, rows, K);
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 10.0 * n * rows * K);
     SOLA_HIP(hipMemsetAsync(scal, 0, (size_t)2 * n * sizeof(float), s));
@@ -278,7 +288,7 @@ int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, 
         for (int i = 0; i < MULTI_MAX; ++i) { a.in[i] = i < nn ? in[i0 + i] : nullptr; a.out[i] = i < nn ? static_cast<float*>(out[i0 + i]) : nullptr; }
         hipLaunchKernelGGL(amax_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, reinterpret_cast<unsigned*>(scal + 2 * i0), elems / 4);
         SOLA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(cast_f16_auto_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, scal + 2 * i0, elems / 8);
+        hipLaunchKernelGGL(cast_f16_auto_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, scal + 2 * i0, elems / 8, bf16);
         SOLA_LAUNCH_CHECK();
     }
     return SOLA_OK;

@@ -120,6 +120,7 @@ Plan make_plan_ragged(const SolaCtx* c, const RagShape& r, bool train) {
 int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                       float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s, bool train, const RagShape* rs) {
     SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
+    SOLA_ARG(c->precision != 3 || train, "forward: precision 3 (bf16 GEMM operands) is a TRAINING mode; inference runs precision 0, 1 or 2");
     if (rs) SOLA_ARG(train && rs->identity, "forward: a ragged training batch has one sample per video (sample_video[i] == i)");
     else SOLA_ARG(B > 0 && N > 0 && T > 0 && L >= 1, "forward: bad sizes B=%d N=%d T=%d L=%d", B, N, T, L);
     for (const Weight& w : c->weights)
@@ -151,14 +152,15 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     // (from ~1024 token rows on: below that the step is launch-bound and the extra cast launches cost more than the GEMMs gain)
     // precision 2 ("pure"): the same structure with plain f16 GEMM operands, ONE MFMA per product - mixed-precision training:
     // activations, statistics, softmax, accumulation and everything the backward reads stay f32
-    const bool pure = c->precision == 2;
+    const bool pure = c->precision >= 2;
+    const int bf = c->precision == 3 ? 1 : 0;  // precision 3: the 16-bit GEMM operands are bfloat16 (training only; BASELINE config C2)
     const bool split = train && c->precision >= 1 && D % (pure ? 64 : 32) == 0 && c->cfg.object_token_dim % (pure ? 64 : 32) == 0 && p.M >= g_train_split_min_rows;
     const int lowp_arith = pure ? 2 : 1;
     auto cast_auto = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
-        return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s, 13, nullptr, bf) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
     };
     auto cast_fixed = [&](const float* in, int ld, float* out, long long rows, int K, float scale) -> int {
-        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s, 13, nullptr, bf) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
     };
 
     // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
@@ -217,7 +219,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             }
             gd.p[0].A = sp_a;
             gd.p[0].W = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->ws16_buf) + c->ws_off[i]) : c->ws16_buf + c->ws_off[i];
-            gd.arith = lowp_arith; gd.out_scale = 1.f;
+            gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
         }
         SOLA_TRY(launch_gemm(gd, s));
         if (i < 5) {
@@ -275,7 +277,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                 gd.p[j].W = lin16(attn, first_proj + j);
                 gd.p[j].scale_dev = lin_inv(attn, first_proj + j);
             }
-            gd.arith = lowp_arith; gd.out_scale = 1.f;
+            gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
             if (a_scal) gd.out_scale_dev = a_scal + 1;
         }
         return launch_gemm(gd, s);
@@ -289,7 +291,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         if (split) {
             SOLA_TRY(cast_fixed(ao, D, sp_a, M, D, 1.f));
             gd.p[0].A = sp_a; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
-            gd.arith = lowp_arith; gd.out_scale = 1.f;
+            gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
         }
         return launch_gemm(gd, s);
     };

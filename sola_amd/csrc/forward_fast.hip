@@ -37,10 +37,10 @@ int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
                 in.push_back(w);
                 out.push_back(c->lin16_buf + ((size_t)(l * 3 + a) * 4 + j) * D * D);
             }
-    if (c->precision == 2) {  // 16-bit storage mode: plain f16 copies (same per-matrix scales), packed in the first half of the buffer
-        std::vector<void*> outh;
+    if (c->precision >= 2) {  // 16-bit storage mode / 16-bit GEMM operands: plain f16 (precision 3: bfloat16) copies, same per-matrix
+        std::vector<void*> outh;  // scales, packed in the first half of the buffer
         for (size_t i = 0; i < out.size(); ++i) outh.push_back(reinterpret_cast<_Float16*>(c->lin16_buf) + i * (size_t)D * D);
-        SOLA_TRY(launch_cast_f16_auto_multi(in.data(), outh.data(), (int)in.size(), D, D, c->scal_pair(2), s));
+        SOLA_TRY(launch_cast_f16_auto_multi(in.data(), outh.data(), (int)in.size(), D, D, c->scal_pair(2), s, c->precision == 3 ? 1 : 0));
     } else {
         SOLA_TRY(launch_cast_sp16_auto_multi(in.data(), out.data(), (int)in.size(), D, D, c->scal_pair(2), s));
     }

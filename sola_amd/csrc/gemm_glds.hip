@@ -45,6 +45,7 @@ struct GldsArgs {
     const float* out_scale_dev;
     int r_sp16, c_sp16;
     int r_f16, c_f16;  // PURE kernels: residual / output stored as _Float16 (ldr / ldc in halfs)
+    int bf16;          // PURE kernels: the 16-bit operands are bfloat16 (launch-time selection of the PURE = 2 instantiations)
     const float* bias_scale_dev;  // optional device multiplier of the bias (GemmDesc::bias_scale_dev)
     int ablate;  // measurement only (sola_tune "gemm_ablate"): 4 = no epilogue
     int* guard;  // c_sp16: range guard word (GemmDesc::guard), null = unchecked
@@ -61,6 +62,7 @@ __device__ __forceinline__ void guard_sp16x4(int* guard, const float (&v)[4]) {
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -82,7 +84,7 @@ __device__ __forceinline__ int conv_tap_bits(int t0, int T_in) {
 // (hi, lo) pairs, so nothing about the DMA, the swizzle or the fragment reads changes - a "hi" chunk is simply halfs
 // 16j..16j+7 of the row and the "lo" chunk halfs 16j+8..16j+15 - and a product is hi*hi + lo*lo (two consecutive k-chunks,
 // the same permutation of k on both operands) instead of lo*hi + hi*lo + hi*hi: a third of the MFMAs for twice the k.
-template <int MI, int WAVES_M, int WAVES_N, bool CONV, bool PURE = false>
+template <int MI, int WAVES_M, int WAVES_N, bool CONV, int PURE = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_kernel(const GldsArgs a) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     constexpr int STAGES = 2;
@@ -215,7 +217,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (PURE) {
+                if constexpr (PURE == 2) {  // bf16 operands: the same 16-byte chunks, v_mfma_f32_32x32x16_bf16
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+                } else if constexpr (PURE == 1) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
                 } else {
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
 // instance, reduced over the wave (DPP + permlane swaps, no LDS), then (v - mean) * rstd * gamma + beta, LeakyReLU, split-f16
 // store - the GroupNorm launch and its read of the f32 conv output disappear (norm.hip's register shapes moved 8 bytes per
 // element for them).  GNT is a template parameter: the eight unrolled strips carry one variant of the statistics, not three.
-template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0, int NW = 8>
+template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
     // NW = 8: 256x256 tiles, 2 x 4 waves, two waves per SIMD.  NW = 4 (experiment, sola_tune "gemm_nw4"): 256x128 tiles, 2 x 2 waves, one
     // wave per SIMD and up to 512 registers each
@@ -531,7 +536,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (PURE) {
+                if constexpr (PURE == 2) {  // bf16 operands: the same 16-byte chunks, v_mfma_f32_32x32x16_bf16
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+                } else if constexpr (PURE == 1) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
                 } else {
@@ -1271,7 +1279,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_glds_pp_kernel(const GldsAr
     }
 }
 
-template <int MI, int WAVES_M, int WAVES_N, bool CONV, bool PURE = false>
+template <int MI, int WAVES_M, int WAVES_N, bool CONV, int PURE = 0>
 static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBM = MI * 32 * WAVES_M, GBN = 64 * WAVES_N;
     a.tiles_m = (M + GBM - 1) / GBM;
@@ -1303,7 +1311,7 @@ int g_gemm_nw4 = 0;  // experiment (sola_tune "gemm_nw4"): plain f32-output laun
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 
-template <bool CONV, int RMODE, int CSP, bool PURE = false, int GNT = 0, int NW = 8>
+template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBN = NW / 2 * 64;
     a.tiles_m = (M + 255) / 256;
@@ -1376,8 +1384,13 @@ static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
 // activations stay f32, only the GEMM inputs are cast); split-K partial sums are always f32 without residual
 template <bool CONV>
 static int launch_persist_pure(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
-    if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0, true>(a, M, N, nprob, s);
     const bool has_r = a.p[0].R != nullptr;
+    if (a.bf16) {  // bf16 operands (training with bf16 GEMM operands, BASELINE config C2): f32 outputs / residuals only
+        if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0, 2>(a, M, N, nprob, s);
+        if (has_r && !CONV) return launch_persist_t<false, 1, 0, 2>(a, M, N, nprob, s);
+        return launch_persist_t<CONV, 0, 0, 2>(a, M, N, nprob, s);
+    }
+    if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0, true>(a, M, N, nprob, s);
     if (a.c_f16) {
         if (CONV || !has_r) return launch_persist_t<CONV, 0, 2, true>(a, M, N, nprob, s);
         return launch_persist_t<false, 3, 2, true>(a, M, N, nprob, s);
@@ -1399,6 +1412,7 @@ static int launch_shape_pure(GldsArgs& a, int shape, int M, int N, int nprob, hi
     // the persistent kernel's residual modes of this arithmetic: f16 residual into an f16 output, f32 into f32
     const bool r_ok = !a.p[0].R || (!CONV && ((a.r_f16 && a.c_f16) || (!a.r_f16 && !a.c_f16)));
     if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV) && r_ok) return launch_persist_pure<CONV>(a, M, N, nprob, s);
+    if (a.bf16) return shape == 4 ? launch_glds<4, 2, 4, CONV, 2>(a, M, N, nprob, s) : launch_glds<2, 2, 2, CONV, 2>(a, M, N, nprob, s);
     if (shape == 4) return launch_glds<4, 2, 4, CONV, true>(a, M, N, nprob, s);
     return launch_glds<2, 2, 2, CONV, true>(a, M, N, nprob, s);
 }
@@ -1430,10 +1444,13 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldr = d.ldr; a.ldc = d.ldc;
     a.conv = d.conv; a.T_in = d.T_in; a.T_out = d.T_out; a.stride = d.stride; a.pad = d.pad; a.Cin = d.Cin;
     a.r_f16 = a.c_f16 = 0;
+    a.bf16 = 0;
     a.bias_scale_dev = d.bias_scale_dev;
-    if (d.arith == 2) {  // plain f16 operand rows: the kernels address A and W in 4-byte units of two halfs
+    if (d.arith == 2) {  // plain f16 (or bf16) operand rows: the kernels address A and W in 4-byte units of two 16-bit values
         a.K = d.K / 2; a.lda = d.lda / 2; a.Cin = d.Cin / 2;
         a.r_f16 = d.r_f16; a.c_f16 = d.c_f16;
+        a.bf16 = d.bf16 ? 1 : 0;
+        SOLA_ARG(!(a.bf16 && (a.r_f16 || a.c_f16)), "gemm: bf16 operands go with f32 outputs and residuals (training); the 16-bit STORAGE mode is f16");
     }
     a.rowmap = d.conv == 1 ? d.rowmap : nullptr;
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;

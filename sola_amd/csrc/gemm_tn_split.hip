@@ -26,12 +26,17 @@ __device__ __forceinline__ float auto_scale_t(unsigned amax_bits) {  // as cast.
 // With rowmap != null (ragged batches) row m reads source row rowmap[m].x + tap, zeros where bit `tap` of rowmap[m].y is clear.
 // With conv_T_out > 0 the input is the implicit im2col of a channels-last conv for ONE tap: row m = (r, to) reads source row
 // r * conv_T_in + to * conv_stride + conv_toff (tap - pad), zeros outside [0, conv_T_in).
-// PURE: the output is plain _Float16 ([cols][ld_out halfs]) for the one-MFMA-per-product GEMM (GemmDesc::arith 2).
+// PURE: the output is plain _Float16 ([cols][ld_out halfs]) for the one-MFMA-per-product GEMM (GemmDesc::arith 2); bf != 0: the
+// 16-bit values are bfloat16 bit patterns instead.
+__device__ __forceinline__ _Float16 cvt16(float v, int bf) {
+    if (bf) return __builtin_bit_cast(_Float16, (__bf16)v);
+    return (_Float16)v;
+}
 template <bool PURE>
 __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                                           int ld_in, long long ld_out, float* __restrict__ scal, int conv_T_in,
                                                           int conv_T_out, int conv_stride, int conv_toff, float* __restrict__ out_rm,
-                                                          long long ld_rm, const int2* __restrict__ rowmap, int tap) {
+                                                          long long ld_rm, const int2* __restrict__ rowmap, int tap, int bf) {
     __shared__ float tile[128][65];
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
                     typedef _Float16 half4t __attribute__((ext_vector_type(4)));
                     half4t h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)(v[e] * scale);
+                    for (int e = 0; e < 4; ++e) h[e] = cvt16(v[e] * scale, bf);
                     *reinterpret_cast<half4t*>(reinterpret_cast<_Float16*>(out_rm) + (long long)(r0 + r) * ld_rm + col) = h;
                 } else {  // 8-value blocks [hi8 | lo8]: this thread owns half a block
                     typedef _Float16 half4t __attribute__((ext_vector_type(4)));
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
         for (int e = 0; e < 8; ++e) {
             const float v = tile[8 * b + e][c];
             _Float16 h1, l1;
-            if (PURE) { h1 = (_Float16)v; l1 = (_Float16)0.f; }
+            if (PURE) { h1 = cvt16(v, bf); l1 = (_Float16)0.f; }
             else split_f16(v, h1, l1);
             hi[e] = h1; lo[e] = l1;
         }
@@ -165,13 +170,14 @@ __global__ __launch_bounds__(256) void col2im_ragged_kernel(const float* __restr
     *reinterpret_cast<float4*>(dx + i * 4) = acc;
 }
 
-int cast_t(bool pure, const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
+int cast_t(int pure, const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
            int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0, float* out_rm = nullptr, long long ld_rm = 0,
            const int2* rowmap = nullptr, int tap = 0) {
+    const int bf = pure == 2 ? 1 : 0;
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, ((pure ? 6.0 : 8.0) + (out_rm ? (pure ? 2.0 : 4.0) : 0.0)) * rows * cols);
     const dim3 grid((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64));
-    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap);
-    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap);
+    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap, bf);
+    else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap, bf);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -187,12 +193,12 @@ void geometry(int M, int& ksplit, long long& Mp, bool pure = false) {
 
 int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
     SOLA_ARG(in && out && rows > 0 && cols > 0 && ld_out % 128 == 0 && ld_out >= rows, "cast_sp16_t: rows=%d ld_out=%lld", rows, ld_out);
-    return cast_t(false, in, ld_in, out, ld_out, rows, cols, scal, s);
+    return cast_t(0, in, ld_in, out, ld_out, rows, cols, scal, s);
 }
 
-int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s) {
+int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int bf16) {
     SOLA_ARG(in && out && rows > 0 && cols > 0 && ld_out % 128 == 0 && ld_out >= rows, "cast_f16_t: rows=%d ld_out=%lld", rows, ld_out);
-    return cast_t(true, in, ld_in, static_cast<float*>(out), ld_out, rows, cols, scal, s);
+    return cast_t(bf16 ? 2 : 1, in, ld_in, static_cast<float*>(out), ld_out, rows, cols, scal, s);
 }
 
 int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s) {
@@ -239,6 +245,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     SOLA_ARG(d.scratch_bytes >= gemm_tn_split_scratch_bytes(d.M, d.N, d.K, d.nprob), "gemm_tn_split: scratch too small");
     int ks; long long Mp;
     const bool pure = d.pure != 0;
+    const int pure_fmt = d.pure;  // 0 split-f16, 1 f16, 2 bf16
     geometry(d.M, ks, Mp, pure);
     // transposed operands: rows of Mp split-f16 pairs (4 bytes per element) or Mp halfs (2 bytes); the buffers are sized for pairs
     const long long rowf = pure ? Mp / 2 : Mp;  // floats per transposed row
@@ -257,9 +264,9 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         if (rm) {  // + the row-major cast of the same gradient matrix (the dX GEMM's operand): one read of dY for both
             const long long off = d.A[j] - d.A[0];
             float* dst = pure ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(d.a_rm) + off) : d.a_rm + off;
-            SOLA_TRY(cast_t(pure, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s, 0, 0, 1, 0, dst, d.a_rm_ld));
+            SOLA_TRY(cast_t(pure_fmt, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s, 0, 0, 1, 0, dst, d.a_rm_ld));
         } else {
-            SOLA_TRY(cast_t(pure, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s));
+            SOLA_TRY(cast_t(pure_fmt, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s));
         }
         for (int e = 0; e < j; ++e)
             if (d.B[e] == d.B[j]) xt_of[j] = xt_of[e];
@@ -267,10 +274,10 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             float* dst = xt + (size_t)n_xt++ * d.K * rowf;
             if (d.conv) {  // rows [kk*Cin, (kk+1)*Cin) of X^T = tap kk of the implicit im2col
                 for (int kk = 0; kk < d.K / d.Cin; ++kk)
-                    SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst + (size_t)kk * d.Cin * rowf, Mp, d.M, d.Cin, d.scal_b, s, d.T_in, d.T_out, d.stride, kk - d.pad,
+                    SOLA_TRY(cast_t(pure_fmt, d.B[j], d.ldb, dst + (size_t)kk * d.Cin * rowf, Mp, d.M, d.Cin, d.scal_b, s, d.T_in, d.T_out, d.stride, kk - d.pad,
                                     nullptr, 0, d.rowmap, kk));
             } else {
-                SOLA_TRY(cast_t(pure, d.B[j], d.ldb, dst, Mp, d.M, d.K, d.scal_b, s));
+                SOLA_TRY(cast_t(pure_fmt, d.B[j], d.ldb, dst, Mp, d.M, d.K, d.scal_b, s));
             }
             xt_of[j] = dst;
         }
@@ -279,7 +286,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     g.nprob = d.nprob;
     for (int j = 0; j < d.nprob; ++j) g.p[j] = GemmProblem{at + (size_t)j * d.N * rowf, xt_of[j], nullptr, nullptr, d.C[j]};
     g.M = d.N; g.N = d.K; g.K = (int)Mp; g.lda = (int)Mp; g.ldr = 0; g.ldc = d.K;
-    g.arith = pure ? 2 : 1; g.out_scale = 1.f; g.out_scale_dev = scal + 1;
+    g.arith = pure ? 2 : 1; g.bf16 = pure_fmt == 2 ? 1 : 0; g.out_scale = 1.f; g.out_scale_dev = scal + 1;
     if (d.scal_b)  // the activations' own scale (the caller's tokens): every problem shares it
         for (int j = 0; j < d.nprob; ++j) g.p[j].scale_dev = d.scal_b + 1;
     g.ksplit = ks; g.splitk_ws = slabs; g.splitk_bytes = (size_t)d.nprob * ks * d.N * d.K * sizeof(float);

@@ -36,6 +36,8 @@ struct GemmDesc {
     int r_sp16;       // arith 1: the residual R is split-f16
     int c_sp16;       // arith 1: write C as split-f16 pairs (N % 8 == 0), e.g. q/k/v for the split attention kernel
     int r_f16, c_f16; // arith 2: R / C are _Float16 matrices (ldr / ldc count halfs then; N % 4 == 0, pitches % 4 == 0)
+    int bf16;         // arith 2: A and W hold bfloat16 rows instead of f16 ones (v_mfma_f32_32x32x16_bf16; f32 C / R only): training with
+                      // bf16 GEMM operands (BASELINE config C2)
     const float* bias_scale_dev;  // direct-to-LDS kernels, optional: the bias is multiplied by this device scalar (an output kept in
                                   // the units of a scaled input: conv0 of the 16-bit storage mode)
     // optional scratch for the two-pass split-K of small grids (fewer 64x64 tiles than CUs): S partial sums per problem,
@@ -76,7 +78,8 @@ struct GemmTnSplitDesc {
     float* scal;  // optional device pair with scal[0] = max|A| over all problems already computed (else found here)
     float* scal_b;  // optional device pair with scal_b[0] = max|B| already computed: B is cast with that power-of-two scale too
                     // (activations whose magnitude the caller does not control: the object tokens); null = B is cast unscaled
-    int pure;     // 1: plain f16 transposed operands and ONE f16 MFMA per product (training with f16 GEMM operands), else split-f16
+    int pure;     // 1: plain f16 transposed operands and ONE f16 MFMA per product (training with f16 GEMM operands), 2: the same in
+                  // bfloat16, else split-f16
     // optional: the transposing cast of A also writes the ROW-MAJOR cast of A (same scale, the format of launch_cast_f16_scaled /
     // launch_cast_sp16_scaled) - the operand of the dX GEMM that consumes the same gradient matrix - so dY is read once for both.
     // a_rm addresses the value (row 0, column of A[0]); problem j lands at column A[j] - A[0]; a_rm_ld = row pitch in values.
@@ -260,12 +263,14 @@ int launch_cast_sp16_auto_multi(const float* const* in, float* const* out, int n
 // f32 rows -> plain _Float16 rows (16-bit storage mode).  scal != null: data-dependent power-of-two scale as above (scal[1]
 // receives its inverse), else the fixed `scale`.  ld_out counts halfs.
 // target_exp: the largest magnitude lands in [2^target_exp, 2^(target_exp+1)); scale_out (optional, device): receives the scale itself
+// bf16 = 1 (every launcher of this group): the 16-bit values are bfloat16 (round to nearest even) instead of f16 - same bytes, same
+// layouts; the GEMM that consumes them gets GemmDesc::bf16
 int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float scale, float* scal, hipStream_t s,
-                    int target_exp = 13, float* scale_out = nullptr);
-int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s);
-int launch_cast_f16_scaled(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
+                    int target_exp = 13, float* scale_out = nullptr, int bf16 = 0);
+int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, int rows, int K, float* scal, hipStream_t s, int bf16 = 0);
+int launch_cast_f16_scaled(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, hipStream_t s, int bf16 = 0);
 // transposing cast to plain f16: in [rows][cols] f32 -> out [cols][ld_out halfs] (ld_out % 128 == 0, zero-filled past rows)
-int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s);
+int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int bf16 = 0);
 // Weight-time range check of the split-f16 activations: a GroupNorm output has E[y^2] = gamma^2 + beta^2 per channel (its
 // input is normalised), so the magnitude of every tensor the norms emit is known from the weights alone.  Sets bit 1 of
 // *guard when the rms of any (gamma, beta) pair lies outside [2^-6, 2^9] - where the fixed-scale split-f16 activations would

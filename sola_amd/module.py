@@ -93,7 +93,9 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # step, forward and backward (attention and GroupNorm backward stay f32); "f16" = 16-bit activation STORAGE for the
         # inference forward, uniform and ragged (plain f16 between kernels, one f16 MFMA per product, f32 accumulate / softmax /
         # statistics; a reduced-precision mode with a stated tolerance); in TRAINING it is mixed
-        # precision: every GEMM of the step on plain-f16 casts, one MFMA per product, everything else f32)
+        # precision: every GEMM of the step on plain-f16 casts, one MFMA per product, everything else f32); "bf16" = the same
+        # mixed-precision TRAINING step with bfloat16 GEMM operands (BASELINE.json configs[2] "bf16 training" - a
+        # build-side mode, the reference itself trains in fp32), inference calls of such a module run "f16x3")
         # Default (round 3): "f16x3", the range-guarded split-f16 mode - what bench.py's headline measures, the same 1e-3 parity
         # bar and error class as the exact-f32 kernels, backed by those kernels whenever its guard trips.  The entry
         # points (train.py / eval.py / inference.py) take it from here; SOLA_PRECISION=f32 selects exact f32 everywhere.
@@ -150,7 +152,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         split-f16 / f16 copies of the projection matrices and their scales) are rebuilt on the next call."""
         self._weights_touched = True
 
-    def _bind_weights(self):
+    def _bind_weights(self, train=False):
         """Hand the library the current device pointer of every state_dict tensor; flag in-place updates."""
         # A training forward is followed by an optimizer step.  ``Tensor._version`` cannot be trusted to show it:
         # torch.optim.AdamW(fused=True) updates the parameters without bumping it (the split-f16 copies of the projection
@@ -175,11 +177,14 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # weight changes; "always" / "cached" force either behaviour (bench.py uses "always")
         every = self.training if self.ws_policy == "auto" else self.ws_policy == "always"
         check(lib().sola_set_ws_policy(self._ctx, 1 if every else 0), "sola_set_ws_policy")
-        if self.precision not in ("f32", "f16x3", "f16"):
-            raise SolaError(f"precision must be 'f32', 'f16x3' or 'f16', got {self.precision!r}")
-        if self._ctx_precision != self.precision:
-            check(lib().sola_set_precision(self._ctx, {"f32": 0, "f16x3": 1, "f16": 2}[self.precision]), "sola_set_precision")
-            self._ctx_precision = self.precision
+        if self.precision not in ("f32", "f16x3", "f16", "bf16"):
+            raise SolaError(f"precision must be 'f32', 'f16x3', 'f16' or 'bf16', got {self.precision!r}")
+        # "bf16" is a TRAINING mode (bfloat16 GEMM operands, library precision 3); inference calls of a module set to it run the
+        # default split-f16 kernels
+        want = {"f32": 0, "f16x3": 1, "f16": 2, "bf16": 3 if train else 1}[self.precision]
+        if self._ctx_precision != want:
+            check(lib().sola_set_precision(self._ctx, want), "sola_set_precision")
+            self._ctx_precision = want
         if self._ctx_guard != bool(self.split_guard):
             check(lib().sola_set_split_guard(self._ctx, 1 if self.split_guard else 0), "sola_set_split_guard")
             self._ctx_guard = bool(self.split_guard)
@@ -335,7 +340,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         obj = object_tokens.detach().to(torch.float32).contiguous()
         lang = lang_tokens.detach().to(torch.float32).contiguous()
         self._ensure_ctx(dev)
-        self._bind_weights()
+        self._bind_weights(train=True)
         self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
         self._set_step_dropout()
         nbytes = lib().sola_train_workspace_bytes(self._ctx, B, N, T, L)
@@ -371,7 +376,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         lang = torch.cat([t.detach() for t in lang_tokens], 0).to(torch.float32).contiguous()
         batch = self._ragged_batch_struct(object_tokens, lang_tokens, list(range(S)))
         self._ensure_ctx(dev)
-        self._bind_weights()
+        self._bind_weights(train=True)
         self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
         self._set_step_dropout()
         nbytes = lib().sola_train_ragged_workspace_bytes(self._ctx, C.byref(batch))

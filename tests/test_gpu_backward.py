@@ -337,7 +337,18 @@ def test_split_training_gradients_match_exact_f32(full_model):
     assert not bad, bad
 
 
-def test_f16_operand_training_vs_exact_f32(full_model, full_golden):
+# stated tolerances of the two 16-bit-operand training modes against the exact-f32 step: (loss rtol, min gradient cosine, worst
+# tensor, median tensor, total-gradient-norm rtol against the REFERENCE's).  bf16 carries 8 significant bits where f16 carries 11:
+# its operand rounding noise is 8x larger, so the same saturated-softmax near-ties (docstring below) move further - measured at
+# this shape: loss within 0.6 %, cosine 0.744, worst tensor 73 %, median 4.8 %.  The yardstick for that error class is the textbook
+# recipe on the ORACLE: autograd through oracle/sola_oracle.py under torch.autocast(bfloat16) against the same step in fp32 gives
+# cosine 0.563, worst tensor 98 %, median 6.1 % (tools/bf16_autocast_oracle.py, profiles/r03_bf16_training.txt) - the library's
+# mode keeps f32 storage between the GEMMs and lands inside it.
+LOWP_TRAIN_TOL = {"f16": (1e-2, 0.95, 0.35, 3e-2, 5e-2), "bf16": (2e-2, 0.70, 0.85, 8e-2, 0.15)}
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_f16_operand_training_vs_exact_f32(full_model, full_golden, mode):
     """precision "f16" in training (BASELINE config C2's 16-bit training): every GEMM of the step - forward, dX, dW - on plain
     f16 casts of the f32 activations / gradients with f32 accumulation (ONE MFMA per product; per-tensor power-of-two scales),
     everything else f32: mixed precision in the sense of torch.autocast, with f16's 11 bits instead of bf16's 8.
@@ -346,32 +357,36 @@ def test_f16_operand_training_vs_exact_f32(full_model, full_golden):
     in the 16-bit inference mode) and the gradients of everything upstream of that attention (its q / k projections, the
     encoder) by 16-22 % in the Frobenius norm, the other tensors by 0.3-0.9 % (median), the whole gradient keeps a cosine of
     0.977-0.987 with the exact-f32 one (profiles/r02_f16_training_errors.log).  Stated: losses within 1 %, cosine >= 0.95,
-    every tensor within 35 %, median within 3 %, total gradient norm within 5 % of the REFERENCE's."""
+    every tensor within 35 %, median within 3 %, total gradient norm within 5 % of the REFERENCE's.
+    precision "bf16" (library precision 3) is the same step with bfloat16 operands (v_mfma_f32_32x32x16_bf16) - the format
+    BASELINE config C2 names; its bounds are the second row of LOWP_TRAIN_TOL."""
     from sola_amd import _lib
     m, _ = full_model
     cfg = synth.DEFAULT_MODEL_CFG
+    l_rtol, min_cos, worst_tol, median_tol, norm_rtol = LOWP_TRAIN_TOL[mode]
     grads, losses = {}, {}
     try:
-        for prec in ("f32", "f16"):
+        for prec in ("f32", mode):
             m.precision = prec
             _, l3, g = train_step_grads(m, cfg, 8, 40, 32, 10, 77)  # 1280 token rows: above the size gate
             grads[prec] = {k: v.double().clone() for k, v in g.items()}
             losses[prec] = l3.detach().cpu().numpy().astype(np.float64)
     finally:
         m.precision = "f32"
-    np.testing.assert_allclose(losses["f16"], losses["f32"], rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(losses[mode], losses["f32"], rtol=l_rtol, atol=1e-3)
     ref = grads["f32"]
     total = math.sqrt(sum(float(v.pow(2).sum()) for v in ref.values()))
-    n16 = math.sqrt(sum(float(v.pow(2).sum()) for v in grads["f16"].values()))
-    cos = sum(float((grads["f16"][k] * ref[k]).sum()) for k in ref) / (total * n16)
-    rel = sorted(float((grads["f16"][k] - ref[k]).norm()) / (float(ref[k].norm()) + 1e-5 * total) for k in ref)
-    print(f"f16-operand training: cosine {cos:.5f}, worst tensor {rel[-1]:.3e}, median {rel[len(rel) // 2]:.3e}")
-    assert cos >= 0.95 and rel[-1] <= 0.35 and rel[len(rel) // 2] <= 3e-2, (cos, rel[-1], rel[len(rel) // 2])
+    n16 = math.sqrt(sum(float(v.pow(2).sum()) for v in grads[mode].values()))
+    cos = sum(float((grads[mode][k] * ref[k]).sum()) for k in ref) / (total * n16)
+    rel = sorted(float((grads[mode][k] - ref[k]).norm()) / (float(ref[k].norm()) + 1e-5 * total) for k in ref)
+    lerr = float(np.abs(losses[mode] / losses["f32"] - 1).max())
+    print(f"{mode}-operand training: loss rel {lerr:.3e}, cosine {cos:.5f}, worst tensor {rel[-1]:.3e}, median {rel[len(rel) // 2]:.3e}")
+    assert cos >= min_cos and rel[-1] <= worst_tol and rel[len(rel) // 2] <= median_tol, (cos, rel[-1], rel[len(rel) // 2])
     # the same mode on a golden case: losses and total gradient norm against the reference's
     ci = 1
     B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
     g = case_dict(full_golden, ci)
-    m.precision = "f16"
+    m.precision = mode
     try:
         _lib.check(_lib.lib().sola_tune(b"train_split_min_rows", 0), "tune")
         _, loss3, _ = train_step_grads(m, cfg, B, N, T, L, 200 + ci)
@@ -379,9 +394,11 @@ def test_f16_operand_training_vs_exact_f32(full_model, full_golden):
     finally:
         m.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_split_min_rows", 1024), "tune")
-    np.testing.assert_allclose(loss3.detach().cpu().numpy().astype(np.float64), g["loss"], rtol=1e-2, atol=1e-3)
     gref = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norm_vals"]))
-    assert gnd["total_grad_norm"] == pytest.approx(gref["total_grad_norm"], rel=5e-2)
+    print(f"{mode}-operand training, golden case {ci}: loss {loss3.detach().cpu().numpy()} vs {g['loss']}, total gradient norm "
+          f"{gnd['total_grad_norm']:.5f} vs {gref['total_grad_norm']:.5f}")
+    np.testing.assert_allclose(loss3.detach().cpu().numpy().astype(np.float64), g["loss"], rtol=l_rtol, atol=1e-3)
+    assert gnd["total_grad_norm"] == pytest.approx(gref["total_grad_norm"], rel=norm_rtol)
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -408,7 +425,7 @@ def test_training_run_tracks_exact_f32_across_optimizer_steps(fused):
             return sum(float(loss_of(m, b)[0]) for b in batches) / len(batches)
 
     final = {}
-    for prec in ("f32", "f16x3", "f16"):
+    for prec in ("f32", "f16x3", "f16", "bf16"):
         m = LanguageAlignedTrackSelectionModule(cfg)
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
         m = m.cuda()
@@ -424,7 +441,8 @@ def test_training_run_tracks_exact_f32_across_optimizer_steps(fused):
         final[prec] = eval_loss(m)
         assert final[prec] < 0.67 * start, (prec, start, final[prec])
         del m, opt
-    for prec in ("f16x3", "f16"):
+    print("eval-mode exact-f32 loss after 12 steps:", final)
+    for prec in ("f16x3", "f16", "bf16"):
         assert abs(final[prec] - final["f32"]) <= 0.15 * final["f32"], final
 
 

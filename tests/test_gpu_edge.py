@@ -56,6 +56,33 @@ def test_bad_inputs_raise(model):
                 m(obj[0], lang)                         # missing batch dimension
 
 
+def test_bf16_is_a_training_mode(model):
+    """Library precision 3 (bfloat16 GEMM operands) exists for the training step only: the inference entry points refuse it
+    (SOLA_ERR_ARG), and a module set to "bf16" runs its inference calls on the default split-f16 kernels."""
+    import ctypes as C
+    from sola_amd import _lib
+    m, sd, cfg = model
+    inp = synth.make_inputs(cfg, 1, 6, 16, 5, 9)
+    obj, lang = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
+    m.precision = "f16x3"
+    with torch.no_grad():
+        want = [t.clone() for t in m(obj, lang)]
+    m.precision = "bf16"
+    try:
+        with torch.no_grad():
+            got = m(obj, lang)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        _lib.check(_lib.lib().sola_set_precision(m._ctx, 3), "sola_set_precision")
+        m._ctx_precision = None  # the module re-applies its own setting on the next call
+        sm, st = torch.empty(1, 6, device="cuda"), torch.empty(1, 6, cfg["lang_token_dim"], device="cuda")
+        ws = torch.empty(int(_lib.lib().sola_workspace_bytes(m._ctx, 1, 6, 16, 5)), dtype=torch.uint8, device="cuda")
+        rc = _lib.lib().sola_forward(m._ctx, _lib.ptr(obj), _lib.ptr(lang), 1, 6, 16, 5, _lib.ptr(sm), _lib.ptr(st), _lib.ptr(ws),
+                                     C.c_size_t(ws.numel()), None)
+        assert rc != 0 and b"TRAINING mode" in _lib.lib().sola_last_error()
+    finally:
+        m.precision = "f32"
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     return [(int(rng.integers(1, 4)), int(rng.integers(1, 41)), int(rng.integers(1, 71)), int(rng.integers(1, 21))) for _ in range(n)]

@@ -178,9 +178,9 @@ def test_mixed_batch_equals_one_sample_steps_small(small):
 FULL_SHAPES = [(8, 8, 16), (64, 32, 16), (16, 32, 9), (3, 1, 4), (80, 32, 11), (7, 33, 24), (12, 150, 5)]
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
 def test_mixed_batch_equals_one_sample_steps_full(full, precision):
-    """Default configuration, all three precision modes: each mode's ragged step against its own one-sample steps (which
+    """Default configuration, all four precision modes: each mode's ragged step against its own one-sample steps (which
     test_gpu_backward.py holds to the reference's gradients)."""
     cfg = synth.DEFAULT_MODEL_CFG
     full.precision = precision
@@ -194,12 +194,15 @@ def test_mixed_batch_equals_one_sample_steps_full(full, precision):
         loss, got, _ = ragged_step(full, samples)
     finally:
         full.precision = "f32"
-    if precision == "f16":  # reduced precision with a stated tolerance (tests/test_gpu_backward.py): per-tensor scales differ between
-        # a one-sample call and the batch, so the comparison is statistical
-        torch.testing.assert_close(loss, torch.stack(ref_loss), rtol=2e-2, atol=2e-2)
+    if precision in ("f16", "bf16"):  # reduced precision with a stated tolerance (tests/test_gpu_backward.py): per-tensor scales differ
+        # between a one-sample call and the batch, so the comparison is statistical
+        tol, min_cos = (2e-2, 0.95) if precision == "f16" else (5e-2, 0.95)  # measured: 2.5e-3 / 0.99993 and 1.4e-2 / 0.99972
         num = sum(float((got[k].double() * ref_sum[k].double()).sum()) for k in got)
         den = (sum(float((got[k].double() ** 2).sum()) for k in got) * sum(float((ref_sum[k].double() ** 2).sum()) for k in got)) ** 0.5
-        assert num / den > 0.95, f"gradient cosine {num / den}"
+        print(f"{precision}: ragged step vs one-sample steps, worst loss difference {float((loss - torch.stack(ref_loss)).abs().max()):.3e}, "
+              f"gradient cosine {num / den:.5f}")
+        torch.testing.assert_close(loss, torch.stack(ref_loss), rtol=tol, atol=tol)
+        assert num / den > min_cos, f"gradient cosine {num / den}"
         return
     torch.testing.assert_close(loss, torch.stack(ref_loss), rtol=3e-4, atol=3e-4)
     assert_grads_close(got, ref_sum, 5e-3 if precision == "f16x3" else 2e-3, f"vs one-sample steps ({precision})")

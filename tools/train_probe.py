@@ -1,6 +1,10 @@
-"""Training step time (forward_train + loss + backward + clip + AdamW) at a batch, exact f32 vs split-f16 forward."""
+"""Training step time (forward_train + loss + backward + clip + AdamW) at a batch, per precision mode.
+
+    python tools/train_probe.py [batch = 64] [modes, comma separated = f32,f16x3,f16,bf16]
+"""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sola_amd import synth
 from sola_amd.loss import track_selection_losses
 from sola_amd.module import LanguageAlignedTrackSelectionModule
@@ -20,7 +24,8 @@ def step():
     m.clip_grad_norm_(1.0)
     opt.step()
     return loss3
-for prec in ("f16x3", "f16", "f16x3", "f16") if len(sys.argv) > 2 else ("f32", "f16x3", "f16", "f32", "f16x3", "f16"):
+modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f32", "f16x3", "f16", "bf16"]
+for prec in modes + modes:
     m.precision = prec
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
