@@ -163,14 +163,22 @@ def gemm_roofline(prof, precision, step_s, steps):
 
 
 def attn_roofline(prof):
+    """Attention core of a profiled leg: algorithmic bytes (q, k, v read + o written) per second against the HBM peak, and - the
+    exact-f32 kernels compute QK^T and PV on v_mfma_f32_16x16x4_f32 - the algorithmic 4*Sq*Sk*dh flops per (unit, head) against
+    the f32 MFMA peak: from ~80 keys per unit on, the matrix pipe's time at its peak rate exceeds the HBM time (N = 128: 219 us vs
+    134 us per inter-object launch), so `frac` alone understates those shapes; `bound` names the larger of the two fractions."""
     a = prof["attn"]
     if a["ms"] <= 0:
         return None
     gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+    tfs = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tfs / F32_MFMA_PEAK_TFLOPS
     return {"kernel": "attention core, all launches of a step: attn_fwd_f32_simple_kernel (inter-object), attn_fwd_small_kernel / attn_fwd_f32_reg_kernel "
-                      "(motion), attn_fwd_f32_res_kernel (object->language); exact f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
-            "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 2)}
+                      "(motion), attn_fwd_f32_res_kernel (object->language); exact f32", "bound": "hbm" if f_hbm >= f_mfma else "mfma",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(f_hbm, 4), "traffic": None, "launches": a["launches"],
+            "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 2),
+            "f32_mfma_side": {"achieved": round(tfs, 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}}
 
 
 def kernel_ms(prof, steps):

@@ -649,10 +649,301 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
     }
 }
 
+// ---- ONE pass for units of at most 128 queries and 128 keys (round 3) ------------------------------------------------------
+// The two-pass kernels recompute S and dP in both passes (7 tile products instead of 5) and read q, k, v, dO twice; on a ragged
+// batch of short units (inter-object attention over 8..80 tracks, motion attention over 3..25 steps) every wave also stages its
+// own copy of the streamed side with no load in flight under its MFMAs: 5.4 ms of a 28 ms step where the traffic takes 1.0 ms and
+// the matrix pipe 0.9 ms.  Here a BLOCK owns one (unit, head):
+//   * wave w keeps ONE 16-key tile in registers - k / v rows as MFMA operands (kf, vf), K again with the key on the contraction
+//     slots (kT) - and its dK / dV accumulators; units of more than 16 * NWU keys walk their key tiles in groups of NWU;
+//   * the block walks the unit's 16-query tiles: q and dO rows are staged ONCE per tile for all waves (NWU = 4: the next tile
+//     travels in registers under the current tile's MFMAs, two LDS buffers);
+//   * per tile a wave computes S = Q K^T and dP = dO V^T for its keys, P from the saved log-sum-exp, dS = P o (dP - D), then
+//     dV += P^T dO, dK += dS^T Q, and - dS transposed through 1 KB of wave-private LDS - its partial dQ = dS K;
+//   * the NWU partial dQ tiles are summed through LDS in wave order (bit-repeatable: no atomics) and written once; a later key
+//     group adds to what the same thread wrote before.
+// D = dO . O and the log-sum-exp of the unit's queries sit in LDS.  Same arithmetic, masks and dropout counters as the two-pass
+// kernels.  q, k, v, o, dO are read once and dQ, dK, dV written once per (unit, head).
+template <int NWU>
+__global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnBwdArgs a) {
+    constexpr int DH = 128, NC = DH / 16, LD = DH + 4, F4 = DH / 4, NT = 64 * NWU;
+    constexpr bool PF = false;  // register prefetch of the next tile + two staging buffers: spills at two waves per SIMD (10 registers), off
+    constexpr int NBUF = PF ? 2 : 1;
+    constexpr int PER = 16 * F4 / NT;  // float4 per thread per tensor per tile
+    constexpr int SLOTS = NWU > 1 ? NWU * 16 * LD : 0;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    float* const Qs = smem;                    // [NBUF][16][LD]
+    float* const Gs = Qs + NBUF * 16 * LD;     // [NBUF][16][LD]  dO rows
+    float* const slots = Gs + NBUF * 16 * LD;  // [NWU][16][LD]   partial dQ tiles
+    float* const tsc = slots + SLOTS + wave * (16 * 17);
+    float* const dsh = slots + SLOTS + NWU * (16 * 17);  // [128] D = dO . O
+    float* const lsh = dsh + 128;                         // [128] log-sum-exp
+
+    const int h = (int)(blockIdx.x % a.H), grp = (int)(blockIdx.x / a.H);
+    const BwdGeo geo = bwd_geo(a, grp);
+    const int nkt = (geo.Sk + 15) >> 4, nqt = (geo.Sq + 15) >> 4;
+
+    for (int r0 = 0; r0 < geo.Sq; r0 += NT / 32) {  // D and lse of the unit's queries: half a wave per row
+        const int r = r0 + (tid >> 5), l32 = tid & 31;
+        const bool ok = r < geo.Sq;
+        const long long row = geo.q0 + (long long)(ok ? r : 0) * geo.q_rs;
+        const float4 ov = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + 4 * l32);
+        const float4 gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + 4 * l32);
+        const float d = half_sum32((ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w));
+        if (ok && l32 == 0) {
+            dsh[r] = d;
+            lsh[r] = a.lse[row * a.H + h];
+        }
+    }
+    auto stage_direct = [&](int qt0, int buf) {
+#pragma unroll (NWU == 2 ? 1 : 2)
+        for (int j = 0; j < PER; ++j) {
+            const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
+            const int q = qt0 + r;
+            const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
+            float4 qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
+            float4 gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
+            if (q >= geo.Sq) qv = gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Qs[(buf * 16 + r) * LD + c4 * 4]) = qv;
+            *reinterpret_cast<float4*>(&Gs[(buf * 16 + r) * LD + c4 * 4]) = gv;
+        }
+    };
+
+    for (int kg = 0; kg < nkt; kg += NWU) {
+        const int kt = kg + wave;
+        const bool w_ok = kt < nkt;
+        const int kj = kt * 16 + c16;
+        const bool k_ok = w_ok && kj < geo.Sk;
+        const long long krow = geo.k0 + (long long)(k_ok ? kj : 0) * geo.k_rs;
+        float4 kf[NC], vf[NC];
+        float kT[NC][4];
+        {
+            const float* kp = a.k + krow * a.ldk + h * DH + 4 * g4;
+            const float* vp = a.v + krow * a.ldv + h * DH + 4 * g4;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 kl = *reinterpret_cast<const float4*>(kp + c * 16);  // clamped row, VALUE select (see attn_bwd_dkv_kernel)
+                const float4 kv = k_ok ? kl : z;
+                kf[c] = make_float4(kv.x * a.scale, kv.y * a.scale, kv.z * a.scale, kv.w * a.scale);
+                const float4 vl = *reinterpret_cast<const float4*>(vp + c * 16);
+                vf[c] = k_ok ? vl : z;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // the same tile with the key on the contraction slots: K[key = 4*g4 + r][d = 16*c + c16]
+                const int kk = kt * 16 + 4 * g4 + r;
+                const bool okr = w_ok && kk < geo.Sk;
+                const float* kr = a.k + (geo.k0 + (long long)(okr ? kk : 0) * geo.k_rs) * a.ldk + h * DH + c16;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float v = kr[c * 16];
+                    kT[c][r] = okr ? v * a.scale : 0.f;
+                }
+            }
+        }
+        f32x4 dkacc[NC], dvacc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        stage_direct(0, 0);
+        __syncthreads();  // also: dsh / lsh written (first group), the previous group's last reduction done
+        for (int it = 0; it < nqt; ++it) {
+            const int qt0 = it * 16, cur = PF ? (it & 1) : 0;
+            const bool more = it + 1 < nqt;
+            float4 pq[PER], pg[PER];
+            if constexpr (PF) {
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
+                        const int q = qt0 + 16 + r;
+                        const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
+                        pq[j] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
+                        pg[j] = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
+                        if (q >= geo.Sq) pq[j] = pg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+            f32x4 dqacc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dqacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w_ok) {
+                const float* Qc = Qs + cur * 16 * LD;
+                const float* Gc = Gs + cur * 16 * LD;
+                // S[q][key] and dP[q][key]: A = Q / dO rows (b128), B = k / v fragments; lane gets q = 4*g4 + r, key = c16
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                const float* qp = &Qc[c16 * LD + 4 * g4];
+                const float* gp = &Gc[c16 * LD + 4 * g4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 qv = *reinterpret_cast<const float4*>(qp + c * 16);
+                    const float4 gv = *reinterpret_cast<const float4*>(gp + c * 16);
+                    if (c & 1) {
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, s1, 0, 0, 0);
+                        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, p1, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[c].y, s1, 0, 0, 0);
+                        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, vf[c].y, p1, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kf[c].z, s1, 0, 0, 0);
+                        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.z, vf[c].z, p1, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kf[c].w, s1, 0, 0, 0);
+                        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, p1, 0, 0, 0);
+                    } else {
+                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, s0, 0, 0, 0);
+                        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, p0, 0, 0, 0);
+                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[c].y, s0, 0, 0, 0);
+                        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, vf[c].y, p0, 0, 0, 0);
+                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kf[c].z, s0, 0, 0, 0);
+                        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.z, vf[c].z, p0, 0, 0, 0);
+                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kf[c].w, s0, 0, 0, 0);
+                        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, p0, 0, 0, 0);
+                    }
+                }
+                const float4 lse4 = *reinterpret_cast<const float4*>(&lsh[qt0 + 4 * g4]);
+                const float4 dv4 = *reinterpret_cast<const float4*>(&dsh[qt0 + 4 * g4]);
+                const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dv_r[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+                float pr[4], ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt0 + 4 * g4 + r;
+                    const bool ok = k_ok && q < geo.Sq;
+                    pr[r] = ok ? __expf((s0[r] + s1[r]) - lse_r[r]) : 0.f;
+                    const float dp = p0[r] + p1[r];
+                    float keep = 1.f;
+                    if (a.drop.enabled)
+                        keep = dropout_keep(a.drop, ((unsigned long long)(grp * a.H + h) * geo.Sq + q) * geo.Sk + kj) ? a.drop.scale : 0.f;
+                    ds[r] = ok ? pr[r] * (dp * keep - dv_r[r]) : 0.f;
+                    pr[r] *= keep;  // dV uses the dropped probabilities
+                }
+                // dV^T[d][key] += sum_q dO[q][d] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* gr = &Gc[(4 * g4 + r) * LD + c16];
+                    const float* qr = &Qc[(4 * g4 + r) * LD + c16];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        dvacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[c * 16], pr[r], dvacc[c], 0, 0, 0);
+                        dkacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[c * 16], ds[r], dkacc[c], 0, 0, 0);
+                    }
+                }
+                // dS with the KEY on the contraction slots: through the wave's own 16 x 17 words of LDS
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tsc[(4 * g4 + r) * 17 + c16] = ds[r];
+                stage_sync<true>();
+                float dst[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = tsc[c16 * 17 + 4 * g4 + r];  // dS[q = c16][key = 4*g4 + r]
+                stage_sync<true>();  // the next tile's writes stay behind these reads
+                // dQ^T[d][q] += sum_key K[key][d] * dS[q][key]   (K pre-scaled)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dqacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kT[c][r], dst[r], dqacc[c], 0, 0, 0);
+                if constexpr (NWU > 1) {
+                    float* sl = slots + wave * 16 * LD + c16 * LD + 4 * g4;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        *reinterpret_cast<float4*>(sl + c * 16) = make_float4(dqacc[c][0], dqacc[c][1], dqacc[c][2], dqacc[c][3]);
+                }
+            }
+            if constexpr (PF) {
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
+                        *reinterpret_cast<float4*>(&Qs[((cur ^ 1) * 16 + r) * LD + c4 * 4]) = pq[j];
+                        *reinterpret_cast<float4*>(&Gs[((cur ^ 1) * 16 + r) * LD + c4 * 4]) = pg[j];
+                    }
+                }
+            }
+            if constexpr (NWU > 1) {
+                __syncthreads();  // partial tiles complete (and, with the prefetch, the next tile staged)
+                const int nact = min(NWU, nkt - kg);
+#pragma unroll 1
+                for (int j = 0; j < PER; ++j) {
+                    const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
+                    float4 acc = *reinterpret_cast<const float4*>(&slots[r * LD + c4 * 4]);
+                    for (int w = 1; w < nact; ++w) {
+                        const float4 v = *reinterpret_cast<const float4*>(&slots[(w * 16 + r) * LD + c4 * 4]);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                    const int q = qt0 + r;
+                    if (q < geo.Sq) {
+                        float* p = a.dq + (geo.q0 + (long long)q * geo.q_rs) * a.ld_dq + h * DH + c4 * 4;
+                        if (kg > 0) {  // written by this same thread in the previous key group
+                            const float4 old = *reinterpret_cast<const float4*>(p);
+                            acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+                        }
+                        *reinterpret_cast<float4*>(p) = acc;
+                    }
+                }
+                if constexpr (!PF) {
+                    if (more) stage_direct(qt0 + 16, 0);
+                }
+                __syncthreads();  // the partial tiles are free again (and the next tile staged)
+            } else {
+                const int q = qt0 + c16;
+                if (q < geo.Sq) {  // one wave, one key tile: dqacc is the whole dQ tile
+                    float* p = a.dq + (geo.q0 + (long long)q * geo.q_rs) * a.ld_dq + h * DH + 4 * g4;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        float4 acc = make_float4(dqacc[c][0], dqacc[c][1], dqacc[c][2], dqacc[c][3]);
+                        if (kg > 0) {
+                            const float4 old = *reinterpret_cast<const float4*>(p + c * 16);
+                            acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+                        }
+                        *reinterpret_cast<float4*>(p + c * 16) = acc;
+                    }
+                }
+                __syncthreads();  // every lane is done with the tile
+                if (more) stage_direct(qt0 + 16, 0);
+                __syncthreads();
+            }
+        }
+        if (k_ok) {
+            float* dkp = a.dk + krow * a.ld_dk + h * DH + 4 * g4;
+            float* dvp = a.dv + krow * a.ld_dv + h * DH + 4 * g4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                *reinterpret_cast<float4*>(dkp + c * 16) = make_float4(dkacc[c][0] * a.scale, dkacc[c][1] * a.scale,
+                                                                       dkacc[c][2] * a.scale, dkacc[c][3] * a.scale);
+                *reinterpret_cast<float4*>(dvp + c * 16) = make_float4(dvacc[c][0], dvacc[c][1], dvacc[c][2], dvacc[c][3]);
+            }
+        }
+    }
+}
+
+
 int g_attn_bwd_rag_wave = 96;  // sola_tune "attn_bwd_rag_wave": ragged batches whose LONGEST unit has at most this many queries and keys take
                                // the per-wave kernels in their RAG form (0 = never)
 int g_attn_bwd_blk = 1;    // sola_tune "attn_bwd_blk": 0 = per-wave staging (the round-1 kernels) for every shape (A/B)
 int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels for every shape (A/B)
+int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
+
+template <int NWU>
+static int launch_bwd_fused_n(const AttnBwdArgs& a, hipStream_t s) {
+    constexpr int LD = 128 + 4;
+    constexpr size_t lds = ((size_t)2 * 16 * LD + (NWU > 1 ? NWU * 16 * LD : 0) + NWU * 16 * 17 + 256) * sizeof(float);
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done(dev);
+    }
+    const long long blocks = (long long)a.G * a.H;
+    SOLA_ARG(blocks < (1ll << 31), "attention backward: grid too large");
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU>), dim3((unsigned)blocks), dim3(64 * NWU), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+static bool bwd_fused_supported(const AttnBwdArgs& a, int DH) { return g_attn_bwd_fused && DH == 128 && a.Sq <= 128 && a.Sk <= 128; }
+static int launch_bwd_fused(const AttnBwdArgs& a, hipStream_t s) {
+    // waves per (unit, head) = key tiles held in registers at a time, sized by the LONGEST unit of the launch
+    if (a.Sk <= 16) return launch_bwd_fused_n<1>(a, s);
+    if (a.Sk <= 32) return launch_bwd_fused_n<2>(a, s);
+    return launch_bwd_fused_n<4>(a, s);
+}
 
 static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
     const long long units = (long long)a.G * a.H;
@@ -750,6 +1041,7 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
 void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
 void sola_attn_set_bwd_blk(int v) { g_attn_bwd_blk = v; }
 void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
+void sola_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
 
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");
@@ -767,6 +1059,7 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
     if (g_attn_bwd_small && d.DH == 128 && d.Sq <= 4 && d.Sk <= 4) return launch_bwd_small(a, s);
+    if (bwd_fused_supported(a, d.DH)) return launch_bwd_fused(a, s);
     switch (d.DH) {
         case 128: return launch_bwd_dh<128>(a, s);
         case 64: return launch_bwd_dh<64>(a, s);

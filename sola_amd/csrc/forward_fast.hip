@@ -66,7 +66,11 @@ int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
     return SOLA_OK;
 }
 
-int g_attn_split_min_keys = 64;  // sola_tune "attn_split_min_keys": units with more keys than this take the split-f16 MFMA shape
+// sola_tune "attn_split_min_keys": units with more keys than this take the split-f16 MFMA attention on q/k/v the projection GEMMs
+// wrote as split pairs.  128 since round 3 (was 64): behind the one-pass / register-only f32 shapes (attn_simple.hip, attn_reg.hip)
+// that kernel loses at 80 keys (401 vs 280 us per launch, step 14.38 -> 13.91 ms at 192 x 80 x 32) and ties at 128 (step 14.52 vs
+// 14.44 ms); it keeps the units of more than 128 keys, where the f32 matrix pipe alone would take longer than the HBM traffic
+int g_attn_split_min_keys = 128;
 void sola_attn_set_split_min_keys(int v) { g_attn_split_min_keys = v; }
 
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,

@@ -23,6 +23,8 @@
 
 int launch_attention_f16(const AttnDesc& d, hipStream_t s);
 
+extern int g_attn_split_min_keys;  // forward_fast.hip
+
 namespace {
 
 // ---- device-side plan: unit tables from the compact per-video / per-sample descriptors ---------------------------
@@ -573,10 +575,10 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
         return launch_attention(ad, s);
     };
     // q/k/v leave the projection already split where the attention runs the split-f16 MFMA shape (forward_fast.hip: units of
-    // more than 64 keys; never the packed short-sequence shape)
-    const int obj_in_sp = (sp && r.maxN > 64 && DH % 16 == 0) ? 1 : 0;
-    const int mot_in_sp = (sp && maxTp > 64 && DH % 16 == 0) ? 1 : 0;
-    const int o2l_in_sp = (sp && r.maxW > 64 && DH % 16 == 0) ? 1 : 0;
+    // more than g_attn_split_min_keys keys; never the packed short-sequence shape)
+    const int obj_in_sp = (sp && r.maxN > g_attn_split_min_keys && DH % 16 == 0) ? 1 : 0;
+    const int mot_in_sp = (sp && maxTp > g_attn_split_min_keys && DH % 16 == 0) ? 1 : 0;
+    const int o2l_in_sp = (sp && r.maxW > g_attn_split_min_keys && DH % 16 == 0) ? 1 : 0;
     const int spi = sp ? 1 : 0;
     float *q = buf("q"), *k = buf("k"), *v = buf("v");
 
