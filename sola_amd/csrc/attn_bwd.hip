@@ -27,6 +27,11 @@ struct AttnBwdArgs {
     // are then the LARGEST lengths: they size the grids and - in the per-wave kernels, whose four waves serve different units
     // between shared block barriers - the loop trip counts; rows past a unit's own length are masked
     const int4 *q_units, *k_units;
+    // one-pass kernel, long query ranges (object -> language): a block serves qc_tiles 16-query tiles of its unit (0 = all of them) and
+    // writes its dK / dV partial sums to part[slot][2][16 * NWU][128], slot = first row / (16 * qc_tiles) + unit + chunk (injective for
+    // units of row stride 1 laid out in unit order); attn_bwd_part_reduce_kernel adds a unit's chunks in order
+    int qc_tiles;
+    float* part;
 };
 
 struct BwdGeo { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
@@ -678,25 +683,17 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
     float* const Gs = Qs + NBUF * 16 * LD;     // [NBUF][16][LD]  dO rows
     float* const slots = Gs + NBUF * 16 * LD;  // [NWU][16][LD]   partial dQ tiles
     float* const tsc = slots + SLOTS + wave * (16 * 17);
-    float* const dsh = slots + SLOTS + NWU * (16 * 17);  // [128] D = dO . O
-    float* const lsh = dsh + 128;                         // [128] log-sum-exp
+    float* const dsh = slots + SLOTS + NWU * (16 * 17);  // [16] D = dO . O of the staged tile's queries
+    float* const lsh = dsh + 16;                          // [16] their log-sum-exp
 
     const int h = (int)(blockIdx.x % a.H), grp = (int)(blockIdx.x / a.H);
     const BwdGeo geo = bwd_geo(a, grp);
-    const int nkt = (geo.Sk + 15) >> 4, nqt = (geo.Sq + 15) >> 4;
+    const int nkt = (geo.Sk + 15) >> 4, nqt_all = (geo.Sq + 15) >> 4;
+    const int qt_begin = a.qc_tiles ? (int)blockIdx.y * a.qc_tiles : 0;
+    const int nqt = a.qc_tiles ? min(nqt_all, qt_begin + a.qc_tiles) : nqt_all;  // this block's tiles: [qt_begin, nqt)
+    if (qt_begin >= nqt) return;  // a chunk past the unit's queries (ragged batches size the grid for the longest unit)
 
-    for (int r0 = 0; r0 < geo.Sq; r0 += NT / 32) {  // D and lse of the unit's queries: half a wave per row
-        const int r = r0 + (tid >> 5), l32 = tid & 31;
-        const bool ok = r < geo.Sq;
-        const long long row = geo.q0 + (long long)(ok ? r : 0) * geo.q_rs;
-        const float4 ov = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + 4 * l32);
-        const float4 gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + 4 * l32);
-        const float d = half_sum32((ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w));
-        if (ok && l32 == 0) {
-            dsh[r] = d;
-            lsh[r] = a.lse[row * a.H + h];
-        }
-    }
+    // a tile's q and dO rows -> LDS; a row is the 32 float4 of half a wave, which also sums D = dO . O for it (DPP, no LDS)
     auto stage_direct = [&](int qt0, int buf) {
 #pragma unroll (NWU == 2 ? 1 : 2)
         for (int j = 0; j < PER; ++j) {
@@ -705,7 +702,13 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
             float4 qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
             float4 gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
+            const float4 ov = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
             if (q >= geo.Sq) qv = gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float d = half_sum32((ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w));
+            if (c4 == 0) {
+                dsh[r] = d;
+                lsh[r] = a.lse[row * a.H + h];
+            }
             *reinterpret_cast<float4*>(&Qs[(buf * 16 + r) * LD + c4 * 4]) = qv;
             *reinterpret_cast<float4*>(&Gs[(buf * 16 + r) * LD + c4 * 4]) = gv;
         }
@@ -747,9 +750,9 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
 #pragma unroll
         for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        stage_direct(0, 0);
-        __syncthreads();  // also: dsh / lsh written (first group), the previous group's last reduction done
-        for (int it = 0; it < nqt; ++it) {
+        stage_direct(qt_begin * 16, 0);
+        __syncthreads();  // also: the previous group's last reduction done
+        for (int it = qt_begin; it < nqt; ++it) {
             const int qt0 = it * 16, cur = PF ? (it & 1) : 0;
             const bool more = it + 1 < nqt;
             float4 pq[PER], pg[PER];
@@ -800,8 +803,8 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                         p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, p0, 0, 0, 0);
                     }
                 }
-                const float4 lse4 = *reinterpret_cast<const float4*>(&lsh[qt0 + 4 * g4]);
-                const float4 dv4 = *reinterpret_cast<const float4*>(&dsh[qt0 + 4 * g4]);
+                const float4 lse4 = *reinterpret_cast<const float4*>(&lsh[4 * g4]);
+                const float4 dv4 = *reinterpret_cast<const float4*>(&dsh[4 * g4]);
                 const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dv_r[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
                 float pr[4], ds[4];
 #pragma unroll
@@ -904,6 +907,11 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         if (k_ok) {
             float* dkp = a.dk + krow * a.ld_dk + h * DH + 4 * g4;
             float* dvp = a.dv + krow * a.ld_dv + h * DH + 4 * g4;
+            if (a.qc_tiles) {  // this chunk's partial sums (one key group: the launcher chunks units of at most 16 * NWU keys only)
+                const long long slot = geo.q0 / (16 * a.qc_tiles) + grp + blockIdx.y;
+                dkp = a.part + ((slot * a.H + h) * 2 * (16 * NWU) + kj) * DH + 4 * g4;
+                dvp = dkp + (16 * NWU) * DH;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 *reinterpret_cast<float4*>(dkp + c * 16) = make_float4(dkacc[c][0] * a.scale, dkacc[c][1] * a.scale,
@@ -911,6 +919,26 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 *reinterpret_cast<float4*>(dvp + c * 16) = make_float4(dvacc[c][0], dvacc[c][1], dvacc[c][2], dvacc[c][3]);
             }
         }
+    }
+}
+
+// dK / dV of a chunked launch: the partial sums of a unit's chunks, added in chunk order
+__global__ __launch_bounds__(256) void attn_bwd_part_reduce_kernel(const AttnBwdArgs a, int kp) {
+    constexpr int DH = 128;
+    const int h = (int)(blockIdx.x % a.H), grp = (int)(blockIdx.x / a.H);
+    const BwdGeo geo = bwd_geo(a, grp);
+    const int nch = ((geo.Sq + 15) / 16 + a.qc_tiles - 1) / a.qc_tiles;
+    const long long slot0 = geo.q0 / (16 * a.qc_tiles) + grp;
+    for (int idx = threadIdx.x; idx < geo.Sk * 2 * (DH / 4); idx += 256) {
+        const int c4 = idx & 31, t = (idx >> 5) & 1, kj = idx >> 6;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < nch; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(a.part + (((slot0 + c) * a.H + h) * 2 + t) * (long long)kp * DH + kj * DH + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const long long krow = geo.k0 + (long long)kj * geo.k_rs;
+        float* p = t ? a.dv + krow * a.ld_dv + h * DH + c4 * 4 : a.dk + krow * a.ld_dk + h * DH + c4 * 4;
+        *reinterpret_cast<float4*>(p) = acc;
     }
 }
 
@@ -922,9 +950,9 @@ int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels f
 int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
 
 template <int NWU>
-static int launch_bwd_fused_n(const AttnBwdArgs& a, hipStream_t s) {
+static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     constexpr int LD = 128 + 4;
-    constexpr size_t lds = ((size_t)2 * 16 * LD + (NWU > 1 ? NWU * 16 * LD : 0) + NWU * 16 * 17 + 256) * sizeof(float);
+    constexpr size_t lds = ((size_t)2 * 16 * LD + (NWU > 1 ? NWU * 16 * LD : 0) + NWU * 16 * 17 + 32) * sizeof(float);
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
@@ -932,17 +960,32 @@ static int launch_bwd_fused_n(const AttnBwdArgs& a, hipStream_t s) {
         once.done(dev);
     }
     const long long blocks = (long long)a.G * a.H;
-    SOLA_ARG(blocks < (1ll << 31), "attention backward: grid too large");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU>), dim3((unsigned)blocks), dim3(64 * NWU), lds, s, a);
+    SOLA_ARG(blocks < (1ll << 31) && chunks < 65536, "attention backward: grid too large");
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
     SOLA_LAUNCH_CHECK();
+    if (a.qc_tiles) {
+        hipLaunchKernelGGL(attn_bwd_part_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, 16 * NWU);
+        SOLA_LAUNCH_CHECK();
+    }
     return SOLA_OK;
 }
-static bool bwd_fused_supported(const AttnBwdArgs& a, int DH) { return g_attn_bwd_fused && DH == 128 && a.Sq <= 128 && a.Sk <= 128; }
-static int launch_bwd_fused(const AttnBwdArgs& a, hipStream_t s) {
+// queries per chunk of a chunked launch (object -> language: up to N * T' = 2048 queries against <= 64 keys): 16 tiles = 256
+constexpr int kBwdChunkTiles = 16;
+static bool bwd_fused_supported(const AttnBwdArgs& a, int DH, bool can_chunk) {
+    if (!g_attn_bwd_fused || DH != 128 || a.Sk > 128) return false;
+    return a.Sq <= 128 || (a.Sk <= 64 && (a.Sq <= 16 * kBwdChunkTiles || can_chunk));
+}
+static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, hipStream_t s) {
     // waves per (unit, head) = key tiles held in registers at a time, sized by the LONGEST unit of the launch
-    if (a.Sk <= 16) return launch_bwd_fused_n<1>(a, s);
-    if (a.Sk <= 32) return launch_bwd_fused_n<2>(a, s);
-    return launch_bwd_fused_n<4>(a, s);
+    int chunks = 1;
+    a.qc_tiles = 0;
+    if (a.Sq > 16 * kBwdChunkTiles && can_chunk) {
+        a.qc_tiles = kBwdChunkTiles;
+        chunks = ((a.Sq + 15) / 16 + kBwdChunkTiles - 1) / kBwdChunkTiles;
+    }
+    if (a.Sk <= 16) return launch_bwd_fused_n<1>(a, chunks, s);
+    if (a.Sk <= 32) return launch_bwd_fused_n<2>(a, chunks, s);
+    return launch_bwd_fused_n<4>(a, chunks, s);
 }
 
 static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
@@ -1038,6 +1081,11 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
 
 }  // namespace
 
+size_t attention_bwd_part_floats(long long q_rows, int G, int H, int Sk) {
+    if (Sk > 64) return 0;
+    return (size_t)(q_rows / (16 * kBwdChunkTiles) + G + 1) * H * 2 * 64 * 128;
+}
+
 void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
 void sola_attn_set_bwd_blk(int v) { g_attn_bwd_blk = v; }
 void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
@@ -1059,7 +1107,13 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
     if (g_attn_bwd_small && d.DH == 128 && d.Sq <= 4 && d.Sk <= 4) return launch_bwd_small(a, s);
-    if (bwd_fused_supported(a, d.DH)) return launch_bwd_fused(a, s);
+    // chunked launches address their partial sums by the unit's first row: units of row stride 1 in unit order (the caller's promise
+    // when it hands over `part`), sized by attention_bwd_part_floats()
+    a.qc_tiles = 0;
+    a.part = d.part;
+    const bool can_chunk = d.part && d.Sk <= 64 && d.part_floats >= attention_bwd_part_floats(d.part_rows, d.G, d.H, d.Sk) &&
+                           (d.q_units || (d.q_rs == 1 && d.inner == 1));
+    if (bwd_fused_supported(a, d.DH, can_chunk)) return launch_bwd_fused(a, can_chunk, s);
     switch (d.DH) {
         case 128: return launch_bwd_dh<128>(a, s);
         case 64: return launch_bwd_dh<64>(a, s);

@@ -64,6 +64,9 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
     a.add("dlkv", BW * 2 * D);
     a.add("dlang", BW * D);
     a.add("dvec", M * H);
+    // object -> language attention backward in one pass: dK / dV partial sums per 256-query chunk of a sample (attn_bwd.hip); sized
+    // for the most keys a text can have against the 64 the chunked launch takes (0 floats otherwise: the two-pass kernels run)
+    a.add("attn_part", attention_bwd_part_floats((long long)M, (int)z.S, (int)H, 64));
     a.add("dlbar_part", R * D);
     a.add("dlbar", z.S * D);
     // GroupNorm partials are [n_inst][C]; n_inst is B*N (per track), B*T' (per time step) or B
@@ -362,6 +365,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                            B, H, DH, max_rows_smp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
             if (rt) { ad.q_units = rt->u_smp; ad.k_units = rt->u_langk; }
             ad.drop = c->attn_drop(l, 2);
+            // a sample's N * T' query rows are consecutive and the samples follow each other: the chunked one-pass launch applies
+            ad.part = ar.get("attn_part");
+            ad.part_floats = attention_bwd_part_floats((long long)M, B, H, 64);
+            ad.part_rows = (long long)M;
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
             float *scq, *sckv;

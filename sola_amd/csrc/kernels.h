@@ -144,8 +144,16 @@ struct AttnBwdDesc {
     // optional, ragged batches: as AttnDesc::q_units / k_units (per-group (first row, row stride, length, -)); Sq / Sk are then
     // the LARGEST lengths
     const int4 *q_units, *k_units;
+    // optional scratch of the one-pass kernel for long query ranges against <= 64 keys (object -> language): a unit's queries are
+    // cut into chunks of 256, each chunk's dK / dV partial sums land here and are added in order.  part_floats >=
+    // attention_bwd_part_floats(part_rows, G, H, Sk), part_rows = rows of the q matrix (the units' rows: stride 1, in unit order).
+    // Without it such launches take the two-pass kernels.
+    float* part = nullptr;
+    size_t part_floats = 0;
+    long long part_rows = 0;
 };
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);
+size_t attention_bwd_part_floats(long long q_rows, int G, int H, int Sk);
 
 // ---- backward of the elementwise / reduction stages (bwd.hip) -------------------------------------------------
 struct GroupNormBwdDesc {
