@@ -13,6 +13,9 @@
 
 namespace {
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 struct AttnBwdArgs {
     const float *q, *k, *v, *o, *dout, *lse;
     float *dq, *dk, *dv, *dvec;  // dvec [q rows][H]
@@ -672,19 +675,25 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
 template <int NWU>
 __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnBwdArgs a) {
     constexpr int DH = 128, NC = DH / 16, LD = DH + 4, F4 = DH / 4, NT = 64 * NWU;
-    constexpr bool PF = false;  // register prefetch of the next tile + two staging buffers: spills at two waves per SIMD (10 registers), off
-    constexpr int NBUF = PF ? 2 : 1;
+    // NWU = 4: the next tile's q, dO and O rows travel straight into LDS (global_load_lds, no registers) under the current tile's
+    // MFMAs - two tile buffers.  The LDS side of the instruction is lane-linear (base + 16 * lane = two 512-byte rows back to back),
+    // so a tile is eight row PAIRS of 1024 + 32 bytes: the b32 column reads stay conflict-free, the b128 row reads see 2-way
+    // conflicts (16 reads per tile).  D = dO . O is then summed from LDS.
+    // NWU = 1, 2: up to eight / four blocks per CU overlap each other; loads through registers, one buffer, rows padded to LD.
+    constexpr bool DMA = NWU == 4;
+    constexpr int NBUF = DMA ? 2 : 1, RP = LD;  // row pitch of a staged tile, floats
     constexpr int PER = 16 * F4 / NT;  // float4 per thread per tensor per tile
     constexpr int SLOTS = NWU > 1 ? NWU * 16 * LD : 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
-    float* const Qs = smem;                    // [NBUF][16][LD]
-    float* const Gs = Qs + NBUF * 16 * LD;     // [NBUF][16][LD]  dO rows
-    float* const slots = Gs + NBUF * 16 * LD;  // [NWU][16][LD]   partial dQ tiles
+    float* const Qs = smem;                         // [NBUF][16][RP]
+    float* const Gs = Qs + NBUF * 16 * RP;          // [NBUF][16][RP]  dO rows
+    float* const Os = Gs + NBUF * 16 * RP;          // [16][RP]        O rows of the tile in flight (DMA only)
+    float* const slots = Os + (DMA ? 16 * RP : 0);  // [NWU][16][LD]   partial dQ tiles
     float* const tsc = slots + SLOTS + wave * (16 * 17);
-    float* const dsh = slots + SLOTS + NWU * (16 * 17);  // [16] D = dO . O of the staged tile's queries
-    float* const lsh = dsh + 16;                          // [16] their log-sum-exp
+    float* const dsh = slots + SLOTS + NWU * (16 * 17);  // [NBUF][16] D = dO . O of the staged tile's queries
+    float* const lsh = dsh + NBUF * 16;                   // [NBUF][16] their log-sum-exp
 
     const int h = (int)(blockIdx.x % a.H), grp = (int)(blockIdx.x / a.H);
     const BwdGeo geo = bwd_geo(a, grp);
@@ -693,9 +702,13 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
     const int nqt = a.qc_tiles ? min(nqt_all, qt_begin + a.qc_tiles) : nqt_all;  // this block's tiles: [qt_begin, nqt)
     if (qt_begin >= nqt) return;  // a chunk past the unit's queries (ragged batches size the grid for the longest unit)
 
-    // a tile's q and dO rows -> LDS; a row is the 32 float4 of half a wave, which also sums D = dO . O for it (DPP, no LDS)
-    auto stage_direct = [&](int qt0, int buf) {
-#pragma unroll (NWU == 2 ? 1 : 2)
+    // element (row r, 16-byte chunk ch) of a staged tile
+    auto at = [&](float* base, int buf, int r, int ch) -> float* {
+        return DMA ? base + buf * 16 * RP + (r >> 1) * (2 * RP) + (r & 1) * DH + (ch << 2) : base + (buf * 16 + r) * RP + (ch << 2);
+    };
+    // registers path: a tile's q and dO rows -> LDS; a row is the 32 float4 of half a wave, which also sums D = dO . O for it
+    auto stage_direct = [&](int qt0) {
+#pragma unroll(NWU == 2 ? 1 : 2)
         for (int j = 0; j < PER; ++j) {
             const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
             const int q = qt0 + r;
@@ -709,9 +722,40 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 dsh[r] = d;
                 lsh[r] = a.lse[row * a.H + h];
             }
-            *reinterpret_cast<float4*>(&Qs[(buf * 16 + r) * LD + c4 * 4]) = qv;
-            *reinterpret_cast<float4*>(&Gs[(buf * 16 + r) * LD + c4 * 4]) = gv;
+            *reinterpret_cast<float4*>(at(Qs, 0, r, c4)) = qv;
+            *reinterpret_cast<float4*>(at(Gs, 0, r, c4)) = gv;
         }
+    };
+    // DMA path: wave w moves row pairs 2w and 2w+1 of each of the three tensors, one pair (1 KB) per instruction; rows past the
+    // unit's queries re-read its first row (finite values; their probabilities are masked to zero).  (Two half-wave instructions
+    // per pair under `if (lane < 32) ... else ...` do NOT work: the compiler merges the branches and reads the LDS base of the first
+    // lane for the whole wave.)
+    auto issue_tile = [&](int qt0, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pr2 = wave * 2 + i, r = pr2 * 2 + (lane >> 5), ch = lane & 31;
+            const int q = qt0 + r;
+            const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
+            const int pc = buf * 16 * RP + pr2 * (2 * RP);  // floats
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.q + row * a.ldq + h * DH + ch * 4), (lptr_t)(Qs + pc), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + row * a.ldo + h * DH + ch * 4), (lptr_t)(Gs + pc), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.o + row * a.ldo + h * DH + ch * 4), (lptr_t)(Os + pr2 * (2 * RP)), 16, 0, 0);
+        }
+    };
+    auto lse_of = [&](int qt0) -> float {  // threads 0..15: the log-sum-exp of the tile's rows
+        const int q = qt0 + (tid & 15);
+        return a.lse[(geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs) * a.H + h];
+    };
+    auto dvec_from_lds = [&](int buf, float lse_reg) {  // D of a landed tile: half a wave per row, two rows per wave and pass
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wave * 2 + j) * 2 + (lane >> 5), c4 = lane & 31;
+            const float4 gv = *reinterpret_cast<const float4*>(at(Gs, buf, r, c4));
+            const float4 ov = *reinterpret_cast<const float4*>(at(Os, 0, r, c4));
+            const float d = half_sum32((ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w));
+            if (c4 == 0) dsh[buf * 16 + r] = d;
+        }
+        if (tid < 16) lsh[buf * 16 + tid] = lse_reg;
     };
 
     for (int kg = 0; kg < nkt; kg += NWU) {
@@ -720,6 +764,8 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         const int kj = kt * 16 + c16;
         const bool k_ok = w_ok && kj < geo.Sk;
         const long long krow = geo.k0 + (long long)(k_ok ? kj : 0) * geo.k_rs;
+        if constexpr (DMA) issue_tile(qt_begin * 16, 0);  // under the K / V loads
+        float lse_reg = DMA ? lse_of(qt_begin * 16) : 0.f;
         float4 kf[NC], vf[NC];
         float kT[NC][4];
         {
@@ -750,39 +796,34 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
 #pragma unroll
         for (int c = 0; c < NC; ++c) dkacc[c] = dvacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        stage_direct(qt_begin * 16, 0);
-        __syncthreads();  // also: the previous group's last reduction done
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile 0 landed; also: the previous group's last reduction done
+            dvec_from_lds(0, lse_reg);
+            __syncthreads();
+        } else {
+            stage_direct(qt_begin * 16);
+            __syncthreads();  // also: the previous group's last reduction done
+        }
         for (int it = qt_begin; it < nqt; ++it) {
-            const int qt0 = it * 16, cur = PF ? (it & 1) : 0;
+            const int qt0 = it * 16, cur = DMA ? ((it - qt_begin) & 1) : 0;
             const bool more = it + 1 < nqt;
-            float4 pq[PER], pg[PER];
-            if constexpr (PF) {
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < PER; ++j) {
-                        const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
-                        const int q = qt0 + 16 + r;
-                        const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
-                        pq[j] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
-                        pg[j] = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
-                        if (q >= geo.Sq) pq[j] = pg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+            if constexpr (DMA) {
+                if (more && !(a.ntile & 2)) {
+                    issue_tile(qt0 + 16, cur ^ 1);
+                    lse_reg = lse_of(qt0 + 16);
                 }
             }
             f32x4 dqacc[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) dqacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (w_ok) {
-                const float* Qc = Qs + cur * 16 * LD;
-                const float* Gc = Gs + cur * 16 * LD;
+            if (w_ok && !(a.ntile & 1)) {
                 // S[q][key] and dP[q][key]: A = Q / dO rows (b128), B = k / v fragments; lane gets q = 4*g4 + r, key = c16
                 f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-                const float* qp = &Qc[c16 * LD + 4 * g4];
-                const float* gp = &Gc[c16 * LD + 4 * g4];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const float4 qv = *reinterpret_cast<const float4*>(qp + c * 16);
-                    const float4 gv = *reinterpret_cast<const float4*>(gp + c * 16);
+                    const float4 qv = *reinterpret_cast<const float4*>(at(Qs, cur, c16, c * 4 + g4));
+                    const float4 gv = *reinterpret_cast<const float4*>(at(Gs, cur, c16, c * 4 + g4));
                     if (c & 1) {
                         s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, s1, 0, 0, 0);
                         p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, p1, 0, 0, 0);
@@ -803,8 +844,8 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                         p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[c].w, p0, 0, 0, 0);
                     }
                 }
-                const float4 lse4 = *reinterpret_cast<const float4*>(&lsh[4 * g4]);
-                const float4 dv4 = *reinterpret_cast<const float4*>(&dsh[4 * g4]);
+                const float4 lse4 = *reinterpret_cast<const float4*>(&lsh[cur * 16 + 4 * g4]);
+                const float4 dv4 = *reinterpret_cast<const float4*>(&dsh[cur * 16 + 4 * g4]);
                 const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dv_r[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
                 float pr[4], ds[4];
 #pragma unroll
@@ -822,12 +863,13 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 // dV^T[d][key] += sum_q dO[q][d] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float* gr = &Gc[(4 * g4 + r) * LD + c16];
-                    const float* qr = &Qc[(4 * g4 + r) * LD + c16];
+                    const int R = 4 * g4 + r;
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
-                        dvacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[c * 16], pr[r], dvacc[c], 0, 0, 0);
-                        dkacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[c * 16], ds[r], dkacc[c], 0, 0, 0);
+                        const float gcol = at(Gs, cur, R, c * 4 + (c16 >> 2))[c16 & 3];
+                        const float qcol = at(Qs, cur, R, c * 4 + (c16 >> 2))[c16 & 3];
+                        dvacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gcol, pr[r], dvacc[c], 0, 0, 0);
+                        dkacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qcol, ds[r], dkacc[c], 0, 0, 0);
                     }
                 }
                 // dS with the KEY on the contraction slots: through the wave's own 16 x 17 words of LDS
@@ -850,18 +892,9 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                         *reinterpret_cast<float4*>(sl + c * 16) = make_float4(dqacc[c][0], dqacc[c][1], dqacc[c][2], dqacc[c][3]);
                 }
             }
-            if constexpr (PF) {
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < PER; ++j) {
-                        const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
-                        *reinterpret_cast<float4*>(&Qs[((cur ^ 1) * 16 + r) * LD + c4 * 4]) = pq[j];
-                        *reinterpret_cast<float4*>(&Gs[((cur ^ 1) * 16 + r) * LD + c4 * 4]) = pg[j];
-                    }
-                }
-            }
             if constexpr (NWU > 1) {
-                __syncthreads();  // partial tiles complete (and, with the prefetch, the next tile staged)
+                if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed
+                __syncthreads();  // partial tiles complete (DMA: and the next tile visible)
                 const int nact = min(NWU, nkt - kg);
 #pragma unroll 1
                 for (int j = 0; j < PER; ++j) {
@@ -881,10 +914,12 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                         *reinterpret_cast<float4*>(p) = acc;
                     }
                 }
-                if constexpr (!PF) {
-                    if (more) stage_direct(qt0 + 16, 0);
+                if constexpr (DMA) {
+                    if (more && !(a.ntile & 2)) dvec_from_lds(cur ^ 1, lse_reg);
+                } else {
+                    if (more && !(a.ntile & 2)) stage_direct(qt0 + 16);
                 }
-                __syncthreads();  // the partial tiles are free again (and the next tile staged)
+                __syncthreads();  // the partial tiles are free again, the next tile's D / lse (registers path: the tile itself) in place
             } else {
                 const int q = qt0 + c16;
                 if (q < geo.Sq) {  // one wave, one key tile: dqacc is the whole dQ tile
@@ -900,7 +935,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                     }
                 }
                 __syncthreads();  // every lane is done with the tile
-                if (more) stage_direct(qt0 + 16, 0);
+                if (more) stage_direct(qt0 + 16);
                 __syncthreads();
             }
         }
@@ -947,12 +982,14 @@ int g_attn_bwd_rag_wave = 96;  // sola_tune "attn_bwd_rag_wave": ragged batches 
                                // the per-wave kernels in their RAG form (0 = never)
 int g_attn_bwd_blk = 1;    // sola_tune "attn_bwd_blk": 0 = per-wave staging (the round-1 kernels) for every shape (A/B)
 int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels for every shape (A/B)
+int g_attn_bwd_ablate = 0;  // measurement only (sola_tune "attn_bwd_ablate"): 1 = no tile arithmetic, 2 = only the first tile staged
 int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
 
 template <int NWU>
 static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     constexpr int LD = 128 + 4;
-    constexpr size_t lds = ((size_t)2 * 16 * LD + (NWU > 1 ? NWU * 16 * LD : 0) + NWU * 16 * 17 + 32) * sizeof(float);
+    constexpr bool DMA = NWU == 4;  // as in the kernel
+    constexpr size_t lds = ((size_t)(DMA ? 5 : 2) * 16 * LD + (NWU > 1 ? NWU * 16 * LD : 0) + NWU * 16 * 17 + (DMA ? 64 : 32)) * sizeof(float);
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
@@ -979,6 +1016,7 @@ static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, hipStream_t s) {
     // waves per (unit, head) = key tiles held in registers at a time, sized by the LONGEST unit of the launch
     int chunks = 1;
     a.qc_tiles = 0;
+    a.ntile = g_attn_bwd_ablate;
     if (a.Sq > 16 * kBwdChunkTiles && can_chunk) {
         a.qc_tiles = kBwdChunkTiles;
         chunks = ((a.Sq + 15) / 16 + kBwdChunkTiles - 1) / kBwdChunkTiles;
@@ -1090,6 +1128,7 @@ void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
 void sola_attn_set_bwd_blk(int v) { g_attn_bwd_blk = v; }
 void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
 void sola_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
+void sola_attn_set_bwd_ablate(int v) { g_attn_bwd_ablate = v; }
 
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");

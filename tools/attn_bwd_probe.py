@@ -20,8 +20,9 @@ for tag, B, N, Tp in (("NS/64", 64, 64, 4), ("N80/64", 64, 80, 4), ("C4/16", 16,
     for name, G, Sq, Sk, inner, qa in ((f"obj {N}x{N}", B * Tp, N, N, Tp, (N * Tp, 1, Tp)), (f"motion {Tp}x{Tp}", B * N, Tp, Tp, 1, (Tp, 0, 1))):
         o, lse = ops.attention(q, k, v, G, H, Sq, Sk, inner, qa, qa, return_lse=True)
         res, t = {}, {}
-        for fused in (1, 0, 1, 0):
-            _lib.check(lib.sola_tune(b"attn_bwd_fused", fused), "tune")
+        for fused in (1, 0, 1, 0, 11, 12):  # 11 / 12: the one-pass kernel without its tile arithmetic / with only the first tile staged
+            _lib.check(lib.sola_tune(b"attn_bwd_fused", 1 if fused else 0), "tune")
+            _lib.check(lib.sola_tune(b"attn_bwd_ablate", fused - 10 if fused > 1 else 0), "tune")
             res[fused] = ops.attention_backward(q, k, v, o, do, lse, G, H, Sq, Sk, inner, qa, qa)
             torch.cuda.synchronize()
             _lib.profile_enable(True); _lib.profile_read(reset=True)
@@ -34,6 +35,7 @@ for tag, B, N, Tp in (("NS/64", 64, 64, 4), ("N80/64", 64, 80, 4), ("C4/16", 16,
         diff = max(float((a - b).abs().max()) for a, b in zip(res[1], res[0]))
         ref = max(float(b.abs().max()) for b in res[0])
         nbytes = 8 * M * D * 4
-        line.append(f"{name}: fused {t[1] * 1e3:6.1f} us ({nbytes / t[1] / 1e6 / 8000 * 100:4.1f}%) two-pass {t[0] * 1e3:6.1f} us  maxdiff {diff:.1e} of {ref:.1e}")
+        line.append(f"{name}: fused {t[1] * 1e3:6.1f} us ({nbytes / t[1] / 1e6 / 8000 * 100:4.1f}%) two-pass {t[0] * 1e3:6.1f} us [no arithmetic {t[11] * 1e3:6.1f}, one staging {t[12] * 1e3:6.1f}]  maxdiff {diff:.1e} of {ref:.1e}")
     print(f"{tag:9s} " + " | ".join(line), flush=True)
 _lib.check(lib.sola_tune(b"attn_bwd_fused", 1), "tune")
+_lib.check(lib.sola_tune(b"attn_bwd_ablate", 0), "tune")
