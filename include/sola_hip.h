@@ -345,6 +345,17 @@ int sola_attention_backward(const float* dev_q, int ldq, const float* dev_k, int
                             int G, int H, int head_dim, int Sq, int Sk, int inner,
                             int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
                             int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, void* stream);
+/* ... with scratch for the one-pass kernel's long query ranges (round 3).  Units of at most 128 queries and 128 keys take the
+ * one-pass kernel either way (one block per (unit, head): S / dP / dS formed once, q, k, v, o, dO read once; sola_tune
+ * "attn_bwd_fused" 0 = the two-pass kernels).  Longer query ranges against <= 64 keys (object -> language) take it when
+ * dev_scratch holds sola_attention_backward_scratch_floats(q rows, G, H, Sk) floats and the units' rows are consecutive
+ * (inner == 1 and q_row_stride == 1): 256-query chunks, one block each, dK / dV partial sums added in chunk order. */
+size_t sola_attention_backward_scratch_floats(int64_t q_rows, int G, int H, int Sk);
+int sola_attention_backward_ws(const float* dev_q, int ldq, const float* dev_k, int ldk, const float* dev_v, int ldv,
+                               const float* dev_o, const float* dev_dout, int ldo, const float* dev_lse,
+                               float* dev_dq, float* dev_dk, float* dev_dv, float* dev_dvec, int G, int H, int head_dim, int Sq, int Sk,
+                               int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride, int64_t k_outer, int64_t k_inner,
+                               int64_t k_row_stride, float scale, int64_t q_rows, float* dev_scratch, size_t scratch_floats, void* stream);
 
 /* ---- mask IoU: replaces track_generation/seg_utils.py:128-142 (compute_mask_iou), :109-125 (compute_masklet_iou)
  * and the prompt-mask nearest resize of generate_tokens_grid.py:269-272 ------------------------------------------
@@ -430,8 +441,10 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * attention backward: "attn_bwd_small" 1 (default) = one-pass kernel for <= 4 steps, "attn_bwd_blk" 1 (default) = block-shared
  * double-buffered staging (bit-identical to 0); GroupNorm: "gn_wide" 1024-thread shape for 64-128 KiB units, "gn_slices"
  * two-launch sliced shape for larger units, "gn_bwd_reg" register-resident backward; "bwd_dual_cast" 1 (default) = the
- * transposing cast of a gradient matrix also writes its row-major cast).
- * Except under gemm_ablate, results are identical across variants up to f32 summation order. */
+ * transposing cast of a gradient matrix also writes its row-major cast; "attn_bwd_fused" 1 (default) = the one-pass attention
+ * backward for units of <= 128 queries and keys and for chunked long query ranges, 0 = the two-pass kernels everywhere;
+ * "attn_split_min_keys" (default 128) = units with more keys take the split-f16 attention on split q / k / v in precision 1).
+ * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
 int sola_profile_enable(int enable);
 /* Synchronises the recorded events and returns, per category: launches, total milliseconds, algorithmic flops,

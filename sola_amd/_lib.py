@@ -109,6 +109,9 @@ SIGNATURES = {
     "sola_group_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
     "sola_attention_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                      _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
+    "sola_attention_backward_scratch_floats": (_sz, [_i64, _i, _i, _i]),
+    "sola_attention_backward_ws": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                        _i64, _i64, _i64, _i64, _i64, _i64, _f, _i64, _vp, _sz, _vp]),
     "sola_pos_encoding": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sola_mask_words": (_i64, [_i, _i]),
     "sola_mask_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

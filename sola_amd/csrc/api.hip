@@ -930,6 +930,22 @@ extern "C" int sola_attention_backward(const float* q, int ldq, const float* k, 
     return launch_attention_bwd(d, as_stream(stream_));
 }
 
+extern "C" size_t sola_attention_backward_scratch_floats(int64_t q_rows, int G, int H, int Sk) {
+    return attention_bwd_part_floats(q_rows, G, H, Sk);
+}
+extern "C" int sola_attention_backward_ws(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                          const float* dout, int ldo, const float* lse, float* dq, float* dk, float* dv, float* dvec, int G,
+                                          int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_rs,
+                                          int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, int64_t q_rows, float* scratch,
+                                          size_t scratch_floats, void* stream_) {
+    SOLA_ARG(q && k && v && o && dout && lse && dq && dk && dv && dvec, "attention_backward_ws: null argument");
+    AttnBwdDesc d{q, k, v, o, dout, lse, dq, dk, dv, dvec, ldq, ldk, ldv, ldo, ldq, ldk, ldv, G, H, head_dim, Sq, Sk, inner,
+                  q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale};
+    d.drop = g_stage_drop;
+    d.part = scratch; d.part_floats = scratch_floats; d.part_rows = q_rows;
+    return launch_attention_bwd(d, as_stream(stream_));
+}
+
 extern "C" int sola_pos_encoding(const float* gauss, int D, int t_len, int max_len, float* pe, void* stream_) {
     SOLA_ARG(gauss && pe, "pos_encoding: null argument");
     return launch_pos_encoding(gauss, D, t_len, max_len, pe, as_stream(stream_));

@@ -162,10 +162,13 @@ def attention_backward(q, k, v, o, dout, lse, G, H, Sq, Sk, inner, q_addr, k_add
     scale = 1.0 / math.sqrt(dh) if scale is None else scale
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
     dvec = torch.zeros((q.shape[0], H), device=q.device, dtype=torch.float32)
-    check(lib().sola_attention_backward(ptr(q), q.shape[-1], ptr(k), k.shape[-1], ptr(v), v.shape[-1], ptr(o), ptr(dout), D,
-                                        ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(dvec), G, H, dh, Sq, Sk, inner,
-                                        q_addr[0], q_addr[1], q_addr[2], k_addr[0], k_addr[1], k_addr[2], scale,
-                                        current_stream(q.device)), "sola_attention_backward")
+    # scratch of the one-pass kernel's chunked launches (long query ranges against <= 64 keys; sola_hip.h)
+    n_scr = int(lib().sola_attention_backward_scratch_floats(q.shape[0], G, H, Sk))
+    scr = torch.empty(max(n_scr, 1), device=q.device, dtype=torch.float32)
+    check(lib().sola_attention_backward_ws(ptr(q), q.shape[-1], ptr(k), k.shape[-1], ptr(v), v.shape[-1], ptr(o), ptr(dout), D,
+                                           ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(dvec), G, H, dh, Sq, Sk, inner,
+                                           q_addr[0], q_addr[1], q_addr[2], k_addr[0], k_addr[1], k_addr[2], scale,
+                                           q.shape[0], ptr(scr) if n_scr else None, n_scr, current_stream(q.device)), "sola_attention_backward_ws")
     return dq, dk, dv
 
 

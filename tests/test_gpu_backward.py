@@ -157,7 +157,10 @@ def _attn_t(q, k, v, H):
 
 
 @pytest.mark.parametrize("B,N,Tp,D", [(2, 5, 3, 128), (1, 64, 4, 1024), (1, 7, 16, 128), (1, 20, 25, 128), (2, 16, 4, 256), (1, 130, 2, 128),
-                                      (2, 9, 2, 1024), (1, 12, 3, 1024)])
+                                      (2, 9, 2, 1024), (1, 12, 3, 1024),
+                                      # the one-pass kernel (head_dim 128): one / two / four waves per unit, two key groups (70, 100, 128
+                                      # keys), object -> language in 256-query chunks with a partial last chunk (360, 700 queries)
+                                      (2, 40, 9, 1024), (1, 70, 10, 1024), (1, 100, 3, 1024), (1, 128, 2, 1024), (3, 20, 25, 1024)])
 def test_attention_backward_three_layouts(B, N, Tp, D):
     H = 8
     rng = np.random.default_rng(N * Tp + D)
