@@ -183,6 +183,56 @@ def test_split_gemm_code_object_has_no_packed_f32_and_the_fused_norm_is_opt_in()
     assert not packed, f"packed-f32 instructions in gemm_glds.hip's code object: {packed}"
 
 
+def _code_object_text(obj_name):
+    """(disassembly, ELF notes) of the gfx950 code object inside build/obj/<obj_name>, or a skip."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "build", "obj", obj_name)
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip(f"{obj_name} not built here (run __graft_entry__.build()) or no llvm-objdump")
+    tmp = tempfile.mkdtemp()
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(tmp, "copy.o")], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+                        f"--output={co}", "--unbundle"], check=True)
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return dis, notes
+
+
+def test_one_pass_attention_backward_code_object():
+    """The one-pass attention backward keeps ~250 registers live at two waves per SIMD: the BUILT kernels must not
+    spill in their tile loops (scratch traffic and vmcnt(0) waits per tile), the four-wave shape must fetch its tiles by
+    direct-to-LDS DMA, and the transposed dS / K products must be there (five f32 MFMA products per tile)."""
+    import re
+    dis, notes = _code_object_text("attn_bwd.o")
+    names = re.findall(r"^[0-9a-f]+ <(\S*attn_bwd_fused_kernel\S*)>:", dis, re.M)
+    assert len(names) == 3, names
+    for nm in names:
+        body = dis[dis.index(f"<{nm}>:"):]
+        body = body[:body.index("s_endpgm")]
+        # at most the two prologue spills the four-wave shape has today (one 8-byte store per key group, one reload): a spill inside
+        # the tile loop shows up as many more scratch instructions
+        assert body.count("scratch_") <= 2, f"{nm}: {body.count('scratch_')} scratch instructions - the tile loop spills"
+        assert body.count("v_mfma_f32_16x16x4") >= 160, (nm, body.count("v_mfma_f32_16x16x4"))
+    four = [nm for nm in names if "ILi4E" in nm]
+    assert len(four) == 1
+    body4 = dis[dis.index(f"<{four[0]}>:"):]
+    assert "global_load_lds_dwordx4" in body4[:body4.index("s_endpgm")]
+
+
+def test_gemm_code_object_has_the_bf16_products():
+    """precision 3 (bf16 GEMM operands, BASELINE config C2) selects the PURE = 2 instantiations of the direct-to-LDS GEMMs."""
+    dis, _ = _code_object_text("gemm_glds.o")
+    assert "v_mfma_f32_32x32x16_bf16" in dis.replace("-", "_")
+
+
 def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
     """What bench.py's headline measures is what a user of the classes and entry points gets."""
     monkeypatch.delenv("SOLA_PRECISION", raising=False)
