@@ -31,6 +31,8 @@ struct AttnHArgs {
     const int4 *q_units, *k_units;
 };
 
+int g_attn_f16_small = 1;  // sola_tune "attn_f16_small": 0 = the MFMA shape for sequences of <= 4 steps too (A/B)
+
 struct GeoH { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
 __device__ __forceinline__ GeoH geo_h(const AttnHArgs& a, int grp) {
     GeoH g;
@@ -198,12 +200,109 @@ __global__ __launch_bounds__(256) void attn_fwd_f16_kernel(const AttnHArgs a) {
     }
 }
 
+// Sequences of at most 4 steps (motion attention over T' = 4 at the headline shape), as attn_fwd_small_kernel (attn_simple.hip): a
+// (track, head) unit is 4 rows each of q, k, v in and 4 of o out - pure streaming.  The MFMA shape above pads it to a 16 x 16
+// tile through a wave-private LDS slice (171 us per launch at 256 samples where the f32 small kernel moves TWICE the bytes in
+// 198 us).  Here a QUARTER wave owns a unit: lane c (0..15) holds the 16-byte chunk c of every row (8 halfs), the TT x TT scores are
+// per-lane partial dot products summed over the 16 lanes (DPP, no LDS), softmax and the weighted sum of the v rows in f32, one
+// 16-byte store per lane and output row.
+__device__ __forceinline__ float row_sum16(float v) {  // all-reduce over a 16-lane row (the first half of half_sum32, common.h)
+    v = SOLA_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
+    v = SOLA_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
+    v = SOLA_DPP_ADD(v, 0x141);  // row_half_mirror
+    v = SOLA_DPP_ADD(v, 0x140);  // row_mirror
+    return v;
+}
+template <int TT>
+__global__ __launch_bounds__(256) void attn_fwd_small_f16_kernel(const AttnHArgs a) {
+    constexpr int DH = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, qw = lane >> 4;
+    const long long unit = ((long long)blockIdx.x * 4 + wave) * 4 + qw;
+    const long long n_units = (long long)a.G * a.H;
+    const bool live = unit < n_units;
+    const long long uu = live ? unit : 0;
+    const int grp = (int)(uu / a.H), h = (int)(uu - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = qu.x; q_rs = qu.y; Sq = qu.z; k0 = ku.x; k_rs = ku.y; Sk = ku.z;
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    if (!live) { Sq = 0; Sk = 0; }
+    float qv[TT][8], kv[TT][8], vv[TT][8];
+    // rows past the unit's length: a CLAMPED row is loaded and the VALUE zeroed (attn_simple.hip: a select of pointers goes through
+    // a scratch copy of the zero constant and a flat load)
+    auto ld = [&](const _Float16* base, long long row0, long long rs, int ld_, int t, int n, float (&out)[8]) {
+        const half8v v = *reinterpret_cast<const half8v*>(base + (row0 + (long long)(t < n ? t : 0) * rs) * ld_ + h * DH + 8 * c);
+        const bool ok = t < n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = ok ? (float)v[j] : 0.f;
+    };
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        ld(a.q, q0, q_rs, a.ldq, t, Sq, qv[t]);
+        ld(a.k, k0, k_rs, a.ldk, t, Sk, kv[t]);
+        ld(a.v, k0, k_rs, a.ldv, t, Sk, vv[t]);
+    }
+    float sc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p += qv[i][e] * kv[j][e];
+            sc[i][j] = row_sum16(p) * a.scale;
+        }
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        if (i >= Sq) break;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) mx = j < Sk ? fmaxf(mx, sc[i][j]) : mx;
+        float den = 0.f, pj[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            pj[j] = j < Sk ? __expf(sc[i][j] - mx) : 0.f;
+            den += pj[j];
+        }
+        const float inv = 1.f / den;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const float w = pj[j] * inv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += w * vv[j][e];
+        }
+        half8v o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o8[e] = (_Float16)o[e];
+            m = fmaxf(m, fabsf(o[e]));
+        }
+        *reinterpret_cast<half8v*>(a.o + (q0 + (long long)i * q_rs) * a.ldo + h * DH + 8 * c) = o8;
+    }
+    if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+}
+
 template <int DH>
 int launch_h(const AttnHArgs& a0, hipStream_t s) {
     AttnHArgs a = a0;
     constexpr int LD = DH + 8;
     const long long units = (long long)a.G * a.H;
-    if (a.Sq <= 16 && a.Sk <= 16) {
+    if (DH == 128 && a.Sq <= 4 && a.Sk <= 4 && g_attn_f16_small && a.ldo % 8 == 0) {
+        const unsigned blocks = (unsigned)((units + 15) / 16);
+        const int need = a.Sq > a.Sk ? a.Sq : a.Sk;
+        if (need <= 1) hipLaunchKernelGGL((attn_fwd_small_f16_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+        else if (need <= 2) hipLaunchKernelGGL((attn_fwd_small_f16_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_small_f16_kernel<4>), dim3(blocks), dim3(256), 0, s, a);
+    } else if (a.Sq <= 16 && a.Sk <= 16) {
         a.nqb = 1;
         const size_t lds = (size_t)4 * 2 * 16 * LD * sizeof(_Float16);
         hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
@@ -218,6 +317,8 @@ int launch_h(const AttnHArgs& a0, hipStream_t s) {
 }
 
 }  // namespace
+
+void sola_attn_set_f16_small(int v) { g_attn_f16_small = v; }
 
 // AttnDesc with q / k / v / o pointing at _Float16 matrices and ld* counting halfs
 int launch_attention_f16(const AttnDesc& d, hipStream_t s) {
