@@ -298,6 +298,91 @@ __global__ __launch_bounds__(NTHR) void group_norm_reg_kernel(const GnArgs a, lo
     }
 }
 
+// 16-bit storage mode (x, y, y2 plain f16): the register shape above with EIGHT channels per lane - one 16-byte load and one
+// 16-byte store per lane and token slot instead of 8-byte ones.  With four channels per lane a unit keeps half as many bytes in
+// flight as in the f32 modes and the f16 norms ran at 77 % of the f32 norms' TIME for half their bytes.
+// R = token slots of 8 channels per lane; same statistics (two passes over the registers), affine, LeakyReLU, y + pe side output
+// and range guard as gn_apply_store's f16 branch.  Inference only (no dropout).
+template <int R, bool WAVE, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void group_norm_reg_h8_kernel(const GnArgs a, long long n_units) {
+    __shared__ float red[NTHR / 64];
+    const int f8 = a.cg >> 3;
+    const int nthr = WAVE ? 64 : NTHR;
+    const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+    const long long unit = WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
+    if (WAVE && unit >= n_units) return;
+    const int inst = (int)(unit / a.groups), g = (int)(unit - (long long)inst * a.groups);
+    const int tpp = nthr / f8;
+    const int tl = tid / f8, c8 = tid - tl * f8;
+    const GnUnit un = gn_unit(a, inst);
+    const long long row0 = un.row0, tok_stride = un.tok_stride;
+    const int ntok = un.ntok;
+    const int ch = g * a.cg + c8 * 8;
+    const float cnt = (float)ntok * (float)a.cg;
+    const float sc_in = a.in_scale_dev ? *a.in_scale_dev : 1.f;
+    const _Float16* x16 = reinterpret_cast<const _Float16*>(a.x);
+    float v[R][8];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        const bool ok = t < ntok;  // a clamped row is loaded and the VALUE zeroed (no select of pointers)
+        const half8 h = *reinterpret_cast<const half8*>(x16 + (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[r][e] = ok ? (float)h[e] * sc_in : 0.f;
+        s += ((v[r][0] + v[r][1]) + (v[r][2] + v[r][3])) + ((v[r][4] + v[r][5]) + (v[r][6] + v[r][7]));
+    }
+    const float mean = (WAVE ? wave_sum(s) : block_sum_n<NTHR>(s, red)) / cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tl + r * tpp < ntok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[r][e] - mean;
+                q += d * d;
+            }
+        }
+    const float var = (WAVE ? wave_sum(q) : block_sum_n<NTHR>(q, red)) / cnt;  // biased, as nn.GroupNorm
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    float ga[8], be[8], pe[8];
+    {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + ch), g1 = *reinterpret_cast<const float4*>(a.gamma + ch + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.beta + ch), b1 = *reinterpret_cast<const float4*>(a.beta + ch + 4);
+        ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+        be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pe[e] = 0.f;
+        if (a.y2) {
+            const float4 p0 = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch);
+            const float4 p1 = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch + 4);
+            pe[0] = p0.x; pe[1] = p0.y; pe[2] = p0.z; pe[3] = p0.w; pe[4] = p1.x; pe[5] = p1.y; pe[6] = p1.z; pe[7] = p1.w;
+        }
+    }
+    float m = 0.f;
+    _Float16* y16 = reinterpret_cast<_Float16*>(a.y);
+    _Float16* y216 = reinterpret_cast<_Float16*>(a.y2);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tl + r * tpp;
+        if (t < ntok) {
+            const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
+            half8 h, h2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = (v[r][e] - mean) * rstd * ga[e] + be[e];
+                if (a.leaky) o = o >= 0.f ? o : o * a.slope;
+                h[e] = (_Float16)o;
+                h2[e] = (_Float16)(o + pe[e]);
+                m = fmaxf(m, fabsf(o));
+            }
+            *reinterpret_cast<half8*>(y16 + off) = h;
+            if (a.y2) *reinterpret_cast<half8*>(y216 + off) = h2;
+        }
+    }
+    if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+}
+
 // Large units (the object->language norm of a long video: N*T' = 2048 tokens x 128 channels = 1 MiB per unit; ragged batches
 // whose largest sample has more than 256 tokens): one block per unit walks the unit three times out of L2 and a launch has only
 // instances x groups blocks (256 at T = 128, N = 128, 32 samples: one block per CU, ~0.5 ms per launch where the traffic takes
@@ -526,6 +611,8 @@ static float2* gn_slice_scratch(size_t bytes, hipStream_t s) {
     sl.cap = want;
     return sl.buf;
 }
+int g_gn_h8 = 1;  // sola_tune "gn_h8": 0 = four channels per lane in the 16-bit storage mode too (A/B)
+void sola_gn_set_h8(int v) { g_gn_h8 = v; }
 void sola_gn_set_variant(int v) { g_gn_variant = v; }
 
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
@@ -547,7 +634,23 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     const long long n_units = (long long)d.n_inst * d.groups;
     const int rw = 64 % f4 == 0 ? (d.ntok + 64 / f4 - 1) / (64 / f4) : 1 << 30;     // float4 per lane, one wave per unit
     const int rb = 256 % f4 == 0 ? (d.ntok + 256 / f4 - 1) / (256 / f4) : 1 << 30;  // ... one block per unit
-    if (g_gn_variant != 0 && rw <= 4 && n_units < (1ll << 31)) {
+    // 16-bit storage mode: eight channels (16 bytes) per lane where the unit fits the register shapes
+    const int f8 = cg / 8;
+    const bool h8 = g_gn_variant != 0 && g_gn_h8 && d.in_f16 && d.out_f16 && !d.drop.enabled && cg % 8 == 0 && n_units < (1ll << 31);
+    const int rw8 = (h8 && 64 % f8 == 0) ? (d.ntok + 64 / f8 - 1) / (64 / f8) : 1 << 30;
+    const int rb8 = (h8 && 256 % f8 == 0) ? (d.ntok + 256 / f8 - 1) / (256 / f8) : 1 << 30;
+    const int rk8 = (h8 && 1024 % f8 == 0) ? (d.ntok + 1024 / f8 - 1) / (1024 / f8) : 1 << 30;
+    if (rw8 <= 2) {
+        const dim3 grid((unsigned)((n_units + 3) / 4));
+        if (rw8 == 1) hipLaunchKernelGGL((group_norm_reg_h8_kernel<1, true>), grid, dim3(256), 0, s, a, n_units);
+        else hipLaunchKernelGGL((group_norm_reg_h8_kernel<2, true>), grid, dim3(256), 0, s, a, n_units);
+    } else if (rb8 <= 4) {
+        const dim3 grid((unsigned)n_units);
+        if (rb8 <= 2) hipLaunchKernelGGL((group_norm_reg_h8_kernel<2, false>), grid, dim3(256), 0, s, a, n_units);
+        else hipLaunchKernelGGL((group_norm_reg_h8_kernel<4, false>), grid, dim3(256), 0, s, a, n_units);
+    } else if (rk8 <= 4) {
+        hipLaunchKernelGGL((group_norm_reg_h8_kernel<4, false, 1024>), dim3((unsigned)n_units), dim3(1024), 0, s, a, n_units);
+    } else if (g_gn_variant != 0 && rw <= 4 && n_units < (1ll << 31)) {
         const dim3 grid((unsigned)((n_units + 3) / 4));
         if (rw == 1) hipLaunchKernelGGL((group_norm_reg_kernel<1, true>), grid, dim3(256), 0, s, a, n_units);
         else if (rw == 2) hipLaunchKernelGGL((group_norm_reg_kernel<2, true>), grid, dim3(256), 0, s, a, n_units);
