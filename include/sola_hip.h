@@ -85,7 +85,10 @@ int sola_set_ws_policy(SolaCtx* ctx, int recompute_every_forward);
  *      sola_forward and sola_forward_ragged (round 3) both run it; a tripped range guard repeats the call in exact f32.
  * In training (sola_forward_train / sola_backward) precision 1 runs every GEMM of the step (forward, dX and dW of the
  * projections and convs) on split-f16 casts of the f32 activations / gradients, from 1024 token rows on; attention and
- * GroupNorm backward and everything saved for the backward stay f32.  Precision 2 in training is MIXED precision (BASELINE
+ * GroupNorm backward and everything saved for the backward stay f32.  Since round 3 the weight-gradient products dW = dY^T X
+ * take PLAIN f16 casts (one MFMA per product; sola_tune "train_dw_f16" 0 = split pairs there too): a sum over >= 1024 token
+ * rows averages the operand rounding out - median per-matrix error 1e-4 against the exact-f32 step, worst tensor and gradient
+ * cosine unchanged (tests/test_gpu_backward.py::test_split_training_weight_gradient_products_on_f16_operands).  Precision 2 in training is MIXED precision (BASELINE
  * config C2): the same step with plain-f16 casts and ONE f16 MFMA per product (f32 accumulation, per-tensor power-of-two
  * scales); activations, statistics, softmax, saved tensors and master weights stay f32.  Reduced precision with a stated
  * tolerance: losses within 1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py).
@@ -443,7 +446,9 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * two-launch sliced shape for larger units, "gn_bwd_reg" register-resident backward; "bwd_dual_cast" 1 (default) = the
  * transposing cast of a gradient matrix also writes its row-major cast; "attn_bwd_fused" 1 (default) = the one-pass attention
  * backward for units of <= 128 queries and keys and for chunked long query ranges, 0 = the two-pass kernels everywhere;
- * "attn_split_min_keys" (default 128) = units with more keys take the split-f16 attention on split q / k / v in precision 1).
+ * "attn_split_min_keys" (default 128) = units with more keys take the split-f16 attention on split q / k / v in precision 1;
+ * "train_dw_f16" 1 (default) = weight-gradient products of the precision-1 training step on plain f16 operands; "gn_h8" /
+ * "attn_f16_small" 1 (default) = the 16-byte-per-lane GroupNorm and the streaming short-sequence attention of precision 2).
  * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
 int sola_profile_enable(int enable);

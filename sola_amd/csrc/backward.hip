@@ -13,6 +13,15 @@ extern int g_train_split_min_rows;
 int g_bwd_dual_cast = 1;  // sola_tune "bwd_dual_cast": the transposing cast of a gradient matrix also writes its row-major cast (A/B)
 void sola_set_bwd_dual_cast(int v) { g_bwd_dual_cast = v; }
 
+// sola_tune "train_dw_f16" (default 1, round 3): in the split-f16 training step (precision 1) the weight-gradient products
+// dW = dY^T X run on PLAIN f16 casts of dY and X (one MFMA per product, f32 accumulation) instead of split pairs (three); forward and
+// dX keep the split pairs.  A weight gradient is a sum over all token rows (>= 1024 here) in which the 2^-11 operand roundings
+// average out: measured against the exact-f32 step (tools/train_dw_f16_errors.py) the median per-matrix error goes 5e-6 -> 1.2e-4
+// (64 samples; 1.1e-5 -> 2.3e-4 at 8), the worst tensor (1.9e-3 / 4.9e-3: the forward's softmax near-ties) and the cosine of the
+// whole gradient (0.999999) do not move; the step is 14 % faster on the ragged mix.  0 = split pairs everywhere.
+int g_train_dw_f16 = 1;
+void sola_train_set_dw_f16(int v) { g_train_dw_f16 = v; }
+
 namespace {
 
 struct Arena {
@@ -196,6 +205,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     const bool pure = c->precision >= 2;
     const int bf = c->precision == 3 ? 1 : 0;  // bfloat16 GEMM operands
     const int lowp_arith = pure ? 2 : 1;
+    // sola_tune "train_dw_f16": in the split-f16 step the weight-gradient products dW = dY^T X take PLAIN f16 operands (one MFMA per
+    // product; a sum over all token rows, where the operand rounding averages out) while forward and dX keep the split pairs
+    const bool dw16 = !pure && g_train_dw_f16 != 0;
     auto cast_scaled = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
         return pure ? launch_cast_f16_scaled(in, ld, out, K, rows, K, scal, s, bf) : launch_cast_sp16_scaled(in, ld, out, K, rows, K, scal, s);
     };
@@ -243,7 +255,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         if (dy_rm_done) *dy_rm_done = false;
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
-            d.scal = sc; d.pure = pure ? 1 + bf : 0;
+            d.scal = sc; d.pure = pure ? 1 + bf : (dw16 ? 1 : 0); d.rm_split = dw16 ? 1 : 0;
             if (dy_rm_done && sc && g_bwd_dual_cast) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy; }
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
@@ -490,7 +502,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes(rows, g.cout, g.k * g.cin, 1)) {
             SOLA_TRY(stats(dy, g.cout, rows, g.cout, 8, &scc));
             GemmTnSplitDesc d{};
-            d.scal = scc; d.pure = pure ? 1 + bf : 0;
+            d.scal = scc; d.pure = pure ? 1 + bf : (dw16 ? 1 : 0); d.rm_split = dw16 ? 1 : 0;
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;

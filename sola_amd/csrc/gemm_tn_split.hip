@@ -32,7 +32,9 @@ __device__ __forceinline__ _Float16 cvt16(float v, int bf) {
     if (bf) return __builtin_bit_cast(_Float16, (__bf16)v);
     return (_Float16)v;
 }
-template <bool PURE>
+// RMP: the format of the optional row-major copy (PURE = as the transposed output; false with PURE = true: the weight-gradient
+// product takes plain f16 operands while the dX GEMM of the same gradient matrix keeps split-f16 ones - sola_tune "train_dw_f16")
+template <bool PURE, bool RMP = PURE>
 __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                                           int ld_in, long long ld_out, float* __restrict__ scal, int conv_T_in,
                                                           int conv_T_out, int conv_stride, int conv_toff, float* __restrict__ out_rm,
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) tile[r][c4 + e] = v[e] * scale;
             if (out_rm && r0 + r < rows) {  // the row-major cast of the same values (vec path guaranteed by the launcher)
                 const long long col = c0 + c4;
-                if (PURE) {
+                if (RMP) {
                     typedef _Float16 half4t __attribute__((ext_vector_type(4)));
                     half4t h;
 #pragma unroll
@@ -172,11 +174,13 @@ __global__ __launch_bounds__(256) void col2im_ragged_kernel(const float* __restr
 
 int cast_t(int pure, const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s, int conv_T_in = 0,
            int conv_T_out = 0, int conv_stride = 1, int conv_toff = 0, float* out_rm = nullptr, long long ld_rm = 0,
-           const int2* rowmap = nullptr, int tap = 0) {
+           const int2* rowmap = nullptr, int tap = 0, int rm_split = 0) {
     const int bf = pure == 2 ? 1 : 0;
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, ((pure ? 6.0 : 8.0) + (out_rm ? (pure ? 2.0 : 4.0) : 0.0)) * rows * cols);
+    const bool rmp = pure && !rm_split;
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, ((pure ? 6.0 : 8.0) + (out_rm ? (rmp ? 2.0 : 4.0) : 0.0)) * rows * cols);
     const dim3 grid((unsigned)(ld_out / 128), (unsigned)((cols + 63) / 64));
-    if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap, bf);
+    if (pure && rm_split) hipLaunchKernelGGL((cast_sp16_t_kernel<true, false>), grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap, bf);
+    else if (pure) hipLaunchKernelGGL(cast_sp16_t_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap, bf);
     else hipLaunchKernelGGL(cast_sp16_t_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, scal, conv_T_in, conv_T_out, conv_stride, conv_toff, out_rm, ld_rm, rowmap, tap, bf);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -263,8 +267,8 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     for (int j = 0; j < d.nprob; ++j) {
         if (rm) {  // + the row-major cast of the same gradient matrix (the dX GEMM's operand): one read of dY for both
             const long long off = d.A[j] - d.A[0];
-            float* dst = pure ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(d.a_rm) + off) : d.a_rm + off;
-            SOLA_TRY(cast_t(pure_fmt, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s, 0, 0, 1, 0, dst, d.a_rm_ld));
+            float* dst = (pure && !d.rm_split) ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(d.a_rm) + off) : d.a_rm + off;
+            SOLA_TRY(cast_t(pure_fmt, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s, 0, 0, 1, 0, dst, d.a_rm_ld, nullptr, 0, d.rm_split));
         } else {
             SOLA_TRY(cast_t(pure_fmt, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s));
         }

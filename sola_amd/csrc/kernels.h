@@ -86,6 +86,7 @@ struct GemmTnSplitDesc {
     // Needs N % 64 == 0 and column offsets % 8 == 0 (else ignored: check gemm_tn_split_writes_rm()).
     float* a_rm;
     int a_rm_ld;
+    int rm_split;  // pure != 0 only: the row-major copy stays split-f16 (the dX GEMM of a split-f16 step whose dW products run on plain f16)
     float* scratch;
     size_t scratch_bytes;
     const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap

@@ -90,7 +90,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self.attention_dropout_p = 0.1  # tools/attention.py:12 (hard-coded in the reference)
         # inference arithmetic of the convs / projections: "f32" (exact f32 MFMA) or "f16x3" (split-f16 operands, three
         # f16 MFMAs per product with f32 accumulation, ~22-bit products); in training "f16x3" covers every GEMM of the
-        # step, forward and backward (attention and GroupNorm backward stay f32); "f16" = 16-bit activation STORAGE for the
+        # step, forward and backward (attention and GroupNorm backward stay f32; the weight-gradient sums take plain f16
+        # operands - sola_tune "train_dw_f16"); "f16" = 16-bit activation STORAGE for the
         # inference forward, uniform and ragged (plain f16 between kernels, one f16 MFMA per product, f32 accumulate / softmax /
         # statistics; a reduced-precision mode with a stated tolerance); in TRAINING it is mixed
         # precision: every GEMM of the step on plain-f16 casts, one MFMA per product, everything else f32); "bf16" = the same

@@ -340,6 +340,36 @@ def test_split_training_gradients_match_exact_f32(full_model):
     assert not bad, bad
 
 
+def test_split_training_weight_gradient_products_on_f16_operands(full_model):
+    """precision "f16x3" in training, sola_tune "train_dw_f16" (default 1): dW = dY^T X on plain f16 casts (one MFMA per product) while
+    forward and dX keep the split pairs.  Against the exact-f32 step the weight matrices' median relative error rises from ~1e-5 to
+    ~2e-4 (operand rounding averaged over >= 1024 rows), the worst tensor and the whole-gradient cosine do not move; with the switch
+    off the median is back at the split level."""
+    from sola_amd import _lib
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    out = {}
+    try:
+        m.precision = "f32"
+        _, _, g = train_step_grads(m, cfg, 8, 40, 32, 10, 77)
+        ref = {k: v.double().clone() for k, v in g.items()}
+        total = math.sqrt(sum(float(v.pow(2).sum()) for v in ref.values()))
+        for dw in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"train_dw_f16", dw), "tune")
+            m.precision = "f16x3"
+            _, _, g = train_step_grads(m, cfg, 8, 40, 32, 10, 77)
+            got = {k: v.double().clone() for k, v in g.items()}
+            rel = sorted(float((got[k] - ref[k]).norm()) / (float(ref[k].norm()) + 1e-6 * total) for k in ref if k.endswith("weight") and ref[k].dim() >= 2)
+            n = math.sqrt(sum(float(v.pow(2).sum()) for v in got.values()))
+            out[dw] = (rel[len(rel) // 2], rel[-1], sum(float((got[k] * ref[k]).sum()) for k in ref) / (total * n))
+    finally:
+        m.precision = "f32"
+        _lib.check(_lib.lib().sola_tune(b"train_dw_f16", 1), "tune")
+    print("weight matrices, (median, worst) relative error and gradient cosine: f16 dW", out[1], "split dW", out[0])
+    assert out[1][0] <= 1e-3 and out[1][1] <= 1e-2 and out[1][2] >= 0.9999, out
+    assert out[0][0] <= 5e-5 and out[0][1] <= 1e-2 and out[0][2] >= 0.9999, out
+
+
 # stated tolerances of the two 16-bit-operand training modes against the exact-f32 step: (loss rtol, min gradient cosine, worst
 # tensor, median tensor, total-gradient-norm rtol against the REFERENCE's).  bf16 carries 8 significant bits where f16 carries 11:
 # its operand rounding noise is 8x larger, so the same saturated-softmax near-ties (docstring below) move further - measured at
