@@ -1070,8 +1070,14 @@ extern "C" int sola_mask_iou_matrix(const void* a, const void* b, int elem_type,
     long long* aarea = reinterpret_cast<long long*>(base + align256((size_t)P * words * 4) + align256((size_t)R * words * 4));
     long long* barea = reinterpret_cast<long long*>(reinterpret_cast<char*>(aarea) + align256((size_t)P * 8));
     hipStream_t s = as_stream(stream_);
-    SOLA_TRY(launch_mask_pack(a, elem_type, P, H, W, H, W, abits, aarea, s));
-    SOLA_TRY(launch_mask_pack(b, elem_type, R, h, w, H, W, bbits, barea, s));
+    int st = SOLA_OK;
+    if (elem_type == 0 && h == H && w == W &&
+        launch_mask_pack_pair(a, P, abits, aarea, b, R, bbits, barea, align256((size_t)P * 8) + (size_t)R * 8, H, W, s, &st)) {
+        SOLA_TRY(st);  // one memset + one pack launch for both sets
+    } else {
+        SOLA_TRY(launch_mask_pack(a, elem_type, P, H, W, H, W, abits, aarea, s));
+        SOLA_TRY(launch_mask_pack(b, elem_type, R, h, w, H, W, bbits, barea, s));
+    }
     return launch_mask_pair(abits, aarea, P, 1, bbits, barea, R, nullptr, (long long)words,
                             reinterpret_cast<long long*>(inter), reinterpret_cast<long long*>(uni), s);
 }

@@ -22,6 +22,12 @@ struct PackArgs {
     long long hw_src, HW, words;
     float sy, sx;
     int identity;
+    // mask_pack_u8_stream_kernel only: masks n >= n_split come from the SECOND set (src2 -> bits2 / area2, index n - n_split):
+    // both mask sets of a P x R matrix in one launch (launch_mask_pack_pair)
+    int n_split;
+    const void* src2;
+    uint32_t* bits2;
+    unsigned long long* area2;
 };
 
 template <typename T>
@@ -208,8 +214,11 @@ __device__ __forceinline__ unsigned pack16(const uint4 v) {
 __global__ __launch_bounds__(256) void mask_pack_u8_stream_kernel(const PackArgs a) {
     __shared__ int red[4];
     constexpr int IT = 4;
-    const int n = blockIdx.y;
-    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.src) + (long long)n * a.hw_src);
+    const bool second = (int)blockIdx.y >= a.n_split;
+    const int n = second ? (int)blockIdx.y - a.n_split : (int)blockIdx.y;
+    uint32_t* const bits = second ? a.bits2 : a.bits;
+    unsigned long long* const area = second ? a.area2 : a.area;
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(second ? a.src2 : a.src) + (long long)n * a.hw_src);
     const long long w0 = (long long)blockIdx.x * (256 * IT) + threadIdx.x;
     uint4 lo[IT], hi[IT];
 #pragma unroll
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void mask_pack_u8_stream_kernel(const PackArgs
     for (int it = 0; it < IT; ++it) {
         const long long w = w0 + it * 256;
         const unsigned word = pack16(lo[it]) | (pack16(hi[it]) << 16);
-        if (w < a.words) a.bits[(long long)n * a.words + w] = word;
+        if (w < a.words) bits[(long long)n * a.words + w] = word;
         cnt += __popc(word);
     }
 #pragma unroll
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void mask_pack_u8_stream_kernel(const PackArgs
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = red[0] + red[1] + red[2] + red[3];
-        if (tot) atomicAdd(&a.area[n], (unsigned long long)tot);
+        if (tot) atomicAdd(&area[n], (unsigned long long)tot);
     }
 }
 
@@ -425,9 +434,11 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
     const long long hw = (long long)H * W;
     // masks of up to 2^32 - 1 pixels keep every count inside 32 bits; a 256-word slice keeps the packed wave sums inside 16
     // Measured (tools/iou_probe.py, P=4, 540x960): R=16 18.6 us per call fused vs 25.3 us pack + pair; R=64 30.6 vs 25.8; R=256
-    // 125 vs 40 (the per-block wave reductions grow with R while the pack + pair path amortises its launches): fused up to
-    // 32 prompts (g_iou_fused == 2 forces it for any R: tests).
-    if (!g_iou_fused || (R > 32 && g_iou_fused != 2) || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 ||
+    // 125 vs 40 (the per-block wave reductions grow with R while the pack + pair path amortises its launches).  Round 3: the pack +
+    // pair path packs BOTH mask sets in one launch behind one memset (launch_mask_pack_pair) - three stream operations instead of
+    // five - and takes 19.4 / 18.8 / 19.9 / 35.1 us at R = 16 / 32 / 64 / 256 against 21.7 / 21.8 / 30.0 / 127 fused
+    // (tools/iou_ab.py): fused up to 16 prompts only (g_iou_fused == 2 forces it for any R: tests).
+    if (!g_iou_fused || (R > 16 && g_iou_fused != 2) || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 ||
         hw > 0xffffffffll || R > 16 * 65535 ||
         (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) ||
         scratch_bytes < mask_iou_fused_scratch_bytes(P, R, hw / 32))
@@ -484,6 +495,7 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
     a.hw_src = (long long)h * w; a.HW = (long long)H * W; a.words = (a.HW + 31) / 32;
     a.sy = (float)h / (float)H; a.sx = (float)w / (float)W;
     a.identity = (h == H && w == W) ? 1 : 0;
+    a.n_split = n; a.src2 = nullptr; a.bits2 = nullptr; a.area2 = nullptr;
     SOLA_HIP(hipMemsetAsync(area, 0, sizeof(long long) * n, s));
     const long long runs = (a.HW + 15) / 16;
     const unsigned blocks = (unsigned)((runs + 255) / 256);
@@ -501,6 +513,36 @@ int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int 
         hipLaunchKernelGGL(mask_pack_kernel<float>, dim3(blocks, n), dim3(256), 0, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
+}
+
+// Both uint8 mask sets of a P x R matrix at the comparison resolution: ONE memset over the two area arrays (`area_span_bytes` from
+// a_area, which must precede b_area in the same buffer) and ONE streaming pack launch instead of two of each - the P = 4, R = 64
+// call of the de-dup loop is five dependent stream operations otherwise, and it is their latencies that it takes (bench: iou).
+// Returns false when the shapes do not take the streaming kernel (the caller packs the sets separately).
+bool launch_mask_pack_pair(const void* a_masks, int P, uint32_t* a_bits, long long* a_area, const void* b_masks, int R, uint32_t* b_bits,
+                           long long* b_area, size_t area_span_bytes, int H, int W, hipStream_t s, int* status) {
+    const long long HW = (long long)H * W;
+    if (HW % 32 != 0 || ((reinterpret_cast<uintptr_t>(a_masks) | reinterpret_cast<uintptr_t>(b_masks)) & 15) != 0 || (HW & 15) != 0 ||
+        P + R > 65535 || reinterpret_cast<char*>(b_area) < reinterpret_cast<char*>(a_area))
+        return false;
+    PackArgs a;
+    a.src = a_masks; a.bits = a_bits; a.area = reinterpret_cast<unsigned long long*>(a_area);
+    a.src2 = b_masks; a.bits2 = b_bits; a.area2 = reinterpret_cast<unsigned long long*>(b_area); a.n_split = P;
+    a.h = H; a.w = W; a.H = H; a.W = W; a.hw_src = HW; a.HW = HW; a.words = (HW + 31) / 32;
+    a.sy = 1.f; a.sx = 1.f; a.identity = 1;
+    *status = SOLA_OK;
+    if (hipMemsetAsync(a_area, 0, area_span_bytes, s) != hipSuccess) {
+        sola_set_error("mask_iou_matrix: hipMemsetAsync failed");
+        *status = SOLA_ERR_HIP;
+        return true;
+    }
+    SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)(P + R) * HW + (double)(P + R) * a.words * 4);
+    hipLaunchKernelGGL(mask_pack_u8_stream_kernel, dim3((unsigned)((a.words + 1023) / 1024), P + R), dim3(256), 0, s, a);
+    if (hipGetLastError() != hipSuccess) {
+        sola_set_error("mask_iou_matrix: pack launch failed");
+        *status = SOLA_ERR_HIP;
+    }
+    return true;
 }
 
 int launch_mask_pair(const uint32_t* a_bits, const long long* a_area, int P, int T, const uint32_t* b_bits,

@@ -324,6 +324,8 @@ int launch_loss(const LossDesc& d, hipStream_t s);
 int launch_select(const float* score, long long n, float thr, float* prob, float* pred, hipStream_t s);
 
 // ---- mask IoU (iou.hip) ----------------------------------------------------------------------------------------
+bool launch_mask_pack_pair(const void* a_masks, int P, uint32_t* a_bits, long long* a_area, const void* b_masks, int R, uint32_t* b_bits,
+                           long long* b_area, size_t area_span_bytes, int H, int W, hipStream_t s, int* status);
 int launch_mask_pack(const void* masks, int elem_type, int n, int h, int w, int H, int W, uint32_t* bits,
                      long long* area, hipStream_t s);
 int launch_mask_pair(const uint32_t* a_bits, const long long* a_area, int P, int T, const uint32_t* b_bits,
