@@ -27,7 +27,7 @@ class _TrackSelection(torch.autograd.Function):
 
 
 def track_selection_forward(module, object_tokens, lang_tokens):
-    params = [p for p in module.parameters()]
+    params = module._param_list()
     return _TrackSelection.apply(module, object_tokens, lang_tokens, *params)
 
 
@@ -53,7 +53,7 @@ class _TrackSelectionRagged(torch.autograd.Function):
 
 
 def track_selection_forward_ragged(module, object_tokens, lang_tokens):
-    params = [p for p in module.parameters()]
+    params = module._param_list()
     return _TrackSelectionRagged.apply(module, len(lang_tokens), *object_tokens, *lang_tokens, *params)
 
 

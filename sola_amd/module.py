@@ -147,6 +147,29 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         except Exception:
             pass
 
+    # The module's structure is fixed at construction (it mirrors module/module.py:55-110): the parameter list, its names and the
+    # state_dict entries are walked ONCE - nn.Module.parameters() re-walks the module tree on every call, ~0.1 ms each, six to
+    # eight times per training step (a batch-1 step is 2.8 ms).  The tensors themselves are looked up by owner and name on every
+    # use (.to() replaces buffers, a caller may replace a Parameter object).
+    def _params(self):
+        return [(key, owner._parameters[leaf]) for key, owner, leaf, is_buf in self._state_entries() if not is_buf]
+
+    def _param_list(self):
+        return [p for _, p in self._params()]
+
+    def _state_entries(self):
+        se = self.__dict__.get("_state_cache")
+        if se is None:
+            se = []
+            for key in self.state_dict(keep_vars=True).keys():
+                owner = self
+                *path, leaf = key.split(".")
+                for part in path:
+                    owner = getattr(owner, part)
+                se.append((key, owner, leaf, leaf in owner._buffers))
+            self.__dict__["_state_cache"] = se
+        return se
+
     def weights_changed(self):
         """Tell the library that parameter VALUES changed in place without torch noticing (e.g. an update through ``p.data``
         or a fused optimizer kernel - neither bumps ``Tensor._version``): cached derived copies (standardised conv weights,
@@ -161,7 +184,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # So every call after a training forward (and after weights_changed()) rebuilds the derived copies.
         changed = bool(getattr(self, "_weights_touched", False))
         self._weights_touched = False
-        for key, t in self.state_dict(keep_vars=True).items():
+        for key, owner, leaf, is_buf in self._state_entries():
+            t = owner._buffers[leaf] if is_buf else owner._parameters[leaf]
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise SolaError(f"{key}: expected a contiguous float32 tensor")
             rec = (t.data_ptr(), t._version)
@@ -217,7 +241,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
     def forward(self, object_tokens, lang_tokens):
         require_cuda(object_tokens, lang_tokens)
         self._check_inputs(object_tokens, lang_tokens)
-        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self._param_list())):
             from .autograd import track_selection_forward  # backward kernels
             return track_selection_forward(self, object_tokens, lang_tokens)
         return self._forward_impl(object_tokens, lang_tokens)
@@ -408,7 +432,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         order sola_backward finishes them (sola_grad_bucket_of), so the multi-GPU path all-reduces each bucket in place
         while the rest of the backward still runs (sola_amd/dist.py: allreduce_gradient_arena).  64-float alignment keeps
         every view 256-byte aligned."""
-        named = list(self.named_parameters())
+        named = self._params()
         dev = named[0][1].device
         if getattr(self, "_grad_arena", None) is not None and self._grad_arena.device == dev and self._grad_ctx is self._ctx:
             return
@@ -468,7 +492,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             sm_shape, st_shape = (B, N), (B, N, D)
         d_sm = torch.zeros(sm_shape, device=dev) if d_score_map is None else d_score_map.to(torch.float32).contiguous()
         d_st = torch.zeros(st_shape, device=dev) if d_score_tokens is None else d_score_tokens.to(torch.float32).contiguous()
-        named = dict(self.named_parameters())
+        named = dict(self._params())
         self._grad_layout()
         lo, hi = self._grad_arena.data_ptr(), self._grad_arena.data_ptr() + 4 * self._grad_arena.numel()
         # sola_backward OVERWRITES its gradient buffers.  If a parameter still holds a gradient that lives in the arena (the
@@ -509,9 +533,12 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
 
     # ------------------------------------------------------------------------------------------ a7
     def _grad_groups(self):
-        groups = [("short_motion_encoder", list(self.short_motion_encoder.parameters()))]
-        groups += [(f"scmola_layer_{i}", list(layer.parameters())) for i, layer in enumerate(self.object_lang_align_layers)]
-        groups.append(("negative_token", list(self.negative_token.parameters())))
+        groups = self.__dict__.get("_group_cache")
+        if groups is None:
+            groups = [("short_motion_encoder", list(self.short_motion_encoder.parameters()))]
+            groups += [(f"scmola_layer_{i}", list(layer.parameters())) for i, layer in enumerate(self.object_lang_align_layers)]
+            groups.append(("negative_token", list(self.negative_token.parameters())))
+            self.__dict__["_group_cache"] = groups
         return groups
 
     def _grad_sq_device(self):
@@ -539,7 +566,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             # device doubles, reused by clip_grad_norm_ without another reduction - but only for these very gradient
             # values: the tag is every gradient's (storage, version), so an all-reduce, unscale, accumulation or a new
             # backward in between makes clip_grad_norm_ reduce again instead of clipping with a stale norm
-            self._last_grad_sq = (sq, self._grad_tag([p.grad for p in self.parameters() if p.grad is not None]))
+            self._last_grad_sq = (sq, self._grad_tag([p.grad for p in self._param_list() if p.grad is not None]))
             vals = sq[:n_groups].cpu().tolist()  # the single host sync
         out = {"total_grad_norm": sum(vals) ** 0.5}
         for (name, _), v in zip(groups, vals):
@@ -574,7 +601,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         """torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm) (train.py:121-122) as one in-place multi-tensor
         launch: the total norm is reduced on the device (or taken from a get_grad_norm_dict() of these very gradients) and
         the kernel itself decides whether to scale - the reference's ``if total_grad_norm > clip`` without a host sync."""
-        grads = [p.grad for p in self.parameters() if p.grad is not None]
+        grads = [p.grad for p in self._param_list() if p.grad is not None]
         if not grads:
             return
         cached = getattr(self, "_last_grad_sq", None)
