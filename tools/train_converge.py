@@ -1,5 +1,6 @@
 """Does a training run in the reduced-precision modes follow the exact-f32 run?  Same initial weights, same batches, same
-dropout seeds; the loss is read in eval mode with the exact-f32 forward every few steps.  -> profiles/r02_train_converge.log"""
+dropout seeds; the loss is read in eval mode with the exact-f32 forward every few steps.  -> profiles/r02_train_converge.log, r03_train_converge.log (bf16 operands; f16x3 with the
+weight-gradient products on plain f16 operands)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sola_amd import synth
@@ -18,7 +19,7 @@ def loss_of(m, inp):
     return track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, 1.5, 0.07, 0.3)
 
 curves = {}
-for prec in ("f32", "f16x3", "f16"):
+for prec in ("f32", "f16x3", "f16", "bf16"):
     m = LanguageAlignedTrackSelectionModule(cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     m = m.cuda()
