@@ -683,6 +683,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
     constexpr bool DMA = NWU == 4;
     constexpr int NBUF = DMA ? 2 : 1, RP = LD;  // row pitch of a staged tile, floats
     constexpr int PER = 16 * F4 / NT;  // float4 per thread per tensor per tile
+    constexpr int STAGE_UNROLL = NWU == 2 ? 1 : 2;  // the two-wave shape keeps its staging loop rolled: it spills otherwise
     constexpr int SLOTS = NWU > 1 ? NWU * 16 * LD : 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
     };
     // registers path: a tile's q and dO rows -> LDS; a row is the 32 float4 of half a wave, which also sums D = dO . O for it
     auto stage_direct = [&](int qt0) {
-#pragma unroll(NWU == 2 ? 1 : 2)
+#pragma unroll STAGE_UNROLL
         for (int j = 0; j < PER; ++j) {
             const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
             const int q = qt0 + r;
