@@ -742,12 +742,13 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + row * a.ldo + h * DH + ch * 4), (lptr_t)(Gs + pc), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(a.o + row * a.ldo + h * DH + ch * 4), (lptr_t)(Os + pr2 * (2 * RP)), 16, 0, 0);
         }
+        if (tid < 16) {  // the rows' log-sum-exp: 4 bytes per lane, straight into the tile's slots
+            const int q = qt0 + tid;
+            const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.lse + row * a.H + h), (lptr_t)(lsh + buf * 16), 4, 0, 0);
+        }
     };
-    auto lse_of = [&](int qt0) -> float {  // threads 0..15: the log-sum-exp of the tile's rows
-        const int q = qt0 + (tid & 15);
-        return a.lse[(geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs) * a.H + h];
-    };
-    auto dvec_from_lds = [&](int buf, float lse_reg) {  // D of a landed tile: half a wave per row, two rows per wave and pass
+    auto dvec_from_lds = [&](int buf) {  // D of a landed tile: half a wave per row, two rows per wave and pass
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = (wave * 2 + j) * 2 + (lane >> 5), c4 = lane & 31;
@@ -756,7 +757,6 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const float d = half_sum32((ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w));
             if (c4 == 0) dsh[buf * 16 + r] = d;
         }
-        if (tid < 16) lsh[buf * 16 + tid] = lse_reg;
     };
 
     for (int kg = 0; kg < nkt; kg += NWU) {
@@ -766,7 +766,6 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         const bool k_ok = w_ok && kj < geo.Sk;
         const long long krow = geo.k0 + (long long)(k_ok ? kj : 0) * geo.k_rs;
         if constexpr (DMA) issue_tile(qt_begin * 16, 0);  // under the K / V loads
-        float lse_reg = DMA ? lse_of(qt_begin * 16) : 0.f;
         float4 kf[NC], vf[NC];
         float kT[NC][4];
         {
@@ -800,7 +799,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         if constexpr (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // tile 0 landed; also: the previous group's last reduction done
-            dvec_from_lds(0, lse_reg);
+            dvec_from_lds(0);
             __syncthreads();
         } else {
             stage_direct(qt_begin * 16);
@@ -810,10 +809,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const int qt0 = it * 16, cur = DMA ? ((it - qt_begin) & 1) : 0;
             const bool more = it + 1 < nqt;
             if constexpr (DMA) {
-                if (more && !(a.ntile & 2)) {
-                    issue_tile(qt0 + 16, cur ^ 1);
-                    lse_reg = lse_of(qt0 + 16);
-                }
+                if (more && !(a.ntile & 2)) issue_tile(qt0 + 16, cur ^ 1);
             }
             f32x4 dqacc[NC];
 #pragma unroll
@@ -916,7 +912,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                     }
                 }
                 if constexpr (DMA) {
-                    if (more && !(a.ntile & 2)) dvec_from_lds(cur ^ 1, lse_reg);
+                    if (more && !(a.ntile & 2)) dvec_from_lds(cur ^ 1);
                 } else {
                     if (more && !(a.ntile & 2)) stage_direct(qt0 + 16);
                 }

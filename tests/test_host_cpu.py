@@ -208,7 +208,7 @@ def _code_object_text(obj_name):
 
 def test_one_pass_attention_backward_code_object():
     """The one-pass attention backward keeps ~250 registers live at two waves per SIMD: the BUILT kernels must not
-    spill in their tile loops (scratch traffic and vmcnt(0) waits per tile), the four-wave shape must fetch its tiles by
+    spill (scratch traffic and vmcnt(0) waits inside the tile loop), the four-wave shape must fetch its tiles by
     direct-to-LDS DMA, and the transposed dS / K products must be there (five f32 MFMA products per tile)."""
     import re
     dis, notes = _code_object_text("attn_bwd.o")
@@ -217,9 +217,7 @@ def test_one_pass_attention_backward_code_object():
     for nm in names:
         body = dis[dis.index(f"<{nm}>:"):]
         body = body[:body.index("s_endpgm")]
-        # at most the two prologue spills the four-wave shape has today (one 8-byte store per key group, one reload): a spill inside
-        # the tile loop shows up as many more scratch instructions
-        assert body.count("scratch_") <= 2, f"{nm}: {body.count('scratch_')} scratch instructions - the tile loop spills"
+        assert "scratch_" not in body, f"{nm} spills to scratch"
         assert body.count("v_mfma_f32_16x16x4") >= 160, (nm, body.count("v_mfma_f32_16x16x4"))
     four = [nm for nm in names if "ILi4E" in nm]
     assert len(four) == 1
