@@ -608,9 +608,14 @@ bool attention_res_supported(const AttnDesc& d);
 int launch_attention_res(const AttnDesc& d, hipStream_t s);
 extern int g_attn_splitm;
 
+bool attention_spin_supported(const AttnDesc& d);
+int launch_attention_spin(const AttnDesc& d, hipStream_t s);
+
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
+    // q / k / v written as split-f16 pairs by the projection GEMMs: the high-occupancy shape for split inputs (attn_simple.hip)
+    if (g_attn_variant == 1 && attention_spin_supported(d)) return launch_attention_spin(d, s);
     // Sequences of <= 4 steps (motion attention at T <= 32): the register-only streaming shape (attn_simple.hip)
     if (g_attn_variant == 1 && attention_small_supported(d)) return launch_attention_small(d, s);
     // register-only shape (attn_reg.hip): every wave on its own 16-query tile, operands straight from global memory

@@ -497,6 +497,217 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_splitm_kernel(const AttnSArgs
     if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
 }
 
+// ---- split-f16 q / k / v (written as split pairs by the projection GEMMs, GemmDesc::c_sp16), high-occupancy shape (round 3) -----
+// From ~48 keys per unit on, the exact-f32 products above take as long at the matrix pipe's peak as the traffic takes at the HBM
+// peak (object -> language at the headline shape: 82 us against 115 us; inter-object attention over 128 tracks: 219 against 134),
+// and the two do not overlap at four waves per SIMD.  attn.hip's kernel for split inputs is the round-1 shape (8 waves, 68 KB of
+// LDS: 401 us where the f32 shape above takes 280-324).  Here the split rows go through the SAME block decomposition as the
+// f32 shape: a row of 128 values is 16 blocks of [hi8 | lo8] = 512 bytes, K / V tiles are staged with plain 16-byte copies
+// (no conversion: the GEMM epilogue did it), and
+//   S^T = K Q^T : A = the key's (hi4, lo4) of a 16-wide head-dim chunk - two 8-byte LDS reads - B = Q's, loaded once;
+//   O^T = V^T P^T: A = V^T fragments through ds_read_b64_tr_b16 (the 4 x 16 block of four keys x sixteen head dims, each lane
+//                 supplying the address of one 8-byte piece of the split row: no transposed copy of V anywhere), B = P split
+//                 in registers;
+// each product hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16: 3 x 16 cycles where the f32 shape spends 4 x 32.
+// Row pitch 560 bytes: both read patterns conflict-free on the 64-bank LDS.
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+// DB: two LDS stages of TK keys, the next tile's rows travel in registers under the current tile's products, one barrier per tile
+// (as the f32 shape above).
+template <int TK, bool DB = false>
+__global__ __launch_bounds__(256, 4) void attn_fwd_spin_kernel(const AttnSArgs a) {
+    constexpr int DH = 128, NC = DH / 16;
+    constexpr int RB = 560;  // LDS row pitch, bytes (512 + 48)
+    constexpr int P16 = DH / 4;  // 16-byte pieces per split row (DH values x 4 bytes)
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    char* Ks = smem_p;
+    char* Vs = smem_p + TK * RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const long long unit = blockIdx.x / a.nqb;
+    const int qb = blockIdx.x - (int)unit * a.nqb;
+    const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
+    long long q0, k0, q_rs, k_rs;
+    int Sq, Sk;
+    if (a.q_units) {
+        const int4 qu = a.q_units[grp], ku = a.k_units[grp];
+        q0 = __builtin_amdgcn_readfirstlane(qu.x); q_rs = __builtin_amdgcn_readfirstlane(qu.y); Sq = __builtin_amdgcn_readfirstlane(qu.z);
+        k0 = __builtin_amdgcn_readfirstlane(ku.x); k_rs = __builtin_amdgcn_readfirstlane(ku.y); Sk = __builtin_amdgcn_readfirstlane(ku.z);
+    } else {
+        q0 = (long long)(grp / a.inner) * a.q_outer + (long long)(grp % a.inner) * a.q_inner;
+        k0 = (long long)(grp / a.inner) * a.k_outer + (long long)(grp % a.inner) * a.k_inner;
+        q_rs = a.q_rs; k_rs = a.k_rs; Sq = a.Sq; Sk = a.Sk;
+    }
+    if (qb * 64 >= Sq) return;
+    const int qi = qb * 64 + wave * 16 + c16;
+    const bool q_ok = qi < Sq;
+    // byte offset, inside a split row, of the hi4 this lane's 4 head dims of chunk 0 (16c + 4*g4 .. +3); lo4 sits 16 bytes on
+    const int frag = (g4 >> 1) * 32 + (g4 & 1) * 8;
+    half4v qh[NC], ql[NC];
+    {
+        const char* qp = reinterpret_cast<const char*>(a.q + (q0 + (long long)(q_ok ? qi : 0) * q_rs) * a.ldq + h * DH) + frag;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const half4v hv = *reinterpret_cast<const half4v*>(qp + c * 64);
+            const half4v lv = *reinterpret_cast<const half4v*>(qp + c * 64 + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qh[c][j] = q_ok ? hv[j] : (_Float16)0.f;
+                ql[c][j] = q_ok ? lv[j] : (_Float16)0.f;
+            }
+        }
+    }
+    f32x4 oacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    // V^T fragment addresses (ds_read_b64_tr_b16): lane p of a 16-lane group supplies the piece (key 4*g4 + (p >> 2), head dims
+    // 4 * (p & 3) .. +3 of the chunk) and receives head dim p of the four keys
+    const int vfrag = (4 * g4 + (c16 >> 2)) * RB + ((c16 & 3) >> 1) * 32 + (c16 & 1) * 8;
+    constexpr int PT = DB ? 2 * TK * P16 / 256 : 1;  // 16-byte pieces per thread and tile (K + V) of the prefetch
+    float4 st[PT];
+    auto fetch = [&](int kt0) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int e = tid + 256 * j, which = e / (TK * P16), r = (e % (TK * P16)) / P16, c4 = e % P16;
+            st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kt0 + r < Sk) {
+                const long long row = k0 + (long long)(kt0 + r) * k_rs;
+                st[j] = which ? *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4)
+                              : *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+            }
+        }
+    };
+    if (DB) fetch(0);
+    int it = 0;
+    for (int kt0 = 0; kt0 < Sk; kt0 += TK, ++it) {
+        const int nrows = min(TK, Sk - kt0);
+        const int nrows16 = (nrows + 15) & ~15;
+        if (DB) {
+            Ks = smem_p + (it & 1) * 2 * TK * RB;
+            Vs = Ks + TK * RB;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int e = tid + 256 * j, which = e / (TK * P16), r = (e % (TK * P16)) / P16, c4 = e % P16;
+                *reinterpret_cast<float4*>((which ? Vs : Ks) + r * RB + c4 * 16) = st[j];
+            }
+            __syncthreads();
+            if (kt0 + TK < Sk) fetch(kt0 + TK);
+        } else {
+        if (kt0 > 0) __syncthreads();
+        for (int idx = tid; idx < nrows16 * P16; idx += 256) {
+            const int r = idx / P16, c4 = idx - r * P16;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (r < nrows) {
+                const long long row = k0 + (long long)(kt0 + r) * k_rs;
+                kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(Ks + r * RB + c4 * 16) = kv;
+            *reinterpret_cast<float4*>(Vs + r * RB + c4 * 16) = vv;
+        }
+        __syncthreads();
+        }
+        const int ntile = nrows16 >> 4;
+        f32x4 sc[TK / 16];
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t) {
+            if (t < ntile) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const char* kp = Ks + (t * 16 + c16) * RB + frag;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const half4v kh = *reinterpret_cast<const half4v*>(kp + c * 64);
+                    const half4v kl = *reinterpret_cast<const half4v*>(kp + c * 64 + 16);
+                    if (c & 1) a1 = mfma3h(kh, kl, qh[c], ql[c], a1);
+                    else a0 = mfma3h(kh, kl, qh[c], ql[c], a0);
+                }
+                const int key0 = kt0 + t * 16 + 4 * g4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < Sk) ? (a0[r] + a1[r]) * a.scale : -INFINITY;
+            } else {
+                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[t][r] = __expf(sc[t][r] - m_new);
+                rs += sc[t][r];
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+#pragma unroll
+        for (int t = 0; t < TK / 16; ++t) {
+            if (t < ntile) {
+                half4v ph, pl;
+                split4h(make_float4(sc[t][0], sc[t][1], sc[t][2], sc[t][3]), ph, pl);
+                const char* vp = Vs + t * 16 * RB + vfrag;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    typedef __attribute__((address_space(3))) short4v lds_s4;
+                    const short4v vh4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(vp + c * 64));
+                    const short4v vl4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(vp + c * 64 + 16));
+                    oacc[c] = mfma3h(__builtin_bit_cast(half4v, vh4), __builtin_bit_cast(half4v, vl4), ph, pl, oacc[c]);
+                }
+            }
+        }
+    }
+    if (!q_ok) return;
+    const float inv = 1.f / l_run;
+    float* op = a.o + (q0 + (long long)qi * q_rs) * a.ldo + h * DH;
+    if (!a.o_sp16) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        return;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        half4v hi, lo;
+        const float4 v = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        split4h(v, hi, lo);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        char* dst = reinterpret_cast<char*>(op + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+        *reinterpret_cast<half4v*>(dst) = hi;
+        *reinterpret_cast<half4v*>(dst + 16) = lo;
+    }
+    if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
+}
+
+int g_attn_spin_db = 1;  // sola_tune "attn_spin" 2 = single-buffered 32-key stages (A/B)
+int launch_spin(const AttnSArgs& a0, hipStream_t s) {
+    AttnSArgs a = a0;
+    constexpr int TK = 32;
+    a.nqb = (a.Sq + 63) / 64;
+    const long long blocks = (long long)a.G * a.H * a.nqb;
+    SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
+    if (g_attn_spin_db) {  // two stages of 16 keys (the same 35.8 KB), next tile prefetched in registers
+        hipLaunchKernelGGL((attn_fwd_spin_kernel<16, true>), dim3((unsigned)blocks), dim3(256), (size_t)2 * 2 * 16 * 560, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
+    const size_t lds = (size_t)2 * TK * 560;
+    hipLaunchKernelGGL((attn_fwd_spin_kernel<TK>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 int launch_splitm(const AttnSArgs& a0, hipStream_t s) {
     AttnSArgs a = a0;
     constexpr int DH = 128, TK = 32;
@@ -590,6 +801,22 @@ int launch_attention_simple(const AttnDesc& d, hipStream_t s) {
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     return d.DH == 128 ? launch_s<128>(a, s) : launch_s<64>(a, s);
+}
+
+// split-f16 q / k / v (GEMM outputs written as split pairs), head_dim 128, inference: the high-occupancy shape for split inputs
+int g_attn_spin = 1;  // sola_tune "attn_spin": 0 = attn.hip's round-1 kernel for split inputs (A/B)
+void sola_attn_set_spin(int v) { g_attn_spin = v != 0; g_attn_spin_db = v != 2; }
+bool attention_spin_supported(const AttnDesc& d) {
+    // units of at most two 64-query blocks (the inter-object attention): with many q-blocks per unit (object -> language) every
+    // block re-stages the unit's K / V and attn.hip's resident-K/V loop wins (158 vs 184 us at the headline shape)
+    return g_attn_spin && d.in_sp16 && !d.lse && !d.drop.enabled && d.DH == 128 && (d.Sq > 16 || d.Sk > 16) && (d.Sq <= 128 || d.q_units) &&
+           d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0;
+}
+int launch_attention_spin(const AttnDesc& d, hipStream_t s) {
+    const AttnSArgs a = make_sargs(d);
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+    return launch_spin(a, s);
 }
 
 // f32 q / k / v with the products evaluated as split-f16 triples (AttnDesc::split_math; head_dim 128, inference)

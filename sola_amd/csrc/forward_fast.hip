@@ -67,10 +67,12 @@ int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
 }
 
 // sola_tune "attn_split_min_keys": units with more keys than this take the split-f16 MFMA attention on q/k/v the projection GEMMs
-// wrote as split pairs.  128 since round 3 (was 64): behind the one-pass / register-only f32 shapes (attn_simple.hip, attn_reg.hip)
-// that kernel loses at 80 keys (401 vs 280 us per launch, step 14.38 -> 13.91 ms at 192 x 80 x 32) and ties at 128 (step 14.52 vs
-// 14.44 ms); it keeps the units of more than 128 keys, where the f32 matrix pipe alone would take longer than the HBM traffic
-int g_attn_split_min_keys = 128;
+// wrote as split pairs.  Rounds 1-2: 64.  Round 3: behind the one-pass / register-only f32 shapes (attn_simple.hip, attn_reg.hip)
+// attn.hip's kernel for split inputs lost at 80 keys (401 vs 280 us per launch in the bench) and tied at 128, so the threshold went
+// to 128; with the high-occupancy shape for split inputs (attn_fwd_spin_kernel: 262 vs 362 us at 128 tracks, 270 vs 285 at 80, 216
+// vs 256 at 64) the attention wins from 64 keys on, but the q/k/v GEMM pays ~70 us per launch for the split-pair epilogue: net
+// gain at 128 tracks (14.41 -> 14.30 ms per step, attention 0.43 -> 0.49 of the HBM peak), net loss at 80 and 64.  96.
+int g_attn_split_min_keys = 96;
 void sola_attn_set_split_min_keys(int v) { g_attn_split_min_keys = v; }
 
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
