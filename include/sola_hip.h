@@ -447,7 +447,9 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * transposing cast of a gradient matrix also writes its row-major cast; "attn_bwd_fused" 1 (default) = the one-pass attention
  * backward for units of <= 128 queries and keys and for chunked long query ranges, 0 = the two-pass kernels everywhere;
  * "attn_split_min_keys" (default 128) = units with more keys take the split-f16 attention on split q / k / v in precision 1;
- * "train_dw_f16" 1 (default) = weight-gradient products of the precision-1 training step on plain f16 operands; "gn_h8" /
+ * "train_dw_f16" 1 (default) = weight-gradient products of the precision-1 training step on plain f16 operands;
+ * "train_gn_cast" 1 (default) = in the 16-bit operand training modes a GroupNorm also writes the operand cast of the GEMM behind
+ * it; "attn_spin" 1 (default) = the high-occupancy attention shape for split-f16 q / k / v; "gn_h8" /
  * "attn_f16_small" 1 (default) = the 16-byte-per-lane GroupNorm and the streaming short-sequence attention of precision 2).
  * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);

@@ -277,6 +277,7 @@ void sola_attn_set_f16_small(int v);
 void sola_gn_set_h8(int v);
 void sola_attn_set_spin(int v);
 void sola_train_set_dw_f16(int v);
+void sola_train_set_gn_cast(int v);
 void sola_attn_set_splitm(int v);
 void sola_attn_set_reg(int v);
 void sola_attn_set_reg_minw(int v);
@@ -331,6 +332,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gn_h8")) { sola_gn_set_h8(value); return SOLA_OK; }
     if (!strcmp(key, "attn_spin")) { sola_attn_set_spin(value); return SOLA_OK; }
     if (!strcmp(key, "train_dw_f16")) { sola_train_set_dw_f16(value); return SOLA_OK; }
+    if (!strcmp(key, "train_gn_cast")) { sola_train_set_gn_cast(value); return SOLA_OK; }
     if (!strcmp(key, "attn_simple_train")) { sola_attn_set_simple_train(value); return SOLA_OK; }
     if (!strcmp(key, "gn_bwd_reg")) { sola_gn_set_bwd_reg(value); return SOLA_OK; }
     if (!strcmp(key, "gn_slices")) { sola_gn_set_slices(value); return SOLA_OK; }

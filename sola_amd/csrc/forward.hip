@@ -8,6 +8,8 @@
 
 #include "ragged.h"
 
+int g_train_gn_cast = 1;  // sola_tune "train_gn_cast": 1 = a GroupNorm of the training forward also writes the operand cast of the GEMM behind it
+void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
 
@@ -196,6 +198,11 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     float* const sp_b = split ? buf("sp_b") : nullptr;
 
     // a2: encoder (module/module.py:74-96,137-140)
+    // Operand casts written by the PRODUCING GroupNorm (GroupNormDesc::y_cast; sola_tune "train_gn_cast" 0 = separate cast launches):
+    // the cast of a GEMM input was a launch of its own reading the f32 activation back - 24 of them per step
+    const int gn_fmt = (split && pure && g_train_gn_cast) ? 2 + bf : 0;  // 16-bit operand modes (split pairs: no gain, kernels.h)
+    const float* pc_src[2] = {nullptr, nullptr};  // activations whose operand cast already sits in pc_dst (consumed by the next GEMM)
+    float* pc_dst[2] = {nullptr, nullptr};
     const float* x = obj;
     int t_in = T;
     for (int i = 0; i < 6; ++i) {
@@ -214,9 +221,10 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             if (i == 0) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip)
                 SOLA_TRY(cast_auto(x, g.cin, sp_a, level_rows(i), g.cin, c->scal_pair(0)));
                 gd.out_scale_dev = c->scal_pair(0) + 1;
-            } else {
+            } else if (pc_src[0] != x) {
                 SOLA_TRY(cast_fixed(x, g.cin, sp_a, level_rows(i), g.cin, 1.f));
             }
+            pc_src[0] = nullptr;
             gd.p[0].A = sp_a;
             gd.p[0].W = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->ws16_buf) + c->ws_off[i]) : c->ws16_buf + c->ws_off[i];
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
@@ -232,6 +240,10 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             nd.ntok = p.Tl[i]; nd.C = g.cout; nd.groups = c->cfg.n_groups; nd.eps = 1e-5f; nd.slope = 0.01f; nd.leaky = 1;
             if (rs) nd.units = rt.u_lvl[i + 1];
             if (train) nd.drop = c->enc_drop(i);
+            if (gn_fmt && c->conv[i + 1].cin % 64 == 0) {  // conv i+1 takes the cast from here
+                nd.y_cast = sp_a; nd.cast_fmt = gn_fmt;
+                pc_src[0] = nd.y; pc_dst[0] = sp_a;
+            }
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
         } else {
@@ -270,7 +282,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                 if (at < 0) {
                     at = nsrc++;
                     src[at] = as[j];
-                    if (a_scal) SOLA_TRY(cast_auto(as[j], D, dst[at], rows, D, a_scal));
+                    if (pc_src[at] == as[j] && pc_dst[at] == dst[at]) {}  // the producing GroupNorm wrote this operand
+                    else if (a_scal) SOLA_TRY(cast_auto(as[j], D, dst[at], rows, D, a_scal));
                     else SOLA_TRY(cast_fixed(as[j], D, dst[at], rows, D, 1.f));
                 }
                 gd.p[j].A = dst[at];
@@ -279,6 +292,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             }
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
             if (a_scal) gd.out_scale_dev = a_scal + 1;
+            pc_src[0] = pc_src[1] = nullptr;
         }
         return launch_gemm(gd, s);
     };
@@ -295,9 +309,22 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         }
         return launch_gemm(gd, s);
     };
+    // next_src0 / next_src1: the FIRST / SECOND distinct input of the projection launch that follows (linear3 casts them into sp_a / sp_b in
+    // that order): when one of them is this norm's y or y2, the norm writes the cast itself
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,
-                  long long outer, long long inner_stride, long long tok_stride, int ntok, const int4* units = nullptr) -> int {
+                  long long outer, long long inner_stride, long long tok_stride, int ntok, const int4* units = nullptr,
+                  const float* next_src0 = nullptr, const float* next_src1 = nullptr) -> int {
         GroupNormDesc nd{};
+        if (gn_fmt) {
+            const float* nxt[2] = {next_src0, next_src1};
+            float* dsts[2] = {sp_a, sp_b};
+            for (int e = 0; e < 2; ++e) {
+                if (!nxt[e]) continue;
+                if (nxt[e] == y) { nd.y_cast = dsts[e]; pc_src[e] = y; pc_dst[e] = dsts[e]; }
+                else if (nxt[e] == y2) { nd.y2_cast = dsts[e]; pc_src[e] = y2; pc_dst[e] = dsts[e]; }
+            }
+            nd.cast_fmt = gn_fmt;
+        }
             nd.slice_ws = buf("gn_slots"); nd.slice_ws_bytes = (size_t)p.bufs.at("gn_slots").rows * p.bufs.at("gn_slots").cols * sizeof(float);
         nd.x = res; nd.y = y; nd.y2 = y2; nd.pe = y2 ? buf("pe") : nullptr;
         nd.gamma = W(lp + "norm." + std::to_string(idx) + ".weight");
@@ -328,8 +355,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
-        if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st));
-        else SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N));
+        if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st, x_pe, x_obj));
+        else SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, nullptr, x_pe, x_obj));
         // (ii) motion attention over T' per track, PE on q and k only: module.py:38-43
         SOLA_TRY(linear3(x_pe, x_pe, x_obj, lp + "motion_attn", 3, M, ab(1, "q"), ab(1, "k"), ab(1, "v"), 0));
         {
@@ -340,8 +367,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
-        if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk));
-        else SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp));
+        if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk, x_mot));
+        else SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp, nullptr, x_mot));
         // (iii) object -> language cross attention: module.py:46-50
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, lp + "object2lang_attn", 1, M, ab(2, "q"), nullptr, nullptr, 0));
         SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, (int)text_rows, ab(2, "lk"), ab(2, "lv"), nullptr, 1,
@@ -354,8 +381,10 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             SOLA_TRY(launch_attention(ad, s));
         }
         SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));
-        if (rs) SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, 0, 0, 1, rt.maxRowsSample, rt.u_smp));
-        else SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp));
+        // the next layer's q / k / v projections read x_o2l: its norm writes their operand (nothing reads it behind the last layer)
+        const float* nxt_in = l + 1 < c->cfg.n_layers ? x_o2l : nullptr;
+        if (rs) SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, 0, 0, 1, rt.maxRowsSample, rt.u_smp, nxt_in));
+        else SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp, nullptr, nxt_in));
         xin = x_o2l;
     }
 

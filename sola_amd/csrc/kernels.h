@@ -252,6 +252,13 @@ struct GroupNormDesc {
     // per-device buffer owned by the library (the stage entry point: one stream at a time)
     void* slice_ws;
     size_t slice_ws_bytes;
+    // optional, f32 outputs only (training forward with 16-bit GEMM operands): besides y / y2 the kernel also writes their casts in
+    // the format the NEXT GEMM takes as its operand, unscaled - cast_fmt 2: plain f16, 3: bfloat16 - so the operand cast launch (a
+    // read of y and a write of the cast) disappears.  Same row pitch C as y.  (Split-f16 pairs were tried too: the pair shuffles and
+    // 16 more bytes per lane cost the norm what the cast launch saved - 34.2 vs 34.3 ms per ragged step.)
+    void* y_cast = nullptr;
+    void* y2_cast = nullptr;
+    int cast_fmt = 0;
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);

@@ -83,6 +83,8 @@ struct GnArgs {
     const int4* units;  // ragged batches: (first row, row stride, token count, pe row) per instance (GroupNormDesc::units)
     int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices with the same element offsets
     const float* in_scale_dev;  // optional multiplier applied to x while reading (GroupNormDesc::in_scale_dev)
+    void *y_cast, *y2_cast;     // f32 outputs: also their casts for the next GEMM (GroupNormDesc::y_cast)
+    int cast_fmt;               // 2 f16, 3 bf16
 };
 
 typedef _Float16 half4n __attribute__((ext_vector_type(4)));
@@ -178,6 +180,19 @@ __device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, c
             }
         }
         return;
+    }
+    if (a.cast_fmt >= 2 && off >= 0) {  // plain f16 / bf16 operand copies: 8 bytes per lane
+        const bool bf = a.cast_fmt == 3;
+        auto cv = [&](float x) -> _Float16 { return bf ? __builtin_bit_cast(_Float16, (__bf16)x) : (_Float16)x; };
+        half4n h;
+        if (a.y_cast) {
+            h[0] = cv(o.x); h[1] = cv(o.y); h[2] = cv(o.z); h[3] = cv(o.w);
+            *reinterpret_cast<half4n*>(static_cast<_Float16*>(a.y_cast) + off) = h;
+        }
+        if (a.y2_cast) {
+            h[0] = cv(o.x + pe.x); h[1] = cv(o.y + pe.y); h[2] = cv(o.z + pe.z); h[3] = cv(o.w + pe.w);
+            *reinterpret_cast<half4n*>(static_cast<_Float16*>(a.y2_cast) + off) = h;
+        }
     }
     if (off < 0) return;
     *reinterpret_cast<float4*>(a.y + off) = o;
@@ -626,6 +641,9 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = (d.out_sp16 || d.out_f16) ? d.guard : nullptr; a.units = d.units;
     a.in_f16 = d.in_f16; a.out_f16 = d.out_f16; a.in_scale_dev = d.in_scale_dev;
+    a.y_cast = d.y_cast; a.y2_cast = d.y2_cast; a.cast_fmt = (d.y_cast || d.y2_cast) ? d.cast_fmt : 0;
+    SOLA_ARG(a.cast_fmt == 0 || (!d.out_sp16 && !d.out_f16 && a.cast_fmt >= 2 && a.cast_fmt <= 3 && (!d.y2_cast || d.y2)),
+             "group_norm: operand casts go with f32 outputs (format 2 = f16, 3 = bf16)");
     SOLA_ARG(!(d.out_f16 && d.out_sp16), "group_norm: one output format at a time");
     SOLA_ARG(!d.out_sp16 || cg % 8 == 0, "group_norm: split-f16 output needs channels per group %% 8 == 0");
     const double elems = (double)d.n_inst * d.ntok * d.C;
