@@ -282,6 +282,10 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
             res[prec]["what"] = ("mixed precision (BASELINE config C2): every GEMM of the step on plain f16 casts of the f32 activations / "
                                  "gradients, f32 accumulation, ONE MFMA per product; everything else f32.  Reduced precision: losses within "
                                  "1 %, gradient cosine >= 0.95 against the exact-f32 step (tests/test_gpu_backward.py)")
+        if prec == "f16x3":
+            res[prec]["what"] = ("every GEMM of the step on split-f16 casts (3 f16 MFMAs per product) except the weight-gradient products dW = dY^T X, "
+                                 "which sum over all token rows and take plain f16 operands (sola_tune train_dw_f16, default 1: median per-matrix error "
+                                 "1e-4 against the exact-f32 step, worst tensor and gradient cosine unchanged; 0 = split pairs there too)")
         if prec == "bf16":
             res[prec]["what"] = ("the same mixed-precision step with BFLOAT16 GEMM operands (v_mfma_f32_32x32x16_bf16), the format BASELINE "
                                  "config C2 names; 8 significant bits, tolerance stated in tests/test_gpu_backward.py (LOWP_TRAIN_TOL)")
