@@ -145,7 +145,10 @@ def _attn_ref64(q, k, v, H):
     return (p @ vh).transpose(0, 2, 1, 3).reshape(G, Sq, D)
 
 
-@pytest.mark.parametrize("B,N,Tp,D", [(1, 64, 4, 1024), (2, 80, 1, 1024), (1, 130, 2, 128), (1, 20, 25, 128), (1, 128, 2, 1024), (2, 17, 3, 256)])
+@pytest.mark.parametrize("B,N,Tp,D", [(1, 64, 4, 1024), (2, 80, 1, 1024), (1, 130, 2, 128), (1, 20, 25, 128), (1, 128, 2, 1024), (2, 17, 3, 256),
+                                      # head_dim 128: the high-occupancy shape for split inputs (attn_fwd_spin_kernel) with partial
+                                      # query / key tiles and three key stages; > 128 queries: attn.hip's kernel
+                                      (3, 33, 2, 1024), (1, 100, 3, 1024), (2, 47, 1, 1024)])
 def test_split_attention_kernel_vs_float64(B, N, Tp, D):
     """sola_attention_split (q, k, v as split-f16 rows, three f16 MFMAs per product) in the inter-object and
     object->language layouts, f32 and split-f16 output, against float64 softmax attention: f32-class error."""
