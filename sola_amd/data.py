@@ -224,14 +224,54 @@ class RaggedBatcher:
     Yields dictionaries: ``videos`` (list of [N_v,T_v,d] tensors), ``sample_video`` (index per sample), ``samples`` (the
     dataset's sample dictionaries, tokens removed)."""
 
-    def __init__(self, dataset, indices, max_samples=128, max_rows=1 << 20):
+    def __init__(self, dataset, indices, max_samples=128, max_rows=1 << 20, num_workers=0, pin=False):
         self.dataset, self.indices = dataset, list(indices)
         self.max_samples, self.max_rows = int(max_samples), int(max_rows)
+        # pin: the reader threads also move a sample's tokens into page-locked memory (Tensor.pin_memory: ~2.5 ms per 2 MB sample,
+        # which held the pipeline at 400 samples/s when the ONE upload thread of DevicePrefetcher did it for every sample)
+        self.pin = bool(pin) and torch.cuda.is_available()
+        # reader THREADS that fetch (or, for the synthetic stand-in, draw) the samples ahead of the batcher, in order.  Threads, not
+        # worker processes: a sample is 1-16 MB of object tokens and a tensor that crosses a process boundary through shared
+        # memory costs ~5 ms to touch on the receiving side (0.4 GB/s: tools/train_pipeline_profile.py measured 330 samples/s
+        # behind 32 worker processes that produced 1 000) - file reads and numpy's generators release the interpreter lock
+        self.num_workers = int(num_workers)
+
+    def set_indices(self, indices):
+        """Another pass over the same dataset in another order (the next epoch's shuffle)."""
+        self.indices = list(indices)
+
+    def _samples(self):
+        if self.num_workers <= 0 or len(self.indices) < 2:
+            for idx in self.indices:
+                yield idx, self.dataset[idx]
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        def fetch(idx):
+            smp = self.dataset[idx]
+            if self.pin and isinstance(smp.get("object_tokens"), torch.Tensor) and not smp["object_tokens"].is_cuda:
+                smp["object_tokens"] = smp["object_tokens"].pin_memory()
+            return smp
+
+        ahead = 4 * self.num_workers
+        with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
+            pending = deque()
+            it = iter(self.indices)
+            for idx in it:
+                pending.append((idx, pool.submit(fetch, idx)))
+                if len(pending) >= ahead:
+                    break
+            while pending:
+                idx, fut = pending.popleft()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append((nxt, pool.submit(fetch, nxt)))
+                yield idx, fut.result()
 
     def __iter__(self):
         videos, keys, sample_video, samples, rows = [], {}, [], [], 0
-        for idx in self.indices:
-            smp = self.dataset[idx]
+        for idx, smp in self._samples():
             tok = smp.pop("object_tokens")
             key = smp.get("token_key", ("sample", idx))
             new_rows = 0 if key in keys else int(tok.shape[0]) * int(tok.shape[1])
@@ -286,8 +326,8 @@ class DevicePrefetcher:
                         return
                     with _t.cuda.stream(stream):
                         vids = []
-                        for v in b["videos"]:
-                            v = v if v.is_cuda else v.pin_memory()
+                        for v in b["videos"]:  # reader threads hand over page-locked tensors (RaggedBatcher pin=True): only the copy is left
+                            v = v if (v.is_cuda or v.is_pinned()) else v.pin_memory()
                             vids.append(v.to(self.device, non_blocking=True))
                         ev = _t.cuda.Event()
                         ev.record(stream)
@@ -333,21 +373,29 @@ def make_ragged_batches(cfg_dataset: dict, split: str, rank=0, world=1, syntheti
     n = len(ds)
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     idx = list(range(lo, hi)) if world > 1 else shard_indices(n, 0, 1)
+    # no reader threads here: the expressions of a video are consecutive and share its tokens (read / drawn once by the dataset's
+    # one-entry cache); concurrent readers fetch them once per expression (inference.py: 446 -> 380 samples/s wall with four)
     return RaggedBatcher(ds, idx, int(cfg_dataset.get("ragged_max_samples", 128)), int(cfg_dataset.get("ragged_max_rows", 1 << 20))), ds
 
 
-def make_ragged_train_batches(cfg_dataset: dict, rank=0, world=1, synthetic=None, model_cfg=None, samples_per_step=64, epoch=0):
+def make_ragged_train_batches(cfg_dataset: dict, rank=0, world=1, synthetic=None, model_cfg=None, samples_per_step=64, epoch=0, reuse=None):
     """Ragged TRAINING batches of one epoch for this rank: the train split shuffled with a seed every rank derives from the
     epoch, sharded i % world == rank with the short shards padded (every rank must issue the same number of optimizer steps:
     each ends in one gradient all-reduce), cut into batches of exactly ``samples_per_step`` samples (the last one shorter) -
     bounded by the sample count only, so all ranks see the same number of batches."""
     from .dist import shard_indices
 
-    ds = make_dataset(cfg_dataset, "train", synthetic, model_cfg)
+    ds = reuse.dataset if reuse is not None else make_dataset(cfg_dataset, "train", synthetic, model_cfg)
     n = len(ds)
     order = np.random.Generator(np.random.PCG64(1234567 + int(epoch))).permutation(n).tolist()
     mine = [order[i] for i in shard_indices(n, rank, world, pad=True)]
-    return RaggedBatcher(ds, mine, int(samples_per_step), max_rows=1 << 62), ds
+    if reuse is not None:  # the next epoch of the same batcher: its worker processes stay
+        reuse.set_indices(mine)
+        return reuse, ds
+    # dataset.reader_threads (default: 16, at most the host's cores): threads that read / draw the samples ahead of the batcher and
+    # page-lock their tokens; dataset.num_workers (the reference's DataLoader key) still sizes the one-sample-per-step loader
+    readers = int(cfg_dataset.get("reader_threads", min(16, os.cpu_count() or 1)))
+    return RaggedBatcher(ds, mine, int(samples_per_step), max_rows=1 << 62, num_workers=readers, pin=True), ds
 
 
 def collate(batch):

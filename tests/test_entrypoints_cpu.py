@@ -104,3 +104,9 @@ def test_ragged_batcher_groups_samples_and_shares_videos():
             return {"object_tokens": torch.zeros(2, 3, 8), "expression": "x"}
     b = list(sdata.RaggedBatcher(NoKey(), range(3)))
     assert len(b) == 1 and b[0]["sample_video"] == [0, 1, 2]
+    # worker processes read the samples ahead of the batcher: same batches, same order, same tensors
+    def digest(batches):
+        return [([tuple(v.shape) for v in bt["videos"]], bt["sample_video"], [s_["expression"] for s_ in bt["samples"]],
+                 [float(v.double().sum()) for v in bt["videos"]]) for bt in batches]
+    order = [5, 4, 17, 16, 3, 22, 9, 8, 11, 10, 0, 1, 2, 6, 7, 12]
+    assert digest(sdata.RaggedBatcher(ds, order, max_samples=5, num_workers=2)) == digest(sdata.RaggedBatcher(ds, order, max_samples=5))

@@ -175,10 +175,11 @@ def train(cfg):
     # --samples_per_step K (default: dataset.train.batch_size = 1, the reference's): K > 1 trains on ragged batches of K
     # variable-shape samples per optimizer step (run_train_ragged); K = 1 is the reference's loop, one sample per step
     per_step = int(cfg.get("samples_per_step", tcfg.get("samples_per_step", cfg["dataset"]["train"].get("batch_size", 1))))
+    batches = None
     for epoch in range(n_epochs):
         t0 = time.time()
         if per_step > 1:
-            batches, _ = make_ragged_train_batches(cfg["dataset"], rank, world, synthetic, cfg["model"], per_step, epoch)
+            batches, _ = make_ragged_train_batches(cfg["dataset"], rank, world, synthetic, cfg["model"], per_step, epoch, reuse=batches)
             tr = run_train_ragged(module, text, batches, tcfg, device, optimizer, world)
         else:
             tr = run_split(module, text, train_loader, tcfg, device, True, optimizer, world)
