@@ -434,8 +434,58 @@ def make_loader(cfg_dataset: dict, split: str, rank=0, world=1, synthetic=None, 
     sub = torch.utils.data.Subset(ds, shard_indices(len(ds), rank, world, pad=(split == "train")))
     # worker processes also for the synthetic stand-in: drawing a sample's tokens on the host (numpy, 0.5 M normals at 64 x 32
     # tracks x frames) is ~5 ms, 40x the GPU time of the sample at 64 samples per step (tools/train_rate.sh)
+    readers = int(cfg_dataset.get("reader_threads", min(16, os.cpu_count() or 1)))
+    if readers > 0:
+        # reader THREADS + page-locked batches (RaggedBatcher's note: tensors that cross a process boundary are ~5 ms per 2 MB
+        # on the receiving side; train.py at one sample per step: 250 samples/s behind four worker processes, step-bound 330-350
+        # behind threads).  dataset.reader_threads 0 = torch's DataLoader with dataset.num_workers processes, as the reference.
+        return ThreadLoader(sub, int(sc.get("batch_size", 1)), split == "train", readers), ds
     nw = int(cfg_dataset.get("num_workers", 0))
     loader = torch.utils.data.DataLoader(sub, batch_size=sc.get("batch_size", 1), shuffle=(split == "train"), num_workers=nw,
                                          pin_memory=True, collate_fn=collate, persistent_workers=nw > 0,
                                          prefetch_factor=4 if nw > 0 else None)
     return loader, ds
+
+
+class ThreadLoader:
+    """DataLoader(sub, batch_size, shuffle, collate_fn=collate, pin_memory=True) on a thread pool: the samples of an epoch are
+    fetched in order by ``threads`` readers running ahead of the consumer, collated per batch and page-locked.  A new shuffle
+    (torch's global generator, like DataLoader's RandomSampler) on every pass."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, threads=16):
+        self.dataset, self.batch_size, self.shuffle, self.threads = dataset, max(1, int(batch_size)), bool(shuffle), int(threads)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = len(self.dataset)
+        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+        groups = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
+        pin = torch.cuda.is_available()
+
+        def fetch(group):
+            b = collate([self.dataset[i] for i in group])
+            if pin:
+                b["object_tokens"] = b["object_tokens"].pin_memory()
+                if b["labels"] is not None:
+                    b["labels"] = {k: v.pin_memory() for k, v in b["labels"].items()}
+            return b
+
+        ahead = 4 * self.threads
+        with ThreadPoolExecutor(max_workers=self.threads) as pool:
+            pending = deque()
+            it = iter(groups)
+            for g in it:
+                pending.append(pool.submit(fetch, g))
+                if len(pending) >= ahead:
+                    break
+            while pending:
+                fut = pending.popleft()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(pool.submit(fetch, nxt))
+                yield fut.result()
