@@ -428,6 +428,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * stores, 16 = without its LDS transpose;
  * "gemm_nw4", "gemm_pp": experimental four-wave shapes of the persistent split-f16 GEMM (256x128 tiles, one wave per SIMD; gemm_pp with
  * two accumulator sets and the epilogue drained under the next tile), bit-identical to the default, 0 (default) = off;
+ * "gemm_k16": experimental one-tile-per-block shape of the split-f16 GEMM - 256x128 tiles, 16-deep k-tiles, two four-wave blocks per
+ * CU (one block's epilogue under the other's k-loop); bit-identical to the default, 7-20 % slower, 0 = off;
  * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose
  * conv outputs fill 256-row tiles, 64 channels per group; ~2 % of the headline step), 0 (default since round 3: the epilogue had two
  * nondeterministic faults in development whose root cause was never established - contained and stress-tested, but opt-in) =

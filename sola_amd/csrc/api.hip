@@ -260,7 +260,7 @@ extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
 void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
-extern int g_gemm_nw4, g_gemm_pp;
+extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
 void sola_set_train_split_min_rows(int v);
@@ -305,6 +305,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_nw4")) { g_gemm_nw4 = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_k16")) { g_gemm_k16 = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }

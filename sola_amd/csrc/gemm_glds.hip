@@ -80,6 +80,106 @@ __device__ __forceinline__ int conv_tap_bits(int t0, int T_in) {
     return bits;
 }
 
+// Epilogue of the one-tile-per-block kernels: shared by the 32-deep and the 16-deep (two blocks per CU) k-loops.
+template <int MI, int WAVES_N>
+__device__ __forceinline__ void glds_tile_epilogue(const GldsArgs& a, const GemmProblem& pr, f32x16 (&acc)[MI][2], char* lds, int wave, int lane,
+                                                   int wr, int wc, int m0, int n0) {
+    // ---- epilogue: the accumulators (one column per lane, 16 scattered rows) go through this wave's 16 KiB of the
+    //      now idle stage buffers, 64 rows at a time, and leave as whole 16-byte row pieces (16 lanes cover one 256-byte
+    //      row segment) instead of 64 strided dword stores per lane.  Bias, output scale and the residual are applied on
+    //      the way out.
+    if (a.ablate & 4) return;
+    const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
+    float* tile = reinterpret_cast<float*>(lds) + wave * (64 * 64);  // [64 rows][64 cols] f32 (256-B rows: b32 writes and b128 reads are conflict-free)
+    const int col_l = lane & 31, row_l = (lane >> 5) << 2;
+    const int c4 = lane & 15;    // 16-byte column piece
+    const int rsub = lane >> 4;  // 4 rows per pass
+    const int n = n0 + wc * 64 + c4 * 4;
+    const bool vec_ok = (a.ldc & 3) == 0 && n + 3 < a.N && (!pr.R || a.r_sp16 || (a.ldr & 3) == 0);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pr.bias) {
+        const float bsc = a.bias_scale_dev ? *a.bias_scale_dev : 1.f;
+        bv.x = n < a.N ? pr.bias[n] * bsc : 0.f;
+        bv.y = n + 1 < a.N ? pr.bias[n + 1] * bsc : 0.f;
+        bv.z = n + 2 < a.N ? pr.bias[n + 2] * bsc : 0.f;
+        bv.w = n + 3 < a.N ? pr.bias[n + 3] * bsc : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < MI / 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                    const int col = j * 32 + col_l;
+                    tile[row * 64 + col] = acc[h * 2 + i][j][r];
+                }
+        __syncthreads();
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 4 + rsub;
+            const int m = m0 + wr * MI * 32 + h * 64 + row;
+            const float4 t = *reinterpret_cast<const float4*>(&tile[row * 64 + c4 * 4]);
+            if (m >= a.M) continue;
+            float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
+            if (pr.R) {
+                if (a.r_f16) {
+                    const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) v[e] += (float)rb[e];
+                } else if (a.r_sp16) {
+                    // 4 consecutive columns sit in one 8-wide block: hi[4] and lo[4] are two aligned 8-byte loads
+                    const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
+                    if (n + 3 < a.N) {
+                        const half4 hh = *reinterpret_cast<const half4*>(rb), ll = *reinterpret_cast<const half4*>(rb + 8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)hh[e] + (float)ll[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < a.N) v[e] += (float)rb[e] + (float)rb[8 + e];
+                    }
+                } else if (vec_ok) {
+                    const float4 rv = *reinterpret_cast<const float4*>(pr.R + (long long)m * a.ldr + n);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) v[e] += pr.R[(long long)m * a.ldr + n + e];
+                }
+            }
+            if (a.c_f16) {
+                if (n >= a.N) continue;  // N % 4 == 0: the four columns are in range together
+                half4 hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * a.ldc + n) = hh;
+                guard_sp16x4(a.guard, v);
+            } else if (a.c_sp16) {
+                if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
+                // 4 consecutive columns of one 8-wide block: hi[4] and lo[4] leave as two aligned 8-byte stores
+                _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
+                half4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
+                *reinterpret_cast<half4*>(cb) = hh;
+                *reinterpret_cast<half4*>(cb + 8) = ll;
+                guard_sp16x4(a.guard, v);
+            } else if (vec_ok) {
+                *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < a.N) pr.C[(long long)m * a.ldc + n + e] = v[e];
+            }
+        }
+        if (h + 1 < MI / 2) __syncthreads();  // this wave's reads of the staging rows are done before they are rewritten
+    }
+}
+
 // PURE = plain f16 operands (GemmDesc::arith 2): the same 128-byte tile rows now hold 64 consecutive halfs instead of 32
 // (hi, lo) pairs, so nothing about the DMA, the swizzle or the fragment reads changes - a "hi" chunk is simply halfs
 // 16j..16j+7 of the row and the "lo" chunk halfs 16j+8..16j+15 - and a product is hi*hi + lo*lo (two consecutive k-chunks,
@@ -274,100 +374,216 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_split_glds_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA of the last iterations must not land in the epilogue's staging
     __syncthreads();
 
-    // ---- epilogue: the accumulators (one column per lane, 16 scattered rows) go through this wave's 16 KiB of the
-    //      now idle stage buffers, 64 rows at a time, and leave as whole 16-byte row pieces (16 lanes cover one 256-byte
-    //      row segment) instead of 64 strided dword stores per lane.  Bias, output scale and the residual are applied on
-    //      the way out.
-    if (a.ablate & 4) return;
-    const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
-    float* tile = reinterpret_cast<float*>(lds) + wave * (64 * 64);  // [64 rows][64 cols] f32 (256-B rows: b32 writes and b128 reads are conflict-free)
-    const int col_l = lane & 31, row_l = (lane >> 5) << 2;
-    const int c4 = lane & 15;    // 16-byte column piece
-    const int rsub = lane >> 4;  // 4 rows per pass
-    const int n = n0 + wc * 64 + c4 * 4;
-    const bool vec_ok = (a.ldc & 3) == 0 && n + 3 < a.N && (!pr.R || a.r_sp16 || (a.ldr & 3) == 0);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pr.bias) {
-        const float bsc = a.bias_scale_dev ? *a.bias_scale_dev : 1.f;
-        bv.x = n < a.N ? pr.bias[n] * bsc : 0.f;
-        bv.y = n + 1 < a.N ? pr.bias[n + 1] * bsc : 0.f;
-        bv.z = n + 2 < a.N ? pr.bias[n + 2] * bsc : 0.f;
-        bv.w = n + 3 < a.N ? pr.bias[n + 3] * bsc : 0.f;
+    glds_tile_epilogue<MI, WAVES_N>(a, pr, acc, lds, wave, lane, wr, wc, m0, n0);
+}
+
+
+// ---- 16-deep k-tiles, two blocks per CU (experiment, sola_tune "gemm_k16") ------------------------------------------
+// What the persistent kernel cannot hide is its epilogue: one block owns the CU, so while its eight waves drain a tile the
+// matrix pipes idle.  Here a block is FOUR waves (one per SIMD) on a 256x128 tile with the same 128x64 wave tiles, and its
+// LDS is small enough for TWO blocks per CU (3 stages x 24 KiB): the second block's k-loop runs under the first one's
+// epilogue and prologue, and in the loop the two blocks give every SIMD its two waves back.  That needs k-tiles of 16:
+//   * tile rows are 64 bytes (4 chunks of 16 B: hi/lo of two 8-wide k-blocks), a 1-KiB DMA piece is 16 rows; the chunk
+//     swizzle key is (row >> 2) & 3 (16 consecutive rows x one logical chunk = 16 distinct slots of the 256-byte bank line);
+//   * one k-tile is ONE MFMA batch (24 MFMAs, 16 with plain 16-bit operands); the next tile's 12 fragment reads go behind
+//     its first MFMA and the 6 DMA pieces of the tile three ahead are spread over the rest;
+//   * three stages: tile kt+1 is read, kt+2 is landing, kt+3 is issued into the stage tile kt's fragments came from (every
+//     wave has them in registers behind the barrier).  One barrier per k-tile; the DMA has two batches to land.
+template <bool CONV, int PURE = 0>
+__global__ __launch_bounds__(256, 2) void gemm_nt_split_glds_k16_kernel(const GldsArgs a) {
+    constexpr int MI = 4, WAVES_N = 2, NWAVE = 4;
+    constexpr int GBM = 256, GBN = 128, KB = 16, RB = 64;
+    constexpr int STAGES = 3, STAGE_BYTES = (GBM + GBN) * RB;
+    constexpr int APW = GBM / 16 / NWAVE, WPW = GBN / 16 / NWAVE;  // 16-row DMA pieces per wave per k-tile
+    static_assert(NWAVE * 64 * 64 * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit in the stage buffers");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const GemmProblem pr = a.p[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    int rt, ct;
+    {
+        const int bid = blockIdx.x;
+        if (a.xcd_remap) {
+            const int x = bid & 7, j = bid >> 3;
+            rt = x + 8 * (j / a.tiles_n);
+            ct = j % a.tiles_n;
+        } else {
+            rt = bid / a.tiles_n;
+            ct = bid % a.tiles_n;
+        }
+    }
+    const int m0 = rt * GBM, n0 = ct * GBN;
+
+    // DMA coordinates: lane -> (row = piece * 16 + lane / 4, physical chunk = lane % 4)
+    const int lrow = lane >> 2, chunk = lane & 3;
+    const char* a_ptr[APW];
+    const char* w_ptr[WPW];
+    int a_t0[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int r = (wave * APW + i) * 16 + lrow;
+        const int col_bytes = (chunk ^ ((r >> 2) & 3)) * 16;
+        const int m = min(m0 + r, a.M - 1);
+        if (CONV) {
+            if (a.rowmap) {
+                const int2 rm = a.rowmap[m];
+                a_t0[i] = rm.y;
+                a_ptr[i] = reinterpret_cast<const char*>(pr.A) + (long long)rm.x * a.Cin * 4 + col_bytes;
+            } else {
+                const int rr = m / a.T_out, to = m - rr * a.T_out;
+                const int t0 = to * a.stride - a.pad;
+                a_t0[i] = conv_tap_bits(t0, a.T_in);
+                a_ptr[i] = reinterpret_cast<const char*>(pr.A) + ((long long)rr * a.T_in + t0) * a.Cin * 4 + col_bytes;
+            }
+        } else {
+            a_t0[i] = 0;
+            a_ptr[i] = reinterpret_cast<const char*>(pr.A + (long long)m * a.lda) + col_bytes;
+        }
     }
 #pragma unroll
-    for (int h = 0; h < MI / 2; ++h) {
+    for (int i = 0; i < WPW; ++i) {
+        const int r = (wave * WPW + i) * 16 + lrow;
+        const int n = min(n0 + r, a.N - 1);
+        w_ptr[i] = reinterpret_cast<const char*>(pr.W + (long long)n * a.K) + (chunk ^ ((r >> 2) & 3)) * 16;
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int nk = a.K / KB;
+    int conv_kk = 0, conv_c = 0;
+    int dma_kt = 0;
+
+    auto issue = [&](int stage) {  // k-tiles in increasing order, one per call; past the last one the pointers stop (see the kernel above)
+        char* sbase = lds + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < APW; ++i) {
+            const char* src = a_ptr[i];
+            if (CONV) src = ((a_t0[i] >> conv_kk) & 1) ? src : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)w_ptr[i], (lptr_t)(sbase + GBM * RB + (wave * WPW + i) * 1024), 16, 0, 0);
+        }
+        const bool more = dma_kt + 1 < nk;
+        const int adv = more ? KB * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_ptr[i] += adv;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) w_ptr[i] += adv;
+        if (CONV) {
+            conv_c += more ? KB : 0;
+            const bool wrap = conv_c == a.Cin;
+            conv_c = wrap ? 0 : conv_c;
+            conv_kk += wrap ? 1 : 0;
+        }
+        ++dma_kt;
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5, key = (lane >> 2) & 3;  // the key is the same for all of a lane's rows (they differ by multiples of 32)
+    const int a_frag = (wr * MI * 32 + fr) * RB, w_frag = GBM * RB + (wc * 64 + fr) * RB;
+    const int hi_off = ((fh * 2) ^ key) << 4, lo_off = hi_off ^ 16;
+
+    // The fragment reads are inline asm: in front of a compiler-visible LDS read the waitcnt pass puts vmcnt(0) (LDS-DMA pieces are in
+    // flight, and it cannot tell the stages apart), which would cut the DMA's two batches of cover to none.  land() is their wait: it
+    // names the fragments as in/out operands, so every use of them is ordered behind it.
+    struct Frags { half8 ah[MI], al[MI], bh[2], bl[2]; };
+    const unsigned a_hi = (unsigned)(a_frag + hi_off), a_lo = (unsigned)(a_frag + lo_off);
+    const unsigned w_hi = (unsigned)(w_frag + hi_off), w_lo = (unsigned)(w_frag + lo_off);
+#define K16_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+    auto load_frags = [&](int stage, Frags& f) {
+        const unsigned sb = (unsigned)(uintptr_t)(lptr_t)lds + (unsigned)(stage * STAGE_BYTES);
+        const unsigned wh = sb + w_hi, wl = sb + w_lo, ah = sb + a_hi, al = sb + a_lo;
+        K16_RD(f.bh[0], wh, 0);
+        K16_RD(f.bl[0], wl, 0);
+        K16_RD(f.bh[1], wh, 2048);
+        K16_RD(f.bl[1], wl, 2048);
+        K16_RD(f.ah[0], ah, 0);
+        K16_RD(f.al[0], al, 0);
+        K16_RD(f.ah[1], ah, 2048);
+        K16_RD(f.al[1], al, 2048);
+        K16_RD(f.ah[2], ah, 4096);
+        K16_RD(f.al[2], al, 4096);
+        K16_RD(f.ah[3], ah, 6144);
+        K16_RD(f.al[3], al, 6144);
+    };
+#undef K16_RD
+    static_assert(MI == 4 && 32 * RB == 2048, "the offsets above");
+    auto land = [&](Frags& f, auto vm) {  // the DMA of the next k-tile and this wave's fragment reads are complete
+        asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)"
+                     : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.ah[2]), "+v"(f.ah[3]), "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.al[2]), "+v"(f.al[3]),
+                       "+v"(f.bh[0]), "+v"(f.bh[1]), "+v"(f.bl[0]), "+v"(f.bl[1])
+                     : "n"(decltype(vm)::value)
+                     : "memory");
+    };
+    auto mfma1 = [&](const Frags& f, int i, int j, int which) {
+        if constexpr (PURE == 2) {
+            if (which == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+        } else if constexpr (PURE == 1) {
+            if (which == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        } else {
+            if (which == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+            else if (which == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    constexpr int PER = PURE ? 2 : 3;  // MFMAs per accumulator and k-tile, in the order lo terms first (as in the kernels above)
+    auto mfmas_rest = [&](const Frags& f) {  // everything but (0, 0, term 0), which the step issues in front of the fragment reads
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                    const int col = j * 32 + col_l;
-                    tile[row * 64 + col] = acc[h * 2 + i][j][r];
-                }
-        __syncthreads();
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int row = pass * 4 + rsub;
-            const int m = m0 + wr * MI * 32 + h * 64 + row;
-            const float4 t = *reinterpret_cast<const float4*>(&tile[row * 64 + c4 * 4]);
-            if (m >= a.M) continue;
-            float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
-            if (pr.R) {
-                if (a.r_f16) {
-                    const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n;
+                for (int w = 0; w < PER; ++w)
+                    if (i || j || w) mfma1(f, i, j, w);
+    };
+
+    constexpr int NMF = PER * 2 * MI;
+    constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");  // k-tile 0 is the oldest third of what is in flight
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    load_frags(0, f0);
+    int s0 = 0;  // stage of k-tile kt (whose fragments are in registers): it takes the DMA of k-tile kt + 3
+    auto step = [&](Frags& cur, Frags& nx) {
+        land(cur, std::integral_constant<int, NDMA>());  // k-tile kt+1 has landed (kt+2 may still be in flight); cur is in registers
+        __builtin_amdgcn_s_barrier();                    // ... for every wave, and nobody reads stage s0 any more
+        __builtin_amdgcn_sched_barrier(0);
+        const int s1 = s0 == 2 ? 0 : s0 + 1;
+        mfma1(cur, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(s1, nx);  // behind the first MFMA: a batch to land
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s0);
+        mfmas_rest(cur);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < a.N) v[e] += (float)rb[e];
-                } else if (a.r_sp16) {
-                    // 4 consecutive columns sit in one 8-wide block: hi[4] and lo[4] are two aligned 8-byte loads
-                    const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
-                    if (n + 3 < a.N) {
-                        const half4 hh = *reinterpret_cast<const half4*>(rb), ll = *reinterpret_cast<const half4*>(rb + 8);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)hh[e] + (float)ll[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < a.N) v[e] += (float)rb[e] + (float)rb[8 + e];
-                    }
-                } else if (vec_ok) {
-                    const float4 rv = *reinterpret_cast<const float4*>(pr.R + (long long)m * a.ldr + n);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < a.N) v[e] += pr.R[(long long)m * a.ldr + n + e];
-                }
-            }
-            if (a.c_f16) {
-                if (n >= a.N) continue;  // N % 4 == 0: the four columns are in range together
-                half4 hh;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * a.ldc + n) = hh;
-                guard_sp16x4(a.guard, v);
-            } else if (a.c_sp16) {
-                if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
-                // 4 consecutive columns of one 8-wide block: hi[4] and lo[4] leave as two aligned 8-byte stores
-                _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * a.ldc + (n & ~7)) + (n & 4);
-                half4 hh, ll;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { _Float16 h1, l1; split_f16(v[e], h1, l1); hh[e] = h1; ll[e] = l1; }
-                *reinterpret_cast<half4*>(cb) = hh;
-                *reinterpret_cast<half4*>(cb + 8) = ll;
-                guard_sp16x4(a.guard, v);
-            } else if (vec_ok) {
-                *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < a.N) pr.C[(long long)m * a.ldc + n + e] = v[e];
-            }
+        for (int g = 0; g < NDMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
-        if (h + 1 < MI / 2) __syncthreads();  // this wave's reads of the staging rows are done before they are rewritten
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        s0 = s1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {  // K is a multiple of 32: an even number of 16-deep k-tiles
+        step(f0, f1);
+        step(f1, f0);
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the surplus DMA and fragment reads of the last iteration must not reach the epilogue's staging
+    __syncthreads();
+
+    glds_tile_epilogue<MI, WAVES_N>(a, pr, acc, lds, wave, lane, wr, wc, m0, n0);
 }
 
 
@@ -1308,8 +1524,26 @@ int g_gemm_gn_fuse = 0;
 void sola_gemm_set_gn_fuse(int v) { g_gemm_gn_fuse = v; }
 int g_gemm_pp = 0;  // experiment (sola_tune "gemm_pp"): 1 = ping-pong kernel where it applies
 int g_gemm_nw4 = 0;  // experiment (sola_tune "gemm_nw4"): plain f32-output launches on 256x128 tiles with four waves, one per SIMD
+int g_gemm_k16 = 0;  // experiment (sola_tune "gemm_k16"): 256x128 tiles, 16-deep k-tiles, two four-wave blocks per CU
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
+
+template <bool CONV, int PURE>
+static int launch_k16(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+    a.tiles_m = (M + 255) / 256;
+    a.tiles_n = (N + 127) / 128;
+    a.xcd_remap = (a.tiles_m % 8 == 0) ? 1 : 0;
+    constexpr size_t lds = (size_t)3 * (256 + 128) * 64;
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_k16_kernel<CONV, PURE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done(dev);
+    }
+    hipLaunchKernelGGL((gemm_nt_split_glds_k16_kernel<CONV, PURE>), dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
@@ -1420,6 +1654,7 @@ static int launch_shape_pure(GldsArgs& a, int shape, int M, int N, int nprob, hi
 template <bool CONV>
 static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
     if (a.ksplit > 1) return launch_persist<CONV>(a, M, N, nprob, s);
+    if (shape == 4 && g_gemm_k16 && !a.gn_gamma) return launch_k16<CONV, 0>(a, M, N, nprob, s);
     if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV)) return launch_persist<CONV>(a, M, N, nprob, s);
     if (shape == 4) return launch_glds<4, 2, 4, CONV>(a, M, N, nprob, s);
     return launch_glds<2, 2, 2, CONV>(a, M, N, nprob, s);

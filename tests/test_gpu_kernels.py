@@ -243,6 +243,46 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
         _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 0), "sola_tune")
 
 
+def test_experimental_k16_gemm_is_bit_identical():
+    """sola_tune "gemm_k16" (256x128 tiles, 16-deep k-tiles in 64-byte LDS rows, three stages, TWO four-wave blocks per CU so that one
+    block's epilogue runs under the other's k-loop - DESIGN.md Appendix A): same fragments and accumulation order as the default
+    kernels, so the same bits - over residual / output formats, ragged M and N edges, the shortest k-loops, and a whole
+    default-precision forward (implicit-im2col conv GEMMs included)."""
+    from sola_amd import _lib, synth
+    from sola_amd.module import LanguageAlignedTrackSelectionModule
+    lib = _lib.lib()
+    torch.manual_seed(5)
+    try:
+        _lib.check(lib.sola_tune(b"gemm_glds", 4), "tune")
+        for (M, N, K, res, osp) in [(16384, 1024, 1024, 0, 0), (16384, 1024, 1024, 1, 0), (16384, 1024, 768, 1, 1), (16384 - 77, 1024, 512, 1, 0),
+                                    (16384, 1024 - 8, 256, 0, 1), (32768, 512, 32, 0, 0), (32768, 512, 96, 1, 1)]:
+            a = ops.cast_sp16(torch.randn(M, K, device="cuda")); w = ops.cast_sp16(torch.randn(N, K, device="cuda") * 0.03, 64.0)
+            b = torch.randn(N, device="cuda"); r = ops.cast_sp16(torch.randn(M, N, device="cuda")) if res else None
+            outs = []
+            for on in (0, 1):
+                _lib.check(lib.sola_tune(b"gemm_k16", on), "tune")
+                outs.append(ops.gemm_nt_split(a, w, b, r, True, 1 / 64, bool(osp)).clone())
+            assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (M, N, K, res, osp)
+        _lib.check(lib.sola_tune(b"gemm_glds", 3), "tune")
+        cfg = synth.DEFAULT_MODEL_CFG
+        sd = synth.make_state_dict(cfg, 42)
+        m = LanguageAlignedTrackSelectionModule(cfg)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        m = m.cuda().eval()
+        inp = synth.make_inputs(cfg, 16, 64, 32, 16, 0)
+        ot, lt = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
+        got = []
+        for on in (0, 1):
+            _lib.check(lib.sola_tune(b"gemm_k16", on), "tune")
+            with torch.no_grad():
+                sm, st = m(ot, lt)
+            got.append((sm.clone(), st.clone()))
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    finally:
+        _lib.check(lib.sola_tune(b"gemm_k16", 0), "tune")
+        _lib.check(lib.sola_tune(b"gemm_glds", 3), "tune")
+
+
 @pytest.mark.parametrize("key", ["gemm_nw4", "gemm_pp"])
 @pytest.mark.parametrize("out_split", [False, True])
 def test_experimental_four_wave_gemm_kernels_are_bit_identical(key, out_split):

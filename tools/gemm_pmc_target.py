@@ -10,6 +10,7 @@ _lib.lib().sola_tune(b"gemm_glds", v)
 import os
 _lib.lib().sola_tune(b"gemm_ablate", int(os.environ.get("SOLA_ABLATE", "0")))
 _lib.lib().sola_tune(b"gemm_persist", int(os.environ.get("SOLA_PERSIST", "1")))
+_lib.lib().sola_tune(b"gemm_k16", int(os.environ.get("SOLA_K16", "0")))
 if os.environ.get("SOLA_NORES"): r = None
 for _ in range(5): ops.gemm_nt_split(a, w, b, r, True, 1 / 64)
 torch.cuda.synchronize()
