@@ -329,6 +329,12 @@ int sola_gemm_tn(const float* dev_a, int lda, const float* dev_b, int ldb, float
 size_t sola_gemm_tn_split_scratch_bytes(int M, int N, int K);
 int sola_gemm_tn_split(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, int M, int N, int K,
                        void* dev_scratch, size_t scratch_bytes, void* stream);
+/* The same weight gradient on plain 16-bit operands (fmt 1 = f16, 2 = bfloat16: training with 16-bit GEMM operands, and the dW
+ * products of the default split-f16 step), ONE MFMA per product.  With N % 256 == 0 and K % 256 == 0 no transposed copy is made: the
+ * operands are cast row-major and the kernel transposes between LDS and the matrix pipe (ds_read_b64_tr_b16; sola_tune "train_tn_tr"
+ * 0 = the transposed-copy route for every shape).  Scratch as for sola_gemm_tn_split. */
+int sola_gemm_tn_f16(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, int M, int N, int K, int fmt,
+                     void* dev_scratch, size_t scratch_bytes, void* stream);
 int sola_conv1d_cl_backward(const float* dev_x, const float* dev_wstd, const float* dev_dy, float* dev_dx,
                             float* dev_dwstd, float* dev_dbias, int R, int T_in, int cin, int cout, int k, int stride,
                             int pad, void* dev_scratch, size_t scratch_bytes, void* stream);
@@ -428,6 +434,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * stores, 16 = without its LDS transpose;
  * "gemm_nw4", "gemm_pp": experimental four-wave shapes of the persistent split-f16 GEMM (256x128 tiles, one wave per SIMD; gemm_pp with
  * two accumulator sets and the epilogue drained under the next tile), bit-identical to the default, 0 (default) = off;
+ * "train_tn_tr": 1 (default) = weight gradients on 16-bit operands whose N and K are multiples of 256 read ROW-MAJOR casts and
+ * transpose in the LDS read (no transposed copies), 0 = always the transposing casts + NT GEMM;
  * "gemm_k16": experimental one-tile-per-block shape of the split-f16 GEMM - 256x128 tiles, 16-deep k-tiles, two four-wave blocks per
  * CU (one block's epilogue under the other's k-loop); bit-identical to the default, 7-20 % slower, 0 = off;
  * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose

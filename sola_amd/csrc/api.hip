@@ -260,7 +260,7 @@ extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
 void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
-extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16;
+extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
 void sola_set_train_split_min_rows(int v);
@@ -306,6 +306,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_nw4")) { g_gemm_nw4 = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_k16")) { g_gemm_k16 = value; return SOLA_OK; }
+    if (!strcmp(key, "train_tn_tr")) { g_train_tn_tr = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }
@@ -747,6 +748,14 @@ extern "C" int sola_gemm_nt(const float* a, int lda, const float* w, const float
     return launch_gemm(gd, as_stream(stream_));
 }
 
+extern "C" int sola_gemm_tn_f16(const float* a, int lda, const float* b, int ldb, float* cmat, int M, int N, int K, int fmt, void* scratch,
+                                size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(a && b && cmat && scratch && (fmt == 1 || fmt == 2), "gemm_tn_f16: null argument or fmt %d", fmt);
+    GemmTnSplitDesc d{};
+    d.A[0] = a; d.B[0] = b; d.C[0] = cmat; d.nprob = 1; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.pure = fmt;
+    d.scratch = static_cast<float*>(scratch); d.scratch_bytes = scratch_bytes;
+    return launch_gemm_tn_split(d, as_stream(stream_));
+}
 extern "C" size_t sola_gemm_tn_scratch_bytes(int M, int N, int K) { return gemm_tn_scratch_bytes(M, N, K); }
 extern "C" size_t sola_gemm_tn_split_scratch_bytes(int M, int N, int K) { return gemm_tn_split_supported(M, N, K) ? gemm_tn_split_scratch_bytes(M, N, K, 1) : 0; }
 extern "C" int sola_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* cmat, int M, int N, int K, void* scratch,

@@ -437,6 +437,24 @@ void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_splitk_tiles = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
+int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
+                         const float* scale_dev, hipStream_t s) {
+    SOLA_ARG(part && ksplit >= 1 && nprob >= 1 && nprob <= 3 && N % 4 == 0 && ldc % 4 == 0, "splitk_reduce: ksplit %d nprob %d N %d", ksplit, nprob, N);
+    GemmArgs a{};
+    for (int j = 0; j < 3; ++j) {
+        a.p[j] = GemmProblem{};
+        a.p[j].C = C[j < nprob ? j : 0];
+        a.p[j].scale_dev = scale_dev;
+    }
+    a.M = M; a.N = N; a.ldc = ldc;
+    a.out_scale = 1.f; a.out_scale_dev = out_scale_dev;
+    a.ksplit = ksplit; a.part = const_cast<float*>(part);
+    const long long quads = (long long)M * (N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256), 1, nprob), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s);
 int gemm_split_glds_shape(const GemmDesc& d);  // 4 = 256x256 blocks, 1 = 128x128
 

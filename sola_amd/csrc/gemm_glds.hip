@@ -29,6 +29,7 @@
 // tried and dropped: a 256x128 / 3-stage shape (DMA two tiles ahead: no faster, latency was not the bound) and
 // sched_group_barrier interleaving of fragment reads (+2-5 % on 64x64 wave tiles only, subsumed by this schedule).
 #include "kernels.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -583,6 +584,228 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_glds_k16_kernel(const Gl
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the surplus DMA and fragment reads of the last iteration must not reach the epilogue's staging
     __syncthreads();
 
+    glds_tile_epilogue<MI, WAVES_N>(a, pr, acc, lds, wave, lane, wr, wc, m0, n0);
+}
+
+
+// ---- weight gradients without transposed copies: dW[n][k] = sum_m dY[m][n] X[m][k] on ROW-MAJOR 16-bit operands -------------------
+// The reduction runs over the rows of both operands.  gemm_tn_split.hip's first route writes both matrices transposed (a streaming
+// pass of its own per operand, 12 % of a ragged training step) and runs the NT kernel above; this kernel reads the row-major 16-bit
+// casts the step has anyway (dY's is the dX GEMM's operand, X's the forward GEMM's) and transposes on the way from LDS to the
+// matrix pipe with gfx950's ds_read_b64_tr_b16: a k-tile is 64 rows x 256 columns of each operand (512-byte rows, two rows per 1-KiB
+// DMA piece), and a 4 (rows) x 16 (columns) block read by sixteen lanes - each supplying the address of one 8-byte piece - comes
+// back with lane j holding column j's four row values, i.e. half of a 32x32x16 MFMA operand.  The 16-byte chunks of a row are
+// XOR-swizzled by 4 * (row & 3): the eight rows one instruction touches (r..r+3 and r+8..r+11, 64 bytes each) then spread over all
+// sixteen 16-byte slots of the 256-byte bank line, two each - the minimum for a 512-byte read.
+// Same block shape, stages, halves and accumulator layout as the 256x256 NT kernel; split over the reduction like its ksplit mode:
+// work item = (tile, row range), partial sums to `part` for gemm.hip's ordered reduce.  Rows beyond M read the zero page.
+struct TnTrArgs {
+    GldsArgs e;  // the epilogue's view: M x N = the dW tile grid (N_out x K_out), ldc, part, ksplit, tiles_m / tiles_n
+    const _Float16* A[3];  // dY as 16-bit rows [Mred][lda]
+    const _Float16* B[3];  // X as 16-bit rows [Mred][ldb]
+    long long lda, ldb;    // halfs
+    int Mred, kper, nkt;   // rows of the reduction; 64-row k-tiles per range / in total
+};
+
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+template <int BF>
+__global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
+    constexpr int MI = 4, WAVES_N = 4, NWAVE = 8, KT = 64;
+    constexpr int OPB = KT * 512, STAGE_BYTES = 2 * OPB;  // one operand's k-tile, one stage (A then B)
+    constexpr int PPW = KT / 2 / NWAVE;                   // two-row DMA pieces per wave, operand and k-tile
+    static_assert(NWAVE * 64 * 64 * 4 <= 2 * STAGE_BYTES, "epilogue staging must fit in the stage buffers");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const GldsArgs& a = t.e;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int tiles = a.tiles_m * a.tiles_n;
+    int range, tile;
+    {   // consecutive block ids go to different XCDs: the tiles of one row range (they share its rows) stay on one XCD's L2
+        const int bid = blockIdx.x;
+        if ((a.ksplit & 7) == 0) {
+            const int x = bid & 7, q = bid >> 3;
+            range = x + 8 * (q / tiles);
+            tile = q % tiles;
+        } else {
+            range = bid / tiles;
+            tile = bid % tiles;
+        }
+    }
+    const int m0 = (tile / a.tiles_n) * 256, n0 = (tile % a.tiles_n) * 256;  // origin of the dW tile: row (dY column), column (X column)
+    const int kt0 = range * t.kper;
+    const int nk = min(t.nkt, kt0 + t.kper) - kt0;
+    const long long mstart = (long long)kt0 * KT;
+
+    // DMA coordinates: piece P = wave * PPW + i holds rows 2P, 2P+1 (lane / 32) of the k-tile; row & 3 = 2 * (i & 1) + lane / 32, so the
+    // swizzled source column is the same for pieces i and i + 2 (four rows apart): one pointer per parity and operand
+    const int prow = lane >> 5, pch = lane & 31;
+    const _Float16* Ab = t.A[blockIdx.z];
+    const _Float16* Bb = t.B[blockIdx.z];
+    const int row0 = wave * PPW * 2 + prow;
+    const char* a_ptr[2];
+    const char* b_ptr[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = row0 + 2 * e;
+        const int logical = pch ^ (4 * (row & 3));
+        a_ptr[e] = reinterpret_cast<const char*>(Ab + (mstart + row) * t.lda + m0 + logical * 8);
+        b_ptr[e] = reinterpret_cast<const char*>(Bb + (mstart + row) * t.ldb + n0 + logical * 8);
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int rem0 = (int)min((long long)t.Mred - mstart, 1LL << 30);
+    int rem_a = rem0, rem_b = rem0;  // rows left from the start of the next k-tile to issue, per operand
+    const long long a_adv = (long long)KT * t.lda * 2, b_adv = (long long)KT * t.ldb * 2;
+    const long long a_r4 = 4 * t.lda * 2, b_r4 = 4 * t.ldb * 2;  // four rows further
+    // one operand's k-tile per call, in order; surplus calls behind the range fill a stage nobody reads; rows beyond M read zeros
+    auto issue_a = [&](int stage) {
+        char* sbase = lds + stage * STAGE_BYTES + wave * PPW * 1024;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const char* src = a_ptr[i & 1] + (i >> 1) * a_r4;
+            __builtin_amdgcn_global_load_lds((gptr_t)(row0 + 2 * i < rem_a ? src : zero), (lptr_t)(sbase + i * 1024), 16, 0, 0);
+        }
+        a_ptr[0] += a_adv;
+        a_ptr[1] += a_adv;
+        rem_a -= KT;
+    };
+    auto issue_b = [&](int stage) {
+        char* sbase = lds + stage * STAGE_BYTES + OPB + wave * PPW * 1024;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const char* src = b_ptr[i & 1] + (i >> 1) * b_r4;
+            __builtin_amdgcn_global_load_lds((gptr_t)(row0 + 2 * i < rem_b ? src : zero), (lptr_t)(sbase + i * 1024), 16, 0, 0);
+        }
+        b_ptr[0] += b_adv;
+        b_ptr[1] += b_adv;
+        rem_b -= KT;
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing fragment reads: sixteen-lane group (g2, g1) = (k half of the operand, 16-column half of the 32-wide fragment);
+    // lane j of the group addresses row j >> 2 of the group's four rows, 8-byte piece j & 3 of its 16 columns
+    const int j16 = lane & 15, g1 = (lane >> 4) & 1, g2 = lane >> 5;
+    const int q = j16 >> 2;  // = row & 3 of every row this lane addresses: the swizzle key
+    const int lane_off = (8 * g2 + q) * 512 + (2 * g1 + ((j16 & 3) >> 1)) * 16 + 8 * (j16 & 1);
+    int a_off[MI], b_off[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a_off[i] = lane_off + ((wr * 4 + (i ^ q)) << 6);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_off[j] = OPB + lane_off + (((wc * 2 + j) ^ q) << 6);
+
+    // The fragment reads are inline asm (as in the k16 kernel above): in front of a compiler-visible LDS read the waitcnt pass puts
+    // vmcnt(0) while LDS-DMA pieces are in flight, which would expose the whole DMA latency once per k-tile.  land() is their wait.
+    struct Frags { half8 a[MI], b[2]; };  // one 16-row step
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+#define TR_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#define TR_STEP(f, base, OFF)                                                                                                        \
+    {                                                                                                                                \
+        short4v l_, h_;                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                              \
+            TR_RD(l_, base + b_off[j], OFF); TR_RD(h_, base + b_off[j], OFF + 2048);                                                 \
+            f.b[j] = __builtin_bit_cast(half8, __builtin_shufflevector(l_, h_, 0, 1, 2, 3, 4, 5, 6, 7));                             \
+        }                                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                                             \
+            TR_RD(l_, base + a_off[i], OFF); TR_RD(h_, base + a_off[i], OFF + 2048);                                                 \
+            f.a[i] = __builtin_bit_cast(half8, __builtin_shufflevector(l_, h_, 0, 1, 2, 3, 4, 5, 6, 7));                             \
+        }                                                                                                                            \
+    }
+    auto land = [&](Frags& f) {  // this wave's fragment reads are complete; every use of f is ordered behind this
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1])::"memory");
+    };
+    auto mfma1 = [&](const Frags& f, int i, int j) {
+        if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+    auto mfmas_rest = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (i || j) mfma1(f, i, j);
+    };
+    constexpr int NMF = 2 * MI;  // MFMAs of one 16-row step
+    auto spread_dma = [&]() {    // the PPW DMA pieces of one operand, one behind each of the step's following MFMAs
+#pragma unroll
+        for (int g = 0; g < PPW; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - PPW, 0);
+    };
+
+    // A k-tile is four 16-row steps on two alternating fragment sets; the next step's reads go right behind a step's first MFMA.
+    // ONE barrier per k-tile, in front of its last step: by then every wave has its last fragments of the stage in registers (so the
+    // stage can take the DMA of k-tile kt+2: A during that last step, B during the next k-tile's first) and k-tile kt+1 has had three
+    // steps to land, so its first fragments are fetched under the last step's MFMAs.
+    issue_a(0);
+    issue_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    Frags f0, f1;
+    TR_STEP(f0, lds0, 0);
+    issue_a(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned cur = lds0 + (unsigned)(stage * STAGE_BYTES), nxt = lds0 + (unsigned)((stage ^ 1) * STAGE_BYTES);
+        // step 0
+        land(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma1(f0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        TR_STEP(f1, cur, 8192);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(stage ^ 1);
+        mfmas_rest(f0);
+        spread_dma();
+        __builtin_amdgcn_sched_barrier(0);
+        // step 1
+        land(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma1(f1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        TR_STEP(f0, cur, 16384);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas_rest(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        // step 2
+        land(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma1(f0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        TR_STEP(f1, cur, 24576);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas_rest(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        // step 3, behind the barrier
+        land(f1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // k-tile kt+1 has landed
+        __builtin_amdgcn_s_barrier();                      // ... for every wave, and nobody reads this stage any more
+        __builtin_amdgcn_sched_barrier(0);
+        mfma1(f1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        TR_STEP(f0, nxt, 0);  // past the last k-tile this reads stale LDS and is never used
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(stage);
+        mfmas_rest(f1);
+        spread_dma();
+        __builtin_amdgcn_sched_barrier(0);
+        stage ^= 1;
+    }
+#undef TR_STEP
+#undef TR_RD
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the surplus DMA and reads must not reach the epilogue's staging
+    __syncthreads();
+
+    GemmProblem pr{};
+    pr.C = a.part + ((long long)blockIdx.z * a.ksplit + range) * a.M * a.N;
     glds_tile_epilogue<MI, WAVES_N>(a, pr, acc, lds, wave, lane, wr, wc, m0, n0);
 }
 
@@ -1713,4 +1936,59 @@ int gemm_split_glds_shape(const GemmDesc& d) {
     const long long t = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nprob;
     const long long rounds = (t + 255) / 256;
     return (t >= 256 && 4 * t >= 3 * rounds * 256) ? 4 : 1;
+}
+
+// ---- weight gradients on row-major 16-bit operands (gemm_tn_tr_kernel) -------------------------------------------------------------
+int g_train_tn_tr = 1;  // sola_tune "train_tn_tr": 0 = always the transposed-copy route of gemm_tn_split.hip
+bool gemm_tn_tr_supported(int M, int N, int K, long long lda, long long ldb) {
+    return g_train_tn_tr && N % 256 == 0 && K % 256 == 0 && lda % 8 == 0 && ldb % 8 == 0 && M >= 128;
+}
+// the number of row ranges: about one work item per CU, every range at least two 64-row k-tiles, at most max_ranges (the scratch)
+void gemm_tn_tr_geometry(int M, int N, int K, int nprob, int max_ranges, int& ksplit, int& kper) {
+    const int nkt = (M + 63) / 64;
+    const int tiles = (N / 256) * (K / 256) * nprob;
+    int ks = std::max(1, sola_cu_count() / std::max(1, tiles));
+    ks = std::min(ks, std::min(max_ranges, std::max(1, nkt / 2)));
+    if (ks >= 8) ks &= ~7;  // whole XCD groups (the kernel's work-item order)
+    kper = (nkt + ks - 1) / ks;
+    ksplit = (nkt + kper - 1) / kper;  // no empty range
+}
+int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s) {
+    SOLA_ARG(d.nprob >= 1 && d.nprob <= 3 && d.part && d.ksplit >= 1 && d.kper >= 1, "gemm_tn_tr: nprob %d ksplit %d", d.nprob, d.ksplit);
+    SOLA_ARG(gemm_tn_tr_supported(d.M, d.N, d.K, d.lda, d.ldb), "gemm_tn_tr: M=%d N=%d K=%d", d.M, d.N, d.K);
+    SolaProfScope prof(SOLA_PROF_GEMM_SPLIT256, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
+                       2.0 * d.nprob * ((double)d.M * d.N + (double)d.M * d.K) + 4.0 * d.nprob * d.ksplit * (double)d.N * d.K);
+    TnTrArgs t{};
+    GldsArgs& a = t.e;
+    a.M = d.N; a.N = d.K; a.ldc = d.K; a.K = 0;
+    a.tiles_m = d.N / 256; a.tiles_n = d.K / 256;
+    a.out_scale = 1.f;
+    a.ksplit = d.ksplit; a.part = d.part; a.nprob = d.nprob;
+    a.ablate = g_gemm_ablate;
+    for (int j = 0; j < 3; ++j) {
+        t.A[j] = static_cast<const _Float16*>(d.A[j < d.nprob ? j : 0]);
+        t.B[j] = static_cast<const _Float16*>(d.B[j < d.nprob ? j : 0]);
+        SOLA_ARG((reinterpret_cast<uintptr_t>(t.A[j]) & 15) == 0 && (reinterpret_cast<uintptr_t>(t.B[j]) & 15) == 0, "gemm_tn_tr: operands must be 16-byte aligned");
+    }
+    t.lda = d.lda; t.ldb = d.ldb; t.Mred = d.M; t.kper = d.kper; t.nkt = (d.M + 63) / 64;
+    SOLA_ARG((long long)d.ksplit * d.kper >= t.nkt && (long long)(d.ksplit - 1) * d.kper < t.nkt, "gemm_tn_tr: ranges %d x %d k-tiles do not cover %d", d.ksplit, d.kper, t.nkt);
+    constexpr size_t lds = 2 * 2 * 64 * 512;
+    static DeviceOnce once_f, once_b;
+    int dev;
+    const dim3 grid(a.tiles_m * a.tiles_n * d.ksplit, 1, d.nprob);
+    if (d.bf16) {
+        if (once_b.needed(&dev)) {
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            once_b.done(dev);
+        }
+        hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(512), lds, s, t);
+    } else {
+        if (once_f.needed(&dev)) {
+            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            once_f.done(dev);
+        }
+        hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, grid, dim3(512), lds, s, t);
+    }
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
 }

@@ -262,6 +262,45 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         for (int j = 0; j < d.nprob; ++j) SOLA_TRY(launch_amax_accumulate(d.A[j], d.lda, d.M, d.N, scal, s));
     }
     const bool rm = gemm_tn_split_writes_rm(d);
+    if (pure && !d.conv && d.ldb % 4 == 0 && gemm_tn_tr_supported(d.M, d.N, d.K, 8, 8)) {
+        // 16-bit operands, linear layers: NO transposed copies.  gemm_glds.hip's gemm_tn_tr_kernel takes the ROW-MAJOR casts - dY's is the
+        // dX GEMM's operand anyway - and transposes between LDS and the matrix pipe (ds_read_b64_tr_b16).
+        const int bf = pure_fmt == 2 ? 1 : 0;
+        GemmTnTrDesc t{};
+        t.nprob = d.nprob; t.M = d.M; t.N = d.N; t.K = d.K; t.bf16 = bf;
+        _Float16* a16 = reinterpret_cast<_Float16*>(at);
+        _Float16* x16 = reinterpret_cast<_Float16*>(xt);
+        const bool rm16 = rm && !d.rm_split;  // the caller's row-major copy has the operand's format: cast once, into it
+        int n_x = 0;
+        for (int j = 0; j < d.nprob; ++j) {
+            const long long off = d.A[j] - d.A[0];
+            if (rm16) {
+                _Float16* dst = reinterpret_cast<_Float16*>(d.a_rm) + off;
+                SOLA_TRY(launch_cast_f16_scaled(d.A[j], d.lda, dst, d.a_rm_ld, d.M, d.N, scal, s, bf));
+                t.A[j] = dst;
+            } else {
+                _Float16* dst = a16 + (size_t)j * d.M * d.N;
+                SOLA_TRY(launch_cast_f16_scaled(d.A[j], d.lda, dst, d.N, d.M, d.N, scal, s, bf));
+                t.A[j] = dst;
+                if (rm) SOLA_TRY(launch_cast_sp16_scaled(d.A[j], d.lda, d.a_rm + off, d.a_rm_ld, d.M, d.N, scal, s));  // the dX GEMM keeps split-f16 operands
+            }
+            t.B[j] = nullptr;
+            for (int e = 0; e < j; ++e)
+                if (d.B[e] == d.B[j]) t.B[j] = t.B[e];
+            if (!t.B[j]) {
+                _Float16* dst = x16 + (size_t)n_x++ * d.M * d.K;
+                if (d.scal_b) SOLA_TRY(launch_cast_f16_scaled(d.B[j], d.ldb, dst, d.K, d.M, d.K, d.scal_b, s, bf));
+                else SOLA_TRY(launch_cast_f16(d.B[j], d.ldb, dst, d.K, d.M, d.K, 1.f, nullptr, s, 13, nullptr, bf));
+                t.B[j] = dst;
+            }
+        }
+        t.lda = rm16 ? d.a_rm_ld : d.N;
+        t.ldb = d.K;
+        gemm_tn_tr_geometry(d.M, d.N, d.K, d.nprob, ks, t.ksplit, t.kper);
+        t.part = slabs;
+        SOLA_TRY(launch_gemm_tn_tr(t, s));
+        return launch_splitk_reduce(slabs, t.ksplit, d.nprob, d.C, d.N, d.K, d.K, scal + 1, d.scal_b ? d.scal_b + 1 : nullptr, s);
+    }
     const float* xt_of[3] = {nullptr, nullptr, nullptr};
     int n_xt = 0;
     for (int j = 0; j < d.nprob; ++j) {

@@ -104,6 +104,24 @@ size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob);
 int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s);
 size_t gemm_tn_scratch_bytes(int M, int N, int K);
 int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s);
+// dW_j[n][k] = sum_m A_j[m][n] B_j[m][k] on ROW-MAJOR 16-bit operands (gemm_glds.hip's gemm_tn_tr_kernel: transposing LDS reads,
+// no transposed copies): raw partial sums of `ksplit` row ranges of `kper` 64-row k-tiles into part[(j * ksplit + range)][N][K]
+struct GemmTnTrDesc {
+    const void* A[3];  // 16-bit rows [M][lda], 16-byte aligned
+    const void* B[3];  // 16-bit rows [M][ldb]
+    int nprob, M, N, K;
+    long long lda, ldb;  // halfs, multiples of 8
+    int bf16;
+    int ksplit, kper;    // gemm_tn_tr_geometry()
+    float* part;
+};
+bool gemm_tn_tr_supported(int M, int N, int K, long long lda, long long ldb);
+void gemm_tn_tr_geometry(int M, int N, int K, int nprob, int max_ranges, int& ksplit, int& kper);
+int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s);
+// C_j = out_scale_dev * scale_dev_j * (sum of the ksplit partial sums, in index order): gemm.hip's second split-K pass on its own
+int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
+                         const float* scale_dev, hipStream_t s);
+
 int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off, hipStream_t s);
 size_t colsum_scratch_bytes(int segments, int seg_rows, int cols);
 int launch_colsum(const float* in, float* out, int segments, int seg_rows, int cols, int ld, float scale, int accumulate,

@@ -201,6 +201,21 @@ def gemm_tn_split(a, b):
     return out
 
 
+def gemm_tn_f16(a, b, bf16=False):
+    """a [M,N]^T @ b [M,K] -> [N,K] on plain f16 / bf16 operands (one MFMA per product; for N, K multiples of 256 without any
+    transposed copy: row-major casts + transposing LDS reads)."""
+    require_cuda(a, b)
+    a, b = _f32c(a), _f32c(b)
+    M, N = a.shape
+    K = b.shape[1]
+    out = torch.empty((N, K), device=a.device, dtype=torch.float32)
+    nb = lib().sola_gemm_tn_split_scratch_bytes(M, N, K)
+    scratch = torch.empty(nb, device=a.device, dtype=torch.uint8)
+    check(lib().sola_gemm_tn_f16(ptr(a), N, ptr(b), K, ptr(out), M, N, K, 2 if bf16 else 1, ptr(scratch), nb, current_stream(a.device)),
+          "sola_gemm_tn_f16")
+    return out
+
+
 def ws_backward(weight, dwstd):
     """Backward of ``ws_standardize``: weight [cout,cin,k], dwstd [cout,k*cin] -> dweight [cout,cin,k]."""
     require_cuda(weight, dwstd)

@@ -243,6 +243,31 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
         _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 0), "sola_tune")
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("shape", [(16384, 1024, 1024), (5321, 256, 512), (200, 256, 256), (8192, 768, 256), (4096, 264, 256)])
+def test_weight_gradient_gemm_on_row_major_16bit_operands(shape, bf16):
+    """sola_gemm_tn_f16: dW = dY^T X on f16 / bf16 operands.  For N, K multiples of 256 the operands are cast ROW-MAJOR and
+    gemm_tn_tr_kernel transposes them in the LDS read (ds_read_b64_tr_b16) - no transposed copies; other shapes (264
+    here) and sola_tune train_tn_tr 0 take the transposing casts + NT GEMM.  Both against the f64 product of the same rounded
+    operands (the f32 accumulation order is all that differs), ragged row counts included (rows beyond M read the zero page)."""
+    from sola_amd import _lib
+    M, N, K = shape
+    torch.manual_seed(11)
+    a = torch.randn(M, N, device="cuda") * 1e-4
+    b = torch.randn(M, K, device="cuda")
+    dt = torch.bfloat16 if bf16 else torch.float16
+    sc = 2.0 ** (13 - int(torch.floor(torch.log2(a.abs().max())).item()))  # cast.hip's data-dependent power-of-two scale
+    ref = ((a * sc).to(dt).double().t() @ b.to(dt).double()) / sc
+    try:
+        for route in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"train_tn_tr", route), "tune")
+            out = ops.gemm_tn_f16(a, b, bf16)
+            err = float((out.double() - ref).abs().max() / ref.abs().max())
+            assert err < 5e-6, (route, err)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
+
+
 def test_experimental_k16_gemm_is_bit_identical():
     """sola_tune "gemm_k16" (256x128 tiles, 16-deep k-tiles in 64-byte LDS rows, three stages, TWO four-wave blocks per CU so that one
     block's epilogue runs under the other's k-loop - DESIGN.md Appendix A): same fragments and accumulation order as the default
