@@ -601,9 +601,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_glds_k16_kernel(const Gl
 // work item = (tile, row range), partial sums to `part` for gemm.hip's ordered reduce.  Rows beyond M read the zero page.
 struct TnTrArgs {
     GldsArgs e;  // the epilogue's view: M x N = the dW tile grid (N_out x K_out), ldc, part, ksplit, tiles_m / tiles_n
-    const _Float16* A[3];  // dY as 16-bit rows [Mred][lda]
-    const _Float16* B[3];  // X as 16-bit rows [Mred][ldb]
-    long long lda, ldb;    // halfs
+    const char* A[3];      // dY as 16-bit rows [Mred][lda]
+    const char* B[3];      // X as 16-bit rows [Mred][ldb]
+    long long lda, ldb;    // row pitch in BYTES
+    int a_sp, b_sp;        // 1: the operand is a SPLIT-f16 row-major matrix (8-value blocks [hi8 | lo8], 4 bytes per value) and the
+                           // kernel takes its hi halves - exactly the plain f16 cast of the same values - by fetching every other
+                           // 16-byte chunk (the split-f16 step's dX operand doubles as the dW operand: no second cast of dY)
     int Mred, kper, nkt;   // rows of the reduction; 64-row k-tiles per range / in total
 };
 
@@ -640,8 +643,8 @@ __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
     // DMA coordinates: piece P = wave * PPW + i holds rows 2P, 2P+1 (lane / 32) of the k-tile; row & 3 = 2 * (i & 1) + lane / 32, so the
     // swizzled source column is the same for pieces i and i + 2 (four rows apart): one pointer per parity and operand
     const int prow = lane >> 5, pch = lane & 31;
-    const _Float16* Ab = t.A[blockIdx.z];
-    const _Float16* Bb = t.B[blockIdx.z];
+    const char* Ab = t.A[blockIdx.z];
+    const char* Bb = t.B[blockIdx.z];
     const int row0 = wave * PPW * 2 + prow;
     const char* a_ptr[2];
     const char* b_ptr[2];
@@ -649,14 +652,14 @@ __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
     for (int e = 0; e < 2; ++e) {
         const int row = row0 + 2 * e;
         const int logical = pch ^ (4 * (row & 3));
-        a_ptr[e] = reinterpret_cast<const char*>(Ab + (mstart + row) * t.lda + m0 + logical * 8);
-        b_ptr[e] = reinterpret_cast<const char*>(Bb + (mstart + row) * t.ldb + n0 + logical * 8);
+        a_ptr[e] = Ab + (mstart + row) * t.lda + ((long long)(m0 * 2 + logical * 16) << t.a_sp);
+        b_ptr[e] = Bb + (mstart + row) * t.ldb + ((long long)(n0 * 2 + logical * 16) << t.b_sp);
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     const int rem0 = (int)min((long long)t.Mred - mstart, 1LL << 30);
     int rem_a = rem0, rem_b = rem0;  // rows left from the start of the next k-tile to issue, per operand
-    const long long a_adv = (long long)KT * t.lda * 2, b_adv = (long long)KT * t.ldb * 2;
-    const long long a_r4 = 4 * t.lda * 2, b_r4 = 4 * t.ldb * 2;  // four rows further
+    const long long a_adv = (long long)KT * t.lda, b_adv = (long long)KT * t.ldb;
+    const long long a_r4 = 4 * t.lda, b_r4 = 4 * t.ldb;  // four rows further
     // one operand's k-tile per call, in order; surplus calls behind the range fill a stage nobody reads; rows beyond M read zeros
     auto issue_a = [&](int stage) {
         char* sbase = lds + stage * STAGE_BYTES + wave * PPW * 1024;
@@ -1966,11 +1969,12 @@ int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s) {
     a.ksplit = d.ksplit; a.part = d.part; a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
     for (int j = 0; j < 3; ++j) {
-        t.A[j] = static_cast<const _Float16*>(d.A[j < d.nprob ? j : 0]);
-        t.B[j] = static_cast<const _Float16*>(d.B[j < d.nprob ? j : 0]);
+        t.A[j] = static_cast<const char*>(d.A[j < d.nprob ? j : 0]);
+        t.B[j] = static_cast<const char*>(d.B[j < d.nprob ? j : 0]);
         SOLA_ARG((reinterpret_cast<uintptr_t>(t.A[j]) & 15) == 0 && (reinterpret_cast<uintptr_t>(t.B[j]) & 15) == 0, "gemm_tn_tr: operands must be 16-byte aligned");
     }
-    t.lda = d.lda; t.ldb = d.ldb; t.Mred = d.M; t.kper = d.kper; t.nkt = (d.M + 63) / 64;
+    t.a_sp = d.a_split ? 1 : 0; t.b_sp = d.b_split ? 1 : 0;
+    t.lda = d.lda * (d.a_split ? 4 : 2); t.ldb = d.ldb * (d.b_split ? 4 : 2); t.Mred = d.M; t.kper = d.kper; t.nkt = (d.M + 63) / 64;
     SOLA_ARG((long long)d.ksplit * d.kper >= t.nkt && (long long)(d.ksplit - 1) * d.kper < t.nkt, "gemm_tn_tr: ranges %d x %d k-tiles do not cover %d", d.ksplit, d.kper, t.nkt);
     constexpr size_t lds = 2 * 2 * 64 * 512;
     static DeviceOnce once_f, once_b;

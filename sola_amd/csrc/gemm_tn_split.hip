@@ -271,6 +271,8 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         _Float16* a16 = reinterpret_cast<_Float16*>(at);
         _Float16* x16 = reinterpret_cast<_Float16*>(xt);
         const bool rm16 = rm && !d.rm_split;  // the caller's row-major copy has the operand's format: cast once, into it
+        // ... or it is the split-f16 copy (the dX GEMM of a split-f16 step): its hi halves ARE the plain f16 cast, the kernel fetches them
+        const bool rmsp = rm && d.rm_split && !bf;
         int n_x = 0;
         for (int j = 0; j < d.nprob; ++j) {
             const long long off = d.A[j] - d.A[0];
@@ -278,6 +280,9 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
                 _Float16* dst = reinterpret_cast<_Float16*>(d.a_rm) + off;
                 SOLA_TRY(launch_cast_f16_scaled(d.A[j], d.lda, dst, d.a_rm_ld, d.M, d.N, scal, s, bf));
                 t.A[j] = dst;
+            } else if (rmsp) {
+                SOLA_TRY(launch_cast_sp16_scaled(d.A[j], d.lda, d.a_rm + off, d.a_rm_ld, d.M, d.N, scal, s));
+                t.A[j] = d.a_rm + off;
             } else {
                 _Float16* dst = a16 + (size_t)j * d.M * d.N;
                 SOLA_TRY(launch_cast_f16_scaled(d.A[j], d.lda, dst, d.N, d.M, d.N, scal, s, bf));
@@ -294,7 +299,8 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
                 t.B[j] = dst;
             }
         }
-        t.lda = rm16 ? d.a_rm_ld : d.N;
+        t.lda = (rm16 || rmsp) ? d.a_rm_ld : d.N;
+        t.a_split = rmsp ? 1 : 0;
         t.ldb = d.K;
         gemm_tn_tr_geometry(d.M, d.N, d.K, d.nprob, ks, t.ksplit, t.kper);
         t.part = slabs;

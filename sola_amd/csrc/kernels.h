@@ -110,7 +110,9 @@ struct GemmTnTrDesc {
     const void* A[3];  // 16-bit rows [M][lda], 16-byte aligned
     const void* B[3];  // 16-bit rows [M][ldb]
     int nprob, M, N, K;
-    long long lda, ldb;  // halfs, multiples of 8
+    long long lda, ldb;  // row pitch in VALUES, multiples of 8
+    int a_split, b_split;  // the operand is a split-f16 row-major matrix ([hi8 | lo8] blocks, 4 bytes per value; f16 only): its hi halves
+                           // are the plain f16 cast of the same values and are what the kernel fetches
     int bf16;
     int ksplit, kper;    // gemm_tn_tr_geometry()
     float* part;
