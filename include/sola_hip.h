@@ -335,6 +335,11 @@ int sola_gemm_tn_split(const float* dev_a, int lda, const float* dev_b, int ldb,
  * 0 = the transposed-copy route for every shape).  Scratch as for sola_gemm_tn_split. */
 int sola_gemm_tn_f16(const float* dev_a, int lda, const float* dev_b, int ldb, float* dev_c, int M, int N, int K, int fmt,
                      void* dev_scratch, size_t scratch_bytes, void* stream);
+/* dW_std[cout][k*cin] of the channels-last conv (module/ws.py:14-22) on 16-bit operands: dy [R*T_out][cout], x [R*T_in][cin].  With
+ * cout % 256 == 0 and cin % 256 == 0 the conv input is cast ONCE, row-major, and the kernel gathers the taps (implicit im2col) in its
+ * LDS-DMA addresses; else one transposing cast per tap.  Scratch: sola_gemm_tn_split_scratch_bytes(R*T_out, cout, k*cin). */
+int sola_conv1d_cl_wgrad_f16(const float* dev_x, const float* dev_dy, float* dev_dwstd, int R, int T_in, int cin, int cout, int k,
+                             int stride, int pad, int fmt, void* dev_scratch, size_t scratch_bytes, void* stream);
 int sola_conv1d_cl_backward(const float* dev_x, const float* dev_wstd, const float* dev_dy, float* dev_dx,
                             float* dev_dwstd, float* dev_dbias, int R, int T_in, int cin, int cout, int k, int stride,
                             int pad, void* dev_scratch, size_t scratch_bytes, void* stream);

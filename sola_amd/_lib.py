@@ -103,6 +103,7 @@ SIGNATURES = {
     "sola_gemm_tn_split_scratch_bytes": (_sz, [_i, _i, _i]),
     "sola_gemm_tn_split": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sola_gemm_tn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sola_conv1d_cl_wgrad_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sola_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sola_conv1d_cl_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sola_conv1d_cl_backward_split_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

@@ -756,6 +756,17 @@ extern "C" int sola_gemm_tn_f16(const float* a, int lda, const float* b, int ldb
     d.scratch = static_cast<float*>(scratch); d.scratch_bytes = scratch_bytes;
     return launch_gemm_tn_split(d, as_stream(stream_));
 }
+extern "C" int sola_conv1d_cl_wgrad_f16(const float* x, const float* dy, float* dwstd, int R, int T_in, int cin, int cout, int k, int stride,
+                                        int pad, int fmt, void* scratch, size_t scratch_bytes, void* stream_) {
+    SOLA_ARG(x && dy && dwstd && scratch && (fmt == 1 || fmt == 2) && R > 0 && T_in > 0 && k >= 1 && k <= 8 && stride >= 1, "conv1d_cl_wgrad_f16: bad argument");
+    const int T_out = (T_in + 2 * pad - k) / stride + 1;
+    SOLA_ARG(T_out > 0 && gemm_tn_split_supported(R * T_out, cout, k * cin), "conv1d_cl_wgrad_f16: R*T_out=%d cout=%d k*cin=%d", R * T_out, cout, k * cin);
+    GemmTnSplitDesc d{};
+    d.nprob = 1; d.A[0] = dy; d.B[0] = x; d.C[0] = dwstd; d.M = R * T_out; d.N = cout; d.K = k * cin; d.lda = cout; d.ldb = cin; d.pure = fmt;
+    d.conv = (k > 1 || stride > 1 || pad > 0) ? 1 : 0; d.T_in = T_in; d.T_out = T_out; d.stride = stride; d.pad = pad; d.Cin = cin;
+    d.scratch = static_cast<float*>(scratch); d.scratch_bytes = scratch_bytes;
+    return launch_gemm_tn_split(d, as_stream(stream_));
+}
 extern "C" size_t sola_gemm_tn_scratch_bytes(int M, int N, int K) { return gemm_tn_scratch_bytes(M, N, K); }
 extern "C" size_t sola_gemm_tn_split_scratch_bytes(int M, int N, int K) { return gemm_tn_split_supported(M, N, K) ? gemm_tn_split_scratch_bytes(M, N, K, 1) : 0; }
 extern "C" int sola_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* cmat, int M, int N, int K, void* scratch,

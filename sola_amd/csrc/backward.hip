@@ -506,7 +506,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
-            d.rowmap = rowmap;
+            d.rowmap = rowmap; d.B_rows = rows_in;
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
             if (scc) SOLA_TRY(bias_from_stats(0, g.cout, G(cp + ".bias")));

@@ -608,11 +608,17 @@ struct TnTrArgs {
                            // kernel takes its hi halves - exactly the plain f16 cast of the same values - by fetching every other
                            // 16-byte chunk (the split-f16 step's dX operand doubles as the dW operand: no second cast of dY)
     int Mred, kper, nkt;   // rows of the reduction; 64-row k-tiles per range / in total
+    // CONV kernels: B is the channels-last conv input [rows_in][Cin] and the product's column k = tap * Cin + ci (implicit im2col; a
+    // 256-column tile lies inside one tap: Cin % 256 == 0).  Reduction row m = (sequence r, output step to) reads source row
+    // r * T_in + to * stride + tap - pad, zeros outside [0, T_in); or, with rowmap (ragged batches), row rowmap[m].x + tap where bit
+    // `tap` of rowmap[m].y is set (GemmDesc::rowmap).
+    int Cin, T_in, T_out, stride, pad;
+    const int2* rowmap;
 };
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
-template <int BF>
+template <int BF, int CONV = 0>  // CONV: 0 = plain rows, 1 = conv taps by geometry, 2 = conv taps by rowmap
 __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
     constexpr int MI = 4, WAVES_N = 4, NWAVE = 8, KT = 64;
     constexpr int OPB = KT * 512, STAGE_BYTES = 2 * OPB;  // one operand's k-tile, one stage (A then B)
@@ -672,16 +678,63 @@ __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
         a_ptr[1] += a_adv;
         rem_a -= KT;
     };
+    // CONV: the tile's tap and first channel; per piece the (sequence, step) of its row (geometry) or the prefetched rowmap entry
+    const int tap = CONV ? n0 / t.Cin : 0;
+    const int bcol = CONV ? ((n0 - tap * t.Cin) * 2 + (pch ^ (4 * (row0 & 3))) * 16) : 0;       // even pieces; odd ones flip chunk bit 3
+    const int bcol_odd = CONV ? ((n0 - tap * t.Cin) * 2 + (pch ^ (4 * ((row0 + 2) & 3))) * 16) : 0;
+    int c_rr[PPW], c_to[PPW];
+    int2 c_rm[PPW];
+    const int q64 = CONV == 1 ? KT / t.T_out : 0, r64 = CONV == 1 ? KT % t.T_out : 0;
+    long long m_b = mstart;  // first row of the next B k-tile to issue
+    if constexpr (CONV == 1) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const long long m = mstart + row0 + 2 * i;
+            c_rr[i] = (int)(m / t.T_out);
+            c_to[i] = (int)(m - (long long)c_rr[i] * t.T_out);
+        }
+    }
+    if constexpr (CONV == 2) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) c_rm[i] = t.rowmap[min(mstart + row0 + 2 * i, (long long)t.Mred - 1)];
+    }
     auto issue_b = [&](int stage) {
         char* sbase = lds + stage * STAGE_BYTES + OPB + wave * PPW * 1024;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const char* src = b_ptr[i & 1] + (i >> 1) * b_r4;
-            __builtin_amdgcn_global_load_lds((gptr_t)(row0 + 2 * i < rem_b ? src : zero), (lptr_t)(sbase + i * 1024), 16, 0, 0);
+            const char* src;
+            bool ok = row0 + 2 * i < rem_b;
+            if constexpr (CONV == 0) {
+                src = b_ptr[i & 1] + (i >> 1) * b_r4;
+            } else {
+                long long srow;
+                if constexpr (CONV == 1) {
+                    const int ti = c_to[i] * t.stride + tap - t.pad;
+                    ok = ok && (unsigned)ti < (unsigned)t.T_in;
+                    srow = (long long)c_rr[i] * t.T_in + ti;
+                    c_rr[i] += q64;
+                    c_to[i] += r64;
+                    const bool wrap = c_to[i] >= t.T_out;
+                    c_to[i] -= wrap ? t.T_out : 0;
+                    c_rr[i] += wrap ? 1 : 0;
+                } else {
+                    ok = ok && ((c_rm[i].y >> tap) & 1);
+                    srow = (long long)c_rm[i].x + tap;
+                }
+                src = Bb + srow * t.ldb + ((i & 1) ? bcol_odd : bcol);
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zero), (lptr_t)(sbase + i * 1024), 16, 0, 0);
         }
-        b_ptr[0] += b_adv;
-        b_ptr[1] += b_adv;
+        if constexpr (CONV == 0) {
+            b_ptr[0] += b_adv;
+            b_ptr[1] += b_adv;
+        }
         rem_b -= KT;
+        if constexpr (CONV == 2) {  // the next k-tile's entries: a k-tile (and its barrier's vmcnt(0)) ahead of their use
+            m_b += KT;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) c_rm[i] = t.rowmap[min(m_b + row0 + 2 * i, (long long)t.Mred - 1)];
+        }
     };
 
     f32x16 acc[MI][2];
@@ -1977,22 +2030,25 @@ int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s) {
     t.lda = d.lda * (d.a_split ? 4 : 2); t.ldb = d.ldb * (d.b_split ? 4 : 2); t.Mred = d.M; t.kper = d.kper; t.nkt = (d.M + 63) / 64;
     SOLA_ARG((long long)d.ksplit * d.kper >= t.nkt && (long long)(d.ksplit - 1) * d.kper < t.nkt, "gemm_tn_tr: ranges %d x %d k-tiles do not cover %d", d.ksplit, d.kper, t.nkt);
     constexpr size_t lds = 2 * 2 * 64 * 512;
-    static DeviceOnce once_f, once_b;
+    t.Cin = d.Cin; t.T_in = d.T_in; t.T_out = d.T_out; t.stride = d.stride; t.pad = d.pad; t.rowmap = d.rowmap;
+    const int conv = !d.conv ? 0 : (d.rowmap ? 2 : 1);
+    SOLA_ARG(!conv || (d.Cin % 256 == 0 && d.K % d.Cin == 0 && d.K / d.Cin <= 8 && !d.b_split && (d.rowmap || (d.T_out > 0 && d.T_in > 0 && d.stride >= 1))),
+             "gemm_tn_tr: conv geometry Cin=%d K=%d", d.Cin, d.K);
+    if (conv) t.ldb = (long long)d.Cin * 2;
+    static DeviceOnce once[2][3];
     int dev;
     const dim3 grid(a.tiles_m * a.tiles_n * d.ksplit, 1, d.nprob);
-    if (d.bf16) {
-        if (once_b.needed(&dev)) {
-            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            once_b.done(dev);
-        }
-        hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(512), lds, s, t);
-    } else {
-        if (once_f.needed(&dev)) {
-            SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            once_f.done(dev);
-        }
-        hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, grid, dim3(512), lds, s, t);
+    const void* fn = nullptr;
+#define TN_TR_PICK(BFV, CV) if ((d.bf16 ? 1 : 0) == BFV && conv == CV) fn = reinterpret_cast<const void*>(&gemm_tn_tr_kernel<BFV, CV>);
+    TN_TR_PICK(0, 0) TN_TR_PICK(0, 1) TN_TR_PICK(0, 2) TN_TR_PICK(1, 0) TN_TR_PICK(1, 1) TN_TR_PICK(1, 2)
+#undef TN_TR_PICK
+    DeviceOnce& o = once[d.bf16 ? 1 : 0][conv];
+    if (o.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        o.done(dev);
     }
+    void* kargs[] = {&t};
+    SOLA_HIP(hipLaunchKernel(fn, grid, dim3(512), kargs, lds, s));
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

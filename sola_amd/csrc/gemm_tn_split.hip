@@ -262,7 +262,8 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         for (int j = 0; j < d.nprob; ++j) SOLA_TRY(launch_amax_accumulate(d.A[j], d.lda, d.M, d.N, scal, s));
     }
     const bool rm = gemm_tn_split_writes_rm(d);
-    if (pure && !d.conv && d.ldb % 4 == 0 && gemm_tn_tr_supported(d.M, d.N, d.K, 8, 8)) {
+    const long long conv_rows_in = !d.conv ? 0 : (d.rowmap ? d.B_rows : (long long)d.M / d.T_out * d.T_in);
+    if (pure && d.ldb % 4 == 0 && gemm_tn_tr_supported(d.M, d.N, d.K, 8, 8) && (!d.conv || (d.Cin % 256 == 0 && d.ldb == d.Cin && conv_rows_in > 0))) {
         // 16-bit operands, linear layers: NO transposed copies.  gemm_glds.hip's gemm_tn_tr_kernel takes the ROW-MAJOR casts - dY's is the
         // dX GEMM's operand anyway - and transposes between LDS and the matrix pipe (ds_read_b64_tr_b16).
         const int bf = pure_fmt == 2 ? 1 : 0;
@@ -293,15 +294,19 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             for (int e = 0; e < j; ++e)
                 if (d.B[e] == d.B[j]) t.B[j] = t.B[e];
             if (!t.B[j]) {
-                _Float16* dst = x16 + (size_t)n_x++ * d.M * d.K;
-                if (d.scal_b) SOLA_TRY(launch_cast_f16_scaled(d.B[j], d.ldb, dst, d.K, d.M, d.K, d.scal_b, s, bf));
-                else SOLA_TRY(launch_cast_f16(d.B[j], d.ldb, dst, d.K, d.M, d.K, 1.f, nullptr, s, 13, nullptr, bf));
+                // conv: ONE row-major cast of the conv input; the kernel gathers the taps (implicit im2col) in its DMA addresses
+                const long long b_rows = d.conv ? conv_rows_in : d.M;
+                const int b_cols = d.conv ? d.Cin : d.K;
+                _Float16* dst = x16 + (size_t)n_x++ * b_rows * b_cols;
+                if (d.scal_b) SOLA_TRY(launch_cast_f16_scaled(d.B[j], d.ldb, dst, b_cols, b_rows, b_cols, d.scal_b, s, bf));
+                else SOLA_TRY(launch_cast_f16(d.B[j], d.ldb, dst, b_cols, b_rows, b_cols, 1.f, nullptr, s, 13, nullptr, bf));
                 t.B[j] = dst;
             }
         }
         t.lda = (rm16 || rmsp) ? d.a_rm_ld : d.N;
         t.a_split = rmsp ? 1 : 0;
-        t.ldb = d.K;
+        t.ldb = d.conv ? d.Cin : d.K;
+        t.conv = d.conv; t.Cin = d.Cin; t.T_in = d.T_in; t.T_out = d.T_out; t.stride = d.stride; t.pad = d.pad; t.rowmap = d.rowmap;
         gemm_tn_tr_geometry(d.M, d.N, d.K, d.nprob, ks, t.ksplit, t.kper);
         t.part = slabs;
         SOLA_TRY(launch_gemm_tn_tr(t, s));

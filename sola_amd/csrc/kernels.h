@@ -90,6 +90,7 @@ struct GemmTnSplitDesc {
     float* scratch;
     size_t scratch_bytes;
     const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap
+    long long B_rows;    // conv = 1 with rowmap: rows of the conv input B (the geometry gives M / T_out * T_in otherwise); 0 = unknown
 };
 // in [rows][cols] f32 -> out [cols][ld_out] split-f16 (rows rows..ld_out zero-filled; ld_out % 128 == 0); scal: optional
 // device pair as for launch_cast_sp16_auto with scal[0] = max|in| already there
@@ -116,6 +117,10 @@ struct GemmTnTrDesc {
     int bf16;
     int ksplit, kper;    // gemm_tn_tr_geometry()
     float* part;
+    // conv = 1: B is the channels-last conv input [rows_in][Cin] as 16-bit rows, K = k * Cin (implicit im2col, Cin % 256 == 0); the
+    // geometry or the ragged rowmap as in GemmDesc
+    int conv, Cin, T_in, T_out, stride, pad;
+    const int2* rowmap;
 };
 bool gemm_tn_tr_supported(int M, int N, int K, long long lda, long long ldb);
 void gemm_tn_tr_geometry(int M, int N, int K, int nprob, int max_ranges, int& ksplit, int& kper);

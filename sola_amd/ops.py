@@ -216,6 +216,22 @@ def gemm_tn_f16(a, b, bf16=False):
     return out
 
 
+def conv1d_cl_wgrad_f16(x, dy, k, stride, pad, bf16=False):
+    """Weight gradient of ``conv1d_cl`` on f16 / bf16 operands: x [R,T,cin], dy [R,T_out,cout] -> dw_std [cout, k*cin]."""
+    require_cuda(x, dy)
+    x, dy = _f32c(x), _f32c(dy)
+    R, T, cin = x.shape
+    cout = dy.shape[2]
+    t_out = (T + 2 * pad - k) // stride + 1
+    assert dy.shape[1] == t_out
+    dw = torch.empty((cout, k * cin), device=x.device, dtype=torch.float32)
+    nb = lib().sola_gemm_tn_split_scratch_bytes(R * t_out, cout, k * cin)
+    scratch = torch.empty(nb, device=x.device, dtype=torch.uint8)
+    check(lib().sola_conv1d_cl_wgrad_f16(ptr(x), ptr(dy), ptr(dw), R, T, cin, cout, k, stride, pad, 2 if bf16 else 1, ptr(scratch), nb,
+                                         current_stream(x.device)), "sola_conv1d_cl_wgrad_f16")
+    return dw
+
+
 def ws_backward(weight, dwstd):
     """Backward of ``ws_standardize``: weight [cout,cin,k], dwstd [cout,k*cin] -> dweight [cout,cin,k]."""
     require_cuda(weight, dwstd)

@@ -268,6 +268,31 @@ def test_weight_gradient_gemm_on_row_major_16bit_operands(shape, bf16):
         _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
 
 
+@pytest.mark.parametrize("geom", [(512, 32, 256, 512, 3, 2, 1), (300, 16, 512, 512, 3, 2, 1), (1024, 4, 512, 1024, 3, 1, 1), (77, 9, 256, 256, 5, 1, 2)])
+def test_conv_weight_gradient_on_row_major_16bit_operands(geom):
+    """sola_conv1d_cl_wgrad_f16: the encoder convs' dW on f16 operands.  gemm_tn_tr_kernel gathers the taps (implicit im2col, zero
+    padding in time, strides) in its DMA addresses from ONE row-major cast of the conv input; sola_tune train_tn_tr 0 = one transposing
+    cast per tap + the NT GEMM.  Both against the f64 product of the same rounded operands over an explicit im2col."""
+    from sola_amd import _lib
+    R, T, cin, cout, k, stride, pad = geom
+    torch.manual_seed(13)
+    x = torch.randn(R, T, cin, device="cuda")
+    t_out = (T + 2 * pad - k) // stride + 1
+    dy = torch.randn(R, t_out, cout, device="cuda") * 1e-4
+    sc = 2.0 ** (13 - int(torch.floor(torch.log2(dy.abs().max())).item()))
+    xp = torch.nn.functional.pad(x.half().double(), (0, 0, pad, pad))
+    cols = torch.stack([xp[:, kk:kk + (t_out - 1) * stride + 1:stride, :] for kk in range(k)], dim=2).reshape(R * t_out, k * cin)
+    ref = ((dy * sc).half().double().reshape(R * t_out, cout).t() @ cols) / sc
+    try:
+        for route in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"train_tn_tr", route), "tune")
+            out = ops.conv1d_cl_wgrad_f16(x, dy, k, stride, pad)
+            err = float((out.double() - ref).abs().max() / ref.abs().max())
+            assert err < 5e-6, (route, err)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
+
+
 def test_experimental_k16_gemm_is_bit_identical():
     """sola_tune "gemm_k16" (256x128 tiles, 16-deep k-tiles in 64-byte LDS rows, three stages, TWO four-wave blocks per CU so that one
     block's epilogue runs under the other's k-loop - DESIGN.md Appendix A): same fragments and accumulation order as the default
