@@ -180,6 +180,7 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (!c) return SOLA_OK;
     if (c->ws_buf) (void)hipFree(c->ws_buf);
     if (c->ws16_buf) (void)hipFree(c->ws16_buf);
+    if (c->x16_arena) (void)hipFree(c->x16_arena);
     if (c->lin16_buf) (void)hipFree(c->lin16_buf);
     if (c->scal_buf) (void)hipFree(c->scal_buf);
     if (c->guard_host) (void)hipHostFree(c->guard_host);
@@ -260,7 +261,7 @@ extern "C" int sola_set_stage_dropout(float p, uint64_t seed) {
 void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
-extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr;
+extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr, g_train_x16_keep;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
 void sola_set_train_split_min_rows(int v);
@@ -307,6 +308,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_nw4")) { g_gemm_nw4 = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_k16")) { g_gemm_k16 = value; return SOLA_OK; }
     if (!strcmp(key, "train_tn_tr")) { g_train_tn_tr = value; return SOLA_OK; }
+    if (!strcmp(key, "train_x16_keep")) { g_train_x16_keep = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }

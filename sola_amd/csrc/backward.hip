@@ -258,7 +258,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.scal = sc; d.pure = pure ? 1 + bf : (dw16 ? 1 : 0); d.rm_split = dw16 ? 1 : 0;
             if (dy_rm_done && sc && g_bwd_dual_cast) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy; }
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
-            for (int j = 0; j < n; ++j) { d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW; }
+            for (int j = 0; j < n; ++j) {
+                d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW;
+                if (pure && ldx == k_in) d.B16[j] = c->x16_find(g[j].X, k_in, 1 + bf);
+            }
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             if (d.scratch_bytes >= gemm_tn_split_scratch_bytes(rows, n_out, k_in, n)) {
                 if (dy_rm_done) *dy_rm_done = gemm_tn_split_writes_rm(d);
@@ -507,6 +510,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.rowmap = rowmap; d.B_rows = rows_in;
+            if (pure && i > 0) d.B16[0] = c->x16_find(x_in, g.cin, 1 + bf);
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
             if (scc) SOLA_TRY(bias_from_stats(0, g.cout, G(cp + ".bias")));

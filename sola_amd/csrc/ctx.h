@@ -80,6 +80,26 @@ struct SolaCtx {
     bool lin16_dirty = true;  // split copies of the projection weights are stale
     float* ws16_buf = nullptr;
     float* lin16_buf = nullptr;
+    // 16-bit operand modes, training: the row-major casts of the forward's GEMM inputs are KEPT (one arena slot each instead of two
+    // shared buffers) and listed by their f32 source, so that the backward's weight-gradient products take them as their X operand
+    // instead of casting the same activations again (sola_tune "train_x16_keep").  The arena grows between steps to the last need.
+    struct X16Entry { const float* src; const void* p16; int cols; int fmt; };
+    std::vector<X16Entry> x16;
+    char* x16_arena = nullptr;
+    size_t x16_cap = 0, x16_used = 0, x16_need = 0;
+    void* x16_alloc(size_t bytes) {  // null = no room this step (the caller uses its shared buffer and lists nothing)
+        bytes = (bytes + 255) & ~(size_t)255;
+        x16_need += bytes;
+        if (x16_used + bytes > x16_cap) return nullptr;
+        void* r = x16_arena + x16_used;
+        x16_used += bytes;
+        return r;
+    }
+    const void* x16_find(const float* src, int cols, int fmt) const {
+        for (const X16Entry& e : x16)
+            if (e.src == src && e.cols == cols && e.fmt == fmt) return e.p16;
+        return nullptr;
+    }
     // Range handling of the split-f16 mode (device floats, ctx-owned): (max|x| bits, 1/scale) pairs of the data-dependent
     // power-of-two scales - [0] object tokens, [1] text ++ negative tokens, [2 + i] projection weight i (same index as
     // lin16_buf) - followed by the guard words: guard[0] is cleared by every inference forward and gets bit 0 from any kernel

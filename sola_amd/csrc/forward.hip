@@ -10,6 +10,7 @@
 
 int g_train_gn_cast = 1;  // sola_tune "train_gn_cast": 1 = a GroupNorm of the training forward also writes the operand cast of the GEMM behind it
 void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
+int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
 
@@ -196,6 +197,31 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     if (split) SOLA_TRY(sola_refresh_lin16(c, s));
     float* const sp_a = split ? buf("sp_a") : nullptr;
     float* const sp_b = split ? buf("sp_b") : nullptr;
+    // 16-bit operand modes: every fixed-scale operand cast gets its own slot of the ctx's arena and is listed by its f32 source - the
+    // backward's dW products read it instead of casting the activation again (ctx.h; data-dependent scales keep the shared buffers)
+    const bool keep16 = split && pure && g_train_x16_keep != 0;
+    c->x16.clear();
+    if (keep16) {
+        if (c->x16_need > c->x16_cap) {  // grow to what the last step asked for (+ 1/8: ragged batches differ from step to step)
+            SOLA_HIP(hipStreamSynchronize(s));
+            if (c->x16_arena) SOLA_HIP(hipFree(c->x16_arena));
+            c->x16_arena = nullptr;
+            c->x16_cap = 0;
+            const size_t want = c->x16_need + c->x16_need / 8;
+            if (hipMalloc(&c->x16_arena, want) == hipSuccess) c->x16_cap = want;
+            else (void)hipGetLastError();  // no room: this step and the following ones cast in the backward as before
+        }
+        c->x16_used = 0;
+        c->x16_need = 0;
+    }
+    auto slot16 = [&](int which, const float* src, long long rows, int cols) -> float* {  // the operand cast of `src` goes here
+        if (keep16)
+            if (void* q = c->x16_alloc((size_t)rows * cols * 2)) {
+                c->x16.push_back(SolaCtx::X16Entry{src, q, cols, 1 + bf});
+                return static_cast<float*>(q);
+            }
+        return which ? sp_b : sp_a;
+    };
 
     // a2: encoder (module/module.py:74-96,137-140)
     // Operand casts written by the PRODUCING GroupNorm (GroupNormDesc::y_cast; sola_tune "train_gn_cast" 0 = separate cast launches):
@@ -221,11 +247,15 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             if (i == 0) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip)
                 SOLA_TRY(cast_auto(x, g.cin, sp_a, level_rows(i), g.cin, c->scal_pair(0)));
                 gd.out_scale_dev = c->scal_pair(0) + 1;
+                gd.p[0].A = sp_a;
             } else if (pc_src[0] != x) {
-                SOLA_TRY(cast_fixed(x, g.cin, sp_a, level_rows(i), g.cin, 1.f));
+                float* dst = slot16(0, x, level_rows(i), g.cin);
+                SOLA_TRY(cast_fixed(x, g.cin, dst, level_rows(i), g.cin, 1.f));
+                gd.p[0].A = dst;
+            } else {
+                gd.p[0].A = pc_dst[0];
             }
             pc_src[0] = nullptr;
-            gd.p[0].A = sp_a;
             gd.p[0].W = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(c->ws16_buf) + c->ws_off[i]) : c->ws16_buf + c->ws_off[i];
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
         }
@@ -241,8 +271,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             if (rs) nd.units = rt.u_lvl[i + 1];
             if (train) nd.drop = c->enc_drop(i);
             if (gn_fmt && c->conv[i + 1].cin % 64 == 0) {  // conv i+1 takes the cast from here
-                nd.y_cast = sp_a; nd.cast_fmt = gn_fmt;
-                pc_src[0] = nd.y; pc_dst[0] = sp_a;
+                float* dst = slot16(0, nd.y, level_rows(i + 1), g.cout);
+                nd.y_cast = dst; nd.cast_fmt = gn_fmt;
+                pc_src[0] = nd.y; pc_dst[0] = dst;
             }
             SOLA_TRY(launch_group_norm(nd, s));
             x = buf("act" + std::to_string(i));
@@ -282,9 +313,12 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                 if (at < 0) {
                     at = nsrc++;
                     src[at] = as[j];
-                    if (pc_src[at] == as[j] && pc_dst[at] == dst[at]) {}  // the producing GroupNorm wrote this operand
+                    if (pc_src[at] == as[j]) dst[at] = pc_dst[at];  // the producing GroupNorm wrote this operand
                     else if (a_scal) SOLA_TRY(cast_auto(as[j], D, dst[at], rows, D, a_scal));
-                    else SOLA_TRY(cast_fixed(as[j], D, dst[at], rows, D, 1.f));
+                    else {
+                        dst[at] = slot16(at, as[j], rows, D);
+                        SOLA_TRY(cast_fixed(as[j], D, dst[at], rows, D, 1.f));
+                    }
                 }
                 gd.p[j].A = dst[at];
                 gd.p[j].W = lin16(attn, first_proj + j);
@@ -303,8 +337,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split) {
-            SOLA_TRY(cast_fixed(ao, D, sp_a, M, D, 1.f));
-            gd.p[0].A = sp_a; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
+            float* dst = slot16(0, ao, M, D);
+            SOLA_TRY(cast_fixed(ao, D, dst, M, D, 1.f));
+            gd.p[0].A = dst; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
         }
         return launch_gemm(gd, s);
@@ -317,11 +352,11 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         GroupNormDesc nd{};
         if (gn_fmt) {
             const float* nxt[2] = {next_src0, next_src1};
-            float* dsts[2] = {sp_a, sp_b};
+            const long long y_rows = std::max<long long>(M, text_rows);  // the norm's token rows, bounded from above
             for (int e = 0; e < 2; ++e) {
                 if (!nxt[e]) continue;
-                if (nxt[e] == y) { nd.y_cast = dsts[e]; pc_src[e] = y; pc_dst[e] = dsts[e]; }
-                else if (nxt[e] == y2) { nd.y2_cast = dsts[e]; pc_src[e] = y2; pc_dst[e] = dsts[e]; }
+                if (nxt[e] == y) { float* dst = slot16(e, y, y_rows, D); nd.y_cast = dst; pc_src[e] = y; pc_dst[e] = dst; }
+                else if (nxt[e] == y2) { float* dst = slot16(e, y2, y_rows, D); nd.y2_cast = dst; pc_src[e] = y2; pc_dst[e] = dst; }
             }
             nd.cast_fmt = gn_fmt;
         }

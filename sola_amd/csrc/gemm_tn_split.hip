@@ -293,6 +293,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             t.B[j] = nullptr;
             for (int e = 0; e < j; ++e)
                 if (d.B[e] == d.B[j]) t.B[j] = t.B[e];
+            if (!t.B[j] && d.B16[j] && !d.scal_b) t.B[j] = d.B16[j];  // the forward's operand cast of the same activation
             if (!t.B[j]) {
                 // conv: ONE row-major cast of the conv input; the kernel gathers the taps (implicit im2col) in its DMA addresses
                 const long long b_rows = d.conv ? conv_rows_in : d.M;

@@ -208,6 +208,28 @@ def test_mixed_batch_equals_one_sample_steps_full(full, precision):
     assert_grads_close(got, ref_sum, 5e-3 if precision == "f16x3" else 2e-3, f"vs one-sample steps ({precision})")
 
 
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, precision):
+    """As tests/test_gpu_backward.py's test of the same name, on a mixed-shape ragged batch (conv taps through the row maps): the
+    backward reading the forward's kept operand casts (sola_tune "train_x16_keep" 1) against casting again (0)."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    full.precision = precision
+    got = {}
+    try:
+        samples = [sample_inputs(cfg, N, T, L, 400 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
+        for keep in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"train_x16_keep", keep), "tune")
+            for _ in range(2):  # the arena is sized from the previous step's need: the second step reuses the casts
+                loss, g, _ = ragged_step(full, samples)
+            got[keep] = (g, loss)
+    finally:
+        full.precision = "f32"
+        _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
+    assert torch.equal(got[1][1], got[0][1])
+    bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
+    assert not bad, bad
+
+
 def test_full_gradient_norms_of_single_golden_samples(full_golden, full):
     """A ragged batch of ONE golden sample must reproduce the reference's per-parameter gradient norms (the ragged kernels
     alone, no summation over samples)."""
