@@ -199,7 +199,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     float* const sp_b = split ? buf("sp_b") : nullptr;
     // 16-bit operand modes: every fixed-scale operand cast gets its own slot of the ctx's arena and is listed by its f32 source - the
     // backward's dW products read it instead of casting the activation again (ctx.h; data-dependent scales keep the shared buffers)
-    const bool keep16 = split && pure && g_train_x16_keep != 0;
+    // (2: also the split pairs of the "f16x3" step, whose hi halves are the dW products' plain-f16 operands - measured neutral: the
+    // kernel then fetches every other 16-byte chunk and its DMA slows by what the saved casts gained; off by default)
+    const bool keep16 = split && (pure ? g_train_x16_keep != 0 : g_train_x16_keep == 2);
     c->x16.clear();
     if (keep16) {
         if (c->x16_need > c->x16_cap) {  // grow to what the last step asked for (+ 1/8: ragged batches differ from step to step)
@@ -216,8 +218,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     }
     auto slot16 = [&](int which, const float* src, long long rows, int cols) -> float* {  // the operand cast of `src` goes here
         if (keep16)
-            if (void* q = c->x16_alloc((size_t)rows * cols * 2)) {
-                c->x16.push_back(SolaCtx::X16Entry{src, q, cols, 1 + bf});
+            if (void* q = c->x16_alloc((size_t)rows * cols * (pure ? 2 : 4))) {
+                c->x16.push_back(SolaCtx::X16Entry{src, q, cols, pure ? 1 + bf : 0});
                 return static_cast<float*>(q);
             }
         return which ? sp_b : sp_a;

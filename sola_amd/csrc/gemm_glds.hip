@@ -680,8 +680,8 @@ __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
     };
     // CONV: the tile's tap and first channel; per piece the (sequence, step) of its row (geometry) or the prefetched rowmap entry
     const int tap = CONV ? n0 / t.Cin : 0;
-    const int bcol = CONV ? ((n0 - tap * t.Cin) * 2 + (pch ^ (4 * (row0 & 3))) * 16) : 0;       // even pieces; odd ones flip chunk bit 3
-    const int bcol_odd = CONV ? ((n0 - tap * t.Cin) * 2 + (pch ^ (4 * ((row0 + 2) & 3))) * 16) : 0;
+    const int bcol = CONV ? ((n0 - tap * t.Cin) * 2 + (pch ^ (4 * (row0 & 3))) * 16) << t.b_sp : 0;  // even pieces; odd ones flip chunk bit 3
+    const int bcol_odd = CONV ? ((n0 - tap * t.Cin) * 2 + (pch ^ (4 * ((row0 + 2) & 3))) * 16) << t.b_sp : 0;
     int c_rr[PPW], c_to[PPW];
     int2 c_rm[PPW];
     const int q64 = CONV == 1 ? KT / t.T_out : 0, r64 = CONV == 1 ? KT % t.T_out : 0;
@@ -2032,9 +2032,10 @@ int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s) {
     constexpr size_t lds = 2 * 2 * 64 * 512;
     t.Cin = d.Cin; t.T_in = d.T_in; t.T_out = d.T_out; t.stride = d.stride; t.pad = d.pad; t.rowmap = d.rowmap;
     const int conv = !d.conv ? 0 : (d.rowmap ? 2 : 1);
-    SOLA_ARG(!conv || (d.Cin % 256 == 0 && d.K % d.Cin == 0 && d.K / d.Cin <= 8 && !d.b_split && (d.rowmap || (d.T_out > 0 && d.T_in > 0 && d.stride >= 1))),
+    SOLA_ARG(!conv || (d.Cin % 256 == 0 && d.K % d.Cin == 0 && d.K / d.Cin <= 8 && (d.rowmap || (d.T_out > 0 && d.T_in > 0 && d.stride >= 1))),
              "gemm_tn_tr: conv geometry Cin=%d K=%d", d.Cin, d.K);
-    if (conv) t.ldb = (long long)d.Cin * 2;
+    SOLA_ARG(!(d.bf16 && (d.a_split || d.b_split)), "gemm_tn_tr: split-f16 operands are f16");
+    if (conv) t.ldb = (long long)d.Cin * (d.b_split ? 4 : 2);
     static DeviceOnce once[2][3];
     int dev;
     const dim3 grid(a.tiles_m * a.tiles_n * d.ksplit, 1, d.nprob);

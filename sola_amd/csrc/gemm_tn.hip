@@ -193,16 +193,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     const int r_end = min(seg_rows, r_begin + chunk_rows);
     // four independent partial sums, fixed combination order: a thread's loads pipeline instead of queueing behind one add
     // chain (a [256][1024] bias pass took 16 us for 1 MB: 64 dependent load-add steps per thread)
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // (round 3: eight - the 70 second-stage bias / norm-parameter reductions of a training step are ~200 dependent rows each)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (c < cols) {
         const float* p = in + (long long)seg * seg_rows * ld + c;
         int r = r_begin + rl;
-        for (; r + 12 < r_end; r += 16) {
+        for (; r + 28 < r_end; r += 32) {
             s0 += p[(long long)r * ld]; s1 += p[(long long)(r + 4) * ld]; s2 += p[(long long)(r + 8) * ld]; s3 += p[(long long)(r + 12) * ld];
+            s4 += p[(long long)(r + 16) * ld]; s5 += p[(long long)(r + 20) * ld]; s6 += p[(long long)(r + 24) * ld]; s7 += p[(long long)(r + 28) * ld];
         }
         for (; r < r_end; r += 4) s0 += p[(long long)r * ld];
     }
-    const float s = (s0 + s1) + (s2 + s3);
+    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && c < cols) {

@@ -275,6 +275,8 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         // ... or it is the split-f16 copy (the dX GEMM of a split-f16 step): its hi halves ARE the plain f16 cast, the kernel fetches them
         const bool rmsp = rm && d.rm_split && !bf;
         int n_x = 0;
+        bool b_kept = !d.scal_b && !(d.b16_split && bf);  // every problem's X comes from the forward's kept operand casts
+        for (int j = 0; j < d.nprob; ++j) b_kept = b_kept && d.B16[j] != nullptr;
         for (int j = 0; j < d.nprob; ++j) {
             const long long off = d.A[j] - d.A[0];
             if (rm16) {
@@ -293,7 +295,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             t.B[j] = nullptr;
             for (int e = 0; e < j; ++e)
                 if (d.B[e] == d.B[j]) t.B[j] = t.B[e];
-            if (!t.B[j] && d.B16[j] && !d.scal_b) t.B[j] = d.B16[j];  // the forward's operand cast of the same activation
+            if (!t.B[j] && b_kept) t.B[j] = d.B16[j];  // the forward's operand cast of the same activation
             if (!t.B[j]) {
                 // conv: ONE row-major cast of the conv input; the kernel gathers the taps (implicit im2col) in its DMA addresses
                 const long long b_rows = d.conv ? conv_rows_in : d.M;
@@ -307,6 +309,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         t.lda = (rm16 || rmsp) ? d.a_rm_ld : d.N;
         t.a_split = rmsp ? 1 : 0;
         t.ldb = d.conv ? d.Cin : d.K;
+        t.b_split = b_kept && d.b16_split ? 1 : 0;
         t.conv = d.conv; t.Cin = d.Cin; t.T_in = d.T_in; t.T_out = d.T_out; t.stride = d.stride; t.pad = d.pad; t.rowmap = d.rowmap;
         gemm_tn_tr_geometry(d.M, d.N, d.K, d.nprob, ks, t.ksplit, t.kper);
         t.part = slabs;

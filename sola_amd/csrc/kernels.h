@@ -93,6 +93,8 @@ struct GemmTnSplitDesc {
     long long B_rows;    // conv = 1 with rowmap: rows of the conv input B (the geometry gives M / T_out * T_in otherwise); 0 = unknown
     const void* B16[3];  // optional, pure != 0: problem j's B already cast row-major in the operand format ([M][K], or the conv input
                          // [rows_in][Cin]), unscaled - the training forward's own operand cast (SolaCtx::x16); used by the row-major route
+                         // when every problem has one
+    int b16_split;       // ... as SPLIT-f16 pairs (the split-f16 step's forward operands; pure == 1): the kernel takes their hi halves
 };
 // in [rows][cols] f32 -> out [cols][ld_out] split-f16 (rows rows..ld_out zero-filled; ld_out % 128 == 0); scal: optional
 // device pair as for launch_cast_sp16_auto with scal[0] = max|in| already there

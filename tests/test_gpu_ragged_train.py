@@ -208,7 +208,7 @@ def test_mixed_batch_equals_one_sample_steps_full(full, precision):
     assert_grads_close(got, ref_sum, 5e-3 if precision == "f16x3" else 2e-3, f"vs one-sample steps ({precision})")
 
 
-@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
 def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, precision):
     """As tests/test_gpu_backward.py's test of the same name, on a mixed-shape ragged batch (conv taps through the row maps): the
     backward reading the forward's kept operand casts (sola_tune "train_x16_keep" 1) against casting again (0)."""
@@ -217,7 +217,7 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
     got = {}
     try:
         samples = [sample_inputs(cfg, N, T, L, 400 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
-        for keep in (1, 0):
+        for keep in (2, 0):  # 2: the split-f16 step keeps its pairs too (1, the default, covers the 16-bit operand modes only)
             _lib.check(_lib.lib().sola_tune(b"train_x16_keep", keep), "tune")
             for _ in range(2):  # the arena is sized from the previous step's need: the second step reuses the casts
                 loss, g, _ = ragged_step(full, samples)
@@ -225,8 +225,8 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
-    assert torch.equal(got[1][1], got[0][1])
-    bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
+    assert torch.equal(got[2][1], got[0][1])
+    bad = [k for k in got[2][0] if not torch.equal(got[2][0][k], got[0][0][k])]
     assert not bad, bad
 
 
