@@ -231,6 +231,31 @@ def test_gemm_code_object_has_the_bf16_products():
     assert "v_mfma_f32_32x32x16_bf16" in dis.replace("-", "_")
 
 
+def test_row_major_weight_gradient_kernel_code_object():
+    """gemm_tn_tr_kernel (dW on row-major 16-bit operands): all six instantiations (f16 / bf16 x plain rows / conv geometry /
+    conv row map) are built, none spills, each k-loop step is 8 MFMAs fed by 12 transposing LDS reads (4 steps unrolled + the prologue's
+    = 60 reads), operands arrive by direct-to-LDS DMA, and the compiler put NO vmcnt(0) of its own between the barriers of the k-loop
+    (the fragment reads are inline asm for exactly that reason: the only full waits are the kernel's own, one per k-tile)."""
+    import re
+    dis, _ = _code_object_text("gemm_glds.o")
+    names = re.findall(r"^[0-9a-f]+ <(\S*gemm_tn_tr_kernel\S*)>:", dis, re.M)
+    assert len(names) == 6, names
+    for nm in names:
+        body = dis[dis.index(f"<{nm}>:"):]
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body, f"{nm} spills to scratch"
+        assert body.count("ds_read_b64_tr_b16") == 60, (nm, body.count("ds_read_b64_tr_b16"))
+        assert body.count("global_load_lds_dwordx4") >= 16, nm
+        assert len(re.findall(r"v_mfma_f32_32x32x16[_-](f16|bf16)", body)) == 32, nm
+    # the k16 experiment: 16-deep tiles, 24 MFMAs and 12 b128 fragment reads per step, two steps unrolled + the prologue's reads
+    k16 = re.findall(r"^[0-9a-f]+ <(\S*gemm_nt_split_glds_k16_kernel\S*)>:", dis, re.M)
+    assert len(k16) == 2, k16
+    for nm in k16:
+        body = dis[dis.index(f"<{nm}>:"):]
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body, f"{nm} spills to scratch"
+
+
 def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
     """What bench.py's headline measures is what a user of the classes and entry points gets."""
     monkeypatch.delenv("SOLA_PRECISION", raising=False)
