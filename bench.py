@@ -334,6 +334,20 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
         _d, profr = profiled(step_ragged, 2, sync, warmup=0)
         rag[prec] = {"value": round(S / dtr, 1), "ms_per_step": round(dtr * 1e3, 3), "model_tflops": round(3 * rflops / dtr / 1e12, 1),
                      "kernel_ms_per_step": kernel_ms(profr, 2)}
+    # the same leg at 128 samples per step, 16-bit GEMM operands: the per-step costs that do not scale with the rows (launches, the
+    # optimizer, the weight-side casts) are halved per sample
+    S2 = 128
+    smp = synth.make_ragged_samples(cfg, S2, 2025, dev)
+    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    rlabels = torch.cat([x["labels"] for x in smp])
+    rpos = torch.stack([x["pos"] for x in smp])
+    rflops2 = sum(synth.flops_per_sample(cfg, int(o.shape[0]), int(o.shape[1]), int(t.shape[0]))["total"] for o, t in zip(objs, langs))
+    rag["samples_per_step_128"] = {"object_token_rows": int(sum(o.shape[0] * o.shape[1] for o in objs)), "seed": 2025}
+    for prec in ("f16", "bf16"):
+        m.precision = prec
+        dtr = timed(step_ragged, max(2, steps // 2), sync)
+        rag["samples_per_step_128"][prec] = {"value": round(S2 / dtr, 1), "ms_per_step": round(dtr * 1e3, 3),
+                                             "model_tflops": round(3 * rflops2 / dtr / 1e12, 1)}
     res["ragged"] = rag
     del smp, objs, langs
     m.precision = "f32"
