@@ -216,6 +216,45 @@ class SyntheticTracks(torch.utils.data.Dataset):
                 "token_key": self.token_key(idx)}
 
 
+class PinnedPool:
+    """Recycled page-locked staging buffers in 1-MiB size classes.  ``Tensor.pin_memory()`` per sample page-locks fresh memory every
+    time (20 ms per 4 MB from one thread, tools/pin_copy_probe.py) and copies with torch's intra-op thread pool, which sixteen reader
+    threads oversubscribe: they staged 860 samples/s where they drew 1 540, and more threads made it worse (tools/batcher_rate.py).
+    A reader thread instead copies its sample into a buffer of the pool with one plain memcpy, and the
+    uploader returns the buffers of a batch once its host-to-device copies have completed.  A buffer that is never returned is
+    ordinary pinned tensor storage: it is freed with its last reference."""
+
+    def __init__(self):
+        import threading
+        self._free, self._lock = {}, threading.Lock()
+        self.hits = self.misses = 0  # stage() calls served from the pool / by page-locking fresh memory
+
+    def stage(self, t):
+        """Copy of ``t`` in page-locked memory + the pool buffer that holds it."""
+        nb = t.numel() * t.element_size()
+        cls = max(1, (nb + (1 << 20) - 1) >> 20)
+        with self._lock:
+            lst = self._free.get(cls)
+            buf = lst.pop() if lst else None
+            self.hits += buf is not None
+            self.misses += buf is None
+        if buf is None:
+            buf = torch.empty(cls << 20, dtype=torch.uint8, pin_memory=True)
+        dst = buf[:nb].view(t.dtype).view(t.shape)
+        if t.is_contiguous() and t.dtype in (torch.float32, torch.float16, torch.uint8, torch.int32, torch.int64):
+            np.copyto(dst.numpy(), t.numpy())  # one memcpy outside the interpreter lock.  NOT Tensor.copy_: from sixteen reader threads
+            # its intra-op thread pool is oversubscribed sixteen-fold (tools/pin_copy_probe.py: 13 GB/s aggregate against 21 from one
+            # thread; the batcher staged 770 samples/s with copy_, 1 680 with OMP_NUM_THREADS=1 or this)
+        else:
+            dst.copy_(t)
+        return dst, buf
+
+    def give_back(self, bufs):
+        with self._lock:
+            for b in bufs:
+                self._free.setdefault(b.numel() >> 20, []).append(b)
+
+
 class RaggedBatcher:
     """Groups consecutive samples of a dataset shard into ragged batches for ``forward_ragged``: up to ``max_samples``
     (video, expression) pairs per launch, bounded by ``max_rows`` object-token rows (sum of N*T over the batch's videos,
@@ -230,6 +269,7 @@ class RaggedBatcher:
         # pin: the reader threads also move a sample's tokens into page-locked memory (Tensor.pin_memory: ~2.5 ms per 2 MB sample,
         # which held the pipeline at 400 samples/s when the ONE upload thread of DevicePrefetcher did it for every sample)
         self.pin = bool(pin) and torch.cuda.is_available()
+        self.pool = PinnedPool() if self.pin else None  # batches carry their staging buffers in "pinned_bufs" (DevicePrefetcher returns them)
         # reader THREADS that fetch (or, for the synthetic stand-in, draw) the samples ahead of the batcher, in order.  Threads, not
         # worker processes: a sample is 1-16 MB of object tokens and a tensor that crosses a process boundary through shared
         # memory costs ~5 ms to touch on the receiving side (0.4 GB/s: tools/train_pipeline_profile.py measured 330 samples/s
@@ -251,7 +291,7 @@ class RaggedBatcher:
         def fetch(idx):
             smp = self.dataset[idx]
             if self.pin and isinstance(smp.get("object_tokens"), torch.Tensor) and not smp["object_tokens"].is_cuda:
-                smp["object_tokens"] = smp["object_tokens"].pin_memory()
+                smp["object_tokens"], smp["_pin_buf"] = self.pool.stage(smp["object_tokens"])
             return smp
 
         ahead = 4 * self.num_workers
@@ -270,23 +310,35 @@ class RaggedBatcher:
                 yield idx, fut.result()
 
     def __iter__(self):
-        videos, keys, sample_video, samples, rows = [], {}, [], [], 0
+        videos, keys, sample_video, samples, rows, bufs = [], {}, [], [], 0, []
+
+        def batch():
+            b = {"videos": videos, "sample_video": sample_video, "samples": samples}
+            if self.pool is not None:
+                b["pinned_bufs"], b["pinned_pool"] = bufs, self.pool
+            return b
+
         for idx, smp in self._samples():
             tok = smp.pop("object_tokens")
+            buf = smp.pop("_pin_buf", None)
             key = smp.get("token_key", ("sample", idx))
             new_rows = 0 if key in keys else int(tok.shape[0]) * int(tok.shape[1])
             if samples and (len(samples) >= self.max_samples or (new_rows > 0 and rows + new_rows > self.max_rows)):
-                yield {"videos": videos, "sample_video": sample_video, "samples": samples}
-                videos, keys, sample_video, samples, rows = [], {}, [], [], 0
+                yield batch()
+                videos, keys, sample_video, samples, rows, bufs = [], {}, [], [], 0, []
                 new_rows = int(tok.shape[0]) * int(tok.shape[1])
             if key not in keys:
                 keys[key] = len(videos)
                 videos.append(tok)
                 rows += new_rows
+                if buf is not None:
+                    bufs.append(buf)
+            elif buf is not None:
+                self.pool.give_back([buf])  # a further expression of a video the batch already holds: its copy is not used
             sample_video.append(keys[key])
             samples.append(smp)
         if samples:
-            yield {"videos": videos, "sample_video": sample_video, "samples": samples}
+            yield batch()
 
 
 class DevicePrefetcher:
@@ -321,9 +373,15 @@ class DevicePrefetcher:
         def work():
             try:
                 _t.cuda.set_device(self.device)
+                inflight = []  # (copy event, staging buffers, pool) of uploaded batches: buffers go back once the copies are done
                 for b in self.batches:
                     if stop.is_set():
                         return
+                    while inflight and inflight[0][0].query():
+                        _ev, bufs, pool = inflight.pop(0)
+                        pool.give_back(bufs)
+                    b = dict(b)
+                    bufs, pool = b.pop("pinned_bufs", None), b.pop("pinned_pool", None)
                     with _t.cuda.stream(stream):
                         vids = []
                         for v in b["videos"]:  # reader threads hand over page-locked tensors (RaggedBatcher pin=True): only the copy is left
@@ -331,6 +389,8 @@ class DevicePrefetcher:
                             vids.append(v.to(self.device, non_blocking=True))
                         ev = _t.cuda.Event()
                         ev.record(stream)
+                    if bufs and pool is not None:
+                        inflight.append((ev, bufs, pool))
                     if not put((dict(b, videos=vids), ev)):
                         return
                 put(done)
