@@ -104,3 +104,27 @@ def test_bench_two_ranks_code_path(tmp_path):
         assert td[k]["value"] > 0 and td[k]["ms_per_step"] > 0
     assert td["allreduce_alone"]["bytes"] >= 4 * 32_980_000 and td["allreduce_alone"]["busbw_GBps"] > 0
     assert td["ragged_inference"]["value"] > 0
+
+
+def test_staged_batches_equal_unstaged_ones_and_buffers_are_recycled():
+    """RaggedBatcher(pin=True): reader threads copy each sample's tokens into PinnedPool buffers (page-locked, recycled once the
+    uploader's copy event has completed).  The uploaded videos must equal the unstaged ones bit for bit over two passes of a ragged
+    synthetic set - a buffer handed back too early would be overwritten by a later sample before its upload - and the second pass
+    must be served from the pool."""
+    sys.path.insert(0, ROOT)
+    from sola_amd.data import DevicePrefetcher, RaggedBatcher, SyntheticTracks
+
+    ds = SyntheticTracks(n_samples=96, token_dim=256, seed=3, with_labels=True, per_video=2, ragged=True)
+    order = list(range(96))
+    plain = [[v.clone() for v in b["videos"]] for b in RaggedBatcher(ds, order, 16, max_rows=1 << 62)]
+    staged = RaggedBatcher(ds, order, 16, max_rows=1 << 62, num_workers=8, pin=True)
+    dev = torch.device("cuda", 0)
+    for _ in range(2):
+        n = 0
+        for b, ref in zip(DevicePrefetcher(staged, dev), plain):
+            assert "pinned_bufs" not in b and len(b["videos"]) == len(ref)
+            for v, r in zip(b["videos"], ref):
+                assert v.is_cuda and torch.equal(v.cpu(), r)
+            n += 1
+        assert n == len(plain)
+    assert staged.pool.hits > 0 and staged.pool.misses <= 96
