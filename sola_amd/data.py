@@ -116,15 +116,28 @@ class TrackDataset(torch.utils.data.Dataset):
         tail = (video_id, expression_id) if "gdino" in root else (video_id,)
         return os.path.join(base, "sam2_masklets", *tail), os.path.join(base, "sam2_object_tokens", *tail)
 
+    def _track_infos(self, mdir):
+        """The small fields of a masklet directory's per-track JSON files (anno_id, prompt_type, iou table), parsed once: the files
+        also hold every frame's RLE, and parsing them again for every expression of the video in every epoch is interpreter-bound
+        work that reader THREADS cannot overlap (dataloader.py:187-199 re-reads them; the values are the same)."""
+        cache = self.__dict__.setdefault("_info_cache", {})
+        infos = cache.get(mdir)
+        if infos is None:
+            infos = []
+            for name in sorted(os.listdir(mdir)):
+                with open(os.path.join(mdir, name), "r") as f:
+                    info = json.load(f)
+                infos.append({"anno_id": info["anno_id"], "prompt_type": info["prompt_type"], "iou": info.get("iou", {})})
+            cache[mdir] = infos
+        return infos
+
     def __getitem__(self, idx):
         s = self.samples[idx]
         tokens, iou, root_type, prompt_type, sam2_ids, gt_ids = [], [], [], [], [], []
         has_gt = s["anno_ids"][0] >= 0
         for root in self.roots:
             mdir, tdir = self._dirs(root, s["video_id"], s["expression_id"])
-            for name in sorted(os.listdir(mdir)):
-                with open(os.path.join(mdir, name), "r") as f:
-                    info = json.load(f)
+            for info in self._track_infos(mdir):
                 best, best_id = 0.0, NO_OBJECT_ID
                 if has_gt:
                     for a in s["anno_ids"]:
