@@ -443,7 +443,7 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * transpose in the LDS read (no transposed copies), 0 = always the transposing casts + NT GEMM;
  * "train_x16_keep": 1 (default) = in the 16-bit operand training modes the forward keeps its fixed-scale operand casts (a ctx-owned
  * arena that grows to the step's need) and the backward's weight-gradient products read them instead of casting the activations again
- * (2 = also the split pairs of the split-f16 step, whose hi halves serve as the f16 operands: measured neutral, not the default);
+ * (the split-f16 step's operand casts write their hi halves once more as plain f16 rows for that purpose);
  * "gemm_k16": experimental one-tile-per-block shape of the split-f16 GEMM - 256x128 tiles, 16-deep k-tiles, two four-wave blocks per
  * CU (one block's epilogue under the other's k-loop); bit-identical to the default, 7-20 % slower, 0 = off;
  * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose

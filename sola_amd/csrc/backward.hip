@@ -260,9 +260,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) {
                 d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW;
-                if ((pure || dw16) && ldx == k_in) d.B16[j] = c->x16_find(g[j].X, k_in, pure ? 1 + bf : 0);
+                if ((pure || dw16) && ldx == k_in) d.B16[j] = c->x16_find(g[j].X, k_in, pure ? 1 + bf : 1);
             }
-            d.b16_split = pure ? 0 : 1;
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             if (d.scratch_bytes >= gemm_tn_split_scratch_bytes(rows, n_out, k_in, n)) {
                 if (dy_rm_done) *dy_rm_done = gemm_tn_split_writes_rm(d);
@@ -511,8 +510,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.rowmap = rowmap; d.B_rows = rows_in;
-            if ((pure || dw16) && i > 0) d.B16[0] = c->x16_find(x_in, g.cin, pure ? 1 + bf : 0);
-            d.b16_split = pure ? 0 : 1;
+            if ((pure || dw16) && i > 0) d.B16[0] = c->x16_find(x_in, g.cin, pure ? 1 + bf : 1);
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
             if (scc) SOLA_TRY(bias_from_stats(0, g.cout, G(cp + ".bias")));

@@ -12,8 +12,10 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// side (optional): the hi halves once more as plain f16 rows [rows][8 * blocks_per_row] - the plain f16 cast of the same values (the
+// split-f16 training forward leaves it for the backward's weight-gradient products: SolaCtx::x16)
 __global__ __launch_bounds__(256) void cast_sp16_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows,
-                                                        int blocks_per_row, int ld_in, int ld_out, float scale) {
+                                                        int blocks_per_row, int ld_in, int ld_out, float scale, _Float16* __restrict__ side) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * blocks_per_row) return;
     const long long r = i / blocks_per_row;
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(256) void cast_sp16_kernel(const float* __restrict_
     half8* o = reinterpret_cast<half8*>(out + r * ld_out + b * 8);
     o[0] = hi;
     o[1] = lo;
+    if (side) *reinterpret_cast<half8*>(side + (r * blocks_per_row + b) * 8) = hi;
 }
 
 // block-wide max -> ONE atomic per block (a launch over 0.5 GB has 65 K blocks: an atomic per wave queued 260 K updates on one
@@ -343,11 +346,12 @@ int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, lo
     return SOLA_OK;
 }
 
-int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s) {
+int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s, void* side16) {
     SOLA_ARG(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, "cast_sp16: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
     const long long n = rows * (K / 8);
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * K);
-    hipLaunchKernelGGL(cast_sp16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, rows, K / 8, ld_in, ld_out, scale);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (side16 ? 10.0 : 8.0) * rows * K);
+    hipLaunchKernelGGL(cast_sp16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, rows, K / 8, ld_in, ld_out, scale,
+                       static_cast<_Float16*>(side16));
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -10,6 +10,7 @@
 
 int g_train_gn_cast = 1;  // sola_tune "train_gn_cast": 1 = a GroupNorm of the training forward also writes the operand cast of the GEMM behind it
 void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
+extern int g_train_dw_f16;
 int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
@@ -162,8 +163,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     auto cast_auto = [&](const float* in, int ld, float* out, long long rows, int K, float* scal) -> int {
         return pure ? launch_cast_f16(in, ld, out, K, rows, K, 0.f, scal, s, 13, nullptr, bf) : launch_cast_sp16_auto(in, ld, out, K, rows, K, scal, s);
     };
-    auto cast_fixed = [&](const float* in, int ld, float* out, long long rows, int K, float scale) -> int {
-        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s, 13, nullptr, bf) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
+    auto cast_fixed = [&](const float* in, int ld, float* out, long long rows, int K, float scale, void* side16 = nullptr) -> int {
+        return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s, 13, nullptr, bf) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s, side16);
     };
 
     // a1: weight standardisation (module/ws.py:9-13), every forward like the reference unless the policy says cached
@@ -199,11 +200,13 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     float* const sp_b = split ? buf("sp_b") : nullptr;
     // 16-bit operand modes: every fixed-scale operand cast gets its own slot of the ctx's arena and is listed by its f32 source - the
     // backward's dW products read it instead of casting the activation again (ctx.h; data-dependent scales keep the shared buffers)
-    // (2: also the split pairs of the "f16x3" step, whose hi halves are the dW products' plain-f16 operands - measured neutral: the
-    // kernel then fetches every other 16-byte chunk and its DMA slows by what the saved casts gained; off by default)
-    const bool keep16 = split && (pure ? g_train_x16_keep != 0 : g_train_x16_keep == 2);
+    // The split-f16 step ("f16x3") keeps nothing of its split pairs (fetching their hi halves with every other 16-byte chunk slowed the
+    // dW kernel's DMA by what the saved casts had cost); its operand casts instead write the hi halves ONCE MORE as plain f16 rows
+    // into the arena (side16 below): 2 more bytes per value written here, 6 fewer moved by the backward's X cast.
+    const bool keep16 = split && pure && g_train_x16_keep != 0;
+    const bool side16_on = split && !pure && g_train_x16_keep != 0 && g_train_dw_f16 != 0;
     c->x16.clear();
-    if (keep16) {
+    if (keep16 || side16_on) {
         if (c->x16_need > c->x16_cap) {  // grow to what the last step asked for (+ 1/8: ragged batches differ from step to step)
             SOLA_HIP(hipStreamSynchronize(s));
             if (c->x16_arena) SOLA_HIP(hipFree(c->x16_arena));
@@ -216,10 +219,16 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         c->x16_used = 0;
         c->x16_need = 0;
     }
+    auto side16 = [&](const float* src, long long rows, int cols) -> void* {  // f16x3: where the plain-f16 side copy of `src` goes
+        if (!side16_on) return nullptr;
+        void* q = c->x16_alloc((size_t)rows * cols * 2);
+        if (q) c->x16.push_back(SolaCtx::X16Entry{src, q, cols, 1});
+        return q;
+    };
     auto slot16 = [&](int which, const float* src, long long rows, int cols) -> float* {  // the operand cast of `src` goes here
         if (keep16)
-            if (void* q = c->x16_alloc((size_t)rows * cols * (pure ? 2 : 4))) {
-                c->x16.push_back(SolaCtx::X16Entry{src, q, cols, pure ? 1 + bf : 0});
+            if (void* q = c->x16_alloc((size_t)rows * cols * 2)) {
+                c->x16.push_back(SolaCtx::X16Entry{src, q, cols, 1 + bf});
                 return static_cast<float*>(q);
             }
         return which ? sp_b : sp_a;
@@ -252,7 +261,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                 gd.p[0].A = sp_a;
             } else if (pc_src[0] != x) {
                 float* dst = slot16(0, x, level_rows(i), g.cin);
-                SOLA_TRY(cast_fixed(x, g.cin, dst, level_rows(i), g.cin, 1.f));
+                SOLA_TRY(cast_fixed(x, g.cin, dst, level_rows(i), g.cin, 1.f, side16(x, level_rows(i), g.cin)));
                 gd.p[0].A = dst;
             } else {
                 gd.p[0].A = pc_dst[0];
@@ -319,7 +328,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                     else if (a_scal) SOLA_TRY(cast_auto(as[j], D, dst[at], rows, D, a_scal));
                     else {
                         dst[at] = slot16(at, as[j], rows, D);
-                        SOLA_TRY(cast_fixed(as[j], D, dst[at], rows, D, 1.f));
+                        SOLA_TRY(cast_fixed(as[j], D, dst[at], rows, D, 1.f, side16(as[j], rows, D)));
                     }
                 }
                 gd.p[j].A = dst[at];
@@ -340,7 +349,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split) {
             float* dst = slot16(0, ao, M, D);
-            SOLA_TRY(cast_fixed(ao, D, dst, M, D, 1.f));
+            SOLA_TRY(cast_fixed(ao, D, dst, M, D, 1.f, side16(ao, M, D)));
             gd.p[0].A = dst; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
         }

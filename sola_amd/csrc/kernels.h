@@ -290,7 +290,8 @@ struct GroupNormDesc {
     int cast_fmt = 0;
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
-int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s);
+// side16 (optional): also the plain f16 cast of the same values, contiguous [rows][K] halfs (= the hi halves)
+int launch_cast_sp16(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float scale, hipStream_t s, void* side16 = nullptr);
 // Same conversion with a data-dependent power-of-two scale (gradients: their magnitude is not known on the host and
 // mostly below the f16 normal range).  scal[0] receives max|in| (as float bits), the cast maps it into [2^13, 2^14) and
 // writes the inverse scale to scal[1] for the GEMM's out_scale_dev.  scal = 2 device floats.
