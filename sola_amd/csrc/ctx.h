@@ -87,6 +87,7 @@ struct SolaCtx {
     std::vector<X16Entry> x16;
     char* x16_arena = nullptr;
     size_t x16_cap = 0, x16_used = 0, x16_need = 0;
+    bool x16_off = false;  // the arena could not be allocated once: stop asking (the backward casts as before)
     void* x16_alloc(size_t bytes) {  // null = no room this step (the caller uses its shared buffer and lists nothing)
         bytes = (bytes + 255) & ~(size_t)255;
         x16_need += bytes;

@@ -203,8 +203,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     // The split-f16 step ("f16x3") keeps nothing of its split pairs (fetching their hi halves with every other 16-byte chunk slowed the
     // dW kernel's DMA by what the saved casts had cost); its operand casts instead write the hi halves ONCE MORE as plain f16 rows
     // into the arena (side16 below): 2 more bytes per value written here, 6 fewer moved by the backward's X cast.
-    const bool keep16 = split && pure && g_train_x16_keep != 0;
-    const bool side16_on = split && !pure && g_train_x16_keep != 0 && g_train_dw_f16 != 0;
+    const bool keep16 = split && pure && g_train_x16_keep != 0 && !c->x16_off;
+    const bool side16_on = split && !pure && g_train_x16_keep != 0 && g_train_dw_f16 != 0 && !c->x16_off;
     c->x16.clear();
     if (keep16 || side16_on) {
         if (c->x16_need > c->x16_cap) {  // grow to what the last step asked for (+ 1/8: ragged batches differ from step to step)
@@ -213,8 +213,13 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             c->x16_arena = nullptr;
             c->x16_cap = 0;
             const size_t want = c->x16_need + c->x16_need / 8;
-            if (hipMalloc(&c->x16_arena, want) == hipSuccess) c->x16_cap = want;
-            else (void)hipGetLastError();  // no room: this step and the following ones cast in the backward as before
+            if (hipMalloc(&c->x16_arena, want) == hipSuccess) {
+                c->x16_cap = want;
+            } else {  // no room: this step and the following ones cast in the backward as before
+                (void)hipGetLastError();
+                c->x16_arena = nullptr;
+                c->x16_off = true;
+            }
         }
         c->x16_used = 0;
         c->x16_need = 0;
