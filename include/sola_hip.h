@@ -471,6 +471,9 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "attn_f16_small" 1 (default) = the 16-byte-per-lane GroupNorm and the streaming short-sequence attention of precision 2).
  * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
+/* In-library kernel timing: two HIP events on the launch stream around every kernel launch.  enable 0 = off, 1 = every category,
+ * a larger value = only the categories c with bit (c + 1) set (each timed launch costs two event records, ~1.5 us of stream time
+ * each: 2.8 % of the headline step with every category on, tools/prof_overhead.py). */
 int sola_profile_enable(int enable);
 /* Synchronises the recorded events and returns, per category: launches, total milliseconds, algorithmic flops,
  * algorithmic bytes accumulated since the last reset. Arrays have SOLA_PROF_NCAT entries. */

@@ -189,8 +189,12 @@ def require_cuda(*tensors):
             raise SolaError("sola_amd runs on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
 
 
-def profile_enable(on=True):
-    check(lib().sola_profile_enable(1 if on else 0), "sola_profile_enable")
+def profile_enable(on=True, categories=None):
+    """``categories``: time only these (names of PROF_CATEGORIES) - every timed launch costs two event records on its stream."""
+    v = 1 if on else 0
+    if on and categories is not None:
+        v = sum(1 << (PROF_CATEGORIES.index(c) + 1) for c in categories)
+    check(lib().sola_profile_enable(v), "sola_profile_enable")
 
 
 def profile_read(reset=True):

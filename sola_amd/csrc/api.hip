@@ -35,6 +35,7 @@ struct ProfRec {
 struct Profiler {
     std::mutex mu;
     bool enabled = false;
+    unsigned mask = ~0u;  // categories that are timed while enabled (sola_profile_enable)
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
     int64_t launches[SOLA_PROF_NCAT] = {0};
@@ -69,7 +70,7 @@ Profiler g_prof;
 
 SolaProfScope::SolaProfScope(int cat_, hipStream_t stream_, double flops, double bytes)
     : cat(cat_), stream(stream_), on(false), slot(-1) {
-    if (!g_prof.enabled) return;
+    if (!g_prof.enabled || !((g_prof.mask >> cat) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     ProfRec r{cat, g_prof.get(), g_prof.get(), flops, bytes};
     if (!r.e0 || !r.e1) return;
@@ -87,6 +88,7 @@ SolaProfScope::~SolaProfScope() {
 extern "C" int sola_profile_enable(int enable) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.enabled = enable != 0;
+    g_prof.mask = (enable == 0 || enable == 1) ? ~0u : ((unsigned)enable >> 1);  // > 1: bit (c + 1) set = category c is timed
     // events are only recycled when the counters are read, so a timed region of K unsynchronised steps needs two per kernel
     // launch per step: create them here, outside anybody's timed region (hipEventCreate costs 3-20 us a piece)
     while (enable && g_prof.pool.size() < 8192) {

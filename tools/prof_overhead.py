@@ -18,14 +18,19 @@ def step():
         ops.select(sm, 0.5)
 for _ in range(3): step()
 gc.collect(); gc.disable()
-res = {0: [], 1: []}
+res = {0: [], 1: [], 2: []}
+ROOF = ["gemm128", "gemm64", "gemm_split", "gemm_split256", "gemm_split256_gn", "attn"]  # what bench.py's timed region brackets
+gemm_us = {1: [], 2: []}
 for rnd in range(6):
-    for on in (1, 0):
-        _lib.profile_enable(bool(on)); _lib.profile_read(reset=True)
+    for on in (1, 2, 0):
+        _lib.profile_enable(bool(on), categories=ROOF if on == 2 else None); _lib.profile_read(reset=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20): step()
         torch.cuda.synchronize(); res[on].append((time.perf_counter() - t0) / 20 * 1e3)
-        _lib.profile_read(reset=True)
+        pr = _lib.profile_read(reset=True)
+        if on: gemm_us[on].append(1e3 * pr["gemm_split256"]["ms"] / max(1, pr["gemm_split256"]["launches"]))
 _lib.profile_enable(False)
-print(f"ms per step, profiler on: min {min(res[1]):.3f} median {sorted(res[1])[3]:.3f}   off: min {min(res[0]):.3f} median {sorted(res[0])[3]:.3f}   "
-      f"overhead {100 * (min(res[1]) / min(res[0]) - 1):.2f} %")
+print(f"ms per step, every launch timed: min {min(res[1]):.3f} median {sorted(res[1])[3]:.3f}   GEMM + attention launches timed: min {min(res[2]):.3f} "
+      f"median {sorted(res[2])[3]:.3f}   profiler off: min {min(res[0]):.3f} median {sorted(res[0])[3]:.3f}   "
+      f"overhead {100 * (min(res[1]) / min(res[0]) - 1):.2f} % / {100 * (min(res[2]) / min(res[0]) - 1):.2f} %")
+print(f"average GEMM launch (us): every launch timed {min(gemm_us[1]):.1f}-{max(gemm_us[1]):.1f}, GEMM + attention only {min(gemm_us[2]):.1f}-{max(gemm_us[2]):.1f}")
