@@ -98,7 +98,7 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
     a.add("tn", tn_max / sizeof(float) + 64);
     a.add("gpart", inst_c_max);
     a.add("bpart", inst_c_max);
-    a.add("colsum", colsum_scratch_bytes(1, (int)std::max(M, std::max(R, z.inst_bt)), (int)D) / sizeof(float) + 64);
+    a.add("colsum", colsum_scratch_bytes(2, (int)std::max(M, std::max(R, z.inst_bt)), (int)D) / sizeof(float) + 64);
     // few-sample regime (the reference trains at batch size 1): the dX GEMMs have fewer 64x64 tiles than the chip has CUs; scratch
     // for their deterministic two-pass split-K, as the forward has (42-136 us per dX GEMM without it, 64 blocks on 256 CUs)
     if (M <= 8192) a.add("splitk", (size_t)8192 * 4096);
@@ -320,8 +320,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         SOLA_TRY(launch_group_norm_bwd(d, s));
         float* cs = ar.get("colsum");
         const size_t csb = ar.total - ar.off.at("colsum");
-        SOLA_TRY(launch_colsum(ar.get("gpart"), G(wname + ".weight"), 1, n_inst, C, C, 1.f, 0, cs, csb, s));
-        return launch_colsum(ar.get("bpart"), G(wname + ".bias"), 1, n_inst, C, C, 1.f, 0, cs, csb, s);
+        return launch_colsum_pair(ar.get("gpart"), ar.get("bpart"), G(wname + ".weight"), G(wname + ".bias"), n_inst, C, C, cs, csb, s);
     };
 
     // ---- score head -------------------------------------------------------------------------------------------

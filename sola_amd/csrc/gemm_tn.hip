@@ -7,6 +7,8 @@
 // Exact f32 on v_mfma_f32_32x32x2_f32.  The reduction index m is the slow (row) index of both operands, so tiles are
 // staged [32 m][128 cols] with coalesced float4 row loads and the MFMA fragments are ds_read_b32 across the columns
 // (lanes 0-31 take row m, lanes 32-63 row m+1: consecutive addresses, conflict-free).
+#include <utility>
+
 #include "kernels.h"
 
 namespace {
@@ -183,8 +185,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // out[(chunk * segments + seg)][c] (+)= scale * sum_{r in chunk of segment} in[(seg * seg_rows + r)][c]
 // block = 64 columns x 4 row lanes; grid.z splits long segments into row chunks (second launch adds the chunks up)
+// seg_stride: elements between the first rows of consecutive segments (seg_rows * ld for back-to-back segments).  out1 / split: output
+// index >= split goes to out1[index - split] instead (two reductions with separate destinations in one launch: launch_colsum_pair).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int seg_rows,
-                                                     int cols, int ld, int chunk_rows, float scale, int accumulate) {
+                                                     int cols, int ld, int chunk_rows, float scale, int accumulate, long long seg_stride,
+                                                     float* __restrict__ out1, long long split) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     // (round 3: eight - the 70 second-stage bias / norm-parameter reductions of a training step are ~200 dependent rows each)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (c < cols) {
-        const float* p = in + (long long)seg * seg_rows * ld + c;
+        const float* p = in + (long long)seg * seg_stride + c;
         int r = r_begin + rl;
         for (; r + 28 < r_end; r += 32) {
             s0 += p[(long long)r * ld]; s1 += p[(long long)(r + 4) * ld]; s2 += p[(long long)(r + 8) * ld]; s3 += p[(long long)(r + 12) * ld];
@@ -209,7 +214,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     __syncthreads();
     if (rl == 0 && c < cols) {
         const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * scale;
-        float* o = out + ((long long)blockIdx.z * gridDim.y + seg) * cols + c;
+        const long long oi = ((long long)blockIdx.z * gridDim.y + seg) * cols + c;
+        float* o = (out1 && oi >= split) ? out1 + (oi - split) : out + oi;
         *o = accumulate ? *o + v : v;
     }
 }
@@ -298,18 +304,45 @@ int launch_colsum(const float* in, float* out, int segments, int seg_rows, int c
     const size_t need = colsum_scratch_bytes(segments, seg_rows, cols);
     if (need == 0 || scratch == nullptr || scratch_bytes < need) {
         hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, segments, 1), dim3(256), 0, s, in, out, seg_rows, cols, ld,
-                           seg_rows, scale, accumulate);
+                           seg_rows, scale, accumulate, (long long)seg_rows * ld, (float*)nullptr, 0LL);
         SOLA_LAUNCH_CHECK();
         return SOLA_OK;
     }
     const int chunks = (int)(need / ((size_t)segments * cols * sizeof(float)));
     const int chunk_rows = (seg_rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, segments, chunks), dim3(256), 0, s, in, scratch, seg_rows, cols,
-                       ld, chunk_rows, 1.0f, 0);
+                       ld, chunk_rows, 1.0f, 0, (long long)seg_rows * ld, (float*)nullptr, 0LL);
     SOLA_LAUNCH_CHECK();
     const int wide = segments * cols;  // second pass: [chunks][segments*cols] -> [segments*cols]
     hipLaunchKernelGGL(colsum_kernel, dim3((wide + 63) / 64, 1, 1), dim3(256), 0, s, scratch, out, chunks, wide, wide, chunks,
-                       scale, accumulate);
+                       scale, accumulate, (long long)chunks * wide, (float*)nullptr, 0LL);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+// Two column sums of equally shaped matrices with separate destinations (GroupNorm's dgamma / dbeta partials) in the launches of one:
+// the same chunking and summation order as two launch_colsum calls, so the same bits.
+int launch_colsum_pair(const float* in0, const float* in1, float* out0, float* out1, int seg_rows, int cols, int ld, float* scratch,
+                       size_t scratch_bytes, hipStream_t s) {
+    SOLA_ARG(in0 && in1 && out0 && out1 && seg_rows > 0 && cols > 0, "colsum_pair: bad arguments");
+    if (in1 < in0) { std::swap(in0, in1); std::swap(out0, out1); }
+    const long long stride = in1 - in0;
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * (double)seg_rows * cols);
+    const size_t need = colsum_scratch_bytes(2, seg_rows, cols);
+    if (need == 0 || scratch == nullptr || scratch_bytes < need) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, 2, 1), dim3(256), 0, s, in0, out0, seg_rows, cols, ld, seg_rows, 1.0f, 0, stride, out1,
+                           (long long)cols);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
+    const int chunks = (int)(need / ((size_t)2 * cols * sizeof(float)));
+    const int chunk_rows = (seg_rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, 2, chunks), dim3(256), 0, s, in0, scratch, seg_rows, cols, ld, chunk_rows, 1.0f, 0, stride,
+                       (float*)nullptr, 0LL);
+    SOLA_LAUNCH_CHECK();
+    const int wide = 2 * cols;
+    hipLaunchKernelGGL(colsum_kernel, dim3((wide + 63) / 64, 1, 1), dim3(256), 0, s, scratch, out0, chunks, wide, wide, chunks, 1.0f, 0,
+                       (long long)chunks * wide, out1, (long long)cols);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -137,6 +137,9 @@ int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, i
 size_t colsum_scratch_bytes(int segments, int seg_rows, int cols);
 int launch_colsum(const float* in, float* out, int segments, int seg_rows, int cols, int ld, float scale, int accumulate,
                   float* scratch, size_t scratch_bytes, hipStream_t s);
+// out0 = column sums of in0, out1 = column sums of in1 (both [seg_rows][ld] views of `cols` columns) in the launches of one call
+int launch_colsum_pair(const float* in0, const float* in1, float* out0, float* out1, int seg_rows, int cols, int ld, float* scratch,
+                       size_t scratch_bytes, hipStream_t s);
 
 // ---- attention core (attn.hip) ---------------------------------------------------------------------------------
 struct AttnDesc {
