@@ -28,6 +28,9 @@
 // overlap + ~28 us epilogue (HBM-bound: C once, residual once; with one round of blocks nothing overlaps it).  Also
 // tried and dropped: a 256x128 / 3-stage shape (DMA two tiles ahead: no faster, latency was not the bound) and
 // sched_group_barrier interleaving of fragment reads (+2-5 % on 64x64 wave tiles only, subsumed by this schedule).
+// Also in this file (round 3): gemm_nt_split_glds_k16_kernel - an experiment, 16-deep k-tiles and two four-wave blocks per CU (slower:
+// DESIGN.md Appendix A) - and gemm_tn_tr_kernel, the weight-gradient product on ROW-MAJOR 16-bit operands (transposing LDS reads
+// instead of transposed copies; the training modes' default dW route).
 #include "kernels.h"
 #include <algorithm>
 #include <type_traits>

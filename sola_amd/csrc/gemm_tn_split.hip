@@ -6,6 +6,9 @@
 // one persistent-kernel work item each, and gemm.hip's splitk_reduce_kernel folds the partial sums in a fixed order.
 // dY is a gradient (entries ~1e-4..1e-9): it is scaled by a data-dependent power of two found on the device
 // (cast.hip's amax pass; all problems of a launch share the scale), undone by the GEMM's out_scale_dev.
+// Second route (round 3, the default for 16-bit operands - GemmTnSplitDesc::pure - when N and K are multiples of 256): NO transposed
+// copies.  The operands are cast ROW-MAJOR (dY's cast is the dX GEMM's operand anyway, X's comes from the training forward's kept
+// casts or one plain cast; convs: one cast of the conv input) and gemm_glds.hip's gemm_tn_tr_kernel transposes them in its LDS reads.
 #include <algorithm>
 
 #include "kernels.h"
