@@ -230,6 +230,30 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
     assert not bad, bad
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
+def test_row_major_weight_gradient_route_equals_the_transposed_copy_route_on_a_ragged_batch(full, precision):
+    """sola_tune "train_tn_tr" 1 (default: gemm_tn_tr_kernel on row-major 16-bit operands, conv taps gathered through the ragged row
+    maps in the DMA addresses, the forward's kept operand casts) against 0 (transposing casts, one per conv tap, + the NT kernel): the
+    same 16-bit operand values enter both, only the f32 accumulation order differs - every gradient tensor within 2e-5 of its norm
+    (a wrong tap, row map entry or zero-padding decision would show at the 1e-2 level)."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    full.precision = precision
+    got = {}
+    try:
+        samples = [sample_inputs(cfg, N, T, L, 500 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
+        for route in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"train_tn_tr", route), "tune")
+            for _ in range(2):
+                loss, g, _ = ragged_step(full, samples)
+            got[route] = g
+    finally:
+        full.precision = "f32"
+        _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
+    worst = max((float((got[1][k].double() - got[0][k].double()).norm()) / (float(got[0][k].double().norm()) + 1e-30), k) for k in got[0])
+    print("row-major vs transposed-copy dW route, worst tensor:", worst)
+    assert worst[0] < 2e-5, worst
+
+
 def test_full_gradient_norms_of_single_golden_samples(full_golden, full):
     """A ragged batch of ONE golden sample must reproduce the reference's per-parameter gradient norms (the ragged kernels
     alone, no summation over samples)."""
