@@ -293,6 +293,28 @@ def test_conv_weight_gradient_on_row_major_16bit_operands(geom):
         _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
 
 
+def test_profiler_category_mask():
+    """sola_profile_enable with a category mask times only those launches (bench.py's timed region brackets the GEMM and attention
+    launches: two event records per timed launch are stream time); with every category on, the same calls are all counted."""
+    from sola_amd import _lib
+    x = torch.randn(4096, 1024, device="cuda"); w = torch.randn(1024, 1024, device="cuda") * 0.03
+    a, ws = ops.cast_sp16(x), ops.cast_sp16(w, 64.0)
+    try:
+        _lib.profile_enable(True, categories=["gemm_split", "gemm_split256"])
+        _lib.profile_read(reset=True)
+        ops.cast_sp16(x)
+        ops.gemm_nt_split(a, ws, None, out_scale=1 / 64)
+        pr = _lib.profile_read(reset=True)
+        assert pr["misc"]["launches"] == 0 and pr["gemm_split"]["launches"] + pr["gemm_split256"]["launches"] == 1
+        _lib.profile_enable(True)
+        ops.cast_sp16(x)
+        ops.gemm_nt_split(a, ws, None, out_scale=1 / 64)
+        pr = _lib.profile_read(reset=True)
+        assert pr["misc"]["launches"] >= 1 and pr["gemm_split"]["launches"] + pr["gemm_split256"]["launches"] == 1
+    finally:
+        _lib.profile_enable(False)
+
+
 def test_experimental_k16_gemm_is_bit_identical():
     """sola_tune "gemm_k16" (256x128 tiles, 16-deep k-tiles in 64-byte LDS rows, three stages, TWO four-wave blocks per CU so that one
     block's epilogue runs under the other's k-loop - DESIGN.md Appendix A): same fragments and accumulation order as the default
