@@ -42,9 +42,9 @@ def test_two_rank_shard_and_gradient_allreduce():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=600) for _ in range(2))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     (r0, m0, c0, ok0, g0), (r1, m1, c1, ok1, g1) = res
     assert sorted(m0 + m1) == list(range(11)) and not set(m0) & set(m1)  # every sample owned exactly once

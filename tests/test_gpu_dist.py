@@ -87,9 +87,9 @@ def test_two_ranks_step_identically_and_match_the_averaged_gradient(overlap):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     (_, w0, n0), (_, w1, n1) = res
     assert n0 == n1
