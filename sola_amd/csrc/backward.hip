@@ -112,7 +112,7 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
     if (lowp) {  // split-f16 / f16-operand dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
         a.add("wt_sp", wt_max);
-        a.add("scal", 64);
+        a.add("scal", 16 + 2 * (6 + 8 * (size_t)c->cfg.n_layers));  // 16 fixed slots + one pair per stats() call of a step (6 convs, <= 8 per layer)
         {   // per-64-row-slab column sums of a gradient matrix (launch_amax_colsum): bias gradients without a second read
             size_t cp = std::max((M / 64 + 1) * 3 * D, (BW / 64 + 1) * 2 * D);
             for (int i = 0; i < 6; ++i) cp = std::max(cp, (z.rows[i + 1] / 64 + 1) * (size_t)c->conv[i].cout);
@@ -232,11 +232,17 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     // its bias gradients (per-slab column sums, folded by a tiny second pass): stats() -> scale slot, bias_from_stats().
     float* cpart = split ? ar.get("cpart") : nullptr;
     int cpart_cols = 0, cpart_slabs = 0;
+    int stat_calls = 0;
+    const int scal_floats = split ? (int)(16 + 2 * (6 + 8 * (size_t)c->cfg.n_layers)) : 0;
+    if (split) SOLA_HIP(hipMemsetAsync(ar.get("scal"), 0, scal_floats * sizeof(float), s));
     auto stats = [&](const float* dY, int ld, int rows, int cols, int slot, float** sc_out) -> int {
         *sc_out = nullptr;
         if (!split || cols % 4 || ld % 4) return SOLA_OK;
-        float* sc = ar.get("scal") + slot;
-        SOLA_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(float), s));
+        // every call takes the next pair of the slots behind the 16 fixed ones: they were zeroed by ONE memset when the call began (a
+        // memset of 8 bytes per gradient matrix was 20 launches of ~5 us per step)
+        (void)slot;
+        SOLA_ARG(16 + 2 * (stat_calls + 1) <= scal_floats, "backward: more gradient-statistics passes (%d) than scale slots", stat_calls + 1);
+        float* sc = ar.get("scal") + 16 + 2 * stat_calls++;
         SOLA_TRY(launch_amax_colsum(dY, ld, rows, cols, sc, cpart, s));
         cpart_cols = cols;
         cpart_slabs = (rows + 63) / 64;
