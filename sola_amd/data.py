@@ -242,6 +242,10 @@ class PinnedPool:
         self._free, self._lock = {}, threading.Lock()
         self.hits = self.misses = 0  # stage() calls served from the pool / by page-locking fresh memory
 
+    @staticmethod
+    def _alloc(nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+
     def stage(self, t):
         """Copy of ``t`` in page-locked memory + the pool buffer that holds it."""
         nb = t.numel() * t.element_size()
@@ -252,7 +256,7 @@ class PinnedPool:
             self.hits += buf is not None
             self.misses += buf is None
         if buf is None:
-            buf = torch.empty(cls << 20, dtype=torch.uint8, pin_memory=True)
+            buf = self._alloc(cls << 20)
         dst = buf[:nb].view(t.dtype).view(t.shape)
         if t.is_contiguous() and t.dtype in (torch.float32, torch.float16, torch.uint8, torch.int32, torch.int64):
             np.copyto(dst.numpy(), t.numpy())  # one memcpy outside the interpreter lock.  NOT Tensor.copy_: from sixteen reader threads

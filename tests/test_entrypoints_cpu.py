@@ -110,3 +110,27 @@ def test_ragged_batcher_groups_samples_and_shares_videos():
                  [float(v.double().sum()) for v in bt["videos"]]) for bt in batches]
     order = [5, 4, 17, 16, 3, 22, 9, 8, 11, 10, 0, 1, 2, 6, 7, 12]
     assert digest(sdata.RaggedBatcher(ds, order, max_samples=5, num_workers=2)) == digest(sdata.RaggedBatcher(ds, order, max_samples=5))
+
+
+def test_staging_pool_bookkeeping(monkeypatch):
+    """RaggedBatcher's staging (PinnedPool) without a GPU: pageable buffers stand in for page-locked ones.  Staged batches equal the
+    unstaged ones; the copy of a further expression of a video the batch already holds goes straight back to the pool; buffers
+    handed back after a batch serve the next pass (1-MiB size classes)."""
+    import torch
+    from sola_amd.data import PinnedPool, RaggedBatcher, SyntheticTracks
+
+    monkeypatch.setattr(PinnedPool, "_alloc", staticmethod(lambda n: torch.empty(n, dtype=torch.uint8)))
+    ds = SyntheticTracks(n_samples=48, token_dim=64, seed=5, with_labels=True, per_video=3, ragged=True)
+    order = list(range(48))
+    plain = [[v.clone() for v in b["videos"]] for b in RaggedBatcher(ds, order, 12, max_rows=1 << 62)]
+    staged = RaggedBatcher(ds, order, 12, max_rows=1 << 62, num_workers=4, pin=False)
+    staged.pin, staged.pool = True, PinnedPool()
+    for _ in range(2):
+        for b, ref in zip(staged, plain):
+            assert len(b["videos"]) == len(ref) == len(b["pinned_bufs"])  # one buffer per VIDEO of the batch, not per sample
+            for v, r in zip(b["videos"], ref):
+                assert torch.equal(v, r)
+            b["pinned_pool"].give_back(b["pinned_bufs"])
+    # 48 samples were staged per pass; the second pass (and the duplicates' buffers within the first) came from the pool
+    assert staged.pool.hits + staged.pool.misses == 96 and staged.pool.misses <= 48 and staged.pool.hits >= 48
+    assert all(buf.numel() % (1 << 20) == 0 for lst in staged.pool._free.values() for buf in lst)
