@@ -458,6 +458,25 @@ def test_kept_operand_casts_give_the_same_gradients_bit_for_bit(full_model, mode
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
+    # the same with dropout ON (train mode, the masks re-seeded per step): the kept casts are the casts of the POST-dropout
+    # activations, which is what the backward's own cast of the stored f32 activations reads
+    got = {}
+    try:
+        m.train()
+        m.precision = mode
+        for keep in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"train_x16_keep", keep), "tune")
+            for _ in range(2):
+                torch.manual_seed(7)
+                _, l3, g = train_step_grads(m, cfg, 8, 40, 32, 10, 77)
+            got[keep] = ({k: v.clone() for k, v in g.items()}, l3.detach().clone())
+    finally:
+        m.eval()
+        m.precision = "f32"
+        _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
+    assert torch.equal(got[1][1], got[0][1])
+    bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("fused", [True, False])
