@@ -282,6 +282,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         for (int j = 0; j < n; ++j) SOLA_TRY(grad_w(g[j].dY, ldy, g[j].X, ldx, rows, n_out, k_in, g[j].dW, g[j].db));
         return SOLA_OK;
     };
+    bool wt_sp_ready = false;  // "wt_sp" already holds the cast of the transposed weights the next grad_x call needs (transpose_into)
     // dX[rows, k_in] = dY[rows, n_cat] * Wcat (+ R), where wt holds Wcat^T as [k_in][n_cat]
     // cast_done: "dy_sp" already holds the row-major cast of the [rows][ldy] matrix that dY - col_off starts (grad_w_many)
     auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX, float* sc = nullptr,
@@ -304,13 +305,18 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                 d.p[0].A = ar.get("dy_sp");
                 d.lda = n_cat;
             }
-            SOLA_TRY(cast_fixed(wt, n_cat, ar.get("wt_sp"), k_in, n_cat, kLinScale));
+            if (!wt_sp_ready) SOLA_TRY(cast_fixed(wt, n_cat, ar.get("wt_sp"), k_in, n_cat, kLinScale));  // else transpose_into wrote the operand itself
+            wt_sp_ready = false;
             d.p[0].W = ar.get("wt_sp");
             d.arith = lowp_arith; d.bf16 = bf; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
         }
         return launch_gemm(d, s);
     };
     auto transpose_into = [&](const float* w, int n_out, int k_in, int n_cat, int col_off) -> int {
+        if (split && n_cat % (pure ? 64 : 32) == 0) {  // grad_x's condition for the reduced-precision GEMM: the operand is written directly
+            wt_sp_ready = true;
+            return launch_transpose_cast(w, ar.get("wt_sp"), n_out, k_in, k_in, n_cat, col_off, kLinScale, pure ? 1 + bf : 0, s);
+        }
         return launch_transpose(w, wt, n_out, k_in, k_in, n_cat, col_off, s);  // wt[k][col_off + n] = w[n][k]
     };
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,

@@ -183,6 +183,41 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// The same transposition written straight in a GEMM operand format (FMT 0 = split-f16 pairs in 8-value blocks [hi8 | lo8], 1 = f16,
+// 2 = bfloat16), scaled: out row c (pitch ldo VALUES) column col_off + r = scale * in[r][c].  One launch where the backward's dX GEMMs
+// ran a transposition into an f32 buffer and a cast of that buffer (two launches per weight matrix and step).
+template <int FMT>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ in, void* __restrict__ out, int rows, int cols, int ldi,
+                                                             int ldo, int col_off, float scale) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = in[(long long)r * ldi + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r >= rows || c >= cols) continue;
+        const float v = tile[tx][ty + 8 * i] * scale;
+        const long long n = col_off + r;
+        if (FMT == 0) {
+            _Float16 hi, lo;
+            split_f16(v, hi, lo);
+            _Float16* blk = reinterpret_cast<_Float16*>(static_cast<float*>(out) + (long long)c * ldo + (n & ~7LL)) + (n & 7);
+            blk[0] = hi;
+            blk[8] = lo;
+        } else if (FMT == 1) {
+            static_cast<_Float16*>(out)[(long long)c * ldo + n] = (_Float16)v;
+        } else {
+            static_cast<__bf16*>(out)[(long long)c * ldo + n] = (__bf16)v;
+        }
+    }
+}
+
 // out[(chunk * segments + seg)][c] (+)= scale * sum_{r in chunk of segment} in[(seg * seg_rows + r)][c]
 // block = 64 columns x 4 row lanes; grid.z splits long segments into row chunks (second launch adds the chunks up)
 // seg_stride: elements between the first rows of consecutive segments (seg_rows * ld for back-to-back segments).  out1 / split: output
@@ -287,6 +322,17 @@ int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, i
     SOLA_ARG(rows > 0 && cols > 0, "transpose: bad dims");
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * rows * cols);
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, out, rows, cols, ldi, ldo, col_off);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_transpose_cast(const float* in, void* out, int rows, int cols, int ldi, int ldo, int col_off, float scale, int fmt, hipStream_t s) {
+    SOLA_ARG(in && out && rows > 0 && cols > 0 && fmt >= 0 && fmt <= 2 && (fmt != 0 || ldo % 8 == 0), "transpose_cast: bad arguments (fmt %d ldo %d)", fmt, ldo);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (fmt == 0 ? 8.0 : 6.0) * rows * cols);
+    const dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    if (fmt == 0) hipLaunchKernelGGL(transpose_cast_kernel<0>, grid, dim3(256), 0, s, in, out, rows, cols, ldi, ldo, col_off, scale);
+    else if (fmt == 1) hipLaunchKernelGGL(transpose_cast_kernel<1>, grid, dim3(256), 0, s, in, out, rows, cols, ldi, ldo, col_off, scale);
+    else hipLaunchKernelGGL(transpose_cast_kernel<2>, grid, dim3(256), 0, s, in, out, rows, cols, ldi, ldo, col_off, scale);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -134,6 +134,8 @@ int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const*
                          const float* scale_dev, hipStream_t s);
 
 int launch_transpose(const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off, hipStream_t s);
+// out row c (pitch ldo values), column col_off + r = scale * in[r][c], written as a GEMM operand: fmt 0 = split-f16 pairs, 1 = f16, 2 = bf16
+int launch_transpose_cast(const float* in, void* out, int rows, int cols, int ldi, int ldo, int col_off, float scale, int fmt, hipStream_t s);
 size_t colsum_scratch_bytes(int segments, int seg_rows, int cols);
 int launch_colsum(const float* in, float* out, int segments, int seg_rows, int cols, int ld, float scale, int accumulate,
                   float* scratch, size_t scratch_bytes, hipStream_t s);
