@@ -213,7 +213,13 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             c->x16_arena = nullptr;
             c->x16_cap = 0;
             const size_t want = c->x16_need + c->x16_need / 8;
-            if (hipMalloc(&c->x16_arena, want) == hipSuccess) {
+            size_t mem_free = 0, mem_total = 0;
+            // the arena is a convenience, not a requirement: it takes at most half of what the device has free right now (the caller's
+            // allocator - torch's - needs the rest for the step's workspaces), else the backward casts as before
+            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || want > mem_free / 2) {
+                (void)hipGetLastError();
+                c->x16_off = true;
+            } else if (hipMalloc(&c->x16_arena, want) == hipSuccess) {
                 c->x16_cap = want;
             } else {  // no room: this step and the following ones cast in the backward as before
                 (void)hipGetLastError();
