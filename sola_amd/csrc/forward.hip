@@ -208,23 +208,25 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     c->x16.clear();
     if (keep16 || side16_on) {
         if (c->x16_need > c->x16_cap) {  // grow to what the last step asked for (+ 1/8: ragged batches differ from step to step)
-            SOLA_HIP(hipStreamSynchronize(s));
-            if (c->x16_arena) SOLA_HIP(hipFree(c->x16_arena));
-            c->x16_arena = nullptr;
-            c->x16_cap = 0;
             const size_t want = c->x16_need + c->x16_need / 8;
             size_t mem_free = 0, mem_total = 0;
-            // the arena is a convenience, not a requirement: it takes at most half of what the device has free right now (the caller's
-            // allocator - torch's - needs the rest for the step's workspaces), else the backward casts as before
-            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || want > mem_free / 2) {
-                (void)hipGetLastError();
-                c->x16_off = true;
-            } else if (hipMalloc(&c->x16_arena, want) == hipSuccess) {
-                c->x16_cap = want;
-            } else {  // no room: this step and the following ones cast in the backward as before
-                (void)hipGetLastError();
+            // the arena is a convenience, not a requirement: it takes at most half of what the device would have free without it (the
+            // caller's allocator - torch's - needs the rest for the step's workspaces); else it stays as it is and the casts that do
+            // not fit are made again by the backward
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && want <= (mem_free + c->x16_cap) / 2) {
+                SOLA_HIP(hipStreamSynchronize(s));
+                if (c->x16_arena) SOLA_HIP(hipFree(c->x16_arena));
                 c->x16_arena = nullptr;
-                c->x16_off = true;
+                c->x16_cap = 0;
+                if (hipMalloc(&c->x16_arena, want) == hipSuccess) {
+                    c->x16_cap = want;
+                } else {  // this step and the following ones cast in the backward as before
+                    (void)hipGetLastError();
+                    c->x16_arena = nullptr;
+                    c->x16_off = true;
+                }
+            } else {
+                (void)hipGetLastError();
             }
         }
         c->x16_used = 0;
