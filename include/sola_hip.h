@@ -471,6 +471,12 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "attn_f16_small" 1 (default) = the 16-byte-per-lane GroupNorm and the streaming short-sequence attention of precision 2).
  * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
+
+/* Measurement only (no reference counterpart): with sola_tune "gemm_trace" 1 the plain persistent split-f16 GEMM (no conv, no
+ * residual, f32 output) runs an instrumented instantiation that records, per (block, wave), the cycles spent at the k-tile wait +
+ * barrier, in the k-loops and in the epilogues, and real-time stamps per tile.  Copies the record of the last traced launch to
+ * `host` (device-synchronising); returns the bytes written, 0 if nothing was traced, < 0 on error.  Layout: tools/gemm_trace.py. */
+long long sola_gemm_trace_read(void* host, long long bytes);
 /* In-library kernel timing: two HIP events on the launch stream around every kernel launch.  enable 0 = off, 1 = every category,
  * a larger value = only the categories c with bit (c + 1) set (each timed launch costs two event records, ~1.5 us of stream time
  * each: 2.8 % of the headline step with every category on, tools/prof_overhead.py). */

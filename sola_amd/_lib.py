@@ -128,6 +128,7 @@ SIGNATURES = {
     "sola_grad_sqnorms": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "sola_grad_clip": (_i, [_vp, _vp, _i, _vp, _f, _vp]),
     "sola_tune": (_i, [C.c_char_p, _i]),
+    "sola_gemm_trace_read": (C.c_longlong, [_vp, C.c_longlong]),
     "sola_profile_enable": (_i, [_i]),
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
 }
@@ -162,6 +163,11 @@ def lib():
             raise SolaLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    # kernel experiments only: SOLA_TUNE="key=value,key=value" applies sola_tune settings at load time (tools/, never the tests or bench defaults)
+    for kv in filter(None, os.environ.get("SOLA_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        if h.sola_tune(k.strip().encode(), int(v)) != 0:
+            raise SolaLibraryError(f"SOLA_TUNE: unknown key {k!r}")
     _lib = h
     return h
 

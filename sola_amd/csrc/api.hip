@@ -264,6 +264,7 @@ void sola_gemm_set_variant(int v);
 void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
 extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr, g_train_x16_keep;
+extern int g_gemm_stagger, g_gemm_order, g_gemm_trace, g_gemm_ld;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
 void sola_set_train_split_min_rows(int v);
@@ -309,6 +310,10 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_nw4")) { g_gemm_nw4 = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_k16")) { g_gemm_k16 = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_order")) { g_gemm_order = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_trace")) { g_gemm_trace = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_ld")) { g_gemm_ld = value; return SOLA_OK; }
     if (!strcmp(key, "train_tn_tr")) { g_train_tn_tr = value; return SOLA_OK; }
     if (!strcmp(key, "train_x16_keep")) { g_train_x16_keep = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }

@@ -58,7 +58,12 @@ struct GldsArgs {
     const float *gn_gamma, *gn_beta;
     int gn_tokens;
     float gn_eps, gn_slope, gn_icnt;  // gn_icnt = 1 / (gn_tokens * 64)
+    // persistent kernel, measurement (sola_tune "gemm_stagger" / "gemm_order" / "gemm_trace"; all 0 in production)
+    int stagger;  // > 0: block b sleeps ((b >> 3) % 4) * stagger * 64 clocks before its first tile (de-synchronises the CUs' epilogues)
+    int order;    // tile order variant (decode())
+    unsigned long long* trace;  // TRACE instantiation: per (block, wave) record, see gemm_trace_words
 };
+constexpr int gemm_trace_words = 8 + 2 * 64;  // 64-bit words per (block, wave): sums, then the tiles' stamps (lane t = tile t of the block)
 
 __device__ __forceinline__ void guard_sp16x4(int* guard, const float (&v)[4]) {
     const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -894,8 +899,15 @@ __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
 // instance, reduced over the wave (DPP + permlane swaps, no LDS), then (v - mean) * rstd * gamma + beta, LeakyReLU, split-f16
 // store - the GroupNorm launch and its read of the f32 conv output disappear (norm.hip's register shapes moved 8 bytes per
 // element for them).  GNT is a template parameter: the eight unrolled strips carry one variant of the statistics, not three.
-template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8>
+// LD != 0 (round 4, plain rows): ONE wave of each SIMD's pair issues the whole DMA stream - LD = 1 the first-dispatched waves 0..3, LD = 2
+// waves 4..7 - 16 pieces per k-tile instead of 8 per wave, as buffer loads (32-bit per-lane offsets + scalar row offsets, rows beyond M / N
+// come back as zeros from the descriptor's bounds check).  Why: the SIMD arbitrates its two waves oldest-first, so the waves do not interleave
+// their MFMAs - the older one runs ahead and parks at the k-tile barrier (45 % of its k-loop time, tools/gemm_trace.py) while the younger one
+// finishes alone, with nobody to cover the ~100 cycles each of its DMA issues costs.  With the DMA on one wave of the pair, that wave's issue
+// stalls are covered by the partner's MFMAs and the partner's stream has no stalls to cover.
+template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8, int TRACE = 0, int LD = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(const GldsArgs a) {
+    static_assert(LD == 0 || (!CONV && NW == 8), "the loader-wave DMA stream is built for plain rows and eight waves");
     // NW = 8: 256x256 tiles, 2 x 4 waves, two waves per SIMD.  NW = 4 (experiment, sola_tune "gemm_nw4"): 256x128 tiles, 2 x 2 waves, one
     // wave per SIMD and up to 512 registers each
     constexpr int MI = 4, WAVES_N = NW / 2, GBM = 256, GBN = WAVES_N * 64, NWAVE = NW;
@@ -917,7 +929,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
     const int total = a.tiles_m * tiles_row;
     auto decode = [&](int tile, int& z, int& ks, int& m0, int& n0) {
         int rt, c;
-        if (a.xcd_remap) {
+        if (a.xcd_remap && a.order == 1 && (tiles_row & 3) == 0 && (a.tiles_m & 63) == 0) {
+            // measurement: an XCD's 32 CUs share 8 row panels x 4 column tiles per round (W tile re-read by 8 CUs instead of 32 / tiles_row)
+            const int x = tile & 7, j = tile >> 3;         // j = index within the XCD
+            const int g = j >> 5, l = j & 31;              // round group of 32 tiles, slot
+            const int cg = tiles_row >> 2;                 // column groups of 4 tiles
+            const int rg = g / cg;                         // row-panel group (8 panels) of this XCD
+            c = (g - rg * cg) * 4 + (l & 3);
+            rt = x + 8 * (rg * 8 + (l >> 2));
+        } else if (a.xcd_remap) {
             const int x = tile & 7, j = tile >> 3;
             rt = x + 8 * (j / tiles_row);
             c = j % tiles_row;
@@ -1008,6 +1028,50 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         }
         ++dma_kt;
     };
+    // ---- LD: the loader waves' stream.  Loader l (0..3) owns pieces l * 8 .. l * 8 + 7 of the A tile and of the W tile; a piece's source =
+    //      descriptor base (the tile's first row) + per-lane offset (row within the piece, swizzled chunk: the key's bit 2 is the piece's
+    //      parity, so two offsets per operand) + scalar offset (k position + the piece's first row)
+    constexpr int APL = GBM / 8 / 4, WPL = GBN / 8 / 4;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LD == 0 || (LD == 1 ? wave_s < 4 : wave_s >= 4);
+    const int lw = LD == 2 ? wave_s - 4 : wave_s;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(zero), 0, 0, 0x00020000), rs_w = rs_a;
+    int a_so = 0, w_so = 0;
+    int a_vo[2] = {0, 0}, w_vo[2] = {0, 0};
+    const int a_pitch8 = a.lda * 32, w_pitch8 = a.K * 32;  // bytes between pieces (8 rows)
+    if constexpr (LD != 0) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int cb = (chunk ^ (lrow >> 1) ^ (par << 2)) << 4;
+            a_vo[par] = lrow * a.lda * 4 + cb;
+            w_vo[par] = lrow * a.K * 4 + cb;
+        }
+    }
+    auto setup_dma_ld = [&](int tile) {
+        int z, ks, m0, n0;
+        decode(tile, z, ks, m0, n0);
+        const int k0 = ks * nk * GBK;
+        const float* Ab = a.p[z].A + (long long)m0 * a.lda;
+        const float* Wb = a.p[z].W + (long long)n0 * a.K;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, min(GBM, a.M - m0) * a.lda * 4, 0x00020000);
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wb), 0, min(GBN, a.N - n0) * a.K * 4, 0x00020000);
+        a_so = k0 * 4 + lw * APL * a_pitch8;
+        w_so = k0 * 4 + lw * WPL * w_pitch8;
+        dma_kt = 0;
+    };
+    auto issue_ld = [&](int stage) {
+        char* sbase = lds + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < APL; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sbase + (lw * APL + i) * 1024), 16, a_vo[i & 1], a_so + i * a_pitch8, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WPL; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sbase + GBM * ROWB + (lw * WPL + i) * 1024), 16, w_vo[i & 1], w_so + i * w_pitch8, 0, 0);
+        const int adv = dma_kt + 1 < nk ? GBK * 4 : 0;
+        a_so += adv;
+        w_so += adv;
+        ++dma_kt;
+    };
 
     const int fr = lane & 31, fh = lane >> 5, key = (lane >> 1) & 7;
     const int a_frag = (wr * MI * 32 + fr) * ROWB, w_frag = GBM * ROWB + (wc * 64 + fr) * ROWB;
@@ -1050,20 +1114,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
 
     int tile = blockIdx.x;
     if (tile >= total) return;
+    if (a.stagger > 0) {  // measurement: four start phases, neighbouring CUs of an XCD in different ones
+        const int ph = (blockIdx.x >> 3) & 3;
+        for (int q = 0; q < ph * a.stagger; ++q) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+    }
+    // TRACE: cycles this wave spent at the k-tile wait + barrier, in the k-loops and in the epilogues; per tile the real-time stamps
+    // (100 MHz, low 32 bits) of the end of its k-loop and of its epilogue, lane t of two registers = tile t of this block
+    unsigned long long tr_wait = 0, tr_loop = 0, tr_epi = 0, tr_t0 = 0, tr_t1 = 0, tr_first = 0;
+    int tr_kend = 0, tr_eend = 0, tr_n = 0;
+    if constexpr (TRACE) tr_first = wall_clock64();
     bool prev_fast = false;  // the previous tile of this block left through the interior epilogue
-    setup_dma(tile);
-    issue(0);
-    issue(1);  // nk >= 2 (checked by the launcher)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");  // k-tile 0 is the older half of what is in flight
+    if constexpr (LD == 0) {
+        setup_dma(tile);
+        issue(0);
+        issue(1);  // nk >= 2 (checked by the launcher)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + WPW) : "memory");  // k-tile 0 is the older half of what is in flight
+    } else if (loader) {
+        setup_dma_ld(tile);
+        issue_ld(0);
+        issue_ld(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APL + WPL) : "memory");
+    }
     __syncthreads();
     int stage = 0;
     constexpr int NRD = 2 * MI + 4, NMF = (PURE ? 4 : 6) * MI;
     constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
+    constexpr int NDMA_L = APL + WPL, DMA_GAP_L = (NMF - 1) / NDMA_L;  // loader waves: one piece behind every MFMA of the second half
+    static_assert(LD == 0 || DMA_GAP_L >= 1, "the loader's pieces must fit behind the second half's MFMAs");
     for (; tile < total; tile += gridDim.x) {
         int z, ks, m0, n0;
         decode(tile, z, ks, m0, n0);
         const int next = tile + gridDim.x;
         const bool has_next = next < total;
+        unsigned long long tr_ls = 0;
+        if constexpr (TRACE) tr_ls = clock64();
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1078,47 +1162,91 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         // One k-tile.  The k-loop itself must stay free of conditions: a scalar branch in front of the barrier (the relaxed
         // wait below) or behind it (switching the DMA stream to the next tile) cost 10 % and 2 % of the loop (measured,
         // one tile per CU), so the first k-tile is peeled for the wait and the last two for the stream switch.
-        auto ktile = [&](auto first) {
+        auto ktile = [&](auto first, auto rolec) {
+            constexpr int ROLE = decltype(rolec)::value;  // 0: every wave loads its share (LD = 0); 1: loader wave; 2: its partner (no DMA)
+            if constexpr (TRACE) tr_wait += tr_t1 - tr_t0;  // the previous k-tile's wait (both stamps have long returned)
             load_frags(lds + stage * STAGE_BYTES, 1, f1);
             mfmas(f0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TRACE) tr_t0 = clock64();
             // k-tile kt+1 has landed.  At kt == 0 behind an interior tile's epilogue that is k-tile 1, issued BEFORE the
             // epilogue's stores: naming the store count (32 float4 or 64 half4 stores per wave; the counter is in order)
             // waits for the DMA without waiting for the stores to be acknowledged.
-            if (decltype(first)::value && prev_fast) {
-                if (CSP == 1) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (ROLE != 2) {  // the partner of a loader wave has no DMA in flight: its stores need no wait
+                if (decltype(first)::value && prev_fast) {
+                    if (CSP == 1) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
             __syncthreads();
+            if constexpr (TRACE) tr_t1 = clock64();
             __builtin_amdgcn_sched_barrier(0);
             load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);  // after the last k-tile: unused
-            issue(stage);
+            if constexpr (ROLE == 0) issue(stage);
+            if constexpr (ROLE == 1) issue_ld(stage);
             mfmas(f1);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            if constexpr (ROLE == 0) {
 #pragma unroll
-            for (int g = 0; g < NDMA; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                for (int g = 0; g < NDMA; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
+            } else if constexpr (ROLE == 1) {
+#pragma unroll
+                for (int g = 0; g < NDMA_L; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP_L, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA_L * DMA_GAP_L, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
             __builtin_amdgcn_sched_barrier(0);
             stage ^= 1;
         };
         // k-tile kt issues the DMA of k-tile kt+2; from kt = nk-2 on that is the next tile's stream
-        int kt = 1;
-        if (nk == 2 && has_next) setup_dma(next);
-        ktile(std::true_type{});
-        for (; kt < nk - 2; ++kt) ktile(std::false_type{});
-        if (nk > 2 && has_next) setup_dma(next);
-        for (; kt < nk; ++kt) ktile(std::false_type{});
+        auto kloop = [&](auto rolec) {
+            constexpr int ROLE = decltype(rolec)::value;
+            auto switch_stream = [&]() {
+                if constexpr (ROLE == 0) setup_dma(next);
+                if constexpr (ROLE == 1) setup_dma_ld(next);
+            };
+            int kt = 1;
+            if (nk == 2 && has_next) switch_stream();
+            ktile(std::true_type{}, rolec);
+            for (; kt < nk - 2; ++kt) ktile(std::false_type{}, rolec);
+            if (nk > 2 && has_next) switch_stream();
+            for (; kt < nk; ++kt) ktile(std::false_type{}, rolec);
+        };
+        if constexpr (LD == 0) kloop(std::integral_constant<int, 0>{});
+        else if (loader) kloop(std::integral_constant<int, 1>{});
+        else kloop(std::integral_constant<int, 2>{});
+        unsigned long long tr_es = 0;
+        if constexpr (TRACE) {
+            tr_wait += tr_t1 - tr_t0;
+            tr_t0 = tr_t1 = 0;
+            tr_es = clock64();
+            tr_loop += tr_es - tr_ls;
+            tr_kend = lane == (tr_n & 63) ? (int)wall_clock64() : tr_kend;
+        }
+        auto trace_tile_end = [&]() {
+            if constexpr (TRACE) {
+                tr_epi += clock64() - tr_es;
+                tr_eend = lane == (tr_n & 63) ? (int)wall_clock64() : tr_eend;
+                ++tr_n;
+            }
+        };
         if (a.ablate & 4) {
             prev_fast = false;  // no stores went out: the next tile's first wait must be the full one
+            trace_tile_end();
             continue;
         }
 
@@ -1306,6 +1434,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                 }
             }
             if (CSP != 0 && a.guard && out_of_range != 0 && lane_e == 0) atomicOr(a.guard, 1);
+            trace_tile_end();
             continue;
         }
 #pragma unroll
@@ -1385,6 +1514,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
+        }
+        trace_tile_end();
+    }
+    if constexpr (TRACE) {
+        if (a.trace) {
+            unsigned long long* rec = a.trace + ((long long)blockIdx.x * NWAVE + wave) * gemm_trace_words;
+            if (lane == 0) {
+                rec[0] = tr_wait; rec[1] = tr_loop; rec[2] = tr_epi; rec[3] = (unsigned long long)tr_n;
+                rec[4] = tr_first; rec[5] = wall_clock64(); rec[6] = (unsigned long long)nk; rec[7] = 0;
+            }
+            rec[8 + lane] = (unsigned)tr_kend;
+            rec[8 + 64 + lane] = (unsigned)tr_eend;
         }
     }
 }
@@ -1809,6 +1950,17 @@ int g_gemm_nw4 = 0;  // experiment (sola_tune "gemm_nw4"): plain f32-output laun
 int g_gemm_k16 = 0;  // experiment (sola_tune "gemm_k16"): 256x128 tiles, 16-deep k-tiles, two four-wave blocks per CU
 int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per CU walks the tiles), 0 = one tile per block
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
+// measurement switches of the persistent kernel (sola_tune "gemm_stagger" / "gemm_order" / "gemm_trace"), all off in production
+int g_gemm_stagger = 0, g_gemm_order = 0, g_gemm_trace = 0, g_gemm_ld = 0;
+static unsigned long long* g_trace_buf = nullptr;  // [1024 blocks][8 waves][gemm_trace_words], allocated on first use
+constexpr size_t TRACE_BYTES = (size_t)1024 * 8 * gemm_trace_words * 8;
+// copies the trace of the LAST traced launch to the host (synchronises the device); returns the number of bytes written, < 0 on error
+extern "C" long long sola_gemm_trace_read(void* host, long long bytes) {
+    if (!g_trace_buf) return 0;
+    const size_t n = (size_t)bytes < TRACE_BYTES ? (size_t)bytes : TRACE_BYTES;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, g_trace_buf, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)n;
+}
 
 template <bool CONV, int PURE>
 static int launch_k16(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
@@ -1827,7 +1979,7 @@ static int launch_k16(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     return SOLA_OK;
 }
 
-template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8>
+template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8, int TRACE = 0, int LD = 0>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     constexpr int GBN = NW / 2 * 64;
     a.tiles_m = (M + 255) / 256;
@@ -1838,14 +1990,14 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT, NW>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT, NW, TRACE, LD>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const int n_cu = sola_cu_count();
     const int total = a.tiles_m * a.tiles_n * nprob * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = total < n_cu ? total : n_cu;
-    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_split_glds_persist_kernel<CONV, RMODE, CSP, PURE, GNT, NW, TRACE, LD>), dim3(grid), dim3(NW * 64), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -1893,6 +2045,23 @@ static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
         return rmode == 2 ? launch_persist_t<false, 2, 1>(a, M, N, nprob, s) : launch_persist_t<false, 1, 1>(a, M, N, nprob, s);
     }
     if (g_gemm_nw4 && !CONV && rmode == 0 && a.ksplit <= 1) return launch_persist_t<false, 0, 0, false, 0, 4>(a, M, N, nprob, s);  // experiment
+    // experiment (sola_tune "gemm_ld"): one wave of each SIMD's pair issues the whole DMA stream; 32-bit buffer offsets: rows within 2 GiB
+    const int ld = (!CONV && g_gemm_ld && (long long)256 * a.lda * 4 < (1LL << 31) && (long long)256 * a.K * 4 < (1LL << 31)) ? g_gemm_ld : 0;
+    if (g_gemm_trace && !CONV && rmode == 0) {  // measurement: the plain instantiation with cycle stamps
+        if (!g_trace_buf && hipMalloc(&g_trace_buf, TRACE_BYTES) != hipSuccess) g_trace_buf = nullptr;
+        if (g_trace_buf) {
+            (void)hipMemsetAsync(g_trace_buf, 0, TRACE_BYTES, s);
+            a.trace = g_trace_buf;
+            if constexpr (!CONV) {
+                if (ld == 1) return launch_persist_t<false, 0, 0, 0, 0, 8, 1, 1>(a, M, N, nprob, s);
+                if (ld == 2) return launch_persist_t<false, 0, 0, 0, 0, 8, 1, 2>(a, M, N, nprob, s);
+            }
+            return launch_persist_t<false, 0, 0, 0, 0, 8, 1>(a, M, N, nprob, s);
+        }
+    }
+    if constexpr (!CONV) {
+        if (ld && rmode == 0) return ld == 1 ? launch_persist_t<false, 0, 0, 0, 0, 8, 0, 1>(a, M, N, nprob, s) : launch_persist_t<false, 0, 0, 0, 0, 8, 0, 2>(a, M, N, nprob, s);
+    }
     if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);
     return rmode == 2 ? launch_persist_t<false, 2, 0>(a, M, N, nprob, s) : launch_persist_t<false, 1, 0>(a, M, N, nprob, s);
 }
@@ -1976,6 +2145,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.c_sp16 = d.c_sp16;
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
+    a.stagger = g_gemm_stagger; a.order = g_gemm_order; a.trace = nullptr;
     a.guard = (d.c_sp16 || d.c_f16) ? d.guard : nullptr;
     a.gn_gamma = d.gn_gamma; a.gn_beta = d.gn_beta; a.gn_tokens = d.gn_tokens; a.gn_eps = d.gn_eps; a.gn_slope = d.gn_slope;
     a.gn_icnt = d.gn_tokens > 0 ? 1.0f / (64.0f * (float)d.gn_tokens) : 0.f;
