@@ -919,6 +919,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    // the thread id re-derived where a tile's set-up or epilogue needs it (scalar wave index + lane count): no register holds it across the k-loops
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto fresh_tid = [&](int salt) {  // `salt`: a value of the current tile, so that the lane count is not computed once and kept (spilled)
+        int l;
+        asm("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l) : "s"(salt));
+        return wave_s * 64 + l;
+    };
     const int ks_n = a.ksplit > 1 ? a.ksplit : 1;
     const int nk = a.ksplit > 1 ? a.kper : a.K / GBK;
 
@@ -967,6 +974,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         const int k0 = ks * nk * GBK;  // first reduction index of this work item
         const float* A = a.p[z].A + k0;
         const float* Wt = a.p[z].W + k0;
+        // lane coordinates from an opaque, tile-dependent copy of the thread id: derived once per kernel, everything this set-up computes from
+        // them (row offsets, swizzled columns) is hoisted out of the tile loop and kept - spilled - across the k-loops (round 4)
+        const int lt = fresh_tid(tile);
+        const int wave = lt >> 6, lrow = (lt >> 3) & 7, chunk = lt & 7;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int r = (wave * APW + i) * 8 + lrow;
@@ -1003,18 +1014,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         conv_c = CONV ? k0 - conv_kk * a.Cin : 0;
         dma_kt = 0;
     };
-    auto issue = [&](int stage) {
+    // piece q of this wave's share of a k-tile: q < APW = A piece q, else W piece q - APW
+    auto issue_piece = [&](int stage, int q) {
         char* sbase = lds + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const char* src = a_ptr0 + a_d[i];
-            if (CONV) src = ((a_t0[i] >> conv_kk) & 1) ? src : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + i) * 1024), 16, 0, 0);
+        if (q < APW) {
+            const char* src = a_ptr0 + a_d[q];
+            if (CONV) src = ((a_t0[q] >> conv_kk) & 1) ? src : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + q) * 1024), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr0 + w_d[q - APW]), (lptr_t)(sbase + GBM * ROWB + (wave * WPW + q - APW) * 1024), 16, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr0 + w_d[i]), (lptr_t)(sbase + GBM * ROWB + (wave * WPW + i) * 1024), 16, 0, 0);
-        }
+    };
+    auto issue_advance = [&]() {
         // past the last k-tile of the last tile the stream re-reads that k-tile (see the one-tile kernel)
         const bool more = dma_kt + 1 < nk;
         const int adv = more ? GBK * 4 : 0;
@@ -1028,11 +1039,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         }
         ++dma_kt;
     };
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int q = 0; q < APW + WPW; ++q) issue_piece(stage, q);
+        issue_advance();
+    };
     // ---- LD: the loader waves' stream.  Loader l (0..3) owns pieces l * 8 .. l * 8 + 7 of the A tile and of the W tile; a piece's source =
     //      descriptor base (the tile's first row) + per-lane offset (row within the piece, swizzled chunk: the key's bit 2 is the piece's
     //      parity, so two offsets per operand) + scalar offset (k position + the piece's first row)
     constexpr int APL = GBM / 8 / 4, WPL = GBN / 8 / 4;
-    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = LD == 0 || (LD == 1 ? wave_s < 4 : wave_s >= 4);
     const int lw = LD == 2 ? wave_s - 4 : wave_s;
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(zero), 0, 0, 0x00020000), rs_w = rs_a;
@@ -1059,18 +1074,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         w_so = k0 * 4 + lw * WPL * w_pitch8;
         dma_kt = 0;
     };
-    auto issue_ld = [&](int stage) {
+    auto issue_piece_ld = [&](int stage, int q) {
         char* sbase = lds + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < APL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sbase + (lw * APL + i) * 1024), 16, a_vo[i & 1], a_so + i * a_pitch8, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WPL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sbase + GBM * ROWB + (lw * WPL + i) * 1024), 16, w_vo[i & 1], w_so + i * w_pitch8, 0, 0);
+        if (q < APL) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sbase + (lw * APL + q) * 1024), 16, a_vo[q & 1], a_so + q * a_pitch8, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sbase + GBM * ROWB + (lw * WPL + q - APL) * 1024), 16, w_vo[(q - APL) & 1], w_so + (q - APL) * w_pitch8, 0, 0);
+    };
+    auto issue_advance_ld = [&]() {
         const int adv = dma_kt + 1 < nk ? GBK * 4 : 0;
         a_so += adv;
         w_so += adv;
         ++dma_kt;
+    };
+    auto issue_ld = [&](int stage) {
+#pragma unroll
+        for (int q = 0; q < APL + WPL; ++q) issue_piece_ld(stage, q);
+        issue_advance_ld();
     };
 
     const int fr = lane & 31, fh = lane >> 5, key = (lane >> 1) & 7;
@@ -1093,23 +1111,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         }
     };
     f32x16 acc[MI][2];
-    auto mfmas = [&](const Frags& f) {
+    // The same fragments and products in four GROUPS per half (one A row block each): the next half's fragments are fetched group by
+    // group - B and A block 0 behind group 0's first MFMA, A block g behind group g's - so that a half holds at most 72 fragment
+    // registers instead of two whole sets (96): the kernel stays inside its 256 registers without scratch (round 4).
+    auto load_b = [&](const char* sbase, int s16, Frags& f) {
+        const int hi_off = (((s16 * 2 + fh) * 2) ^ key) << 4, lo_off = hi_off ^ 16;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const char* q = sbase + w_frag + j * 32 * ROWB;
+            f.bh[j] = *reinterpret_cast<const half8*>(q + hi_off);
+            f.bl[j] = *reinterpret_cast<const half8*>(q + lo_off);
+        }
+    };
+    auto load_a = [&](const char* sbase, int s16, Frags& f, int i) {
+        const int hi_off = (((s16 * 2 + fh) * 2) ^ key) << 4, lo_off = hi_off ^ 16;
+        const char* p = sbase + a_frag + i * 32 * ROWB;
+        f.ah[i] = *reinterpret_cast<const half8*>(p + hi_off);
+        f.al[i] = *reinterpret_cast<const half8*>(p + lo_off);
+    };
+    auto for_groups = [&](auto&& fn) {
+        static_assert(MI == 4, "four A row blocks per wave tile");
+        fn(std::integral_constant<int, 0>{}); fn(std::integral_constant<int, 1>{}); fn(std::integral_constant<int, 2>{}); fn(std::integral_constant<int, 3>{});
+    };
+    auto mfma_group = [&](const Frags& f, int i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if constexpr (PURE == 2) {  // bf16 operands: the same 16-byte chunks, v_mfma_f32_32x32x16_bf16
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
-                } else if constexpr (PURE == 1) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-                } else {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-                }
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (PURE == 2) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+            } else if constexpr (PURE == 1) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
             }
+        }
     };
 
     int tile = blockIdx.x;
@@ -1164,13 +1202,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         // one tile per CU), so the first k-tile is peeled for the wait and the last two for the stream switch.
         auto ktile = [&](auto first, auto rolec) {
             constexpr int ROLE = decltype(rolec)::value;  // 0: every wave loads its share (LD = 0); 1: loader wave; 2: its partner (no DMA)
+            constexpr int MPG = NMF / MI;                  // MFMAs of one group (one A row block): 6 split, 4 plain 16-bit
+            constexpr int NP = ROLE == 0 ? NDMA : (ROLE == 1 ? NDMA_L : 0), PPG = NP / MI;  // DMA pieces of this wave per k-tile / per group
+            constexpr int GAP = PPG > 0 ? (MPG - 1) / PPG : 0;                                // MFMAs in front of each of a group's pieces
+            static_assert(NP % MI == 0 && (PPG == 0 || GAP >= 1), "a group's DMA pieces must fit between its MFMAs");
             if constexpr (TRACE) tr_wait += tr_t1 - tr_t0;  // the previous k-tile's wait (both stamps have long returned)
-            load_frags(lds + stage * STAGE_BYTES, 1, f1);
-            mfmas(f0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            // ---- first half: products of k 0..15 (f0); the fragments of k 16..31 of the same stage arrive group by group
+            {
+                const char* sb = lds + stage * STAGE_BYTES;
+                for_groups([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if (g == 0) load_b(sb, 1, f1);
+                    load_a(sb, 1, f1, g);
+                    mfma_group(f0, g);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, g == 0 ? 6 : 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG - 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
             if constexpr (TRACE) tr_t0 = clock64();
             // k-tile kt+1 has landed.  At kt == 0 behind an interior tile's epilogue that is k-tile 1, issued BEFORE the
             // epilogue's stores: naming the store count (32 float4 or 64 half4 stores per wave; the counter is in order)
@@ -1186,30 +1236,36 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
             __syncthreads();
             if constexpr (TRACE) tr_t1 = clock64();
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(lds + (stage ^ 1) * STAGE_BYTES, 0, f0);  // after the last k-tile: unused
-            if constexpr (ROLE == 0) issue(stage);
-            if constexpr (ROLE == 1) issue_ld(stage);
-            mfmas(f1);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-            if constexpr (ROLE == 0) {
+            // ---- second half: products of k 16..31 (f1); the next k-tile's first fragments (the other stage) arrive group by group and
+            //      the DMA pieces of k-tile kt+2 go into the stage every wave has just left, spread over the MFMAs (issued back to back they
+            //      queue in the CU's one texture-address path and a wave stuck at a full memory queue issues no MFMAs: tools/micro/lds_dma.hip)
+            {
+                const char* sb = lds + (stage ^ 1) * STAGE_BYTES;  // after the last k-tile: read, never used
+                for_groups([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if (g == 0) load_b(sb, 0, f0);
+                    load_a(sb, 0, f0, g);
 #pragma unroll
-                for (int g = 0; g < NDMA; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA * DMA_GAP, 0);
-            } else if constexpr (ROLE == 1) {
+                    for (int q = 0; q < PPG; ++q) {
+                        if constexpr (ROLE == 0) issue_piece(stage, g * PPG + q);
+                        if constexpr (ROLE == 1) issue_piece_ld(stage, g * PPG + q);
+                    }
+                    if (g == MI - 1) {
+                        if constexpr (ROLE == 0) issue_advance();
+                        if constexpr (ROLE == 1) issue_advance_ld();
+                    }
+                    mfma_group(f1, g);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, g == 0 ? 6 : 2, 0);
 #pragma unroll
-                for (int g = 0; g < NDMA_L; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, DMA_GAP_L, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - NDMA_L * DMA_GAP_L, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+                    for (int q = 0; q < PPG; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG - 1 - PPG * GAP, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             }
-            __builtin_amdgcn_sched_barrier(0);
             stage ^= 1;
         };
         // k-tile kt issues the DMA of k-tile kt+2; from kt = nk-2 on that is the next tile's stream
@@ -1263,7 +1319,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         // Everything the epilogue derives from the lane id goes through an opaque copy made here: otherwise the row
         // offsets of all 32 passes (64-bit, tile-invariant) are hoisted out of the tile loop and live - spilled - across
         // the k-loop.
-        int le = tid;
+        int le = fresh_tid(tile);
         asm volatile("" : "+v"(le));
         const int lane_e = le & 63, wave_e = le >> 6;
         const int fh_e = lane_e >> 5;

@@ -256,6 +256,32 @@ def test_row_major_weight_gradient_kernel_code_object():
         assert "scratch_" not in body, f"{nm} spills to scratch"
 
 
+def test_persistent_split_gemm_instantiations_do_not_spill():
+    """every instantiation of the persistent split-f16 GEMM that launch_* selects by default - conv and plain rows, the
+    residual / output formats, plain f16 / bf16 operands, the fused-GroupNorm epilogues - keeps its vector registers inside the 256 of two
+    waves per SIMD: .vgpr_spill_count == 0, no scratch segment, and no scratch instruction anywhere in the kernel (so none between the first
+    and the last MFMA of a k-loop).  The experiments (four-wave shapes, trace and loader-wave instantiations, gemm_pp) are not held to it."""
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import co_regs
+    obj = os.path.join(root, "build", "obj", "gemm_glds.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(co_regs.LLVM, "llvm-readelf")):
+        pytest.skip("gemm_glds.o not built here (run __graft_entry__.build()) or no llvm-readelf")
+    rows = [r for r in co_regs.kernel_table(obj) if "gemm_nt_split_glds_persist_kernel<" in r["demangled"]]
+    default = [r for r in rows if re.search(r"persist_kernel<(true|false), \d+, \d+, \d+, \d+, 8, 0, 0>", r["demangled"])]
+    assert len(default) >= 23, [r["demangled"] for r in rows]
+    dis, _ = _code_object_text("gemm_glds.o")
+    for r in default:
+        assert r["spill"] == 0 and r["scratch"] == 0, (r["demangled"], r["spill"], r["scratch"])
+        assert r["vgpr"] + r["agpr"] <= 256, (r["demangled"], r["vgpr"], r["agpr"])
+        body = dis[dis.index(f"<{r['name']}>:"):]
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body, f"{r['demangled']} touches scratch"
+        assert body.count("v_mfma_f32_32x32x16") >= 96, r["demangled"]
+
+
 def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
     """What bench.py's headline measures is what a user of the classes and entry points gets."""
     monkeypatch.delenv("SOLA_PRECISION", raising=False)
