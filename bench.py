@@ -232,8 +232,8 @@ def cpu_baseline(cfg, sd, N, T, L, budget_s):
     model, phys = cpu_info()
     return {"value": round(it / el, 3), "unit": "samples/s", "cores": best, "kind": "port", "cpu_model": model, "physical_cores": phys,
             "logical_cpus": ncpu, "one_thread_value": round(1.0 / trials[1], 3) if 1 in trials else None,
-            "sample": f"{it} batch-1 forward+loss iterations of the PyTorch-CPU oracle at (T={T},N={N},L={L}) in {el:.1f} s with "
-                      f"torch.set_num_threads({best}) (best of sweep {sweep}; host: {model}, {phys} physical cores, {ncpu} logical CPUs)"}
+            "sample": f"{it} batch-1 fwd+loss iterations of the PyTorch-CPU oracle at (T={T},N={N},L={L}) in {el:.1f} s, {best} threads",
+            "thread_sweep": sweep}
 
 
 def training_leg(cfg, sd, dev, B, N, T, L, steps):
@@ -651,6 +651,75 @@ def iou_leg(dev, cpu_seconds):
     return res
 
 
+# ------------------------------------------------------------------------------------------------------ the printed line
+# The driver keeps a bounded tail of stdout: the line that goes there carries NUMBERS (every leg, short keys) and stays under ~6 KB; the
+# prose that explains a field lives in DESIGN.md 5 ("Fields of the bench line"), and the verbose object - every string this file
+# builds - is written next to it as gpurun_out/bench_full.json (or $SOLA_BENCH_FULL).
+_DROP = {"what", "tolerance", "shapes", "traffic_source", "traffic_kernel", "kernel_ms_per_step_source", "frac_algorithmic",
+         "algorithmic_vs_f32_mfma_peak", "gflop_per_sample_reference", "object_token_rows", "launches_per_call", "algorithmic_bytes",
+         "physical_cores", "logical_cpus", "seed", "thread_sweep", "videos", "pairs", "gflop_per_sample_fwd_bwd", "model_tflops_reference",
+         "executed_vs_uniform_batch_model_tflops", "pairs_per_s", "workload"}
+_DROP_NESTED = {"model_tflops", "gflop_per_sample", "achieved", "avg_launch_us", "launches", "share_of_step_time", "steps", "dtype"}  # below the top level and its two rooflines
+_KEEP_KERNEL_MS = {("kernel_ms_per_step",), ("training_step", "ragged", "f16x3", "kernel_ms_per_step"),
+                   ("training_step", "ragged", "f16", "kernel_ms_per_step"), ("training_step", "f16x3", "kernel_ms_per_step")}
+_CONTRACT_ROOFLINES = {("roofline",), ("roofline_attention",)}
+
+
+def _sig(x, n=4):
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0 or not np.isfinite(x):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def compact(o, path=()):
+    """The short form of the result object: explanatory strings, duplicated fields and most per-leg kernel tables dropped, kernel names cut
+    at their template list, floats to four significant digits.  Contract keys of the top level and of its two rooflines are untouched."""
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            p = path + (k,)
+            if k in _DROP and p != ("config", "workload"):
+                continue
+            if k in _DROP_NESTED and len(path) > 0 and path not in _CONTRACT_ROOFLINES:
+                continue
+            if k in ("kernel_ms_per_step", "kernel_ms_per_launch") and p not in _KEEP_KERNEL_MS:
+                continue
+            if k == "f32_mfma_side" and isinstance(v, dict):
+                out["mfma_frac"] = _sig(v.get("frac"))
+                continue
+            if k == "fused_norm_launches" and isinstance(v, dict) and not v.get("launches"):
+                continue
+            if k in ("unit", "peak", "bound") and len(path) > 0 and path not in _CONTRACT_ROOFLINES and path != ("cpu_baseline",):
+                continue
+            if k == "kernel" and isinstance(v, str):
+                cut = min([i for i in (v.find("<"), v.find(" ("), v.find(",")) if i > 0] or [len(v)])
+                out[k] = v[:cut][:48]
+                continue
+            if k == "sample" and isinstance(v, str):
+                out[k] = v[:110]
+                continue
+            out[k] = compact(v, p)
+        return out
+    if isinstance(o, list):
+        return [compact(v, path) for v in o]
+    if isinstance(o, str) and len(path) > 1 and len(o) > 64 and path != ("config", "workload"):
+        return o[:64]
+    return _sig(o) if len(path) > 1 or path[:1] not in (("value",), ("ms_per_step",)) else o
+
+
+def emit(out):
+    full = os.environ.get("SOLA_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        with open(full, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        pass
+    print(json.dumps(compact(out), separators=(",", ":")), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -822,13 +891,10 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * step_s, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (hi+lo f16 operand pairs, 3 f16 MFMAs per product, f32 accumulate; "
-                                                              "device-side scales + range guard with exact-f32 repeat)",
-            "config": {"workload": f"SOLA track selection forward+BCE+alignment loss+selection, T={T} N={N} d=256 L={L}, "
-                                   f"configs/mevis/default.yaml model (32.98M params, random-init PCG64 seed 42), "
-                                   f"{B} samples/step/GPU, "
-                                   + ("conv weights standardised once (inference cache)" if args.cached_ws
-                                      else "conv weights re-standardised every step"),
+            "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (hi+lo f16 operand pairs, 3 f16 MFMAs per product, f32 accumulate)",
+            "config": {"workload": f"SOLA track selection forward+BCE+alignment loss+selection, T={T} N={N} d=256 L={L}, mevis/default model "
+                                   f"(32.98M params, random init), {B} samples/step/GPU, "
+                                   + ("conv weights standardised once" if args.cached_ws else "conv weights re-standardised every step"),
                        "batch_per_gpu": B, "tracks": N, "frames": T, "text_len": L, "sharding": f"per-sample x{world}",
                        "collective_backend": backend_name, "world_size_reported_by_backend": world if world > 1 else None,
                        **({"tune": args.tune} if args.tune else {})},
@@ -855,7 +921,7 @@ def main():
             out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, N, T, L, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         torch.distributed.destroy_process_group()
 
