@@ -114,6 +114,16 @@ int sola_set_precision(SolaCtx* ctx, int precision);
  * weight changes.  The guard words, their pinned host copy and the precision switch of the repeat belong to the CONTEXT: a
  * context serves one stream / one host thread at a time (use one context per stream for concurrent calls). */
 int sola_set_split_guard(SolaCtx* ctx, int enable);
+
+/* Operand-cast arena of the reduced-precision TRAINING modes (no reference counterpart).  In precisions 1 / 2 / 3 the training forward
+ * keeps the 16-bit operand casts of its GEMM inputs so that the backward's weight-gradient products read them instead of casting the
+ * same activations again (sola_tune "train_x16_keep").  The memory is the CALLER's: `dev_ptr` (256-byte aligned, `bytes` long) is
+ * borrowed until it is replaced (null = keep nothing; the backward then casts as before - results are bit-identical either way).
+ * Replace it only between a backward and the next forward.  sola_x16_arena_info reports what the LAST training forward asked for in
+ * total (`need_bytes`, whether it fitted or not), the capacity and the bytes in use, so a caller can grow its buffer between steps
+ * (sola_amd/module.py keeps a torch tensor 1/8 above the largest need seen).  Round 4; before, the ctx allocated this arena itself. */
+int sola_set_x16_arena(SolaCtx* ctx, void* dev_ptr, size_t bytes);
+int sola_x16_arena_info(const SolaCtx* ctx, size_t* need_bytes, size_t* capacity_bytes, size_t* used_bytes);
 int sola_split_fallback_count(const SolaCtx* ctx, int64_t* count, int32_t* last_guard);
 /* f32 rows -> split-f16 rows (same bytes per element; K % 8 == 0); scale must be a power of two */
 int sola_cast_sp16(const float* dev_in, int ld_in, float* dev_out, int ld_out, int64_t rows, int K, float scale, void* stream);

@@ -127,6 +127,8 @@ SIGNATURES = {
     "sola_grad_sqnorms_scratch_bytes": (_sz, [_i, _vp]),
     "sola_grad_sqnorms": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "sola_grad_clip": (_i, [_vp, _vp, _i, _vp, _f, _vp]),
+    "sola_set_x16_arena": (_i, [_vp, _vp, _sz]),
+    "sola_x16_arena_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "sola_tune": (_i, [C.c_char_p, _i]),
     "sola_gemm_trace_read": (C.c_longlong, [_vp, C.c_longlong]),
     "sola_profile_enable": (_i, [_i]),

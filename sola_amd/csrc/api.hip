@@ -182,7 +182,6 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (!c) return SOLA_OK;
     if (c->ws_buf) (void)hipFree(c->ws_buf);
     if (c->ws16_buf) (void)hipFree(c->ws16_buf);
-    if (c->x16_arena) (void)hipFree(c->x16_arena);
     if (c->lin16_buf) (void)hipFree(c->lin16_buf);
     if (c->scal_buf) (void)hipFree(c->scal_buf);
     if (c->guard_host) (void)hipHostFree(c->guard_host);
@@ -585,6 +584,24 @@ extern "C" int sola_loss_ragged(const float* score_map, const float* score_token
 extern "C" int sola_set_split_guard(SolaCtx* c, int enable) {
     SOLA_ARG(c, "set_split_guard: null ctx");
     c->split_guard = enable != 0;
+    return SOLA_OK;
+}
+
+extern "C" int sola_set_x16_arena(SolaCtx* c, void* dev_ptr, size_t bytes) {
+    SOLA_ARG(c, "set_x16_arena: null ctx");
+    SOLA_ARG((reinterpret_cast<uintptr_t>(dev_ptr) & 255) == 0, "set_x16_arena: the arena must be 256-byte aligned");
+    c->x16.clear();  // casts listed by an earlier forward lived in the previous arena
+    c->x16_arena = static_cast<char*>(dev_ptr);
+    c->x16_cap = dev_ptr ? bytes : 0;
+    c->x16_used = 0;
+    return SOLA_OK;
+}
+
+extern "C" int sola_x16_arena_info(const SolaCtx* c, size_t* need_bytes, size_t* capacity_bytes, size_t* used_bytes) {
+    SOLA_ARG(c, "x16_arena_info: null ctx");
+    if (need_bytes) *need_bytes = c->x16_need;
+    if (capacity_bytes) *capacity_bytes = c->x16_cap;
+    if (used_bytes) *used_bytes = c->x16_used;
     return SOLA_OK;
 }
 

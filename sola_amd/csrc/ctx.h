@@ -85,9 +85,8 @@ struct SolaCtx {
     // instead of casting the same activations again (sola_tune "train_x16_keep").  The arena grows between steps to the last need.
     struct X16Entry { const float* src; const void* p16; int cols; int fmt; };
     std::vector<X16Entry> x16;
-    char* x16_arena = nullptr;
-    size_t x16_cap = 0, x16_used = 0, x16_need = 0;
-    bool x16_off = false;  // the arena could not be allocated once: stop asking (the backward casts as before)
+    char* x16_arena = nullptr;  // BORROWED from the caller (sola_set_x16_arena); null = nothing is kept, the backward casts as before
+    size_t x16_cap = 0, x16_used = 0, x16_need = 0;  // x16_need: what the last training forward asked for in total (fitting or not)
     void* x16_alloc(size_t bytes) {  // null = no room this step (the caller uses its shared buffer and lists nothing)
         bytes = (bytes + 255) & ~(size_t)255;
         x16_need += bytes;

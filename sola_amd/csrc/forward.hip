@@ -203,32 +203,16 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     // The split-f16 step ("f16x3") keeps nothing of its split pairs (fetching their hi halves with every other 16-byte chunk slowed the
     // dW kernel's DMA by what the saved casts had cost); its operand casts instead write the hi halves ONCE MORE as plain f16 rows
     // into the arena (side16 below): 2 more bytes per value written here, 6 fewer moved by the backward's X cast.
-    const bool keep16 = split && pure && g_train_x16_keep != 0 && !c->x16_off;
-    const bool side16_on = split && !pure && g_train_x16_keep != 0 && g_train_dw_f16 != 0 && !c->x16_off;
+    const bool keep16 = split && pure && g_train_x16_keep != 0;
+    const bool side16_on = split && !pure && g_train_x16_keep != 0 && g_train_dw_f16 != 0;
     c->x16.clear();
     if (keep16 || side16_on) {
-        if (c->x16_need > c->x16_cap) {  // grow to what the last step asked for (+ 1/8: ragged batches differ from step to step)
-            const size_t want = c->x16_need + c->x16_need / 8;
-            size_t mem_free = 0, mem_total = 0;
-            // the arena is a convenience, not a requirement: it takes at most half of what the device would have free without it (the
-            // caller's allocator - torch's - needs the rest for the step's workspaces); else it stays as it is and the casts that do
-            // not fit are made again by the backward
-            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && want <= (mem_free + c->x16_cap) / 2) {
-                SOLA_HIP(hipStreamSynchronize(s));
-                if (c->x16_arena) SOLA_HIP(hipFree(c->x16_arena));
-                c->x16_arena = nullptr;
-                c->x16_cap = 0;
-                if (hipMalloc(&c->x16_arena, want) == hipSuccess) {
-                    c->x16_cap = want;
-                } else {  // this step and the following ones cast in the backward as before
-                    (void)hipGetLastError();
-                    c->x16_arena = nullptr;
-                    c->x16_off = true;
-                }
-            } else {
-                (void)hipGetLastError();
-            }
-        }
+        // the arena is the CALLER's (sola_set_x16_arena, round 4: an allocation of its own - half of the free device memory at most, grown with a
+        // stream sync and a device-wide free inside the training forward - was memory torch's allocator could neither see nor reclaim);
+        // what a forward asked for in total is read with sola_x16_arena_info; what does not fit is cast again by the backward as before
+        c->x16_used = 0;
+        c->x16_need = 0;
+    } else {
         c->x16_used = 0;
         c->x16_need = 0;
     }

@@ -97,10 +97,15 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # precision: every GEMM of the step on plain-f16 casts, one MFMA per product, everything else f32); "bf16" = the same
         # mixed-precision TRAINING step with bfloat16 GEMM operands (BASELINE.json configs[2] "bf16 training" - a
         # build-side mode, the reference itself trains in fp32), inference calls of such a module run "f16x3")
-        # Default (round 3): "f16x3", the range-guarded split-f16 mode - what bench.py's headline measures, the same 1e-3 parity
-        # bar and error class as the exact-f32 kernels, backed by those kernels whenever its guard trips.  The entry
-        # points (train.py / eval.py / inference.py) take it from here; SOLA_PRECISION=f32 selects exact f32 everywhere.
-        self.precision = os.environ.get("SOLA_PRECISION", "f16x3")
+        # Defaults.  INFERENCE calls: "f16x3", the range-guarded split-f16 mode - what bench.py's headline measures, the same 1e-3
+        # parity bar and error class as the exact-f32 kernels, backed by those kernels whenever its guard trips.
+        # TRAINING calls (differentiable forward + backward): "f32", exact-f32 kernels like the reference (round 4, ADVICE r3: the
+        # training step has no range guard, so its reduced-precision forms are opt-in).  Assigning ``module.precision = X`` is the
+        # explicit choice and covers both; ``module.train_precision = X`` sets the training side alone (train.py: train.precision /
+        # --precision).  SOLA_PRECISION=f32 selects exact f32 everywhere; SOLA_TRAIN_PRECISION sets the training default.
+        env = os.environ.get("SOLA_PRECISION")
+        self._precision = env or "f16x3"
+        self.train_precision = os.environ.get("SOLA_TRAIN_PRECISION") or env or "f32"
         self._ctx_precision = None
         # "f16x3" inference calls are range-guarded: a value outside the split-f16 pairs' range (or GroupNorm weights that
         # would put activations there) makes the library repeat the call on the exact-f32 kernels (one 4-byte read-back and
@@ -170,6 +175,16 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             self.__dict__["_state_cache"] = se
         return se
 
+    @property
+    def precision(self):
+        """Arithmetic of the inference calls; assigning it is the explicit choice for training calls too (see __init__)."""
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        self._precision = value
+        self.train_precision = value
+
     def weights_changed(self):
         """Tell the library that parameter VALUES changed in place without torch noticing (e.g. an update through ``p.data``
         or a fused optimizer kernel - neither bumps ``Tensor._version``): cached derived copies (standardised conv weights,
@@ -202,11 +217,12 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         # weight changes; "always" / "cached" force either behaviour (bench.py uses "always")
         every = self.training if self.ws_policy == "auto" else self.ws_policy == "always"
         check(lib().sola_set_ws_policy(self._ctx, 1 if every else 0), "sola_set_ws_policy")
-        if self.precision not in ("f32", "f16x3", "f16", "bf16"):
-            raise SolaError(f"precision must be 'f32', 'f16x3', 'f16' or 'bf16', got {self.precision!r}")
+        prec = self.train_precision if train else self._precision
+        if prec not in ("f32", "f16x3", "f16", "bf16"):
+            raise SolaError(f"precision must be 'f32', 'f16x3', 'f16' or 'bf16', got {prec!r}")
         # "bf16" is a TRAINING mode (bfloat16 GEMM operands, library precision 3); inference calls of a module set to it run the
         # default split-f16 kernels
-        want = {"f32": 0, "f16x3": 1, "f16": 2, "bf16": 3 if train else 1}[self.precision]
+        want = {"f32": 0, "f16x3": 1, "f16": 2, "bf16": 3 if train else 1}[prec]
         if self._ctx_precision != want:
             check(lib().sola_set_precision(self._ctx, want), "sola_set_precision")
             self._ctx_precision = want
@@ -357,6 +373,47 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         return list(torch.split(score_map, counts)), list(torch.split(score_tokens, counts))
 
     # ------------------------------------------------------------------------------------------ training path
+    def _size_x16_arena(self, dev):
+        """Reduced-precision training modes: the forward keeps its 16-bit operand casts for the backward's dW products in an arena this
+        module owns as a torch tensor (sola_set_x16_arena; ``x16_arena_max_bytes`` caps it, 0 = keep nothing).  Sized before a forward
+        from what the previous one asked for, + 1/8 (ragged batches differ from step to step); never shrinks below the largest need seen
+        unless ``release_x16_arena()`` is called."""
+        if self.train_precision == "f32":
+            return
+        need, cap, used = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        check(lib().sola_x16_arena_info(self._ctx, C.byref(need), C.byref(cap), C.byref(used)), "sola_x16_arena_info")
+        limit = getattr(self, "x16_arena_max_bytes", None)
+        want = need.value + need.value // 8
+        if limit is not None:
+            want = min(want, int(limit))
+        arena = getattr(self, "_x16_arena", None)
+        if arena is not None and (arena.device != dev or (arena.numel() < want)):
+            arena = None
+        if arena is not None and cap.value != arena.numel():  # a new context (device change): hand it the arena again
+            check(lib().sola_set_x16_arena(self._ctx, ptr(arena), arena.numel()), "sola_set_x16_arena")
+        if arena is None and want > 0 and not getattr(self, "_x16_arena_failed", False):
+            self._x16_arena = None  # release before allocating the larger one
+            check(lib().sola_set_x16_arena(self._ctx, None, 0), "sola_set_x16_arena")
+            try:
+                arena = torch.empty(int(want), dtype=torch.uint8, device=dev)
+            except torch.OutOfMemoryError:  # a convenience, not a requirement: the backward casts again
+                self._x16_arena_failed = True
+                arena = None
+            self._x16_arena = arena
+            check(lib().sola_set_x16_arena(self._ctx, ptr(arena), 0 if arena is None else arena.numel()), "sola_set_x16_arena")
+
+    def x16_arena_bytes(self):
+        """Bytes currently held for kept operand casts (0 in exact-f32 training)."""
+        a = getattr(self, "_x16_arena", None)
+        return 0 if a is None else int(a.numel())
+
+    def release_x16_arena(self):
+        """Give the operand-cast arena back to torch's allocator (call between a backward and the next forward)."""
+        if getattr(self, "_ctx", None):
+            check(lib().sola_set_x16_arena(self._ctx, None, 0), "sola_set_x16_arena")
+        self._x16_arena = None
+        self._x16_arena_failed = False
+
     def _forward_train_impl(self, object_tokens, lang_tokens):
         """sola_forward_train: same numerics as the inference forward, activations kept for sola_backward."""
         B, N, T, d = object_tokens.shape
@@ -368,6 +425,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._bind_weights(train=True)
         self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
         self._set_step_dropout()
+        self._size_x16_arena(dev)
         nbytes = lib().sola_train_workspace_bytes(self._ctx, B, N, T, L)
         if self._train_ws is None or self._train_ws.numel() < nbytes or self._train_ws.device != dev:
             self._train_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
@@ -404,6 +462,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._bind_weights(train=True)
         self._weights_touched = True  # the caller is about to update the parameters (see _bind_weights)
         self._set_step_dropout()
+        self._size_x16_arena(dev)
         nbytes = lib().sola_train_ragged_workspace_bytes(self._ctx, C.byref(batch))
         if nbytes == 0:
             raise SolaError("forward_ragged (training): invalid batch description: " + (lib().sola_last_error() or b"").decode())

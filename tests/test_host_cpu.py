@@ -285,7 +285,18 @@ def test_persistent_split_gemm_instantiations_do_not_spill():
 def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
     """What bench.py's headline measures is what a user of the classes and entry points gets."""
     monkeypatch.delenv("SOLA_PRECISION", raising=False)
+    monkeypatch.delenv("SOLA_TRAIN_PRECISION", raising=False)
     m = LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG)
     assert m.precision == "f16x3" and m.split_guard is True
+    # ... for INFERENCE calls; a training call runs exact f32 like the reference unless asked otherwise (ADVICE r3: the training step
+    # has no range guard).  Assigning module.precision is the explicit choice and covers both sides.
+    assert m.train_precision == "f32"
+    m.precision = "f16x3"
+    assert m.train_precision == "f16x3"
+    m.train_precision = "bf16"
+    assert m.precision == "f16x3" and m.train_precision == "bf16"
     monkeypatch.setenv("SOLA_PRECISION", "f32")
-    assert LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG).precision == "f32"
+    m2 = LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG)
+    assert m2.precision == "f32" and m2.train_precision == "f32"
+    monkeypatch.setenv("SOLA_TRAIN_PRECISION", "f16x3")
+    assert LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG).train_precision == "f16x3"

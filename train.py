@@ -16,6 +16,7 @@ the 32.98M-element gradient before get_grad_norm_dict()/clipping, so every rank 
 (effective batch = world size; the reference itself is single-process, batch 1).  AdamW / ReduceLROnPlateau stay on
 PyTorch as in the reference (train.py:44-57).  Weights are saved as ``<output_dir>/epoch_{k}.pth`` (train.py:246).
 """
+import math
 import os
 import random
 import time
@@ -24,6 +25,7 @@ import numpy as np
 import torch
 
 from sola_amd import dist as sdist
+from sola_amd._lib import SolaError
 from sola_amd.config import load_configs
 from sola_amd.data import make_loader, make_ragged_batches, make_ragged_train_batches, DevicePrefetcher
 from sola_amd.loss import track_selection_losses, track_selection_losses_ragged
@@ -159,6 +161,11 @@ def train(cfg):
     device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     module = LanguageAlignedTrackSelectionModule(cfg["model"]).to(device)
+    # Arithmetic of the training step: exact f32 like the reference unless asked otherwise (--precision f16x3 | f16 | bf16, or
+    # train.precision in the YAML): the reduced-precision steps have no range guard, so they are opt-in
+    tp = cfg.get("precision", cfg["train"].get("precision"))
+    if tp is not None:
+        module.train_precision = str(tp)
     if world > 1:  # identical initial weights on every rank
         for t in module.state_dict().values():
             torch.distributed.broadcast(t, src=0)
@@ -183,6 +190,9 @@ def train(cfg):
             tr = run_train_ragged(module, text, batches, tcfg, device, optimizer, world)
         else:
             tr = run_split(module, text, train_loader, tcfg, device, True, optimizer, world)
+        if not math.isfinite(tr["total"]):  # the loops have no per-step host sync; an overflow shows in the epoch's sums
+            raise SolaError(f"epoch {epoch + 1}: non-finite training loss with training precision {module.train_precision!r}"
+                            + ("" if module.train_precision == "f32" else " - a value left the 16-bit operand range; rerun with --precision f32"))
         va = run_split_ragged(module, text, valid_batches, tcfg, device, world)
         scheduler.step(va["total"])
         if rank == 0:
