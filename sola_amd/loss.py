@@ -42,7 +42,10 @@ def track_selection_losses(score_map, score_tokens, labels, pos_tokens, neg_toke
     score_map, score_tokens and neg_tokens (HIP backward, sola_loss_backward)."""
     needs_grad = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (score_map, score_tokens, neg_tokens))
-    if needs_grad and not return_argmax:
+    if needs_grad and return_argmax:
+        raise SolaError("track_selection_losses: return_argmax=True is an evaluation option; call it under torch.no_grad() (or on "
+                        "detached inputs), and call again without it for the differentiable loss")
+    if needs_grad:
         from .autograd import _Losses
 
         return _Losses.apply(score_map, score_tokens, labels, pos_tokens, neg_tokens, positive_weight, temperature,
@@ -122,7 +125,12 @@ def track_selection_losses_ragged(score_map, score_tokens, labels, pos_tokens, n
     the batch objective whose gradient is the average of the reference's per-sample (batch-size-1) gradients."""
     needs_grad = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (score_map, score_tokens, neg_tokens))
-    if needs_grad and not return_argmax:
+    if needs_grad and return_argmax:
+        # the hardest-negative indices come from the non-differentiable evaluation: silently handing back a loss without a graph
+        # (ADVICE r3) would train without the alignment loss's gradient
+        raise SolaError("track_selection_losses_ragged: return_argmax=True is an evaluation option; call it under torch.no_grad() "
+                        "(or on detached inputs), and call again without it for the differentiable loss")
+    if needs_grad:
         from .autograd import _LossesRagged
 
         return _LossesRagged.apply(score_map, score_tokens, labels, pos_tokens, neg_tokens, track_offsets.contiguous(), list(counts),

@@ -377,7 +377,10 @@ def test_split_training_weight_gradient_products_on_f16_operands(full_model):
 # recipe on the ORACLE: autograd through oracle/sola_oracle.py under torch.autocast(bfloat16) against the same step in fp32 gives
 # cosine 0.563, worst tensor 98 %, median 6.1 % (tools/bf16_autocast_oracle.py, profiles/r03_bf16_training.txt) - the library's
 # mode keeps f32 storage between the GEMMs and lands inside it.
-LOWP_TRAIN_TOL = {"f16": (1e-2, 0.95, 0.35, 3e-2, 5e-2), "bf16": (2e-2, 0.70, 0.85, 8e-2, 0.15)}
+# Round 4: the bounds sit a small margin off the MEASURED statistics (profiles/r03_bf16_training.txt: f16 loss 1.3e-4,
+# cosine 0.985, worst tensor 18 %, median 1.0 %; bf16 6.0e-3, 0.744, 73 %, 4.8 %), not at twice their value; the kernels are
+# deterministic, so a regression of the tail shows.  (loss rtol, min cosine, worst tensor, median tensor, total-norm rtol)
+LOWP_TRAIN_TOL = {"f16": (2e-3, 0.975, 0.22, 1.5e-2, 5e-2), "bf16": (1e-2, 0.73, 0.78, 6e-2, 0.15)}
 
 
 @pytest.mark.parametrize("mode", ["f16", "bf16"])

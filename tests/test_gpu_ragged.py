@@ -148,9 +148,12 @@ def test_ragged_losses_equal_per_sample_losses(full):
     pos = torch.stack([t.mean(0) for t in texts], 0)
     sms, sts = full.forward_ragged(videos, texts, sample_video)
     flat_sm, flat_st, offs, counts = full.last_ragged
-    neg = full.negative_token.weight
+    neg = full.negative_token.weight.detach()  # return_argmax is an evaluation option: no graph
     loss, argmax = track_selection_losses_ragged(flat_sm, flat_st, torch.cat(labels), pos, neg, offs, counts, POS_W, TEMP, ALIGN_W,
                                                  return_argmax=True)
+    with pytest.raises(SolaError):  # ... and asking for it on the differentiable path is an error, not a loss without a graph
+        track_selection_losses_ragged(flat_sm, flat_st, torch.cat(labels), pos, full.negative_token.weight, offs, counts, POS_W, TEMP,
+                                      ALIGN_W, return_argmax=True)
     assert loss.shape == (len(sample_video), 3)
     o = 0
     for i in range(len(sample_video)):

@@ -182,9 +182,9 @@ def test_batch_256_every_row_vs_oracle(base_models, precision, seed):
     e_tok = float(np.abs(st - rst).max())
     print(f"{precision} seed {seed}: logits worst {e_rows.max():.3e} mean {e_rows.mean():.3e} rows>5e-4 {(e_rows > 5e-4).sum()}; tokens worst {e_tok:.3e}")
     np.testing.assert_array_equal(sm > 0, rsm > 0)
-    # the north star's 1e-3 is stated for the logits; the 1024-dim score tokens (entries up to ~4) are held to 1.5e-3 over the
-    # 16.8 M values of a batch (measured worst 9.5e-4)
-    assert e_rows.max() <= 1e-3 and e_tok <= 1.5e-3
+    # the north star's 1e-3, on the logits AND on the 1024-dim score tokens (entries up to ~4; 16.8 M values per batch, measured worst
+    # 9.5e-4 - round 4, ADVICE r3: held to the same hard bound instead of 1.5e-3)
+    assert e_rows.max() <= 1e-3 and e_tok <= 1e-3
     assert e_rows.mean() <= 2.5e-4 and (e_rows > 5e-4).sum() <= 8
 
 
