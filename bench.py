@@ -236,7 +236,7 @@ def cpu_baseline(cfg, sd, N, T, L, budget_s):
             "thread_sweep": sweep}
 
 
-def training_leg(cfg, sd, dev, B, N, T, L, steps):
+def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
     """Outside the timed region, rank 0 at N=1 only: one optimizer step of the same network (sola_forward_train + losses +
     sola_backward + gradient norms / clip + AdamW) at up to 64 samples: exact f32, split-f16 GEMMs, f16-operand GEMMs."""
     from sola_amd import synth
@@ -334,6 +334,16 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps):
         _d, profr = profiled(step_ragged, 2, sync, warmup=0)
         rag[prec] = {"value": round(S / dtr, 1), "ms_per_step": round(dtr * 1e3, 3), "model_tflops": round(3 * rflops / dtr / 1e12, 1),
                      "kernel_ms_per_step": kernel_ms(profr, 2)}
+    if oracle_parity:  # the TRAINING forward of this batch (sola_forward_train_ragged, dropout off), every logit against the fp32 oracle
+        m.eval()
+        bt = {"sample_video": list(range(S)), "videos": [o.cpu().numpy() for o in objs], "texts": [t.cpu().numpy() for t in langs]}
+        ref = oracle_ragged_rows(cfg, oracle_parity, bt)
+        rag["train_forward_logit_err_vs_oracle"] = {}
+        for prec in ("f32", "f16x3"):
+            m.precision = prec
+            m.forward_ragged(objs, langs, differentiable=True)
+            rag["train_forward_logit_err_vs_oracle"][prec] = row_errors(m.last_ragged[0].detach().cpu().numpy(), ref, m.last_ragged[3])
+        m.train()
     # the same leg at 128 samples per step, 16-bit GEMM operands: the per-step costs that do not scale with the rows (launches, the
     # optimizer, the weight-side casts) are halved per sample
     S2 = 128
@@ -552,7 +562,7 @@ def f16_storage_leg(cfg, m, dev, steps):
     return out
 
 
-def ragged_leg(cfg, m, dev, steps, uniform_model_tflops):
+def ragged_leg(cfg, m, dev, steps, uniform_model_tflops, oracle_parity=None):
     """sola_forward_ragged + sola_loss_ragged + sola_select on a MeViS-like mix of shapes (N in [8,80] tracks, T in [20,200]
     frames, L in [4,24] text tokens; seeded), 128 samples per launch: (a) one expression per video, (b) four expressions per
     video.  FLOPs: `reference` = what per-sample forwards of these samples cost (the reference's batch-1 loop, and this
@@ -560,18 +570,15 @@ def ragged_leg(cfg, m, dev, steps, uniform_model_tflops):
     from sola_amd import ops, synth
     from sola_amd.loss import track_selection_losses_ragged
 
-    rng = np.random.Generator(np.random.PCG64(2024))
     S = 128
     out = {"samples_per_launch": S, "shapes": "N~U[8,80], T~U[20,200], L~U[4,24], seed 2024"}
-    d, D = cfg["object_token_dim"], cfg["lang_token_dim"]
-    for tag, per_video in (("one_expression_per_video", 1), ("four_expressions_per_video", 4)):
+    batches = synth.make_ragged_infer_batches(cfg, S, 2024)
+    for tag, bt in batches.items():
+        per_video, shapes, lens, sample_video = bt["per_video"], bt["shapes"], bt["lens"], bt["sample_video"]
         V = S // per_video
-        shapes = [(int(rng.integers(8, 81)), int(rng.integers(20, 201))) for _ in range(V)]
-        lens = [int(rng.integers(4, 25)) for _ in range(S)]
-        sample_video = [i // per_video for i in range(S)]
-        videos = [torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)).to(dev) for n, t in shapes]
-        texts = [torch.from_numpy(rng.standard_normal((ln, D)).astype(np.float32)).to(dev) for ln in lens]
-        labels = torch.cat([torch.from_numpy((rng.uniform(size=shapes[v][0]) < 0.2).astype(np.float32)) for v in sample_video]).to(dev)
+        videos = [torch.from_numpy(v).to(dev) for v in bt["videos"]]
+        texts = [torch.from_numpy(t).to(dev) for t in bt["texts"]]
+        labels = torch.cat([torch.from_numpy(l) for l in bt["labels"]]).to(dev)
         pos = torch.stack([t.mean(0) for t in texts], 0)
 
         def step():
@@ -595,9 +602,39 @@ def ragged_leg(cfg, m, dev, steps, uniform_model_tflops):
                     "model_tflops_reference": round(f_ref / dt / 1e12, 1), "model_tflops_executed": round(f_exec / dt / 1e12, 1),
                     "executed_vs_uniform_batch_model_tflops": round(f_exec / dt / 1e12 / uniform_model_tflops, 3) if uniform_model_tflops else None,
                     "roofline_attention": attn_roofline(prof), "kernel_ms_per_launch": kernel_ms(prof, steps)}
+        if oracle_parity:  # EVERY logit of this batch against the fp32 oracle's per-sample forwards, this mode and exact f32
+            ref = oracle_ragged_rows(cfg, oracle_parity, bt)
+            keep = m.precision
+            par = {}
+            for prec in (keep, "f32"):
+                m.precision = prec
+                m.forward_ragged(videos, texts, sample_video)
+                par[prec] = row_errors(m.last_ragged[0].cpu().numpy(), ref, m.last_ragged[3])
+            m.precision = keep
+            out[tag]["logit_err_vs_oracle"] = par
         del videos, texts
         torch.cuda.empty_cache()
     return out
+
+
+def oracle_ragged_rows(cfg, tsd, bt):
+    """fp32 oracle logits of every sample of a ragged batch (checker only): one per-sample forward each, concatenated."""
+    from oracle import sola_oracle
+
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    rows = []
+    for i, v in enumerate(bt["sample_video"]):
+        sm, _ = sola_oracle.forward(tsd, cfg, bt["videos"][v][None], bt["texts"][i][None])
+        rows.append(np.asarray(sm)[0])
+    return np.concatenate(rows)
+
+
+def row_errors(got, ref, counts):
+    """Worst / mean-per-sample-worst absolute logit error, samples above 5e-4, equality of the selections (sigmoid > 0.5)."""
+    e = np.abs(got - ref)
+    per = np.array([e[o:o + c].max() for o, c in zip(np.cumsum([0] + list(counts[:-1])), counts)])
+    return {"max": float(e.max()), "mean_sample_max": float(per.mean()), "samples_above_5e-4": int((per > 5e-4).sum()), "samples": len(counts),
+            "selections_equal": bool(np.array_equal(got > 0, ref > 0))}
 
 
 def iou_leg(dev, cpu_seconds):
@@ -912,13 +949,23 @@ def main():
         if world == 1 and args.extra_legs:
             k = max(3, args.steps // 4)
             out["stress_T128_N128"] = stress_leg(cfg, m, dev, args.precision, k)
-            out["ragged"] = ragged_leg(cfg, m, dev, k, out["model_tflops"])
+            tsd_par = None
+            if args.cpu_seconds > 0:
+                from oracle import sola_oracle  # checker only
+
+                tsd_par = sola_oracle.to_torch_state(sd)
+            out["ragged"] = ragged_leg(cfg, m, dev, k, out["model_tflops"], tsd_par)
             out["iou"] = iou_leg(dev, args.cpu_seconds)
             out["f16_storage_mode"] = f16_storage_leg(cfg, m, dev, k)
         if dist_res is not None:
             out["training_step_dist"] = dist_res
         if world == 1 and args.train_steps > 0:
-            out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps)
+            tsd_par = None
+            if args.cpu_seconds > 0:
+                from oracle import sola_oracle  # checker only
+
+                tsd_par = sola_oracle.to_torch_state(sd)
+            out["training_step"] = training_leg(cfg, sd, dev, min(B, 64), N, T, L, args.train_steps, tsd_par)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, N, T, L, args.cpu_seconds)
         emit(out)

@@ -181,6 +181,26 @@ def make_ragged_samples(cfg, n_samples, seed=2024, device=None, n_range=(8, 80),
     return out
 
 
+def make_ragged_infer_batches(cfg, n_samples=128, seed=2024):
+    """The two ragged INFERENCE batches of bench.py's ragged leg (and of tests/test_gpu_ragged.py's every-row parity check), numpy: the
+    MeViS-like mix N ~ U[8,80], T ~ U[20,200], L ~ U[4,24] with (a) one expression per video and (b) four expressions per video, drawn
+    from ONE generator in this order.  Returns {tag: dict(shapes, lens, sample_video, videos, texts, labels)}."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, D = cfg["object_token_dim"], cfg["lang_token_dim"]
+    out = {}
+    for tag, per_video in (("one_expression_per_video", 1), ("four_expressions_per_video", 4)):
+        V = n_samples // per_video
+        shapes = [(int(rng.integers(8, 81)), int(rng.integers(20, 201))) for _ in range(V)]
+        lens = [int(rng.integers(4, 25)) for _ in range(n_samples)]
+        sample_video = [i // per_video for i in range(n_samples)]
+        videos = [rng.standard_normal((n, t, d)).astype(np.float32) for n, t in shapes]
+        texts = [rng.standard_normal((ln, D)).astype(np.float32) for ln in lens]
+        labels = [(rng.uniform(size=shapes[v][0]) < 0.2).astype(np.float32) for v in sample_video]
+        out[tag] = {"per_video": per_video, "shapes": shapes, "lens": lens, "sample_video": sample_video, "videos": videos, "texts": texts,
+                    "labels": labels}
+    return out
+
+
 def t_out_lengths(T):
     """Frame count after each encoder conv (three stride-2 k=3 p=1 convs, then stride 1)."""
     lens = []

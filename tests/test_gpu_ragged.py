@@ -245,3 +245,45 @@ def test_ragged_under_the_16_bit_storage_mode():
     assert n == 1 and (bits & 1)
     for x, y in zip(a2, b2):
         assert torch.equal(x, y)
+
+
+# ---- every logit of the benched ragged batches against the fp32 oracle --------------------------------------------
+_ORACLE_ROWS = {}
+
+
+def _oracle_rows(tag, bt):
+    """fp32 oracle logits of every sample of a ragged batch (one per-sample forward each), cached per batch across the two precisions."""
+    if tag not in _ORACLE_ROWS:
+        from oracle import sola_oracle  # checker only
+
+        torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 32))
+        tsd = sola_oracle.to_torch_state(synth.make_state_dict(synth.DEFAULT_MODEL_CFG, 42))
+        rows = []
+        for i, v in enumerate(bt["sample_video"]):
+            sm, _ = sola_oracle.forward(tsd, synth.DEFAULT_MODEL_CFG, bt["videos"][v][None], bt["texts"][i][None])
+            rows.append(np.asarray(sm)[0])
+        _ORACLE_ROWS[tag] = np.concatenate(rows)
+    return _ORACLE_ROWS[tag]
+
+
+@pytest.mark.parametrize("tag", ["one_expression_per_video", "four_expressions_per_video"])
+def test_benched_ragged_batch_every_logit_vs_oracle(full, tag):
+    """bench.py's ragged leg: 128 samples of the MeViS-like mix in ONE sola_forward_ragged call, (a) one expression per video, (b) four
+    expressions per video (the text-independent half computed once per video).  EVERY logit of the batch against the fp32 oracle's
+    per-sample forward: the north star's 1e-3, selections equal - in exact f32 and in the default split-f16 mode (fixture param)."""
+    bt = synth.make_ragged_infer_batches(synth.DEFAULT_MODEL_CFG, 128, 2024)[tag]
+    ref = _oracle_rows(tag, bt)
+    videos = [torch.from_numpy(v).cuda() for v in bt["videos"]]
+    texts = [torch.from_numpy(t).cuda() for t in bt["texts"]]
+    full.forward_ragged(videos, texts, bt["sample_video"])
+    flat, _tok, _offs, counts = full.last_ragged
+    got = flat.cpu().numpy()
+    assert got.shape == ref.shape and sum(counts) == got.shape[0]
+    e = np.abs(got - ref)
+    starts = np.cumsum([0] + list(counts[:-1]))
+    per = np.array([e[o:o + c].max() for o, c in zip(starts, counts)])
+    print(f"{tag} {full.precision}: worst logit error {e.max():.3e}, mean per-sample worst {per.mean():.3e}, samples > 5e-4: {(per > 5e-4).sum()} of {len(counts)}")
+    np.testing.assert_array_equal(got > 0, ref > 0)
+    assert e.max() <= 1e-3
+    if full.precision == "f16x3":
+        assert full.split_fallbacks()[1] == 0  # the range guard did not trip: these are the split-f16 kernels' numbers

@@ -408,3 +408,32 @@ def test_edge_shapes_equal_one_sample_steps(small, shapes):
     loss, got, _ = ragged_step(small, samples)
     torch.testing.assert_close(loss, torch.stack(ref_loss), rtol=2e-4, atol=2e-4)
     assert_grads_close(got, ref_sum, 2e-3, f"edge shapes {shapes}")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_training_forward_of_the_benched_ragged_batch_every_logit_vs_oracle(full, precision):
+    """the 64-sample ragged TRAINING batch of bench.py (synth.make_ragged_samples seed 2024) through
+    sola_forward_train_ragged (differentiable call, eval mode: dropout off) - EVERY logit against the fp32 oracle's per-sample forward,
+    in exact f32 and with the split-f16 GEMMs: the north star's 1e-3, selections equal."""
+    from oracle import sola_oracle  # checker only
+
+    cfg = synth.DEFAULT_MODEL_CFG
+    smp = synth.make_ragged_samples(cfg, 64, 2024)
+    tsd = sola_oracle.to_torch_state(synth.make_state_dict(cfg, 42))
+    torch.set_num_threads(32)
+    ref = np.concatenate([np.asarray(sola_oracle.forward(tsd, cfg, x["obj"].numpy()[None], x["lang"].numpy()[None])[0])[0] for x in smp])
+    full.eval()
+    full.precision = precision
+    try:
+        full.forward_ragged([x["obj"].cuda() for x in smp], [x["lang"].cuda() for x in smp], differentiable=True)
+        flat, _tok, _offs, counts = full.last_ragged
+        assert flat.requires_grad
+        got = flat.detach().cpu().numpy()
+    finally:
+        full.precision = "f32"
+    e = np.abs(got - ref)
+    starts = np.cumsum([0] + list(counts[:-1]))
+    per = np.array([e[o:o + c].max() for o, c in zip(starts, counts)])
+    print(f"training forward {precision}: worst logit error {e.max():.3e}, mean per-sample worst {per.mean():.3e}, samples > 5e-4: {(per > 5e-4).sum()} of 64")
+    np.testing.assert_array_equal(got > 0, ref > 0)
+    assert e.max() <= 1e-3
