@@ -438,7 +438,7 @@ def test_f16_operand_training_vs_exact_f32(full_model, full_golden, mode):
 
 
 # (min cosine, worst tensor, median tensor) on weights whose first softmax is NOT saturated - measured values in the test's docstring
-LOWP_TRAIN_TOL_UNSATURATED = {"f16": (0.999, 0.05, 5e-3), "bf16": (0.99, 0.2, 3e-2)}
+LOWP_TRAIN_TOL_UNSATURATED = {"f16": (0.9993, 0.055, 6e-4), "bf16": (0.994, 0.16, 4e-3)}
 
 
 @pytest.mark.parametrize("mode", ["f16", "bf16"])
@@ -446,7 +446,8 @@ def test_16_bit_operand_training_on_weights_with_an_unsaturated_softmax(mode):
     """VERDICT r3 item 6 / weak point 7: the bounds of LOWP_TRAIN_TOL are measured at random-init weights, where the first inter-object
     softmax is saturated (scores of rms ~100) and 2^-8 / 2^-11 operand noise flips near-ties.  Here the projection matrices are
     scaled by 1/64 (synth.make_state_dict_variant "lin_div64": attention scores x 1/4096, a nearly uniform softmax) - the regime of a
-    network whose attention is not an arg-max - and the 16-bit operand steps are held to much tighter bounds against the exact-f32 step."""
+    network whose attention is not an arg-max - and the 16-bit operand steps are held to much tighter bounds against the exact-f32 step
+    (measured, round 4: f16 cosine 0.99950, worst tensor 4.5 %, median 0.038 %; bf16 0.99522, 13.7 %, 0.29 %; at random init 0.985 / 0.744)."""
     from sola_amd import _lib
     cfg = synth.DEFAULT_MODEL_CFG
     m = LanguageAlignedTrackSelectionModule(cfg)
