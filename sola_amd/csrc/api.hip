@@ -516,14 +516,8 @@ extern "C" size_t sola_ragged_workspace_bytes(const SolaCtx* c, const SolaRagged
     if (!c || !batch) return 0;
     // the exact-f32 repeat of a guarded split-f16 call runs in the same arena: size it for the larger of the two plans
     try {
-        size_t n = sola_ragged_workspace_bytes_impl(c, batch);
-        if (c->precision >= 1) {
-            SolaCtx* m = const_cast<SolaCtx*>(c);
-            const int prec = c->precision;
-            m->precision = 0;
-            n = std::max(n, sola_ragged_workspace_bytes_impl(c, batch));
-            m->precision = prec;
-        }
+        size_t n = sola_ragged_workspace_bytes_impl(c, batch, c->precision);
+        if (c->precision >= 1) n = std::max(n, sola_ragged_workspace_bytes_impl(c, batch, 0));  // room for the guard's exact-f32 repeat
         return n;
     } catch (const std::exception& e) {
         sola_set_error("ragged_workspace_bytes: %s", e.what());

@@ -165,6 +165,6 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
 int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                           float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s);
 size_t sola_backward_scratch_bytes(const SolaCtx* c, const Plan& p);
-size_t sola_ragged_workspace_bytes_impl(const SolaCtx* c, const SolaRaggedBatch* b);
+size_t sola_ragged_workspace_bytes_impl(const SolaCtx* c, const SolaRaggedBatch* b, int precision);
 int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch, float* score_map,
                              float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s);

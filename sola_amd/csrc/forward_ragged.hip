@@ -206,10 +206,10 @@ size_t rag_gn_slots_bytes(const RagShape& r) {
 
 namespace {
 
-RagPlan rag_plan(const SolaCtx* c, const RagShape& r) {
+RagPlan rag_plan(const SolaCtx* c, const RagShape& r, int precision) {  // `precision`: the arithmetic the plan is sized for (the ctx's, or 0 for the guard's exact-f32 repeat)
     RagPlan p;
     const size_t D = c->cfg.lang_token_dim, f = sizeof(float);
-    const bool sp = c->precision >= 1;  // split-f16 or plain-f16 copies of the caller's tensors
+    const bool sp = precision >= 1;  // split-f16 or plain-f16 copies of the caller's tensors
     p.add("tables", rag_tables_bytes(r, false));
     for (int i = 0; i < 6; ++i) {
         p.add("conv" + std::to_string(i), (size_t)r.rows[i + 1] * c->conv[i].cout * f);
@@ -364,10 +364,10 @@ int rag_build_tables(SolaCtx* c, const RagShape& r, char* base, bool train, RagT
     return SOLA_OK;
 }
 
-size_t sola_ragged_workspace_bytes_impl(const SolaCtx* c, const SolaRaggedBatch* b) {
+size_t sola_ragged_workspace_bytes_impl(const SolaCtx* c, const SolaRaggedBatch* b, int precision) {
     RagShape r;
     if (!c || rag_shape(c, b, r) != SOLA_OK) return 0;
-    return rag_plan(c, r).total;
+    return rag_plan(c, r, precision).total;
 }
 
 int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, const SolaRaggedBatch* batch, float* score_map,
@@ -391,7 +391,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
                  "split-f16 mode needs channel counts per GroupNorm group that are multiples of 8");
     RagShape r;
     SOLA_TRY(rag_shape(c, batch, r));
-    const RagPlan p = rag_plan(c, r);
+    const RagPlan p = rag_plan(c, r, c->precision);
     if (ws_bytes < p.total) {
         sola_set_error("forward_ragged: workspace %zu bytes < required %zu", ws_bytes, p.total);
         return SOLA_ERR_WORKSPACE;
