@@ -187,6 +187,10 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     if (c->guard_host) (void)hipHostFree(c->guard_host);
     sola_rag_stage_free(c->rag_stage);
     for (hipEvent_t e : c->bucket_ev) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_side)
+        if (e) (void)hipEventDestroy(e);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     delete c;
     return SOLA_OK;
 }
@@ -264,6 +268,7 @@ void sola_gemm_set_glds(int v);
 void sola_gemm_set_splitk(int v);
 extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr, g_train_x16_keep;
 extern int g_gemm_stagger, g_gemm_order, g_gemm_trace, g_gemm_ld;
+extern int g_bwd_side_rows;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
 void sola_set_train_split_min_rows(int v);
@@ -313,6 +318,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_order")) { g_gemm_order = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_trace")) { g_gemm_trace = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_ld")) { g_gemm_ld = value; return SOLA_OK; }
+    if (!strcmp(key, "bwd_side_rows")) { g_bwd_side_rows = value; return SOLA_OK; }
     if (!strcmp(key, "train_tn_tr")) { g_train_tn_tr = value; return SOLA_OK; }
     if (!strcmp(key, "train_x16_keep")) { g_train_x16_keep = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }

@@ -21,6 +21,13 @@ void sola_set_bwd_dual_cast(int v) { g_bwd_dual_cast = v; }
 // whole gradient (0.999999) do not move; the step is 14 % faster on the ragged mix.  0 = split pairs everywhere.
 int g_train_dw_f16 = 1;
 void sola_train_set_dw_f16(int v) { g_train_dw_f16 = v; }
+// sola_tune "bwd_side_rows" (round 4): exact-f32 backward of at most this many token rows (the few-sample regime; the reference trains at
+// batch size 1) runs its weight-gradient products dW = dY^T X - leaves of the graph, a third of the step's kernel time there - on a side
+// stream beside the dX chain.  Kernels of 64-512 blocks leave most of the chip idle, so the two streams really overlap.  0 = off.
+// Same kernels, same per-gradient order: results are bit-identical (tests/test_gpu_backward.py).  OFF by default: measured at one sample
+// per step (tools/train_one_probe.py, profiles/r04_train_one_sample.txt) the step is bound by the HOST's enqueue rate as much as by the GPU
+// (2.2 ms of host time per 2.7 ms step), and the ~60 event records / waits of the lane cost more host time (+0.5 ms) than the overlap saves.
+int g_bwd_side_rows = 0;
 
 namespace {
 
@@ -218,13 +225,51 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         return pure ? launch_cast_f16(in, ld, out, K, rows, K, scale, nullptr, s, 13, nullptr, bf) : launch_cast_sp16(in, ld, out, K, rows, K, scale, s);
     };
 
+    // ---- side lane of the few-sample exact-f32 backward: dW products on c->side_stream.  dw_begin(): the side stream waits for everything
+    //      the main stream has enqueued (the dY it reads); dw_end(slot): marks the side stream's progress for the buffer class `slot`
+    //      (0 = dres, 1 = dqkv / dlkv, 2 = the encoder's dy, 3 = everything); wait_side(slot): the main stream waits for that mark before
+    //      it overwrites the buffer.  `tn` (the dW kernels' slab scratch) is touched by the side stream only.
+    const bool lane_on = !split && g_bwd_side_rows > 0 && M <= g_bwd_side_rows;
+    if (lane_on && !c->side_stream) {
+        SOLA_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        SOLA_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (hipEvent_t& e : c->ev_side) SOLA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipStream_t s2 = lane_on ? c->side_stream : s;
+    bool side_pending[4] = {false, false, false, false};
+    auto dw_begin = [&]() -> int {
+        if (!lane_on) return SOLA_OK;
+        SOLA_HIP(hipEventRecord(c->ev_fork, s));
+        SOLA_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        return SOLA_OK;
+    };
+    auto dw_end = [&](int slot) -> int {
+        if (!lane_on) return SOLA_OK;
+        SOLA_HIP(hipEventRecord(c->ev_side[slot], s2));
+        side_pending[slot] = true;
+        return SOLA_OK;
+    };
+    auto wait_side = [&](int slot) -> int {
+        if (!lane_on || !side_pending[slot]) return SOLA_OK;
+        SOLA_HIP(hipStreamWaitEvent(s, c->ev_side[slot], 0));
+        side_pending[slot] = false;
+        return SOLA_OK;
+    };
+    auto join_side = [&]() -> int {  // every gradient the side stream has been given is final for the main stream's next operation
+        if (!lane_on) return SOLA_OK;
+        SOLA_TRY(dw_end(3));
+        SOLA_TRY(wait_side(3));
+        side_pending[0] = side_pending[1] = side_pending[2] = false;
+        return SOLA_OK;
+    };
+
     // ---- helpers ----------------------------------------------------------------------------------------------
     // dW[N_out, K_in] = dY^T X, db = colsum(dY)
     auto grad_w = [&](const float* dY, int ldy, const float* X, int ldx, int rows, int n_out, int k_in, float* dW, float* db) -> int {
         GemmTnDesc d{};
         d.A = dY; d.B = X; d.C = dW; d.bias_grad = db; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
         d.scratch = tn; d.scratch_bytes = tn_bytes;
-        return launch_gemm_tn(d, s);
+        return launch_gemm_tn(d, s2);
     };
     // up to three weight gradients sharing rows / sizes / pitches (q, k, v of one attention): one launch on the split-f16
     // path (gemm_tn_split.hip) + the bias gradients as column sums, or the f32 kernel per problem
@@ -329,6 +374,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         d.dgamma_part = ar.get("gpart"); d.dbeta_part = ar.get("bpart");
         d.n_inst = n_inst; d.inner = inner; d.outer_stride = outer; d.inner_stride = inner_stride; d.tok_stride = tok_stride;
         d.ntok = ntok; d.C = C; d.groups = groups; d.eps = 1e-5f; d.slope = 0.01f; d.leaky = leaky;
+        SOLA_TRY(wait_side(0));  // a GroupNorm backward writes dres (layers) or the encoder's next dy: the side stream's readers are done
+        SOLA_TRY(wait_side(2));
         SOLA_TRY(launch_group_norm_bwd(d, s));
         float* cs = ar.get("colsum");
         const size_t csb = ar.total - ar.off.at("colsum");
@@ -375,7 +422,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (sc) SOLA_TRY(bias_from_stats(0, D, G(an + ".out_proj.bias")));
             const WG wo[1] = {{dres, ab(a, "attn"), G(an + ".out_proj.weight"), G(an + ".out_proj.bias")}};
             bool rm;
+            SOLA_TRY(dw_begin());
             SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D, sc, sc != nullptr, &rm));
+            SOLA_TRY(dw_end(0));
             SOLA_TRY(transpose_into(W(an + ".out_proj.weight"), D, D, D, 0));
             return grad_x(dres, D, M, D, D, nullptr, dattn, sc, rm);
         };
@@ -395,6 +444,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             ad.part = ar.get("attn_part");
             ad.part_floats = attention_bwd_part_floats((long long)M, B, H, 64);
             ad.part_rows = (long long)M;
+            SOLA_TRY(wait_side(1));  // dqkv / dlkv: the previous sub-block's weight gradients have read them
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
             float *scq, *sckv;
@@ -402,6 +452,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (scq) SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
             const WG wq[1] = {{dqkv, x_mot, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")}};
             bool rmq;
+            SOLA_TRY(dw_begin());
             SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr, &rmq));
             SOLA_TRY(stats(dlkv, 2 * D, BW, 2 * D, 6, &sckv));
             if (sckv) {
@@ -411,6 +462,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const WG wkv[2] = {{dlkv, fb("lang"), G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                                {dlkv + D, fb("lang"), G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
             SOLA_TRY(grad_w_many(wkv, 2, 2 * D, D, BW, D, D, sckv, sckv != nullptr));
+            SOLA_TRY(dw_end(1));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, D, 0));
             SOLA_TRY(grad_x(dqkv, 3 * D, M, D, D, dres, gbuf[1 - cur], scq, rmq));  // d x_mot = dres + dq Wq
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
@@ -430,6 +482,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                            R, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
             if (rt) ad.q_units = rt->u_strk;
             ad.drop = c->attn_drop(l, 1);
+            SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
             const float* x_obj = fb(ls + "_obj");
@@ -444,7 +497,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                               {dqkv + D, x_pe, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                               {dqkv + 2 * D, x_obj, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
             bool rm3;
+            SOLA_TRY(dw_begin());
             SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr, &rm3));
+            SOLA_TRY(dw_end(1));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, D));
             SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad, sc3, rm3, 0));  // d(x_obj + pe) = dq Wq + dk Wk
@@ -463,6 +518,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                            n_bt, H, DH, N, N, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
             if (rt) ad.q_units = rt->u_st;
             ad.drop = c->attn_drop(l, 0);
+            SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             float* sc3;
             SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3));
@@ -475,19 +531,25 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                               {dqkv + D, xin, G(an + ".k_proj.weight"), G(an + ".k_proj.bias")},
                               {dqkv + 2 * D, xin, G(an + ".v_proj.weight"), G(an + ".v_proj.bias")}};
             bool rm3;
+            SOLA_TRY(dw_begin());
             SOLA_TRY(grad_w_many(w3, 3, 3 * D, D, M, D, D, sc3, sc3 != nullptr, &rm3));
+            SOLA_TRY(dw_end(1));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 3 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 3 * D, D));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 3 * D, 2 * D));
             SOLA_TRY(grad_x(dqkv, 3 * D, M, 3 * D, D, dres, gbuf[1 - cur], sc3, rm3, 0));  // d xin = dres + [dq|dk|dv] [Wq;Wk;Wv]
             cur = 1 - cur;
         }
-        if (l > 0) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final
+        if (l > 0) {
+            SOLA_TRY(join_side());
+            SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final
+        }
     }
 
     // ---- negative tokens: rows L.. of d(lang ++ neg) from the k/v projections + the mean-over-W of the score head
     SOLA_TRY(launch_neg_token_grad(dlang, ar.get("dlbar"), nullptr, G("negative_token.weight"), B, L, c->cfg.n_negative, D, s,
                                    rt ? rt->u_lang : nullptr));
+    SOLA_TRY(join_side());
     SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1], s));  // layer 0 + negative tokens
 
     // ---- encoder ----------------------------------------------------------------------------------------------
@@ -533,7 +595,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.rowmap = rowmap;
             d.scratch = tn; d.scratch_bytes = tn_bytes;
-            SOLA_TRY(launch_gemm_tn(d, s));
+            SOLA_TRY(dw_begin());
+            SOLA_TRY(launch_gemm_tn(d, s2));
+            SOLA_TRY(dw_end(2));
         }
         if (i == 0) break;
         // d act_{i-1}[(r, ti)][ci] = sum_{kk, co} dY[(r, to)][co] w_std[co][kk][ci]: the NT kernel with the transposed-conv
@@ -591,6 +655,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         dy = enc[1];  // dact (enc[0]) is consumed; the next stage's dX may overwrite it, its GN backward overwrites enc[1]
     }
     // weight-standardisation backward for all six convs
+    SOLA_TRY(join_side());  // dwstd is the side stream's
     {
         WsBwdLayer layers[6];
         for (int i = 0; i < 6; ++i) {

@@ -118,6 +118,9 @@ struct SolaCtx {
     // backward's stream when a bucket is complete, so the caller can start that bucket's all-reduce on another stream
     // while the rest of the backward still runs (sola_backward_wait_bucket).
     std::vector<hipEvent_t> bucket_ev;
+    // few-sample backward (exact f32, round 4): the weight-gradient products run on a side stream beside the dX chain (backward.hip)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
     bool bucket_recorded = false;
     int n_buckets() const { return cfg.n_layers + 1; }
     float* scal_pair(int i) const { return scal_buf + 2 * i; }

@@ -622,3 +622,28 @@ def test_grad_norm_dict_and_clip_match_torch(small_model):
     m.clip_grad_norm_(10 * max_norm)  # below the threshold: untouched
     for k, p in m.named_parameters():
         assert torch.allclose(p.grad, before[k] * coef, rtol=1e-6, atol=0)
+
+
+def test_side_stream_weight_gradients_are_bit_identical(full_model):
+    """Round 4: in the few-sample exact-f32 backward (the reference's batch size of 1) the weight-gradient products run on a side stream
+    beside the dX chain (sola_tune "bwd_side_rows").  Same kernels in the same per-gradient order: all 83 gradients, the losses and a
+    second step's gradients must equal the single-stream run bit for bit."""
+    from sola_amd import _lib
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    out = {}
+    try:
+        for rows in (0, 4096):
+            _lib.check(_lib.lib().sola_tune(b"bwd_side_rows", rows), "tune")
+            res = []
+            for seed in (5, 6):
+                _, l3, g = train_step_grads(m, cfg, 1, 64, 32, 16, seed)
+                res.append((l3.detach().clone(), {k: v.clone() for k, v in g.items()}))
+            out[rows] = res
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"bwd_side_rows", 0), "tune")  # the default (off: the lane costs the host more than it saves)
+    for (la, ga), (lb, gb) in zip(out[0], out[4096]):
+        assert torch.equal(la, lb)
+        assert set(ga) == set(gb) and len(ga) == 83
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
