@@ -219,9 +219,22 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
         samples = [sample_inputs(cfg, N, T, L, 400 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
         for keep in (1, 0):
             _lib.check(_lib.lib().sola_tune(b"train_x16_keep", keep), "tune")
+            full.release_x16_arena()
             for _ in range(2):  # the arena is sized from the previous step's need: the second step reuses the casts
                 loss, g, _ = ragged_step(full, samples)
             got[keep] = (g, loss)
+            if keep:  # round 4: the arena is a torch tensor of the module (sola_set_x16_arena), 1/8 above what the first step asked for
+                assert full.x16_arena_bytes() > 0
+                held = full.x16_arena_bytes()
+                full.x16_arena_max_bytes = 1 << 20  # a cap below the need: the arena is not grown past it, the backward casts what did not fit
+                full.release_x16_arena()
+                for _ in range(2):
+                    loss_c, g_c, _ = ragged_step(full, samples)
+                assert 0 < full.x16_arena_bytes() <= (1 << 20) < held
+                assert torch.equal(loss_c, loss) and all(torch.equal(g_c[k], g[k]) for k in g)
+                full.x16_arena_max_bytes = None
+            else:
+                assert full.x16_arena_bytes() == 0  # nothing is kept, nothing is asked for
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
