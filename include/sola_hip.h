@@ -451,15 +451,19 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * two accumulator sets and the epilogue drained under the next tile), bit-identical to the default, 0 (default) = off;
  * "train_tn_tr": 1 (default) = weight gradients on 16-bit operands whose N and K are multiples of 256 read ROW-MAJOR casts and
  * transpose in the LDS read (no transposed copies), 0 = always the transposing casts + NT GEMM;
- * "train_x16_keep": 1 (default) = in the 16-bit operand training modes the forward keeps its fixed-scale operand casts (a ctx-owned
- * arena that grows to the step's need) and the backward's weight-gradient products read them instead of casting the activations again
+ * "train_x16_keep": 1 (default) = in the 16-bit operand training modes the forward keeps its fixed-scale operand casts (in the
+ * arena the caller lends the context: sola_set_x16_arena) and the backward's weight-gradient products read them instead of casting the activations again
  * (the split-f16 step's operand casts write their hi halves once more as plain f16 rows for that purpose);
  * "gemm_k16": experimental one-tile-per-block shape of the split-f16 GEMM - 256x128 tiles, 16-deep k-tiles, two four-wave blocks per
  * CU (one block's epilogue under the other's k-loop); bit-identical to the default, 7-20 % slower, 0 = off;
  * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose
  * conv outputs fill 256-row tiles, 64 channels per group; ~2 % of the headline step), 0 (default since round 3: the epilogue had two
- * nondeterministic faults in development whose root cause was never established - contained and stress-tested, but opt-in) =
- * separate GroupNorm launches;
+ * nondeterministic faults in development; round 4's ISA-level bisection - profiles/r04_gnf_fault.txt - shows packed-f32 code to be necessary
+ * and no wait state inside the issuing wave to be sufficient, but names no instruction-level cause: contained - no packed-f32 instruction in
+ * the built code object - and stress-tested, but opt-in) = separate GroupNorm launches;
+ * "gemm_trace" / "gemm_stagger" / "gemm_order" / "gemm_ld" / "bwd_side_rows": round-4 measurement switches and experiments (in-kernel cycle
+ * stamps of the persistent GEMM, start stagger, W-affine tile order, one wave of each SIMD pair issuing the whole DMA stream, the few-sample
+ * backward's weight gradients on a side stream), all off by default, results bit-identical - DESIGN.md 5, profiles/r04_*.txt;
  * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for
  * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
  * "pack_resample_lds": nearest-resampling mask pack, 1 (default) = source rows staged through LDS / 0 = per-pixel gather;
