@@ -413,7 +413,7 @@ def dist_legs(cfg, sd, dev, world, rank, steps):
         m.clip_grad_norm_(1.0)
         opt.step()
 
-    res = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "precision": m.precision, "samples_per_rank_per_step": B,
+    res = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "precision": m.train_precision, "samples_per_rank_per_step": B,
            "what": "forward_train + losses + backward + all-reduce (AVG) of the flat gradient arena + clip + AdamW on every rank; "
                    "the buckets of the arena are reduced in place on a side stream as sola_backward completes them (overlap) or after it"}
     for tag, ov, red in (("overlap", True, True), ("no_overlap", False, True), ("no_collective", True, False)):
