@@ -594,6 +594,7 @@ extern "C" int sola_set_x16_arena(SolaCtx* c, void* dev_ptr, size_t bytes) {
     c->x16_arena = static_cast<char*>(dev_ptr);
     c->x16_cap = dev_ptr ? bytes : 0;
     c->x16_used = 0;
+    if (!dev_ptr) c->x16_need = 0;  // a released arena: the next forward states its need afresh
     return SOLA_OK;
 }
 

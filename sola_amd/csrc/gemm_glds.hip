@@ -1196,7 +1196,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         // k-tile 0 of this tile is in LDS (waited for and published by the barrier of the previous tile's last k-tile, or by
         // the prologue).  Its first fragments are fetched here rather than kept in registers across the epilogue.
         Frags f0, f1;
-        load_frags(lds + stage * STAGE_BYTES, 0, f0);
         // One k-tile.  The k-loop itself must stay free of conditions: a scalar branch in front of the barrier (the relaxed
         // wait below) or behind it (switching the DMA stream to the next tile) cost 10 % and 2 % of the loop (measured,
         // one tile per CU), so the first k-tile is peeled for the wait and the last two for the stream switch.
@@ -1275,6 +1274,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                 if constexpr (ROLE == 0) setup_dma(next);
                 if constexpr (ROLE == 1) setup_dma_ld(next);
             };
+            // k-tile 0 of this tile is in LDS (see above).  Its first fragments are fetched here, inside the role's own loop: fetched in front of
+            // the role branch they stayed live - spilled - across the other role's code (LD != 0)
+            load_frags(lds + stage * STAGE_BYTES, 0, f0);
             int kt = 1;
             if (nk == 2 && has_next) switch_stream();
             ktile(std::true_type{}, rolec);
