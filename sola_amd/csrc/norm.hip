@@ -447,26 +447,15 @@ __global__ __launch_bounds__(256) void group_norm_slice_stats_kernel(const GnArg
             m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     m2 = block_sum_256(m2, red);
-    if (q.nslice > 1) {  // block-uniform
-        if (threadIdx.x == 0) slots[blockIdx.x] = make_float2(mean, m2);
-        return;
-    }
-    // a unit that fits one slice (the short samples of a ragged batch) is finished here, from the registers
-    const float rstd = 1.0f / sqrtf(m2 / ((float)ntok_i * (float)a.cg) + a.eps);
-    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
-    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
-    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)q.pe_row * a.C + ch);
-#pragma unroll
-    for (int r = 0; r < GNC_R; ++r) {
-        const int t = q.t0 + q.tl + r * q.tpp;
-        const long long off = t < q.ntok ? (q.row0 + (long long)t * q.tok_stride) * a.C + ch : -1;
-        gn_apply_store(a, off, v[r], mean, rstd, ga, be, pe, q.c4);
-    }
+    // One-slice units (the short samples of a ragged batch) used to be normalised HERE from the registers: that epilogue's 32 calls of
+    // gn_apply_store were not unrolled, v[] became a scratch array (528 bytes per lane) and every load of the loop above was followed by a
+    // wait and a scratch store - 206 us for 168 MB (round 4, tools/co_regs.py).  The apply launch takes every unit: same numbers
+    // (one slice: weight 1, d = 0), the slice's second read comes out of L2.
+    if (threadIdx.x == 0) slots[blockIdx.x] = make_float2(mean, m2);
 }
 __global__ __launch_bounds__(256) void group_norm_slice_apply_kernel(const GnArgs a, int S, const float2* __restrict__ slots) {
     const GncGeo q = gnc_geo(a, S);
-    if (q.t0 < 0 || q.nslice == 1) return;  // one-slice units were finished by the stats launch
+    if (q.t0 < 0) return;
     const int ts = q.tpp * GNC_R;
     const long long unit = blockIdx.x / S;
     // combine the unit's slices in index order (every block of the unit computes the same numbers)
