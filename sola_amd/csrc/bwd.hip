@@ -182,17 +182,29 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 xv[R], dv[R];
     float s = 0.f;
+    // Token slots beyond the unit load token 0 (always there) and are zeroed by a select: written as `t < ntok ? *(float4*)p : z` each
+    // load became FOUR predicated 4-byte loads in an exec-mask region of its own, and the dy2 term a load + wait per slot (round 4,
+    // tools/co_loads.py: 64 dword loads at R = 8; the inter-object norm's backward ran at half the speed its traffic allows).
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
-        const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-        xv[r] = t < ntok ? *reinterpret_cast<const float4*>(a.x + off) : z;
-        dv[r] = t < ntok ? *reinterpret_cast<const float4*>(a.dy + off) : z;
-        if (a.dy2 && t < ntok) {
-            const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
-            dv[r].x += e.x; dv[r].y += e.y; dv[r].z += e.z; dv[r].w += e.w;
-        }
+        const bool ok = t < ntok;
+        const long long off = (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch;
+        const float4 xr = *reinterpret_cast<const float4*>(a.x + off);
+        const float4 dr = *reinterpret_cast<const float4*>(a.dy + off);
+        xv[r] = make_float4(ok ? xr.x : 0.f, ok ? xr.y : 0.f, ok ? xr.z : 0.f, ok ? xr.w : 0.f);
+        dv[r] = make_float4(ok ? dr.x : 0.f, ok ? dr.y : 0.f, ok ? dr.z : 0.f, ok ? dr.w : 0.f);
         s += (xv[r].x + xv[r].y) + (xv[r].z + xv[r].w);
+    }
+    if (a.dy2) {  // block-uniform: the second gradient of the inter-object norm (x_obj feeds x_obj + pe too)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = tl + r * tpp;
+            const bool ok = t < ntok;
+            const long long off = (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch;
+            const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
+            dv[r].x += ok ? e.x : 0.f; dv[r].y += ok ? e.y : 0.f; dv[r].z += ok ? e.z : 0.f; dv[r].w += ok ? e.w : 0.f;
+        }
     }
     const float mean = (WAVE ? wave_sum(s) : bwd_block_sum<NTHR>(s, red)) / cnt;
     float q = 0.f;
