@@ -454,6 +454,9 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "train_x16_keep": 1 (default) = in the 16-bit operand training modes the forward keeps its fixed-scale operand casts (in the
  * arena the caller lends the context: sola_set_x16_arena) and the backward's weight-gradient products read them instead of casting the activations again
  * (the split-f16 step's operand casts write their hi halves once more as plain f16 rows for that purpose);
+ * "train_attn_cast": 1 (default) = in the f16 / bf16 operand training steps the forward's attention kernels also write the operand cast of
+ * their output that the out-projection GEMM takes (where the shape can; bit-identical to the separate cast launch: -0.5 % of the ragged step),
+ * 2 = the split-f16 step too (pairs + the plain-f16 side copy: measured no gain), 0 = always the cast launch;
  * "gemm_k16": experimental one-tile-per-block shape of the split-f16 GEMM - 256x128 tiles, 16-deep k-tiles, two four-wave blocks per
  * CU (one block's epilogue under the other's k-loop); bit-identical to the default, 7-20 % slower, 0 = off;
  * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose

@@ -27,6 +27,9 @@ struct AttnSArgs {
     int xcd_remap;
     float* lse;       // TR instantiation: optional [q rows][H] log-sum-exp of the scaled scores (saved for the backward)
     DropoutCfg drop;  // TR instantiation: dropout on the probabilities (tools/attention.py:71), same counter-based mask as attn.hip
+    void* o_cast;     // TR instantiation: AttnDesc::o_cast / o_side / o_cast_fmt
+    void* o_side;
+    int o_cast_fmt;
 };
 
 // DB: two LDS stages of TK keys; the next tile's K/V rows travel in registers while the current tile is multiplied and there
@@ -202,6 +205,46 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
 #pragma unroll
         for (int c = 0; c < NC; ++c)
             *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        if constexpr (TR) {
+            if (a.o_cast) {  // the out-projection's operand cast of the same values (uniform branch)
+                const long long eo = (q0 + (long long)qi * q_rs) * a.ldo + h * DH;  // element offset of this row's head slice
+                if (a.o_cast_fmt == 1) {
+                    float* pp = static_cast<float*>(a.o_cast) + eo;
+                    _Float16* sd = a.o_side ? static_cast<_Float16*>(a.o_side) + eo : nullptr;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        half4v hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            _Float16 h1, l1;
+                            split_f16(oacc[c][j] * inv, h1, l1);
+                            hi[j] = h1; lo[j] = l1;
+                        }
+                        char* dst = reinterpret_cast<char*>(pp + c * 16 + 8 * (g4 >> 1)) + 8 * (g4 & 1);
+                        *reinterpret_cast<half4v*>(dst) = hi;
+                        *reinterpret_cast<half4v*>(dst + 16) = lo;
+                        if (sd) *reinterpret_cast<half4v*>(sd + c * 16 + 4 * g4) = hi;
+                    }
+                } else {
+                    _Float16* cp = static_cast<_Float16*>(a.o_cast) + eo;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        half4v hv;
+                        if (a.o_cast_fmt == 3) {
+                            typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+                            bf16x4s b;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) b[j] = (__bf16)(oacc[c][j] * inv);
+                            hv = __builtin_bit_cast(half4v, b);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hv[j] = (_Float16)(oacc[c][j] * inv);
+                        }
+                        *reinterpret_cast<half4v*>(cp + c * 16 + 4 * g4) = hv;
+                    }
+                }
+            }
+        }
         return;
     }
     float m = 0.f;
@@ -771,6 +814,7 @@ static AttnSArgs make_sargs(const AttnDesc& d) {
     a.xcd_remap = 0;
     a.lse = d.lse;
     a.drop = d.drop;
+    a.o_cast = nullptr; a.o_side = nullptr; a.o_cast_fmt = 0;  // launch_attention_simple's training instantiation takes them
     return a;
 }
 
@@ -797,7 +841,11 @@ bool attention_simple_supported(const AttnDesc& d) {
 void sola_attn_set_simple_train(int v) { g_attn_simple_train = v; }
 
 int launch_attention_simple(const AttnDesc& d, hipStream_t s) {
-    const AttnSArgs a = make_sargs(d);
+    AttnSArgs a = make_sargs(d);
+    if (d.o_cast && d.o_cast_done && (d.lse || d.drop.enabled) && !d.o_sp16 && d.ldo % 8 == 0) {  // the TR instantiation runs (launch_s)
+        a.o_cast = d.o_cast; a.o_side = d.o_cast_fmt == 1 ? d.o_side : nullptr; a.o_cast_fmt = d.o_cast_fmt;
+        *d.o_cast_done = true;
+    }
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     return d.DH == 128 ? launch_s<128>(a, s) : launch_s<64>(a, s);

@@ -11,6 +11,8 @@
 int g_train_gn_cast = 1;  // sola_tune "train_gn_cast": 1 = a GroupNorm of the training forward also writes the operand cast of the GEMM behind it
 void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
 extern int g_train_dw_f16;
+int g_train_attn_cast = 1;  // sola_tune "train_attn_cast": 1 = f16 / bf16 operand steps: the training forward's attention kernels also write the out-projection's operand cast; 2 = the split-f16 step too
+void sola_train_set_attn_cast(int v) { g_train_attn_cast = v; }
 int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
@@ -338,6 +340,25 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         }
         return launch_gemm(gd, s);
     };
+    // The attention output's operand cast for the out-projection is written by the attention kernel itself where its shape can
+    // (AttnDesc::o_cast, round 4; sola_tune "train_attn_cast" 0 = always the separate cast launch)
+    const float* ac_src = nullptr;
+    float* ac_dst = nullptr;
+    void* ac_side = nullptr;
+    bool ac_done = false;
+    auto attention = [&](AttnDesc& ad) -> int {
+        ac_src = nullptr; ac_done = false;
+        // measured on the 64-sample ragged mix (same box): f16 operands 22.67 -> 22.55 ms per step (attention +0.10 ms, cast launches -0.26 ms);
+        // split pairs + side copy (10 instead of 4 bytes per element out of a latency-bound kernel) 31.76 -> 31.78 ms: no gain, so the
+        // split-f16 step keeps its cast launches unless the key is 2
+        if (split && (pure ? g_train_attn_cast != 0 : g_train_attn_cast == 2) && ad.ldo == D) {
+            ac_src = ad.o;
+            ac_dst = slot16(0, ad.o, M, D);
+            ac_side = side16(ad.o, M, D);
+            ad.o_cast = ac_dst; ad.o_side = ac_side; ad.o_cast_fmt = pure ? 2 + bf : 1; ad.o_cast_done = &ac_done;
+        }
+        return launch_attention(ad, s);
+    };
     auto out_proj = [&](const std::string& attn, const float* ao, const float* resid, float* res) -> int {
         GemmDesc gd{};
         gd.nprob = 1;
@@ -345,8 +366,15 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split) {
-            float* dst = slot16(0, ao, M, D);
-            SOLA_TRY(cast_fixed(ao, D, dst, M, D, 1.f, side16(ao, M, D)));
+            float* dst;
+            if (ac_src == ao) {  // attention() reserved the operand's place; the attention kernel wrote it unless its shape cannot
+                dst = ac_dst;
+                if (!ac_done) SOLA_TRY(cast_fixed(ao, D, dst, M, D, 1.f, ac_side));
+            } else {
+                dst = slot16(0, ao, M, D);
+                SOLA_TRY(cast_fixed(ao, D, dst, M, D, 1.f, side16(ao, M, D)));
+            }
+            ac_src = nullptr;
             gd.p[0].A = dst; gd.p[0].W = lin16(attn, 3); gd.p[0].scale_dev = lin_inv(attn, 3);
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
         }
@@ -395,7 +423,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                         (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale, lse(0)};
             if (rs) { ad.G = rt.sumTpS; ad.inner = 1; ad.q_units = rt.u_st; }
             if (train) ad.drop = c->attn_drop(l, 0);
-            SOLA_TRY(launch_attention(ad, s));
+            SOLA_TRY(attention(ad));
         }
         SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
         if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st, x_pe, x_obj));
@@ -407,7 +435,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                         (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale, lse(1)};
             if (rs) { ad.G = rt.sumNS; ad.q_units = rt.u_strk; }
             if (train) ad.drop = c->attn_drop(l, 1);
-            SOLA_TRY(launch_attention(ad, s));
+            SOLA_TRY(attention(ad));
         }
         SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
         if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk, x_mot));
@@ -421,7 +449,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                         (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale, lse(2)};
             if (rs) { ad.Sq = rt.maxRowsSample; ad.q_units = rt.u_smp; ad.k_units = rt.u_langk; }
             if (train) ad.drop = c->attn_drop(l, 2);
-            SOLA_TRY(launch_attention(ad, s));
+            SOLA_TRY(attention(ad));
         }
         SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));
         // the next layer's q / k / v projections read x_o2l: its norm writes their operand (nothing reads it behind the last layer)

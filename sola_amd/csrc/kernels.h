@@ -163,6 +163,15 @@ struct AttnDesc {
     // f32 q / k / v, but the caller's arithmetic is the split-f16 mode's: QK^T and PV may be evaluated as hi*hi + hi*lo + lo*hi
     // on f16 MFMAs (22-bit products, f32 accumulate and softmax) instead of the exact-f32 MFMA (attn_simple.hip)
     int split_math;
+    // training forward, optional (round 4): the operand cast of the output that the out-projection GEMM behind this launch takes, written by
+    // the attention kernel next to the f32 output (the cast launch read the f32 output back: 62 us per attention on the ragged mix).
+    // o_cast_fmt 1: split-f16 pairs (rows of ldo floats) + optionally o_side = the hi halves once more as plain f16 rows (ldo halfs; the
+    // backward's dW operand); 2 / 3: plain f16 / bfloat16 rows (ldo halfs).  Unscaled, bit-identical to launch_cast_sp16 / launch_cast_f16.
+    // Only some shapes write it: the launch that did sets *o_cast_done (else the caller casts as before).
+    void* o_cast = nullptr;
+    void* o_side = nullptr;
+    int o_cast_fmt = 0;
+    bool* o_cast_done = nullptr;
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 

@@ -244,6 +244,35 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("train", [True, False])
+def test_attention_written_operand_casts_give_the_same_ragged_step_bit_for_bit(full, precision, train):
+    """Round 4: the training forward's attention kernels write the out-projection's operand cast themselves (AttnDesc::o_cast; sola_tune
+    "train_attn_cast" 1, the default) - split pairs + the plain-f16 side copy in the split-f16 step, f16 / bf16 rows in the 16-bit operand
+    steps.  Against the separate cast launch (0): same loss, every gradient bit for bit, with dropout on (training mode: the simple
+    kernel's training instantiation takes all three attentions of a ragged batch) and off."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    full.precision = precision
+    was_training = full.training
+    full.train(train)
+    got = {}
+    try:
+        samples = [sample_inputs(cfg, N, T, L, 450 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
+        for fold in (2, 0):  # 2: the split-f16 step too (1, the default, covers the f16 / bf16 operand steps only)
+            _lib.check(_lib.lib().sola_tune(b"train_attn_cast", fold), "tune")
+            torch.manual_seed(1234)  # the dropout masks' seeds come from torch's CPU generator: the same two masks for both settings
+            for _ in range(2):
+                loss, g, _ = ragged_step(full, samples)
+            got[fold] = (g, loss)
+    finally:
+        full.precision = "f32"
+        full.train(was_training)
+        _lib.check(_lib.lib().sola_tune(b"train_attn_cast", 1), "tune")
+    assert torch.equal(got[2][1], got[0][1])
+    bad = [k for k in got[2][0] if not torch.equal(got[2][0][k], got[0][0][k])]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
 def test_row_major_weight_gradient_route_equals_the_transposed_copy_route_on_a_ragged_batch(full, precision):
     """sola_tune "train_tn_tr" 1 (default: gemm_tn_tr_kernel on row-major 16-bit operands, conv taps gathered through the ragged row
     maps in the DMA addresses, the forward's kept operand casts) against 0 (transposing casts, one per conv tap, + the NT kernel): the
