@@ -6,6 +6,9 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <initializer_list>
+#include <string>
+#include <vector>
 
 #include "ragged.h"
 
@@ -28,6 +31,12 @@ void sola_train_set_dw_f16(int v) { g_train_dw_f16 = v; }
 // per step (tools/train_one_probe.py, profiles/r04_train_one_sample.txt) the step is bound by the HOST's enqueue rate as much as by the GPU
 // (2.2 ms of host time per 2.7 ms step), and the ~60 event records / waits of the lane cost more host time (+0.5 ms) than the overlap saves.
 int g_bwd_side_rows = 0;
+// sola_tune "bwd_group_rows" (round 4): an exact-f32 backward of at most this many token rows DEFERS the weight-gradient products of its
+// linear layers - every dY keeps a buffer of its own - and runs them all in ONE grouped launch behind the layers (gemm_tn.hip:
+// gemm_tn_f32_group_kernel; 24 products + 48 slab reductions -> 1 launch), and transposes the weights its dX GEMMs read in one launch in
+// front of them (36 -> 1).  At one sample per step (the reference's batch size) that is a third of the step's launches.  0 = off.
+// Same products, a different (still fixed) summation order over the rows: deterministic, not bit-identical to the slab form.
+int g_bwd_group_rows = 2048;
 
 namespace {
 
@@ -110,6 +119,10 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
     // for their deterministic two-pass split-K, as the forward has (42-136 us per dX GEMM without it, 64 blocks on 256 CUs)
     if (M <= 8192) a.add("splitk", (size_t)8192 * 4096);
     const bool lowp = c->precision >= 1 && (long long)M >= g_train_split_min_rows;
+    if (!lowp && g_bwd_group_rows > 0 && M <= (size_t)g_bwd_group_rows) {  // few-sample exact-f32 backward: deferred grouped dW (see g_bwd_group_rows)
+        a.add("dwkeep", (size_t)c->cfg.n_layers * (12 * M * D + 2 * BW * D + 7 * 64));  // per layer: 3 dres + 3 dqkv (3D wide) + dlkv
+        a.add("wtkeep", (size_t)c->cfg.n_layers * 12 * D * D);                          // every transposed weight block of the dX GEMMs
+    }
     {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather: the split-f16 / f16 modes, and every ragged batch
         // (the f32 path's transposed-conv gather needs one sequence length)
         size_t zmax = 0;
@@ -236,6 +249,55 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         for (hipEvent_t& e : c->ev_side) SOLA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     hipStream_t s2 = lane_on ? c->side_stream : s;
+    // ---- few-sample exact-f32 backward: deferred, grouped weight gradients of the linear layers + one grouped weight transposition
+    //      (g_bwd_group_rows).  keep(): the next private buffer for a gradient matrix a deferred product reads at the end.
+    const bool group = !split && !lane_on && ar.off.count("dwkeep") != 0;
+    float* keep_ptr = group ? ar.get("dwkeep") : nullptr;
+    auto keep = [&](size_t floats) { float* q = keep_ptr; keep_ptr += (floats + 63) & ~(size_t)63; return q; };
+    GemmTnGroupDesc gq{};
+    gq.N = D; gq.K = D;
+    auto flush_group = [&]() -> int {
+        if (gq.nprob == 0) return SOLA_OK;
+        SOLA_TRY(launch_gemm_tn_group(gq, s));
+        gq.nprob = 0;
+        return SOLA_OK;
+    };
+    // the transposed weight blocks in the order the layer loop consumes them: per layer (last first) and sub-block (object->language, motion,
+    // inter-object) the out-projection, then the q / k / v blocks exactly as the dX GEMMs take them (transpose_into below)
+    struct WtUse { const float* w[3]; int nw; float* dst; };
+    std::vector<WtUse> wt_seq;
+    size_t wt_next = 0;
+    if (group) {
+        float* base = ar.get("wtkeep");
+        size_t off = 0;
+        auto use = [&](std::initializer_list<std::string> names) {
+            WtUse u{};
+            for (const std::string& n : names) u.w[u.nw++] = W(n);
+            u.dst = base + off;
+            off += (size_t)D * D * u.nw;
+            wt_seq.push_back(u);
+        };
+        for (int l = c->cfg.n_layers - 1; l >= 0; --l) {
+            const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
+            const std::string o2l = lp + kAttnLong[2], mot = lp + kAttnLong[1], obj = lp + kAttnLong[0];
+            use({o2l + ".out_proj.weight"});
+            use({o2l + ".q_proj.weight"});
+            use({o2l + ".k_proj.weight", o2l + ".v_proj.weight"});
+            use({mot + ".out_proj.weight"});
+            use({mot + ".q_proj.weight", mot + ".k_proj.weight"});
+            use({mot + ".v_proj.weight"});
+            use({obj + ".out_proj.weight"});
+            use({obj + ".q_proj.weight", obj + ".k_proj.weight", obj + ".v_proj.weight"});
+        }
+        TransposeGroupDesc td{};
+        for (const WtUse& u : wt_seq)
+            for (int j = 0; j < u.nw; ++j) {
+                if (td.n == 48) { SOLA_TRY(launch_transpose_group(td, s)); td.n = 0; }
+                td.in[td.n] = u.w[j]; td.out[td.n] = u.dst; td.rows[td.n] = D; td.cols[td.n] = D; td.ldo[td.n] = u.nw * D; td.col_off[td.n] = j * D;
+                ++td.n;
+            }
+        if (td.n) SOLA_TRY(launch_transpose_group(td, s));
+    }
     bool side_pending[4] = {false, false, false, false};
     auto dw_begin = [&]() -> int {
         if (!lane_on) return SOLA_OK;
@@ -304,6 +366,15 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     auto grad_w_many = [&](const WG* g, int n, int ldy, int ldx, int rows, int n_out, int k_in, float* sc = nullptr, bool db_done = false,
                            bool* dy_rm_done = nullptr) -> int {
         if (dy_rm_done) *dy_rm_done = false;
+        if (group && n_out == D && k_in == D) {  // deferred: one grouped launch behind the layers (the dY buffers are private: keep())
+            for (int j = 0; j < n; ++j) {
+                if (gq.nprob == 32) SOLA_TRY(flush_group());
+                const int q = gq.nprob++;
+                gq.A[q] = g[j].dY; gq.B[q] = g[j].X; gq.C[q] = g[j].dW; gq.bias_grad[q] = db_done ? nullptr : g[j].db;
+                gq.M[q] = rows; gq.lda[q] = ldy; gq.ldb[q] = ldx;
+            }
+            return SOLA_OK;
+        }
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
             d.scal = sc; d.pure = pure ? 1 + bf : (dw16 ? 1 : 0); d.rm_split = dw16 ? 1 : 0;
@@ -358,6 +429,16 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         return launch_gemm(d, s);
     };
     auto transpose_into = [&](const float* w, int n_out, int k_in, int n_cat, int col_off) -> int {
+        if (group) {  // already transposed (one launch in front of the layers): switch wt to the block this dX GEMM reads
+            if (col_off == 0) {
+                SOLA_ARG(wt_next < wt_seq.size(), "backward: more transposed weight blocks than planned");
+                wt = wt_seq[wt_next++].dst;
+            }
+            const WtUse& u = wt_seq[wt_next - 1];
+            SOLA_ARG(n_out == D && k_in == D && n_cat == u.nw * D && col_off % D == 0 && col_off / D < u.nw && u.w[col_off / D] == w,
+                     "backward: transposed weight block out of the planned order");
+            return SOLA_OK;
+        }
         if (split && n_cat % (pure ? 64 : 32) == 0) {  // grad_x's condition for the reduced-precision GEMM: the operand is written directly
             wt_sp_ready = true;
             return launch_transpose_cast(w, ar.get("wt_sp"), n_out, k_in, k_in, n_cat, col_off, kLinScale, pure ? 1 + bf : 0, s);
@@ -432,6 +513,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         // (iii) object -> language: x_o2l = GN2(x_mot + attn(q(x_mot), k(lang), v(lang)) Wo)
         {
             const std::string an = lp + "object2lang_attn";
+            if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); dlkv = keep((size_t)BW * 2 * D); }
             SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, max_rows_smp, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr));
             SOLA_TRY(out_proj_bwd(2));
@@ -474,6 +556,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         // (ii) motion: x_mot = GN1(x_obj + attn(q(x_obj+pe), k(x_obj+pe), v(x_obj)) Wo)
         {
             const std::string an = lp + "motion_attn";
+            if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, R, 1, Tp, 0, 1, Tp, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr));
             SOLA_TRY(out_proj_bwd(1));
@@ -510,6 +593,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         // (i) inter-object: x_obj = GN0(xin + attn(q,k,v(xin)) Wo); x_obj also feeds x_obj + pe
         {
             const std::string an = lp + "obj_attn";
+            if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr));
             SOLA_TRY(out_proj_bwd(0));
@@ -542,8 +626,13 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         }
         if (l > 0) {
             SOLA_TRY(join_side());
-            SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final
+            if (!group) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final
         }
+    }
+    if (group) {  // the deferred weight gradients of every layer: one launch; all layer buckets are final behind it
+        wt = ar.get("wt");  // the encoder's dX GEMMs transpose into the shared buffer again
+        SOLA_TRY(flush_group());
+        for (int l = c->cfg.n_layers - 1; l > 0; --l) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));
     }
 
     // ---- negative tokens: rows L.. of d(lang ++ neg) from the k/v projections + the mean-over-W of the score head

@@ -7,6 +7,7 @@
 // Exact f32 on v_mfma_f32_32x32x2_f32.  The reduction index m is the slow (row) index of both operands, so tiles are
 // staged [32 m][128 cols] with coalesced float4 row loads and the MFMA fragments are ds_read_b32 across the columns
 // (lanes 0-31 take row m, lanes 32-63 row m+1: consecutive addresses, conflict-free).
+#include <algorithm>
 #include <utility>
 
 #include "kernels.h"
@@ -28,15 +29,14 @@ constexpr int TB = 128;       // output tile (n and k)
 constexpr int TM = 32;        // rows of the reduction per LDS stage
 constexpr int TP = TB + 4;    // LDS pitch (floats), 16-byte aligned rows
 
-__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// one (tile, row split) work item: tile = tn * tiles_k + tk
+__device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, float* smem) {
     float* As = smem;                 // [2][TM][TP]
     float* Bs = smem + 2 * TM * TP;   // [2][TM][TP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int tn = blockIdx.x / a.tiles_k, tk = blockIdx.x % a.tiles_k;
+    const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
     const int n0 = tn * TB, k0 = tk * TB;
-    const int split = blockIdx.y;
     const int m_begin = split * a.m_per_split;
     const int m_end = min(a.M, m_begin + a.m_per_split);
 
@@ -150,6 +150,71 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
                 const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                 if (n < a.N) P[(long long)n * a.K + k] = acc[i][j][r];
             }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    tn_tile(a, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
+// ---- grouped form (round 4): the weight gradients of ALL linear layers of a few-sample step in ONE launch --------------------------
+// One sample per optimizer step (the reference's batch size) has 256-2000 token rows: a [1024 x 1024] weight gradient is 64 tiles
+// whose reduction over the rows is 8-60 stages.  Per matrix the launch above cut the rows into slabs to fill the chip (16 MB of
+// partial sums written and read back per matrix) and two sum_slabs launches folded them: 24 + 48 launches of 5-17 us per step, 0.63
+// ms of a 2.7 ms step.  The backward now defers these products (backward.hip): each dY keeps a buffer of its own until the end, and
+// this kernel takes them all - blockIdx.x = (problem, tile), every block reduces over ALL rows of its problem and writes its dW tile
+// and bias gradient directly (no partial sums, no second pass, fixed summation order).
+constexpr int TN_GROUP_MAX = 32;
+struct TnGroupArgs {
+    const float* A[TN_GROUP_MAX];
+    const float* B[TN_GROUP_MAX];
+    float* C[TN_GROUP_MAX];
+    float* db[TN_GROUP_MAX];
+    int M[TN_GROUP_MAX];
+    int lda[TN_GROUP_MAX], ldb[TN_GROUP_MAX];
+    int N, K, tiles_n, tiles_k;
+};
+__global__ __launch_bounds__(256) void gemm_tn_f32_group_kernel(const TnGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles = g.tiles_n * g.tiles_k;
+    const int p = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - p * tiles;
+    TnArgs a;
+    a.A = g.A[p]; a.B = g.B[p]; a.P = g.C[p]; a.Pb = g.db[p];
+    a.M = g.M[p]; a.N = g.N; a.K = g.K; a.lda = g.lda[p]; a.ldb = g.ldb[p];
+    a.conv = 0; a.T_in = a.T_out = a.stride = a.pad = a.Cin = 0; a.rowmap = nullptr;
+    a.tiles_n = g.tiles_n; a.tiles_k = g.tiles_k;
+    a.m_per_split = (a.M + TM - 1) / TM * TM;  // one split: every row
+    tn_tile(a, tile, 0, smem);
+}
+
+// out_e[c * ldo_e + col_off_e + r] = in_e[r * ldi_e + c] for up to TR_GROUP_MAX matrices in one launch (blockIdx.z = e): the weight
+// transpositions W -> W^T of a few-sample backward's dX GEMMs (36 launches of ~5 us per step)
+constexpr int TR_GROUP_MAX = 48;
+struct TrGroupArgs {
+    const float* in[TR_GROUP_MAX];
+    float* out[TR_GROUP_MAX];
+    int rows[TR_GROUP_MAX], cols[TR_GROUP_MAX], ldo[TR_GROUP_MAX], col_off[TR_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void transpose_group_kernel(const TrGroupArgs g) {
+    __shared__ float tile[32][33];
+    const int e = blockIdx.z;
+    const int rows = g.rows[e], cols = g.cols[e];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (r0 >= rows || c0 >= cols) return;  // the grid is sized for the largest matrix (block-uniform)
+    const float* __restrict__ in = g.in[e];
+    float* __restrict__ out = g.out[e];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = in[(long long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) out[(long long)c * g.ldo[e] + g.col_off[e] + r] = tile[tx][ty + 8 * i];
     }
 }
 
@@ -315,6 +380,46 @@ int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
             SOLA_LAUNCH_CHECK();
         }
     }
+    return SOLA_OK;
+}
+
+int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s) {
+    SOLA_ARG(d.nprob >= 1 && d.nprob <= TN_GROUP_MAX && d.N > 0 && d.K > 0 && d.N % 4 == 0 && d.K % 4 == 0, "gemm_tn_group: nprob=%d N=%d K=%d", d.nprob, d.N, d.K);
+    TnGroupArgs g;
+    double rows = 0;
+    for (int j = 0; j < d.nprob; ++j) {
+        SOLA_ARG(d.A[j] && d.B[j] && d.C[j] && d.M[j] > 0 && d.lda[j] % 4 == 0 && d.ldb[j] % 4 == 0, "gemm_tn_group: problem %d", j);
+        g.A[j] = d.A[j]; g.B[j] = d.B[j]; g.C[j] = d.C[j]; g.db[j] = d.bias_grad[j]; g.M[j] = d.M[j]; g.lda[j] = d.lda[j]; g.ldb[j] = d.ldb[j];
+        rows += d.M[j];
+    }
+    g.N = d.N; g.K = d.K; g.tiles_n = (d.N + TB - 1) / TB; g.tiles_k = (d.K + TB - 1) / TB;
+    constexpr size_t lds = (size_t)4 * TM * TP * sizeof(float);
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done(dev);
+    }
+    SolaProfScope prof(SOLA_PROF_GEMM_TN, s, 2.0 * rows * d.N * (double)d.K, 4.0 * (rows * (d.N + d.K) + (double)d.nprob * d.N * d.K));
+    hipLaunchKernelGGL(gemm_tn_f32_group_kernel, dim3((unsigned)(d.nprob * g.tiles_n * g.tiles_k)), dim3(256), lds, s, g);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_transpose_group(const TransposeGroupDesc& d, hipStream_t s) {
+    SOLA_ARG(d.n >= 1 && d.n <= TR_GROUP_MAX, "transpose_group: %d matrices", d.n);
+    TrGroupArgs g;
+    int max_r = 0, max_c = 0;
+    double el = 0;
+    for (int e = 0; e < d.n; ++e) {
+        SOLA_ARG(d.in[e] && d.out[e] && d.rows[e] > 0 && d.cols[e] > 0, "transpose_group: matrix %d", e);
+        g.in[e] = d.in[e]; g.out[e] = d.out[e]; g.rows[e] = d.rows[e]; g.cols[e] = d.cols[e]; g.ldo[e] = d.ldo[e]; g.col_off[e] = d.col_off[e];
+        max_r = std::max(max_r, d.rows[e]); max_c = std::max(max_c, d.cols[e]);
+        el += (double)d.rows[e] * d.cols[e];
+    }
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * el);
+    hipLaunchKernelGGL(transpose_group_kernel, dim3((max_c + 31) / 32, (max_r + 31) / 32, d.n), dim3(256), 0, s, g);
+    SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 

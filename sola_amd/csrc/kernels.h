@@ -68,6 +68,25 @@ struct GemmTnDesc {
     size_t scratch_bytes;
     const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap (T_in / T_out / stride / pad are then unused)
 };
+// Grouped exact-f32 form (few-sample steps): up to 32 problems dW_j = A_j^T B_j (+ bias gradients) sharing N and K, each reduced over all
+// of its own M_j rows by the blocks of its tiles - one launch, no partial sums (gemm_tn.hip)
+struct GemmTnGroupDesc {
+    const float* A[32];
+    const float* B[32];
+    float* C[32];
+    float* bias_grad[32];  // optional per problem
+    int M[32], lda[32], ldb[32];
+    int nprob, N, K;
+};
+int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s);
+// up to 48 transpositions out_e[c][col_off_e + r] = in_e[r][c] (in_e contiguous [rows_e][cols_e], out pitch ldo_e) in one launch
+struct TransposeGroupDesc {
+    const float* in[48];
+    float* out[48];
+    int rows[48], cols[48], ldo[48], col_off[48];
+    int n;
+};
+int launch_transpose_group(const TransposeGroupDesc& d, hipStream_t s);
 // Split-f16 version (gemm_tn_split.hip): up to three problems dW_j = A_j^T B_j sharing M, N, K and the pitches
 struct GemmTnSplitDesc {
     const float* A[3];  // dY_j [M, N], pitch lda (column slices of one buffer are fine)

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sola_amd import _lib, synth
 from sola_amd.loss import track_selection_losses
 from sola_amd.module import LanguageAlignedTrackSelectionModule
+for kv in sys.argv[1:]:  # sola_tune switches for A/B runs: key=value
+    k, v = kv.split("="); _lib.check(_lib.lib().sola_tune(k.encode(), int(v)), kv)
 cfg = synth.DEFAULT_MODEL_CFG
 m = LanguageAlignedTrackSelectionModule(cfg)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()}, strict=True)
