@@ -1009,14 +1009,18 @@ static bool bwd_fused_supported(const AttnBwdArgs& a, int DH, bool can_chunk) {
     if (!g_attn_bwd_fused || DH != 128 || a.Sk > 128) return false;
     return a.Sq <= 128 || (a.Sk <= 64 && (a.Sq <= 16 * kBwdChunkTiles || can_chunk));
 }
-static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, hipStream_t s) {
+// few-sample launches (at most kBwdFewRows query rows in total - one sample per step is 256-2000): chunks of 4 tiles = 64 queries, so that
+// a single unit's eight (unit, head) blocks become 8 x Sq/64 (one sample of 256 queries: 75 -> ~25 us per launch)
+constexpr int kBwdFewRows = 4096, kBwdFewChunkTiles = 4;
+static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, long long part_rows, hipStream_t s) {
     // waves per (unit, head) = key tiles held in registers at a time, sized by the LONGEST unit of the launch
     int chunks = 1;
     a.qc_tiles = 0;
     a.ntile = g_attn_bwd_ablate;
-    if (a.Sq > 16 * kBwdChunkTiles && can_chunk) {
-        a.qc_tiles = kBwdChunkTiles;
-        chunks = ((a.Sq + 15) / 16 + kBwdChunkTiles - 1) / kBwdChunkTiles;
+    const int qc = (can_chunk && part_rows <= kBwdFewRows) ? kBwdFewChunkTiles : kBwdChunkTiles;
+    if (a.Sq > 16 * qc && can_chunk) {
+        a.qc_tiles = qc;
+        chunks = ((a.Sq + 15) / 16 + qc - 1) / qc;
     }
     if (a.Sk <= 16) return launch_bwd_fused_n<1>(a, chunks, s);
     if (a.Sk <= 32) return launch_bwd_fused_n<2>(a, chunks, s);
@@ -1118,7 +1122,8 @@ int launch_bwd_dh(const AttnBwdArgs& a0, hipStream_t s) {
 
 size_t attention_bwd_part_floats(long long q_rows, int G, int H, int Sk) {
     if (Sk > 64) return 0;
-    return (size_t)(q_rows / (16 * kBwdChunkTiles) + G + 1) * H * 2 * 64 * 128;
+    const int qc = q_rows <= 4096 ? 4 : 16;  // kBwdFewRows / kBwdFewChunkTiles / kBwdChunkTiles (launch_bwd_fused)
+    return (size_t)(q_rows / (16 * qc) + G + 1) * H * 2 * 64 * 128;
 }
 
 void sola_attn_set_bwd_small(int v) { g_attn_bwd_small = v; }
@@ -1149,7 +1154,7 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.part = d.part;
     const bool can_chunk = d.part && d.Sk <= 64 && d.part_floats >= attention_bwd_part_floats(d.part_rows, d.G, d.H, d.Sk) &&
                            (d.q_units || (d.q_rs == 1 && d.inner == 1));
-    if (bwd_fused_supported(a, d.DH, can_chunk)) return launch_bwd_fused(a, can_chunk, s);
+    if (bwd_fused_supported(a, d.DH, can_chunk)) return launch_bwd_fused(a, can_chunk, d.part_rows, s);
     switch (d.DH) {
         case 128: return launch_bwd_dh<128>(a, s);
         case 64: return launch_bwd_dh<64>(a, s);
