@@ -120,7 +120,9 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
     if (M <= 8192) a.add("splitk", (size_t)8192 * 4096);
     const bool lowp = c->precision >= 1 && (long long)M >= g_train_split_min_rows;
     if (!lowp && g_bwd_group_rows > 0 && M <= (size_t)g_bwd_group_rows) {  // few-sample exact-f32 backward: deferred grouped dW (see g_bwd_group_rows)
-        a.add("dwkeep", (size_t)c->cfg.n_layers * (12 * M * D + 2 * BW * D + 7 * 64));  // per layer: 3 dres + 3 dqkv (3D wide) + dlkv
+        size_t enc_keep = 0;  // + the encoder stages' dY (GroupNorm backward outputs) for the deferred conv weight gradients
+        for (int i = 0; i < 5; ++i) enc_keep += z.rows[i + 1] * (size_t)c->conv[i].cout + 64;
+        a.add("dwkeep", (size_t)c->cfg.n_layers * (12 * M * D + 2 * BW * D + 7 * 64) + enc_keep);  // per layer: 3 dres + 3 dqkv (3D wide) + dlkv
         a.add("wtkeep", (size_t)c->cfg.n_layers * 12 * D * D);                          // every transposed weight block of the dX GEMMs
     }
     {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather: the split-f16 / f16 modes, and every ragged batch
@@ -255,7 +257,6 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     float* keep_ptr = group ? ar.get("dwkeep") : nullptr;
     auto keep = [&](size_t floats) { float* q = keep_ptr; keep_ptr += (floats + 63) & ~(size_t)63; return q; };
     GemmTnGroupDesc gq{};
-    gq.N = D; gq.K = D;
     auto flush_group = [&]() -> int {
         if (gq.nprob == 0) return SOLA_OK;
         SOLA_TRY(launch_gemm_tn_group(gq, s));
@@ -369,9 +370,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         if (group && n_out == D && k_in == D) {  // deferred: one grouped launch behind the layers (the dY buffers are private: keep())
             for (int j = 0; j < n; ++j) {
                 if (gq.nprob == 32) SOLA_TRY(flush_group());
-                const int q = gq.nprob++;
-                gq.A[q] = g[j].dY; gq.B[q] = g[j].X; gq.C[q] = g[j].dW; gq.bias_grad[q] = db_done ? nullptr : g[j].db;
-                gq.M[q] = rows; gq.lda[q] = ldy; gq.ldb[q] = ldx;
+                GemmTnGroupDesc::Prob& q = gq.p[gq.nprob++];
+                q = GemmTnGroupDesc::Prob{};
+                q.A = g[j].dY; q.B = g[j].X; q.C = g[j].dW; q.bias_grad = db_done ? nullptr : g[j].db;
+                q.M = rows; q.N = n_out; q.K = k_in; q.lda = ldy; q.ldb = ldx;
             }
             return SOLA_OK;
         }
@@ -684,9 +686,18 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.rowmap = rowmap;
             d.scratch = tn; d.scratch_bytes = tn_bytes;
+            if (group) {  // deferred with the other few-sample weight gradients: dy stays intact (keep() below)
+                if (gq.nprob == 32) SOLA_TRY(flush_group());
+                GemmTnGroupDesc::Prob& q = gq.p[gq.nprob++];
+                q = GemmTnGroupDesc::Prob{};
+                q.A = d.A; q.B = d.B; q.C = d.C; q.bias_grad = d.bias_grad; q.rowmap = d.rowmap;
+                q.M = d.M; q.N = d.N; q.K = d.K; q.lda = d.lda; q.ldb = d.ldb;
+                q.conv = d.conv; q.T_in = d.T_in; q.T_out = d.T_out; q.stride = d.stride; q.pad = d.pad; q.Cin = d.Cin;
+            } else {
             SOLA_TRY(dw_begin());
             SOLA_TRY(launch_gemm_tn(d, s2));
             SOLA_TRY(dw_end(2));
+            }
         }
         if (i == 0) break;
         // d act_{i-1}[(r, ti)][ci] = sum_{kk, co} dY[(r, to)][co] w_std[co][kk][ci]: the NT kernel with the transposed-conv
@@ -739,11 +750,13 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         // GroupNorm + LeakyReLU backward of stage i-1
         const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i - 1]);
         const DropoutCfg edrop = c->enc_drop(i - 1);
+        if (group) enc[1] = keep((size_t)rows_in * g.cin);  // conv i-1's dY: read again by its deferred weight gradient
         SOLA_TRY(gn_bwd(fb("conv" + std::to_string(i - 1)), dact, nullptr, np, enc[1], R, 1, t_in, 0, 1, t_in, g.cin,
                         c->cfg.n_groups, 1, &edrop, rt ? rt->u_lvl[i] : nullptr));
         dy = enc[1];  // dact (enc[0]) is consumed; the next stage's dX may overwrite it, its GN backward overwrites enc[1]
     }
     // weight-standardisation backward for all six convs
+    if (group) SOLA_TRY(flush_group());  // the encoder's deferred weight gradients
     SOLA_TRY(join_side());  // dwstd is the side stream's
     {
         WsBwdLayer layers[6];

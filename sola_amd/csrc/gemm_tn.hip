@@ -166,26 +166,33 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
 // this kernel takes them all - blockIdx.x = (problem, tile), every block reduces over ALL rows of its problem and writes its dW tile
 // and bias gradient directly (no partial sums, no second pass, fixed summation order).
 constexpr int TN_GROUP_MAX = 32;
+struct TnGroupProb {
+    const float* A;
+    const float* B;
+    float* C;
+    float* db;
+    const int2* rowmap;
+    int M, N, K, lda, ldb;
+    int conv, T_in, T_out, stride, pad, Cin;
+    int tiles_k, tile_begin;  // this problem's tiles are [tile_begin, next problem's tile_begin)
+};
 struct TnGroupArgs {
-    const float* A[TN_GROUP_MAX];
-    const float* B[TN_GROUP_MAX];
-    float* C[TN_GROUP_MAX];
-    float* db[TN_GROUP_MAX];
-    int M[TN_GROUP_MAX];
-    int lda[TN_GROUP_MAX], ldb[TN_GROUP_MAX];
-    int N, K, tiles_n, tiles_k;
+    TnGroupProb p[TN_GROUP_MAX];
+    int nprob;
 };
 __global__ __launch_bounds__(256) void gemm_tn_f32_group_kernel(const TnGroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tiles = g.tiles_n * g.tiles_k;
-    const int p = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - p * tiles;
+    int pi = 0;
+    for (int j = 1; j < g.nprob; ++j)  // block-uniform, at most 32 entries
+        if ((int)blockIdx.x >= g.p[j].tile_begin) pi = j;
+    const TnGroupProb& q = g.p[pi];
     TnArgs a;
-    a.A = g.A[p]; a.B = g.B[p]; a.P = g.C[p]; a.Pb = g.db[p];
-    a.M = g.M[p]; a.N = g.N; a.K = g.K; a.lda = g.lda[p]; a.ldb = g.ldb[p];
-    a.conv = 0; a.T_in = a.T_out = a.stride = a.pad = a.Cin = 0; a.rowmap = nullptr;
-    a.tiles_n = g.tiles_n; a.tiles_k = g.tiles_k;
+    a.A = q.A; a.B = q.B; a.P = q.C; a.Pb = q.db;
+    a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb;
+    a.conv = q.conv; a.T_in = q.T_in; a.T_out = q.T_out; a.stride = q.stride; a.pad = q.pad; a.Cin = q.Cin; a.rowmap = q.rowmap;
+    a.tiles_n = 0; a.tiles_k = q.tiles_k;
     a.m_per_split = (a.M + TM - 1) / TM * TM;  // one split: every row
-    tn_tile(a, tile, 0, smem);
+    tn_tile(a, (int)blockIdx.x - q.tile_begin, 0, smem);
 }
 
 // out_e[c * ldo_e + col_off_e + r] = in_e[r * ldi_e + c] for up to TR_GROUP_MAX matrices in one launch (blockIdx.z = e): the weight
@@ -384,15 +391,26 @@ int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
 }
 
 int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s) {
-    SOLA_ARG(d.nprob >= 1 && d.nprob <= TN_GROUP_MAX && d.N > 0 && d.K > 0 && d.N % 4 == 0 && d.K % 4 == 0, "gemm_tn_group: nprob=%d N=%d K=%d", d.nprob, d.N, d.K);
+    SOLA_ARG(d.nprob >= 1 && d.nprob <= TN_GROUP_MAX, "gemm_tn_group: nprob=%d", d.nprob);
     TnGroupArgs g;
-    double rows = 0;
+    g.nprob = d.nprob;
+    double flops = 0, bytes = 0;
+    int tiles = 0;
     for (int j = 0; j < d.nprob; ++j) {
-        SOLA_ARG(d.A[j] && d.B[j] && d.C[j] && d.M[j] > 0 && d.lda[j] % 4 == 0 && d.ldb[j] % 4 == 0, "gemm_tn_group: problem %d", j);
-        g.A[j] = d.A[j]; g.B[j] = d.B[j]; g.C[j] = d.C[j]; g.db[j] = d.bias_grad[j]; g.M[j] = d.M[j]; g.lda[j] = d.lda[j]; g.ldb[j] = d.ldb[j];
-        rows += d.M[j];
+        const GemmTnGroupDesc::Prob& q = d.p[j];
+        SOLA_ARG(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0 && q.N % 4 == 0 && q.K % 4 == 0 && q.lda % 4 == 0 && (q.conv || q.ldb % 4 == 0),
+                 "gemm_tn_group: problem %d (M=%d N=%d K=%d)", j, q.M, q.N, q.K);
+        if (q.conv) SOLA_ARG(q.Cin % 4 == 0 && q.K % q.Cin == 0, "gemm_tn_group conv: Cin=%d K=%d", q.Cin, q.K);
+        TnGroupProb& o = g.p[j];
+        o.A = q.A; o.B = q.B; o.C = q.C; o.db = q.bias_grad; o.rowmap = q.conv ? q.rowmap : nullptr;
+        o.M = q.M; o.N = q.N; o.K = q.K; o.lda = q.lda; o.ldb = q.ldb;
+        o.conv = q.conv; o.T_in = q.T_in; o.T_out = q.T_out; o.stride = q.stride; o.pad = q.pad; o.Cin = q.Cin;
+        o.tiles_k = (q.K + TB - 1) / TB;
+        o.tile_begin = tiles;
+        tiles += ((q.N + TB - 1) / TB) * o.tiles_k;
+        flops += 2.0 * q.M * q.N * (double)q.K;
+        bytes += 4.0 * ((double)q.M * (q.N + q.K) + (double)q.N * q.K);
     }
-    g.N = d.N; g.K = d.K; g.tiles_n = (d.N + TB - 1) / TB; g.tiles_k = (d.K + TB - 1) / TB;
     constexpr size_t lds = (size_t)4 * TM * TP * sizeof(float);
     static DeviceOnce once;
     int dev;
@@ -400,8 +418,8 @@ int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s) {
         SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
-    SolaProfScope prof(SOLA_PROF_GEMM_TN, s, 2.0 * rows * d.N * (double)d.K, 4.0 * (rows * (d.N + d.K) + (double)d.nprob * d.N * d.K));
-    hipLaunchKernelGGL(gemm_tn_f32_group_kernel, dim3((unsigned)(d.nprob * g.tiles_n * g.tiles_k)), dim3(256), lds, s, g);
+    SolaProfScope prof(SOLA_PROF_GEMM_TN, s, flops, bytes);
+    hipLaunchKernelGGL(gemm_tn_f32_group_kernel, dim3((unsigned)tiles), dim3(256), lds, s, g);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

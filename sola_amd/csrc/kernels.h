@@ -68,15 +68,19 @@ struct GemmTnDesc {
     size_t scratch_bytes;
     const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap (T_in / T_out / stride / pad are then unused)
 };
-// Grouped exact-f32 form (few-sample steps): up to 32 problems dW_j = A_j^T B_j (+ bias gradients) sharing N and K, each reduced over all
-// of its own M_j rows by the blocks of its tiles - one launch, no partial sums (gemm_tn.hip)
+// Grouped exact-f32 form (few-sample steps): up to 32 problems dW_j = A_j^T B_j (+ bias gradients), each reduced over all of its own M_j
+// rows by the blocks of its 128 x 128 tiles - one launch, no partial sums (gemm_tn.hip)
 struct GemmTnGroupDesc {
-    const float* A[32];
-    const float* B[32];
-    float* C[32];
-    float* bias_grad[32];  // optional per problem
-    int M[32], lda[32], ldb[32];
-    int nprob, N, K;
+    struct Prob {
+        const float* A;         // dY [M, N]
+        const float* B;         // X [M, K], or the channels-last conv input when conv = 1 (K = k * Cin: implicit im2col, as GemmTnDesc)
+        float* C;               // [N, K]
+        float* bias_grad;       // optional [N]
+        const int2* rowmap;     // conv = 1, ragged batches
+        int M, N, K, lda, ldb;
+        int conv, T_in, T_out, stride, pad, Cin;
+    } p[32];
+    int nprob;
 };
 int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s);
 // up to 48 transpositions out_e[c][col_off_e + r] = in_e[r][c] (in_e contiguous [rows_e][cols_e], out pitch ldo_e) in one launch
