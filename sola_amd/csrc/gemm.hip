@@ -425,6 +425,7 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
 }
 
 int g_gemm_splitk = 1;  // 0 disables the split-K of small grids (A/B)
+int g_gemm_splitk_max = 8;      // sola_tune "gemm_splitk_max": most K ranges per tile (A/B)
 int g_gemm_splitk_tiles = 512;  // grids with fewer 64x64 tiles than this are split (target: twice as many blocks)
 int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 by 5%, mid-tile staging on 64x64 by 6%), 0 / 1 force
 
@@ -435,6 +436,7 @@ int g_gemm_glds_force = 0;  // tests: take the direct-to-LDS kernels for grids o
 void sola_gemm_set_glds_force(int v) { g_gemm_glds_force = v; }
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_splitk_tiles = v; }
+void sola_gemm_set_splitk_max(int v) { g_gemm_splitk_max = v < 2 ? 2 : v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
@@ -513,7 +515,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nprob;
         const int nk_all = (d.K + BK - 1) / BK;
         if (g_gemm_splitk && !big && d.splitk_ws && t64 < g_gemm_splitk_tiles && nk_all >= 8 && d.N % 4 == 0 && d.ldc % 4 == 0 && (!a.c_sp16 || d.N % 8 == 0)) {
-            long long S = std::min<long long>(8, std::min<long long>(nk_all / 4, (2 * g_gemm_splitk_tiles + t64 - 1) / t64));
+            long long S = std::min<long long>(g_gemm_splitk_max, std::min<long long>(nk_all / (g_gemm_splitk_max > 8 ? 2 : 4), (2 * g_gemm_splitk_tiles + t64 - 1) / t64));
             const long long per_split = (long long)d.nprob * d.M * d.N * 4;
             S = std::min<long long>(S, (long long)(d.splitk_bytes / (size_t)per_split));
             if (S >= 2) {
