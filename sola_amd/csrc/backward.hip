@@ -123,7 +123,7 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
         size_t enc_keep = 0;  // + the encoder stages' dY (GroupNorm backward outputs) for the deferred conv weight gradients
         for (int i = 0; i < 5; ++i) enc_keep += z.rows[i + 1] * (size_t)c->conv[i].cout + 64;
         a.add("dwkeep", (size_t)c->cfg.n_layers * (12 * M * D + 2 * BW * D + 7 * 64) + enc_keep);  // per layer: 3 dres + 3 dqkv (3D wide) + dlkv
-        a.add("wtkeep", (size_t)c->cfg.n_layers * 12 * D * D);                          // every transposed weight block of the dX GEMMs
+        a.add("wtkeep", (size_t)c->cfg.n_layers * 12 * D * D + ws_total + 64);          // every transposed weight block of the dX GEMMs (layers + encoder)
     }
     {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather: the split-f16 / f16 modes, and every ragged batch
         // (the f32 path's transposed-conv gather needs one sequence length)
@@ -268,6 +268,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     struct WtUse { const float* w[3]; int nw; float* dst; };
     std::vector<WtUse> wt_seq;
     size_t wt_next = 0;
+    float* enc_wt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // group: the encoder convs' transposed weights
     if (group) {
         float* base = ar.get("wtkeep");
         size_t off = 0;
@@ -291,12 +292,27 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             use({obj + ".q_proj.weight", obj + ".k_proj.weight", obj + ".v_proj.weight"});
         }
         TransposeGroupDesc td{};
+        auto add_t = [&](const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off) -> int {
+            if (td.n == 48) { SOLA_TRY(launch_transpose_group(td, s)); td.n = 0; }
+            td.in[td.n] = in; td.out[td.n] = out; td.rows[td.n] = rows; td.cols[td.n] = cols; td.ldi[td.n] = ldi; td.ldo[td.n] = ldo; td.col_off[td.n] = col_off;
+            ++td.n;
+            return SOLA_OK;
+        };
         for (const WtUse& u : wt_seq)
-            for (int j = 0; j < u.nw; ++j) {
-                if (td.n == 48) { SOLA_TRY(launch_transpose_group(td, s)); td.n = 0; }
-                td.in[td.n] = u.w[j]; td.out[td.n] = u.dst; td.rows[td.n] = D; td.cols[td.n] = D; td.ldo[td.n] = u.nw * D; td.col_off[td.n] = j * D;
-                ++td.n;
+            for (int j = 0; j < u.nw; ++j) SOLA_TRY(add_t(u.w[j], u.dst, D, D, D, u.nw * D, j * D));
+        // the encoder's standardised conv weights (ws_buf, left by the forward) in the layouts its dX GEMMs read: ragged batches the
+        // whole [cout][k*cin] matrix, uniform ones tap by tap into [cin][k*cout]
+        for (int i = 5; i >= 1; --i) {
+            const ConvGeom& g = c->conv[i];
+            enc_wt[i] = base + off;
+            off += (size_t)g.cout * g.cin * g.k;
+            if (rt) {
+                SOLA_TRY(add_t(c->ws_buf + c->ws_off[i], enc_wt[i], g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0));
+            } else {
+                for (int kk = 0; kk < g.k; ++kk)
+                    SOLA_TRY(add_t(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, enc_wt[i], g.cout, g.cin, g.k * g.cin, g.k * g.cout, kk * g.cout));
             }
+        }
         if (td.n) SOLA_TRY(launch_transpose_group(td, s));
     }
     bool side_pending[4] = {false, false, false, false};
@@ -725,7 +741,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         } else if (rt) {
             // ragged, exact f32: the same decomposition - z = dY W over the OUTPUT rows (a plain GEMM on the concatenated rows, half
             // the products of the gather form for the stride-2 convs), then the taps are gathered per sequence
-            SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i], wt, g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0, s));  // wt [k*cin][cout]
+            if (group) wt = enc_wt[i];  // transposed in front of the layers (one launch for every weight of the step)
+            else SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i], wt, g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0, s));  // wt [k*cin][cout]
             GemmDesc d{};
             d.nprob = 1;
             d.p[0] = GemmProblem{dy, wt, nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
@@ -734,6 +751,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(launch_gemm(d, s));
             if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
         } else {
+        if (group) wt = enc_wt[i];
+        else
         for (int kk = 0; kk < g.k; ++kk)
             SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, wt, g.cout, g.cin, g.k * g.cin,
                                       g.k * g.cout, kk * g.cout, s));

@@ -195,13 +195,13 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_group_kernel(const TnGroupArg
     tn_tile(a, (int)blockIdx.x - q.tile_begin, 0, smem);
 }
 
-// out_e[c * ldo_e + col_off_e + r] = in_e[r * ldi_e + c] for up to TR_GROUP_MAX matrices in one launch (blockIdx.z = e): the weight
+// out_e[c * ldo_e + col_off_e + r] = in_e[r * ldi_e + c] (ldi_e = 0: contiguous rows) for up to TR_GROUP_MAX matrices in one launch (blockIdx.z = e): the weight
 // transpositions W -> W^T of a few-sample backward's dX GEMMs (36 launches of ~5 us per step)
 constexpr int TR_GROUP_MAX = 48;
 struct TrGroupArgs {
     const float* in[TR_GROUP_MAX];
     float* out[TR_GROUP_MAX];
-    int rows[TR_GROUP_MAX], cols[TR_GROUP_MAX], ldo[TR_GROUP_MAX], col_off[TR_GROUP_MAX];
+    int rows[TR_GROUP_MAX], cols[TR_GROUP_MAX], ldi[TR_GROUP_MAX], ldo[TR_GROUP_MAX], col_off[TR_GROUP_MAX];
 };
 __global__ __launch_bounds__(256) void transpose_group_kernel(const TrGroupArgs g) {
     __shared__ float tile[32][33];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void transpose_group_kernel(const TrGroupArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * i][tx] = in[(long long)r * cols + c];
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = in[(long long)r * g.ldi[e] + c];
     }
     __syncthreads();
 #pragma unroll
@@ -431,7 +431,8 @@ int launch_transpose_group(const TransposeGroupDesc& d, hipStream_t s) {
     double el = 0;
     for (int e = 0; e < d.n; ++e) {
         SOLA_ARG(d.in[e] && d.out[e] && d.rows[e] > 0 && d.cols[e] > 0, "transpose_group: matrix %d", e);
-        g.in[e] = d.in[e]; g.out[e] = d.out[e]; g.rows[e] = d.rows[e]; g.cols[e] = d.cols[e]; g.ldo[e] = d.ldo[e]; g.col_off[e] = d.col_off[e];
+        g.in[e] = d.in[e]; g.out[e] = d.out[e]; g.rows[e] = d.rows[e]; g.cols[e] = d.cols[e]; g.ldi[e] = d.ldi[e] ? d.ldi[e] : d.cols[e];
+        g.ldo[e] = d.ldo[e]; g.col_off[e] = d.col_off[e];
         max_r = std::max(max_r, d.rows[e]); max_c = std::max(max_c, d.cols[e]);
         el += (double)d.rows[e] * d.cols[e];
     }
