@@ -454,6 +454,12 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "train_x16_keep": 1 (default) = in the 16-bit operand training modes the forward keeps its fixed-scale operand casts (in the
  * arena the caller lends the context: sola_set_x16_arena) and the backward's weight-gradient products read them instead of casting the activations again
  * (the split-f16 step's operand casts write their hi halves once more as plain f16 rows for that purpose);
+ * "gemm_small_rows": exact-f32 GEMMs on plain rows of at most this many rows (default 2048: one sample per call or optimizer step) take the
+ * 32 x 32 shape whose split over K happens inside the block (no partial sums in memory, no reduce launch); 0 = the 64 x 64 + split-K pair;
+ * "gemm_splitk_max": most K ranges per tile of that pair (default 8; A/B);
+ * "bwd_group_rows": an exact-f32 backward of at most this many token rows (default 2048) defers the weight-gradient products of its linear
+ * layers and encoder convs into grouped launches and transposes the weights its dX GEMMs read in one launch (deterministic; not bit-identical
+ * to the per-matrix slab form: another fixed summation order), 0 = per-matrix launches;
  * "train_attn_cast": 1 (default) = in the f16 / bf16 operand training steps the forward's attention kernels also write the operand cast of
  * their output that the out-projection GEMM takes (where the shape can; bit-identical to the separate cast launch: -0.5 % of the ragged step),
  * 2 = the split-f16 step too (pairs + the plain-f16 side copy: measured no gain), 0 = always the cast launch;

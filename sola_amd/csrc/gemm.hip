@@ -399,6 +399,147 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     }
 }
 
+// ---- few rows (round 4): one sample per call or per optimizer step has 256-2000 token rows -----------------------------------
+// The 64x64 shape above needs a split-K over 8 ranges to fill the chip at M = 256 (512 blocks of four k-tiles each: load -> LDS ->
+// barrier -> MFMA with nothing to overlap, 15 us) and a second launch to fold the ranges (5 us): 41 such pairs are 0.8 ms of a 2.1 ms
+// one-sample training step.  Here a block owns a 32 x 32 output tile (M = 256, N = 1024: 256 tiles, one per CU) over the WHOLE of K,
+// and the split over K happens inside the block: wave w reduces K range w of four through a double-buffered stage in a slice of LDS
+// that only it touches (no block barrier in the loop: LDS executes one wave's writes and reads in order), the four 32 x 32 partial
+// sums meet in LDS once, are added in wave order (fixed: deterministic) and leave through the usual epilogue (scale, bias,
+// residual) as 16-byte row stores.  No partial sums in memory, no second launch.  Logical tiles are ordered W-panel-major and dealt
+// to the XCDs in contiguous ranges, so one XCD's L2 holds N/8 rows of W and all of A.
+// Exact f32 (v_mfma_f32_32x32x2_f32), plain rows only (no conv gather), N % 32 == 0, K % 128 == 0.
+constexpr int SM_LD = 36;  // stage row pitch in floats (as LDP)
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_small_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    GemmProblem pr = a.p[0];  // (a.p[blockIdx.z] made the compiler copy the argument array to scratch to index it)
+    if (blockIdx.z == 1) pr = a.p[1];
+    if (blockIdx.z == 2) pr = a.p[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int L = a.xcd_remap ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;  // W-panel-major logical tile
+    const int ct = L / a.tiles_m, rt = L - ct * a.tiles_m;
+    const int m0 = rt * 32, n0 = ct * 32;
+    float* const st = smem + wave * (2 * 2 * 32 * SM_LD);  // this wave's two stages of (A 32 x 32 | W 32 x 32)
+    const int kw = a.K >> 2;                               // this wave's K range
+    const int kb = wave * kw;
+    // loads: 8 lanes cover one 128-byte row segment, 8 rows per instruction, 4 instructions per operand and step
+    const int lr = lane >> 3, lk = (lane & 7) << 2;
+    const float* ap[4];
+    const float* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + lr + 8 * i, a.M - 1);  // rows past M: clamped (their results are never stored)
+        ap[i] = pr.A + (long long)m * a.lda + kb + lk;
+        wp[i] = pr.W + (long long)(n0 + lr + 8 * i) * a.K + kb + lk;
+    }
+    // (prefetch registers as eight named values and the staging as macros: with arrays captured by lambdas the compiler kept them in a
+    // 144-byte scratch frame - a scratch store behind every load and a full wait in front of every LDS write)
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define SM_LOAD(k)                                                                                                      \
+    do {                                                                                                                \
+        ra0 = *reinterpret_cast<const float4*>(ap[0] + (k)); rw0 = *reinterpret_cast<const float4*>(wp[0] + (k));        \
+        ra1 = *reinterpret_cast<const float4*>(ap[1] + (k)); rw1 = *reinterpret_cast<const float4*>(wp[1] + (k));        \
+        ra2 = *reinterpret_cast<const float4*>(ap[2] + (k)); rw2 = *reinterpret_cast<const float4*>(wp[2] + (k));        \
+        ra3 = *reinterpret_cast<const float4*>(ap[3] + (k)); rw3 = *reinterpret_cast<const float4*>(wp[3] + (k));        \
+    } while (0)
+#define SM_STORE(buf)                                                                                                   \
+    do {                                                                                                                \
+        float* As_ = st + (buf) * (2 * 32 * SM_LD) + lr * SM_LD + lk;                                                    \
+        float* Ws_ = As_ + 32 * SM_LD;                                                                                   \
+        *reinterpret_cast<float4*>(As_) = ra0; *reinterpret_cast<float4*>(As_ + 8 * SM_LD) = ra1;                         \
+        *reinterpret_cast<float4*>(As_ + 16 * SM_LD) = ra2; *reinterpret_cast<float4*>(As_ + 24 * SM_LD) = ra3;            \
+        *reinterpret_cast<float4*>(Ws_) = rw0; *reinterpret_cast<float4*>(Ws_ + 8 * SM_LD) = rw1;                         \
+        *reinterpret_cast<float4*>(Ws_ + 16 * SM_LD) = rw2; *reinterpret_cast<float4*>(Ws_ + 24 * SM_LD) = rw3;            \
+    } while (0)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int frag_row = lane & 31, frag_k = (lane >> 5) << 2;
+    const int nk = kw >> 5;
+    SM_LOAD(0);
+    SM_STORE(0);
+    if (nk > 1) SM_LOAD(32);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const float* Ab = st + buf * (2 * 32 * SM_LD) + frag_row * SM_LD + frag_k;
+        const float* Wb = Ab + 32 * SM_LD;
+        const float4 af0 = *reinterpret_cast<const float4*>(Ab), af1 = *reinterpret_cast<const float4*>(Ab + 8);
+        const float4 af2 = *reinterpret_cast<const float4*>(Ab + 16), af3 = *reinterpret_cast<const float4*>(Ab + 24);
+        const float4 bf0 = *reinterpret_cast<const float4*>(Wb), bf1 = *reinterpret_cast<const float4*>(Wb + 8);
+        const float4 bf2 = *reinterpret_cast<const float4*>(Wb + 16), bf3 = *reinterpret_cast<const float4*>(Wb + 24);
+        if (kt + 1 < nk) SM_STORE(buf ^ 1);          // the registers hold step kt + 1
+        if (kt + 2 < nk) SM_LOAD((kt + 2) * 32);
+#define SM_MFMA4(af, bf)                                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        SM_MFMA4(af0, bf0) SM_MFMA4(af1, bf1) SM_MFMA4(af2, bf2) SM_MFMA4(af3, bf3)
+    }
+#undef SM_LOAD
+#undef SM_STORE
+#undef SM_MFMA4
+    // the four K ranges meet: C/D layout of the 32x32 MFMA - col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    __syncthreads();  // every wave is done with its stages
+    float* red = smem;  // [4][32][33]
+    {
+        const int col = lane & 31, row_l = (lane >> 5) << 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + row_l) * 33 + col] = acc[r];
+    }
+    __syncthreads();
+    const int row = tid >> 3, c4 = (tid & 7) << 2;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= a.M) return;
+    const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* q = red + row * 33 + c4 + e;
+        v[e] = (((q[0] + q[32 * 33]) + q[2 * 32 * 33]) + q[3 * 32 * 33]) * osc;
+    }
+    if (pr.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(pr.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (pr.R) {
+        const float4 r4 = *reinterpret_cast<const float4*>(pr.R + (long long)m * a.ldr + n);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+int g_gemm_small_rows = 2048;  // sola_tune "gemm_small_rows": exact-f32 GEMMs of at most this many rows take the 32x32 in-block split-K shape (0 = never)
+static bool gemm_small_applies(const GemmDesc& d) {
+    if (d.arith != 0 || d.conv || d.M > g_gemm_small_rows || d.N % 32 != 0 || d.K % 128 != 0 || d.lda % 4 != 0 || d.ldc % 4 != 0) return false;
+    for (int j = 0; j < d.nprob; ++j) {
+        if (d.p[j].R && d.ldr % 4 != 0) return false;
+        if (d.p[j].bias && (reinterpret_cast<uintptr_t>(d.p[j].bias) & 15)) return false;
+        if ((reinterpret_cast<uintptr_t>(d.p[j].A) | reinterpret_cast<uintptr_t>(d.p[j].W) | reinterpret_cast<uintptr_t>(d.p[j].C)) & 15) return false;
+        if (d.p[j].R && (reinterpret_cast<uintptr_t>(d.p[j].R) & 15)) return false;
+    }
+    return true;
+}
+static int launch_small(const GemmArgs& base, int nprob, hipStream_t s) {
+    GemmArgs a = base;
+    a.tiles_m = (a.M + 31) / 32;
+    a.tiles_n = a.N / 32;
+    a.xcd_remap = ((a.tiles_m * a.tiles_n) % 8 == 0) ? 1 : 0;
+    constexpr size_t lds = (size_t)4 * 2 * 2 * 32 * SM_LD * sizeof(float);  // 73.7 KB: four waves x two stages; the reduction (16.9 KB) reuses it
+    static_assert(4 * 32 * 33 <= 4 * 2 * 2 * 32 * SM_LD, "the reduction tile must fit in the stages");
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done(dev);
+    }
+    hipLaunchKernelGGL(gemm_nt_f32_small_kernel, dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(256), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 template <int BM, int BN, int PIPE, int ARITH>
 int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     GemmArgs a = base;
@@ -437,6 +578,7 @@ void sola_gemm_set_glds_force(int v) { g_gemm_glds_force = v; }
 void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_splitk_tiles = v; }
 void sola_gemm_set_splitk_max(int v) { g_gemm_splitk_max = v < 2 ? 2 : v; }
+void sola_gemm_set_small_rows(int v) { g_gemm_small_rows = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
@@ -508,6 +650,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
                                  : (big ? SOLA_PROF_GEMM : SOLA_PROF_GEMM_SMALL);
     SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
+    if (gemm_small_applies(d)) return launch_small(a, d.nprob, s);
     const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
     // small grids (fewer 64x64 tiles than CUs, the single-sample regime): split K over up to 8 blocks per tile so the
     // serial k-loop gets ~8x shorter; partial sums go through the caller's scratch and are reduced in a fixed order

@@ -51,6 +51,30 @@ def test_gemm_nt(M, N, K):
     assert_close(got2, a.astype(np.float64) @ w.astype(np.float64).T, name="gemm nobias")
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 32, 128), (31, 64, 256), (256, 1024, 1024), (257, 1024, 3072), (640, 1024, 2048), (1000, 96, 128), (1024, 1024, 1024), (2048, 1024, 1024)])
+def test_gemm_nt_few_rows_shape(M, N, K):
+    """Round 4: exact-f32 GEMMs of at most 2048 rows (one sample per call / optimizer step) take gemm_nt_f32_small_kernel - 32 x 32 tiles,
+    the split over K inside the block (four waves, wave-private stages, one ordered sum in LDS), no partial sums in memory, no reduce
+    launch.  Against float64 at the bound of every f32 GEMM here, and against the 64 x 64 + split-K shape it replaces (sola_tune
+    "gemm_small_rows" 0): the same products in another summation order - 2e-6 of the result's norm; twice the same bits."""
+    from sola_amd import _lib
+    rng = np.random.default_rng(7 * M + N + K)
+    a, w, b, r = rnd(rng, M, K), rnd(rng, N, K, scale=0.05), rnd(rng, N), rnd(rng, M, N)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b + r
+    got = ops.gemm_nt(cuda(a), cuda(w), cuda(b), cuda(r))
+    assert_close(got, ref, name=f"few-row gemm {M}x{N}x{K}")
+    assert torch.equal(got, ops.gemm_nt(cuda(a), cuda(w), cuda(b), cuda(r)))
+    plain = ops.gemm_nt(cuda(a), cuda(w))
+    assert_close(plain, a.astype(np.float64) @ w.astype(np.float64).T, name="few-row gemm, no bias / residual")
+    try:
+        _lib.check(_lib.lib().sola_tune(b"gemm_small_rows", 0), "tune")
+        old = ops.gemm_nt(cuda(a), cuda(w), cuda(b), cuda(r))
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"gemm_small_rows", 2048), "tune")
+    rel = float((got.double() - old.double()).norm() / old.double().norm())
+    assert rel < 2e-6, rel
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric W catches a transposed C write."""
     K = 64
