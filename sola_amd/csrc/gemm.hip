@@ -410,7 +410,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 // to the XCDs in contiguous ranges, so one XCD's L2 holds N/8 rows of W and all of A.
 // Exact f32 (v_mfma_f32_32x32x2_f32), plain rows only (no conv gather), N % 32 == 0, K % 128 == 0.
 constexpr int SM_LD = 36;  // stage row pitch in floats (as LDP)
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_small_kernel(const GemmArgs a) {
+// NW waves split K: 4 (two blocks per CU) or 8 (launches of at most ~one tile per CU: twice the loads in flight per tile, 13 -> ~9 us
+// at 256 x 1024 x 1024 where a wave's four-to-eight-step loop is bound by the latency of its own loads)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GemmProblem pr = a.p[0];  // (a.p[blockIdx.z] made the compiler copy the argument array to scratch to index it)
     if (blockIdx.z == 1) pr = a.p[1];
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_small_kernel(const GemmArg
     const int ct = L / a.tiles_m, rt = L - ct * a.tiles_m;
     const int m0 = rt * 32, n0 = ct * 32;
     float* const st = smem + wave * (2 * 2 * 32 * SM_LD);  // this wave's two stages of (A 32 x 32 | W 32 x 32)
-    const int kw = a.K >> 2;                               // this wave's K range
+    const int kw = a.K / NW;                               // this wave's K range
     const int kb = wave * kw;
     // loads: 8 lanes cover one 128-byte row segment, 8 rows per instruction, 4 instructions per operand and step
     const int lr = lane >> 3, lk = (lane & 7) << 2;
@@ -483,13 +486,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_small_kernel(const GemmArg
 #undef SM_MFMA4
     // the four K ranges meet: C/D layout of the 32x32 MFMA - col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     __syncthreads();  // every wave is done with its stages
-    float* red = smem;  // [4][32][33]
+    float* red = smem;  // [NW][32][33]
     {
         const int col = lane & 31, row_l = (lane >> 5) << 2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + row_l) * 33 + col] = acc[r];
     }
     __syncthreads();
+    if (tid >= 256) return;  // NW = 8: the first four waves write the tile
     const int row = tid >> 3, c4 = (tid & 7) << 2;
     const int m = m0 + row, n = n0 + c4;
     if (m >= a.M) return;
@@ -498,7 +502,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_small_kernel(const GemmArg
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float* q = red + row * 33 + c4 + e;
-        v[e] = (((q[0] + q[32 * 33]) + q[2 * 32 * 33]) + q[3 * 32 * 33]) * osc;
+        float t = q[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += q[w * 32 * 33];  // wave order: fixed
+        v[e] = t * osc;
     }
     if (pr.bias) {
         const float4 b = *reinterpret_cast<const float4*>(pr.bias + n);
@@ -522,22 +529,29 @@ static bool gemm_small_applies(const GemmDesc& d) {
     }
     return true;
 }
+int g_gemm_small_nw8 = 1;  // sola_tune "gemm_small_nw8": 0 = always four waves per tile (A/B)
+template <int NW>
+static int launch_small_n(const GemmArgs& a, int nprob, hipStream_t s) {
+    constexpr size_t lds = (size_t)NW * 2 * 2 * 32 * SM_LD * sizeof(float);  // NW waves x two stages (73.7 / 147.5 KB); the reduction reuses it
+    static_assert(NW * 32 * 33 <= NW * 2 * 2 * 32 * SM_LD, "the reduction tile must fit in the stages");
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done(dev);
+    }
+    hipLaunchKernelGGL(gemm_nt_f32_small_kernel<NW>, dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(64 * NW), lds, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 static int launch_small(const GemmArgs& base, int nprob, hipStream_t s) {
     GemmArgs a = base;
     a.tiles_m = (a.M + 31) / 32;
     a.tiles_n = a.N / 32;
     a.xcd_remap = ((a.tiles_m * a.tiles_n) % 8 == 0) ? 1 : 0;
-    constexpr size_t lds = (size_t)4 * 2 * 2 * 32 * SM_LD * sizeof(float);  // 73.7 KB: four waves x two stages; the reduction (16.9 KB) reuses it
-    static_assert(4 * 32 * 33 <= 4 * 2 * 2 * 32 * SM_LD, "the reduction tile must fit in the stages");
-    static DeviceOnce once;
-    int dev;
-    if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        once.done(dev);
-    }
-    hipLaunchKernelGGL(gemm_nt_f32_small_kernel, dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(256), lds, s, a);
-    SOLA_LAUNCH_CHECK();
-    return SOLA_OK;
+    const long long tiles = (long long)a.tiles_m * a.tiles_n * nprob;
+    if (g_gemm_small_nw8 && a.K % 256 == 0 && tiles <= 2 * sola_cu_count()) return launch_small_n<8>(a, nprob, s);
+    return launch_small_n<4>(a, nprob, s);
 }
 
 template <int BM, int BN, int PIPE, int ARITH>
@@ -579,6 +593,7 @@ void sola_gemm_set_variant(int v) { g_gemm_variant = v; }
 void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_splitk_tiles = v; }
 void sola_gemm_set_splitk_max(int v) { g_gemm_splitk_max = v < 2 ? 2 : v; }
 void sola_gemm_set_small_rows(int v) { g_gemm_small_rows = v; }
+void sola_gemm_set_small_nw8(int v) { g_gemm_small_nw8 = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
