@@ -272,6 +272,7 @@ void sola_gemm_set_small_nw8(int v);
 extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr, g_train_x16_keep, g_train_attn_cast;
 extern int g_gemm_stagger, g_gemm_order, g_gemm_trace, g_gemm_ld;
 extern int g_bwd_side_rows, g_bwd_group_rows;
+extern int g_infer_f32_rows;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
 void sola_set_train_split_min_rows(int v);
@@ -329,6 +330,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_splitk")) { sola_gemm_set_splitk(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_splitk_max")) { sola_gemm_set_splitk_max(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_small_rows")) { sola_gemm_set_small_rows(value); return SOLA_OK; }
+    if (!strcmp(key, "infer_f32_rows")) { g_infer_f32_rows = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_small_nw8")) { sola_gemm_set_small_nw8(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }
@@ -497,10 +499,23 @@ int sola_split_guard_tripped(SolaCtx* c, hipStream_t s, bool* tripped) {
 // precision 1 only: the weight-time guard bit is known to be set for the current weights -> skip the split pass
 static bool split_known_out_of_range(const SolaCtx* c) { return c->precision == 1 && c->split_guard && c->weight_range_bad && !c->lin16_dirty; }
 
+// sola_tune "infer_f32_rows" (round 4): a precision-1 inference call over at most this many object-token rows (one sample per call: the
+// reference's inference.py / evaluator batch size) runs the exact-f32 kernels.  Since the few-row GEMM shape (gemm.hip) they are FASTER there
+// than the split-f16 pass - whose casts, guard read-back (a stream synchronisation per call) and 64x64 split-K GEMMs are fixed costs
+// - and exact: one sample of the headline shape 0.61 -> 0.45 ms per call (tools/infer_one_probe.py).  0 = never.
+int g_infer_f32_rows = 4096;
+static bool few_rows_f32(const SolaCtx* c, long long rows0) { return c->precision == 1 && g_infer_f32_rows > 0 && rows0 <= g_infer_f32_rows; }
+
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                             float* score_tokens, void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t s = as_stream(stream_);
     SOLA_ARG(!c || c->precision != 3, "forward: precision 3 (bf16 GEMM operands) is a TRAINING mode; inference runs precision 0, 1 or 2");
+    if (c && B > 0 && N > 0 && T > 0 && few_rows_f32(c, (long long)B * N * T)) {
+        c->precision = 0;
+        const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
+        c->precision = 1;
+        return st;
+    }
     if (c && split_known_out_of_range(c)) {
         c->split_fallbacks += 1;
         c->precision = 0;
@@ -544,6 +559,16 @@ extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* la
     hipStream_t s = as_stream(stream_);
     SOLA_ARG(!c || c->precision != 3, "forward_ragged: precision 3 (bf16 GEMM operands) is a TRAINING mode; inference runs precision 0, 1 or 2");
     try {  // the host-side plan allocates; nothing may throw across the ABI
+        if (c && batch && c->precision == 1 && batch->n_videos > 0 && batch->video_tracks && batch->video_frames) {
+            long long rows0 = 0;
+            for (int v = 0; v < batch->n_videos; ++v) rows0 += (long long)batch->video_tracks[v] * batch->video_frames[v];
+            if (few_rows_f32(c, rows0)) {  // see g_infer_f32_rows
+                c->precision = 0;
+                const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
+                c->precision = 1;
+                return st;
+            }
+        }
         if (c && split_known_out_of_range(c)) {
             c->split_fallbacks += 1;
             c->precision = 0;

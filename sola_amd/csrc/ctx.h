@@ -68,6 +68,8 @@ struct SolaCtx {
     float* ws_buf = nullptr;  // standardised conv weights [cout][k*cin], all six layers, ctx-owned
     size_t ws_off[6];
     bool ws_dirty = true;
+    int ws16_fmt = 0;         // what ws16_buf holds for the CURRENT ws_buf: 0 nothing / stale, 1 split-f16 pairs, 2 f16, 3 bf16 (a forward in another
+                              // arithmetic clears ws_dirty without writing this copy: round 4, few-row calls routed to exact f32)
     bool ws_every_forward = true;
     Plan last;                // plan of the last forward (taps, backward)
     const float* last_obj = nullptr;  // input of the last training forward (conv0's weight gradient reads it)

@@ -177,6 +177,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             layers[i] = WsLayer{W(nm), c->ws_buf + c->ws_off[i], c->conv[i].cout, c->conv[i].cin, c->conv[i].k};
         }
         SOLA_TRY(launch_ws_standardize(layers, 6, s));
+        c->ws16_fmt = split ? (pure ? 2 + bf : 1) : 0;  // ws_buf is new: ws16_buf is current only if it is rewritten below
         if (split)
             for (int i = 0; i < 6; ++i) {
                 const int kc = c->conv[i].k * c->conv[i].cin;

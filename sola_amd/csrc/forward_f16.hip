@@ -46,7 +46,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
     _Float16* const lin16 = reinterpret_cast<_Float16*>(c->lin16_buf);
     auto linw = [&](int layer, int attn, int proj) { return reinterpret_cast<const float*>(lin16 + ((size_t)(layer * 3 + attn) * 4 + proj) * D * D); };
 
-    if (c->ws_dirty || c->ws_every_forward) {
+    if (c->ws_dirty || c->ws_every_forward || c->ws16_fmt != 2) {
         WsLayer layers[6];
         for (int i = 0; i < 6; ++i) {
             const std::string nm = "short_motion_encoder." + std::to_string(kConvIdx[i]) + ".weight";
@@ -58,6 +58,7 @@ int sola_forward_f16_impl(SolaCtx* c, const float* obj, const float* lang, int B
             SOLA_TRY(launch_cast_f16(c->ws_buf + c->ws_off[i], kc, ws16 + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, nullptr, s));
         }
         c->ws_dirty = false;
+        c->ws16_fmt = 2;
     }
     SOLA_TRY(sola_refresh_lin16(c, s));
     SOLA_HIP(hipMemsetAsync(c->guard, 0, sizeof(int), s));

@@ -104,7 +104,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
     auto lin16 = [&](int layer, int attn, int proj) { return c->lin16_buf + ((size_t)(layer * 3 + attn) * 4 + proj) * D * D; };
 
     // ---- weights: standardise the conv weights (module/ws.py:9-13) and refresh the split-f16 copies
-    if (c->ws_dirty || c->ws_every_forward) {
+    if (c->ws_dirty || c->ws_every_forward || c->ws16_fmt != 1) {
         WsLayer layers[6];
         for (int i = 0; i < 6; ++i) {
             const std::string nm = "short_motion_encoder." + std::to_string(kConvIdx[i]) + ".weight";
@@ -116,6 +116,7 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
             SOLA_TRY(launch_cast_sp16(c->ws_buf + c->ws_off[i], kc, c->ws16_buf + c->ws_off[i], kc, c->conv[i].cout, kc, 1.f, s));
         }
         c->ws_dirty = false;
+        c->ws16_fmt = 1;
     }
     // The projection weights are used as they are by the reference (no per-forward transform), so their split copies
     // are refreshed only when a weight pointer or value changed (sola_set_weight / sola_weights_changed).

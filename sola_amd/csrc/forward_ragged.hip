@@ -422,7 +422,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
     };
 
     // ---- weights
-    if (c->ws_dirty || c->ws_every_forward) {
+    if (c->ws_dirty || c->ws_every_forward || (sp && c->ws16_fmt != 1) || (h16 && c->ws16_fmt != 2)) {
         WsLayer layers[6];
         for (int i = 0; i < 6; ++i) {
             const std::string nm = "short_motion_encoder." + std::to_string(kConvIdx[i]) + ".weight";
@@ -441,6 +441,7 @@ int sola_forward_ragged_impl(SolaCtx* c, const float* obj, const float* lang, co
                                          nullptr, s));
             }
         c->ws_dirty = false;
+        c->ws16_fmt = sp ? 1 : (h16 ? 2 : 0);
     }
     if (sp || h16) {
         SOLA_TRY(sola_refresh_lin16(c, s));

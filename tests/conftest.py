@@ -20,6 +20,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def split_kernels_at_every_size():
+    """Round 4: a precision-"f16x3" inference call over at most 4096 object-token rows (one sample per call) runs the exact-f32 kernels -
+    faster there, and exact (sola_tune "infer_f32_rows").  The parity tests of the split-f16 path use small shapes on purpose; they keep
+    testing the split kernels (0 = no routing).  tests/test_gpu_fast.py::test_few_row_calls_of_the_default_mode_run_exact_f32 covers the
+    routing itself; entry-point tests (subprocesses) run the real default."""
+    try:
+        from sola_amd import _lib
+        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 0), "tune")
+    except Exception:
+        pass
+    yield
+
+
 def _load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

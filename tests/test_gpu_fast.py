@@ -85,6 +85,35 @@ def full_f32():
     return build(synth.DEFAULT_MODEL_CFG, "f32")
 
 
+def test_few_row_calls_of_the_default_mode_run_exact_f32(full_fast, full_f32):
+    """Round 4 (sola_tune "infer_f32_rows", default 4096 object-token rows - conftest.py switches it off for the other tests): one sample per
+    call in the default precision runs the exact-f32 kernels (faster there since the few-row GEMM shape, no guard read-back) - the output of
+    the "f16x3" module IS the "f32" module's, uniform and ragged; larger calls and the key at 0 take the split-f16 pass as before."""
+    from sola_amd import _lib
+    mf, _ = full_fast
+    m32, _ = full_f32
+    cfg = synth.DEFAULT_MODEL_CFG
+    try:
+        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 4096), "tune")
+        _, sm_a, st_a, _, _ = run(mf, cfg, 1, 64, 32, 16, 77)      # 2048 rows: routed
+        _, sm_b, st_b, _, _ = run(m32, cfg, 1, 64, 32, 16, 77)
+        assert torch.equal(sm_a, sm_b) and torch.equal(st_a, st_b)
+        _, sm_c, _, _, _ = run(mf, cfg, 4, 64, 32, 16, 78)          # 8192 rows: the split pass
+        _, sm_d, _, _, _ = run(m32, cfg, 4, 64, 32, 16, 78)
+        assert not torch.equal(sm_c, sm_d) and float((sm_c - sm_d).abs().max()) < 1e-3
+        inp = synth.make_inputs(cfg, 1, 20, 50, 7, 79)
+        obj, lang = torch.from_numpy(inp["object_tokens"][0]).cuda(), torch.from_numpy(inp["lang_tokens"][0]).cuda()
+        with torch.no_grad():
+            ra = mf.forward_ragged([obj], [lang])
+            rb = m32.forward_ragged([obj], [lang])
+        assert all(torch.equal(x, y) for x, y in zip(ra[0], rb[0]))
+        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 0), "tune")
+        _, sm_e, _, _, _ = run(mf, cfg, 1, 64, 32, 16, 77)
+        assert not torch.equal(sm_e, sm_b) and float((sm_e - sm_b).abs().max()) < 1e-3
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 0), "tune")
+
+
 @pytest.mark.parametrize("ci", range(5))
 def test_full_cases_vs_golden_in_split_mode(full_golden, full_fast, ci):
     m, _ = full_fast
