@@ -412,7 +412,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 constexpr int SM_LD = 36;  // stage row pitch in floats (as LDP)
 // NW waves split K: 4 (two blocks per CU) or 8 (launches of at most ~one tile per CU: twice the loads in flight per tile, 13 -> ~9 us
 // at 256 x 1024 x 1024 where a wave's four-to-eight-step loop is bound by the latency of its own loads)
-template <int NW>
+// CONV: A is the channels-last conv input and K = k * Cin (implicit im2col, GemmArgs::conv == 1; Cin % 32 == 0, so a 32-deep k-step lies
+// inside one tap): a row's window is (first tap's address, valid-tap bits) - from the uniform geometry or the ragged row map - and a step
+// reads its tap's 32 channels, zeros where the tap falls outside the sequence (clamped address, value select).
+template <int NW, bool CONV>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GemmProblem pr = a.p[0];  // (a.p[blockIdx.z] made the compiler copy the argument array to scratch to index it)
@@ -431,21 +434,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
     const int lr = lane >> 3, lk = (lane & 7) << 2;
     const float* ap[4];
     const float* wp[4];
+    int amask[4], afall[4];  // CONV: valid taps of the row's window, and one of them (the address of an invalid tap's load)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = min(m0 + lr + 8 * i, a.M - 1);  // rows past M: clamped (their results are never stored)
-        ap[i] = pr.A + (long long)m * a.lda + kb + lk;
+        if constexpr (CONV) {
+            if (a.rowmap) {
+                const int2 rm = a.rowmap[m];
+                ap[i] = pr.A + (long long)rm.x * a.Cin + lk;
+                amask[i] = rm.y;
+            } else {
+                const int r = m / a.T_out, to = m - r * a.T_out, t0 = to * a.stride - a.pad;
+                ap[i] = pr.A + ((long long)r * a.T_in + t0) * a.Cin + lk;
+                int bits = 0;
+                for (int kk = 0; kk < a.K / a.Cin; ++kk) bits |= (t0 + kk >= 0 && t0 + kk < a.T_in) ? 1 << kk : 0;
+                amask[i] = bits;
+            }
+            afall[i] = amask[i] ? __builtin_ctz(amask[i]) : 0;
+        } else {
+            ap[i] = pr.A + (long long)m * a.lda + kb + lk;
+            amask[i] = afall[i] = 0;
+        }
         wp[i] = pr.W + (long long)(n0 + lr + 8 * i) * a.K + kb + lk;
     }
     // (prefetch registers as eight named values and the staging as macros: with arrays captured by lambdas the compiler kept them in a
     // 144-byte scratch frame - a scratch store behind every load and a full wait in front of every LDS write)
     float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SM_LOAD_A(i, k, dst)                                                                                             \
+    do {                                                                                                                \
+        if constexpr (CONV) {                                                                                           \
+            const int kabs_ = kb + (k), kk_ = kabs_ / a.Cin, ci_ = kabs_ - kk_ * a.Cin; /* wave-uniform */              \
+            const bool ok_ = (amask[i] >> kk_) & 1;                                                                     \
+            const float4 v_ = *reinterpret_cast<const float4*>(ap[i] + (long long)(ok_ ? kk_ : afall[i]) * a.Cin + ci_); \
+            dst = ok_ ? v_ : z4;                                                                                        \
+        } else {                                                                                                        \
+            dst = *reinterpret_cast<const float4*>(ap[i] + (k));                                                         \
+        }                                                                                                               \
+    } while (0)
 #define SM_LOAD(k)                                                                                                      \
     do {                                                                                                                \
-        ra0 = *reinterpret_cast<const float4*>(ap[0] + (k)); rw0 = *reinterpret_cast<const float4*>(wp[0] + (k));        \
-        ra1 = *reinterpret_cast<const float4*>(ap[1] + (k)); rw1 = *reinterpret_cast<const float4*>(wp[1] + (k));        \
-        ra2 = *reinterpret_cast<const float4*>(ap[2] + (k)); rw2 = *reinterpret_cast<const float4*>(wp[2] + (k));        \
-        ra3 = *reinterpret_cast<const float4*>(ap[3] + (k)); rw3 = *reinterpret_cast<const float4*>(wp[3] + (k));        \
+        SM_LOAD_A(0, k, ra0); rw0 = *reinterpret_cast<const float4*>(wp[0] + (k));                                       \
+        SM_LOAD_A(1, k, ra1); rw1 = *reinterpret_cast<const float4*>(wp[1] + (k));                                       \
+        SM_LOAD_A(2, k, ra2); rw2 = *reinterpret_cast<const float4*>(wp[2] + (k));                                       \
+        SM_LOAD_A(3, k, ra3); rw3 = *reinterpret_cast<const float4*>(wp[3] + (k));                                       \
     } while (0)
 #define SM_STORE(buf)                                                                                                   \
     do {                                                                                                                \
@@ -482,6 +514,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
         SM_MFMA4(af0, bf0) SM_MFMA4(af1, bf1) SM_MFMA4(af2, bf2) SM_MFMA4(af3, bf3)
     }
 #undef SM_LOAD
+#undef SM_LOAD_A
 #undef SM_STORE
 #undef SM_MFMA4
     // the four K ranges meet: C/D layout of the 32x32 MFMA - col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -520,7 +553,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
 
 int g_gemm_small_rows = 2048;  // sola_tune "gemm_small_rows": exact-f32 GEMMs of at most this many rows take the 32x32 in-block split-K shape (0 = never)
 static bool gemm_small_applies(const GemmDesc& d) {
-    if (d.arith != 0 || d.conv || d.M > g_gemm_small_rows || d.N % 32 != 0 || d.K % 128 != 0 || d.lda % 4 != 0 || d.ldc % 4 != 0) return false;
+    if (d.arith != 0 || d.conv > 1 || d.M > g_gemm_small_rows || d.N % 32 != 0 || d.K % 128 != 0 || d.ldc % 4 != 0) return false;
+    if (d.conv ? (d.Cin % 32 != 0 || d.K % d.Cin != 0 || d.K / d.Cin > 8 || (!d.rowmap && (d.T_out <= 0 || d.T_in <= 0))) : d.lda % 4 != 0) return false;
     for (int j = 0; j < d.nprob; ++j) {
         if (d.p[j].R && d.ldr % 4 != 0) return false;
         if (d.p[j].bias && (reinterpret_cast<uintptr_t>(d.p[j].bias) & 15)) return false;
@@ -530,17 +564,17 @@ static bool gemm_small_applies(const GemmDesc& d) {
     return true;
 }
 int g_gemm_small_nw8 = 1;  // sola_tune "gemm_small_nw8": 0 = always four waves per tile (A/B)
-template <int NW>
+template <int NW, bool CONV>
 static int launch_small_n(const GemmArgs& a, int nprob, hipStream_t s) {
     constexpr size_t lds = (size_t)NW * 2 * 2 * 32 * SM_LD * sizeof(float);  // NW waves x two stages (73.7 / 147.5 KB); the reduction reuses it
     static_assert(NW * 32 * 33 <= NW * 2 * 2 * 32 * SM_LD, "the reduction tile must fit in the stages");
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel<NW, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
-    hipLaunchKernelGGL(gemm_nt_f32_small_kernel<NW>, dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_f32_small_kernel<NW, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(64 * NW), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -550,8 +584,9 @@ static int launch_small(const GemmArgs& base, int nprob, hipStream_t s) {
     a.tiles_n = a.N / 32;
     a.xcd_remap = ((a.tiles_m * a.tiles_n) % 8 == 0) ? 1 : 0;
     const long long tiles = (long long)a.tiles_m * a.tiles_n * nprob;
-    if (g_gemm_small_nw8 && a.K % 256 == 0 && tiles <= 2 * sola_cu_count()) return launch_small_n<8>(a, nprob, s);
-    return launch_small_n<4>(a, nprob, s);
+    const bool nw8 = g_gemm_small_nw8 && a.K % 256 == 0 && tiles <= 2 * sola_cu_count();
+    if (a.conv) return nw8 ? launch_small_n<8, true>(a, nprob, s) : launch_small_n<4, true>(a, nprob, s);
+    return nw8 ? launch_small_n<8, false>(a, nprob, s) : launch_small_n<4, false>(a, nprob, s);
 }
 
 template <int BM, int BN, int PIPE, int ARITH>

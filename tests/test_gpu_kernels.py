@@ -97,6 +97,27 @@ def test_conv1d_cl(R, T, cin, cout, k, s, p):
     assert_close(got, ref.numpy(), name="conv")
 
 
+@pytest.mark.parametrize("R,T,cin,cout,k,s,p", [(1, 7, 128, 64, 3, 2, 1), (3, 50, 256, 96, 3, 1, 1), (2, 200, 128, 64, 3, 2, 1), (1, 1, 128, 32, 3, 1, 1),
+                                                (64, 32, 256, 512, 3, 2, 1), (5, 9, 512, 1024, 3, 1, 1)])
+def test_conv1d_cl_few_rows_shape(R, T, cin, cout, k, s, p):
+    """The few-row GEMM's conv gather (gemm_nt_f32_small_kernel<., true>: a window = first tap's address + valid-tap bits, zeros outside the
+    sequence) against the float64 oracle, and against the 64 x 64 + split-K kernel's gather (sola_tune "gemm_small_rows" 0) at 2e-6."""
+    from sola_amd import _lib
+    rng = np.random.default_rng(R * T + cin + cout)
+    x, w, b = rnd(rng, R, T, cin), rnd(rng, cout, cin, k, scale=0.1), rnd(rng, cout)
+    ref = sola_oracle.conv1d_cl(torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64),
+                                torch.tensor(b, dtype=torch.float64), s, p)
+    wk = np.ascontiguousarray(np.transpose(w, (0, 2, 1)).reshape(cout, k * cin))
+    got = ops.conv1d_cl(cuda(x), cuda(wk), cuda(b), k, s, p)
+    assert_close(got, ref.numpy(), name="few-row conv")
+    try:
+        _lib.check(_lib.lib().sola_tune(b"gemm_small_rows", 0), "tune")
+        old = ops.conv1d_cl(cuda(x), cuda(wk), cuda(b), k, s, p)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"gemm_small_rows", 2048), "tune")
+    assert float((got.double() - old.double()).norm() / old.double().norm()) < 2e-6
+
+
 def _gn_ref(x, gamma, beta, groups):
     return sola_oracle.group_norm_tokens(torch.tensor(x, dtype=torch.float64), torch.tensor(gamma, dtype=torch.float64),
                                          torch.tensor(beta, dtype=torch.float64), groups).numpy()
