@@ -104,6 +104,41 @@ __device__ __forceinline__ float4 gn_load(const GnArgs& a, long long off) {
     return v;
 }
 
+// R token slots of a lane -> registers: slot r holds token tl + r * tpp (+ t0) of the unit, zeros beyond ntok.  Written as
+// `t < ntok ? gn_load(...) : zero` every slot's load sat in an exec-mask region of its own, behind a format branch, with a full
+// s_waitcnt vmcnt(0) before the next one (round 4, code-object scan: R serialized memory round trips per lane).  Here the row index is
+// clamped (token 0 of a unit is always there), the loads are unconditional and back to back, the VALUE is selected, and the format
+// branch (f32 / f16 input) is taken once around the whole loop.  Same values as gn_load (x * 1.0f is exact where there is no scale).
+template <int R>
+__device__ __forceinline__ void gn_load_slots(const GnArgs& a, float4 (&v)[R], long long row0, long long tok_stride, int ntok, int t_first, int tpp, int ch) {
+    const float sc = a.in_scale_dev ? *a.in_scale_dev : 1.f;
+    if (a.in_f16) {
+        const _Float16* x = reinterpret_cast<const _Float16*>(a.x);
+        half4n h[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = t_first + r * tpp;
+            h[r] = *reinterpret_cast<const half4n*>(x + (row0 + (long long)(t < ntok ? t : 0) * tok_stride) * a.C + ch);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = t_first + r * tpp < ntok;
+            v[r] = make_float4(ok ? (float)h[r][0] * sc : 0.f, ok ? (float)h[r][1] * sc : 0.f, ok ? (float)h[r][2] * sc : 0.f, ok ? (float)h[r][3] * sc : 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = t_first + r * tpp;
+            v[r] = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)(t < ntok ? t : 0) * tok_stride) * a.C + ch);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = t_first + r * tpp < ntok;
+            v[r] = make_float4(ok ? v[r].x * sc : 0.f, ok ? v[r].y * sc : 0.f, ok ? v[r].z * sc : 0.f, ok ? v[r].w * sc : 0.f);
+        }
+    }
+}
+
 // The token set of instance `inst`: first row, row stride, token count and the positional-encoding row of the y + pe output.
 struct GnUnit { long long row0, tok_stride; int ntok, pe_row; };
 __device__ __forceinline__ GnUnit gn_unit(const GnArgs& a, int inst) {
@@ -282,13 +317,10 @@ __global__ __launch_bounds__(NTHR) void group_norm_reg_kernel(const GnArgs a, lo
     const int ch = g * a.cg + c4 * 4;
     const float cnt = (float)ntok * (float)a.cg;
     float4 v[R];
+    gn_load_slots<R>(a, v, row0, tok_stride, ntok, tl, tpp, ch);
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int t = tl + r * tpp;
-        v[r] = t < ntok ? gn_load(a, (row0 + (long long)t * tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
-    }
+    for (int r = 0; r < R; ++r) s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
     const float mean = (WAVE ? wave_sum(s) : block_sum_n<NTHR>(s, red)) / cnt;
     float q = 0.f;
 #pragma unroll
@@ -430,13 +462,10 @@ __global__ __launch_bounds__(256) void group_norm_slice_stats_kernel(const GnArg
     if (q.t0 < 0) return;  // block-uniform: this unit has fewer slices
     const int ch = q.g * a.cg + q.c4 * 4;
     float4 v[GNC_R];
+    gn_load_slots<GNC_R>(a, v, q.row0, q.tok_stride, q.ntok, q.t0 + q.tl, q.tpp, ch);
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < GNC_R; ++r) {
-        const int t = q.t0 + q.tl + r * q.tpp;
-        v[r] = t < q.ntok ? gn_load(a, (q.row0 + (long long)t * q.tok_stride) * a.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
-    }
+    for (int r = 0; r < GNC_R; ++r) s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
     const int ntok_i = min(q.ntok - q.t0, q.tpp * GNC_R);
     const float mean = block_sum_256(s, red) / ((float)ntok_i * (float)a.cg);
     float m2 = 0.f;
