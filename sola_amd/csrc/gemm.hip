@@ -50,10 +50,16 @@ constexpr int LDP = 36;  // LDS row pitch in floats (144 B: 16-byte aligned, con
 //          v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, f32 accumulate): ~22-bit products at 3/16 of the f32 MFMA
 //          cost.  Bytes per element, tile staging and LDS layout are identical to ARITH 0 (a k16 MFMA step consumes
 //          two 32-byte blocks; lanes 0-31 take the first, lanes 32-63 the second - exactly the MFMA A/B fragment).
-template <int BM, int BN, int PIPE, int ARITH>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {  // two blocks per CU (their LDS allows exactly that): <= 256 registers
-    constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte loads per thread per operand per k-tile
-    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
+// NW = 8 (round 4, exact f32 at 128x128): eight waves of 32x64 instead of four of 64x64 - half the accumulators per wave (the two-level sum
+// doubles them), <= 128 registers, so the CU's two blocks put FOUR waves on every SIMD instead of two.  PMC on the four-wave form
+// (profiles/r04_gemm_f32_pmc.txt): matrix pipe busy 70.6 %, not power-bound - with two waves per SIMD, each from another block, both are
+// regularly at their k-tile barrier at once.  Same k order per output element: bit-identical results.
+template <int BM, int BN, int PIPE, int ARITH, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_nt_f32_kernel(const GemmArgs a) {  // two blocks per CU (their LDS allows exactly that)
+    constexpr int LROWS = 8 * NW;                       // rows one load pass of the block covers (8 lanes per 128-byte row segment)
+    constexpr int RA = BM / LROWS, RW = BN / LROWS;     // 16-byte loads per thread per operand per k-tile
+    constexpr int WROWS = NW / 2;                       // wave grid: WROWS x 2
+    constexpr int TM = BM / (32 * WROWS), TN = BN / 64; // 32x32 MFMA tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDP]
     float* Ws = smem + 2 * BM * LDP;   // [2][BN][LDP]
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
     bool a_ok[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + lr + 32 * i;
+        const int m = m0 + lr + LROWS * i;
         a_ok[i] = m < a.M;
         if (a.conv == 1 && a.rowmap) {
             // ragged: a_t0 = tap-validity bits, a_off = offset of the window's tap 0 (possibly outside the sequence)
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
     bool w_ok[RW];
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
-        const int n = n0 + lr + 32 * j;
+        const int n = n0 + lr + LROWS * j;
         w_ok[j] = n < a.N;
         w_off[j] = (long long)n * a.K;
     }
@@ -160,10 +166,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<float4*>(&As[(buf * BM + lr + 32 * i) * LDP + lk]) = ra[i];
+            *reinterpret_cast<float4*>(&As[(buf * BM + lr + LROWS * i) * LDP + lk]) = ra[i];
 #pragma unroll
         for (int j = 0; j < RW; ++j)
-            *reinterpret_cast<float4*>(&Ws[(buf * BN + lr + 32 * j) * LDP + lk]) = rw[j];
+            *reinterpret_cast<float4*>(&Ws[(buf * BN + lr + LROWS * j) * LDP + lk]) = rw[j];
     };
 
     f32x16 acc[TM][TN];
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
 
     auto compute = [&](int buf, int ks_begin, int ks_end) {
         if constexpr (ARITH == 1) {
-            const char* Ab = reinterpret_cast<const char*>(&As[(buf * BM + wr * (BM / 2) + frag_row) * LDP]) + (lane >> 5) * 32;
+            const char* Ab = reinterpret_cast<const char*>(&As[(buf * BM + wr * (TM * 32) + frag_row) * LDP]) + (lane >> 5) * 32;
             const char* Wb = reinterpret_cast<const char*>(&Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP]) + (lane >> 5) * 32;
 #pragma unroll
             for (int s16 = ks_begin / 2; s16 < ks_end / 2; ++s16) {
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
             }
             return;
         }
-        const float* Ab = &As[(buf * BM + wr * (BM / 2) + frag_row) * LDP + frag_k];
+        const float* Ab = &As[(buf * BM + wr * (TM * 32) + frag_row) * LDP + frag_k];
         const float* Wb = &Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP + frag_k];
 #pragma unroll
         for (int ks = ks_begin; ks < ks_end; ++ks) {
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                    const int m = m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                     if (m < a.M) part[(long long)m * a.N + n] = acc[i][j][r];
                 }
         }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                const int m = m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                 if (m < a.M) {
                     float v = acc[i][j][r] * osc + bv;
                     if (pr.R) {
@@ -589,7 +595,7 @@ static int launch_small(const GemmArgs& base, int nprob, hipStream_t s) {
     return nw8 ? launch_small_n<8, false>(a, nprob, s) : launch_small_n<4, false>(a, nprob, s);
 }
 
-template <int BM, int BN, int PIPE, int ARITH>
+template <int BM, int BN, int PIPE, int ARITH, int NW = 4>
 int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     GemmArgs a = base;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -599,12 +605,12 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>),
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kernel<BM, BN, PIPE, ARITH, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit > 1 ? a.ksplit : 1, nprob);
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE, ARITH>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, PIPE, ARITH, NW>), grid, dim3(64 * NW), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (a.ksplit > 1) {
         const long long quads = (long long)a.M * (a.N >> 2);
@@ -615,6 +621,7 @@ int launch_tile(const GemmArgs& base, int nprob, hipStream_t s) {
 }
 
 int g_gemm_splitk = 1;  // 0 disables the split-K of small grids (A/B)
+int g_gemm_f32_nw8 = 1;         // sola_tune "gemm_f32_nw8": the exact-f32 128x128 shape with eight waves per block (0 = four; A/B)
 int g_gemm_splitk_max = 8;      // sola_tune "gemm_splitk_max": most K ranges per tile (A/B)
 int g_gemm_splitk_tiles = 512;  // grids with fewer 64x64 tiles than this are split (target: twice as many blocks)
 int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 by 5%, mid-tile staging on 64x64 by 6%), 0 / 1 force
@@ -629,6 +636,7 @@ void sola_gemm_set_splitk(int v) { g_gemm_splitk = v != 0; if (v > 1) g_gemm_spl
 void sola_gemm_set_splitk_max(int v) { g_gemm_splitk_max = v < 2 ? 2 : v; }
 void sola_gemm_set_small_rows(int v) { g_gemm_small_rows = v; }
 void sola_gemm_set_small_nw8(int v) { g_gemm_small_nw8 = v; }
+void sola_gemm_set_f32_nw8(int v) { g_gemm_f32_nw8 = v; }
 void sola_gemm_set_glds(int v) { g_gemm_glds = v; }
 bool gemm_split_glds_supported(const GemmDesc& d);
 int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
@@ -737,6 +745,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
         if (big) return pipe ? launch_tile<128, 128, 1, 1>(a, d.nprob, s) : launch_tile<128, 128, 0, 1>(a, d.nprob, s);
         return pipe ? launch_tile<64, 64, 1, 1>(a, d.nprob, s) : launch_tile<64, 64, 0, 1>(a, d.nprob, s);
     }
+    if (big && g_gemm_f32_nw8) return pipe ? launch_tile<128, 128, 1, 0, 8>(a, d.nprob, s) : launch_tile<128, 128, 0, 0, 8>(a, d.nprob, s);
     if (big) return pipe ? launch_tile<128, 128, 1, 0>(a, d.nprob, s) : launch_tile<128, 128, 0, 0>(a, d.nprob, s);
     return pipe ? launch_tile<64, 64, 1, 0>(a, d.nprob, s) : launch_tile<64, 64, 0, 0>(a, d.nprob, s);
 }
