@@ -457,6 +457,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "infer_f32_rows": a precision-1 inference call (sola_forward / sola_forward_ragged) over at most this many object-token rows (default 4096:
  * one sample per call, the reference's inference batch size) runs the exact-f32 kernels - faster there since the few-row GEMM shape (no casts, no
  * guard read-back: 0.61 -> 0.45 ms per call at the headline shape) and exact; 0 = the split-f16 pass at every size;
+ * "gemm_f32_nw8", "gemm_tn_nw8": 1 (default) = the exact-f32 128 x 128 GEMM / the exact-f32 weight-gradient kernels run eight waves of 32 x 64 per
+ * block (four waves per SIMD instead of two; bit-identical outputs, bias gradients in another fixed summation order), 0 = four waves of 64 x 64;
  * "gemm_small_rows": exact-f32 GEMMs on plain rows of at most this many rows (default 2048: one sample per call or optimizer step) take the
  * 32 x 32 shape whose split over K happens inside the block (no partial sums in memory, no reduce launch); 0 = the 64 x 64 + split-K pair;
  * "gemm_splitk_max": most K ranges per tile of that pair (default 8; A/B);

@@ -30,7 +30,13 @@ constexpr int TM = 32;        // rows of the reduction per LDS stage
 constexpr int TP = TB + 4;    // LDS pitch (floats), 16-byte aligned rows
 
 // one (tile, row split) work item: tile = tn * tiles_k + tk
+// NW = 4: 2 x 2 waves of 64 x 64; NW = 8 (round 4): 4 x 2 waves of 32 x 64 - the CU's two blocks (LDS) put four waves on every SIMD instead of
+// two, as in the NT kernel (gemm.hip); the same reduction order per output element: bit-identical.
+template <int NW>
 __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, float* smem) {
+    constexpr int TMW = NW == 8 ? 1 : 2;     // 32-row MFMA tiles per wave along n
+    constexpr int LP = NW == 8 ? 2 : 4;      // load passes: 8 rows per pass at 256 threads, 16 at 512
+    constexpr int LR = NW == 8 ? 16 : 8;
     float* As = smem;                 // [2][TM][TP]
     float* Bs = smem + 2 * TM * TP;   // [2][TM][TP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,10 +46,10 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
     const int m_begin = split * a.m_per_split;
     const int m_end = min(a.M, m_begin + a.m_per_split);
 
-    // loads: 32 lanes cover one 128-float row; 8 rows per pass, 4 passes
-    const int lrow = tid >> 5;         // 0..7
+    // loads: 32 lanes cover one 128-float row; LR rows per pass, LP passes
+    const int lrow = tid >> 5;         // 0..LR-1
     const int lcol = (tid & 31) << 2;  // 0..124
-    float4 ra[4], rb[4];
+    float4 ra[LP], rb[LP];
     auto load_stage = [&](int mbase) {
         int kk = 0, ci = k0 + lcol;
         if (a.conv) {
@@ -51,8 +57,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
             ci -= kk * a.Cin;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mbase + lrow + 8 * i;
+        for (int i = 0; i < LP; ++i) {
+            const int m = mbase + lrow + LR * i;
             const bool mok = m < m_end;
             ra[i] = (mok && n0 + lcol < a.N) ? *reinterpret_cast<const float4*>(a.A + (long long)m * a.lda + n0 + lcol)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -76,15 +82,15 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As[(buf * TM + lrow + 8 * i) * TP + lcol]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[(buf * TM + lrow + 8 * i) * TP + lcol]) = rb[i];
+        for (int i = 0; i < LP; ++i) {
+            *reinterpret_cast<float4*>(&As[(buf * TM + lrow + LR * i) * TP + lcol]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[(buf * TM + lrow + LR * i) * TP + lcol]) = rb[i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TMW][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -98,7 +104,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
         load_stage(m_begin);
         if (want_bias) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
+            for (int i = 0; i < LP; ++i) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
         }
         store_stage(0);
     }
@@ -106,34 +112,37 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
         if (st + 1 < nstage) load_stage(m_begin + (st + 1) * TM);
-        const float* Ab = &As[(buf * TM + fm) * TP + wr * 64 + fcol];
+        const float* Ab = &As[(buf * TM + fm) * TP + wr * (32 * TMW) + fcol];
         const float* Bb = &Bs[(buf * TM + fm) * TP + wc * 64 + fcol];
 #pragma unroll
         for (int mm = 0; mm < TM; mm += 2) {
-            const float a0 = Ab[mm * TP], a1 = Ab[mm * TP + 32];
+            const float a0 = Ab[mm * TP];
             const float b0 = Bb[mm * TP], b1 = Bb[mm * TP + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (TMW == 2) {
+                const float a1 = Ab[mm * TP + 32];
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         if (st + 1 < nstage) {
             if (want_bias) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
+                for (int i = 0; i < LP; ++i) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
             }
             store_stage(buf ^ 1);
         }
         __syncthreads();
     }
     if (want_bias) {
-        float* red = smem;  // [8][TB]: reduce the 8 row lanes (the stage buffers are free after the last barrier)
+        float* red = smem;  // [LR][TB]: reduce the LR row lanes (the stage buffers are free after the last barrier)
         *reinterpret_cast<float4*>(&red[lrow * TB + lcol]) = bsum;
         __syncthreads();
         if (tid < TB && n0 + tid < a.N) {
             float v = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v += red[r * TB + tid];
+            for (int r = 0; r < LR; ++r) v += red[r * TB + tid];
             a.Pb[(long long)split * a.N + n0 + tid] = v;
         }
     }
@@ -144,18 +153,19 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
         const int k = k0 + wc * 64 + j * 32 + col_l;
         if (k >= a.K) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                const int n = n0 + wr * (32 * TMW) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                 if (n < a.N) P[(long long)n * a.K + k] = acc[i][j][r];
             }
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const TnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f32_kernel(const TnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    tn_tile(a, (int)blockIdx.x, (int)blockIdx.y, smem);
+    tn_tile<NW>(a, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // ---- grouped form (round 4): the weight gradients of ALL linear layers of a few-sample step in ONE launch --------------------------
@@ -180,7 +190,8 @@ struct TnGroupArgs {
     TnGroupProb p[TN_GROUP_MAX];
     int nprob;
 };
-__global__ __launch_bounds__(256) void gemm_tn_f32_group_kernel(const TnGroupArgs g) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f32_group_kernel(const TnGroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int pi = 0;
     for (int j = 1; j < g.nprob; ++j)  // block-uniform, at most 32 entries
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_group_kernel(const TnGroupArg
     a.conv = q.conv; a.T_in = q.T_in; a.T_out = q.T_out; a.stride = q.stride; a.pad = q.pad; a.Cin = q.Cin; a.rowmap = q.rowmap;
     a.tiles_n = 0; a.tiles_k = q.tiles_k;
     a.m_per_split = (a.M + TM - 1) / TM * TM;  // one split: every row
-    tn_tile(a, (int)blockIdx.x - q.tile_begin, 0, smem);
+    tn_tile<NW>(a, (int)blockIdx.x - q.tile_begin, 0, smem);
 }
 
 // out_e[c * ldo_e + col_off_e + r] = in_e[r * ldi_e + c] (ldi_e = 0: contiguous rows) for up to TR_GROUP_MAX matrices in one launch (blockIdx.z = e): the weight
@@ -329,6 +340,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
 
 }  // namespace
 
+int g_gemm_tn_nw8 = 1;  // sola_tune "gemm_tn_nw8": the exact-f32 weight-gradient kernels with eight waves per block (0 = four; A/B)
+void sola_gemm_tn_set_nw8(int v) { g_gemm_tn_nw8 = v; }
 static int tn_splits(int M, int N, int K) {
     const long long tiles = (long long)((N + TB - 1) / TB) * ((K + TB - 1) / TB);
     int splits = (int)((768 + tiles - 1) / tiles);
@@ -367,13 +380,14 @@ int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     {
         SolaProfScope prof(SOLA_PROF_GEMM_TN, s, 2.0 * d.M * d.N * (double)d.K, 4.0 * ((double)d.M * (d.N + d.K) + (double)splits * d.N * d.K));
-        hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(a.tiles_n * a.tiles_k, splits), dim3(256), lds, s, a);
+        if (g_gemm_tn_nw8) hipLaunchKernelGGL(gemm_tn_f32_kernel<8>, dim3(a.tiles_n * a.tiles_k, splits), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(gemm_tn_f32_kernel<4>, dim3(a.tiles_n * a.tiles_k, splits), dim3(256), lds, s, a);
         SOLA_LAUNCH_CHECK();
     }
     {
@@ -415,11 +429,13 @@ int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_group_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     SolaProfScope prof(SOLA_PROF_GEMM_TN, s, flops, bytes);
-    hipLaunchKernelGGL(gemm_tn_f32_group_kernel, dim3((unsigned)tiles), dim3(256), lds, s, g);
+    if (g_gemm_tn_nw8) hipLaunchKernelGGL(gemm_tn_f32_group_kernel<8>, dim3((unsigned)tiles), dim3(512), lds, s, g);
+    else hipLaunchKernelGGL(gemm_tn_f32_group_kernel<4>, dim3((unsigned)tiles), dim3(256), lds, s, g);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
