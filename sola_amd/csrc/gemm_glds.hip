@@ -1175,9 +1175,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
     }
     __syncthreads();
     int stage = 0;
-    constexpr int NRD = 2 * MI + 4, NMF = (PURE ? 4 : 6) * MI;
-    constexpr int NDMA = APW + WPW, DMA_GAP = (NMF - 1) / NDMA;
-    constexpr int NDMA_L = APL + WPL, DMA_GAP_L = (NMF - 1) / NDMA_L;  // loader waves: one piece behind every MFMA of the second half
+    constexpr int NMF = (PURE ? 4 : 6) * MI;
+    constexpr int NDMA = APW + WPW;
+    constexpr int NDMA_L = APL + WPL, DMA_GAP_L = NDMA_L > 0 ? (NMF - 1) / NDMA_L : 1;  // loader waves: one piece behind every MFMA of the second half
     static_assert(LD == 0 || DMA_GAP_L >= 1, "the loader's pieces must fit behind the second half's MFMAs");
     for (; tile < total; tile += gridDim.x) {
         int z, ks, m0, n0;
@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
             constexpr int ROLE = decltype(rolec)::value;  // 0: every wave loads its share (LD = 0); 1: loader wave; 2: its partner (no DMA)
             constexpr int MPG = NMF / MI;                  // MFMAs of one group (one A row block): 6 split, 4 plain 16-bit
             constexpr int NP = ROLE == 0 ? NDMA : (ROLE == 1 ? NDMA_L : 0), PPG = NP / MI;  // DMA pieces of this wave per k-tile / per group
-            constexpr int GAP = PPG > 0 ? (MPG - 1) / PPG : 0;                                // MFMAs in front of each of a group's pieces
+            constexpr int GAP = (MPG - 1) / (PPG > 0 ? PPG : 1) * (PPG > 0 ? 1 : 0);          // MFMAs in front of each of a group's pieces (0: no pieces)
             static_assert(NP % MI == 0 && (PPG == 0 || GAP >= 1), "a group's DMA pieces must fit between its MFMAs");
             if constexpr (TRACE) tr_wait += tr_t1 - tr_t0;  // the previous k-tile's wait (both stamps have long returned)
             // ---- first half: products of k 0..15 (f0); the fragments of k 16..31 of the same stage arrive group by group
