@@ -237,8 +237,8 @@ __device__ __forceinline__ void gn_apply_store(const GnArgs& a, long long off, c
 // General shape: three passes over an L2-resident unit (any token count).
 __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     __shared__ float red[4];
-    const int g = blockIdx.y;
-    const int inst = blockIdx.x;
+    // block -> (instance, group), the group fastest (blocks in flight together cover all column slices of the same token rows)
+    const int inst = (int)(blockIdx.x / a.groups), g = (int)(blockIdx.x % a.groups);
     const int f4 = a.cg >> 2;                 // float4 per token slice
     const int lpt = f4;                       // lanes per token
     const int tpp = 256 / lpt;                // tokens per pass
@@ -440,13 +440,18 @@ __global__ __launch_bounds__(NTHR) void group_norm_reg_h8_kernel(const GnArgs a,
 //           slice is read again, normalised and stored (same epilogue as every other shape).
 // No inter-block waiting.  Traffic 2 reads + 1 write, from (units x slices) blocks.
 constexpr int GNC_R = 32;
-struct GncGeo { long long row0, tok_stride; int ntok, pe_row, g, inst, t0, tl, c4, tpp, nslice; };
+struct GncGeo { long long row0, tok_stride, unit; int ntok, pe_row, g, inst, t0, tl, c4, tpp, nslice, sl; };
 __device__ __forceinline__ GncGeo gnc_geo(const GnArgs& a, int S) {
     GncGeo q;
-    const long long unit = blockIdx.x / S;
-    const int sl = (int)(blockIdx.x - unit * S);
+    // block -> (instance, slice, group), the GROUP fastest: neighbouring blocks read the eight column slices of the same token rows, as the
+    // register shapes do (with the slice fastest, the blocks in flight all sat on one 512-byte column slice of 4-KiB rows: 2.8 TB/s)
+    const long long rest = blockIdx.x / a.groups;
+    q.g = (int)(blockIdx.x - rest * a.groups);
+    q.inst = (int)(rest / S);
+    const int sl = (int)(rest - (long long)q.inst * S);
+    q.sl = sl;
+    q.unit = (long long)q.inst * a.groups + q.g;  // slot index of (unit, slice): unit * S + slice
     const int f4 = a.cg >> 2;
-    q.inst = (int)(unit / a.groups); q.g = (int)(unit - (long long)q.inst * a.groups);
     const GnUnit un = gn_unit(a, q.inst);
     q.row0 = un.row0; q.tok_stride = un.tok_stride; q.ntok = un.ntok; q.pe_row = un.pe_row;
     q.tpp = 256 / f4;
@@ -480,22 +485,34 @@ __global__ __launch_bounds__(256) void group_norm_slice_stats_kernel(const GnArg
     // gn_apply_store were not unrolled, v[] became a scratch array (528 bytes per lane) and every load of the loop above was followed by a
     // wait and a scratch store - 206 us for 168 MB (round 4, tools/co_regs.py).  The apply launch takes every unit: same numbers
     // (one slice: weight 1, d = 0), the slice's second read comes out of L2.
-    if (threadIdx.x == 0) slots[blockIdx.x] = make_float2(mean, m2);
+    if (threadIdx.x == 0) slots[q.unit * S + q.sl] = make_float2(mean, m2);
 }
 __global__ __launch_bounds__(256) void group_norm_slice_apply_kernel(const GnArgs a, int S, const float2* __restrict__ slots) {
     const GncGeo q = gnc_geo(a, S);
     if (q.t0 < 0) return;
     const int ts = q.tpp * GNC_R;
-    const long long unit = blockIdx.x / S;
-    // combine the unit's slices in index order (every block of the unit computes the same numbers)
+    const long long unit = q.unit;
+    // combine the unit's slices in index order (every block of the unit computes the same numbers).  Lane i of every wave fetches slot i - one
+    // round trip instead of 2 * nslice dependent ones in front of the block's first data load - and the sums run over lane broadcasts in
+    // the same order as before (same bits).  Units of more than 64 slices (16 384 tokens) keep the loop over memory.
     float mean = 0.f;
     const float ntot = (float)q.ntok * (float)a.cg;
-    for (int i = 0; i < q.nslice; ++i) mean += slots[unit * S + i].x * ((float)min(q.ntok - i * ts, ts) * (float)a.cg / ntot);
     float m2 = 0.f;
-    for (int i = 0; i < q.nslice; ++i) {
-        const float2 sm = slots[unit * S + i];
-        const float d = sm.x - mean;
-        m2 += sm.y + (float)min(q.ntok - i * ts, ts) * (float)a.cg * d * d;
+    if (q.nslice <= 64) {
+        const int li = threadIdx.x & 63;
+        const float2 mine = li < q.nslice ? slots[unit * S + li] : make_float2(0.f, 0.f);
+        for (int i = 0; i < q.nslice; ++i) mean += __shfl(mine.x, i, 64) * ((float)min(q.ntok - i * ts, ts) * (float)a.cg / ntot);
+        for (int i = 0; i < q.nslice; ++i) {
+            const float d = __shfl(mine.x, i, 64) - mean;
+            m2 += __shfl(mine.y, i, 64) + (float)min(q.ntok - i * ts, ts) * (float)a.cg * d * d;
+        }
+    } else {
+        for (int i = 0; i < q.nslice; ++i) mean += slots[unit * S + i].x * ((float)min(q.ntok - i * ts, ts) * (float)a.cg / ntot);
+        for (int i = 0; i < q.nslice; ++i) {
+            const float2 sm = slots[unit * S + i];
+            const float d = sm.x - mean;
+            m2 += sm.y + (float)min(q.ntok - i * ts, ts) * (float)a.cg * d * d;
+        }
     }
     const float rstd = 1.0f / sqrtf(m2 / ntot + a.eps);  // biased variance, as nn.GroupNorm
     const int ch = q.g * a.cg + q.c4 * 4;
@@ -503,13 +520,21 @@ __global__ __launch_bounds__(256) void group_norm_slice_apply_kernel(const GnArg
     const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
     float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)q.pe_row * a.C + ch);
-#pragma unroll 4
-    for (int r = 0; r < GNC_R; ++r) {
-        const int t = q.t0 + q.tl + r * q.tpp;
-        // out-of-range token slots still take part in the split-f16 shuffles; off < 0 marks "do not store"
-        const long long off = t < q.ntok ? (q.row0 + (long long)t * q.tok_stride) * a.C + ch : -1;
-        const float4 v = off >= 0 ? gn_load(a, off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        gn_apply_store(a, off, v, mean, rstd, ga, be, pe, q.c4);
+    // eight slots at a time: their loads back to back (gn_load_slots), then the eight normalise + store steps (each load used to sit behind
+    // the previous slot's store with a full wait in between: 249 us for 672 MB on the 128-sample ragged batch)
+    constexpr int CH = 8;
+    for (int c = 0; c < GNC_R / CH; ++c) {
+        const int tf = q.t0 + q.tl + c * CH * q.tpp;
+        if (tf - q.tl >= q.ntok) break;  // block-uniform: the slice ends before this chunk
+        float4 v[CH];
+        gn_load_slots<CH>(a, v, q.row0, q.tok_stride, q.ntok, tf, q.tpp, ch);
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            const int t = tf + r * q.tpp;
+            // out-of-range token slots still take part in the split-f16 shuffles; off < 0 marks "do not store"
+            const long long off = t < q.ntok ? (q.row0 + (long long)t * q.tok_stride) * a.C + ch : -1;
+            gn_apply_store(a, off, v[r], mean, rstd, ga, be, pe, q.c4);
+        }
     }
 }
 
@@ -668,6 +693,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     SolaProfScope prof(SOLA_PROF_NORM, s, 8.0 * elems, (d.y2 ? 12.0 : 8.0) * elems);
     const int f4 = cg / 4;
     const long long n_units = (long long)d.n_inst * d.groups;
+    SOLA_ARG(n_units < (1ll << 31), "group_norm: %lld (instance, group) units exceed the grid", n_units);
     const int rw = 64 % f4 == 0 ? (d.ntok + 64 / f4 - 1) / (64 / f4) : 1 << 30;     // float4 per lane, one wave per unit
     const int rb = 256 % f4 == 0 ? (d.ntok + 256 / f4 - 1) / (256 / f4) : 1 << 30;  // ... one block per unit
     // 16-bit storage mode: eight channels (16 bytes) per lane where the unit fits the register shapes
@@ -714,10 +740,10 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
             SOLA_LAUNCH_CHECK();
             hipLaunchKernelGGL(group_norm_slice_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, S, slots);
         } else {
-            hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(group_norm_kernel, dim3((unsigned)n_units), dim3(256), 0, s, a);
         }
     } else {
-        hipLaunchKernelGGL(group_norm_kernel, dim3(d.n_inst, d.groups), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(group_norm_kernel, dim3((unsigned)n_units), dim3(256), 0, s, a);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
