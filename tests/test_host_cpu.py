@@ -311,6 +311,48 @@ def test_group_norm_kernels_keep_registers_and_16_byte_loads():
     assert seen >= 20, seen
 
 
+def test_no_kernel_outside_the_known_experiments_has_a_scratch_segment():
+    """Round 4: three kernels ran far below their traffic's speed because the compiler had put a register array into SCRATCH (an epilogue loop
+    it did not unroll; arrays filled and drained by lambdas) - invisible in the source, one line in the code object's metadata.  Every kernel
+    of the library: no scratch segment and no spilled vector register, except the listed experiments / fallbacks whose counts are pinned
+    (they may not grow either)."""
+    import glob
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import co_regs
+    objs = sorted(glob.glob(os.path.join(root, "build", "obj", "*.o")))
+    if not objs or not os.path.exists(os.path.join(co_regs.LLVM, "llvm-readelf")):
+        pytest.skip("objects not built here (run __graft_entry__.build()) or no llvm-readelf")
+    known = [  # (demangled-name pattern, most spilled VGPRs, largest scratch segment in bytes)
+        (r"attn_fwd_f32_kernel<128, false, [48], (true|false), 2>", 8, 32),            # round-1 shared-staging attention (the uniform training forward's motion / object->language launches): 5-6 values
+        (r"attn_fwd_f32_reg_kernel<[34]>", 200, 540),                                   # A/B register budgets (attn_reg_minw)
+        (r"attn_fwd_sm_res_kernel", 20, 84),                                            # A/B (attn_res_splitm)
+        (r"attn_fwd_f32_simple_kernel<128, 16, true, true>", 1, 8),                     # training forward: one value
+        (r"group_norm_reg_kernel<32, false, 256>", 0, 528),                             # gn_wide = 0 only
+        (r"group_norm_bwd_reg_kernel<8, false, 1024>", 14, 60),                         # 128 registers at 16 waves per block
+        (r"gemm_nt_split_glds_kernel<4, 2, 4, true, [012]>", 21, 56),                   # non-persistent conv shape (gemm_persist = 0)
+        (r"gemm_nt_split_glds_pp_kernel", 99, 800),                                     # gemm_pp experiment
+        (r"gemm_nt_split_glds_persist_kernel<false, 0, 0, 0, 0, 8, [01], [12]>", 41, 160),  # loader-wave (gemm_ld) experiments
+        (r"gemm_nt_split_glds_persist_kernel<false, 0, 0, 0, 0, 8, 1, 0>", 8, 64),      # trace instantiation
+    ]
+    seen = 0
+    for obj in objs:
+        try:
+            rows = co_regs.kernel_table(obj)
+        except Exception:
+            continue  # host-only object
+        for r in rows:
+            seen += 1
+            if r["spill"] == 0 and r["scratch"] == 0:
+                continue
+            hit = [k for k in known if re.search(k[0], r["demangled"])]
+            assert hit, (os.path.basename(obj), r["demangled"], r["spill"], r["scratch"])
+            assert r["spill"] <= hit[0][1] and r["scratch"] <= hit[0][2], (r["demangled"], r["spill"], r["scratch"], hit[0])
+    assert seen >= 200, seen
+
+
 def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
     """What bench.py's headline measures is what a user of the classes and entry points gets."""
     monkeypatch.delenv("SOLA_PRECISION", raising=False)
