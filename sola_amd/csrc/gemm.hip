@@ -55,7 +55,8 @@ constexpr int LDP = 36;  // LDS row pitch in floats (144 B: 16-byte aligned, con
 // (profiles/r04_gemm_f32_pmc.txt): matrix pipe busy 70.6 %, not power-bound - with two waves per SIMD, each from another block, both are
 // regularly at their k-tile barrier at once.  Same k order per output element: bit-identical results.
 template <int BM, int BN, int PIPE, int ARITH, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void gemm_nt_f32_kernel(const GemmArgs a) {  // two blocks per CU (their LDS allows exactly that)
+__global__ __launch_bounds__(64 * NW, NW / 2)  // (hipcc: the second argument is waves per SIMD)
+void gemm_nt_f32_kernel(const GemmArgs a) {  // two blocks per CU (their LDS allows exactly that): NW / 2 waves per SIMD, <= 1024 / NW registers
     constexpr int LROWS = 8 * NW;                       // rows one load pass of the block covers (8 lanes per 128-byte row segment)
     constexpr int RA = BM / LROWS, RW = BN / LROWS;     // 16-byte loads per thread per operand per k-tile
     constexpr int WROWS = NW / 2;                       // wave grid: WROWS x 2
@@ -248,21 +249,29 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_f32_kernel(const GemmArgs 
         }
         const float* Ab = &As[(buf * BM + wr * (TM * 32) + frag_row) * LDP + frag_k];
         const float* Wb = &Ws[(buf * BN + wc * (BN / 2) + frag_row) * LDP + frag_k];
+        // the fragments of step ks + 1 are requested before the MFMAs of step ks (pinned by a scheduling barrier: left alone the scheduler
+        // issues reads -> wait -> MFMAs per step, with the LDS latency in front of every step's first MFMA)
+        float4 af[2][TM], bf[2][TN];
+        auto frag = [&](int ks, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDP + ks * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(Wb + j * 32 * LDP + ks * 8);
+        };
+        frag(ks_begin, 0);
 #pragma unroll
         for (int ks = ks_begin; ks < ks_end; ++ks) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDP + ks * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * LDP + ks * 8);
+            const int slot = (ks - ks_begin) & 1;
+            if (ks + 1 < ks_end) frag(ks + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+                    const float av = s == 0 ? af[slot][i].x : s == 1 ? af[slot][i].y : s == 2 ? af[slot][i].z : af[slot][i].w;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+                        const float bv = s == 0 ? bf[slot][j].x : s == 1 ? bf[slot][j].y : s == 2 ? bf[slot][j].z : bf[slot][j].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
                 }
@@ -324,6 +333,36 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_f32_kernel(const GemmArgs 
         return;
     }
     const float osc = (a.out_scale_dev ? a.out_scale * *a.out_scale_dev : a.out_scale) * (pr.scale_dev ? *pr.scale_dev : 1.f);
+    if (ARITH == 0 && pr.R && !a.r_sp16 && !a.c_sp16) {
+        // f32 residual, f32 output (out-projections, the dX GEMMs that add the skip gradient): the generic loop below compiles to load -> full
+        // wait -> add -> store per ELEMENT (round 4 disassembly: 16 TM TN serialized round trips per lane, 13 % of such a launch).  Here the
+        // tile's residual values are requested first - clamped coordinates, unconditional loads, back to back - and then added and stored.
+        float rv[TM][TN][16];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n0 + wc * (BN / 2) + j * 32 + col_l, a.N - 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l, a.M - 1);
+                    rv[i][j][r] = pr.R[(long long)m * a.ldr + n];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 32 + col_l;
+            const float bv = (pr.bias && n < a.N) ? pr.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                    if (n < a.N && m < a.M) pr.C[(long long)m * a.ldc + n] = (acc[i][j][r] * osc + bv) + rv[i][j][r];  // same association as below
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wc * (BN / 2) + j * 32 + col_l;

@@ -114,16 +114,34 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, int tile, int split, fl
         if (st + 1 < nstage) load_stage(m_begin + (st + 1) * TM);
         const float* Ab = &As[(buf * TM + fm) * TP + wr * (32 * TMW) + fcol];
         const float* Bb = &Bs[(buf * TM + fm) * TP + wc * 64 + fcol];
+        // fragments of four row pairs at a time, the next four requested before the current four's MFMAs (as one unrolled loop the compiler
+        // issued read -> full wait -> two MFMAs per row pair: the LDS latency sat between every pair of MFMAs)
+        constexpr int CHK = 4, NCH = TM / 2 / CHK;
+        float fa0[2][CHK], fa1[2][CHK], fb0[2][CHK], fb1[2][CHK];
+        auto frag = [&](int cidx, int slot) {
 #pragma unroll
-        for (int mm = 0; mm < TM; mm += 2) {
-            const float a0 = Ab[mm * TP];
-            const float b0 = Bb[mm * TP], b1 = Bb[mm * TP + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            if constexpr (TMW == 2) {
-                const float a1 = Ab[mm * TP + 32];
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int e = 0; e < CHK; ++e) {
+                const int mm = (cidx * CHK + e) * 2;
+                fa0[slot][e] = Ab[mm * TP];
+                if constexpr (TMW == 2) fa1[slot][e] = Ab[mm * TP + 32];
+                fb0[slot][e] = Bb[mm * TP];
+                fb1[slot][e] = Bb[mm * TP + 32];
+            }
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int cidx = 0; cidx < NCH; ++cidx) {
+            const int slot = cidx & 1;
+            if (cidx + 1 < NCH) frag(cidx + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's reads in front of this chunk's MFMAs (the scheduler sinks loads to their uses)
+#pragma unroll
+            for (int e = 0; e < CHK; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[slot][e], fb0[slot][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[slot][e], fb1[slot][e], acc[0][1], 0, 0, 0);
+                if constexpr (TMW == 2) {
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[slot][e], fb0[slot][e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[slot][e], fb1[slot][e], acc[1][1], 0, 0, 0);
+                }
             }
         }
         if (st + 1 < nstage) {
