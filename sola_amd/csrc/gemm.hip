@@ -784,7 +784,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
         if (big) return pipe ? launch_tile<128, 128, 1, 1>(a, d.nprob, s) : launch_tile<128, 128, 0, 1>(a, d.nprob, s);
         return pipe ? launch_tile<64, 64, 1, 1>(a, d.nprob, s) : launch_tile<64, 64, 0, 1>(a, d.nprob, s);
     }
-    if (big && g_gemm_f32_nw8) return pipe ? launch_tile<128, 128, 1, 0, 8>(a, d.nprob, s) : launch_tile<128, 128, 0, 0, 8>(a, d.nprob, s);
+    if (big && g_gemm_f32_nw8 && !pipe) return launch_tile<128, 128, 0, 0, 8>(a, d.nprob, s);  // (the mid-tile staging schedule - an A/B - keeps four waves: at eight it spills)
     if (big) return pipe ? launch_tile<128, 128, 1, 0>(a, d.nprob, s) : launch_tile<128, 128, 0, 0>(a, d.nprob, s);
     return pipe ? launch_tile<64, 64, 1, 0>(a, d.nprob, s) : launch_tile<64, 64, 0, 0>(a, d.nprob, s);
 }
