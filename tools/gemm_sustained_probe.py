@@ -1,4 +1,4 @@
-"""sustained timing of the K=256 linear shapes: standalone launches vs their in-step time"""
+"""Sustained per-launch time of the persistent split-f16 GEMM on a few shapes, in chunks of launches with rotating operand buffers: does the time drift, is a launch slower inside a step than alone?"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from sola_amd import ops
