@@ -924,7 +924,8 @@ def main():
             tr = json.load(open(tpath))
             if tr.get("batch") == B and (N, T, L) == (64, 32, 16):
                 kk = tr["kernels"]
-                gk = tr.get("dominant_gemm") if args.precision == "f16x3" else "gemm_nt_f32_kernel<128, 128, 0, 0>"
+                f32k = next((k for k in kk if k.startswith("gemm_nt_f32_kernel<128, 128, 0, 0")), None)  # <..., 8>: eight waves per block since round 4
+                gk = tr.get("dominant_gemm") if args.precision == "f16x3" else f32k
                 if roofline and gk in kk:
                     roofline["traffic_kernel"] = gk
                     roofline["traffic"] = kk[gk]["hbm_bytes_per_launch"]
@@ -932,8 +933,8 @@ def main():
                 ak = [(kk[k]["hbm_bytes_per_launch"], kk[k]["calls"]) for k in kk if k.startswith("attn_fwd")]
                 if roofline_attn and ak:  # launch-weighted mean over the attention kernels of the profiled run
                     roofline_attn["traffic"] = int(sum(b * c for b, c in ak) / sum(c for _, c in ak))
-                if exact and exact.get("roofline") and "gemm_nt_f32_kernel<128, 128, 0, 0>" in kk:
-                    exact["roofline"]["traffic"] = kk["gemm_nt_f32_kernel<128, 128, 0, 0>"]["hbm_bytes_per_launch"]
+                if exact and exact.get("roofline") and f32k:
+                    exact["roofline"]["traffic"] = kk[f32k]["hbm_bytes_per_launch"]
             break
         out = {
             "metric": "track-selection forward+loss samples/sec at (T=32,N=64,d=256)",
