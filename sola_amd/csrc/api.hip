@@ -270,6 +270,10 @@ void sola_gemm_set_splitk_max(int v);
 void sola_gemm_set_small_rows(int v);
 void sola_gemm_set_small_nw8(int v);
 void sola_gemm_set_f32_nw8(int v);
+void sola_gemm_set_f32_persist(int v);
+#ifdef SOLA_EXPERIMENTS
+extern int g_gemm_f32p_ablate;
+#endif
 void sola_gemm_tn_set_nw8(int v);
 extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr, g_train_x16_keep, g_train_attn_cast;
 extern int g_gemm_stagger, g_gemm_order, g_gemm_trace, g_gemm_ld;
@@ -335,6 +339,10 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "infer_f32_rows")) { g_infer_f32_rows = value; return SOLA_OK; }
     if (!strcmp(key, "gemm_small_nw8")) { sola_gemm_set_small_nw8(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_f32_nw8")) { sola_gemm_set_f32_nw8(value); return SOLA_OK; }
+    if (!strcmp(key, "gemm_f32_persist")) { sola_gemm_set_f32_persist(value); return SOLA_OK; }
+#ifdef SOLA_EXPERIMENTS
+    if (!strcmp(key, "gemm_f32p_ablate")) { g_gemm_f32p_ablate = value; return SOLA_OK; }
+#endif
     if (!strcmp(key, "gemm_tn_nw8")) { sola_gemm_tn_set_nw8(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }

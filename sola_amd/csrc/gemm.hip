@@ -698,6 +698,8 @@ int launch_splitk_reduce(const float* part, int ksplit, int nprob, float* const*
 
 int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s);
 int gemm_split_glds_shape(const GemmDesc& d);  // 4 = 256x256 blocks, 1 = 128x128
+bool gemm_f32_persist_applies(const GemmDesc& d);  // gemm_f32p.hip: exact f32, persistent direct-to-LDS form (bit-identical to the kernels here)
+int launch_gemm_f32_persist(const GemmDesc& d, hipStream_t s);
 
 int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3, "gemm: nprob %d", d.nprob);
@@ -748,6 +750,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     SolaProfScope prof(cat, s, 2.0 * d.M * d.N * (double)d.K * d.nprob,
                        4.0 * d.nprob * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
     if (gemm_small_applies(d)) return launch_small(a, d.nprob, s);
+    if (d.arith == 0 && big && gemm_f32_persist_applies(d)) return launch_gemm_f32_persist(d, s);
     const int pipe = g_gemm_variant < 0 ? (big ? 0 : 1) : g_gemm_variant;
     // small grids (fewer 64x64 tiles than CUs, the single-sample regime): split K over up to 8 blocks per tile so the
     // serial k-loop gets ~8x shorter; partial sums go through the caller's scratch and are reduced in a fixed order
