@@ -52,23 +52,33 @@ __device__ __forceinline__ int tap_bits(int t0, int T_in) {
 }
 
 struct FragF32 { f32x4 a[2], b[2]; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // RMODE: 0 = no residual, 1 = f32 residual [M][ldr]
 // ABL (measurement, SOLA_EXPERIMENTS builds only; results are garbage): 1 = no two-level fold, 2 = no DMA in the k-loop, 4 = no epilogue,
-// 8 = no barrier in the k-loop, 16 = cycle stamps to F32pArgs::trace
+// 16 = cycle sums to F32pArgs::trace
+//
+// The k-loop carries NO vector-ALU work beyond the fold's 64 adds per 128 values of k: on gfx950 a VALU instruction does not overlap
+// with the f32 MFMA (tools/micro/mfma_f32_mix.hip, profiles/r05_mfma_f32_valu.txt: every v_fma costs the matrix pipe 5-8 cycles, a
+// v_pk_add_f32 12-17, at any occupancy - the f32 MFMA and the packed-f32 VALU share their peak), so
+//   * the fragment addresses are eight registers computed once (one per k-step and operand; stage and row block are immediates);
+//   * the DMA pieces are buffer loads: descriptor (scalar) + a per-lane offset that never changes + a scalar offset that carries the
+//     piece's rows and the k position - the stream advances on the scalar ALU;
+//   * the first MFMA of an accumulator after a fold takes an inline zero as its C operand (no clearing moves);
+//   * the epilogue's loads and stores are buffer accesses with scalar row offsets (no 64-bit address arithmetic per row).
 template <bool CONV, int RMODE, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs a) {
     constexpr int GBM = 256, GBN = 128, WAVES_N = 2, NWAVE = 8, TM = 2, TN = 2;
     constexpr int STAGE_BYTES = (GBM + GBN) * PROWB;
     constexpr int APW = GBM / 8 / NWAVE, WPW = GBN / 8 / NWAVE;  // 8-row DMA pieces per wave and k-tile: 4 + 2
     constexpr int NDMA = APW + WPW;
-    constexpr int FOLD = 4;          // k-tiles per inner accumulation (128 values of k, as gemm_nt_f32_kernel)
     constexpr int STRIP_ROWS = 16;
-    constexpr int NSTORE = TM * 2 * 4;  // float4 stores per lane of an interior tile's epilogue
+    constexpr int NSTORE = TM * 2 * 4;  // float4 stores per lane of a fast tile's epilogue
+    constexpr unsigned OOB = 0x80000000u;  // a per-lane offset beyond every descriptor's range: the load returns zeros
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-    const int nk = a.K / PBK;
+    const int nq = a.K / (4 * PBK);  // groups of four k-tiles = 128 values of k = one inner accumulation (gemm_nt_f32_kernel's FOLD)
 
     // tile order: the problems of a launch and the column tiles are the inner index, so the tiles that read one 256-row block of A
     // run back to back on one XCD (block b and its tiles b, b + grid, ... stay on XCD b % 8: the grid is a multiple of 8)
@@ -89,203 +99,227 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
         n0 = (c - z * a.tiles_n) * GBN;
     };
 
-    // ---- DMA stream: this wave owns row groups wave * APW + i (8 rows each) of the A tile and wave * WPW + i of the W tile;
-    //      lane -> (row = group * 8 + lane / 8, physical 16-byte chunk = lane % 8)
+    // ---- DMA stream: this wave owns row groups wave * APW + q (8 rows each) of the A tile and wave * WPW + i of the W tile;
+    //      lane -> (row = group * 8 + lane / 8, physical 16-byte chunk = lane % 8).  The swizzle key of a piece's rows,
+    //      ((group * 8 + lane / 8) >> 1) & 7, depends on the piece only through its parity: two per-lane offsets per operand.
     const int lrow = lane >> 3, chunk = lane & 7;
-    const char* a_ptr0;
-    const char* w_ptr0;
-    int a_d[APW], w_d[WPW];
-    int a_t0[APW];
-    int conv_kk = 0, conv_c = 0;
+    unsigned a_vo[2], w_vo[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int cb = (chunk ^ (lrow >> 1) ^ (par << 2)) << 4;
+        a_vo[par] = (unsigned)(lrow * a.lda * 4 + cb);  // plain rows; CONV: the row part comes from the geometry / row map (c_vo)
+        w_vo[par] = (unsigned)(lrow * a.K * 4 + cb);
+    }
+    unsigned c_vo[APW], c_eff[APW];  // CONV: per-lane offset of the piece's window start; ... with taps outside the sequence sent out of range
+    int a_t0[APW];                   // CONV: tap-validity bits of the piece's row
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(g_zero_page_f32p, 0, 0, 0x00020000), rs_w = rs_a;
+    int a_so = 0, w_so = 0;          // scalar offsets of this wave's first piece at the stream's k position
+    const int a_pitch8 = CONV ? 0 : a.lda * 32, w_pitch8 = a.K * 32;  // bytes between pieces (8 rows)
+    int conv_kk = 0, conv_c = 0;     // CONV: tap and channel of the next k-tile to issue
     int dma_kt = 0;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page_f32p);
+    const int nk = a.K / PBK;
+    auto conv_taps = [&]() {  // CONV: the per-lane offsets at tap conv_kk (a vector select per piece, when the tap changes)
+        if constexpr (CONV) {
+#pragma unroll
+            for (int q = 0; q < APW; ++q) c_eff[q] = ((a_t0[q] >> conv_kk) & 1) ? c_vo[q] : OOB;
+        }
+    };
     auto setup_dma = [&](int tile) {
         int z, m0, n0;
         decode(tile, z, m0, n0);
         const float* A = a.p[z].A;
-        const float* Wt = a.p[z].W;
-#pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const int r = (wave * APW + i) * 8 + lrow;
-            const int col_bytes = (chunk ^ ((r >> 1) & 7)) * 16;  // the logical chunk that must land in this physical slot
-            const int m = min(m0 + r, a.M - 1);                   // rows past M: clamped (never stored)
-            const char* p;
-            if (CONV) {
+        const float* Wt = a.p[z].W + (long long)n0 * a.K;
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, min(GBN, a.N - n0) * a.K * 4, 0x00020000);
+        w_so = wave * WPW * w_pitch8;
+        if constexpr (CONV) {
+            // window start of output row m: source row of tap 0 (may lie outside its sequence: the tap bits say which taps exist).
+            // Source rows ascend with m (sequences are concatenated in order), so offsets are taken from the tile's first row.
+            auto window = [&](int m, int& row0, int& bits) {
                 if (a.rowmap) {
                     const int2 rm = a.rowmap[m];
-                    a_t0[i] = rm.y;
-                    p = reinterpret_cast<const char*>(A) + (long long)rm.x * a.Cin * 4 + col_bytes;
+                    row0 = rm.x;
+                    bits = rm.y;
                 } else {
-                    const int rr = m / a.T_out, to = m - rr * a.T_out;
-                    const int t0 = to * a.stride - a.pad;
-                    a_t0[i] = tap_bits(t0, a.T_in);
-                    p = reinterpret_cast<const char*>(A) + ((long long)rr * a.T_in + t0) * a.Cin * 4 + col_bytes;
+                    const int rr = m / a.T_out, to = m - rr * a.T_out, t0 = to * a.stride - a.pad;
+                    row0 = rr * a.T_in + t0;
+                    bits = tap_bits(t0, a.T_in);
                 }
-            } else {
-                a_t0[i] = 0;
-                p = reinterpret_cast<const char*>(A + (long long)m * a.lda) + col_bytes;
-            }
-            if (i == 0) a_ptr0 = p;
-            a_d[i] = (int)(p - a_ptr0);
-        }
+            };
+            int base_row, base_bits;
+            window(min(m0, a.M - 1), base_row, base_bits);
+            base_row = __builtin_amdgcn_readfirstlane(base_row);
+            rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (long long)base_row * a.Cin), 0, 0x7fffff00, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) {
-            const int r = (wave * WPW + i) * 8 + lrow;
-            const int n = min(n0 + r, a.N - 1);
-            const char* p = reinterpret_cast<const char*>(Wt + (long long)n * a.K) + (chunk ^ ((r >> 1) & 7)) * 16;
-            if (i == 0) w_ptr0 = p;
-            w_d[i] = (int)(p - w_ptr0);
+            for (int q = 0; q < APW; ++q) {
+                const int r = (wave * APW + q) * 8 + lrow;
+                int row0, bits;
+                window(min(m0 + r, a.M - 1), row0, bits);  // rows past M: clamped (never stored)
+                a_t0[q] = bits;
+                c_vo[q] = (unsigned)((row0 - base_row) * a.Cin * 4 + ((chunk ^ (lrow >> 1) ^ ((q & 1) << 2)) << 4));
+            }
+            a_so = 0;
+        } else {
+            rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (long long)m0 * a.lda), 0, min(GBM, a.M - m0) * a.lda * 4, 0x00020000);
+            a_so = wave * APW * a_pitch8;
         }
         conv_kk = 0;
         conv_c = 0;
         dma_kt = 0;
+        conv_taps();
     };
     auto issue_piece = [&](int stage, int q) {
         char* sbase = lds + stage * STAGE_BYTES;
         if (q < APW) {
-            const char* src = a_ptr0 + a_d[q];
-            if (CONV) src = ((a_t0[q] >> conv_kk) & 1) ? src : zero;  // zero padding in time
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * APW + q) * 1024), 16, 0, 0);
+            const unsigned vo = CONV ? c_eff[q] : a_vo[q & 1];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sbase + (wave * APW + q) * 1024), 16, vo, a_so + q * a_pitch8, 0, 0);
         } else {
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr0 + w_d[q - APW]), (lptr_t)(sbase + GBM * PROWB + (wave * WPW + q - APW) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sbase + GBM * PROWB + (wave * WPW + q - APW) * 1024), 16, w_vo[(q - APW) & 1],
+                                                     w_so + (q - APW) * w_pitch8, 0, 0);
         }
     };
-    auto issue_advance = [&]() {  // past the last k-tile of the last tile the stream re-reads that k-tile into a stage nobody reads
+    // past the last k-tile of the last tile the stream re-reads that k-tile into a stage nobody reads.  Returns whether the conv tap changed.
+    auto issue_advance = [&]() -> bool {
         const bool more = dma_kt + 1 < nk;
         const int adv = more ? PBK * 4 : 0;
-        a_ptr0 += adv;
-        w_ptr0 += adv;
-        if (CONV) {
+        a_so += adv;
+        w_so += adv;
+        ++dma_kt;
+        if constexpr (CONV) {
             conv_c += more ? PBK : 0;
             const bool wrap = conv_c == a.Cin;
             conv_c = wrap ? 0 : conv_c;
             conv_kk += wrap ? 1 : 0;
+            return wrap;
         }
-        ++dma_kt;
-    };
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int q = 0; q < NDMA; ++q) issue_piece(stage, q);
-        issue_advance();
+        return false;
     };
 
     // ---- fragments: lane -> tile row (lane & 31) of each 32-row block, k half (lane >> 5) of an 8-deep step; the swizzle key
-    //      (row >> 1) & 7 is the same for all of a lane's rows (they differ by multiples of 32)
+    //      (row >> 1) & 7 is the same for all of a lane's rows (they differ by multiples of 32).  Step ks reads physical chunk
+    //      (2 ks + fh) ^ key = byte offset xoff ^ (ks << 5): one address register per step and operand, stage and row block as immediates.
     const int fr = lane & 31, fh = lane >> 5, key = (lane >> 1) & 7;
     const int a_frag = (wr * TM * 32 + fr) * PROWB, w_frag = GBM * PROWB + (wc * TN * 32 + fr) * PROWB;
-    const int xoff = (fh ^ key) << 4;  // step ks reads physical chunk (2 ks + fh) ^ key = byte offset xoff ^ (ks << 5)
+    const int xoff = (fh ^ key) << 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+    unsigned ra[4], rw[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ra[ks] = lds_base + (unsigned)(a_frag + (xoff ^ (ks << 5)));
+        rw[ks] = lds_base + (unsigned)(w_frag + (xoff ^ (ks << 5)));
+    }
     // The fragment reads are inline asm: in front of a compiler-visible LDS read the waitcnt pass puts vmcnt(0) when LDS-DMA pieces are
     // in flight (it cannot tell the stages apart), which would cut the DMA's tile time of cover to nothing.  land() is their wait: it
     // names the fragments as in/out operands, so every use of them is ordered behind it.
-    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
-#define F32P_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
-    auto read_step = [&](int stage, int ks, FragF32& f) {
-        const unsigned sb = lds_base + (unsigned)(stage * STAGE_BYTES) + (unsigned)(xoff ^ (ks << 5));
-        const unsigned wa = sb + w_frag, aa = sb + a_frag;
-        F32P_RD(f.b[0], wa, 0);
-        F32P_RD(f.b[1], wa, 4096);
-        F32P_RD(f.a[0], aa, 0);
-        F32P_RD(f.a[1], aa, 4096);
+#define F32P_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+    auto read_step = [&ra = ra, &rw = rw](auto stc, auto ksc, FragF32& f) {
+        constexpr int ST = decltype(stc)::value, KS = decltype(ksc)::value;
+        F32P_RD(f.b[0], rw[KS], ST * STAGE_BYTES);
+        F32P_RD(f.b[1], rw[KS], ST * STAGE_BYTES + 32 * PROWB);
+        F32P_RD(f.a[0], ra[KS], ST * STAGE_BYTES);
+        F32P_RD(f.a[1], ra[KS], ST * STAGE_BYTES + 32 * PROWB);
     };
-#undef F32P_RD
-    static_assert(TM == 2 && TN == 2 && 32 * PROWB == 4096, "the offsets above");
+    static_assert(TM == 2 && TN == 2 && STAGE_BYTES + 32 * PROWB < 65536, "the immediates above");
     auto land = [&](FragF32& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1])::"memory"); };
     f32x16 acc[TM][TN], outer[TM][TN];
     // the 16 MFMAs of one 8-deep k-step, in gemm_nt_f32_kernel's order per accumulator: s = 0..3, lanes 0-31 k = 8 ks + s, lanes 32-63
-    // k = 8 ks + 4 + s.  `first`: the step's first MFMA alone (the next fragments are requested right behind it), else the other fifteen
-    auto mfma_step = [&](const FragF32& f, bool first) {
+    // k = 8 ks + 4 + s.  `first`: the step's first MFMA alone (the next fragments are requested right behind it), else the other fifteen.
+    // ZERO: the step opens an inner accumulation - its s = 0 products start from an inline zero instead of a cleared register.
+    auto mfma_step = [&](const FragF32& f, bool first, auto zc) {
+        constexpr bool ZERO = decltype(zc)::value;
+        const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    if (first == (s == 0 && i == 0 && j == 0)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+                    if (first == (s == 0 && i == 0 && j == 0))
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], (ZERO && s == 0) ? z16 : acc[i][j], 0, 0, 0);
     };
     constexpr int NMF = 4 * TM * TN;
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
 
     int tile = blockIdx.x;
     if (tile >= total) return;
-    bool prev_fast = false;  // the previous tile of this block left through the interior epilogue (its store count is known)
+    bool prev_fast = false;  // the previous tile of this block left through the buffer-store epilogue (its store count is known)
     setup_dma(tile);
-    issue(0);
-    issue(1);  // nk >= 2 (checked by the launcher)
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(0, q);
+    if (issue_advance()) conv_taps();
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(1, q);
+    if (issue_advance()) conv_taps();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // k-tile 0 is the older half of what is in flight
     __builtin_amdgcn_s_barrier();
-    int stage = 0;
-    unsigned long long tr_loop = 0, tr_wait = 0, tr_epi = 0, tr_n = 0, tr_t = 0;
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};  // ABL & 128: steps 0-2, DMA wait, barrier, step 3, fold
+    unsigned long long tr_loop = 0, tr_epi = 0, tr_n = 0, tr_t = 0;
     for (; tile < total; tile += gridDim.x) {
         int z, m0, n0;
         decode(tile, z, m0, n0);
-        if constexpr (ABL & (16 | 128)) tr_t = clock64();
         const int next = tile + gridDim.x;
         const bool has_next = next < total;
+        if constexpr (ABL & 16) tr_t = clock64();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = outer[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) outer[i][j][r] = 0.f;
 
-        // k-tile 0 of this tile is in LDS (waited for and published by the barrier of the previous tile's last k-tile, or by the prologue)
+        // k-tile 0 of this tile is in LDS, stage 0 (a tile is a whole number of k-tile groups): waited for and published by the barrier of the
+        // previous tile's last k-tile, or by the prologue
         FragF32 f0, f1;
-        read_step(stage, 0, f0);
-        for (int kt = 0; kt < nk; ++kt) {
-            // k-tile kt issues the DMA of k-tile kt + 2; from kt = nk - 2 on that is the next tile's stream
-            if (kt == nk - 2 && has_next) setup_dma(next);
-            unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
-            if constexpr (ABL & 128) p0 = clock64();
-            __builtin_amdgcn_sched_barrier(0);
+        read_step(T0{}, T0{}, f0);
+        // One k-tile at position KQ of its group of four (stage KQ & 1).  It issues the DMA of the stream's k-tile two ahead.
+        auto ktile = [&](auto kqc, bool relaxed_wait) {
+            constexpr int KQ = decltype(kqc)::value;
+            using ST = std::integral_constant<int, (KQ & 1)>;
+            using SN = std::integral_constant<int, ((KQ & 1) ^ 1)>;
+            using ZF = std::integral_constant<bool, KQ == 0>;
+            using NZ = std::integral_constant<bool, false>;
             // ---- steps 0..2: the next step's fragments are requested right behind the step's first MFMA
             land(f0);
-            mfma_step(f0, true);
+            mfma_step(f0, true, ZF{});
             __builtin_amdgcn_sched_barrier(0);
-            read_step(stage, 1, f1);
+            read_step(ST{}, T1{}, f1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(f0, false);
+            mfma_step(f0, false, ZF{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(1);
             land(f1);
-            mfma_step(f1, true);
+            mfma_step(f1, true, NZ{});
             __builtin_amdgcn_sched_barrier(0);
-            read_step(stage, 2, f0);
+            read_step(ST{}, T2{}, f0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(f1, false);
+            mfma_step(f1, false, NZ{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(0);
             land(f0);
-            mfma_step(f0, true);
+            mfma_step(f0, true, NZ{});
             __builtin_amdgcn_sched_barrier(0);
-            read_step(stage, 3, f1);
+            read_step(ST{}, T3{}, f1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(f0, false);
+            mfma_step(f0, false, NZ{});
             __builtin_amdgcn_sched_barrier(0);
-            // ---- k-tile kt + 1 has landed (and this wave's last fragments of k-tile kt).  At kt == 0 behind an interior tile's epilogue that
-            //      is k-tile 1, issued BEFORE the epilogue's stores: vmcnt is one in-order counter, so naming the store count waits for the DMA
-            //      without waiting for the stores to be acknowledged
-            if constexpr (ABL & 128) p1 = clock64();
-            if (kt == 0 && prev_fast) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+            // ---- k-tile kt + 1 has landed (and this wave's last fragments of k-tile kt).  Behind a fast tile's epilogue the first wait names
+            //      the store count: vmcnt is one in-order counter and k-tile 1's DMA was issued BEFORE the epilogue's stores, so this waits for
+            //      the DMA without waiting for the stores to be acknowledged
+            if (relaxed_wait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             land(f1);
-            if constexpr (ABL & 128) p2 = clock64();
-            unsigned long long tw = 0;
-            if constexpr (ABL & 16) tw = clock64();
-            if constexpr (!(ABL & 8))
             __builtin_amdgcn_s_barrier();  // ... for every wave, and nobody reads this stage any more (step 3's fragments are in registers)
-            if constexpr (ABL & 16) tr_wait += clock64() - tw;
-            if constexpr (ABL & 128) p3 = clock64();
-            if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(2);
-            if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(3);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- step 3: the next k-tile's first fragments (the other stage) behind the first MFMA, the DMA pieces of k-tile kt + 2 spread
-            //      over the rest (back to back they queue in the CU's one texture-address path)
-            mfma_step(f1, true);
+            // ---- step 3: the next k-tile's first fragments (the other stage) behind the first MFMA, the DMA pieces of the k-tile two ahead
+            //      spread over the rest (back to back they queue in the CU's one texture-address path)
+            mfma_step(f1, true, NZ{});
             __builtin_amdgcn_sched_barrier(0);
-            read_step(stage ^ 1, 0, f0);  // behind the tile's last k-tile: the next tile's k-tile 0 (requested again at its start)
+            read_step(SN{}, T0{}, f0);  // behind the tile's last k-tile: the next tile's k-tile 0 (requested again at its start)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 2)) issue(stage);
-            mfma_step(f1, false);
+            if constexpr (!(ABL & 2)) {
+#pragma unroll
+                for (int q = 0; q < NDMA; ++q) issue_piece(KQ & 1, q);
+            }
+            mfma_step(f1, false, NZ{});
 #pragma unroll
             for (int q = 0; q < ((ABL & 2) ? 0 : NDMA); ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -293,28 +327,24 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - ((ABL & 2) ? 0 : 2 * NDMA), 0);
             __builtin_amdgcn_sched_barrier(0);
-            stage ^= 1;
-            if constexpr (ABL & 128) p4 = clock64();
-            // ---- two-level sum (gemm_nt_f32_kernel's): after every FOLD k-tiles and behind the last one, outer += acc in a fixed order
-            if (!(ABL & 1) && ((kt & (FOLD - 1)) == FOLD - 1 || kt == nk - 1)) {
+            if (issue_advance()) conv_taps();
+        };
+        for (int kq = 0; kq < nq; ++kq) {
+            ktile(T0{}, kq == 0 && prev_fast);
+            ktile(T1{}, false);
+            if (kq == nq - 1 && has_next) setup_dma(next);  // from the tile's last-but-one k-tile on the stream fetches the next tile
+            ktile(T2{}, false);
+            ktile(T3{}, false);
+            // ---- two-level sum (gemm_nt_f32_kernel's): outer += acc after every 128 values of k, in a fixed order
+            if constexpr (!(ABL & 1)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            outer[i][j][r] += acc[i][j][r];
-                            acc[i][j][r] = 0.f;
-                        }
+                        for (int r = 0; r < 16; ++r) outer[i][j][r] += acc[i][j][r];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL & 128) {
-                asm volatile("" : "+v"(acc[0][0]));
-                const unsigned long long p5 = clock64();
-                ph[0] += p1 - p0; ph[1] += p2 - p1; ph[2] += p3 - p2; ph[3] += p4 - p3; ph[4] += p5 - p4;
-            }
-            if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);
-            if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(2);
         }
         land(f0);  // the surplus request of the last k-tile (the next tile's first fragments are requested again above)
         if constexpr (ABL & 1) {
@@ -324,17 +354,13 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
                 for (int j = 0; j < TN; ++j) outer[i][j] = acc[i][j];
         }
         unsigned long long te = 0;
-        if constexpr (ABL & (16 | 128)) { te = clock64(); tr_loop += te - tr_t; ++tr_n; }
+        if constexpr (ABL & 16) { te = clock64(); tr_loop += te - tr_t; ++tr_n; }
         auto trace_end = [&]() {
-            if constexpr (ABL & (16 | 128)) {
+            if constexpr (ABL & 16) {
                 tr_epi += clock64() - te;
                 if (tile + (int)gridDim.x >= total && a.trace && lane == 0) {
                     unsigned long long* rec = a.trace + ((long long)blockIdx.x * NWAVE + wave) * 4;
-                    rec[0] = tr_loop; rec[1] = tr_wait; rec[2] = tr_epi; rec[3] = tr_n;
-                    if constexpr (ABL & 128) {
-                        unsigned long long* r2 = a.trace + 256 * 8 * 4 + ((long long)blockIdx.x * NWAVE + wave) * 8;
-                        for (int e = 0; e < 5; ++e) r2[e] = ph[e];
-                    }
+                    rec[0] = tr_loop; rec[1] = 0; rec[2] = tr_epi; rec[3] = tr_n;
                 }
             }
         };
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
             continue;
         }
 
-        // ---- epilogue: four 16-row strips per wave tile through this wave's private LDS strip (above the stages), 16-byte row stores
+        // ---- epilogue: four 16-row strips per wave tile through this wave's private LDS strip (above the stages), 16-byte row pieces
         const GemmProblem pr = a.p[z];
         const float osc = pr.scale_dev ? *pr.scale_dev : 1.f;
         float* strip = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave * (STRIP_ROWS * 64);
@@ -363,8 +389,6 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
             bv.z = n + 2 < a.N ? pr.bias[n + 2] : 0.f;
             bv.w = n + 3 < a.N ? pr.bias[n + 3] : 0.f;
         }
-        const bool interior = m0 + GBM <= a.M && n0 + GBN <= a.N && (a.ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
-        prev_fast = interior;
         // rows of a 32x32 accumulator block held by this lane: (r & 3) + 8 * (r >> 2) + 4 * fh; r = hf * 8 .. hf * 8 + 7 are strip rows
         // (q & 3) + 8 * (q >> 2) + 4 * fh.  Bit 2 of the strip row (= fh) flips the column's bit 5 so the two half waves write different banks.
         auto to_strip = [&](int i, int hf) {
@@ -380,16 +404,25 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
-        if (interior) {
+        // Fast path: every column of the tile in range and 16-byte rows.  Loads and stores are buffer accesses - descriptor of the tile
+        // (rows past M fall outside it: loads return zeros, stores are dropped), a per-lane offset that never changes, the row as a scalar offset.
+        const bool fast = n0 + GBN <= a.N && (a.ldc & 3) == 0 && (RMODE != 1 || (a.ldr & 3) == 0);
+        prev_fast = fast;
+        if (fast) {
+            const int rows = min(GBM, a.M - m0);
+            const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(pr.C + (long long)m0 * a.ldc + n0, 0, rows * a.ldc * 4, 0x00020000);
+            const unsigned vo_c = (unsigned)((rsub * a.ldc + wc * 64 + c4 * 4) * 4);
             // vmcnt is one in-order counter for loads and stores: a residual load issued between stores would wait for the acknowledgement of
             // every store before it, so the tile's residual values are requested first, back to back (64 registers; the fragments are dead)
             f32x4 rbuf[RMODE ? TM * 2 * 4 : 1];
             if (RMODE) {
+                const __amdgpu_buffer_rsrc_t rs_r =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.R) + (long long)m0 * a.ldr + n0, 0, rows * a.ldr * 4, 0x00020000);
+                const unsigned vo_r = (unsigned)((rsub * a.ldr + wc * 64 + c4 * 4) * 4);
 #pragma unroll
                 for (int sp = 0; sp < TM * 2 * 4; ++sp) {
                     const int st = sp >> 2, pass = sp & 3;
-                    const int m = m0 + wr * (TM * 32) + st * 16 + pass * 4 + rsub;
-                    rbuf[sp] = *reinterpret_cast<const f32x4*>(pr.R + (long long)m * a.ldr + n);
+                    rbuf[sp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo_r, (wr * (TM * 32) + st * 16 + pass * 4) * a.ldr * 4, 0));
                 }
             }
 #pragma unroll
@@ -398,15 +431,16 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int row = pass * 4 + rsub;
-                    const int m = m0 + wr * (TM * 32) + st * 16 + row;
                     const float4 t = *reinterpret_cast<const float4*>(&strip[row * 64 + ((c4 ^ ((pass & 1) << 3)) << 2)]);
-                    float v[4] = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
+                    f32x4 v = {t.x * osc + bv.x, t.y * osc + bv.y, t.z * osc + bv.z, t.w * osc + bv.w};
                     if (RMODE) {
                         const f32x4 rv = rbuf[st * 4 + pass];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rv[e];
                     }
-                    *reinterpret_cast<float4*>(pr.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    // (the row goes into the per-lane offset, not the scalar one: with a register in the scalar-offset field the hazard recogniser
+                    // assumes a store's data registers may be rewritten at once - on gfx950 that lost parts of 16-byte stores, round 5)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, vo_c + (unsigned)((wr * (TM * 32) + st * 16 + pass * 4) * a.ldc * 4), 0, 0);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -447,6 +481,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
         }
         trace_end();
     }
+#undef F32P_RD
 }
 
 template <bool CONV, int RMODE, int ABL = 0>
@@ -483,7 +518,7 @@ void sola_gemm_set_f32_persist(int v) { g_gemm_f32_persist = v; }
 // Shapes the persistent kernel takes: plain rows or the conv window gather (not the transposed-conv gather), 16-byte rows, whole k-tiles,
 // and a grid whose rounds of one 256x128 tile per CU are at least as full as the 128x128 kernel's rounds of two blocks per CU.
 bool gemm_f32_persist_applies(const GemmDesc& d) {
-    if (!g_gemm_f32_persist || d.arith != 0 || d.conv > 1 || d.K % PBK != 0 || d.K / PBK < 2) return false;
+    if (!g_gemm_f32_persist || d.arith != 0 || d.conv > 1 || d.K % (4 * PBK) != 0) return false;  // whole groups of four k-tiles
     if (d.conv == 1 ? (d.Cin % PBK != 0 || d.K % d.Cin != 0 || d.K / d.Cin > 8) : d.lda % 4 != 0) return false;
     for (int j = 0; j < d.nprob; ++j) {
         if ((reinterpret_cast<uintptr_t>(d.p[j].A) | reinterpret_cast<uintptr_t>(d.p[j].W) | reinterpret_cast<uintptr_t>(d.p[j].C) | reinterpret_cast<uintptr_t>(d.p[j].R)) & 15) return false;
@@ -493,11 +528,12 @@ bool gemm_f32_persist_applies(const GemmDesc& d) {
     const long long tiles = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) * d.nprob;
     if (tiles < cus) return false;
     const long long rounds = (tiles + cus - 1) / cus;
-    // time estimates in units of one 128x128 tile on a quarter of a CU... persistent: rounds of 256x128 tiles at ~0.92 of the pipe;
-    // one-tile kernel: rounds of 2 * cus 128x128 tiles at ~0.75
+    // Rounds of one 256x128 tile per CU at ~0.92 of the pipe against the one-tile kernel's 128x128 blocks, two per CU, at ~0.75: its
+    // blocks are dispatched as others finish, so a partial last round costs it about its share (+ a quarter round of imbalance), while
+    // the persistent kernel pays a whole round (12288 x 1024 x 1024 = 1.5 rounds: 234 us here, 230 us there; from 2 rounds on it wins)
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
-    const long long rounds128 = (t128 + 2 * cus - 1) / (2 * cus);
-    return (double)rounds * 2.0 / 0.92 <= (double)rounds128 * 2.0 / 0.75;
+    const double one_tile = ((double)t128 / (2.0 * cus) + (t128 % (2 * cus) ? 0.25 : 0.0)) / 0.75;
+    return (double)rounds / 0.92 <= one_tile;
 }
 
 int launch_gemm_f32_persist(const GemmDesc& d, hipStream_t s) {
@@ -520,17 +556,8 @@ int launch_gemm_f32_persist(const GemmDesc& d, hipStream_t s) {
             case 1: return res ? launch_f32p_t<false, 1, 1>(a, s) : launch_f32p_t<false, 0, 1>(a, s);
             case 2: return res ? launch_f32p_t<false, 1, 2>(a, s) : launch_f32p_t<false, 0, 2>(a, s);
             case 4: return res ? launch_f32p_t<false, 1, 4>(a, s) : launch_f32p_t<false, 0, 4>(a, s);
-            case 8: return res ? launch_f32p_t<false, 1, 8>(a, s) : launch_f32p_t<false, 0, 8>(a, s);
-            case 32: return res ? launch_f32p_t<false, 1, 32>(a, s) : launch_f32p_t<false, 0, 32>(a, s);
-            case 64: return res ? launch_f32p_t<false, 1, 64>(a, s) : launch_f32p_t<false, 0, 64>(a, s);
-            case 48: return res ? launch_f32p_t<false, 1, 48>(a, s) : launch_f32p_t<false, 0, 48>(a, s);
-            case 36: return res ? launch_f32p_t<false, 1, 36>(a, s) : launch_f32p_t<false, 0, 36>(a, s);
-            case 128: return res ? launch_f32p_t<false, 1, 128>(a, s) : launch_f32p_t<false, 0, 128>(a, s);
-            case 192: return res ? launch_f32p_t<false, 1, 192>(a, s) : launch_f32p_t<false, 0, 192>(a, s);
-            case 160: return res ? launch_f32p_t<false, 1, 160>(a, s) : launch_f32p_t<false, 0, 160>(a, s);
             case 16: return res ? launch_f32p_t<false, 1, 16>(a, s) : launch_f32p_t<false, 0, 16>(a, s);
             case 7: return res ? launch_f32p_t<false, 1, 7>(a, s) : launch_f32p_t<false, 0, 7>(a, s);
-            case 15: return res ? launch_f32p_t<false, 1, 15>(a, s) : launch_f32p_t<false, 0, 15>(a, s);
             default: break;
         }
     }
