@@ -643,6 +643,53 @@ def row_errors(got, ref, counts):
             "selections_equal": bool(np.array_equal(got > 0, ref > 0))}
 
 
+def call_pattern_leg(cfg, sd, dev, steps):
+    """The reference's own call pattern (inference.py:58, evaluator.py:100: ONE sample per call) and the uniform BASELINE shapes besides
+    the headline one (C0 (T=8, N=8), C1 (T=32, N=16) and (T=32, N=80)), each in both arithmetic modes.  S=1: wall time per call
+    incl. the host side (forward + selection, the output left on the device).  Uniform shapes: samples/s at a batch of ~16 K layer tokens."""
+    from sola_amd import ops, synth
+    from sola_amd.module import LanguageAlignedTrackSelectionModule
+
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    m.ws_policy = "always"
+    sync = lambda: torch.cuda.synchronize(dev)
+    out = {"one_sample_per_call_ms": {}, "uniform": {}}
+    for tag, (N, T, L) in (("NS_N64_T32", (64, 32, 16)), ("N44_T110", (44, 110, 16))):
+        inp = synth.make_inputs(cfg, 1, N, T, L, seed=5)
+        obj, lang = torch.from_numpy(inp["object_tokens"]).to(dev), torch.from_numpy(inp["lang_tokens"]).to(dev)
+        rec = {}
+        for prec in ("f16x3", "f32"):
+            m.precision = prec
+
+            def call():
+                with torch.no_grad():
+                    sm, _ = m(obj, lang)
+                    ops.select(sm, 0.5)
+
+            rec[prec] = round(1e3 * timed(call, 50, sync, warmup=5), 4)
+        out["one_sample_per_call_ms"][tag] = rec
+    for tag, (N, T, B) in (("C0_T8_N8", (8, 8, 2048)), ("C1_T32_N16", (16, 32, 1024)), ("C1_T32_N80", (80, 32, 192))):
+        inp = synth.make_inputs(cfg, B, N, T, 16, seed=6)
+        obj, lang = torch.from_numpy(inp["object_tokens"]).to(dev), torch.from_numpy(inp["lang_tokens"]).to(dev)
+        rec = {"samples": B}
+        for prec in ("f16x3", "f32"):
+            m.precision = prec
+
+            def step():
+                with torch.no_grad():
+                    sm, _ = m(obj, lang)
+                    ops.select(sm, 0.5)
+
+            rec[prec] = round(B / timed(step, max(3, steps), sync, warmup=2), 1)
+        out["uniform"][tag] = rec
+        del obj, lang
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def iou_leg(dev, cpu_seconds):
     """The mask-IoU de-dup predicate (seg_utils.py:128-142 through generate_tokens_grid.py:266-278) at its real call sizes:
     P=4 new-track masks against R prompt masks at 540x960 uint8.  Algorithmic bytes = (P+R)*H*W (every mask read once)."""
@@ -700,12 +747,16 @@ def iou_leg(dev, cpu_seconds):
 # builds - is written next to it as gpurun_out/bench_full.json (or $SOLA_BENCH_FULL).
 _DROP = {"what", "tolerance", "shapes", "traffic_source", "traffic_kernel", "kernel_ms_per_step_source", "frac_algorithmic",
          "algorithmic_vs_f32_mfma_peak", "gflop_per_sample_reference", "object_token_rows", "launches_per_call", "algorithmic_bytes",
-         "physical_cores", "logical_cpus", "seed", "thread_sweep", "videos", "pairs", "gflop_per_sample_fwd_bwd", "model_tflops_reference",
+         "logical_cpus", "seed", "thread_sweep", "videos", "pairs", "gflop_per_sample_fwd_bwd", "model_tflops_reference",
          "executed_vs_uniform_batch_model_tflops", "pairs_per_s", "workload"}
 _DROP_NESTED = {"model_tflops", "gflop_per_sample", "achieved", "avg_launch_us", "launches", "share_of_step_time", "steps", "dtype"}  # below the top level and its two rooflines
 _KEEP_KERNEL_MS = {("kernel_ms_per_step",), ("training_step", "ragged", "f16x3", "kernel_ms_per_step"),
                    ("training_step", "ragged", "f16", "kernel_ms_per_step"), ("training_step", "f16x3", "kernel_ms_per_step")}
 _CONTRACT_ROOFLINES = {("roofline",), ("roofline_attention",)}
+_OPTIONAL = [("iou", "cpu_baseline", "sample"), ("training_step", "ragged", "f16", "kernel_ms_per_step"), ("training_step", "f16x3", "kernel_ms_per_step"),
+             ("f16_storage_mode", "ragged_four_expressions_per_video"), ("training_step", "ragged", "samples_per_step_128"),
+             ("training_step", "ragged", "f16x3", "kernel_ms_per_step"), ("stress_T128_N128", "kernel_ms_per_step"), ("iou", "cpu_baseline"),
+             ("f16_storage_mode", "C4_T128_N128", "roofline"), ("f16_storage_mode", "NS_T32_N64", "roofline")]
 _SHORT = {"max_abs_logit_err_vs_oracle": "max", "mean_row_max_err": "mean", "rows_above_5e-4": "gt5e-4", "samples_above_5e-4": "gt5e-4",
           "mean_sample_max": "mean", "selections_equal": "sel_eq", "max_abs_logit_diff_vs_f32_mode": "max_diff_f32",
           "rms_logit_diff_vs_f32_mode": "rms_diff_f32", "calls_repeated_in_f32": "f32_repeats", "max_abs_logit_diff_vs_split_mode": "max_diff_split",
@@ -766,7 +817,17 @@ def emit(out):
             json.dump(out, f, indent=1)
     except OSError:
         pass
-    print(json.dumps(compact(out), separators=(",", ":")), flush=True)
+    line = compact(out)
+    # the driver keeps a bounded tail of stdout: stay under 6 KB by dropping, in this order, what the verbose file keeps anyway
+    for path in _OPTIONAL:
+        if len(json.dumps(line, separators=(",", ":"))) <= 6000:
+            break
+        node = line
+        for key in path[:-1]:
+            node = node.get(key, {}) if isinstance(node, dict) else {}
+        if isinstance(node, dict):
+            node.pop(path[-1], None)
+    print(json.dumps(line, separators=(",", ":")), flush=True)
 
 
 def main():
@@ -941,7 +1002,8 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * step_s, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (hi+lo f16 operand pairs, 3 f16 MFMAs per product, f32 accumulate)",
+            "dtype": "f32" if args.precision == "f32" or B * N * T <= 4096 and not any(t.startswith("infer_f32_rows") for t in args.tune)
+                     else "f32 via split-f16 (hi+lo f16 operand pairs, 3 f16 MFMAs per product, f32 accumulate)",
             "config": {"workload": f"SOLA track selection forward+BCE+alignment loss+selection, T={T} N={N} d=256 L={L}, mevis/default model "
                                    f"(32.98M params, random init), {B} samples/step/GPU, "
                                    + ("conv weights standardised once" if args.cached_ws else "conv weights re-standardised every step"),
@@ -970,6 +1032,7 @@ def main():
             out["ragged"] = ragged_leg(cfg, m, dev, k, out["model_tflops"], tsd_par)
             out["iou"] = iou_leg(dev, args.cpu_seconds)
             out["f16_storage_mode"] = f16_storage_leg(cfg, m, dev, k)
+            out["call_pattern"] = call_pattern_leg(cfg, sd, dev, k)
         if dist_res is not None:
             out["training_step_dist"] = dist_res
         if world == 1 and args.train_steps > 0:

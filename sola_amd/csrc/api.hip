@@ -271,6 +271,7 @@ void sola_gemm_set_small_rows(int v);
 void sola_gemm_set_small_nw8(int v);
 void sola_gemm_set_f32_nw8(int v);
 void sola_gemm_set_f32_persist(int v);
+void sola_gemm_tn_set_persist(int v);
 #ifdef SOLA_EXPERIMENTS
 extern int g_gemm_f32p_ablate;
 #endif
@@ -344,6 +345,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_f32p_ablate")) { g_gemm_f32p_ablate = value; return SOLA_OK; }
 #endif
     if (!strcmp(key, "gemm_tn_nw8")) { sola_gemm_tn_set_nw8(value); return SOLA_OK; }
+    if (!strcmp(key, "gemm_tn_persist")) { sola_gemm_tn_set_persist(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }
     if (!strcmp(key, "train_split_min_rows")) { sola_set_train_split_min_rows(value); return SOLA_OK; }
@@ -516,6 +518,16 @@ static bool split_known_out_of_range(const SolaCtx* c) { return c->precision == 
 // than the split-f16 pass - whose casts, guard read-back (a stream synchronisation per call) and 64x64 split-K GEMMs are fixed costs
 // - and exact: one sample of the headline shape 0.61 -> 0.45 ms per call (tools/infer_one_probe.py).  0 = never.
 int g_infer_f32_rows = 4096;
+// a temporary switch of the ctx's arithmetic for one call: restored on every exit, exceptions included (a throwing plan left the
+// ctx on the exact-f32 kernels for good, silently)
+struct PrecScope {
+    SolaCtx* c;
+    int saved;
+    PrecScope(SolaCtx* ctx, int p) : c(ctx), saved(ctx->precision) { c->precision = p; }
+    ~PrecScope() { c->precision = saved; }
+    PrecScope(const PrecScope&) = delete;
+    PrecScope& operator=(const PrecScope&) = delete;
+};
 static bool few_rows_f32(const SolaCtx* c, long long rows0) { return c->precision == 1 && g_infer_f32_rows > 0 && rows0 <= g_infer_f32_rows; }
 
 extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
@@ -523,17 +535,13 @@ extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int
     hipStream_t s = as_stream(stream_);
     SOLA_ARG(!c || c->precision != 3, "forward: precision 3 (bf16 GEMM operands) is a TRAINING mode; inference runs precision 0, 1 or 2");
     if (c && B > 0 && N > 0 && T > 0 && few_rows_f32(c, (long long)B * N * T)) {
-        c->precision = 0;
-        const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
-        c->precision = 1;
-        return st;
+        PrecScope f32(c, 0);
+        return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
     }
     if (c && split_known_out_of_range(c)) {
         c->split_fallbacks += 1;
-        c->precision = 0;
-        const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
-        c->precision = 1;
-        return st;
+        PrecScope f32(c, 0);
+        return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
     }
     if (c && c->precision >= 1) {
         const int prec = c->precision;
@@ -545,10 +553,8 @@ extern "C" int sola_forward(SolaCtx* c, const float* obj, const float* lang, int
         // a value left the range the split-f16 pairs cover (or the weights say it would): same call, exact-f32 kernels.
         // The f32 plan is a subset of the split plan, so the workspace fits.
         c->split_fallbacks += 1;
-        c->precision = 0;
-        const int st = sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
-        c->precision = prec;
-        return st;
+        PrecScope f32(c, 0);
+        return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
     }
     return sola_forward_impl(c, obj, lang, B, N, T, L, score_map, score_tokens, workspace, ws_bytes, s, false);
 }
@@ -575,18 +581,14 @@ extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* la
             long long rows0 = 0;
             for (int v = 0; v < batch->n_videos; ++v) rows0 += (long long)batch->video_tracks[v] * batch->video_frames[v];
             if (few_rows_f32(c, rows0)) {  // see g_infer_f32_rows
-                c->precision = 0;
-                const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
-                c->precision = 1;
-                return st;
+                PrecScope f32(c, 0);
+                return sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
             }
         }
         if (c && split_known_out_of_range(c)) {
             c->split_fallbacks += 1;
-            c->precision = 0;
-            const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
-            c->precision = 1;
-            return st;
+            PrecScope f32(c, 0);
+            return sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
         }
         SOLA_TRY(sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s));
         if (c->precision < 1) return SOLA_OK;
@@ -594,11 +596,8 @@ extern "C" int sola_forward_ragged(SolaCtx* c, const float* obj, const float* la
         SOLA_TRY(sola_split_guard_tripped(c, s, &tripped));
         if (!tripped) return SOLA_OK;
         c->split_fallbacks += 1;
-        const int prec = c->precision;
-        c->precision = 0;
-        const int st = sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
-        c->precision = prec;
-        return st;
+        PrecScope f32(c, 0);
+        return sola_forward_ragged_impl(c, obj, lang, batch, score_map, score_tokens, workspace, ws_bytes, s);
     } catch (const std::exception& e) {
         sola_set_error("forward_ragged: %s", e.what());
         return SOLA_ERR_ARG;

@@ -550,6 +550,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
         const float4 bf0 = *reinterpret_cast<const float4*>(Wb), bf1 = *reinterpret_cast<const float4*>(Wb + 8);
         const float4 bf2 = *reinterpret_cast<const float4*>(Wb + 16), bf3 = *reinterpret_cast<const float4*>(Wb + 24);
         if (kt + 1 < nk) SM_STORE(buf ^ 1);          // the registers hold step kt + 1
+        // the stage written here is read by other lanes of THIS wave in the next iteration: pin the order (a wave's DS operations execute in
+        // order; this keeps the compiler from ever moving the next iteration's fragment reads above these writes - no instruction is emitted)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (kt + 2 < nk) SM_LOAD((kt + 2) * 32);
 #define SM_MFMA4(af, bf)                                                          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);         \
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
 
 int g_gemm_small_rows = 2048;  // sola_tune "gemm_small_rows": exact-f32 GEMMs of at most this many rows take the 32x32 in-block split-K shape (0 = never)
 static bool gemm_small_applies(const GemmDesc& d) {
+    if (d.r_sp16 || d.c_sp16 || d.gn_gamma) return false;  // the kernel reads R and writes C as plain f32 rows, no fused norm
     if (d.arith != 0 || d.conv > 1 || d.M > g_gemm_small_rows || d.N % 32 != 0 || d.K % 128 != 0 || d.ldc % 4 != 0) return false;
     if (d.conv ? (d.Cin % 32 != 0 || d.K % d.Cin != 0 || d.K / d.Cin > 8 || (!d.rowmap && (d.T_out <= 0 || d.T_in <= 0))) : d.lda % 4 != 0) return false;
     for (int j = 0; j < d.nprob; ++j) {

@@ -121,7 +121,10 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
     auto conv_taps = [&]() {  // CONV: the per-lane offsets at tap conv_kk (a vector select per piece, when the tap changes)
         if constexpr (CONV) {
 #pragma unroll
-            for (int q = 0; q < APW; ++q) c_eff[q] = ((a_t0[q] >> conv_kk) & 1) ? c_vo[q] : OOB;
+            for (int q = 0; q < APW; ++q) {
+                c_eff[q] = ((a_t0[q] >> conv_kk) & 1) ? c_vo[q] : OOB;
+                asm volatile("" : "+v"(c_eff[q]));  // computed HERE, once per tap (left alone the compiler re-derives the select at every k-tile's DMA)
+            }
         }
     };
     auto setup_dma = [&](int tile) {
@@ -327,7 +330,10 @@ __global__ __launch_bounds__(512) void gemm_nt_f32_persist_kernel(const F32pArgs
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - ((ABL & 2) ? 0 : 2 * NDMA), 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (issue_advance()) conv_taps();
+            if (issue_advance()) {  // (a real branch: speculated, the selects would sit in every k-tile)
+                asm volatile("" ::: "memory");
+                conv_taps();
+            }
         };
         for (int kq = 0; kq < nq; ++kq) {
             ktile(T0{}, kq == 0 && prev_fast);

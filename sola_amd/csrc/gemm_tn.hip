@@ -369,10 +369,18 @@ static int tn_splits(int M, int N, int K) {
     return splits;
 }
 
+int gemm_tn_persist_plan(int M, int N, int K);  // gemm_tn_f32p.hip
+size_t colsum_scratch_bytes(int segments, int seg_rows, int cols);
 size_t gemm_tn_scratch_bytes(int M, int N, int K) {
     const int splits = tn_splits(M, N, K);
-    return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
+    const size_t one_tile = (size_t)splits * ((size_t)N * K + N) * sizeof(float);
+    const int ps = gemm_tn_persist_plan(M, N, K);  // the persistent kernel's partial sums + the bias gradient's column-sum pass behind them
+    const size_t persist = ps > 0 ? (size_t)ps * N * K * sizeof(float) + colsum_scratch_bytes(1, M, N) : 0;
+    return std::max(one_tile, persist);
 }
+
+int gemm_tn_persist_splits(const GemmTnDesc& d, int max_splits);  // gemm_tn_f32p.hip: the persistent direct-to-LDS form (0 = not its shape)
+int launch_gemm_tn_f32_persist(const GemmTnDesc& d, int splits, float* P, int* splits_out, hipStream_t s);
 
 int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
     SOLA_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.N % 4 == 0 && d.K % 4 == 0, "gemm_tn: bad dims M=%d N=%d K=%d", d.M, d.N, d.K);
@@ -390,6 +398,32 @@ int launch_gemm_tn(const GemmTnDesc& d, hipStream_t s) {
         return SOLA_ERR_WORKSPACE;
     }
     const int splits = tn_splits(d.M, d.N, d.K);
+    // round 5: the persistent kernel where the shape is its own (N % 256, K % 128, a grid that fills whole rounds).  Its partial sums stay
+    // inside the scratch sized for `splits`; the bias gradient (column sums of dY) is a pass of its own there - launch_colsum in the
+    // slab a split less leaves free (the one-tile kernel sums the rows it stages, in registers: vector adds the f32 MFMA cannot hide)
+    {
+        const size_t cs_need = d.bias_grad ? colsum_scratch_bytes(1, d.M, d.N) : 0;
+        const int room = (int)std::min<size_t>(64, (d.scratch_bytes - std::min(d.scratch_bytes, cs_need)) / ((size_t)d.N * d.K * sizeof(float)));
+        const int ps = room >= 1 ? gemm_tn_persist_splits(d, room) : 0;
+        if (ps > 0) {
+            int used = 0;
+            {
+                SolaProfScope prof(SOLA_PROF_GEMM_TN, s, 2.0 * d.M * d.N * (double)d.K, 4.0 * ((double)d.M * (d.N + d.K) + (double)ps * d.N * d.K));
+                SOLA_TRY(launch_gemm_tn_f32_persist(d, ps, d.scratch, &used, s));
+            }
+            const long long n4 = (long long)d.N * d.K / 4;
+            {
+                SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (used + 1.0) * d.N * d.K);
+                hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d.scratch, d.C, n4, used);
+                SOLA_LAUNCH_CHECK();
+            }
+            if (d.bias_grad) {
+                float* cs = d.scratch + (size_t)used * d.N * d.K;
+                SOLA_TRY(launch_colsum(d.A, d.bias_grad, 1, d.M, d.N, d.lda, 1.0f, 0, cs, d.scratch_bytes - (size_t)used * d.N * d.K * sizeof(float), s));
+            }
+            return SOLA_OK;
+        }
+    }
     if (d.bias_grad) a.Pb = d.scratch + (size_t)splits * d.N * d.K;
     int mps = (d.M + splits - 1) / splits;
     mps = (mps + TM - 1) / TM * TM;

@@ -26,11 +26,13 @@ def split_kernels_at_every_size():
     faster there, and exact (sola_tune "infer_f32_rows").  The parity tests of the split-f16 path use small shapes on purpose; they keep
     testing the split kernels (0 = no routing).  tests/test_gpu_fast.py::test_few_row_calls_of_the_default_mode_run_exact_f32 covers the
     routing itself; entry-point tests (subprocesses) run the real default."""
+    from sola_amd import _lib
     try:
-        from sola_amd import _lib
-        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 0), "tune")
-    except Exception:
-        pass
+        handle = _lib.lib()
+    except _lib.SolaLibraryError:
+        handle = None  # CPU box without a built library: the -m "not gpu" tests that need it say so themselves
+    if handle is not None:
+        _lib.check(handle.sola_tune(b"infer_f32_rows", 0), "tune infer_f32_rows")  # a rejected key is an error, not something to swallow
     yield
 
 

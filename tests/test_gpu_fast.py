@@ -115,6 +115,29 @@ def test_few_row_calls_of_the_default_mode_run_exact_f32(full_fast, full_f32):
 
 
 @pytest.mark.parametrize("ci", range(5))
+def test_full_cases_vs_golden_in_the_shipped_routing(full_golden, full_fast, ci):
+    """the golden cases through the PRODUCTION configuration of the default mode - sola_tune "infer_f32_rows" at its shipped
+    4096 (conftest.py switches it off for the other tests), so the few-row cases take the exact-f32 route inside the "f16x3" module and the
+    larger ones the split-f16 pass - against the reference's outputs, not against another module of this library."""
+    from sola_amd import _lib
+    m, _ = full_fast
+    cfg = synth.DEFAULT_MODEL_CFG
+    B, N, T, L = [int(v) for v in full_golden["cases"][ci]]
+    g = case_dict(full_golden, ci)
+    try:
+        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 4096), "tune")
+        _, sm, st, loss3, argmax = run(m, cfg, B, N, T, L, 200 + ci)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"infer_f32_rows", 0), "tune")
+    assert np.abs(sm.cpu().numpy() - g["score_map"]).max() <= 1e-3
+    assert np.abs(st.cpu().numpy() - g["score_tokens"]).max() <= 1e-3
+    np.testing.assert_allclose(loss3.cpu().numpy().astype(np.float64), g["loss"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_array_equal((torch.sigmoid(sm) > 0.5).float().cpu().numpy(), g["selected"])
+    np.testing.assert_array_equal(sm.argmax(dim=1).cpu().numpy(), g["argmax_track"])
+    np.testing.assert_array_equal(argmax.cpu().numpy(), g["neg_argmax"])
+
+
+@pytest.mark.parametrize("ci", range(5))
 def test_full_cases_vs_golden_in_split_mode(full_golden, full_fast, ci):
     m, _ = full_fast
     cfg = synth.DEFAULT_MODEL_CFG

@@ -75,6 +75,77 @@ def test_gemm_nt_few_rows_shape(M, N, K):
     assert rel < 2e-6, rel
 
 
+@pytest.mark.parametrize("M,N,K,has_res", [(65536, 1024, 1024, True), (65536, 512, 768, False), (40930, 1024, 1024, True), (33000, 520, 256, True),
+                                           (66000, 1000, 384, False), (24577, 1024, 3072, True)])
+def test_gemm_nt_persistent_f32_kernel(M, N, K, has_res):
+    """Round 5 (gemm_f32p.hip): exact-f32 GEMMs that fill whole rounds of one 256 x 128 tile per CU take the persistent direct-to-LDS kernel -
+    buffer-load DMA with scalar offsets, no vector arithmetic in the k-loop.  Same products in the same order as the 128 x 128 one-tile
+    kernel (sola_tune "gemm_f32_persist" 0): BIT-identical, interior and edge tiles (rows past M, columns past N), with bias and residual;
+    against float64 on sampled rows; twice the same bits."""
+    from sola_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g); r = torch.randn(M, N, device="cuda", generator=g) if has_res else None
+    got = ops.gemm_nt(a, w, b, r)
+    assert torch.equal(got, ops.gemm_nt(a, w, b, r))
+    try:
+        _lib.check(_lib.lib().sola_tune(b"gemm_f32_persist", 0), "tune")
+        old = ops.gemm_nt(a, w, b, r)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"gemm_f32_persist", 1), "tune")
+    assert torch.equal(got, old)
+    rows = torch.tensor([0, 1, 255, 256, M // 2, M - 257, M - 2, M - 1], device="cuda")
+    ref = a[rows].double() @ w.double().t() + b.double() + (r[rows].double() if has_res else 0.0)
+    assert_close(got[rows], ref.cpu().numpy(), name=f"persistent gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("R,T,cin,cout,k,s,p", [(4096, 32, 256, 512, 3, 2, 1), (16384, 4, 512, 1024, 3, 1, 1), (8192, 8, 1024, 1024, 1, 1, 0), (3001, 33, 256, 512, 3, 2, 1)])
+def test_conv1d_cl_persistent_f32_kernel(R, T, cin, cout, k, s, p):
+    """The persistent kernel's conv rows (window start from the geometry, taps outside the sequence as out-of-range offsets that come back as
+    zeros): bit-identical to the one-tile kernel's gather, and against the float64 oracle on the first sequences."""
+    from sola_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(R + T + cin)
+    x = torch.randn(R, T, cin, device="cuda", generator=g); wk = torch.randn(cout, k * cin, device="cuda", generator=g) * 0.05
+    b = torch.randn(cout, device="cuda", generator=g)
+    got = ops.conv1d_cl(x, wk, b, k, s, p)
+    try:
+        _lib.check(_lib.lib().sola_tune(b"gemm_f32_persist", 0), "tune")
+        old = ops.conv1d_cl(x, wk, b, k, s, p)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"gemm_f32_persist", 1), "tune")
+    assert torch.equal(got, old)
+    w3 = wk[:, :].reshape(cout, k, cin).permute(0, 2, 1).contiguous()
+    ref = sola_oracle.conv1d_cl(x[:4].double().cpu(), w3.double().cpu(), b.double().cpu(), s, p)
+    assert_close(got[:4], ref.numpy(), name="persistent conv")
+
+
+@pytest.mark.parametrize("M,N,K,wb", [(65536, 1024, 1024, True), (40930, 1024, 1024, True), (30001, 1024, 3072, False), (16384, 512, 768, True)])
+def test_gemm_tn_persistent_f32_kernel(M, N, K, wb):
+    """Round 5 (gemm_tn_f32p.hip): the exact-f32 weight gradient dW = dY^T X as a persistent direct-to-LDS kernel over (256 x 128 tile, row
+    split) work items - buffer-load DMA, fragments read across the columns, partial sums folded in split order - with the bias gradient as
+    a column-sum pass of its own.  Against float64 (on 64 output rows) at the one-tile kernel's own distance from it, twice the same bits."""
+    from sola_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, N, device="cuda", generator=g); b = torch.randn(M, K, device="cuda", generator=g)
+    got = ops.gemm_tn(a, b, wb)
+    again = ops.gemm_tn(a, b, wb)
+    dw = got[0] if wb else got
+    assert torch.equal(dw, again[0] if wb else again)
+    try:
+        _lib.check(_lib.lib().sola_tune(b"gemm_tn_persist", 0), "tune")
+        old = ops.gemm_tn(a, b, wb)
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"gemm_tn_persist", 1), "tune")
+    dw_old = old[0] if wb else old
+    ref = (a[:, :64].double().t() @ b.double()).float()
+    e_new, e_old = float((dw[:64] - ref).abs().max()), float((dw_old[:64] - ref).abs().max())
+    assert e_new <= max(2.0 * e_old, 1e-5 * float(ref.abs().max())), (e_new, e_old)
+    assert float((dw - dw_old).abs().max()) <= 4.0 * max(e_new, e_old) + 1e-6
+    if wb:
+        rb = a.double().sum(0).float()
+        assert float((got[1] - rb).abs().max()) <= max(2.0 * float((old[1] - rb).abs().max()), 1e-5 * float(rb.abs().max()))
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric W catches a transposed C write."""
     K = 64

