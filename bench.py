@@ -156,7 +156,8 @@ def gemm_roofline(prof, precision, step_s, steps):
     if g["ms"] <= 0:
         return None
     ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-    return {"kernel": "gemm_nt_f32_kernel<128,128> (v_mfma_f32_32x32x2_f32, exact f32)" if g is prof["gemm128"] else "gemm_nt_f32_kernel<64,64>",
+    return {"kernel": "gemm_nt_f32_persist_kernel (persistent 256x128 tiles, buffer-load DMA to LDS, v_mfma_f32_32x32x2_f32, exact f32; launches whose grid "
+                      "does not fill whole rounds: gemm_nt_f32_kernel<128,128>)" if g is prof["gemm128"] else "gemm_nt_f32_kernel<64,64>",
             "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": g["launches"],
             "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2), "share_of_step_time": round(g["ms"] * 1e-3 / (step_s * steps), 4)}
@@ -978,14 +979,15 @@ def main():
         # HBM traffic cannot be read from inside the run (PMC needs rocprofv3); it is the committed per-launch PMC
         # measurement of this same command line (tools/profile_bench.sh -> profiles/r0X_traffic.json), used only when the
         # batch matches the profiled one, else null
-        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if not os.path.exists(tpath):
                 continue
             tr = json.load(open(tpath))
             if tr.get("batch") == B and (N, T, L) == (64, 32, 16):
                 kk = tr["kernels"]
-                f32k = next((k for k in kk if k.startswith("gemm_nt_f32_kernel<128, 128, 0, 0")), None)  # <..., 8>: eight waves per block since round 4
+                f32k = next((k for k in kk if k.startswith("gemm_nt_f32_persist_kernel<false, 0")), None) or \
+                    next((k for k in kk if k.startswith("gemm_nt_f32_kernel<128, 128, 0, 0")), None)  # (profiles before round 5: the one-tile kernel)
                 gk = tr.get("dominant_gemm") if args.precision == "f16x3" else f32k
                 if roofline and gk in kk:
                     roofline["traffic_kernel"] = gk

@@ -499,6 +499,10 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * "attn_f16_small" 1 (default) = the 16-byte-per-lane GroupNorm and the streaming short-sequence attention of precision 2).
  * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
+/* 1 when the library was built with EXPERIMENTS=1 (make -C sola_amd/csrc EXPERIMENTS=1): the closed experiments' kernels and their
+ * sola_tune keys (gemm_pp, gemm_nw4, gemm_k16, gemm_stagger, gemm_order, gemm_trace, gemm_ld, gemm_gn_fuse, gemm_ablate, attn_bwd_ablate,
+ * attn_reg_minw, attn_res_splitm, gemm_f32p_ablate) exist only there; the default library rejects those keys. */
+int sola_has_experiments(void);
 
 /* Measurement only (no reference counterpart): with sola_tune "gemm_trace" 1 the plain persistent split-f16 GEMM (no conv, no
  * residual, f32 output) runs an instrumented instantiation that records, per (block, wave), the cycles spent at the k-tile wait +

@@ -130,6 +130,7 @@ SIGNATURES = {
     "sola_set_x16_arena": (_i, [_vp, _vp, _sz]),
     "sola_x16_arena_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "sola_tune": (_i, [C.c_char_p, _i]),
+    "sola_has_experiments": (_i, []),
     "sola_gemm_trace_read": (C.c_longlong, [_vp, C.c_longlong]),
     "sola_profile_enable": (_i, [_i]),
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
@@ -172,6 +173,11 @@ def lib():
             raise SolaLibraryError(f"SOLA_TUNE: unknown key {k!r}")
     _lib = h
     return h
+
+
+def has_experiments():
+    """True when the library was built with EXPERIMENTS=1 (closed experiments' kernels and their sola_tune keys compiled in)."""
+    return bool(lib().sola_has_experiments())
 
 
 def check(status, what=""):

@@ -317,18 +317,19 @@ void sola_attn_set_simple_remap(int v);
 void sola_attn_set_simple_db(int v);
 void sola_pack_set_resample_lds(int v);
 static int g_stage_split_math = 0;
+extern "C" int sola_has_experiments(void) {
+#ifdef SOLA_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int sola_tune(const char* key, int value) {
     SOLA_ARG(key, "tune: null key");
     if (!strcmp(key, "attn_stage_split_math")) { g_stage_split_math = value != 0; return SOLA_OK; }
     if (!strcmp(key, "gemm_variant")) { sola_gemm_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
-    if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value; return SOLA_OK; }
-    if (!strcmp(key, "gemm_nw4")) { g_gemm_nw4 = value; return SOLA_OK; }
-    if (!strcmp(key, "gemm_k16")) { g_gemm_k16 = value; return SOLA_OK; }
-    if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return SOLA_OK; }
-    if (!strcmp(key, "gemm_order")) { g_gemm_order = value; return SOLA_OK; }
-    if (!strcmp(key, "gemm_trace")) { g_gemm_trace = value; return SOLA_OK; }
-    if (!strcmp(key, "gemm_ld")) { g_gemm_ld = value; return SOLA_OK; }
     if (!strcmp(key, "bwd_side_rows")) { g_bwd_side_rows = value; return SOLA_OK; }
     if (!strcmp(key, "bwd_group_rows")) { g_bwd_group_rows = value; return SOLA_OK; }
     if (!strcmp(key, "train_tn_tr")) { g_train_tn_tr = value; return SOLA_OK; }
@@ -346,7 +347,6 @@ extern "C" int sola_tune(const char* key, int value) {
 #endif
     if (!strcmp(key, "gemm_tn_nw8")) { sola_gemm_tn_set_nw8(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_tn_persist")) { sola_gemm_tn_set_persist(value); return SOLA_OK; }
-    if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_glds_force")) { sola_gemm_set_glds_force(value); return SOLA_OK; }
     if (!strcmp(key, "train_split_min_rows")) { sola_set_train_split_min_rows(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_persist")) { sola_gemm_set_persist(value); return SOLA_OK; }
@@ -358,16 +358,13 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }
-    if (!strcmp(key, "attn_reg_minw")) { sola_attn_set_reg_minw(value); return SOLA_OK; }
     if (!strcmp(key, "attn_res")) { sola_attn_set_res(value); return SOLA_OK; }
     if (!strcmp(key, "attn_res_tiles")) { sola_attn_set_res_tiles(value); return SOLA_OK; }
     if (!strcmp(key, "attn_res_shape")) { sola_attn_set_res_shape(value); return SOLA_OK; }
-    if (!strcmp(key, "attn_res_splitm")) { sola_attn_set_res_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_small")) { sola_attn_set_bwd_small(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_blk")) { sola_attn_set_bwd_blk(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_rag_wave")) { sola_attn_set_bwd_rag_wave(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_fused")) { sola_attn_set_bwd_fused(value); return SOLA_OK; }
-    if (!strcmp(key, "attn_bwd_ablate")) { sola_attn_set_bwd_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "attn_f16_small")) { sola_attn_set_f16_small(value); return SOLA_OK; }
     if (!strcmp(key, "gn_h8")) { sola_gn_set_h8(value); return SOLA_OK; }
     if (!strcmp(key, "attn_spin")) { sola_attn_set_spin(value); return SOLA_OK; }
@@ -377,12 +374,25 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gn_bwd_reg")) { sola_gn_set_bwd_reg(value); return SOLA_OK; }
     if (!strcmp(key, "gn_slices")) { sola_gn_set_slices(value); return SOLA_OK; }
     if (!strcmp(key, "gn_wide")) { sola_gn_set_wide(value); return SOLA_OK; }
-    if (!strcmp(key, "gemm_gn_fuse")) { sola_gemm_set_gn_fuse(value); return SOLA_OK; }
     if (!strcmp(key, "bwd_dual_cast")) { sola_set_bwd_dual_cast(value); return SOLA_OK; }
     if (!strcmp(key, "attn_simple_remap")) { sola_attn_set_simple_remap(value); return SOLA_OK; }
     if (!strcmp(key, "attn_simple_db")) { sola_attn_set_simple_db(value); return SOLA_OK; }
     if (!strcmp(key, "pack_resample_lds")) { sola_pack_set_resample_lds(value); return SOLA_OK; }
-    sola_set_error("tune: unknown key '%s'", key);
+#ifdef SOLA_EXPERIMENTS  // closed experiments and measurement switches: EXPERIMENTS=1 builds only (make -C sola_amd/csrc EXPERIMENTS=1)
+    if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_nw4")) { g_gemm_nw4 = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_k16")) { g_gemm_k16 = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_order")) { g_gemm_order = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_trace")) { g_gemm_trace = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_ld")) { g_gemm_ld = value; return SOLA_OK; }
+    if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_reg_minw")) { sola_attn_set_reg_minw(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_res_splitm")) { sola_attn_set_res_splitm(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_bwd_ablate")) { sola_attn_set_bwd_ablate(value); return SOLA_OK; }
+    if (!strcmp(key, "gemm_gn_fuse")) { sola_gemm_set_gn_fuse(value); return SOLA_OK; }
+#endif
+    sola_set_error("tune: unknown key '%s'%s", key, sola_has_experiments() ? "" : " (experiment keys exist in EXPERIMENTS=1 builds only)");
     return SOLA_ERR_ARG;
 }
 

@@ -280,9 +280,12 @@ int launch_attention_reg(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
+#ifdef SOLA_EXPERIMENTS  // the register budgets that spill (A/B record: 1.3x / 2.4x slower)
     if (g_attn_reg_minw >= 4) hipLaunchKernelGGL((attn_fwd_f32_reg_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (g_attn_reg_minw == 3) hipLaunchKernelGGL((attn_fwd_f32_reg_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_f32_reg_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+#endif
+    hipLaunchKernelGGL((attn_fwd_f32_reg_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -216,6 +216,7 @@ __device__ __forceinline__ void sm_tile(const AttnQArgs& a, const _Float16* Kh, 
     }
 }
 
+#ifdef SOLA_EXPERIMENTS  // the object->language shape on f16-MFMA triples (sola_tune "attn_res_splitm"): measured no faster than exact f32, spills 20 registers
 __global__ __launch_bounds__(512, 4) void attn_fwd_sm_res_kernel(const AttnQArgs a) {
     constexpr int DH = 128, NW = 8;
     extern __shared__ __attribute__((aligned(16))) float smem_r[];
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_sm_res_kernel(const AttnQArgs
     // anything that left the f16 range (q, k, v or the output pairs; NaN fails the comparison too): the forward repeats in f32
     if (a.guard && !(amax < 65000.f)) atomicOr(a.guard, 1);
 }
+#endif
 
 // NW waves per block, compiled for MINW waves per SIMD.  PF: the Q rows of a wave's next tile are requested into a second
 // register set before the current tile is computed (needs the 168 VGPRs of MINW = 3; at 128 it spills and loses).
@@ -439,6 +441,7 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     // for the second tile - about half of a 32 us block is memory latency under load.  Acting on it did not pay: requesting
     // the first tile's Q rows before the staging 183 -> 197 us (the K/V loads queue behind them), all staging loads in front of
     // the first LDS write 183 -> 183 us
+#ifdef SOLA_EXPERIMENTS
     if (d.split_math && g_attn_res_splitm) {  // the split precision mode's arithmetic (f16 MFMA triples, K/V converted once per block)
         a.guard = d.guard;
         a.tiles_per_wave = g_attn_res_tiles > 0 ? g_attn_res_tiles : 0;
@@ -463,6 +466,7 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
         SOLA_LAUNCH_CHECK();
         return SOLA_OK;
     }
+#endif
     if (g_attn_res_shape == 2) return launch_res<4, 3, true>(a, d, s);
     return launch_res<8, 4, false>(a, d, s);
 }

@@ -1996,7 +1996,9 @@ static int launch_glds(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     return SOLA_OK;
 }
 
-// sola_tune "gemm_gn_fuse": 1 = encoder conv0-2 apply their GroupNorm + LeakyReLU in the GEMM epilogue.  OFF by default (round 3): the
+// sola_tune "gemm_gn_fuse" (EXPERIMENTS builds): 1 = encoder conv0-2 apply their GroupNorm + LeakyReLU in the GEMM epilogue.  Round 5 decision: CLOSED.
+// 500 fused forwards were bit-repeatable, but the headline did not move (18.73 K against 18.80 K samples/s: GroupNorm -0.36 ms, GEMM +0.17 ms, the
+// rest in the launches around them - on a launch that sits at the board's power limit the epilogue's arithmetic is paid in clock).  History (round 3): the
 // fused epilogue showed two nondeterministic corruption faults during development whose cause was never pinned to an instruction
 // (DESIGN.md 5); they are contained (no packed-f32 code: -fno-slp-vectorize + tests/test_host_cpu.py's disassembly check; no exec
 // change in the interior epilogue; the repeatability stress in the GPU suite), but a ~2 % step-time gain does not justify shipping an
@@ -2020,6 +2022,7 @@ extern "C" long long sola_gemm_trace_read(void* host, long long bytes) {
     return (long long)n;
 }
 
+#ifdef SOLA_EXPERIMENTS
 template <bool CONV, int PURE>
 static int launch_k16(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = (M + 255) / 256;
@@ -2036,6 +2039,7 @@ static int launch_k16(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
+#endif
 
 template <bool CONV, int RMODE, int CSP, int PURE = 0, int GNT = 0, int NW = 8, int TRACE = 0, int LD = 0>
 static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
@@ -2061,6 +2065,7 @@ static int launch_persist_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s)
 }
 
 
+#ifdef SOLA_EXPERIMENTS
 template <bool CONV, int CSP>
 static int launch_pp_t(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     a.tiles_m = M / 256;
@@ -2087,21 +2092,29 @@ static bool pp_applies(const GldsArgs& a, int M, int N) {
     return g_gemm_pp && !a.p[0].R && !a.gn_gamma && a.ksplit <= 1 && M % 256 == 0 && N % 128 == 0 && (a.ldc & 3) == 0 && a.K / GBK >= 11 &&
            (!a.p[0].bias || (reinterpret_cast<uintptr_t>(a.p[0].bias) & 15) == 0);
 }
+#endif
 
 template <bool CONV>
 static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
+#ifdef SOLA_EXPERIMENTS
     if (pp_applies(a, M, N)) return a.c_sp16 ? launch_pp_t<CONV, 1>(a, M, N, nprob, s) : launch_pp_t<CONV, 0>(a, M, N, nprob, s);
+#endif
     if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);  // partial sums: f32, no residual
+#ifdef SOLA_EXPERIMENTS
     if (a.gn_gamma) {  // conditions checked by gemm_gn_fusable()
         if (a.gn_tokens == 16) return launch_persist_t<CONV, 0, 1, false, 16>(a, M, N, nprob, s);
         if (a.gn_tokens == 8) return launch_persist_t<CONV, 0, 1, false, 8>(a, M, N, nprob, s);
         return launch_persist_t<CONV, 0, 1, false, 4>(a, M, N, nprob, s);
     }
+#else
+    SOLA_ARG(!a.gn_gamma, "gemm: the fused GroupNorm epilogue is compiled in EXPERIMENTS builds only (closed in round 5: no gain on the power-bound kernel)");
+#endif
     const int rmode = !a.p[0].R ? 0 : (a.r_sp16 ? 2 : 1);
     if (a.c_sp16) {
         if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 1>(a, M, N, nprob, s);
         return rmode == 2 ? launch_persist_t<false, 2, 1>(a, M, N, nprob, s) : launch_persist_t<false, 1, 1>(a, M, N, nprob, s);
     }
+#ifdef SOLA_EXPERIMENTS
     if (g_gemm_nw4 && !CONV && rmode == 0 && a.ksplit <= 1) return launch_persist_t<false, 0, 0, false, 0, 4>(a, M, N, nprob, s);  // experiment
     // experiment (sola_tune "gemm_ld"): one wave of each SIMD's pair issues the whole DMA stream; 32-bit buffer offsets: rows within 2 GiB
     const int ld = (!CONV && g_gemm_ld && (long long)256 * a.lda * 4 < (1LL << 31) && (long long)256 * a.K * 4 < (1LL << 31)) ? g_gemm_ld : 0;
@@ -2120,6 +2133,7 @@ static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     if constexpr (!CONV) {
         if (ld && rmode == 0) return ld == 1 ? launch_persist_t<false, 0, 0, 0, 0, 8, 0, 1>(a, M, N, nprob, s) : launch_persist_t<false, 0, 0, 0, 0, 8, 0, 2>(a, M, N, nprob, s);
     }
+#endif
     if (CONV || rmode == 0) return launch_persist_t<CONV, 0, 0>(a, M, N, nprob, s);
     return rmode == 2 ? launch_persist_t<false, 2, 0>(a, M, N, nprob, s) : launch_persist_t<false, 1, 0>(a, M, N, nprob, s);
 }
@@ -2163,7 +2177,9 @@ static int launch_shape_pure(GldsArgs& a, int shape, int M, int N, int nprob, hi
 template <bool CONV>
 static int launch_shape(GldsArgs& a, int shape, int M, int N, int nprob, hipStream_t s) {
     if (a.ksplit > 1) return launch_persist<CONV>(a, M, N, nprob, s);
+#ifdef SOLA_EXPERIMENTS
     if (shape == 4 && g_gemm_k16 && !a.gn_gamma) return launch_k16<CONV, 0>(a, M, N, nprob, s);
+#endif
     if (shape == 4 && g_gemm_persist && a.K / GBK >= 2 && persist_uniform(a, CONV)) return launch_persist<CONV>(a, M, N, nprob, s);
     if (shape == 4) return launch_glds<4, 2, 4, CONV>(a, M, N, nprob, s);
     return launch_glds<2, 2, 2, CONV>(a, M, N, nprob, s);
@@ -2177,6 +2193,9 @@ int gemm_split_glds_shape(const GemmDesc& d);
 // The fused-GroupNorm epilogue exists for the persistent 256x256 kernel only, on interior tiles: split-f16 arithmetic and
 // output, one problem, no residual, M and N multiples of 256, 64 channels per group (a wave's columns), 4 / 8 / 16 tokens.
 bool gemm_gn_fusable(const GemmDesc& d, int channels_per_group, int tokens) {
+#ifndef SOLA_EXPERIMENTS
+    return false;  // round 5: closed (bit-repeatable over 500 forwards, but no gain: the epilogue's arithmetic costs the power-bound launch what the norm's pass saved - profiles/r05_gnf_decision.txt)
+#endif
     return g_gemm_gn_fuse && g_gemm_persist && d.arith == 1 && d.nprob == 1 && !d.p[0].R && d.ksplit <= 1 && d.M % 256 == 0 && d.N % 256 == 0 &&
            d.K / GBK >= 2 && channels_per_group == 64 && (tokens == 4 || tokens == 8 || tokens == 16) && (d.ldc & 7) == 0 &&
            gemm_split_glds_supported(d) && gemm_split_glds_shape(d) == 4;

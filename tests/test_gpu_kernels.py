@@ -337,7 +337,8 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
     qc, kc, vc = (cuda(t).reshape(B * N * Tp, D) for t in (q, k, v))
     _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 1), "sola_tune")
     _lib.check(_lib.lib().sola_tune(b"attn_splitm", 1), "sola_tune")      # both split-math shapes are off by default (measured slower /
-    _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 1), "sola_tune")  # no faster than exact f32): forced here
+    if _lib.has_experiments():
+        _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 1), "sola_tune")  # no faster than exact f32): forced here (EXPERIMENTS=1 builds)
     try:
         tr = lambda t: np.transpose(t, (0, 2, 1, 3)).reshape(B * Tp, N, D)
         ref = _attn_ref(tr(q64), tr(k64), tr(v64), H).reshape(B, Tp, N, D).transpose(0, 2, 1, 3)
@@ -356,7 +357,8 @@ def test_attention_split_math_on_f32_inputs(B, N, Tp):
     finally:
         _lib.check(_lib.lib().sola_tune(b"attn_stage_split_math", 0), "sola_tune")
         _lib.check(_lib.lib().sola_tune(b"attn_splitm", 0), "sola_tune")
-        _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 0), "sola_tune")
+        if _lib.has_experiments():
+            _lib.check(_lib.lib().sola_tune(b"attn_res_splitm", 0), "sola_tune")
 
 
 @pytest.mark.parametrize("bf16", [False, True])
@@ -438,6 +440,8 @@ def test_experimental_k16_gemm_is_bit_identical():
     default-precision forward (implicit-im2col conv GEMMs included)."""
     from sola_amd import _lib, synth
     from sola_amd.module import LanguageAlignedTrackSelectionModule
+    if not _lib.has_experiments():
+        pytest.skip("closed experiment: compiled in EXPERIMENTS=1 builds of the library only (make -C sola_amd/csrc EXPERIMENTS=1)")
     lib = _lib.lib()
     torch.manual_seed(5)
     try:
@@ -478,6 +482,8 @@ def test_experimental_four_wave_gemm_kernels_are_bit_identical(key, out_split):
     gemm_pp: the same with two accumulator sets, a tile's epilogue drained under the next tile's k-loop - DESIGN.md 5) keep the
     fragment layout and accumulation order of the default kernel: same bits, with bias, in both output formats."""
     from sola_amd import _lib
+    if not _lib.has_experiments():
+        pytest.skip("closed experiment: compiled in EXPERIMENTS=1 builds of the library only (make -C sola_amd/csrc EXPERIMENTS=1)")
     lib = _lib.lib()
     torch.manual_seed(3)
     outs = {}
