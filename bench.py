@@ -294,13 +294,17 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
     # train.py runs on variable-shape data (sola_forward_train takes one uniform batch)
     inp1 = {k: v[:1].contiguous() for k, v in inp.items()}
 
-    def step1():
+    def step1_autograd():
         opt.zero_grad(set_to_none=True)
         sm, st = m(inp1["object_tokens"], inp1["lang_tokens"])
         neg = m.negative_token.weight.clone().unsqueeze(0)
         loss3 = track_selection_losses(sm, st, inp1["labels"], inp1["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
         loss3[0].backward()
         m.clip_grad_norm_(1.0)
+        opt.step()
+
+    def step1():  # round 5: the same step with its device work enqueued by ONE library call (module.train_step -> sola_train_step; bit-identical)
+        m.train_step(inp1["object_tokens"], inp1["lang_tokens"], inp1["labels"], inp1["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0)
         opt.step()
 
     # variable-shape samples in ONE step (sola_forward_train_ragged / sola_backward_ragged): the MeViS-like mix of the ragged
@@ -352,9 +356,13 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
     res["ragged"] = rag
     del smp, objs, langs
     m.precision = "f32"
-    dt1 = timed(step1, max(steps, 10), sync)
+    dt1 = timed(step1, max(steps, 50), sync, warmup=5)
+    dt1a = timed(step1_autograd, max(steps, 50), sync, warmup=5)
     res["one_sample_per_step"] = {"value": round(1.0 / dt1, 1), "ms_per_step": round(dt1 * 1e3, 3), "precision": "f32",
-                                  "what": "the reference's training batch size; below 1024 token rows every precision mode runs the exact-f32 kernels"}
+                                  "autograd_path_ms": round(dt1a * 1e3, 3),
+                                  "what": "the reference's training batch size (module.train_step: the step's device work in one library call, then "
+                                          "torch's fused AdamW; autograd_path_ms: the same step call by call through autograd); below 1024 token rows "
+                                          "every precision mode runs the exact-f32 kernels"}
     if oracle_parity:  # the TRAINING forward of the 64-sample ragged batch (sola_forward_train_ragged, dropout off), every logit against the fp32
         # oracle - on the ORIGINAL weights: the timed steps above have updated the module's
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})

@@ -267,6 +267,27 @@ int sola_forward_train(SolaCtx* ctx, const float* dev_object_tokens, const float
                        void* dev_workspace, size_t workspace_bytes, void* stream);
 int sola_backward(SolaCtx* ctx, const float* dev_d_score_map, const float* dev_d_score_tokens,
                   const void* dev_forward_workspace, void* dev_scratch, size_t scratch_bytes, void* stream);
+/* ---- one optimizer step's device work in ONE call (round 5) ----------------------------------------------------------------------
+ * The body of the reference's training loop - forward, weighted BCE + alignment loss, loss.backward(), get_grad_norm_dict(), gradient
+ * clipping (train.py:62-125 at its batch size of one sample, configs/mevis/default.yaml:37) - enqueued from C++ on `stream`: the ~110
+ * launches of a one-sample step cost 1.6-2.4 ms of host time when driven call by call from Python, more than their GPU time.
+ * Same kernels, arguments and order as sola_forward_train + sola_loss + sola_loss_backward + sola_backward + sola_grad_sqnorms +
+ * sola_grad_clip called one by one (bit-identical gradients).  The optimizer update is the caller's: the gradients are where
+ * sola_set_grad bound them.
+ *   sola_train_step_bind: the parameters in the order module/module.py:164-199 walks them (names[i] of group group[i]: encoder, every
+ *     layer, negative tokens) - the gradient-norm reduction takes them in that order.  Call once per context (after sola_set_grad).
+ *   dev_loss3 [3] = {total, bce, alignment} (train.py:98-113); dev_grad_sq [n_groups + 1] doubles = the groups' sums of squares of the
+ *     UNclipped gradients and their total (module/module.py:164-199 reports the square roots); max_grad_norm <= 0: no clipping.
+ *   dev_labels [B, N], dev_pos_tokens [B, 1, D]; the negative tokens are the context's own `negative_token.weight` (train.py:92), whose
+ *     gradient receives both of its contributions (through the network and straight from the alignment loss).
+ *   Workspaces (caller-owned): sola_train_workspace_bytes / sola_backward_workspace_bytes / sola_train_step_workspace_bytes. */
+int sola_train_step_bind(SolaCtx* ctx, const char* const* names, const int32_t* group, int n, int n_groups);
+size_t sola_train_step_workspace_bytes(const SolaCtx* ctx, int B, int N);
+int sola_train_step(SolaCtx* ctx, const float* dev_object_tokens, const float* dev_lang_tokens, int B, int N, int T, int L,
+                    const float* dev_labels, const float* dev_pos_tokens, float positive_weight, float temperature, float alignment_weight,
+                    float max_grad_norm, float* dev_score_map, float* dev_score_tokens, float* dev_loss3, double* dev_grad_sq,
+                    void* dev_train_workspace, size_t train_workspace_bytes, void* dev_backward_scratch, size_t backward_scratch_bytes,
+                    void* dev_step_workspace, size_t step_workspace_bytes, void* stream);
 /* ---- ragged training step: many (video, expression) samples of DIFFERENT shapes per optimizer step -------------------------
  * The reference trains at batch size 1 (configs/mevis/default.yaml:37; train.py:62-137: one forward, one backward, one AdamW
  * step per sample) because every sample has its own N tracks, T frames and L text tokens (dataloader.py:119-163,187-199).

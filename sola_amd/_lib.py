@@ -131,6 +131,9 @@ SIGNATURES = {
     "sola_x16_arena_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "sola_tune": (_i, [C.c_char_p, _i]),
     "sola_has_experiments": (_i, []),
+    "sola_train_step_bind": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _i, _i]),
+    "sola_train_step_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "sola_train_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     "sola_gemm_trace_read": (C.c_longlong, [_vp, C.c_longlong]),
     "sola_profile_enable": (_i, [_i]),
     "sola_profile_read": (_i, [C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),

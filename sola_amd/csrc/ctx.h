@@ -128,6 +128,15 @@ struct SolaCtx {
     float* scal_pair(int i) const { return scal_buf + 2 * i; }
     float* scal_extra(int i) const { return scal_buf + 2 * (2 + (size_t)cfg.n_layers * 12) + 2 + i; }  // 4 spare device floats behind the guard words
     const float* lin_inv_scale(int layer, int attn, int proj) const { return scal_buf + 2 * (2 + (layer * 3 + attn) * 4 + proj) + 1; }
+    // sola_train_step (train_step.hip): the gradient tensors in the order the norm reduction takes them (group by group, as
+    // module/module.py:164-199 walks them), resolved by name once (sola_train_step_bind)
+    struct StepBinding {
+        std::vector<int> widx;
+        std::vector<int32_t> group;
+        std::vector<long long> numel;
+        int n_groups = 0;
+        size_t sq_scratch = 0;
+    } step;
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
     // the seed used by the last sola_forward_train is kept for sola_backward
     float p_drop_encoder = 0.f, p_drop_attention = 0.f;

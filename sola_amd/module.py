@@ -582,6 +582,96 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._grads_in_arena = not aliased
         return grads
 
+    def train_step(self, object_tokens, lang_tokens, labels, pos_tokens, positive_weight=1.5, temperature=0.07, alignment_weight=0.3,
+                   max_grad_norm=0.0):
+        """The body of the reference's training loop (train.py:62-125: forward, weighted BCE + alignment loss on the module's own negative
+        tokens, ``loss.backward()``, ``get_grad_norm_dict()``, gradient clipping) as ONE library call (sola_train_step): the ~110 launches
+        of a one-sample step are enqueued from C++ instead of call by call through autograd and ctypes (1.6-2.4 ms of host time per step,
+        more than their GPU time).  Same kernels in the same order as ``module(...)`` + ``track_selection_losses`` + ``.backward()`` +
+        ``clip_grad_norm_``: bit-identical gradients.  Uniform batches ``object_tokens [B,N,T,d]``, ``lang_tokens [B,L,D]``,
+        ``labels [B,N]``, ``pos_tokens [B,1,D]``; exact-f32 or any training precision (``train_precision``).
+
+        Returns ``(loss3, score_map, score_tokens)`` - ``loss3 = [total, bce, alignment]`` on the device, no host sync.  Every parameter's
+        ``.grad`` is (a view of) the gradient arena afterwards, so ``optimizer.step()`` follows directly; no ``zero_grad`` is needed
+        (the backward overwrites).  ``max_grad_norm <= 0``: no clipping (multi-GPU: all-reduce first, then ``clip_grad_norm_``).
+        ``get_grad_norm_dict()`` after the call reads the step's own reduction (one host sync)."""
+        require_cuda(object_tokens, lang_tokens, labels, pos_tokens)
+        self._check_inputs(object_tokens, lang_tokens)
+        B, N, T, _d = object_tokens.shape
+        _, L, D = lang_tokens.shape
+        dev = object_tokens.device
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        obj, lang, lab, pos = f(object_tokens), f(lang_tokens), f(labels), f(pos_tokens)
+        if lab.numel() != B * N or pos.numel() != B * D:
+            raise SolaError("train_step: labels must be [B,N] and pos_tokens [B,1,D]")
+        self._ensure_ctx(dev)
+        self._bind_weights(train=True)
+        self._weights_touched = True  # the caller is about to update the parameters
+        self._set_step_dropout()
+        self._size_x16_arena(dev)
+        named = self._params()
+        self._grad_layout()
+        if self._grad_bound != "arena":
+            self._bind_grad_arena()
+        if getattr(self, "_step_bound_ctx", None) is not self._ctx:
+            groups = self._grad_groups()
+            key_of = {id(p): k for k, p in named}
+            names, gids = [], []
+            for gi, (_name, params) in enumerate(groups):
+                for p in params:
+                    names.append(key_of[id(p)].encode())
+                    gids.append(gi)
+            arr = (C.c_char_p * len(names))(*names)
+            check(lib().sola_train_step_bind(self._ctx, arr, (C.c_int32 * len(gids))(*gids), len(names), len(groups)), "sola_train_step_bind")
+            self._step_bound_ctx = self._ctx
+        nb_t = lib().sola_train_workspace_bytes(self._ctx, B, N, T, L)
+        if self._train_ws is None or self._train_ws.numel() < nb_t or self._train_ws.device != dev:
+            self._train_ws = torch.empty(int(nb_t), dtype=torch.uint8, device=dev)
+        nb_b = lib().sola_backward_workspace_bytes(self._ctx, B, N, T, L)
+        if self._bwd_ws is None or self._bwd_ws.numel() < nb_b or self._bwd_ws.device != dev:
+            self._bwd_ws = None
+            self._bwd_ws = torch.empty(int(nb_b), dtype=torch.uint8, device=dev)
+        nb_s = lib().sola_train_step_workspace_bytes(self._ctx, B, N)
+        sw = getattr(self, "_step_ws", None)
+        if sw is None or sw.numel() < nb_s or sw.device != dev:
+            self._step_ws = sw = torch.empty(int(nb_s), dtype=torch.uint8, device=dev)
+        n_groups = len(self._grad_groups())
+        score_map = torch.empty((B, N), device=dev, dtype=torch.float32)
+        score_tokens = torch.empty((B, N, D), device=dev, dtype=torch.float32)
+        loss3 = torch.empty(3, device=dev, dtype=torch.float32)
+        grad_sq = torch.empty(n_groups + 1, device=dev, dtype=torch.float64)
+        check(lib().sola_train_step(self._ctx, ptr(obj), ptr(lang), B, N, T, L, ptr(lab), ptr(pos), float(positive_weight), float(temperature),
+                                    float(alignment_weight), float(max_grad_norm), ptr(score_map), ptr(score_tokens), ptr(loss3), ptr(grad_sq),
+                                    ptr(self._train_ws), self._train_ws.numel(), ptr(self._bwd_ws), self._bwd_ws.numel(), ptr(sw), sw.numel(),
+                                    current_stream(dev)), "sola_train_step")
+        self._train_inputs = (obj, lang)
+        self._train_shape = (B, N, T, L)
+        self._train_generation += 1
+        self._workspace = self._train_ws
+        self._grads_in_arena = True
+        self._step_grad_sq = grad_sq  # sums of squares of the UNclipped gradients (module/module.py:164-199 reports their roots)
+        self._last_grad_sq = None
+        # every parameter's .grad = its slot of the arena (persistent views: nothing to do from the second step on)
+        lo, hi = self._grad_arena.data_ptr(), self._grad_arena.data_ptr() + 4 * self._grad_arena.numel()
+        for key, p in named:
+            g = p.grad
+            if g is None or not (lo <= g.data_ptr() < hi):
+                p.grad = self._grad_view(key)
+        return loss3, score_map, score_tokens
+
+    def step_grad_norm_dict(self):
+        """``get_grad_norm_dict()`` (module/module.py:164-199) of the last ``train_step``: the norms of its gradients BEFORE clipping, from
+        the reduction the step ran on the device (one host sync)."""
+        sq = getattr(self, "_step_grad_sq", None)
+        if sq is None:
+            raise SolaError("step_grad_norm_dict: no train_step yet")
+        groups = self._grad_groups()
+        vals = sq[:len(groups)].cpu().tolist()
+        out = {"total_grad_norm": sum(vals) ** 0.5}
+        for (name, _), v in zip(groups, vals):
+            out[name] = v ** 0.5
+        return out
+
     def workspace_tap(self, name):
         """Copy of a named intermediate of the last forward (see sola_workspace_tap); for parity tests."""
         off, rows, cols = C.c_size_t(), C.c_int64(), C.c_int64()

@@ -687,3 +687,60 @@ def test_grouped_few_sample_weight_gradients_equal_the_slab_form(full_model, sha
         worst = max(worst, (err, k))
     print("grouped vs slab weight gradients, worst tensor:", worst)
     assert worst[0] < 2e-6, worst
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+@pytest.mark.parametrize("shape", [(1, 64, 32, 16), (1, 21, 77, 9), (3, 16, 32, 12)])
+def test_train_step_call_equals_the_autograd_path(shape, train_mode):
+    """Round 5 (sola_train_step / module.train_step): the body of the training loop as ONE library call - forward, losses on the module's own
+    negative tokens, backward, gradient norms, clipping, enqueued from C++ - against the call-by-call path through autograd
+    (module(...) + track_selection_losses + .backward() + clip_grad_norm_), dropout on (the same seeds) and off.  One sample per step (the
+    reference's batch size, configs/mevis/default.yaml:37): the same kernels with the same arguments in the same order - losses, every
+    gradient, the norm dict and, after three clipped AdamW steps, every weight are BIT-identical.  Batches of several samples: the
+    per-sample negative-token gradients are summed by torch there (repeat's backward) and by the library here - same values at 1e-6."""
+    B, N, T, L = shape
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, N, T, L, 123).items()}
+    models, opts, outs = [], [], []
+    for _ in range(2):
+        m, _sd = build(cfg)
+        m.train(train_mode)
+        m.precision = "f32"
+        models.append(m)
+        opts.append(torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True))
+    for step in range(3):
+        # (a) call by call through autograd
+        m, opt = models[0], opts[0]
+        torch.manual_seed(1000 + step)  # the step's dropout seed comes from torch's CPU generator
+        opt.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            sm, st = m(inp["object_tokens"], inp["lang_tokens"])
+            neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+            la = track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
+            la[0].backward()
+        norms_a = m.get_grad_norm_dict()
+        m.clip_grad_norm_(1.0)
+        ga = {k: p.grad.clone() for k, p in m._params()}
+        opt.step()
+        # (b) one call
+        m2, opt2 = models[1], opts[1]
+        torch.manual_seed(1000 + step)
+        lb, sm2, st2 = m2.train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0)
+        norms_b = m2.step_grad_norm_dict()
+        gb = {k: p.grad.clone() for k, p in m2._params()}
+        opt2.step()
+        torch.cuda.synchronize()
+        assert torch.equal(sm, sm2) and torch.equal(st, st2) and torch.equal(la, lb), step
+        if B == 1:
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), (step, k)
+            assert norms_a == norms_b, (norms_a, norms_b)
+        else:
+            for k in ga:
+                d = float((ga[k] - gb[k]).abs().max())
+                assert d <= 1e-6 * max(1e-12, float(ga[k].abs().max())) + 1e-12, (step, k, d)
+            for k in norms_a:
+                assert abs(norms_a[k] - norms_b[k]) <= 1e-6 * max(norms_a[k], 1e-12), k
+    if B == 1:
+        for (k, p), (_k2, p2) in zip(models[0]._params(), models[1]._params()):
+            assert torch.equal(p.detach(), p2.detach()), k
