@@ -278,7 +278,7 @@ extern int g_gemm_f32p_ablate;
 void sola_gemm_tn_set_nw8(int v);
 extern int g_gemm_nw4, g_gemm_pp, g_gemm_k16, g_train_tn_tr, g_train_x16_keep, g_train_attn_cast;
 extern int g_gemm_stagger, g_gemm_order, g_gemm_trace, g_gemm_ld;
-extern int g_bwd_side_rows, g_bwd_group_rows;
+extern int g_bwd_side_rows, g_bwd_group_rows, g_lang_shared_neg;
 extern int g_infer_f32_rows;
 void sola_gemm_set_ablate(int v);
 void sola_gemm_set_persist(int v);
@@ -332,6 +332,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_glds")) { sola_gemm_set_glds(value); return SOLA_OK; }
     if (!strcmp(key, "bwd_side_rows")) { g_bwd_side_rows = value; return SOLA_OK; }
     if (!strcmp(key, "bwd_group_rows")) { g_bwd_group_rows = value; return SOLA_OK; }
+    if (!strcmp(key, "lang_shared_neg")) { g_lang_shared_neg = value; return SOLA_OK; }
     if (!strcmp(key, "train_tn_tr")) { g_train_tn_tr = value; return SOLA_OK; }
     if (!strcmp(key, "train_x16_keep")) { g_train_x16_keep = value; return SOLA_OK; }
     if (!strcmp(key, "train_attn_cast")) { g_train_attn_cast = value; return SOLA_OK; }

@@ -26,6 +26,8 @@ struct AttnQArgs {
     int o_sp16;
     int* guard;
     const int4 *q_units, *k_units;
+    int k_priv;          // keys >= k_priv are the shared rows k_shared + (j - k_priv) (AttnDesc::k_private; INT_MAX = none)
+    long long k_shared;
 };
 
 constexpr int RES_LD = 128 + 4;     // LDS row pitch in floats: 528 B = 16 B past two bank rows, so the 16 keys of a ds_read_b128
@@ -252,8 +254,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_sm_res_kernel(const AttnQArgs
         const int r = e >> 5, c = e & 31;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (r < Sk) {
-            kv = *reinterpret_cast<const float4*>(a.k + (k0 + (long long)r * k_rs) * a.ldk + h * DH + 4 * c);
-            vv = *reinterpret_cast<const float4*>(a.v + (k0 + (long long)r * k_rs) * a.ldv + h * DH + 4 * c);
+            const long long row = r < a.k_priv ? k0 + (long long)r * k_rs : a.k_shared + (r - a.k_priv);
+            kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + 4 * c);
+            vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + 4 * c);
         }
         const HL4r kk = split4r(kv.x, kv.y, kv.z, kv.w, amax), vs = split4r(vv.x, vv.y, vv.z, vv.w, amax);
         *reinterpret_cast<half4r*>(Kh + r * SM_KP + 4 * c) = kk.hi;
@@ -337,8 +340,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_f32_res_kernel(const A
         const int r = e >> 5, c = e & 31;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (r < Sk) {
-            kv = *reinterpret_cast<const float4*>(a.k + (k0 + (long long)r * k_rs) * a.ldk + h * DH + 4 * c);
-            vv = *reinterpret_cast<const float4*>(a.v + (k0 + (long long)r * k_rs) * a.ldv + h * DH + 4 * c);
+            const long long row = r < a.k_priv ? k0 + (long long)r * k_rs : a.k_shared + (r - a.k_priv);
+            kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + 4 * c);
+            vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + 4 * c);
         }
         *reinterpret_cast<float4*>(Ks + r * RES_LD + 4 * c) = kv;
         *reinterpret_cast<float4*>(Vs + r * RES_LD + 4 * c) = vv;
@@ -393,6 +397,8 @@ bool attention_res_supported(const AttnDesc& d) {
     return g_attn_res && !d.drop.enabled && !d.in_sp16 && d.DH == 128 && d.Sk <= 64 && d.Sq >= 128;
 }
 
+bool attention_shared_keys_supported(const AttnDesc& d) { return attention_res_supported(d) && !d.q_units && d.k_private > 0 && d.k_private <= d.Sk; }
+
 template <int NW, int MINW, bool PF>
 static int launch_res(AttnQArgs a, const AttnDesc& d, hipStream_t s) {
     const int max_tiles = PF ? 8 : 4;
@@ -429,6 +435,8 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     a.scale = d.scale; a.o_sp16 = d.o_sp16; a.guard = d.o_sp16 ? d.guard : nullptr;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     a.tiles_per_wave = 1; a.nchunk = 1;
+    a.k_priv = d.k_private > 0 ? d.k_private : 0x7fffffff;
+    a.k_shared = d.k_shared_row;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));
     // measured at 256 samples (256 queries x 48 keys per unit, tools/attn_probe3.py): 8 waves without prefetch 180-183 us, three
@@ -442,7 +450,7 @@ int launch_attention_res(const AttnDesc& d, hipStream_t s) {
     // the first tile's Q rows before the staging 183 -> 197 us (the K/V loads queue behind them), all staging loads in front of
     // the first LDS write 183 -> 183 us
 #ifdef SOLA_EXPERIMENTS
-    if (d.split_math && g_attn_res_splitm) {  // the split precision mode's arithmetic (f16 MFMA triples, K/V converted once per block)
+    if (d.split_math && g_attn_res_splitm && d.k_private <= 0) {  // the split precision mode's arithmetic (f16 MFMA triples, K/V converted once per block)
         a.guard = d.guard;
         a.tiles_per_wave = g_attn_res_tiles > 0 ? g_attn_res_tiles : 0;
         if (a.tiles_per_wave == 0) {

@@ -75,6 +75,8 @@ int sola_refresh_lin16(SolaCtx* c, hipStream_t s) {
 int g_attn_split_min_keys = 96;
 void sola_attn_set_split_min_keys(int v) { g_attn_split_min_keys = v; }
 
+int g_lang_shared_neg = 1;  // sola_tune "lang_shared_neg": 0 = the negative tokens repeated per sample through the text-side projections (A/B)
+
 int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int B, int N, int T, int L, float* score_map,
                            float* score_tokens, void* workspace, size_t ws_bytes, hipStream_t s) {
     SOLA_ARG(c && obj && lang && score_map && score_tokens && workspace, "forward: null argument");
@@ -185,8 +187,20 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
     if (!conv5_split) SOLA_TRY(launch_cast_sp16(buf("conv5"), D, buf("conv5_sp"), D, M, D, 1.f, s));
 
     SOLA_TRY(launch_pos_encoding(W("positional_encoding_gaussian_matrix"), D, Tp, c->cfg.max_temporal_length, buf("pe"), s));
-    SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
-    SOLA_TRY(launch_cast_sp16_auto(buf("lang"), D, buf("lang_sp"), D, (long long)B * Wn, D, c->scal_pair(1), s));
+    // round 5 (sola_tune "lang_shared_neg", default 1): the negative tokens' key / value rows are the same for every sample - project them
+    // once (B * L + n_neg rows through the two text-side GEMMs of a layer instead of B * (L + n_neg)) and let the object -> language
+    // attention read the shared rows behind each sample's L own ones.  Same products per row, same bits - from 1024 text rows on: below
+    // that the projection's 64x64 kernel splits K by the size of its grid, and the two forms would sum in different orders (nothing to gain there).
+    bool shared_neg = false;
+    if (g_lang_shared_neg && c->cfg.n_negative > 0 && Wn <= g_attn_split_min_keys && (long long)B * L + c->cfg.n_negative >= 1024) {
+        AttnDesc probe{};
+        probe.G = B; probe.H = H; probe.DH = DH; probe.Sq = N * Tp; probe.Sk = Wn; probe.inner = 1; probe.k_private = L;
+        shared_neg = attention_shared_keys_supported(probe);
+    }
+    const long long lang_rows = shared_neg ? (long long)B * L + c->cfg.n_negative : (long long)B * Wn;
+    if (shared_neg) SOLA_TRY(launch_lang_concat_shared(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
+    else SOLA_TRY(launch_lang_concat(lang, W("negative_token.weight"), buf("lang"), buf("lbar"), B, L, c->cfg.n_negative, D, s));
+    SOLA_TRY(launch_cast_sp16_auto(buf("lang"), D, buf("lang_sp"), D, lang_rows, D, c->scal_pair(1), s));
 
     const float scale = 1.0f / sqrtf((float)DH);
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, int layer, int attn, int nprob, int rows, float* o0,
@@ -228,8 +242,11 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         return launch_group_norm(nd, s);
     };
     auto attention = [&](const float* q, const float* k, const float* v, int G, int Sq, int Sk, int inner, long long qo,
-                         long long qi, long long qr, long long ko, long long ki, long long kr, int in_sp16) -> int {
+                         long long qi, long long qr, long long ko, long long ki, long long kr, int in_sp16, int k_private = 0,
+                         long long k_shared_row = 0) -> int {
         AttnDesc ad{q, k, v, buf("attn"), D, D, D, D, G, H, DH, Sq, Sk, inner, qo, qi, qr, ko, ki, kr, scale, nullptr};
+        ad.k_private = k_private;
+        ad.k_shared_row = k_shared_row;
         ad.o_sp16 = 1;
         ad.in_sp16 = in_sp16;
         ad.guard = c->guard;
@@ -267,8 +284,9 @@ int sola_forward_fast_impl(SolaCtx* c, const float* obj, const float* lang, int 
         SOLA_TRY(gn(lp, 1, x_mot, nullptr, 1, B * N, 1, Tp, 0, 1, Tp));
         // (iii) object -> language attention (module.py:46-50)
         SOLA_TRY(linear3(x_mot, nullptr, nullptr, l, 2, 1, M, q, nullptr, nullptr, 0, o2l_sp));
-        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, B * Wn, buf("lk"), buf("lv"), nullptr, 1, o2l_sp, c->scal_pair(1) + 1));
-        SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, o2l_sp));
+        SOLA_TRY(linear3(buf("lang_sp"), buf("lang_sp"), nullptr, l, 2, 2, (int)lang_rows, buf("lk"), buf("lv"), nullptr, 1, o2l_sp, c->scal_pair(1) + 1));
+        if (shared_neg) SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)L, 0, 1, o2l_sp, L, (long long)B * L));
+        else SOLA_TRY(attention(q, buf("lk"), buf("lv"), B, N * Tp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, o2l_sp));
         SOLA_TRY(out_proj(l, 2, x_mot, 1));
         SOLA_TRY(gn(lp, 2, x_o2l, nullptr, last ? 0 : 1, B, 1, (long long)N * Tp, 0, 1, N * Tp));  // the score head reads f32
         xin = x_o2l;

@@ -191,12 +191,18 @@ struct AttnDesc {
     // o_cast_fmt 1: split-f16 pairs (rows of ldo floats) + optionally o_side = the hi halves once more as plain f16 rows (ldo halfs; the
     // backward's dW operand); 2 / 3: plain f16 / bfloat16 rows (ldo halfs).  Unscaled, bit-identical to launch_cast_sp16 / launch_cast_f16.
     // Only some shapes write it: the launch that did sets *o_cast_done (else the caller casts as before).
+    // optional (round 5, the few-keys shape of attn_res.hip only - check attention_shared_keys_supported): the keys j >= k_private of EVERY
+    // group are shared rows k_shared_row + (j - k_private) of k / v instead of rows of the group's own range - the object -> language
+    // attention's 32 negative tokens (module/module.py:146-147), whose key / value projections are the same for every sample
+    int k_private = 0;
+    long long k_shared_row = 0;
     void* o_cast = nullptr;
     void* o_side = nullptr;
     int o_cast_fmt = 0;
     bool* o_cast_done = nullptr;
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
+bool attention_shared_keys_supported(const AttnDesc& d);  // d.k_private / k_shared_row can be honoured (the launch then takes attn_res.hip's shape)
 
 struct AttnBwdDesc {
     const float *q, *k, *v, *o, *dout, *lse;
@@ -364,6 +370,8 @@ int launch_pos_encoding(const float* gauss, int D, int t_len, int max_len, float
 // lang_cat[b] = [lang[b] (L rows); neg (n_neg rows)], lbar[b] = mean over the W rows
 int launch_lang_concat(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D,
                        hipStream_t s);
+// out = [B * L text rows | n_neg negative rows] (the negative tokens once, not per sample), lbar as above
+int launch_lang_concat_shared(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D, hipStream_t s);
 // ragged: sample b has units[b] = (first input row, L_b, first output row, L_b + n_neg)
 int launch_lang_concat_ragged(const float* lang, const float* neg, float* out, float* lbar, int B, const int4* units, int n_neg,
                               int D, hipStream_t s);

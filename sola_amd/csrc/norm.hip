@@ -568,6 +568,29 @@ __global__ void lang_concat_kernel(const float* __restrict__ lang, const float* 
     *reinterpret_cast<float4*>(lbar + (long long)b * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
+// round 5: the same concatenation WITHOUT repeating the negative tokens per sample - out = [B * L text rows | n_neg negative rows]; the key /
+// value projections of the negative tokens are the same for every sample (module/module.py:146-147 repeats the table), so the projection
+// GEMM takes B * L + n_neg rows instead of B * (L + n_neg) and the attention reads the shared rows (AttnDesc::k_private).  lbar: unchanged
+// (the mean over the sample's L + n_neg tokens, summed in the same order).
+__global__ void lang_concat_shared_kernel(const float* __restrict__ lang, const float* __restrict__ neg, float* out, float* lbar, int B, int L,
+                                          int n_neg, int D) {
+    const int d4 = D >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d4) return;
+    const int b = i / d4, c = (i - b * d4) * 4;
+    const int W = L + n_neg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < W; ++w) {
+        const float4 v = w < L ? *reinterpret_cast<const float4*>(lang + ((long long)b * L + w) * D + c)
+                               : *reinterpret_cast<const float4*>(neg + (long long)(w - L) * D + c);
+        if (w < L) *reinterpret_cast<float4*>(out + ((long long)b * L + w) * D + c) = v;
+        else if (b == 0) *reinterpret_cast<float4*>(out + ((long long)B * L + (w - L)) * D + c) = v;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float inv = 1.f / (float)W;
+    *reinterpret_cast<float4*>(lbar + (long long)b * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
 // ragged batches: sample b reads L_b text rows from lang[units[b].x ..] and writes W_b = L_b + n_neg rows at out[units[b].z ..]
 __global__ void lang_concat_ragged_kernel(const float* __restrict__ lang, const float* __restrict__ neg, float* out, float* lbar,
                                           int B, const int4* __restrict__ units, int n_neg, int D) {
@@ -600,6 +623,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 }  // namespace
+
+int launch_lang_concat_shared(const float* lang, const float* neg, float* out, float* lbar, int B, int L, int n_neg, int D, hipStream_t s) {
+    SOLA_ARG(D % 4 == 0 && B > 0 && L > 0 && n_neg >= 0, "lang_concat_shared: bad arguments");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * ((double)B * (2.0 * L + n_neg) + n_neg) * D);
+    const int total = B * (D >> 2);
+    hipLaunchKernelGGL(lang_concat_shared_kernel, dim3((total + 255) / 256), dim3(256), 0, s, lang, neg, out, lbar, B, L, n_neg, D);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 int launch_lang_concat_ragged(const float* lang, const float* neg, float* out, float* lbar, int B, const int4* units, int n_neg,
                               int D, hipStream_t s) {

@@ -469,3 +469,26 @@ def test_norm_fused_into_the_conv_epilogue_matches_the_separate_launch():
     # shape): two correct evaluation orders differ by a few 1e-4; the absolute bar is test_batch_256_every_row_vs_oracle
     assert d_sm <= 6e-4 and d_st <= 6e-4, (d_sm, d_st)
     assert torch.equal(outs[1][0] > 0, outs[0][0] > 0) or float((outs[1][0] - outs[0][0]).abs()[(outs[1][0] > 0) != (outs[0][0] > 0)].max()) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(256, 64, 32, 16), (64, 16, 32, 16), (70, 33, 40, 24), (8, 64, 32, 5)])
+def test_negative_token_projections_shared_across_samples(full_fast, shape):
+    """Round 5 (sola_tune "lang_shared_neg"): the 32 negative tokens appended to every sample's text (module/module.py:146-147) have the
+    same key / value projections for every sample - the text-side GEMMs of the default forward take B * L + 32 rows instead of B * (L + 32)
+    and the object -> language attention reads the shared rows (AttnDesc::k_private).  Same products per row: logits and tokens are
+    BIT-identical to the repeated form (small batches keep the repeated form: the few-row GEMM's split over K depends on the row count)."""
+    from sola_amd import _lib
+    m, _ = full_fast
+    B, N, T, L = shape
+    inp = synth.make_inputs(synth.DEFAULT_MODEL_CFG, B, N, T, L, 17)
+    obj, lang = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
+    outs = []
+    try:
+        for v in (0, 1):
+            _lib.check(_lib.lib().sola_tune(b"lang_shared_neg", v), "tune")
+            with torch.no_grad():
+                sm, tok = m(obj, lang)
+            outs.append((sm.clone(), tok.clone()))
+    finally:
+        _lib.check(_lib.lib().sola_tune(b"lang_shared_neg", 1), "tune")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
