@@ -52,6 +52,14 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
         n_smp += int(obj.shape[0])
         labels = (batch["labels"][tcfg["positive_metric"]] > tcfg["positive_threshold"]).float().to(device)
         lang, pos = text.encode(batch["expression"])
+        if train and world == 1:
+            # round 5: forward, both losses on the module's own negative tokens (train.py:92), loss.backward(), the gradient norms and the
+            # clipping (train.py:95-122) as ONE library call (module.train_step -> sola_train_step); bit-identical to the statements below
+            loss3, score, tokens = module.train_step(obj, lang, labels, pos, pw, temp, aw, max_grad_norm=max(float(tcfg["grad_clip_norm"]), 0.0))
+            optimizer.step()
+            sums += loss3.detach()
+            n += 1
+            continue
         with torch.set_grad_enabled(train):
             score, tokens = module(obj, lang)
             # train.py:92 (batch_size = lang_tokens.shape[0])
