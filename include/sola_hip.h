@@ -288,6 +288,16 @@ int sola_train_step(SolaCtx* ctx, const float* dev_object_tokens, const float* d
                     float max_grad_norm, float* dev_score_map, float* dev_score_tokens, float* dev_loss3, double* dev_grad_sq,
                     void* dev_train_workspace, size_t train_workspace_bytes, void* dev_backward_scratch, size_t backward_scratch_bytes,
                     void* dev_step_workspace, size_t step_workspace_bytes, void* stream);
+/* Gradient clipping + the AdamW update (train.py:121-125) in ONE multi-tensor launch, with torch.optim.AdamW(fused=True)'s own arithmetic
+ * (ATen/native/cuda/fused_adam_utils.cuh: double scalars, float tensors, the same expressions): bit-identical parameters and moments.
+ *   sola_adamw_bind: the optimizer's state tensors per parameter name (exp_avg, exp_avg_sq as float arrays of the parameter's size; step =
+ *     torch's per-parameter device float, kept in sync, or null).  Parameters and gradients are the context's own bindings
+ *     (sola_set_weight / sola_set_grad): the update writes the caller's parameter storage.  Bind again when a pointer changes.
+ *   sola_adamw_step: `step` = number of this update (1, 2, ...); max_grad_norm > 0 scales every gradient by min(1, max_norm / (sqrt(*dev_total_sq)
+ *     + 1e-6)) first (torch.nn.utils.clip_grad_norm_; the scaled gradient is written back), decided on the device. */
+int sola_adamw_bind(SolaCtx* ctx, const char* const* names, void* const* dev_exp_avg, void* const* dev_exp_avg_sq, void* const* dev_step, int n);
+int sola_adamw_step(SolaCtx* ctx, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, const double* dev_total_sq,
+                    float max_grad_norm, void* stream);
 /* ---- ragged training step: many (video, expression) samples of DIFFERENT shapes per optimizer step -------------------------
  * The reference trains at batch size 1 (configs/mevis/default.yaml:37; train.py:62-137: one forward, one backward, one AdamW
  * step per sample) because every sample has its own N tracks, T frames and L text tokens (dataloader.py:119-163,187-199).

@@ -191,6 +191,7 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
     for (hipEvent_t e : c->ev_side)
         if (e) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->adam_tab) (void)hipFree(c->adam_tab);
     delete c;
     return SOLA_OK;
 }

@@ -124,6 +124,7 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
         for (int i = 0; i < 5; ++i) enc_keep += z.rows[i + 1] * (size_t)c->conv[i].cout + 64;
         a.add("dwkeep", (size_t)c->cfg.n_layers * (12 * M * D + 2 * BW * D + 7 * 64) + enc_keep);  // per layer: 3 dres + 3 dqkv (3D wide) + dlkv
         a.add("wtkeep", (size_t)c->cfg.n_layers * 12 * D * D + ws_total + 64);          // every transposed weight block of the dX GEMMs (layers + encoder)
+        a.add("gnkeep", (size_t)(3 * c->cfg.n_layers + 5) * 2 * (inst_c_max + 64));     // private (dgamma, dbeta) partials of every GroupNorm backward: one grouped column-sum launch per bucket
     }
     {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather: the split-f16 / f16 modes, and every ragged batch
         // (the f32 path's transposed-conv gather needs one sequence length)
@@ -463,6 +464,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         }
         return launch_transpose(w, wt, n_out, k_in, k_in, n_cat, col_off, s);  // wt[k][col_off + n] = w[n][k]
     };
+    ColsumPairGroupDesc gn_q{};
+    float* gn_keep = (group && ar.off.count("gnkeep")) ? ar.get("gnkeep") : nullptr;
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
                       int leaky, const DropoutCfg* drop, const int4* units = nullptr) -> int {
@@ -475,10 +478,28 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         d.ntok = ntok; d.C = C; d.groups = groups; d.eps = 1e-5f; d.slope = 0.01f; d.leaky = leaky;
         SOLA_TRY(wait_side(0));  // a GroupNorm backward writes dres (layers) or the encoder's next dy: the side stream's readers are done
         SOLA_TRY(wait_side(2));
+        // round 5, few-sample backward: private partial buffers; the column sums of all norms of a bucket leave in ONE launch (flush_gn)
+        const bool defer = group && n_inst <= 256 && gn_q.n < 16 && ar.off.count("gnkeep") != 0;
+        if (defer) {
+            d.dgamma_part = gn_keep; gn_keep += ((size_t)n_inst * C + 63) & ~(size_t)63;
+            d.dbeta_part = gn_keep; gn_keep += ((size_t)n_inst * C + 63) & ~(size_t)63;
+        }
         SOLA_TRY(launch_group_norm_bwd(d, s));
+        if (defer) {
+            const int e = gn_q.n++;
+            gn_q.in0[e] = d.dgamma_part; gn_q.in1[e] = d.dbeta_part; gn_q.out0[e] = G(wname + ".weight"); gn_q.out1[e] = G(wname + ".bias");
+            gn_q.rows[e] = n_inst; gn_q.cols[e] = C;
+            return SOLA_OK;
+        }
         float* cs = ar.get("colsum");
         const size_t csb = ar.total - ar.off.at("colsum");
         return launch_colsum_pair(ar.get("gpart"), ar.get("bpart"), G(wname + ".weight"), G(wname + ".bias"), n_inst, C, C, cs, csb, s);
+    };
+    auto flush_gn = [&]() -> int {
+        if (gn_q.n == 0) return SOLA_OK;
+        SOLA_TRY(launch_colsum_pair_group(gn_q, s));
+        gn_q.n = 0;
+        return SOLA_OK;
     };
 
     // ---- score head -------------------------------------------------------------------------------------------
@@ -650,6 +671,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     if (group) {  // the deferred weight gradients of every layer: one launch; all layer buckets are final behind it
         wt = ar.get("wt");  // the encoder's dX GEMMs transpose into the shared buffer again
         SOLA_TRY(flush_group());
+        SOLA_TRY(flush_gn());  // the layers' norm parameter gradients
         for (int l = c->cfg.n_layers - 1; l > 0; --l) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));
     }
 
@@ -776,6 +798,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     }
     // weight-standardisation backward for all six convs
     if (group) SOLA_TRY(flush_group());  // the encoder's deferred weight gradients
+    SOLA_TRY(flush_gn());                // ... and its norms' parameter gradients
     SOLA_TRY(join_side());  // dwstd is the side stream's
     {
         WsBwdLayer layers[6];

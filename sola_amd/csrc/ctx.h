@@ -137,6 +137,10 @@ struct SolaCtx {
         int n_groups = 0;
         size_t sq_scratch = 0;
     } step;
+    // sola_adamw_bind / sola_adamw_step (train_step.hip): device table of (param, grad, exp_avg, exp_avg_sq, step) records, ctx-owned
+    void* adam_tab = nullptr;
+    int adam_n = 0, adam_blocks = 0;
+    double adam_bytes = 0.0;
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
     // the seed used by the last sola_forward_train is kept for sola_backward
     float p_drop_encoder = 0.f, p_drop_attention = 0.f;

@@ -356,6 +356,50 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     }
 }
 
+
+// up to 16 (dgamma, dbeta) pairs of column sums in ONE launch (round 5, few-sample backward: the 11 GroupNorm backwards of a one-sample step
+// each ended in a launch_colsum_pair of ~5 us; deferred - every norm keeps private partial buffers - they are one launch per bucket).  Same
+// per-column arithmetic as colsum_kernel with one chunk (rows r = lane, lane + 4, ... in eight partial sums, the four row lanes combined in
+// a fixed order): the same bits as launch_colsum_pair on <= 256 rows.
+constexpr int CSG_MAX = 16;
+struct ColsumGroupArgs {
+    const float* in0[CSG_MAX];
+    const float* in1[CSG_MAX];
+    float* out0[CSG_MAX];
+    float* out1[CSG_MAX];
+    int rows[CSG_MAX], cols[CSG_MAX], first_block[CSG_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void colsum_pair_group_kernel(const ColsumGroupArgs a) {
+    __shared__ float red[4][64];
+    int e = 0;
+    for (int j = 1; j < a.n; ++j)
+        if ((int)blockIdx.x >= a.first_block[j]) e = j;
+    const int lb = (int)blockIdx.x - a.first_block[e];
+    const int cb = (a.cols[e] + 63) / 64;
+    const int which = lb / cb;
+    const int c = (lb - which * cb) * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int cols = a.cols[e], ld = cols, r_end = a.rows[e];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    if (c < cols) {
+        const float* p = (which ? a.in1[e] : a.in0[e]) + c;
+        int r = rl;
+        for (; r + 28 < r_end; r += 32) {
+            s0 += p[(long long)r * ld]; s1 += p[(long long)(r + 4) * ld]; s2 += p[(long long)(r + 8) * ld]; s3 += p[(long long)(r + 12) * ld];
+            s4 += p[(long long)(r + 16) * ld]; s5 += p[(long long)(r + 20) * ld]; s6 += p[(long long)(r + 24) * ld]; s7 += p[(long long)(r + 28) * ld];
+        }
+        for (; r < r_end; r += 4) s0 += p[(long long)r * ld];
+    }
+    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * 1.0f;
+        (which ? a.out1[e] : a.out0[e])[c] = v;
+    }
+}
+
 }  // namespace
 
 int g_gemm_tn_nw8 = 1;  // sola_tune "gemm_tn_nw8": the exact-f32 weight-gradient kernels with eight waves per block (0 = four; A/B)
@@ -581,6 +625,27 @@ int launch_colsum_pair(const float* in0, const float* in1, float* out0, float* o
     const int wide = 2 * cols;
     hipLaunchKernelGGL(colsum_kernel, dim3((wide + 63) / 64, 1, 1), dim3(256), 0, s, scratch, out0, chunks, wide, wide, chunks, 1.0f, 0,
                        (long long)chunks * wide, out1, (long long)cols);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+
+int launch_colsum_pair_group(const ColsumPairGroupDesc& d, hipStream_t s) {
+    SOLA_ARG(d.n >= 1 && d.n <= CSG_MAX, "colsum_pair_group: %d pairs", d.n);
+    ColsumGroupArgs a;
+    a.n = d.n;
+    int blocks = 0;
+    double bytes = 0;
+    for (int e = 0; e < d.n; ++e) {
+        SOLA_ARG(d.in0[e] && d.in1[e] && d.out0[e] && d.out1[e] && d.rows[e] > 0 && d.rows[e] <= 256 && d.cols[e] > 0, "colsum_pair_group: pair %d (rows %d)", e, d.rows[e]);
+        a.in0[e] = d.in0[e]; a.in1[e] = d.in1[e]; a.out0[e] = d.out0[e]; a.out1[e] = d.out1[e]; a.rows[e] = d.rows[e]; a.cols[e] = d.cols[e];
+        a.first_block[e] = blocks;
+        blocks += 2 * ((d.cols[e] + 63) / 64);
+        bytes += 8.0 * d.rows[e] * d.cols[e];
+    }
+    a.first_block[d.n] = blocks;
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
+    hipLaunchKernelGGL(colsum_pair_group_kernel, dim3(blocks), dim3(256), 0, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

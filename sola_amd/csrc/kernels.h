@@ -165,6 +165,16 @@ int launch_colsum(const float* in, float* out, int segments, int seg_rows, int c
 // out0 = column sums of in0, out1 = column sums of in1 (both [seg_rows][ld] views of `cols` columns) in the launches of one call
 int launch_colsum_pair(const float* in0, const float* in1, float* out0, float* out1, int seg_rows, int cols, int ld, float* scratch,
                        size_t scratch_bytes, hipStream_t s);
+// up to 16 such pairs over <= 256 rows each in one launch (the few-sample backward's GroupNorm parameter gradients, deferred); bit-identical to launch_colsum_pair
+struct ColsumPairGroupDesc {
+    const float* in0[16];
+    const float* in1[16];
+    float* out0[16];
+    float* out1[16];
+    int rows[16], cols[16];
+    int n;
+};
+int launch_colsum_pair_group(const ColsumPairGroupDesc& d, hipStream_t s);
 
 // ---- attention core (attn.hip) ---------------------------------------------------------------------------------
 struct AttnDesc {
@@ -291,6 +301,12 @@ size_t mt_sqnorm_scratch_bytes(int n, const long long* numel);
 int launch_mt_sqnorm(const float* const* ptrs, const long long* numel, const int* group, int n, int n_groups, double* out,
                      void* scratch, size_t scratch_bytes, hipStream_t s);
 int launch_mt_clip(float* const* ptrs, const long long* numel, int n, const double* total_sq, float max_norm, hipStream_t s);
+// clip + AdamW (torch's fused arithmetic) in one multi-tensor launch over a device-side table of (param, grad, exp_avg, exp_avg_sq, step) records
+size_t mt_adam_entry_bytes();
+void mt_adam_entry_fill(void* host_entry, float* p, float* g, float* m, float* v, float* step, long long numel, int first_block);
+int mt_adam_blocks(long long numel);
+int launch_mt_clip_adamw(const void* tab_dev, int n, int blocks, double bytes, const double* total_sq, float max_norm, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, float step, hipStream_t s);
 
 // ---- normalisation / elementwise (norm.hip) --------------------------------------------------------------------
 struct WsLayer {

@@ -100,6 +100,92 @@ __global__ __launch_bounds__(256) void mt_clip_kernel(const MtScaleArgs a, const
         if (base + i < n) p[base + i] *= coef;
 }
 
+
+// ---- clip + AdamW in one multi-tensor pass (round 5) ---------------------------------------------------------------------------------
+// train.py:121-125 at the reference's batch size is ~130 launches of 2-25 us; clipping (one pass over the 132 MB of gradients) and torch's
+// fused AdamW (three launches) are six of them.  Here: ONE launch that scales the gradient by the clip coefficient (the decision taken in
+// the kernel from the device-side norm, as mt_clip_kernel does; the scaled gradient is written back, so .grad holds what torch's path
+// leaves there) and applies the AdamW update with torch's own arithmetic - torch/include/ATen/native/cuda/fused_adam_utils.cuh, adam_math
+// with ADAM_MODE::ADAMW, no amsgrad / maximize / grad scaler: the scalars are doubles, the tensors floats, the expressions below are
+// written with the same types and in the same order, so the updated weights and moments are bit-identical to torch.optim.AdamW(fused=True)
+// (tests/test_gpu_backward.py::test_fused_clip_adamw_equals_torch).  The table of tensor pointers lives in device memory (84 tensors x
+// four pointers exceed what a launch should carry as arguments); `step` is the step count AFTER this update (torch increments first).
+struct AdamEntry {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    float* step;  // torch's per-parameter step tensor (device float), kept in sync: set to `step`
+    long long numel;
+    int first_block;
+    int pad;
+};
+__global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __restrict__ tab, int n, const double* __restrict__ total_sq, float max_norm,
+                                                             double lr, double beta1, double beta2, double eps, double weight_decay, float step) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AdamEntry e = tab[lo];
+    float coef = 1.f;
+    if (max_norm > 0.f) {  // mt_clip_kernel's coefficient
+        const double tn = sqrt(*total_sq);
+        coef = (float)fmin(1.0, (double)max_norm / (tn + 1e-6));
+    }
+    const bool clip = coef < 1.f;
+    // torch: bias_correction1 = 1 - pow(beta1, step), bias_correction2_sqrt = sqrt(1 - pow(beta2, step)), computed in double, used as floats
+    const float bias_correction1 = (float)(1 - pow(beta1, (double)step));
+    const float bias_correction2_sqrt = (float)sqrt(1 - pow(beta2, (double)step));
+    const long long base = (long long)(blockIdx.x - e.first_block) * MT_CHUNK;
+    if (base == 0 && threadIdx.x == 0 && e.step) *e.step = step;
+    for (int i = threadIdx.x * 4; i < MT_CHUNK; i += 1024) {
+        const long long idx = base + i;
+        if (idx >= e.numel) break;
+        const int cnt = (int)((e.numel - idx) < 4 ? (e.numel - idx) : 4);
+        float pr[4], gr[4], mr[4], vr[4];
+        const bool vec = cnt == 4 && ((reinterpret_cast<uintptr_t>(e.p + idx) | reinterpret_cast<uintptr_t>(e.g + idx) | reinterpret_cast<uintptr_t>(e.m + idx) |
+                                       reinterpret_cast<uintptr_t>(e.v + idx)) & 15) == 0;
+        if (vec) {
+            const float4 a = *reinterpret_cast<const float4*>(e.p + idx), b = *reinterpret_cast<const float4*>(e.g + idx);
+            const float4 c = *reinterpret_cast<const float4*>(e.m + idx), d = *reinterpret_cast<const float4*>(e.v + idx);
+            pr[0] = a.x; pr[1] = a.y; pr[2] = a.z; pr[3] = a.w; gr[0] = b.x; gr[1] = b.y; gr[2] = b.z; gr[3] = b.w;
+            mr[0] = c.x; mr[1] = c.y; mr[2] = c.z; mr[3] = c.w; vr[0] = d.x; vr[1] = d.y; vr[2] = d.z; vr[3] = d.w;
+        } else {
+            for (int j = 0; j < cnt; ++j) { pr[j] = e.p[idx + j]; gr[j] = e.g[idx + j]; mr[j] = e.m[idx + j]; vr[j] = e.v[idx + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= cnt) break;
+            float param = pr[j];
+            float grad = gr[j];
+            if (clip) grad *= coef;
+            gr[j] = grad;
+            float exp_avg = mr[j];
+            float exp_avg_sq = vr[j];
+            if (weight_decay != 0) param -= lr * weight_decay * param;
+            exp_avg = beta1 * exp_avg + (1 - beta1) * grad;
+            exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad * grad;
+            const float step_size = lr / bias_correction1;
+            float denom;
+            denom = (sqrtf(exp_avg_sq) / bias_correction2_sqrt) + eps;
+            param -= step_size * exp_avg / denom;
+            pr[j] = param; mr[j] = exp_avg; vr[j] = exp_avg_sq;
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(e.p + idx) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            *reinterpret_cast<float4*>(e.m + idx) = make_float4(mr[0], mr[1], mr[2], mr[3]);
+            *reinterpret_cast<float4*>(e.v + idx) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+            if (clip) *reinterpret_cast<float4*>(e.g + idx) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+        } else {
+            for (int j = 0; j < cnt; ++j) {
+                e.p[idx + j] = pr[j]; e.m[idx + j] = mr[j]; e.v[idx + j] = vr[j];
+                if (clip) e.g[idx + j] = gr[j];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 size_t mt_sqnorm_scratch_bytes(int n, const long long* numel) {
@@ -153,6 +239,24 @@ int launch_mt_clip(float* const* ptrs, const long long* numel, int n, const doub
     a.first_block[n] = blocks;
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
     hipLaunchKernelGGL(mt_clip_kernel, dim3(blocks), dim3(256), 0, s, a, total_sq, max_norm);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+
+// tab_dev: n AdamEntry records in device memory (built by the caller: api.hip sola_adamw_bind); blocks = the table's total chunk count
+size_t mt_adam_entry_bytes() { return sizeof(AdamEntry); }
+void mt_adam_entry_fill(void* host_entry, float* p, float* g, float* m, float* v, float* step, long long numel, int first_block) {
+    AdamEntry* e = static_cast<AdamEntry*>(host_entry);
+    e->p = p; e->g = g; e->m = m; e->v = v; e->step = step; e->numel = numel; e->first_block = first_block; e->pad = 0;
+}
+int mt_adam_blocks(long long numel) { return (int)((numel + MT_CHUNK - 1) / MT_CHUNK); }
+int launch_mt_clip_adamw(const void* tab_dev, int n, int blocks, double bytes, const double* total_sq, float max_norm, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, float step, hipStream_t s) {
+    SOLA_ARG(tab_dev && n > 0 && blocks > 0 && step >= 1.f && (max_norm <= 0.f || total_sq), "clip_adamw: bad arguments");
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
+    hipLaunchKernelGGL(mt_clip_adamw_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const AdamEntry*>(tab_dev), n, total_sq, max_norm, lr, beta1, beta2, eps,
+                       weight_decay, step);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

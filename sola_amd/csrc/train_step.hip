@@ -130,3 +130,49 @@ extern "C" int sola_train_step(SolaCtx* c, const float* obj, const float* lang, 
         return SOLA_ERR_ARG;
     }
 }
+
+
+// ---- clip + AdamW in one launch (optim.hip: mt_clip_adamw_kernel) --------------------------------------------------------------------
+// bind: the optimizer's state tensors by parameter name (torch.optim.AdamW keeps exp_avg / exp_avg_sq / step per parameter; with fused=True
+// the step is a device float).  The parameter and gradient pointers are the context's own bindings (sola_set_weight / sola_set_grad): the
+// update writes the CALLER's parameter storage in place.  Bind again whenever one of the pointers changes.
+extern "C" int sola_adamw_bind(SolaCtx* c, const char* const* names, void* const* exp_avg, void* const* exp_avg_sq, void* const* step, int n) {
+    SOLA_ARG(c && names && exp_avg && exp_avg_sq && n > 0 && n <= 128, "adamw_bind: bad argument");
+    try {
+        const size_t eb = mt_adam_entry_bytes();
+        std::vector<char> host((size_t)n * eb);
+        int blocks = 0;
+        double bytes = 0;
+        for (int i = 0; i < n; ++i) {
+            auto it = c->index.find(names[i]);
+            SOLA_ARG(it != c->index.end(), "adamw_bind: unknown parameter '%s'", names[i]);
+            const Weight& w = c->weights[it->second];
+            SOLA_ARG(w.ptr && w.grad && exp_avg[i] && exp_avg_sq[i], "adamw_bind: '%s' needs its weight, gradient and both moments bound", names[i]);
+            mt_adam_entry_fill(host.data() + (size_t)i * eb, const_cast<float*>(w.ptr), w.grad, static_cast<float*>(exp_avg[i]), static_cast<float*>(exp_avg_sq[i]),
+                               step ? static_cast<float*>(step[i]) : nullptr, w.numel, blocks);
+            blocks += mt_adam_blocks(w.numel);
+            bytes += 28.0 * (double)w.numel;  // p, g, m, v in; p, m, v out
+        }
+        if (c->adam_tab && c->adam_n < n) { (void)hipFree(c->adam_tab); c->adam_tab = nullptr; }
+        if (!c->adam_tab) SOLA_HIP(hipMalloc(&c->adam_tab, (size_t)n * eb));
+        SOLA_HIP(hipMemcpy(c->adam_tab, host.data(), (size_t)n * eb, hipMemcpyHostToDevice));
+        c->adam_n = n; c->adam_blocks = blocks; c->adam_bytes = bytes;
+        return SOLA_OK;
+    } catch (const std::exception& e) {
+        sola_set_error("adamw_bind: %s", e.what());
+        return SOLA_ERR_ARG;
+    }
+}
+
+// step = the update's number (1 for the first); dev_total_sq = the gradients' total sum of squares on the device (sola_train_step's
+// dev_grad_sq + n_groups) when max_grad_norm > 0, else ignored.  Invalidate derived weight copies afterwards (sola_weights_changed).
+extern "C" int sola_adamw_step(SolaCtx* c, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, const double* dev_total_sq,
+                               float max_grad_norm, void* stream_) {
+    SOLA_ARG(c && c->adam_tab && c->adam_n > 0, "adamw_step: sola_adamw_bind has not been called on this context");
+    SOLA_ARG(step >= 1 && step < (1 << 24), "adamw_step: step %lld (a float counts it exactly up to 2^24)", (long long)step);
+    SOLA_TRY(launch_mt_clip_adamw(c->adam_tab, c->adam_n, c->adam_blocks, c->adam_bytes, dev_total_sq, max_grad_norm, lr, beta1, beta2, eps, weight_decay, (float)step,
+                                  as_stream(stream_)));
+    c->ws_dirty = true;
+    c->lin16_dirty = true;
+    return SOLA_OK;
+}

@@ -583,7 +583,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         return grads
 
     def train_step(self, object_tokens, lang_tokens, labels, pos_tokens, positive_weight=1.5, temperature=0.07, alignment_weight=0.3,
-                   max_grad_norm=0.0):
+                   max_grad_norm=0.0, optimizer=None):
         """The body of the reference's training loop (train.py:62-125: forward, weighted BCE + alignment loss on the module's own negative
         tokens, ``loss.backward()``, ``get_grad_norm_dict()``, gradient clipping) as ONE library call (sola_train_step): the ~110 launches
         of a one-sample step are enqueued from C++ instead of call by call through autograd and ctypes (1.6-2.4 ms of host time per step,
@@ -594,7 +594,11 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         Returns ``(loss3, score_map, score_tokens)`` - ``loss3 = [total, bce, alignment]`` on the device, no host sync.  Every parameter's
         ``.grad`` is (a view of) the gradient arena afterwards, so ``optimizer.step()`` follows directly; no ``zero_grad`` is needed
         (the backward overwrites).  ``max_grad_norm <= 0``: no clipping (multi-GPU: all-reduce first, then ``clip_grad_norm_``).
-        ``get_grad_norm_dict()`` after the call reads the step's own reduction (one host sync)."""
+        ``get_grad_norm_dict()`` after the call reads the step's own reduction (one host sync).
+
+        ``optimizer``: a ``torch.optim.AdamW`` over exactly this module's parameters (one param group, no amsgrad / maximize) - the clipping and
+        the update then run as ONE more launch here (sola_adamw_step: torch's fused AdamW arithmetic, bit-identical parameters and moments; the
+        optimizer's own state tensors are updated, ``optimizer.step()`` must NOT be called for this step)."""
         require_cuda(object_tokens, lang_tokens, labels, pos_tokens)
         self._check_inputs(object_tokens, lang_tokens)
         B, N, T, _d = object_tokens.shape
@@ -640,8 +644,9 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         score_tokens = torch.empty((B, N, D), device=dev, dtype=torch.float32)
         loss3 = torch.empty(3, device=dev, dtype=torch.float32)
         grad_sq = torch.empty(n_groups + 1, device=dev, dtype=torch.float64)
+        adam = self._adamw_plan(optimizer) if optimizer is not None else None
         check(lib().sola_train_step(self._ctx, ptr(obj), ptr(lang), B, N, T, L, ptr(lab), ptr(pos), float(positive_weight), float(temperature),
-                                    float(alignment_weight), float(max_grad_norm), ptr(score_map), ptr(score_tokens), ptr(loss3), ptr(grad_sq),
+                                    float(alignment_weight), 0.0 if adam is not None else float(max_grad_norm), ptr(score_map), ptr(score_tokens), ptr(loss3), ptr(grad_sq),
                                     ptr(self._train_ws), self._train_ws.numel(), ptr(self._bwd_ws), self._bwd_ws.numel(), ptr(sw), sw.numel(),
                                     current_stream(dev)), "sola_train_step")
         self._train_inputs = (obj, lang)
@@ -651,6 +656,11 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._grads_in_arena = True
         self._step_grad_sq = grad_sq  # sums of squares of the UNclipped gradients (module/module.py:164-199 reports their roots)
         self._last_grad_sq = None
+        if adam is not None:  # clip + AdamW in one launch; the kernel reads the total norm where the step left it
+            g = optimizer.param_groups[0]
+            self._adam_step += 1
+            check(lib().sola_adamw_step(self._ctx, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                        self._adam_step, C.c_void_p(grad_sq.data_ptr() + 8 * n_groups), float(max_grad_norm), current_stream(dev)), "sola_adamw_step")
         # every parameter's .grad = its slot of the arena (persistent views: nothing to do from the second step on)
         lo, hi = self._grad_arena.data_ptr(), self._grad_arena.data_ptr() + 4 * self._grad_arena.numel()
         for key, p in named:
@@ -658,6 +668,38 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             if g is None or not (lo <= g.data_ptr() < hi):
                 p.grad = self._grad_view(key)
         return loss3, score_map, score_tokens
+
+    def _adamw_plan(self, opt):
+        """Bind a torch.optim.AdamW's state tensors to the context (sola_adamw_bind) - once, and again when a pointer changed."""
+        named = self._params()
+        if type(opt) is not torch.optim.AdamW or len(opt.param_groups) != 1:
+            raise SolaError("train_step(optimizer=...): a torch.optim.AdamW with one parameter group")
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or not isinstance(g["lr"], float):
+            raise SolaError("train_step(optimizer=...): amsgrad / maximize / capturable / differentiable / tensor learning rates are not supported")
+        if [id(p) for p in g["params"]] != [id(p) for _, p in named]:
+            raise SolaError("train_step(optimizer=...): the optimizer must hold exactly this module's parameters, in parameters() order")
+        for _, p in named:  # torch creates the state at its first step(): the same tensors, the same way (Adam._init_group, fused)
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        sig = (id(opt), id(self._ctx), self._grad_bound) + tuple((p.data_ptr(), opt.state[p]["exp_avg"].data_ptr(), opt.state[p]["exp_avg_sq"].data_ptr(),
+                                                                  opt.state[p]["step"].data_ptr()) for _, p in named)
+        if getattr(self, "_adam_sig", None) != sig:
+            steps = [opt.state[p]["step"] for _, p in named]
+            if any(not s_.is_cuda or s_.dtype != torch.float32 for s_ in steps):
+                raise SolaError("train_step(optimizer=...): the optimizer's step counters must be device float32 scalars (torch.optim.AdamW(fused=True) or fresh state)")
+            first = float(steps[0].item())  # one host sync, at (re)binding only
+            n = len(named)
+            names = (C.c_char_p * n)(*[k.encode() for k, _ in named])
+            vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            check(lib().sola_adamw_bind(self._ctx, names, vp([opt.state[p]["exp_avg"] for _, p in named]), vp([opt.state[p]["exp_avg_sq"] for _, p in named]),
+                                        vp(steps), n), "sola_adamw_bind")
+            self._adam_sig = sig
+            self._adam_step = int(first)
+        return True
 
     def step_grad_norm_dict(self):
         """``get_grad_norm_dict()`` (module/module.py:164-199) of the last ``train_step``: the norms of its gradients BEFORE clipping, from

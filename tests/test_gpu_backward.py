@@ -744,3 +744,33 @@ def test_train_step_call_equals_the_autograd_path(shape, train_mode):
     if B == 1:
         for (k, p), (_k2, p2) in zip(models[0]._params(), models[1]._params()):
             assert torch.equal(p.detach(), p2.detach()), k
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 1.0, 1e-3])
+def test_fused_clip_adamw_equals_torch(max_norm):
+    """Round 5 (sola_adamw_step, module.train_step(optimizer=...)): gradient clipping + the AdamW update as ONE multi-tensor launch with torch's
+    fused arithmetic (double scalars, float tensors, the expressions of ATen/native/cuda/fused_adam_utils.cuh) against
+    module.train_step + torch.optim.AdamW(fused=True).step(): after four steps (weight decay on; clipping off, rarely active, always active)
+    every parameter, both moments, the step counters and the gradients left in .grad are BIT-identical."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, 1, 64, 32, 16, 5).items()}
+    ms, opts = [], []
+    for _ in range(2):
+        m, _sd = build(cfg)
+        m.train(True)
+        m.precision = "f32"
+        ms.append(m)
+        opts.append(torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.05, betas=(0.9, 0.98), fused=True))
+    for step in range(4):
+        torch.manual_seed(77 + step)
+        ms[0].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=max_norm)
+        opts[0].step()
+        torch.manual_seed(77 + step)
+        ms[1].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=max_norm, optimizer=opts[1])
+        torch.cuda.synchronize()
+        for (k, p), (_k, q) in zip(ms[0]._params(), ms[1]._params()):
+            assert torch.equal(p.detach(), q.detach()), (step, k, "parameter")
+            assert torch.equal(p.grad, q.grad), (step, k, "gradient")
+            sa, sb = opts[0].state[p], opts[1].state[q]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (step, k, "moments")
+            assert float(sa["step"]) == float(sb["step"]) == step + 1, (step, k)

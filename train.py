@@ -55,8 +55,9 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
         if train and world == 1:
             # round 5: forward, both losses on the module's own negative tokens (train.py:92), loss.backward(), the gradient norms and the
             # clipping (train.py:95-122) as ONE library call (module.train_step -> sola_train_step); bit-identical to the statements below
-            loss3, score, tokens = module.train_step(obj, lang, labels, pos, pw, temp, aw, max_grad_norm=max(float(tcfg["grad_clip_norm"]), 0.0))
-            optimizer.step()
+            # (clipping + the AdamW update: one more launch with torch's fused arithmetic on the optimizer's own state tensors - sola_adamw_step)
+            loss3, score, tokens = module.train_step(obj, lang, labels, pos, pw, temp, aw, max_grad_norm=max(float(tcfg["grad_clip_norm"]), 0.0),
+                                                     optimizer=optimizer)
             sums += loss3.detach()
             n += 1
             continue
