@@ -256,8 +256,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
         neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
         loss3 = track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)
         loss3[0].backward()
-        m.clip_grad_norm_(1.0)
-        opt.step()
+        m.optimizer_step(opt, 1.0)  # clip + AdamW as one launch with torch's fused arithmetic (sola_adamw_step; bit-identical to clip_grad_norm_ + opt.step())
 
     fl = synth.flops_per_sample(cfg, N, T, L)
     res = {"batch": B, "steps": steps, "unit": "samples/s",
@@ -324,8 +323,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
         flat, tok, offs, counts = m.last_ragged
         loss = track_selection_losses_ragged(flat, tok, rlabels, rpos, m.negative_token.weight, offs, counts, POS_W, TEMP, ALIGN_W)
         loss[:, 0].mean().backward()
-        m.clip_grad_norm_(1.0)
-        opt.step()
+        m.optimizer_step(opt, 1.0)  # clip + AdamW as one launch with torch's fused arithmetic (sola_adamw_step; bit-identical to clip_grad_norm_ + opt.step())
 
     rag = {"samples_per_step": S, "shapes": "N~U[8,80], T~U[20,200], L~U[4,24], seed 2024", "unit": "samples/s",
            "object_token_rows": int(sum(o.shape[0] * o.shape[1] for o in objs)),

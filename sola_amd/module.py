@@ -669,6 +669,38 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
                 p.grad = self._grad_view(key)
         return loss3, score_map, score_tokens
 
+    def optimizer_step(self, optimizer, max_grad_norm=0.0):
+        """``clip_grad_norm_(max_grad_norm)`` + ``optimizer.step()`` (train.py:121-125) as ONE launch for a ``torch.optim.AdamW`` over this
+        module's parameters: the gradients' norm is reduced on the device (or taken from a ``get_grad_norm_dict()`` of these very gradients),
+        the clip decision, the scaling and the update happen in sola_adamw_step with torch's fused arithmetic (bit-identical parameters and
+        moments; the optimizer's own state tensors are updated).  Call it where the loop called ``clip_grad_norm_`` and ``optimizer.step()``
+        - after the backward and, with several ranks, after the gradient all-reduce.  Needs the gradients in the module's arena (a
+        ``zero_grad(set_to_none=True)`` loop, the default)."""
+        named = self._params()
+        if any(p.grad is None for _, p in named) or not getattr(self, "_grads_in_arena", False):
+            raise SolaError("optimizer_step: every parameter needs a gradient in the module's arena (run the backward after zero_grad(set_to_none=True))")
+        base = self._grad_arena.data_ptr()
+        for key, p in named:  # a gradient autograd accumulated into a tensor of its own (negative_token.weight: two contributions) goes back to its slot
+            o, _n, _shape = self._grad_spans[key]
+            if p.grad.data_ptr() != base + 4 * o:
+                view = self._grad_view(key)
+                view.copy_(p.grad)
+                p.grad = view
+        grads = [p.grad for _, p in named]
+        dev = grads[0].device
+        self._adamw_plan(optimizer)
+        total = None
+        if max_grad_norm and max_grad_norm > 0:
+            cached = getattr(self, "_last_grad_sq", None)
+            sq = cached[0] if cached is not None and cached[1] == self._grad_tag(grads) else self._grad_sq_device()
+            total = sq[-1:]
+        g = optimizer.param_groups[0]
+        self._adam_step += 1
+        check(lib().sola_adamw_step(self._ctx, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                    self._adam_step, ptr(total), float(max_grad_norm or 0.0), current_stream(dev)), "sola_adamw_step")
+        self._last_grad_sq = None
+        self._weights_touched = True
+
     def _adamw_plan(self, opt):
         """Bind a torch.optim.AdamW's state tensors to the context (sola_adamw_bind) - once, and again when a pointer changed."""
         named = self._params()

@@ -774,3 +774,35 @@ def test_fused_clip_adamw_equals_torch(max_norm):
             sa, sb = opts[0].state[p], opts[1].state[q]
             assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (step, k, "moments")
             assert float(sa["step"]) == float(sb["step"]) == step + 1, (step, k)
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 0.5])
+def test_optimizer_step_after_an_autograd_backward_equals_torch(max_norm):
+    """module.optimizer_step(optimizer, max_grad_norm) - clip + AdamW as one launch behind a backward that went through autograd (uniform
+    batch of three samples; negative_token.weight's gradient is accumulated by autograd from two contributions) - against
+    clip_grad_norm_ + torch's fused AdamW: bit-identical parameters after three steps."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    B = 3
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, B, 16, 32, 12, 9).items()}
+    ms, opts = [], []
+    for _ in range(2):
+        m, _sd = build(cfg)
+        m.precision = "f32"
+        ms.append(m)
+        opts.append(torch.optim.AdamW(m.parameters(), lr=2e-4, fused=True))
+    for step in range(3):
+        for i, (m, opt) in enumerate(zip(ms, opts)):
+            opt.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                sm, st = m(inp["object_tokens"], inp["lang_tokens"])
+                neg = m.negative_token.weight.clone().unsqueeze(0).repeat(B, 1, 1)
+                track_selection_losses(sm, st, inp["labels"], inp["pos_tokens"], neg, POS_W, TEMP, ALIGN_W)[0].backward()
+            if i == 0:
+                if max_norm > 0:
+                    m.clip_grad_norm_(max_norm)
+                opt.step()
+            else:
+                m.optimizer_step(opt, max_norm)
+        torch.cuda.synchronize()
+        for (k, p), (_k, q) in zip(ms[0]._params(), ms[1]._params()):
+            assert torch.equal(p.detach(), q.detach()), (step, k)

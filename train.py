@@ -70,11 +70,9 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
             optimizer.zero_grad(set_to_none=True)
             loss3[0].backward()
             sdist.allreduce_gradient_arena(module, world)  # in place on the flat arena, bucket by bucket, overlapping the backward
-            if tcfg["grad_clip_norm"] > 0:
-                # train.py:120-122 (norm dict, then clip if the total exceeds the threshold): the norms are reduced and the
-                # decision is taken on the device, so the step has no host sync (the reference does 83 .item() calls here)
-                module.clip_grad_norm_(tcfg["grad_clip_norm"])
-            optimizer.step()
+            # train.py:120-125 (norm, clip if the total exceeds the threshold, AdamW): the norm is reduced and the decision taken on the
+            # device (the reference does 83 .item() calls here), and clip + update are ONE launch with torch's fused AdamW arithmetic
+            module.optimizer_step(optimizer, max(float(tcfg["grad_clip_norm"]), 0.0))
         else:
             pred = (torch.sigmoid(score) > tcfg["pred_threshold"]).float()
             counts += torch.stack([(pred * labels).sum(), (pred * (1 - labels)).sum(), ((1 - pred) * labels).sum(),
@@ -111,9 +109,7 @@ def run_train_ragged(module, text, batches, tcfg, device, optimizer, world=1):
         optimizer.zero_grad(set_to_none=True)
         loss[:, 0].mean().backward()
         sdist.allreduce_gradient_arena(module, world)
-        if tcfg["grad_clip_norm"] > 0:
-            module.clip_grad_norm_(tcfg["grad_clip_norm"])
-        optimizer.step()
+        module.optimizer_step(optimizer, max(float(tcfg["grad_clip_norm"]), 0.0))  # clip + AdamW, one launch (bit-identical to clip_grad_norm_ + step)
         sums += loss.detach().sum(0)
         n += len(counts)
         n_smp += len(counts)
