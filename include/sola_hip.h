@@ -521,7 +521,8 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * attention backward: "attn_bwd_small" 1 (default) = one-pass kernel for <= 4 steps, "attn_bwd_blk" 1 (default) = block-shared
  * double-buffered staging (bit-identical to 0); GroupNorm: "gn_wide" 1024-thread shape for 64-128 KiB units, "gn_slices"
  * two-launch sliced shape for larger units, "gn_bwd_reg" register-resident backward; "bwd_dual_cast" 1 (default) = the
- * transposing cast of a gradient matrix also writes its row-major cast; "attn_bwd_fused" 1 (default) = the one-pass attention
+ * transposing cast of a gradient matrix also writes its row-major cast; "bwd_fused_bf16_cast" 1 (default) = bf16 storage: the
+ * statistics pass over a gradient matrix (bias sums) writes its bf16 cast as well - no max|x| pass, no scale; "attn_bwd_fused" 1 (default) = the one-pass attention
  * backward for units of <= 128 queries and keys and for chunked long query ranges, 0 = the two-pass kernels everywhere;
  * "attn_split_min_keys" (default 128) = units with more keys take the split-f16 attention on split q / k / v in precision 1;
  * "train_dw_f16" 1 (default) = weight-gradient products of the precision-1 training step on plain f16 operands;

@@ -15,6 +15,8 @@
 extern int g_train_split_min_rows;
 int g_bwd_dual_cast = 1;  // sola_tune "bwd_dual_cast": the transposing cast of a gradient matrix also writes its row-major cast (A/B)
 void sola_set_bwd_dual_cast(int v) { g_bwd_dual_cast = v; }
+int g_bwd_fused_bf16_cast = 1;  // sola_tune "bwd_fused_bf16_cast": bf16 storage - the gradient statistics pass is the cast as well (A/B)
+void sola_set_bwd_fused_bf16_cast(int v) { g_bwd_fused_bf16_cast = v; }
 
 // sola_tune "train_dw_f16" (default 1, round 3): in the split-f16 training step (precision 1) the weight-gradient products
 // dW = dY^T X run on PLAIN f16 casts of dY and X (one MFMA per product, f32 accumulation) instead of split pairs (three); forward and
@@ -360,15 +362,26 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     int stat_calls = 0;
     const int scal_floats = split ? (int)(16 + 2 * (6 + 8 * (size_t)c->cfg.n_layers)) : 0;
     if (split) SOLA_HIP(hipMemsetAsync(ar.get("scal"), 0, scal_floats * sizeof(float), s));
-    auto stats = [&](const float* dY, int ld, int rows, int cols, int slot, float** sc_out) -> int {
+    // bf16 storage: the pass is the CAST as well (launch_cast_bf16_colsum: bfloat16 needs no scale, so no max|x| in front of the
+    // cast) - "dy_sp" then holds the row-major bf16 copy of [rows][cols] at pitch ld, and the dW / dX GEMMs of the matrix skip theirs
+    const float* cast_src = nullptr;  // the matrix whose cast "dy_sp" holds (fused pass), its pitch and columns
+    int cast_ld = 0, cast_cols = 0;
+    const size_t dy_sp_halfs = split ? 2 * (size_t)std::max(M, BW) * 3 * D : 0;
+    auto stats = [&](const float* dY, int ld, int rows, int cols, int slot, float** sc_out, bool may_cast = true) -> int {
         *sc_out = nullptr;
+        if (may_cast) cast_src = nullptr;
         if (!split || cols % 4 || ld % 4) return SOLA_OK;
         // every call takes the next pair of the slots behind the 16 fixed ones: they were zeroed by ONE memset when the call began (a
         // memset of 8 bytes per gradient matrix was 20 launches of ~5 us per step)
         (void)slot;
         SOLA_ARG(16 + 2 * (stat_calls + 1) <= scal_floats, "backward: more gradient-statistics passes (%d) than scale slots", stat_calls + 1);
         float* sc = ar.get("scal") + 16 + 2 * stat_calls++;
-        SOLA_TRY(launch_amax_colsum(dY, ld, rows, cols, sc, cpart, s));
+        if (may_cast && pure && bf && g_bwd_fused_bf16_cast && g_bwd_dual_cast && ld % 8 == 0 && (size_t)rows * ld <= dy_sp_halfs) {
+            SOLA_TRY(launch_cast_bf16_colsum(dY, ld, ar.get("dy_sp"), ld, rows, cols, sc, cpart, s));
+            cast_src = dY; cast_ld = ld; cast_cols = cols;
+        } else {
+            SOLA_TRY(launch_amax_colsum(dY, ld, rows, cols, sc, cpart, s));
+        }
         cpart_cols = cols;
         cpart_slabs = (rows + 63) / 64;
         *sc_out = sc;
@@ -397,7 +410,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, n_out, k_in)) {
             GemmTnSplitDesc d{};
             d.scal = sc; d.pure = pure ? 1 + bf : (dw16 ? 1 : 0); d.rm_split = dw16 ? 1 : 0;
-            if (dy_rm_done && sc && g_bwd_dual_cast) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy; }
+            if (dy_rm_done && sc && g_bwd_dual_cast) {
+                d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy;
+                d.a_rm_ready = cast_src && cast_src == g[0].dY && cast_ld == ldy && (g[n - 1].dY - g[0].dY) + n_out <= cast_cols;
+            }
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) {
                 d.A[j] = g[j].dY; d.B[j] = g[j].X; d.C[j] = g[j].dW;
@@ -435,6 +451,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                 d.p[0].A = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(ar.get("dy_sp")) + col_off) : ar.get("dy_sp") + col_off;
                 d.lda = ldy;
             } else {
+                cast_src = nullptr;  // "dy_sp" is rewritten
                 if (sc) SOLA_TRY(cast_scaled(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
                 else SOLA_TRY(cast_auto(dY, ldy, ar.get("dy_sp"), rows, n_cat, scal));
                 d.p[0].A = ar.get("dy_sp");
@@ -575,7 +592,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             bool rmq;
             SOLA_TRY(dw_begin());
             SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr, &rmq));
-            SOLA_TRY(stats(dlkv, 2 * D, BW, 2 * D, 6, &sckv));
+            SOLA_TRY(stats(dlkv, 2 * D, BW, 2 * D, 6, &sckv, false));  // no fused cast: "dy_sp" holds dq's for the dX GEMM below
             if (sckv) {
                 SOLA_TRY(bias_from_stats(0, D, G(an + ".k_proj.bias")));
                 SOLA_TRY(bias_from_stats(D, D, G(an + ".v_proj.bias")));
@@ -712,6 +729,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.M = rows; d.N = g.cout; d.K = g.k * g.cin; d.lda = g.cout; d.ldb = g.cin;
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.rowmap = rowmap; d.B_rows = rows_in;
+            if (cast_src == dy && cast_ld == g.cout && cast_cols == g.cout) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = g.cout; d.a_rm_ready = 1; }
             if ((pure || dw16) && i > 0) d.B16[0] = c->x16_find(x_in, g.cin, pure ? 1 + bf : 1);
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
@@ -749,7 +767,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             // split-f16: z[(r,to)][kk*cin+ci] = sum_co dY[(r,to)][co] w_std[co][kk*cin+ci] in ONE NT GEMM over the output steps (a
             // strided conv's gather form would multiply zeros for every skipped step), then the k taps are gathered into dX
             float* scal = scc ? scc : ar.get("scal");
-            if (scc) SOLA_TRY(cast_scaled(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
+            if (scc && cast_src == dy && cast_ld == g.cout && cast_cols == g.cout) {}  // the statistics pass left the cast (bf16)
+            else if (scc) SOLA_TRY(cast_scaled(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
             else SOLA_TRY(cast_auto(dy, g.cout, ar.get("dy_sp"), rows, g.cout, scal));
             if (pure) SOLA_TRY(launch_cast_f16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s, bf));
             else SOLA_TRY(launch_cast_sp16_t(c->ws_buf + c->ws_off[i], g.k * g.cin, ar.get("wt_sp"), g.cout, g.cout, g.k * g.cin, nullptr, s));

@@ -90,6 +90,36 @@ __global__ __launch_bounds__(256) void amax_colsum_kernel(const float* __restric
     block_amax_commit(m, out);
 }
 
+// bf16 storage mode (round 5): bfloat16 has f32's exponent range, so the gradient cast needs no data-dependent scale - and no max|x|
+// pass in front of it.  ONE read of the gradient matrix leaves its row-major bf16 cast (the operand of the dW and dX GEMMs) and
+// the 64-row slab column sums amax_colsum_kernel leaves (same slabs, same order: the bias gradients keep their bits).  A wave owns
+// one slab x 64 float4 columns; the scale slot reads {2^13, 1}: auto_scale() of it is 1 for every later consumer.
+typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void cast_bf16_colsum_kernel(const float* __restrict__ in, __bf16* __restrict__ out, float* __restrict__ scal,
+                                                               float* __restrict__ part, long long rows, int f4_per_row, int ld_in, int ld_out) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const long long slab = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        scal[0] = 8192.f;
+        scal[1] = 1.f;
+    }
+    const long long r0 = slab * 64;
+    if (c >= f4_per_row || r0 >= rows) return;
+    const int nr = (int)min((long long)64, rows - r0);
+    const float* p = in + r0 * ld_in + (long long)c * 4;
+    __bf16* o = out + r0 * ld_out + (long long)c * 4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int r = 0; r < nr; ++r, p += ld_in, o += ld_out) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        bf16x4c b;
+        b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4c*>(o) = b;
+    }
+    *reinterpret_cast<float4*>(part + (slab * f4_per_row + c) * 4) = sum;
+}
+
 // scale = 2^(13 - floor(log2(amax))): the largest magnitude lands in [2^13, 2^14), far from the f16 overflow at 65504
 __device__ __forceinline__ float auto_scale(unsigned amax_bits, int target = 13) {
     const int e = (int)(amax_bits >> 23) - 127;  // floor(log2(amax)) for normal floats
@@ -335,6 +365,17 @@ int launch_amax_colsum(const float* in, int ld_in, long long rows, int K, float*
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * rows * K);
     hipLaunchKernelGGL(amax_colsum_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in,
                        reinterpret_cast<unsigned*>(scal), part, rows, K / 4, ld_in);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_cast_bf16_colsum(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, float* part, hipStream_t s) {
+    SOLA_ARG(in && out && scal && part && rows > 0 && K > 0 && K % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out >= K,
+             "cast_bf16_colsum: K=%d ld_in=%d ld_out=%d", K, ld_in, ld_out);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 6.0 * rows * K);
+    const long long slabs = (rows + 63) / 64;
+    hipLaunchKernelGGL(cast_bf16_colsum_kernel, dim3((unsigned)((K / 4 + 63) / 64), (unsigned)((slabs + 3) / 4)), dim3(256), 0, s, in,
+                       reinterpret_cast<__bf16*>(out), scal, part, rows, K / 4, ld_in, ld_out);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

@@ -284,7 +284,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
             const long long off = d.A[j] - d.A[0];
             if (rm16) {
                 _Float16* dst = reinterpret_cast<_Float16*>(d.a_rm) + off;
-                SOLA_TRY(launch_cast_f16_scaled(d.A[j], d.lda, dst, d.a_rm_ld, d.M, d.N, scal, s, bf));
+                if (!d.a_rm_ready) SOLA_TRY(launch_cast_f16_scaled(d.A[j], d.lda, dst, d.a_rm_ld, d.M, d.N, scal, s, bf));
                 t.A[j] = dst;
             } else if (rmsp) {
                 SOLA_TRY(launch_cast_sp16_scaled(d.A[j], d.lda, d.a_rm + off, d.a_rm_ld, d.M, d.N, scal, s));
@@ -322,7 +322,7 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
     const float* xt_of[3] = {nullptr, nullptr, nullptr};
     int n_xt = 0;
     for (int j = 0; j < d.nprob; ++j) {
-        if (rm) {  // + the row-major cast of the same gradient matrix (the dX GEMM's operand): one read of dY for both
+        if (rm && !(d.a_rm_ready && pure && !d.rm_split)) {  // + the row-major cast of the same gradient matrix (the dX GEMM's operand): one read of dY for both
             const long long off = d.A[j] - d.A[0];
             float* dst = (pure && !d.rm_split) ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(d.a_rm) + off) : d.a_rm + off;
             SOLA_TRY(cast_t(pure_fmt, d.A[j], d.lda, at + (size_t)j * d.N * rowf, Mp, d.M, d.N, scal, s, 0, 0, 1, 0, dst, d.a_rm_ld, nullptr, 0, d.rm_split));

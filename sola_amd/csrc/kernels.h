@@ -110,6 +110,7 @@ struct GemmTnSplitDesc {
     float* a_rm;
     int a_rm_ld;
     int rm_split;  // pure != 0 only: the row-major copy stays split-f16 (the dX GEMM of a split-f16 step whose dW products run on plain f16)
+    int a_rm_ready;  // pure 16-bit, rm_split == 0: a_rm already holds the cast of every problem (launch_cast_bf16_colsum): no cast here
     float* scratch;
     size_t scratch_bytes;
     const int2* rowmap;  // conv = 1, optional, ragged batches: as GemmDesc::rowmap
@@ -359,6 +360,8 @@ int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, fl
 // amax into scal[0] (accumulating; the caller zeroes the pair) AND the column sums of every 64-row slab into
 // part[(rows + 63) / 64][K]: one read of a gradient matrix for its scale and its bias gradients
 int launch_amax_colsum(const float* in, int ld_in, long long rows, int K, float* scal, float* part, hipStream_t s);
+// bf16 mode: one read leaves the unscaled row-major bf16 cast [rows][ld_out] + amax_colsum's slab sums; scal <- {2^13, 1} (scale 1)
+int launch_cast_bf16_colsum(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, float* part, hipStream_t s);
 // the cast half of launch_cast_sp16_auto: scal[0] already holds max|in|
 int launch_cast_sp16_scaled(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);

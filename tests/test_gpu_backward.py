@@ -517,6 +517,29 @@ def test_kept_operand_casts_give_the_same_gradients_bit_for_bit(full_model, mode
     assert not bad, bad
 
 
+def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_gradients_bit_for_bit(full_model):
+    """Round 5, bf16 storage: bfloat16 has f32's exponent range, so the backward's pass over a gradient matrix (bias sums) also writes
+    its UNSCALED bf16 cast - no max|x| in front, no second read by the casts of the dW / dX GEMMs (sola_tune "bwd_fused_bf16_cast",
+    default 1).  The two-pass path scales by a power of two before rounding and undoes it behind the f32 accumulation: the same
+    products, so every gradient must keep its bits with the switch off."""
+    from sola_amd import _lib
+    m, _ = full_model
+    cfg = synth.DEFAULT_MODEL_CFG
+    got = {}
+    try:
+        m.precision = "bf16"
+        for fused in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", fused), "tune")
+            _, l3, g = train_step_grads(m, cfg, 8, 40, 32, 10, 77)
+            got[fused] = ({k: v.clone() for k, v in g.items()}, l3.detach().clone())
+    finally:
+        m.precision = "f32"
+        _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
+    assert torch.equal(got[1][1], got[0][1])
+    bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_training_run_tracks_exact_f32_across_optimizer_steps(fused):
     """Several optimizer steps, not one: the reduced-precision modes keep derived copies of the weights (split-f16 / f16

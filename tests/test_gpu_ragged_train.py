@@ -243,6 +243,27 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
     assert not bad, bad
 
 
+def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_ragged_gradients_bit_for_bit(full):
+    """Round 5 (tests/test_gpu_backward.py has the uniform-batch twin): in the bf16 step the pass over a gradient matrix that takes its
+    bias sums writes its unscaled bf16 cast too (sola_tune "bwd_fused_bf16_cast" 1, the default) - against the two-pass path (max|x| +
+    sums, then power-of-two-scaled casts): the same loss, every gradient bit for bit, on a ragged batch."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    full.precision = "bf16"
+    got = {}
+    try:
+        samples = [sample_inputs(cfg, N, T, L, 450 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
+        for fused in (1, 0):
+            _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", fused), "tune")
+            loss, g, _ = ragged_step(full, samples)
+            got[fused] = (g, loss)
+    finally:
+        full.precision = "f32"
+        _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
+    assert torch.equal(got[1][1], got[0][1])
+    bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
 @pytest.mark.parametrize("train", [True, False])
 def test_attention_written_operand_casts_give_the_same_ragged_step_bit_for_bit(full, precision, train):

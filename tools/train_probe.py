@@ -1,6 +1,6 @@
 """Training step time (forward_train + loss + backward + clip + AdamW) at a batch, per precision mode.
 
-    python tools/train_probe.py [batch = 64] [modes, comma separated = f32,f16x3,f16,bf16]
+    python tools/train_probe.py [batch = 64] [modes, comma separated = f32,f16x3,f16,bf16] [sola_tune settings: key=value,...]
 """
 import sys, time, torch
 import os
@@ -9,6 +9,12 @@ from sola_amd import synth
 from sola_amd.loss import track_selection_losses
 from sola_amd.module import LanguageAlignedTrackSelectionModule
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+if len(sys.argv) > 3:
+    from sola_amd import _lib
+    for kv in sys.argv[3].split(","):
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().sola_tune(k.encode(), int(v)), "tune " + k)
+        print("tune", k, v)
 cfg = synth.DEFAULT_MODEL_CFG
 m = LanguageAlignedTrackSelectionModule(cfg)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()}, strict=True)
