@@ -315,6 +315,10 @@ void sola_gn_set_wide(int v);
 void sola_gemm_set_gn_fuse(int v);
 void sola_set_bwd_dual_cast(int v);
 void sola_set_bwd_fused_bf16_cast(int v);
+void sola_attn_set_ring(int v);
+void sola_attn_set_ring_blocks(int v);
+void sola_attn_set_ring_remap(int v);
+void sola_attn_set_ring_ablate(int v);
 void sola_attn_set_simple_remap(int v);
 void sola_attn_set_simple_db(int v);
 void sola_pack_set_resample_lds(int v);
@@ -393,6 +397,10 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_ablate")) { sola_gemm_set_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg_minw")) { sola_attn_set_reg_minw(value); return SOLA_OK; }
     if (!strcmp(key, "attn_res_splitm")) { sola_attn_set_res_splitm(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_ring")) { sola_attn_set_ring(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_ring_blocks")) { sola_attn_set_ring_blocks(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_ring_remap")) { sola_attn_set_ring_remap(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_ring_ablate")) { sola_attn_set_ring_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "attn_bwd_ablate")) { sola_attn_set_bwd_ablate(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_gn_fuse")) { sola_gemm_set_gn_fuse(value); return SOLA_OK; }
 #endif

@@ -63,8 +63,7 @@ __device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, co
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(max_xor16(mx));
     float rs = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -73,8 +72,7 @@ __device__ __forceinline__ void res_tile(const AttnQArgs& a, const float* Ks, co
             sc[t][r] = __expf(sc[t][r] - mx);
             rs += sc[t][r];
         }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = sum_xor32(sum_xor16(rs));
     f32x4 oacc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -172,8 +170,7 @@ __device__ __forceinline__ void sm_tile(const AttnQArgs& a, const _Float16* Kh, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(max_xor16(mx));
     float rs = 0.f;
     HL4r p[NT];
     float dummy = 0.f;
@@ -186,8 +183,7 @@ __device__ __forceinline__ void sm_tile(const AttnQArgs& a, const _Float16* Kh, 
         }
         p[t] = split4r(sc[t][0], sc[t][1], sc[t][2], sc[t][3], dummy);
     }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = sum_xor32(sum_xor16(rs));
     f32x4 oacc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};

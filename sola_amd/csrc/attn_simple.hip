@@ -155,8 +155,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
         for (int t = 0; t < TK / 16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_xor32(max_xor16(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float rs = 0.f;
@@ -167,8 +166,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
                 sc[t][r] = __expf(sc[t][r] - m_new);
                 rs += sc[t][r];
             }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = sum_xor32(sum_xor16(rs));
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll
@@ -484,8 +482,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_splitm_kernel(const AttnSArgs
         for (int t = 0; t < TK / 16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_xor32(max_xor16(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float rs = 0.f;
@@ -496,8 +493,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_splitm_kernel(const AttnSArgs
                 sc[t][r] = __expf(sc[t][r] - m_new);
                 rs += sc[t][r];
             }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = sum_xor32(sum_xor16(rs));
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll
@@ -676,8 +672,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_spin_kernel(const AttnSArgs a
         for (int t = 0; t < TK / 16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_xor32(max_xor16(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float rs = 0.f;
@@ -688,8 +683,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_spin_kernel(const AttnSArgs a
                 sc[t][r] = __expf(sc[t][r] - m_new);
                 rs += sc[t][r];
             }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = sum_xor32(sum_xor16(rs));
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll

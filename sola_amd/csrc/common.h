@@ -56,6 +56,28 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+// The cross-row steps of a 64-lane butterfly (lane ^ 16, lane ^ 32) on the vector ALU: gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange the odd 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another - fed the same
+// value twice they leave {x[l & ~16], x[l | 16]} ({x[l & 31], x[l | 32]}) in the two.  __shfl_xor is a ds_bpermute round trip through
+// the LDS (~100 cycles of latency each, four in a row per 16-key tile of an attention kernel).  Same operand pairs: same bits.
+typedef unsigned u32x2_swap __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float max_xor16(float x) {
+    const u32x2_swap r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float x) {
+    const u32x2_swap r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor16(float x) {
+    const u32x2_swap r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+    const u32x2_swap r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
