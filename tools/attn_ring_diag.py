@@ -19,7 +19,18 @@ M = B * N * Tp
 q, k, v = (torch.randn(M, D, device="cuda") for _ in range(3))
 Wn = 48
 lk, lv = torch.randn(B * Wn, D, device="cuda"), torch.randn(B * Wn, D, device="cuda")
-defaults = {"attn_ring": 1, "attn_ring_blocks": 2, "attn_ring_remap": 1}
+fused = os.environ.get("RING_FUSED") == "1"  # q | k | v as the column blocks of one [M, 3 D] matrix (the projection GEMM's output in the model)
+if fused:
+    import ctypes as C
+    qkv = torch.randn(M, 3 * D, device="cuda")
+    out = torch.empty(M, D, device="cuda")
+    stream = _lib.current_stream(out.device)
+
+    def fused_obj():
+        base = qkv.data_ptr()
+        _lib.check(lib.sola_attention(C.c_void_p(base), 3 * D, C.c_void_p(base + 4 * D), 3 * D, C.c_void_p(base + 8 * D), 3 * D, _lib.ptr(out), D,
+                                      B * Tp, H, D // H, N, N, Tp, N * Tp, 1, Tp, N * Tp, 1, Tp, 1.0 / (D // H) ** 0.5, None, stream), "sola_attention")
+defaults = {"attn_ring": 1, "attn_ring_blocks": 2, "attn_ring_remap": 1} if lib.sola_has_experiments() else {}
 for cfg in sys.argv[1:]:
     kv = dict(defaults)
     for item in cfg.split(","):
@@ -30,7 +41,9 @@ for cfg in sys.argv[1:]:
     for key, val in kv.items():
         _lib.check(lib.sola_tune(key.encode(), val), key)
     for _ in range(30):
-        if shape == "obj":
+        if fused:
+            fused_obj()
+        elif shape == "obj":
             ops.attention(q, k, v, B * Tp, H, N, N, Tp, (N * Tp, 1, Tp), (N * Tp, 1, Tp))
         else:
             ops.attention(q, lk, lv, B, H, N * Tp, Wn, 1, (N * Tp, 0, 1), (Wn, 0, 1))
