@@ -316,6 +316,7 @@ void sola_gemm_set_gn_fuse(int v);
 void sola_set_bwd_dual_cast(int v);
 void sola_set_bwd_fused_bf16_cast(int v);
 void sola_attn_set_ring(int v);
+void sola_attn_set_f16_qpb(int v);
 void sola_attn_set_ring_blocks(int v);
 void sola_attn_set_ring_remap(int v);
 void sola_attn_set_ring_ablate(int v);
@@ -382,6 +383,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "gn_slices")) { sola_gn_set_slices(value); return SOLA_OK; }
     if (!strcmp(key, "gn_wide")) { sola_gn_set_wide(value); return SOLA_OK; }
     if (!strcmp(key, "bwd_dual_cast")) { sola_set_bwd_dual_cast(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_f16_qpb")) { sola_attn_set_f16_qpb(value); return SOLA_OK; }
     if (!strcmp(key, "bwd_fused_bf16_cast")) { sola_set_bwd_fused_bf16_cast(value); return SOLA_OK; }
     if (!strcmp(key, "attn_simple_remap")) { sola_attn_set_simple_remap(value); return SOLA_OK; }
     if (!strcmp(key, "attn_simple_db")) { sola_attn_set_simple_db(value); return SOLA_OK; }

@@ -4,10 +4,15 @@
 //
 // Same single [B, N, T', D] layout and the same (outer, inner, row) / unit-table addressing as attn.hip.  One wave owns a
 // 16-query tile:
-//   S^T = K Q^T : A = K rows (one 8-byte LDS read per 16-wide head-dim chunk), B = Q (registers); lane (c16, g4) ends with
-//                 the scores of query c16 against keys 4*g4 + {0..3} of the tile: a softmax row lives in one 16-lane column;
+//   S^T = K Q^T : A = K rows, B = Q (registers); lane (c16, g4) ends with the scores of query c16 against keys 4*g4 + {0..3} of
+//                 the tile: a softmax row lives in one 16-lane column.  Round 5: the head dimension is taken in PAIRS of 16-wide
+//                 chunks - lane g4 holds the 8 halfs 32 cp + 8 g4 .. + 7 of q and of the K row (one 16-byte global load / LDS read),
+//                 the first four feed the pair's first MFMA, the last four its second: a dot product does not care which k slot
+//                 carries which element as long as both operands agree, and the 8-byte fragment-shaped loads (16 rows x 32 bytes
+//                 per instruction) were twice the instructions on the address path;
 //   O^T = V^T P^T: A = V^T (four 2-byte LDS reads down a column of the row-major tile), B = P straight from the score
-//                 registers; lane ends with o[q = c16][16c + 4*g4 + {0..3}]: one 8-byte store per chunk.
+//                 registers; MFMA row m of a pair's first / second product is head-dim element 32 cp + 8 (m >> 2) + (m & 3) [+ 4],
+//                 so a lane ends with o[q = c16][32 cp + 8 g4 .. + 7]: one 16-byte store per pair.
 // K/V tiles are 64 keys x head_dim halfs (pitch + 8 halfs: conflict-free for both read patterns on the 64-bank LDS), 34 KB
 // per block at head_dim 128, so four 4-wave blocks share a CU and cover each other's memory latency; longer key sequences
 // take further tiles with an online softmax.  Sequences of at most 16 steps (motion attention over T') use one wave per
@@ -29,9 +34,11 @@ struct AttnHArgs {
     float scale;
     int* guard;
     const int4 *q_units, *k_units;
+    int qpb;  // consecutive 64-query blocks of a unit per thread block (> 1 only where the unit's keys fit one tile: K / V staged once)
 };
 
-int g_attn_f16_small = 1;  // sola_tune "attn_f16_small": 0 = the MFMA shape for sequences of <= 4 steps too (A/B)
+int g_attn_f16_small = 1;
+int g_attn_f16_qpb = 4;  // sola_tune "attn_f16_qpb": q-blocks per block against <= 64 keys, at most (1 = every q-block stages the unit's K / V itself; < 0: exactly -v, tests)  // sola_tune "attn_f16_small": 0 = the MFMA shape for sequences of <= 4 steps too (A/B)
 
 struct GeoH { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
 __device__ __forceinline__ GeoH geo_h(const AttnHArgs& a, int grp) {
@@ -49,9 +56,12 @@ __device__ __forceinline__ GeoH geo_h(const AttnHArgs& a, int grp) {
 }
 
 // WPU = wave per unit (sequences of <= 16 steps): the block's four waves serve four different (group, head) units
+// (Round 5, measured and removed: two 32-key LDS stages with the next tile's rows prefetched in registers, attn_fwd_f32_simple_kernel's DB
+// shape - 161 vs 151 us at the 128-key inter-object site, equal at 64 keys: at four blocks per CU the other blocks already cover a tile's load.)
 template <int DH, bool WPU>
-__global__ __launch_bounds__(256) void attn_fwd_f16_kernel(const AttnHArgs a) {
+__global__ __launch_bounds__(256, WPU ? 2 : 4) void attn_fwd_f16_kernel(const AttnHArgs a) {
     constexpr int NC = DH / 16;        // 16-wide head-dim chunks
+    constexpr bool PAIR = NC % 2 == 0; // chunk pairs with 16-byte accesses (head_dim 16: the 8-byte fragment shapes)
     constexpr int LD = DH + 8;         // tile pitch in halfs
     constexpr int H8 = DH / 8;         // 16-byte pieces per row
     constexpr int TROWS = WPU ? 16 : 64;
@@ -65,138 +75,182 @@ __global__ __launch_bounds__(256) void attn_fwd_f16_kernel(const AttnHArgs a) {
         unit = (long long)blockIdx.x * 4 + wave;
         if (unit >= (long long)a.G * a.H) return;  // whole waves leave; this mode has no block-level sync
     } else {
-        unit = blockIdx.x / a.nqb;
-        qb = blockIdx.x - (int)unit * a.nqb;
+        const int nqg = (a.nqb + a.qpb - 1) / a.qpb;  // q-block groups per unit
+        unit = blockIdx.x / nqg;
+        qb = (blockIdx.x - (int)unit * nqg) * a.qpb;
     }
     const int grp = (int)(unit / a.H), h = (int)(unit - (long long)grp * a.H);
     const GeoH g = geo_h(a, grp);
     _Float16* Ks = smem_h + (WPU ? wave * 2 * TROWS * LD : 0);
     _Float16* Vs = Ks + TROWS * LD;
 
-    const int qi = qb * 64 + (WPU ? 0 : wave * 16) + c16;
-    const bool q_ok = qi < g.Sq;
-    if (!WPU && qb * 64 >= g.Sq) return;  // ragged: this unit has fewer q-blocks than the largest one (block-uniform)
-    // Q fragment: d = 16c + 4*g4 .. +3
-    half4v qf[NC];
-    {
-        const _Float16* qp = a.q + (g.q0 + (long long)qi * g.q_rs) * a.ldq + h * DH + 4 * g4;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (q_ok) qf[c] = *reinterpret_cast<const half4v*>(qp + c * 16);
-            else qf[c] = half4v{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
-        }
-    }
-    f32x4 oacc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    for (int kt0 = 0; kt0 < g.Sk; kt0 += TROWS) {
-        const int nrows = min(TROWS, g.Sk - kt0);
-        const int nrows16 = (nrows + 15) & ~15;
-        if (!WPU && kt0 > 0) __syncthreads();  // the previous tile has been consumed by every wave
-        // stage K and V rows (16 bytes per lane), rows past the sequence zero-filled
+    const int nq_iter = WPU ? 1 : a.qpb;
+    for (int qq = 0; qq < nq_iter; ++qq) {
+        const int qi = (qb + qq) * 64 + (WPU ? 0 : wave * 16) + c16;
+        const bool q_ok = qi < g.Sq;
+        if (!WPU && (qb + qq) * 64 >= g.Sq) return;  // ragged: this unit has fewer q-blocks than the largest one (block-uniform)
+        // Q fragment: chunk pair cp, lane g4: d = 32 cp + 8 g4 .. + 7 (first four: MFMA 2 cp, last four: MFMA 2 cp + 1)
+        half4v qf[NC];
         {
-            const int nthr = WPU ? 64 : 256, t0 = WPU ? lane : tid;
-            for (int idx = t0; idx < nrows16 * H8; idx += nthr) {
-                const int r = idx / H8, c8 = idx - r * H8;
-                half8v kv, vv;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { kv[j] = (_Float16)0; vv[j] = (_Float16)0; }
-                if (r < nrows) {
-                    const long long row = g.k0 + (long long)(kt0 + r) * g.k_rs;
-                    kv = *reinterpret_cast<const half8v*>(a.k + row * a.ldk + h * DH + c8 * 8);
-                    vv = *reinterpret_cast<const half8v*>(a.v + row * a.ldv + h * DH + c8 * 8);
-                }
-                *reinterpret_cast<half8v*>(&Ks[r * LD + c8 * 8]) = kv;
-                *reinterpret_cast<half8v*>(&Vs[r * LD + c8 * 8]) = vv;
-            }
-        }
-        if (WPU) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else {
-            __syncthreads();
-        }
-        const int ntile = nrows16 >> 4;
-        f32x4 sc[TROWS / 16];
-#pragma unroll
-        for (int t = 0; t < TROWS / 16; ++t) {
-            if (t < ntile) {
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const _Float16* kp = &Ks[(t * 16 + c16) * LD + 4 * g4];
+            const _Float16* qp = a.q + (g.q0 + (long long)qi * g.q_rs) * a.ldq + h * DH + (PAIR ? 8 : 4) * g4;
+            if constexpr (!PAIR) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const half4v kf = *reinterpret_cast<const half4v*>(kp + c * 16);
-                    if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc0, 0, 0, 0);
+                    if (q_ok) qf[c] = *reinterpret_cast<const half4v*>(qp + c * 16);
+                    else qf[c] = half4v{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
                 }
-                const int key0 = kt0 + t * 16 + 4 * g4;
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < g.Sk) ? (acc0[r] + acc1[r]) * a.scale : -INFINITY;
+            for (int cp = 0; cp < NC / 2; ++cp) {
+                half8v q8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q8[j] = (_Float16)0;
+                if (q_ok) q8 = *reinterpret_cast<const half8v*>(qp + cp * 32);
+                qf[2 * cp] = half4v{q8[0], q8[1], q8[2], q8[3]};
+                qf[2 * cp + 1] = half4v{q8[4], q8[5], q8[6], q8[7]};
+            }
+        }
+        f32x4 oacc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+
+        for (int kt0 = 0; kt0 < g.Sk; kt0 += TROWS) {
+            const int nrows = min(TROWS, g.Sk - kt0);
+            const int nrows16 = (nrows + 15) & ~15;
+            if (qq == 0) {  // later q-blocks of the unit (qpb > 1: the keys fit this one tile) find K / V staged
+            if (!WPU && kt0 > 0) __syncthreads();  // the previous tile has been consumed by every wave
+            // stage K and V rows (16 bytes per lane), rows past the sequence zero-filled
+            {
+                const int nthr = WPU ? 64 : 256, t0 = WPU ? lane : tid;
+                for (int idx = t0; idx < nrows16 * H8; idx += nthr) {
+                    const int r = idx / H8, c8 = idx - r * H8;
+                    half8v kv, vv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { kv[j] = (_Float16)0; vv[j] = (_Float16)0; }
+                    if (r < nrows) {
+                        const long long row = g.k0 + (long long)(kt0 + r) * g.k_rs;
+                        kv = *reinterpret_cast<const half8v*>(a.k + row * a.ldk + h * DH + c8 * 8);
+                        vv = *reinterpret_cast<const half8v*>(a.v + row * a.ldv + h * DH + c8 * 8);
+                    }
+                    *reinterpret_cast<half8v*>(&Ks[r * LD + c8 * 8]) = kv;
+                    *reinterpret_cast<half8v*>(&Vs[r * LD + c8 * 8]) = vv;
+                }
+            }
+            if (WPU) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             } else {
-                sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                __syncthreads();
             }
-        }
-        // online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < TROWS / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
-        float rs = 0.f;
-#pragma unroll
-        for (int t = 0; t < TROWS / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sc[t][r] = __expf(sc[t][r] - m_new);
-                rs += sc[t][r];
             }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+            const int ntile = nrows16 >> 4;
+            f32x4 sc[TROWS / 16];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
-        // O^T += V^T P^T
+            for (int t = 0; t < TROWS / 16; ++t) {
+                if (t < ntile) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    const _Float16* kp = &Ks[(t * 16 + c16) * LD + (PAIR ? 8 : 4) * g4];
+                    if constexpr (!PAIR) {
 #pragma unroll
-        for (int t = 0; t < TROWS / 16; ++t) {
-            if (t < ntile) {
-                half4v pf;
+                        for (int c = 0; c < NC; ++c) {
+                            const half4v kf = *reinterpret_cast<const half4v*>(kp + c * 16);
+                            if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc0, 0, 0, 0);
+                        }
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pf[r] = (_Float16)sc[t][r];
-                const _Float16* vp = &Vs[(t * 16 + 4 * g4) * LD + c16];
+                    for (int cp = 0; cp < NC / 2; ++cp) {
+                        const half8v k8 = *reinterpret_cast<const half8v*>(kp + cp * 32);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(half4v{k8[0], k8[1], k8[2], k8[3]}, qf[2 * cp], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(half4v{k8[4], k8[5], k8[6], k8[7]}, qf[2 * cp + 1], acc1, 0, 0, 0);
+                    }
+                    const int key0 = kt0 + t * 16 + 4 * g4;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    half4v vf;
+                    for (int r = 0; r < 4; ++r) sc[t][r] = (key0 + r < g.Sk) ? (acc0[r] + acc1[r]) * a.scale : -INFINITY;
+                } else {
+                    sc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+            }
+            // online softmax over this key tile (row = 16-lane column c16; key slots spread over g4 and r)
+            float mx = -INFINITY;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) vf[j] = vp[j * LD + c * 16];
-                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, oacc[c], 0, 0, 0);
+            for (int t = 0; t < TROWS / 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < TROWS / 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[t][r] = __expf(sc[t][r] - m_new);
+                    rs += sc[t][r];
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+            // O^T += V^T P^T
+#pragma unroll
+            for (int t = 0; t < TROWS / 16; ++t) {
+                if (t < ntile) {
+                    half4v pf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pf[r] = (_Float16)sc[t][r];
+                    // MFMA row m = c16 -> element 32 cp + 8 (m >> 2) + (m & 3) [+ 4] (PAIR), else 16 c + m
+                    const _Float16* vp = &Vs[(t * 16 + 4 * g4) * LD + (PAIR ? 8 * (c16 >> 2) + (c16 & 3) : c16)];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        half4v vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vf[j] = vp[j * LD + (PAIR ? (c >> 1) * 32 + (c & 1) * 4 : c * 16)];
+                        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, oacc[c], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
-    if (q_ok) {
-        const float inv = 1.f / l_run;
-        _Float16* op = a.o + (g.q0 + (long long)qi * g.q_rs) * a.ldo + h * DH + 4 * g4;
-        float m = 0.f;
+        if (q_ok) {
+            const float inv = 1.f / l_run;
+            _Float16* op = a.o + (g.q0 + (long long)qi * g.q_rs) * a.ldo + h * DH + (PAIR ? 8 : 4) * g4;
+            float m = 0.f;
+            if constexpr (!PAIR) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            half4v o4;
+                for (int c = 0; c < NC; ++c) {
+                    half4v o4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = oacc[c][j] * inv;
-                o4[j] = (_Float16)v;
-                m = fmaxf(m, fabsf(v));
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = oacc[c][j] * inv;
+                        o4[j] = (_Float16)v;
+                        m = fmaxf(m, fabsf(v));
+                    }
+                    *reinterpret_cast<half4v*>(op + c * 16) = o4;
+                }
             }
-            *reinterpret_cast<half4v*>(op + c * 16) = o4;
+#pragma unroll
+            for (int cp = 0; cp < NC / 2; ++cp) {
+                half8v o8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = oacc[2 * cp + (j >> 2)][j & 3] * inv;
+                    o8[j] = (_Float16)v;
+                    m = fmaxf(m, fabsf(v));
+                }
+                if (a.ldo % 8 == 0) {
+                    *reinterpret_cast<half8v*>(op + cp * 32) = o8;
+                } else {  // row pitch a multiple of 4 halfs only: two 8-byte stores
+                    *reinterpret_cast<half4v*>(op + cp * 32) = half4v{o8[0], o8[1], o8[2], o8[3]};
+                    *reinterpret_cast<half4v*>(op + cp * 32 + 4) = half4v{o8[4], o8[5], o8[6], o8[7]};
+                }
+            }
+            if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
         }
-        if (a.guard && !(m < 65000.f)) atomicOr(a.guard, 1);
     }
 }
 
@@ -303,14 +357,22 @@ int launch_h(const AttnHArgs& a0, hipStream_t s) {
         else if (need <= 2) hipLaunchKernelGGL((attn_fwd_small_f16_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_small_f16_kernel<4>), dim3(blocks), dim3(256), 0, s, a);
     } else if (a.Sq <= 16 && a.Sk <= 16) {
-        a.nqb = 1;
+        a.nqb = 1; a.qpb = 1;
         const size_t lds = (size_t)4 * 2 * 16 * LD * sizeof(_Float16);
         hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
     } else {
         a.nqb = (a.Sq + 63) / 64;
-        SOLA_ARG(units * a.nqb < (1ll << 31), "attention (f16): grid too large");
+        // many queries against at most one tile of keys (object -> language): a block walks qpb q-blocks of its unit over the staged K / V
+        // as long as the grid still fills the chip several times over
+        a.qpb = 1;
+        if (a.Sk <= 64 && g_attn_f16_qpb < 0)  // tests: forced, whatever the grid
+            a.qpb = std::min(-g_attn_f16_qpb, a.nqb);
+        else if (a.Sk <= 64 && g_attn_f16_qpb > 1)
+            while (a.qpb < g_attn_f16_qpb && a.qpb * 2 <= a.nqb && units * ((a.nqb + 2 * a.qpb - 1) / (2 * a.qpb)) >= 8ll * sola_cu_count()) a.qpb *= 2;
+        const long long blocks = units * ((a.nqb + a.qpb - 1) / a.qpb);
+        SOLA_ARG(blocks < (1ll << 31), "attention (f16): grid too large");
         const size_t lds = (size_t)2 * 64 * LD * sizeof(_Float16);
-        hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, false>), dim3((unsigned)(units * a.nqb)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     }
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
@@ -319,6 +381,7 @@ int launch_h(const AttnHArgs& a0, hipStream_t s) {
 }  // namespace
 
 void sola_attn_set_f16_small(int v) { g_attn_f16_small = v; }
+void sola_attn_set_f16_qpb(int v) { g_attn_f16_qpb = v == 0 ? 1 : v; }
 
 // AttnDesc with q / k / v / o pointing at _Float16 matrices and ld* counting halfs
 int launch_attention_f16(const AttnDesc& d, hipStream_t s) {
@@ -332,7 +395,7 @@ int launch_attention_f16(const AttnDesc& d, hipStream_t s) {
     a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
     a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
-    a.scale = d.scale; a.guard = d.guard;
+    a.scale = d.scale; a.guard = d.guard; a.qpb = 1;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 2.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

@@ -103,6 +103,31 @@ def test_f16_attention_vs_float64(G, H, Sq, Sk, inner, case):
     assert worst <= 4e-3, worst  # probabilities are rounded to f16 for the PV product, outputs to f16
 
 
+@pytest.mark.parametrize("Sq,Sk,qpb", [(200, 48, 2), (200, 48, 4), (300, 21, 4), (1000, 64, 8), (130, 5, 3)])
+def test_f16_attention_walking_several_query_blocks_over_staged_keys(Sq, Sk, qpb):
+    """Round 5: many queries against at most one 64-key tile (object -> language) - a block stages the unit's K / V ONCE and walks
+    `qpb` 64-query blocks over it (sola_tune "attn_f16_qpb"; negative = forced, the default applies it only while the grid still
+    fills the chip).  The same arithmetic per query row: bit-identical to one q-block per block, ragged last group included."""
+    G, H, DH = 3, 8, 128
+    D = H * DH
+    rng = np.random.default_rng(Sq * 7 + Sk)
+    q = torch.from_numpy(rng.standard_normal((G * Sq, D)).astype(np.float32)).half().cuda()
+    k = torch.from_numpy(rng.standard_normal((G * Sk, D)).astype(np.float32)).half().cuda()
+    v = torch.from_numpy(rng.standard_normal((G * Sk, D)).astype(np.float32)).half().cuda()
+    outs = {}
+    try:
+        for mode in (1, -qpb):
+            check(lib().sola_tune(b"attn_f16_qpb", mode), "tune")
+            o = torch.zeros((G * Sq, D), device="cuda", dtype=torch.float16)
+            check(lib().sola_attention_f16(ptr(q), D, ptr(k), D, ptr(v), D, ptr(o), D, G, H, DH, Sq, Sk, 1, Sq, 0, 1, Sk, 0, 1, 1.0 / math.sqrt(DH),
+                                           current_stream(o.device)), "sola_attention_f16")
+            outs[mode] = o
+    finally:
+        check(lib().sola_tune(b"attn_f16_qpb", 4), "tune")
+    assert not torch.isnan(outs[-qpb].float()).any()
+    assert torch.equal(outs[1], outs[-qpb])
+
+
 def build(precision, cfg=synth.DEFAULT_MODEL_CFG):
     m = LanguageAlignedTrackSelectionModule(cfg)
     sd = synth.make_state_dict(cfg, 42)
