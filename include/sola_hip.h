@@ -224,6 +224,13 @@ int sola_ws_standardize(const float* dev_w, int cout, int cin, int k, float* dev
 /* C[M,N] = A[M,K] * W[N,K]^T + bias[N] (+ R[M,N]); F.linear (tools/attention.py:63-65,73). K % 4 == 0. */
 int sola_gemm_nt(const float* dev_a, int lda, const float* dev_w, const float* dev_bias, const float* dev_r, int ldr,
                  float* dev_c, int ldc, int M, int N, int K, void* stream);
+/* C[M,N] = A[M,K] * Wcat[K,N] (+ R[M,N]), Wcat = up to three row-major matrices of w_rows rows each stacked along K (dev_w1 / dev_w2 NULL
+ * when K == w_rows / 2 w_rows): the input gradient of F.linear - dX = dY W, d[x] = [dq|dk|dv] [Wq;Wk;Wv] (tools/attention.py:63-65 backward)
+ * - with the weights read where they lie, no transposed copy.  The few-row exact-f32 shape only (one sample per optimizer step,
+ * train.py:116-125): M <= 2048, N % 32 == 0, K % 128 == 0, w_rows % 32 == 0, 16-byte aligned rows; SOLA_ERR_ARG otherwise.  Bit-identical
+ * to sola_gemm_nt on the transposed copy. */
+int sola_gemm_nn(const float* dev_a, int lda, const float* dev_w0, const float* dev_w1, const float* dev_w2, int w_rows, const float* dev_r,
+                 int ldr, float* dev_c, int ldc, int M, int N, int K, void* stream);
 /* channels-last conv1d along T (module/ws.py:14-22): x [R,T_in,cin], w_std [cout,k*cin] -> y [R,T_out,cout] */
 int sola_conv1d_cl(const float* dev_x, const float* dev_wstd, const float* dev_bias, float* dev_y,
                    int R, int T_in, int cin, int cout, int k, int stride, int pad, void* stream);

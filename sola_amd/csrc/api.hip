@@ -843,6 +843,17 @@ extern "C" int sola_gemm_nt(const float* a, int lda, const float* w, const float
     return launch_gemm(gd, as_stream(stream_));
 }
 
+extern "C" int sola_gemm_nn(const float* a, int lda, const float* w0, const float* w1, const float* w2, int w_rows, const float* r, int ldr,
+                            float* cmat, int ldc, int M, int N, int K, void* stream_) {
+    SOLA_ARG(a && w0 && cmat && w_rows > 0, "gemm_nn: null argument");
+    GemmDesc gd{};
+    gd.nprob = 1;
+    gd.p[0] = GemmProblem{a, nullptr, nullptr, r, cmat};
+    gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
+    gd.w_nn[0] = w0; gd.w_nn[1] = w1; gd.w_nn[2] = w2; gd.w_nn_rows = w_rows;
+    return launch_gemm(gd, as_stream(stream_));
+}
+
 extern "C" int sola_gemm_tn_f16(const float* a, int lda, const float* b, int ldb, float* cmat, int M, int N, int K, int fmt, void* scratch,
                                 size_t scratch_bytes, void* stream_) {
     SOLA_ARG(a && b && cmat && scratch && (fmt == 1 || fmt == 2), "gemm_tn_f16: null argument or fmt %d", fmt);

@@ -125,14 +125,14 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
         size_t enc_keep = 0;  // + the encoder stages' dY (GroupNorm backward outputs) for the deferred conv weight gradients
         for (int i = 0; i < 5; ++i) enc_keep += z.rows[i + 1] * (size_t)c->conv[i].cout + 64;
         a.add("dwkeep", (size_t)c->cfg.n_layers * (12 * M * D + 2 * BW * D + 7 * 64) + enc_keep);  // per layer: 3 dres + 3 dqkv (3D wide) + dlkv
-        a.add("wtkeep", (size_t)c->cfg.n_layers * 12 * D * D + ws_total + 64);          // every transposed weight block of the dX GEMMs (layers + encoder)
         a.add("gnkeep", (size_t)(3 * c->cfg.n_layers + 5) * 2 * (inst_c_max + 64));     // private (dgamma, dbeta) partials of every GroupNorm backward: one grouped column-sum launch per bucket
     }
     {   // conv dX as one GEMM z = dY W (every tap's contribution) + a col2im gather: the split-f16 / f16 modes, and every ragged batch
         // (the f32 path's transposed-conv gather needs one sequence length)
         size_t zmax = 0;
         for (int i = 1; i < 6; ++i) zmax = std::max(zmax, z.rows[i + 1] * (size_t)c->conv[i].k * c->conv[i].cin);
-        if (lowp || z.rag) a.add("zcol", zmax);
+        const bool few = !lowp && g_bwd_group_rows > 0 && M <= (size_t)g_bwd_group_rows;  // the few-sample backward takes this form too (weights read where they lie)
+        if (lowp || z.rag || few) a.add("zcol", zmax);
     }
     if (lowp) {  // split-f16 / f16-operand dX GEMMs (same size gate as the training forward): casts of dY and of the transposed weights, the data-dependent scale
         a.add("dy_sp", std::max(M, BW) * 3 * D);
@@ -266,58 +266,11 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         gq.nprob = 0;
         return SOLA_OK;
     };
-    // the transposed weight blocks in the order the layer loop consumes them: per layer (last first) and sub-block (object->language, motion,
-    // inter-object) the out-projection, then the q / k / v blocks exactly as the dX GEMMs take them (transpose_into below)
-    struct WtUse { const float* w[3]; int nw; float* dst; };
-    std::vector<WtUse> wt_seq;
-    size_t wt_next = 0;
-    float* enc_wt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // group: the encoder convs' transposed weights
-    if (group) {
-        float* base = ar.get("wtkeep");
-        size_t off = 0;
-        auto use = [&](std::initializer_list<std::string> names) {
-            WtUse u{};
-            for (const std::string& n : names) u.w[u.nw++] = W(n);
-            u.dst = base + off;
-            off += (size_t)D * D * u.nw;
-            wt_seq.push_back(u);
-        };
-        for (int l = c->cfg.n_layers - 1; l >= 0; --l) {
-            const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
-            const std::string o2l = lp + kAttnLong[2], mot = lp + kAttnLong[1], obj = lp + kAttnLong[0];
-            use({o2l + ".out_proj.weight"});
-            use({o2l + ".q_proj.weight"});
-            use({o2l + ".k_proj.weight", o2l + ".v_proj.weight"});
-            use({mot + ".out_proj.weight"});
-            use({mot + ".q_proj.weight", mot + ".k_proj.weight"});
-            use({mot + ".v_proj.weight"});
-            use({obj + ".out_proj.weight"});
-            use({obj + ".q_proj.weight", obj + ".k_proj.weight", obj + ".v_proj.weight"});
-        }
-        TransposeGroupDesc td{};
-        auto add_t = [&](const float* in, float* out, int rows, int cols, int ldi, int ldo, int col_off) -> int {
-            if (td.n == 48) { SOLA_TRY(launch_transpose_group(td, s)); td.n = 0; }
-            td.in[td.n] = in; td.out[td.n] = out; td.rows[td.n] = rows; td.cols[td.n] = cols; td.ldi[td.n] = ldi; td.ldo[td.n] = ldo; td.col_off[td.n] = col_off;
-            ++td.n;
-            return SOLA_OK;
-        };
-        for (const WtUse& u : wt_seq)
-            for (int j = 0; j < u.nw; ++j) SOLA_TRY(add_t(u.w[j], u.dst, D, D, D, u.nw * D, j * D));
-        // the encoder's standardised conv weights (ws_buf, left by the forward) in the layouts its dX GEMMs read: ragged batches the
-        // whole [cout][k*cin] matrix, uniform ones tap by tap into [cin][k*cout]
-        for (int i = 5; i >= 1; --i) {
-            const ConvGeom& g = c->conv[i];
-            enc_wt[i] = base + off;
-            off += (size_t)g.cout * g.cin * g.k;
-            if (rt) {
-                SOLA_TRY(add_t(c->ws_buf + c->ws_off[i], enc_wt[i], g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0));
-            } else {
-                for (int kk = 0; kk < g.k; ++kk)
-                    SOLA_TRY(add_t(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, enc_wt[i], g.cout, g.cin, g.k * g.cin, g.k * g.cout, kk * g.cout));
-            }
-        }
-        if (td.n) SOLA_TRY(launch_transpose_group(td, s));
-    }
+    // few-sample backward, round 5: the dX GEMMs read the weight matrices in their own row-major layout (GemmDesc::w_nn, the few-row
+    // kernel's NN form: the same products in the same order as on a transposed copy) - the step's 49 weight transpositions (one grouped
+    // launch, 264 MB of traffic) are gone.  transpose_into() records the matrices of the next product, grad_x() hands them over.
+    const float* nn_w[3] = {nullptr, nullptr, nullptr};
+    int nn_rows = 0;
     bool side_pending[4] = {false, false, false, false};
     auto dw_begin = [&]() -> int {
         if (!lane_on) return SOLA_OK;
@@ -443,6 +396,17 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
         d.M = rows; d.N = k_in; d.K = n_cat; d.lda = ldy; d.ldr = k_in; d.ldc = k_in;
         d.splitk_ws = splitk_ws; d.splitk_bytes = splitk_bytes;
+        if (group) {
+            SOLA_ARG(nn_rows > 0 && n_cat % nn_rows == 0 && n_cat / nn_rows <= 3, "backward: dX product over %d columns of %d-row weight matrices", n_cat, nn_rows);
+            for (int j = 0; j < n_cat / nn_rows; ++j) d.w_nn[j] = nn_w[j];
+            d.w_nn_rows = nn_rows;
+            d.p[0].W = nullptr;
+            if (!gemm_nn_supported(d)) {  // outside the few-row shape: the transposed copy, as the many-row path
+                d.w_nn_rows = 0;
+                for (int j = 0; j < n_cat / nn_rows; ++j) SOLA_TRY(launch_transpose(nn_w[j], wt, nn_rows, k_in, k_in, n_cat, j * nn_rows, s));
+                d.p[0].W = wt;
+            }
+        }
         if (split && n_cat % (pure ? 64 : 32) == 0 && ldy % 4 == 0) {
             // dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal range), the
             // transposed weights with the fixed 2^6; the epilogue undoes both
@@ -465,14 +429,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         return launch_gemm(d, s);
     };
     auto transpose_into = [&](const float* w, int n_out, int k_in, int n_cat, int col_off) -> int {
-        if (group) {  // already transposed (one launch in front of the layers): switch wt to the block this dX GEMM reads
-            if (col_off == 0) {
-                SOLA_ARG(wt_next < wt_seq.size(), "backward: more transposed weight blocks than planned");
-                wt = wt_seq[wt_next++].dst;
-            }
-            const WtUse& u = wt_seq[wt_next - 1];
-            SOLA_ARG(n_out == D && k_in == D && n_cat == u.nw * D && col_off % D == 0 && col_off / D < u.nw && u.w[col_off / D] == w,
-                     "backward: transposed weight block out of the planned order");
+        if (group) {  // no copy: grad_x reads the matrix where it lies
+            SOLA_ARG(col_off % n_out == 0 && col_off / n_out < 3, "backward: weight block at column %d of %d-row matrices", col_off, n_out);
+            nn_w[col_off / n_out] = w;
+            nn_rows = n_out;
             return SOLA_OK;
         }
         if (split && n_cat % (pure ? 64 : 32) == 0) {  // grad_x's condition for the reduced-precision GEMM: the operand is written directly
@@ -686,7 +646,6 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         }
     }
     if (group) {  // the deferred weight gradients of every layer: one launch; all layer buckets are final behind it
-        wt = ar.get("wt");  // the encoder's dX GEMMs transpose into the shared buffer again
         SOLA_TRY(flush_group());
         SOLA_TRY(flush_gn());  // the layers' norm parameter gradients
         for (int l = c->cfg.n_layers - 1; l > 0; --l) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));
@@ -763,7 +722,20 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (rt) return launch_col2im_ragged(zc, dact, rows_in, rt->imap[i - 1], g.cin, g.k, g.stride, g.pad, s);
             return launch_col2im(zc, dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s);
         };
-        if (split && g.cout % 128 == 0 && g.cin % 8 == 0 && (size_t)rows * g.cout <= std::max((size_t)M, (size_t)BW) * 3 * D) {
+        // few-sample exact-f32 backward: z = dY W over the OUTPUT rows with the standardised weights read where the forward left them
+        // ([cout][k*cin] row-major = the few-row kernel's NN form: no transposed copy), then the taps are gathered - uniform batches too
+        // (their transposed-conv gather form multiplies twice the products for the stride-2 convs and ran on the 64x64 + split-K pair)
+        GemmDesc zd{};
+        if (group) {
+            zd.nprob = 1;
+            zd.p[0] = GemmProblem{dy, nullptr, nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
+            zd.M = rows; zd.N = g.k * g.cin; zd.K = g.cout; zd.lda = g.cout; zd.ldc = g.k * g.cin;
+            zd.w_nn[0] = c->ws_buf + c->ws_off[i]; zd.w_nn_rows = g.cout;
+        }
+        if (group && gemm_nn_supported(zd)) {
+            SOLA_TRY(launch_gemm(zd, s));
+            if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
+        } else if (split && g.cout % 128 == 0 && g.cin % 8 == 0 && (size_t)rows * g.cout <= std::max((size_t)M, (size_t)BW) * 3 * D) {
             // split-f16: z[(r,to)][kk*cin+ci] = sum_co dY[(r,to)][co] w_std[co][kk*cin+ci] in ONE NT GEMM over the output steps (a
             // strided conv's gather form would multiply zeros for every skipped step), then the k taps are gathered into dX
             float* scal = scc ? scc : ar.get("scal");
@@ -782,8 +754,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         } else if (rt) {
             // ragged, exact f32: the same decomposition - z = dY W over the OUTPUT rows (a plain GEMM on the concatenated rows, half
             // the products of the gather form for the stride-2 convs), then the taps are gathered per sequence
-            if (group) wt = enc_wt[i];  // transposed in front of the layers (one launch for every weight of the step)
-            else SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i], wt, g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0, s));  // wt [k*cin][cout]
+            SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i], wt, g.cout, g.k * g.cin, g.k * g.cin, g.cout, 0, s));  // wt [k*cin][cout]
             GemmDesc d{};
             d.nprob = 1;
             d.p[0] = GemmProblem{dy, wt, nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
@@ -792,8 +763,6 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(launch_gemm(d, s));
             if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
         } else {
-        if (group) wt = enc_wt[i];
-        else
         for (int kk = 0; kk < g.k; ++kk)
             SOLA_TRY(launch_transpose(c->ws_buf + c->ws_off[i] + (size_t)kk * g.cin, wt, g.cout, g.cin, g.k * g.cin,
                                       g.k * g.cout, kk * g.cout, s));

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossBwdArgs a) {
     for (int m = wave; m < a.n_neg; m += 4) {
         const float4* nv = reinterpret_cast<const float4*>(negb + (long long)m * a.D);
         float s = 0.f;
+#pragma unroll 4
         for (int i = lane; i < d4n; i += 64) {
             const float4 tv = tok[i], v = nv[i];
             s += (tv.x * v.x + tv.y * v.y) + (tv.z * v.z + tv.w * v.w);
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossBwdArgs a) {
     for (int i = threadIdx.x; i < d4n; i += 256) {
         const float4 pv = pos[i];
         float4 acc = make_float4(dpos * pv.x, dpos * pv.y, dpos * pv.z, dpos * pv.w);
+#pragma unroll 8
         for (int m = 0; m < a.n_neg; ++m) {
             const float cf = negl[m];
             const float4 v = reinterpret_cast<const float4*>(negb + (long long)m * a.D)[i];
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(256) void loss_dneg_kernel(const float* __restrict_
     if (trk_off) N = trk_off[b + 1] - trk_off[b];
     for (int i = threadIdx.x; i < d4n; i += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
         for (int n = 0; n < N; ++n) {
             const float cf = coef[(first + n) * n_neg + m];
             const float4 v = reinterpret_cast<const float4*>(tok + (first + n) * D)[i];

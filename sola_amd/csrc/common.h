@@ -56,37 +56,48 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-// The cross-row steps of a 64-lane butterfly (lane ^ 16, lane ^ 32) on the vector ALU: gfx950's v_permlane16_swap / v_permlane32_swap
-// exchange the odd 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another - fed the same
-// value twice they leave {x[l & ~16], x[l | 16]} ({x[l & 31], x[l | 32]}) in the two.  __shfl_xor is a ds_bpermute round trip through
-// the LDS (~100 cycles of latency each, four in a row per 16-key tile of an attention kernel).  Same operand pairs: same bits.
-typedef unsigned u32x2_swap __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float max_xor16(float x) {
-    const u32x2_swap r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+// A 64-lane xor butterfly on the vector ALU.  __shfl_xor is a ds_bpermute round trip through the LDS crossbar (~100+ cycles of latency
+// each; six dependent ones per wave_sum).  Every step below exchanges with exactly lane ^ o, so a sum / max taken with them in the same
+// order (32, 16, 8, 4, 2, 1) has the bits of the __shfl_xor form (tools/micro/wave_reduce_check.hip compares every lane of every step):
+//   o = 32, 16: v_permlane32_swap / v_permlane16_swap exchange the upper 32 lanes (the odd 16-lane rows) of one register with the lower
+//               32 lanes (the even rows) of another - fed two copies of v they leave {v[l & ~o], v[l | o]} in the two.  Inline asm: hipcc
+//               7.2 has folded the two results of the builtin called on (u, u) into ONE register inside larger kernels; s_nop 1 on both
+//               sides: a VALU result needs two wait states before a permlane reads it and the hazard recogniser does not look inside asm;
+//   o = 8:      DPP row_ror:8 (a rotation by half a row IS the xor);
+//   o = 4:      DPP row_ror:4 gives lane l the value of lane l - 4 (mod 16): the partner for the quads with bit 2 set (bank mask 0b1010),
+//               row_ror:12 the value of lane l + 4 for the others (0b0101);
+//   o = 2, 1:   DPP quad_perm [2,3,0,1] / [1,0,3,2].
+#define SOLA_DPP_MOV(old, v, ctrl, bank) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (old)), __builtin_bit_cast(int, (v)), (ctrl), 0xF, (bank), false))
+__device__ __forceinline__ void swap32_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ float max_xor32(float x) {
-    const u32x2_swap r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+__device__ __forceinline__ void swap16_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ float sum_xor16(float x) {
-    const u32x2_swap r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float sum_xor32(float x) {
-    const u32x2_swap r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+__device__ __forceinline__ float xor8_of(float v) { return SOLA_DPP_MOV(0.f, v, 0x128, 0xF); }
+__device__ __forceinline__ float xor4_of(float v) { return SOLA_DPP_MOV(SOLA_DPP_MOV(0.f, v, 0x124, 0xA), v, 0x12C, 0x5); }
+__device__ __forceinline__ float xor2_of(float v) { return SOLA_DPP_MOV(0.f, v, 0x4E, 0xF); }
+__device__ __forceinline__ float xor1_of(float v) { return SOLA_DPP_MOV(0.f, v, 0xB1, 0xF); }
+__device__ __forceinline__ float sum_xor32(float x) { float a, b; swap32_pair(x, a, b); return a + b; }
+__device__ __forceinline__ float sum_xor16(float x) { float a, b; swap16_pair(x, a, b); return a + b; }
+__device__ __forceinline__ float max_xor32(float x) { float a, b; swap32_pair(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float max_xor16(float x) { float a, b; swap16_pair(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float sum_xor8(float x) { return x + xor8_of(x); }
+__device__ __forceinline__ float sum_xor4(float x) { return x + xor4_of(x); }
+__device__ __forceinline__ float sum_xor2(float x) { return x + xor2_of(x); }
+__device__ __forceinline__ float sum_xor1(float x) { return x + xor1_of(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return sum_xor1(sum_xor2(sum_xor4(sum_xor8(sum_xor16(sum_xor32(v))))));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max_xor16(max_xor32(v));
+    v = fmaxf(v, xor8_of(v));
+    v = fmaxf(v, xor4_of(v));
+    v = fmaxf(v, xor2_of(v));
+    return fmaxf(v, xor1_of(v));
 }
 // Sum over the 32-lane half of the wave a lane belongs to, the same value in all of its lanes.  DPP adds inside the 16-lane rows
 // (swap pairs, swap quad halves, mirror the 8-lane halves, mirror the row: after each step the sum is uniform over twice as many

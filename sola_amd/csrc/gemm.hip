@@ -32,6 +32,8 @@ struct GemmArgs {
     int kt_per;
     float* part;      // [nprob][ksplit][M][N]
     int* guard;       // c_sp16: range guard word (GemmDesc::guard)
+    const float* w_nn[3];  // few-row shape, NN form (GemmDesc::w_nn)
+    int w_nn_rows;
 };
 
 // |v| must stay inside the f16 range to be written as a split-f16 pair; NaN fails the comparison too
@@ -460,8 +462,13 @@ constexpr int SM_LD = 36;  // stage row pitch in floats (as LDP)
 // CONV: A is the channels-last conv input and K = k * Cin (implicit im2col, GemmArgs::conv == 1; Cin % 32 == 0, so a 32-deep k-step lies
 // inside one tap): a row's window is (first tap's address, valid-tap bits) - from the uniform geometry or the ragged row map - and a step
 // reads its tap's 32 channels, zeros where the tap falls outside the sequence (clamped address, value select).
-template <int NW, bool CONV>
+// NN (round 5): W is given as its row-major [K][N] image (GemmDesc::w_nn: up to three stacked matrices) - a step's W tile is then 32
+// reduction rows x 32 output columns (rows of 128 contiguous bytes, the same load shape), staged as it lies, and the B fragments are column
+// reads (16 ds_read_b32 per step instead of 4 ds_read_b128; conflict-free: 32 consecutive columns per half-wave).  The same products in the
+// same order as the NT form on a transposed copy: bit-identical, without the copy (the 49 weight transpositions of a one-sample step).
+template <int NW, bool CONV, bool NN = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_kernel(const GemmArgs a) {
+    static_assert(!(CONV && NN), "NN: plain rows only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GemmProblem pr = a.p[0];  // (a.p[blockIdx.z] made the compiler copy the argument array to scratch to index it)
     if (blockIdx.z == 1) pr = a.p[1];
@@ -500,8 +507,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
             ap[i] = pr.A + (long long)m * a.lda + kb + lk;
             amask[i] = afall[i] = 0;
         }
-        wp[i] = pr.W + (long long)(n0 + lr + 8 * i) * a.K + kb + lk;
+        wp[i] = NN ? nullptr : pr.W + (long long)(n0 + lr + 8 * i) * a.K + kb + lk;
     }
+    // NN: element (reduction row kb + k + lr + 8 i, column n0 + lk) of the stacked matrices; a 32-row step lies inside one of them
+    auto nn_row = [&](int k) -> const float* {
+        const int kabs = kb + k, seg = kabs / a.w_nn_rows;  // wave-uniform
+        const float* base = seg == 0 ? a.w_nn[0] : (seg == 1 ? a.w_nn[1] : a.w_nn[2]);
+        return base + (long long)(kabs - seg * a.w_nn_rows + lr) * a.N + n0 + lk;
+    };
     // (prefetch registers as eight named values and the staging as macros: with arrays captured by lambdas the compiler kept them in a
     // 144-byte scratch frame - a scratch store behind every load and a full wait in front of every LDS write)
     float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
@@ -517,12 +530,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
             dst = *reinterpret_cast<const float4*>(ap[i] + (k));                                                         \
         }                                                                                                               \
     } while (0)
+#define SM_LOAD_W(i, k, dst, nnp)                                                                                        \
+    do {                                                                                                                \
+        if constexpr (NN) dst = *reinterpret_cast<const float4*>((nnp) + (long long)(8 * (i)) * a.N);                    \
+        else dst = *reinterpret_cast<const float4*>(wp[i] + (k));                                                        \
+    } while (0)
 #define SM_LOAD(k)                                                                                                      \
     do {                                                                                                                \
-        SM_LOAD_A(0, k, ra0); rw0 = *reinterpret_cast<const float4*>(wp[0] + (k));                                       \
-        SM_LOAD_A(1, k, ra1); rw1 = *reinterpret_cast<const float4*>(wp[1] + (k));                                       \
-        SM_LOAD_A(2, k, ra2); rw2 = *reinterpret_cast<const float4*>(wp[2] + (k));                                       \
-        SM_LOAD_A(3, k, ra3); rw3 = *reinterpret_cast<const float4*>(wp[3] + (k));                                       \
+        const float* nnp_ = nullptr;                                                                                    \
+        if constexpr (NN) nnp_ = nn_row(k);                                                                             \
+        SM_LOAD_A(0, k, ra0); SM_LOAD_W(0, k, rw0, nnp_);                                                                \
+        SM_LOAD_A(1, k, ra1); SM_LOAD_W(1, k, rw1, nnp_);                                                                \
+        SM_LOAD_A(2, k, ra2); SM_LOAD_W(2, k, rw2, nnp_);                                                                \
+        SM_LOAD_A(3, k, ra3); SM_LOAD_W(3, k, rw3, nnp_);                                                                \
     } while (0)
 #define SM_STORE(buf)                                                                                                   \
     do {                                                                                                                \
@@ -547,8 +567,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
         const float* Wb = Ab + 32 * SM_LD;
         const float4 af0 = *reinterpret_cast<const float4*>(Ab), af1 = *reinterpret_cast<const float4*>(Ab + 8);
         const float4 af2 = *reinterpret_cast<const float4*>(Ab + 16), af3 = *reinterpret_cast<const float4*>(Ab + 24);
-        const float4 bf0 = *reinterpret_cast<const float4*>(Wb), bf1 = *reinterpret_cast<const float4*>(Wb + 8);
-        const float4 bf2 = *reinterpret_cast<const float4*>(Wb + 16), bf3 = *reinterpret_cast<const float4*>(Wb + 24);
+        float4 bf0, bf1, bf2, bf3;
+        if constexpr (NN) {  // the staged tile is [reduction row][column]: B[k = frag_k + 8 j + e][n = frag_row]
+            const float* Wc = st + buf * (2 * 32 * SM_LD) + 32 * SM_LD + frag_k * SM_LD + frag_row;
+            bf0 = make_float4(Wc[0], Wc[SM_LD], Wc[2 * SM_LD], Wc[3 * SM_LD]);
+            bf1 = make_float4(Wc[8 * SM_LD], Wc[9 * SM_LD], Wc[10 * SM_LD], Wc[11 * SM_LD]);
+            bf2 = make_float4(Wc[16 * SM_LD], Wc[17 * SM_LD], Wc[18 * SM_LD], Wc[19 * SM_LD]);
+            bf3 = make_float4(Wc[24 * SM_LD], Wc[25 * SM_LD], Wc[26 * SM_LD], Wc[27 * SM_LD]);
+        } else {
+            bf0 = *reinterpret_cast<const float4*>(Wb); bf1 = *reinterpret_cast<const float4*>(Wb + 8);
+            bf2 = *reinterpret_cast<const float4*>(Wb + 16); bf3 = *reinterpret_cast<const float4*>(Wb + 24);
+        }
         if (kt + 1 < nk) SM_STORE(buf ^ 1);          // the registers hold step kt + 1
         // the stage written here is read by other lanes of THIS wave in the next iteration: pin the order (a wave's DS operations execute in
         // order; this keeps the compiler from ever moving the next iteration's fragment reads above these writes - no instruction is emitted)
@@ -564,6 +593,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
         SM_MFMA4(af0, bf0) SM_MFMA4(af1, bf1) SM_MFMA4(af2, bf2) SM_MFMA4(af3, bf3)
     }
 #undef SM_LOAD
+#undef SM_LOAD_W
 #undef SM_LOAD_A
 #undef SM_STORE
 #undef SM_MFMA4
@@ -604,28 +634,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_nt_f32_small_ke
 int g_gemm_small_rows = 2048;  // sola_tune "gemm_small_rows": exact-f32 GEMMs of at most this many rows take the 32x32 in-block split-K shape (0 = never)
 static bool gemm_small_applies(const GemmDesc& d) {
     if (d.r_sp16 || d.c_sp16 || d.gn_gamma) return false;  // the kernel reads R and writes C as plain f32 rows, no fused norm
+    if (d.w_nn_rows) {  // NN form: one problem, plain rows, whole 32-row steps inside each stacked matrix, 16-byte aligned rows
+        if (d.nprob != 1 || d.conv || d.w_nn_rows % 32 != 0 || d.K % d.w_nn_rows != 0 || d.K / d.w_nn_rows > 3 || d.N % 4 != 0) return false;
+        for (int j = 0; j < d.K / d.w_nn_rows; ++j)
+            if (!d.w_nn[j] || (reinterpret_cast<uintptr_t>(d.w_nn[j]) & 15)) return false;
+    }
     if (d.arith != 0 || d.conv > 1 || d.M > g_gemm_small_rows || d.N % 32 != 0 || d.K % 128 != 0 || d.ldc % 4 != 0) return false;
     if (d.conv ? (d.Cin % 32 != 0 || d.K % d.Cin != 0 || d.K / d.Cin > 8 || (!d.rowmap && (d.T_out <= 0 || d.T_in <= 0))) : d.lda % 4 != 0) return false;
     for (int j = 0; j < d.nprob; ++j) {
         if (d.p[j].R && d.ldr % 4 != 0) return false;
         if (d.p[j].bias && (reinterpret_cast<uintptr_t>(d.p[j].bias) & 15)) return false;
-        if ((reinterpret_cast<uintptr_t>(d.p[j].A) | reinterpret_cast<uintptr_t>(d.p[j].W) | reinterpret_cast<uintptr_t>(d.p[j].C)) & 15) return false;
+        if ((reinterpret_cast<uintptr_t>(d.p[j].A) | (d.w_nn_rows ? 0 : reinterpret_cast<uintptr_t>(d.p[j].W)) | reinterpret_cast<uintptr_t>(d.p[j].C)) & 15) return false;
         if (d.p[j].R && (reinterpret_cast<uintptr_t>(d.p[j].R) & 15)) return false;
     }
     return true;
 }
 int g_gemm_small_nw8 = 1;  // sola_tune "gemm_small_nw8": 0 = always four waves per tile (A/B)
-template <int NW, bool CONV>
+template <int NW, bool CONV, bool NN = false>
 static int launch_small_n(const GemmArgs& a, int nprob, hipStream_t s) {
     constexpr size_t lds = (size_t)NW * 2 * 2 * 32 * SM_LD * sizeof(float);  // NW waves x two stages (73.7 / 147.5 KB); the reduction reuses it
     static_assert(NW * 32 * 33 <= NW * 2 * 2 * 32 * SM_LD, "the reduction tile must fit in the stages");
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel<NW, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_small_kernel<NW, CONV, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
-    hipLaunchKernelGGL((gemm_nt_f32_small_kernel<NW, CONV>), dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_f32_small_kernel<NW, CONV, NN>), dim3(a.tiles_m * a.tiles_n, 1, nprob), dim3(64 * NW), lds, s, a);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
@@ -636,6 +671,7 @@ static int launch_small(const GemmArgs& base, int nprob, hipStream_t s) {
     a.xcd_remap = ((a.tiles_m * a.tiles_n) % 8 == 0) ? 1 : 0;
     const long long tiles = (long long)a.tiles_m * a.tiles_n * nprob;
     const bool nw8 = g_gemm_small_nw8 && a.K % 256 == 0 && tiles <= 2 * sola_cu_count();
+    if (a.w_nn_rows) return nw8 ? launch_small_n<8, false, true>(a, nprob, s) : launch_small_n<4, false, true>(a, nprob, s);
     if (a.conv) return nw8 ? launch_small_n<8, true>(a, nprob, s) : launch_small_n<4, true>(a, nprob, s);
     return nw8 ? launch_small_n<8, false>(a, nprob, s) : launch_small_n<4, false>(a, nprob, s);
 }
@@ -672,6 +708,8 @@ int g_gemm_splitk_tiles = 512;  // grids with fewer 64x64 tiles than this are sp
 int g_gemm_variant = -1;  // -1 auto (measured: simple schedule wins on 128x128 by 5%, mid-tile staging on 64x64 by 6%), 0 / 1 force
 
 }  // namespace
+
+bool gemm_nn_supported(const GemmDesc& d) { return d.w_nn_rows > 0 && gemm_small_applies(d); }
 
 int g_gemm_glds = 3;  // split-f16 GEMM, direct-to-LDS staging (gemm_glds.hip): 0 off, 1 128x128 blocks, 4 256x256 blocks, 3 auto
 int g_gemm_glds_force = 0;  // tests: take the direct-to-LDS kernels for grids of any size
@@ -727,6 +765,9 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.c_sp16 = d.arith == 1 ? d.c_sp16 : 0;
     a.ksplit = 1; a.kt_per = 0; a.part = nullptr;
     a.guard = a.c_sp16 ? d.guard : nullptr;
+    for (int j = 0; j < 3; ++j) a.w_nn[j] = d.w_nn_rows ? d.w_nn[j] : nullptr;
+    a.w_nn_rows = d.w_nn_rows;
+    SOLA_ARG(!d.w_nn_rows || gemm_nn_supported(d), "gemm: the row-major weight form needs the few-row exact-f32 shape (M=%d N=%d K=%d, rows per matrix %d)", d.M, d.N, d.K, d.w_nn_rows);
     SOLA_ARG(!a.c_sp16 || (d.N % 8 == 0 && d.ldc % 8 == 0), "gemm: split-f16 output needs N %% 8 == 0 and ldc %% 8 == 0");
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nprob;
     const bool big = t128 >= 512;  // two 128x128 blocks per CU x 256 CUs

@@ -220,20 +220,33 @@ __global__ __launch_bounds__(256) void loss_terms_regs_kernel(const LossArgs a) 
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     const float* negb = a.neg + (long long)b * a.neg_batch_stride;
     const int stride = a.n_neg + 1;
+    // the next vector travels while this one is reduced (at one sample per call a wave's nine iterations each waited for their own load;
+    // the loop holds cross-lane operations, so the compiler will not unroll it over a runtime trip count)
+    auto vec_of = [&](int m) { return reinterpret_cast<const float4*>(m < a.n_neg ? negb + (long long)m * a.D : a.pos + (long long)b * a.D); };
+    float4 vcur[NI], vnext[NI];
+    if (wave <= a.n_neg) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) vcur[i] = vec_of(wave)[lane + 64 * i];
+    }
     for (int m = wave; m <= a.n_neg; m += 4) {
-        const float4* vec = reinterpret_cast<const float4*>(m < a.n_neg ? negb + (long long)m * a.D : a.pos + (long long)b * a.D);
+        if (m + 4 <= a.n_neg) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) vnext[i] = vec_of(m + 4)[lane + 64 * i];
+        }
         float s[LOSS_RPB];
 #pragma unroll
         for (int r = 0; r < LOSS_RPB; ++r) s[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const float4 v = vec[lane + 64 * i];
+            const float4 v = vcur[i];
 #pragma unroll
             for (int r = 0; r < LOSS_RPB; ++r) {
                 const float4 tv = tk[r][i];
                 s[r] += (tv.x * v.x + tv.y * v.y) + (tv.z * v.z + tv.w * v.w);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) vcur[i] = vnext[i];
 #pragma unroll
         for (int r = 0; r < LOSS_RPB; ++r) {
             const float t = wave_sum(s[r]);

@@ -52,7 +52,13 @@ struct GemmDesc {
     const float *gn_gamma, *gn_beta;
     int gn_tokens;
     float gn_eps, gn_slope;
+    // arith 0, few-row shape only (gemm_nn_supported): the weights in their ROW-MAJOR [K][N] form instead of W[N][K] - the reduction index
+    // runs over the rows of up to three matrices of w_nn_rows rows each, stacked (K = their total; pitch N; p[].W unused): a dX GEMM reads
+    // the layer's weight matrices where they lie, no transposed copy.  One problem.  0 = off.
+    const float* w_nn[3];
+    int w_nn_rows;
 };
+bool gemm_nn_supported(const GemmDesc& d);  // the launch takes the w_nn form (else launch_gemm fails)
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 bool gemm_gn_fusable(const GemmDesc& d, int channels_per_group, int tokens);
 

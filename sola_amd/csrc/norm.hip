@@ -550,19 +550,30 @@ __global__ void pos_encoding_kernel(const float* __restrict__ gauss, int half, i
 }
 
 // lang_cat[b, w, :] and lbar[b, :] = mean_w lang_cat[b, w, :]; one thread per (b, float4 column)
-__global__ void lang_concat_kernel(const float* __restrict__ lang, const float* __restrict__ neg, float* out,
-                                   float* lbar, int B, int L, int n_neg, int D) {
+// (eight rows' loads in flight per thread: at one sample per call the 256 threads of the only block walked the 48 rows one load at a time)
+__global__ void lang_concat_kernel(const float* __restrict__ lang, const float* __restrict__ neg, float* __restrict__ out,
+                                   float* __restrict__ lbar, int B, int L, int n_neg, int D) {
     const int d4 = D >> 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * d4) return;
     const int b = i / d4, c = (i - b * d4) * 4;
     const int W = L + n_neg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = 0; w < W; ++w) {
-        const float4 v = w < L ? *reinterpret_cast<const float4*>(lang + ((long long)b * L + w) * D + c)
-                               : *reinterpret_cast<const float4*>(neg + (long long)(w - L) * D + c);
-        *reinterpret_cast<float4*>(out + ((long long)b * W + w) * D + c) = v;
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int w0 = 0; w0 < W; w0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = min(w0 + j, W - 1);
+            v[j] = w < L ? *reinterpret_cast<const float4*>(lang + ((long long)b * L + w) * D + c)
+                         : *reinterpret_cast<const float4*>(neg + (long long)(w - L) * D + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (w0 + j < W) {  // the same order of additions as a row-by-row walk
+                *reinterpret_cast<float4*>(out + ((long long)b * W + w0 + j) * D + c) = v[j];
+                acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+            }
+        }
     }
     const float inv = 1.f / (float)W;
     *reinterpret_cast<float4*>(lbar + (long long)b * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);

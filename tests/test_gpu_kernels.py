@@ -75,6 +75,41 @@ def test_gemm_nt_few_rows_shape(M, N, K):
     assert rel < 2e-6, rel
 
 
+@pytest.mark.parametrize("M,N,w_rows,nw,has_res", [(256, 1024, 1024, 1, True), (256, 1024, 1024, 3, True), (616, 1024, 1024, 2, False), (31, 64, 128, 1, True),
+                                                   (1000, 96, 128, 3, False), (2048, 1024, 512, 2, True), (48, 1536, 1024, 1, False), (300, 768, 1024, 1, True)])
+def test_gemm_nn_few_rows_shape(M, N, w_rows, nw, has_res):
+    """Round 5: the input gradient of F.linear, dX = dY W (tools/attention.py:63-65 backward; d x = [dq|dk|dv] [Wq;Wk;Wv]), on the few-row
+    exact-f32 kernel with the weights read in their own row-major layout (sola_gemm_nn: up to three stacked matrices) instead of a
+    transposed copy: against float64, and BIT-IDENTICAL to sola_gemm_nt on the transposed, concatenated copy (the same products in the
+    same order - the one-sample training step dropped its 49 weight transpositions for this)."""
+    from sola_amd import _lib
+    from sola_amd._lib import check, current_stream, lib, ptr
+    K = w_rows * nw
+    rng = np.random.default_rng(M + N + K + nw)
+    a = cuda(rnd(rng, M, K))
+    ws = [cuda(rnd(rng, w_rows, N, scale=0.05)) for _ in range(nw)]
+    r = cuda(rnd(rng, M, N)) if has_res else None
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    check(lib().sola_gemm_nn(ptr(a), K, ptr(ws[0]), ptr(ws[1]) if nw > 1 else None, ptr(ws[2]) if nw > 2 else None, w_rows, ptr(r), N, ptr(out), N,
+                             M, N, K, current_stream(out.device)), "sola_gemm_nn")
+    wcat = torch.cat(ws, dim=0)  # [K, N]
+    ref = a.double().cpu().numpy() @ wcat.double().cpu().numpy()
+    if has_res:
+        ref = ref + r.double().cpu().numpy()
+    assert_close(out, ref, name=f"gemm_nn {M}x{N}x{K}")
+    nt = ops.gemm_nt(a, wcat.t().contiguous(), None, r)
+    assert torch.equal(out, nt)
+
+
+def test_gemm_nn_outside_the_few_row_shape_is_an_error():
+    from sola_amd._lib import current_stream, lib, ptr
+    a = torch.zeros((4096, 1024), device="cuda")
+    w = torch.zeros((1024, 1024), device="cuda")
+    out = torch.empty((4096, 1024), device="cuda")
+    rc = lib().sola_gemm_nn(ptr(a), 1024, ptr(w), None, None, 1024, None, 0, ptr(out), 1024, 4096, 1024, 1024, current_stream(out.device))
+    assert rc < 0 and b"row-major weight form" in lib().sola_last_error()
+
+
 @pytest.mark.parametrize("M,N,K,has_res", [(65536, 1024, 1024, True), (65536, 512, 768, False), (40930, 1024, 1024, True), (33000, 520, 256, True),
                                            (66000, 1000, 384, False), (24577, 1024, 3072, True)])
 def test_gemm_nt_persistent_f32_kernel(M, N, K, has_res):
