@@ -304,7 +304,9 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
 
     def step1():  # round 5: the same step with its device work enqueued by ONE library call (module.train_step -> sola_train_step; bit-identical)
         # ... and clipping + AdamW as one more launch with torch's fused arithmetic (sola_adamw_step: bit-identical parameters and moments)
-        m.train_step(inp1["object_tokens"], inp1["lang_tokens"], inp1["labels"], inp1["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0, optimizer=opt)
+        # (write_back_grads=False, as train.py calls it: an active clip does not rewrite .grad, which the loop never reads again)
+        m.train_step(inp1["object_tokens"], inp1["lang_tokens"], inp1["labels"], inp1["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0, optimizer=opt,
+                     write_back_grads=False)
 
     # variable-shape samples in ONE step (sola_forward_train_ragged / sola_backward_ragged): the MeViS-like mix of the ragged
     # inference leg (N~U[8,80], T~U[20,200], L~U[4,24]); objective = mean of the per-sample totals

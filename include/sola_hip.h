@@ -301,10 +301,11 @@ int sola_train_step(SolaCtx* ctx, const float* dev_object_tokens, const float* d
  *     torch's per-parameter device float, kept in sync, or null).  Parameters and gradients are the context's own bindings
  *     (sola_set_weight / sola_set_grad): the update writes the caller's parameter storage.  Bind again when a pointer changes.
  *   sola_adamw_step: `step` = number of this update (1, 2, ...); max_grad_norm > 0 scales every gradient by min(1, max_norm / (sqrt(*dev_total_sq)
- *     + 1e-6)) first (torch.nn.utils.clip_grad_norm_; the scaled gradient is written back), decided on the device. */
+ *     + 1e-6)) first (torch.nn.utils.clip_grad_norm_), decided on the device; write_back_grads != 0 leaves the scaled gradients in the
+ *     gradient tensors as clip_grad_norm_ does, 0 leaves them unclipped (an eighth less traffic; train.py:121-125 never reads them again). */
 int sola_adamw_bind(SolaCtx* ctx, const char* const* names, void* const* dev_exp_avg, void* const* dev_exp_avg_sq, void* const* dev_step, int n);
 int sola_adamw_step(SolaCtx* ctx, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, const double* dev_total_sq,
-                    float max_grad_norm, void* stream);
+                    float max_grad_norm, int write_back_grads, void* stream);
 /* ---- ragged training step: many (video, expression) samples of DIFFERENT shapes per optimizer step -------------------------
  * The reference trains at batch size 1 (configs/mevis/default.yaml:37; train.py:62-137: one forward, one backward, one AdamW
  * step per sample) because every sample has its own N tracks, T frames and L text tokens (dataloader.py:119-163,187-199).

@@ -133,7 +133,7 @@ SIGNATURES = {
     "sola_tune": (_i, [C.c_char_p, _i]),
     "sola_has_experiments": (_i, []),
     "sola_adamw_bind": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i]),
-    "sola_adamw_step": (_i, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp, _f, _vp]),
+    "sola_adamw_step": (_i, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp, _f, _i, _vp]),
     "sola_train_step_bind": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _i, _i]),
     "sola_train_step_workspace_bytes": (_sz, [_vp, _i, _i]),
     "sola_train_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),

@@ -961,9 +961,12 @@ __global__ __launch_bounds__(256) void attn_bwd_part_reduce_kernel(const AttnBwd
     const BwdGeo geo = bwd_geo(a, grp);
     const int nch = ((geo.Sq + 15) / 16 + a.qc_tiles - 1) / a.qc_tiles;
     const long long slot0 = geo.q0 / (16 * a.qc_tiles) + grp;
-    for (int idx = threadIdx.x; idx < geo.Sk * 2 * (DH / 4); idx += 256) {
+    // blockIdx.y: 256 of the unit's Sk * 64 float4 each (one sample per step has eight (unit, head) pairs: eight blocks walked twelve
+    // positions x four chunks one load at a time, 16 us)
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < geo.Sk * 2 * (DH / 4); idx += 256 * gridDim.y) {
         const int c4 = idx & 31, t = (idx >> 5) & 1, kj = idx >> 6;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
         for (int c = 0; c < nch; ++c) {
             const float4 v = *reinterpret_cast<const float4*>(a.part + (((slot0 + c) * a.H + h) * 2 + t) * (long long)kp * DH + kj * DH + c4 * 4);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -998,7 +1001,9 @@ static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (a.qc_tiles) {
-        hipLaunchKernelGGL(attn_bwd_part_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, 16 * NWU);
+        // few (unit, head) pairs: the positions of a unit (at most 16 NWU keys x 64 float4) over several blocks
+        const int ysplit = blocks >= 2048 ? 1 : std::min((16 * NWU * 64 + 255) / 256, (int)std::max<long long>(1, 2048 / blocks));
+        hipLaunchKernelGGL(attn_bwd_part_reduce_kernel, dim3((unsigned)blocks, (unsigned)ysplit), dim3(256), 0, s, a, 16 * NWU);
         SOLA_LAUNCH_CHECK();
     }
     return SOLA_OK;

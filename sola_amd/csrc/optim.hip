@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const double* __restrict__
     double s[MT_FOLD_GROUPS];
 #pragma unroll
     for (int g = 0; g < MT_FOLD_GROUPS; ++g) s[g] = 0.0;
+#pragma unroll 8
     for (int i = threadIdx.x; i < n_blocks; i += 256) {
         const int pg = pgroup[i];
         const double v = partial[i];
@@ -134,7 +135,7 @@ struct AdamEntry {
     int pad;
 };
 __global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __restrict__ tab, int n, const double* __restrict__ total_sq, float max_norm,
-                                                             double lr, double beta1, double beta2, double eps, double weight_decay, float step) {
+                                                             double lr, double beta1, double beta2, double eps, double weight_decay, float step, int write_back) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -189,11 +190,11 @@ __global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __r
             *reinterpret_cast<float4*>(e.p + idx) = make_float4(pr[0], pr[1], pr[2], pr[3]);
             *reinterpret_cast<float4*>(e.m + idx) = make_float4(mr[0], mr[1], mr[2], mr[3]);
             *reinterpret_cast<float4*>(e.v + idx) = make_float4(vr[0], vr[1], vr[2], vr[3]);
-            if (clip) *reinterpret_cast<float4*>(e.g + idx) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+            if (clip && write_back) *reinterpret_cast<float4*>(e.g + idx) = make_float4(gr[0], gr[1], gr[2], gr[3]);
         } else {
             for (int j = 0; j < cnt; ++j) {
                 e.p[idx + j] = pr[j]; e.m[idx + j] = mr[j]; e.v[idx + j] = vr[j];
-                if (clip) e.g[idx + j] = gr[j];
+                if (clip && write_back) e.g[idx + j] = gr[j];
             }
         }
     }
@@ -266,11 +267,11 @@ void mt_adam_entry_fill(void* host_entry, float* p, float* g, float* m, float* v
 }
 int mt_adam_blocks(long long numel) { return (int)((numel + MT_CHUNK - 1) / MT_CHUNK); }
 int launch_mt_clip_adamw(const void* tab_dev, int n, int blocks, double bytes, const double* total_sq, float max_norm, double lr, double beta1, double beta2,
-                         double eps, double weight_decay, float step, hipStream_t s) {
+                         double eps, double weight_decay, float step, int write_back, hipStream_t s) {
     SOLA_ARG(tab_dev && n > 0 && blocks > 0 && step >= 1.f && (max_norm <= 0.f || total_sq), "clip_adamw: bad arguments");
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
     hipLaunchKernelGGL(mt_clip_adamw_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const AdamEntry*>(tab_dev), n, total_sq, max_norm, lr, beta1, beta2, eps,
-                       weight_decay, step);
+                       weight_decay, step, write_back);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

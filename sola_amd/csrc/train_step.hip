@@ -166,12 +166,14 @@ extern "C" int sola_adamw_bind(SolaCtx* c, const char* const* names, void* const
 
 // step = the update's number (1 for the first); dev_total_sq = the gradients' total sum of squares on the device (sola_train_step's
 // dev_grad_sq + n_groups) when max_grad_norm > 0, else ignored.  Invalidate derived weight copies afterwards (sola_weights_changed).
+// write_back_grads: 1 = an active clip leaves the scaled gradients in the gradient tensors (what clip_grad_norm_ leaves in .grad); 0 = they
+// keep the unclipped values (one eighth less traffic: train.py never reads .grad behind optimizer.step()) - parameters and moments the same
 extern "C" int sola_adamw_step(SolaCtx* c, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, const double* dev_total_sq,
-                               float max_grad_norm, void* stream_) {
+                               float max_grad_norm, int write_back_grads, void* stream_) {
     SOLA_ARG(c && c->adam_tab && c->adam_n > 0, "adamw_step: sola_adamw_bind has not been called on this context");
     SOLA_ARG(step >= 1 && step < (1 << 24), "adamw_step: step %lld (a float counts it exactly up to 2^24)", (long long)step);
     SOLA_TRY(launch_mt_clip_adamw(c->adam_tab, c->adam_n, c->adam_blocks, c->adam_bytes, dev_total_sq, max_grad_norm, lr, beta1, beta2, eps, weight_decay, (float)step,
-                                  as_stream(stream_)));
+                                  write_back_grads, as_stream(stream_)));
     c->ws_dirty = true;
     c->lin16_dirty = true;
     return SOLA_OK;

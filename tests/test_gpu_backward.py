@@ -801,6 +801,37 @@ def test_fused_clip_adamw_equals_torch(max_norm):
             assert float(sa["step"]) == float(sb["step"]) == step + 1, (step, k)
 
 
+def test_fused_clip_adamw_without_gradient_write_back():
+    """sola_adamw_step(write_back_grads = 0) - what train.py and the bench's one-sample step pass: with the clip ACTIVE the parameters and
+    both moments are bit-identical to the write-back form (and so to torch's), and .grad keeps the UNCLIPPED gradient."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, 1, 64, 32, 16, 5).items()}
+    ms, opts = [], []
+    for _ in range(2):
+        m, _sd = build(cfg)
+        m.train(True)
+        m.precision = "f32"
+        ms.append(m)
+        opts.append(torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.05, fused=True))
+    for step in range(3):
+        for j, wb in enumerate((True, False)):
+            torch.manual_seed(31 + step)
+            ms[j].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1e-3,
+                             optimizer=opts[j], write_back_grads=wb)
+        torch.cuda.synchronize()
+        scale = None
+        for (k, p), (_k, q) in zip(ms[0]._params(), ms[1]._params()):
+            assert torch.equal(p.detach(), q.detach()), (step, k, "parameter")
+            sa, sb = opts[0].state[p], opts[1].state[q]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (step, k, "moments")
+            if float(q.grad.abs().max()) > 0:
+                assert not torch.equal(p.grad, q.grad), (step, k)  # clipped against unclipped
+                if scale is None:
+                    i = int(q.grad.abs().argmax())
+                    scale = float(p.grad.flatten()[i] / q.grad.flatten()[i])
+        assert scale is not None and 0.0 < scale < 1.0
+
+
 @pytest.mark.parametrize("max_norm", [0.0, 0.5])
 def test_optimizer_step_after_an_autograd_backward_equals_torch(max_norm):
     """module.optimizer_step(optimizer, max_grad_norm) - clip + AdamW as one launch behind a backward that went through autograd (uniform

@@ -28,13 +28,15 @@ def step_call():
     opt.step()
 def step_call_adam():
     m.train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], 1.5, 0.07, 0.3, max_grad_norm=1.0, optimizer=opt)
+def step_call_adam_nowb():  # as train.py calls it: an active clip does not rewrite .grad
+    m.train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], 1.5, 0.07, 0.3, max_grad_norm=1.0, optimizer=opt, write_back_grads=False)
 def wall(fn, n=200):
     for _ in range(20): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     return (t2 - t0) / n, (t1 - t0) / n
-for name, fn in (("autograd path", step_autograd), ("train_step call", step_call), ("train_step + in-library clip+AdamW", step_call_adam), ("autograd path", step_autograd), ("train_step call", step_call), ("train_step + in-library clip+AdamW", step_call_adam)):
+for name, fn in (("autograd path", step_autograd), ("train_step call", step_call), ("train_step + in-library clip+AdamW", step_call_adam), ("... without gradient write-back", step_call_adam_nowb), ("autograd path", step_autograd), ("train_step call", step_call), ("train_step + in-library clip+AdamW", step_call_adam), ("... without gradient write-back", step_call_adam_nowb)):
     w, h = wall(fn)
     print(f"{name}: wall {w * 1e3:.3f} ms/step ({1 / w:.0f} samples/s), host enqueue {h * 1e3:.3f} ms/step", flush=True)
 _lib.profile_enable(True); _lib.profile_read(reset=True)

@@ -57,7 +57,7 @@ def run_split(module, text, loader, tcfg, device, train, optimizer=None, world=1
             # clipping (train.py:95-122) as ONE library call (module.train_step -> sola_train_step); bit-identical to the statements below
             # (clipping + the AdamW update: one more launch with torch's fused arithmetic on the optimizer's own state tensors - sola_adamw_step)
             loss3, score, tokens = module.train_step(obj, lang, labels, pos, pw, temp, aw, max_grad_norm=max(float(tcfg["grad_clip_norm"]), 0.0),
-                                                     optimizer=optimizer)
+                                                     optimizer=optimizer, write_back_grads=False)  # .grad is not read behind the step
             sums += loss3.detach()
             n += 1
             continue
