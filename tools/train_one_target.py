@@ -14,7 +14,7 @@ m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_di
 m = m.cuda().train(); m.precision = "f32"
 opt = torch.optim.AdamW(m.parameters(), lr=1e-5, fused=True)
 inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, 1, N, T, L, 1).items()}
-for _ in range(100):
+for _ in range(int(os.environ.get("ONE_STEPS", "100"))):
     m.train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], 1.5, 0.07, 0.3, max_grad_norm=1.0, optimizer=opt)
 torch.cuda.synchronize()
 print("done")

@@ -36,6 +36,10 @@ def wall(fn, n=200):
     for _ in range(n): fn()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     return (t2 - t0) / n, (t1 - t0) / n
+if os.environ.get("PROBE_SIDE_STREAM") == "1":  # a created (non-null) stream instead of the legacy default stream
+    _side = torch.cuda.Stream()
+    torch.cuda.set_stream(_side)
+    print("running on a created stream")
 for name, fn in (("autograd path", step_autograd), ("train_step call", step_call), ("train_step + in-library clip+AdamW", step_call_adam), ("... without gradient write-back", step_call_adam_nowb), ("autograd path", step_autograd), ("train_step call", step_call), ("train_step + in-library clip+AdamW", step_call_adam), ("... without gradient write-back", step_call_adam_nowb)):
     w, h = wall(fn)
     print(f"{name}: wall {w * 1e3:.3f} ms/step ({1 / w:.0f} samples/s), host enqueue {h * 1e3:.3f} ms/step", flush=True)
