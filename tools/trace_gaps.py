@@ -1,6 +1,6 @@
 """A steady-state step of a rocprofv3 kernel trace as a timeline: per kernel name the launches per step, their mean duration and the mean
 idle time in front of them (start minus the previous kernel's end).  The last `steps` repetitions of a `period`-launch pattern are used.
-    python tools/trace_gaps.py <stats_kernel_trace.csv> [steps = 50]"""
+    python tools/trace_gaps.py <stats_kernel_trace.csv> [steps = 50] [substring of the kernel that ends a step = mt_clip_adamw]"""
 import collections
 import csv
 import sys
@@ -10,7 +10,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 names = [r["Kernel_Name"] for r in rows]
 # period: distance between the last two launches of the optimizer kernel (one per step)
-marks = [i for i, n in enumerate(names) if "mt_clip_adamw" in n]
+marker = sys.argv[3] if len(sys.argv) > 3 else "mt_clip_adamw"
+marks = [i for i, n in enumerate(names) if marker in n]
 period = marks[-1] - marks[-2]
 seg = rows[marks[-1 - steps] + 1: marks[-1] + 1]
 dur = collections.defaultdict(float); gap = collections.defaultdict(float); cnt = collections.Counter()
