@@ -224,35 +224,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f32_group_kernel(const TnG
     tn_tile<NW>(a, (int)blockIdx.x - q.tile_begin, 0, smem);
 }
 
-// out_e[c * ldo_e + col_off_e + r] = in_e[r * ldi_e + c] (ldi_e = 0: contiguous rows) for up to TR_GROUP_MAX matrices in one launch (blockIdx.z = e): the weight
-// transpositions W -> W^T of a few-sample backward's dX GEMMs (36 launches of ~5 us per step)
-constexpr int TR_GROUP_MAX = 48;
-struct TrGroupArgs {
-    const float* in[TR_GROUP_MAX];
-    float* out[TR_GROUP_MAX];
-    int rows[TR_GROUP_MAX], cols[TR_GROUP_MAX], ldi[TR_GROUP_MAX], ldo[TR_GROUP_MAX], col_off[TR_GROUP_MAX];
-};
-__global__ __launch_bounds__(256) void transpose_group_kernel(const TrGroupArgs g) {
-    __shared__ float tile[32][33];
-    const int e = blockIdx.z;
-    const int rows = g.rows[e], cols = g.cols[e];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    if (r0 >= rows || c0 >= cols) return;  // the grid is sized for the largest matrix (block-uniform)
-    const float* __restrict__ in = g.in[e];
-    float* __restrict__ out = g.out[e];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty + 8 * i, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * i][tx] = in[(long long)r * g.ldi[e] + c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (r < rows && c < cols) out[(long long)c * g.ldo[e] + g.col_off[e] + r] = tile[tx][ty + 8 * i];
-    }
-}
+// (round 4's grouped weight transposition - W -> W^T for the dX GEMMs of a few-sample backward, 49 matrices in one launch - left with round 5:
+// those GEMMs read the weights where they lie, gemm.hip's NN form)
 
 __global__ void sum_slabs_kernel(const float* __restrict__ P, float* __restrict__ C, long long n4, int splits) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,24 +505,6 @@ int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s) {
     SolaProfScope prof(SOLA_PROF_GEMM_TN, s, flops, bytes);
     if (g_gemm_tn_nw8) hipLaunchKernelGGL(gemm_tn_f32_group_kernel<8>, dim3((unsigned)tiles), dim3(512), lds, s, g);
     else hipLaunchKernelGGL(gemm_tn_f32_group_kernel<4>, dim3((unsigned)tiles), dim3(256), lds, s, g);
-    SOLA_LAUNCH_CHECK();
-    return SOLA_OK;
-}
-
-int launch_transpose_group(const TransposeGroupDesc& d, hipStream_t s) {
-    SOLA_ARG(d.n >= 1 && d.n <= TR_GROUP_MAX, "transpose_group: %d matrices", d.n);
-    TrGroupArgs g;
-    int max_r = 0, max_c = 0;
-    double el = 0;
-    for (int e = 0; e < d.n; ++e) {
-        SOLA_ARG(d.in[e] && d.out[e] && d.rows[e] > 0 && d.cols[e] > 0, "transpose_group: matrix %d", e);
-        g.in[e] = d.in[e]; g.out[e] = d.out[e]; g.rows[e] = d.rows[e]; g.cols[e] = d.cols[e]; g.ldi[e] = d.ldi[e] ? d.ldi[e] : d.cols[e];
-        g.ldo[e] = d.ldo[e]; g.col_off[e] = d.col_off[e];
-        max_r = std::max(max_r, d.rows[e]); max_c = std::max(max_c, d.cols[e]);
-        el += (double)d.rows[e] * d.cols[e];
-    }
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 8.0 * el);
-    hipLaunchKernelGGL(transpose_group_kernel, dim3((max_c + 31) / 32, (max_r + 31) / 32, d.n), dim3(256), 0, s, g);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

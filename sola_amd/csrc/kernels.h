@@ -89,14 +89,6 @@ struct GemmTnGroupDesc {
     int nprob;
 };
 int launch_gemm_tn_group(const GemmTnGroupDesc& d, hipStream_t s);
-// up to 48 transpositions out_e[c][col_off_e + r] = in_e[r][c] (input pitch ldi_e, output pitch ldo_e) in one launch
-struct TransposeGroupDesc {
-    const float* in[48];
-    float* out[48];
-    int rows[48], cols[48], ldi[48], ldo[48], col_off[48];  // ldi 0 = cols (contiguous input rows)
-    int n;
-};
-int launch_transpose_group(const TransposeGroupDesc& d, hipStream_t s);
 // Split-f16 version (gemm_tn_split.hip): up to three problems dW_j = A_j^T B_j sharing M, N, K and the pitches
 struct GemmTnSplitDesc {
     const float* A[3];  // dY_j [M, N], pitch lda (column slices of one buffer are fine)
