@@ -543,6 +543,9 @@ int sola_tune(const char* key, int value);
  * sola_tune keys (gemm_pp, gemm_nw4, gemm_k16, gemm_stagger, gemm_order, gemm_trace, gemm_ld, gemm_gn_fuse, gemm_ablate, attn_bwd_ablate,
  * attn_reg_minw, attn_res_splitm, gemm_f32p_ablate) exist only there; the default library rejects those keys. */
 int sola_has_experiments(void);
+/* Self-test of the library's cross-lane primitives on the current device: wave sums / maxima on v_permlane*_swap + DPP against the
+ * ds_bpermute butterfly, every lane of every step bit for bit (synchronises the stream).  SOLA_OK or SOLA_ERR_STATE + sola_last_error(). */
+int sola_selftest(void* stream);
 
 /* Measurement only (no reference counterpart): with sola_tune "gemm_trace" 1 the plain persistent split-f16 GEMM (no conv, no
  * residual, f32 output) runs an instrumented instantiation that records, per (block, wave), the cycles spent at the k-tile wait +

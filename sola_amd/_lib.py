@@ -132,6 +132,7 @@ SIGNATURES = {
     "sola_x16_arena_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "sola_tune": (_i, [C.c_char_p, _i]),
     "sola_has_experiments": (_i, []),
+    "sola_selftest": (_i, [_vp]),
     "sola_adamw_bind": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i]),
     "sola_adamw_step": (_i, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp, _f, _i, _vp]),
     "sola_train_step_bind": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _i, _i]),

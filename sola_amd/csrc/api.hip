@@ -324,6 +324,55 @@ void sola_attn_set_simple_remap(int v);
 void sola_attn_set_simple_db(int v);
 void sola_pack_set_resample_lds(int v);
 static int g_stage_split_math = 0;
+// ---- self-test of the cross-lane primitives (common.h): wave_sum / wave_max run on v_permlane*_swap + DPP; every lane of every butterfly
+// step must equal the ds_bpermute (__shfl_xor) form bit for bit - a compiler that folds a swap's two results (seen with the builtin form,
+// common.h) or a wrong rotation would show here, not as a tolerance drift three kernels later
+__global__ void selftest_wave_kernel(const float* __restrict__ in, int* __restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = in[i];
+    float v = x, m = x;
+    int wrong = 0;
+    float w = x;
+#pragma unroll
+    for (int o = 32, s = 0; o > 0; o >>= 1, ++s) {
+        v += __shfl_xor(v, o, 64);
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+        w = s == 0 ? sum_xor32(w) : s == 1 ? sum_xor16(w) : s == 2 ? sum_xor8(w) : s == 3 ? sum_xor4(w) : s == 4 ? sum_xor2(w) : sum_xor1(w);
+        wrong |= __float_as_uint(w) != __float_as_uint(v) ? 1 << s : 0;
+    }
+    wrong |= __float_as_uint(wave_sum(x)) != __float_as_uint(v) ? 64 : 0;
+    wrong |= __float_as_uint(wave_max(x)) != __float_as_uint(m) ? 128 : 0;
+    if (wrong) atomicOr(bad, wrong);
+}
+extern "C" int sola_selftest(void* stream_) {
+    hipStream_t s = as_stream(stream_);
+    constexpr int n = 64 * 1024;
+    std::vector<float> h(n);
+    unsigned r = 12345u;
+    for (int i = 0; i < n; ++i) {
+        r = r * 1664525u + 1013904223u;
+        h[i] = ((int)(r >> 8) % 20001 - 10000) / 37.0f * ((i % 7) ? 1.f : 1e-3f);
+    }
+    float* d_in = nullptr;
+    int* d_bad = nullptr;
+    SOLA_HIP(hipMalloc(&d_in, n * sizeof(float)));
+    if (hipMalloc(&d_bad, sizeof(int)) != hipSuccess) { (void)hipFree(d_in); sola_set_error("selftest: hipMalloc"); return SOLA_ERR_HIP; }
+    int bad = 0, rc = SOLA_OK;
+    if (hipMemcpyAsync(d_in, h.data(), n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(d_bad, 0, sizeof(int), s) != hipSuccess) rc = SOLA_ERR_HIP;
+    if (rc == SOLA_OK) {
+        hipLaunchKernelGGL(selftest_wave_kernel, dim3(n / 256), dim3(256), 0, s, d_in, d_bad);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SOLA_ERR_HIP;
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_bad);
+    if (rc != SOLA_OK) { sola_set_error("selftest: HIP error"); return rc; }
+    if (bad) {
+        sola_set_error("selftest: the vector-ALU wave reductions differ from the __shfl_xor butterfly (mask 0x%x: bits 0-5 = steps 32..1, 64 = wave_sum, 128 = wave_max)", bad);
+        return SOLA_ERR_STATE;
+    }
+    return SOLA_OK;
+}
+
 extern "C" int sola_has_experiments(void) {
 #ifdef SOLA_EXPERIMENTS
     return 1;

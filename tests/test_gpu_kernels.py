@@ -101,6 +101,14 @@ def test_gemm_nn_few_rows_shape(M, N, w_rows, nw, has_res):
     assert torch.equal(out, nt)
 
 
+def test_library_selftest_of_the_cross_lane_primitives():
+    """Round 5: wave_sum / wave_max (every block reduction of the library: losses, norms, casts) run on v_permlane32_swap / v_permlane16_swap + DPP
+    rotations instead of six ds_bpermute round trips - the same xor butterfly in the same order.  sola_selftest compares every lane of every
+    step with the __shfl_xor form on 65 536 values, bit for bit."""
+    from sola_amd._lib import check, current_stream, lib
+    check(lib().sola_selftest(current_stream(torch.device("cuda", 0))), "sola_selftest")
+
+
 def test_gemm_nn_outside_the_few_row_shape_is_an_error():
     from sola_amd._lib import current_stream, lib, ptr
     a = torch.zeros((4096, 1024), device="cuda")
