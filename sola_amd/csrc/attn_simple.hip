@@ -79,17 +79,33 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
     float m_run = -INFINITY, l_run = 0.f;
     constexpr int PT = DB ? 2 * TK * F4 / 256 : 1;  // float4 per thread and tile (K + V) of the prefetch
     float4 st[PT];
-    auto fetch = [&](int kt0) {
+    // round 5: this kernel's time is its SIMD issue time - PMC: the f32 MFMA busy 50 % of the SIMD cycles and 1 066 VALU instructions per
+    // wave, which do not overlap it on gfx950 (profiles/r05_attention_ring.txt) - so the prefetch keeps a pointer per piece and advances it
+    // by the tile's stride (the 64-bit row products, quarter-rate multiplies, left the loop) and whole tiles load without the row test
+    const float* fp[PT];
+    int fr[PT];
+    if constexpr (DB) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int e = tid + 256 * j, which = e / (TK * F4), r = (e % (TK * F4)) / F4, c4 = e % F4;
-            st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kt0 + r < Sk) {
-                const long long row = k0 + (long long)(kt0 + r) * k_rs;
-                st[j] = which ? *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * DH + c4 * 4)
-                              : *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * DH + c4 * 4);
+            fr[j] = r;
+            fp[j] = which ? a.v + (k0 + (long long)r * k_rs) * a.ldv + h * DH + c4 * 4 : a.k + (k0 + (long long)r * k_rs) * a.ldk + h * DH + c4 * 4;
+        }
+    }
+    const long long fstep_k = (long long)TK * k_rs * a.ldk, fstep_v = (long long)TK * k_rs * a.ldv;  // wave-uniform
+    auto fetch = [&](int kt0) {
+        if (kt0 + TK <= Sk) {  // a whole tile (block-uniform)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) st[j] = *reinterpret_cast<const float4*>(fp[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kt0 + fr[j] < Sk) st[j] = *reinterpret_cast<const float4*>(fp[j]);
             }
         }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) fp[j] += (tid + 256 * j) / (TK * F4) ? fstep_v : fstep_k;
     };
     if (DB) fetch(0);
     int it = 0;
@@ -169,8 +185,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
         rs = sum_xor32(sum_xor16(rs));
         l_run = l_run * alpha + rs;
         m_run = m_new;
+        // the accumulators are rescaled only where some row's running maximum moved (x * 1 = x: the same bits; 32 multiplies of the SIMD's
+        // issue time saved on every other tile or so)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+            for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+        }
         if constexpr (TR) {
             if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped (attn.hip)
                 const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * Sq + qi) * Sk;

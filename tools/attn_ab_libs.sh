@@ -8,7 +8,7 @@ for shape in obj o2l; do
   for lib in $A $B; do
     export SOLA_HIP_LIB=$PWD/$lib
     tag=ab_${shape}_$(basename $lib .so)
-    tools/prof_stats.sh $tag tools/attn_ring_diag.py attn_ring=0 attn_ring=0 attn_ring=0 > /dev/null 2>&1
+    tools/prof_stats.sh $tag tools/attn_ring_diag.py attn_simple_db=1 attn_simple_db=1 attn_simple_db=1 > /dev/null 2>&1
     echo "== $shape $lib"
     python tools/trace_runs.py gpurun_out/prof_$tag/stats_kernel_trace.csv
   done
