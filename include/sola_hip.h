@@ -298,9 +298,12 @@ int sola_train_step(SolaCtx* ctx, const float* dev_object_tokens, const float* d
 /* Gradient clipping + the AdamW update (train.py:121-125) in ONE multi-tensor launch, with torch.optim.AdamW(fused=True)'s own arithmetic
  * (ATen/native/cuda/fused_adam_utils.cuh: double scalars, float tensors, the same expressions): bit-identical parameters and moments.
  *   sola_adamw_bind: the optimizer's state tensors per parameter name (exp_avg, exp_avg_sq as float arrays of the parameter's size; step =
- *     torch's per-parameter device float, kept in sync, or null).  Parameters and gradients are the context's own bindings
- *     (sola_set_weight / sola_set_grad): the update writes the caller's parameter storage.  Bind again when a pointer changes.
- *   sola_adamw_step: `step` = number of this update (1, 2, ...); max_grad_norm > 0 scales every gradient by min(1, max_norm / (sqrt(*dev_total_sq)
+ *     torch's per-parameter device float counter, or null).  Parameters and gradients are the context's own bindings
+ *     (sola_set_weight / sola_set_grad): the update writes the caller's parameter storage.  Bind again when a pointer changes: a
+ *     sola_set_weight / sola_set_grad with a NEW pointer unbinds the optimizer and sola_adamw_step fails until the next bind.
+ *   sola_adamw_step: `step` = 0: this update's number is read from the bound step tensors ON THE DEVICE (counter + 1) and the kernel
+ *     advances them, exactly as torch's own step() does - the two may be mixed on one optimizer, and a load_state_dict into the same
+ *     storage is picked up (needs step tensors); `step` >= 1: an explicit number (1, 2, ...).  max_grad_norm > 0 scales every gradient by min(1, max_norm / (sqrt(*dev_total_sq)
  *     + 1e-6)) first (torch.nn.utils.clip_grad_norm_), decided on the device; write_back_grads != 0 leaves the scaled gradients in the
  *     gradient tensors as clip_grad_norm_ does, 0 leaves them unclipped (an eighth less traffic; train.py:121-125 never reads them again). */
 int sola_adamw_bind(SolaCtx* ctx, const char* const* names, void* const* dev_exp_avg, void* const* dev_exp_avg_sq, void* const* dev_step, int n);

@@ -192,6 +192,7 @@ extern "C" int sola_ctx_destroy(SolaCtx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->adam_tab) (void)hipFree(c->adam_tab);
+    if (c->adam_ticket) (void)hipFree(c->adam_ticket);
     delete c;
     return SOLA_OK;
 }
@@ -228,6 +229,7 @@ static int find_weight(SolaCtx* c, const char* what, const char* name, const voi
 extern "C" int sola_set_weight(SolaCtx* c, const char* name, const void* dev_ptr, int64_t numel) {
     Weight* w = nullptr;
     SOLA_TRY(find_weight(c, "set_weight", name, dev_ptr, numel, &w));
+    if (w->ptr != static_cast<const float*>(dev_ptr)) c->adam_n = 0;  // the update table holds the old pointer: sola_adamw_step asks for a new bind
     w->ptr = static_cast<const float*>(dev_ptr);
     c->ws_dirty = true;
     c->lin16_dirty = true;
@@ -237,6 +239,7 @@ extern "C" int sola_set_weight(SolaCtx* c, const char* name, const void* dev_ptr
 extern "C" int sola_set_grad(SolaCtx* c, const char* name, void* dev_ptr, int64_t numel) {
     Weight* w = nullptr;
     SOLA_TRY(find_weight(c, "set_grad", name, dev_ptr, numel, &w));
+    if (w->grad != static_cast<float*>(dev_ptr)) c->adam_n = 0;  // as in sola_set_weight
     w->grad = static_cast<float*>(dev_ptr);
     return SOLA_OK;
 }

@@ -610,9 +610,11 @@ extern int g_attn_splitm;
 
 bool attention_spin_supported(const AttnDesc& d);
 int launch_attention_spin(const AttnDesc& d, hipStream_t s);
+#ifdef SOLA_EXPERIMENTS  // closed experiment (lab/attn_ring.hip): EXPERIMENTS=1 builds with sola_tune "attn_ring" only
 bool attention_ring_supported(const AttnDesc& d);
 int launch_attention_ring(const AttnDesc& d, hipStream_t s);
 extern int g_attn_ring;
+#endif
 
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
@@ -627,8 +629,10 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     if (g_attn_variant == 1 && attention_small_supported(d)) return launch_attention_small(d, s);
     // register-only shape (attn_reg.hip): every wave on its own 16-query tile, operands straight from global memory
     if (g_attn_variant == 1 && attention_reg_supported(d)) return launch_attention_reg(d, s);
+#ifdef SOLA_EXPERIMENTS
     // sola_tune "attn_ring" 2 (A/B): the ring-staged shape also where the resident-K/V shape applies
     if (g_attn_variant == 1 && g_attn_ring == 2 && attention_res_supported(d) && attention_ring_supported(d)) return launch_attention_ring(d, s);
+#endif
     // few keys, many queries (object -> language): K/V resident in LDS, 8-wave blocks streaming 16-query tiles (attn_res.hip)
     if (g_attn_variant == 1 && attention_res_supported(d)) return launch_attention_res(d, s);
     // split precision mode: f16-MFMA triples instead of the exact-f32 MFMA for every longer shape (attn_simple.hip)
@@ -639,8 +643,11 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
     // Ragged batches take it for every shape: its q-blocks are independent blocks, so units of very different lengths
     // balance over the chip (the resident-K/V loop walks a unit's q-blocks inside one block: 1 to 31 of them per unit in
     // the object -> language attention of a MeViS-like mix).
-    // Round 5: persistent blocks with a DMA ring of K/V tiles (attn_ring.hip) take the same shapes in inference - bit-identical outputs
+#ifdef SOLA_EXPERIMENTS
+    // EXPERIMENTS builds with sola_tune "attn_ring" 1 only (closed experiment, lab/attn_ring.hip: bit-identical, 2-9 % slower than the
+    // shipped kernel below); attention_ring_supported() is false unless that key is set
     if (g_attn_variant == 1 && attention_ring_supported(d) && ((d.Sq <= 128 && d.Sk <= 128) || d.q_units)) return launch_attention_ring(d, s);
+#endif
     if (attention_simple_supported(d) && (g_attn_variant == 2 || (g_attn_variant == 1 && ((d.Sq <= 128 && d.Sk <= 128) || d.q_units))))
         return launch_attention_simple(d, s);
     AttnArgs a;

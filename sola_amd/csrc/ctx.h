@@ -139,7 +139,9 @@ struct SolaCtx {
     } step;
     // sola_adamw_bind / sola_adamw_step (train_step.hip): device table of (param, grad, exp_avg, exp_avg_sq, step) records, ctx-owned
     void* adam_tab = nullptr;
-    int adam_n = 0, adam_blocks = 0;
+    int adam_n = 0, adam_cap = 0, adam_blocks = 0;  // adam_n = 0: not bound (also after a weight / gradient pointer changed: bind again)
+    bool adam_has_steps = false;                    // the bound optimizer carries device step tensors (step 0 = "read them")
+    int* adam_ticket = nullptr;                     // the update kernel's last-block ticket (device int, zero between launches)
     double adam_bytes = 0.0;
     // dropout of the training forward (module/module.py:78-94 p = dropout_p; tools/attention.py:12,71 p = 0.1);
     // the seed used by the last sola_forward_train is kept for sola_backward

@@ -305,7 +305,7 @@ size_t mt_adam_entry_bytes();
 void mt_adam_entry_fill(void* host_entry, float* p, float* g, float* m, float* v, float* step, long long numel, int first_block);
 int mt_adam_blocks(long long numel);
 int launch_mt_clip_adamw(const void* tab_dev, int n, int blocks, double bytes, const double* total_sq, float max_norm, double lr, double beta1, double beta2,
-                         double eps, double weight_decay, float step, int write_back, hipStream_t s);
+                         double eps, double weight_decay, float step, int write_back, int* ticket, hipStream_t s);
 
 // ---- normalisation / elementwise (norm.hip) --------------------------------------------------------------------
 struct WsLayer {

@@ -27,7 +27,7 @@
 // softmax per 16-key tile): the outputs are bit-identical to that kernel's.
 #include <type_traits>
 
-#include "kernels.h"
+#include "../kernels.h"
 
 #ifdef SOLA_EXPERIMENTS
 namespace {
@@ -406,12 +406,5 @@ int launch_attention_ring(const AttnDesc& d, hipStream_t s) {
     if (g_attn_ring_ablate == 2) return launch_ring<2>(a, grid, s);
     if (g_attn_ring_ablate == 3) return launch_ring<3>(a, grid, s);
     return launch_ring<0>(a, grid, s);
-}
-#else
-int g_attn_ring = 0;
-bool attention_ring_supported(const AttnDesc&) { return false; }
-int launch_attention_ring(const AttnDesc&, hipStream_t) {
-    sola_set_error("attention: the ring-staged shape is compiled in EXPERIMENTS=1 builds only");
-    return SOLA_ERR_ARG;
 }
 #endif

@@ -56,9 +56,11 @@ __global__ __launch_bounds__(256) void mt_sqnorm_kernel(const MtArgs a, double* 
 // one block; every thread walks its partial sums ONCE and keeps one accumulator per group (each in the order the per-group loops of the
 // first version took: ascending block index, stride 256), then the groups' tree reductions run side by side - the same sums, bit for bit,
 // in a fifth of the time (35 -> ~10 us of a 1.7 ms one-sample step)
-constexpr int MT_FOLD_GROUPS = 16;  // encoder + negative tokens + up to 14 layers
+// A launch folds MT_FOLD_GROUPS groups (encoder + negative tokens + 14 layers); deeper configurations take one launch per 16 groups
+// (g0 = the launch's first group), the last of which sums the total over ALL groups in group order from what the earlier ones wrote.
+constexpr int MT_FOLD_GROUPS = 16;
 __global__ __launch_bounds__(256) void mt_fold_kernel(const double* __restrict__ partial, const int* __restrict__ pgroup,
-                                                     int n_blocks, int n_groups, double* __restrict__ out) {
+                                                     int n_blocks, int n_groups, int g0, int last, double* out) {
     __shared__ double red[MT_FOLD_GROUPS][256];
     double s[MT_FOLD_GROUPS];
 #pragma unroll
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const double* __restrict__
         const int pg = pgroup[i];
         const double v = partial[i];
 #pragma unroll
-        for (int g = 0; g < MT_FOLD_GROUPS; ++g) s[g] += pg == g ? v : 0.0;
+        for (int g = 0; g < MT_FOLD_GROUPS; ++g) s[g] += pg == g0 + g ? v : 0.0;
     }
 #pragma unroll
     for (int g = 0; g < MT_FOLD_GROUPS; ++g) red[g][threadIdx.x] = s[g];
@@ -81,12 +83,12 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const double* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        double total = 0.0;  // out[n_groups] = sum over all groups (the clip kernel reads it)
-        for (int g = 0; g < n_groups; ++g) {
-            out[g] = red[g][0];
-            total += red[g][0];
+        for (int g = g0; g < n_groups && g < g0 + MT_FOLD_GROUPS; ++g) out[g] = red[g - g0][0];
+        if (last) {
+            double total = 0.0;  // out[n_groups] = sum over all groups (the clip kernel reads it)
+            for (int g = 0; g < n_groups; ++g) total += g >= g0 ? red[g - g0][0] : out[g];
+            out[n_groups] = total;
         }
-        out[n_groups] = total;
     }
 }
 
@@ -123,25 +125,31 @@ __global__ __launch_bounds__(256) void mt_clip_kernel(const MtScaleArgs a, const
 // with ADAM_MODE::ADAMW, no amsgrad / maximize / grad scaler: the scalars are doubles, the tensors floats, the expressions below are
 // written with the same types and in the same order, so the updated weights and moments are bit-identical to torch.optim.AdamW(fused=True)
 // (tests/test_gpu_backward.py::test_fused_clip_adamw_equals_torch).  The table of tensor pointers lives in device memory (84 tensors x
-// four pointers exceed what a launch should carry as arguments); `step` is the step count AFTER this update (torch increments first).
+// four pointers exceed what a launch should carry as arguments).  The update's number comes from the optimizer's OWN device step tensors
+// (torch increments first: this update is number *step + 1): every block reads its entry's counter, the block that finishes LAST (ticket
+// counter) writes counter + 1 into every entry - so a torch optimizer.step() in between, or a load_state_dict, can never leave a stale
+// host-side count behind.  `step` > 0 = an explicit number for callers without step tensors.
 struct AdamEntry {
     float* p;
     float* g;
     float* m;
     float* v;
-    float* step;  // torch's per-parameter step tensor (device float), kept in sync: set to `step`
+    float* step;  // torch's per-parameter step tensor (device float): read for the update's number, advanced by the last block
     long long numel;
     int first_block;
     int pad;
 };
 __global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __restrict__ tab, int n, const double* __restrict__ total_sq, float max_norm,
-                                                             double lr, double beta1, double beta2, double eps, double weight_decay, float step, int write_back) {
+                                                             double lr, double beta1, double beta2, double eps, double weight_decay, float step_arg, int write_back,
+                                                             int* __restrict__ ticket) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const AdamEntry e = tab[lo];
+    // a float counts exactly up to 2^24 and stays there, as torch's counter does
+    const float step = step_arg > 0.f ? step_arg : *e.step + 1.f;
     float coef = 1.f;
     if (max_norm > 0.f) {  // mt_clip_kernel's coefficient
         const double tn = sqrt(*total_sq);
@@ -152,7 +160,6 @@ __global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __r
     const float bias_correction1 = (float)(1 - pow(beta1, (double)step));
     const float bias_correction2_sqrt = (float)sqrt(1 - pow(beta2, (double)step));
     const long long base = (long long)(blockIdx.x - e.first_block) * MT_CHUNK;
-    if (base == 0 && threadIdx.x == 0 && e.step) *e.step = step;
     for (int i = threadIdx.x * 4; i < MT_CHUNK; i += 1024) {
         const long long idx = base + i;
         if (idx >= e.numel) break;
@@ -198,6 +205,21 @@ __global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __r
             }
         }
     }
+    // every block has read its counter by now (its stores depend on it); the last one to arrive advances all of them
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float* sp = tab[i].step;
+            if (sp) *sp = step_arg > 0.f ? step_arg : *sp + 1.f;
+        }
+        if (threadIdx.x == 0) *ticket = 0;
+    }
 }
 
 }  // namespace
@@ -233,9 +255,10 @@ int launch_mt_sqnorm(const float* const* ptrs, const long long* numel, const int
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
     hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(blocks), dim3(256), 0, s, a, partial, pgroup);
     SOLA_LAUNCH_CHECK();
-    SOLA_ARG(n_groups <= MT_FOLD_GROUPS, "grad_sqnorms: %d parameter groups (at most %d)", n_groups, MT_FOLD_GROUPS);
-    hipLaunchKernelGGL(mt_fold_kernel, dim3(1), dim3(256), 0, s, partial, pgroup, blocks, n_groups, out);
-    SOLA_LAUNCH_CHECK();
+    for (int g0 = 0; g0 < n_groups; g0 += MT_FOLD_GROUPS) {
+        hipLaunchKernelGGL(mt_fold_kernel, dim3(1), dim3(256), 0, s, partial, pgroup, blocks, n_groups, g0, g0 + MT_FOLD_GROUPS >= n_groups ? 1 : 0, out);
+        SOLA_LAUNCH_CHECK();
+    }
     return SOLA_OK;
 }
 
@@ -267,11 +290,11 @@ void mt_adam_entry_fill(void* host_entry, float* p, float* g, float* m, float* v
 }
 int mt_adam_blocks(long long numel) { return (int)((numel + MT_CHUNK - 1) / MT_CHUNK); }
 int launch_mt_clip_adamw(const void* tab_dev, int n, int blocks, double bytes, const double* total_sq, float max_norm, double lr, double beta1, double beta2,
-                         double eps, double weight_decay, float step, int write_back, hipStream_t s) {
-    SOLA_ARG(tab_dev && n > 0 && blocks > 0 && step >= 1.f && (max_norm <= 0.f || total_sq), "clip_adamw: bad arguments");
+                         double eps, double weight_decay, float step, int write_back, int* ticket, hipStream_t s) {
+    SOLA_ARG(tab_dev && n > 0 && blocks > 0 && step >= 0.f && ticket && (max_norm <= 0.f || total_sq), "clip_adamw: bad arguments");
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
     hipLaunchKernelGGL(mt_clip_adamw_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const AdamEntry*>(tab_dev), n, total_sq, max_norm, lr, beta1, beta2, eps,
-                       weight_decay, step, write_back);
+                       weight_decay, step, write_back, ticket);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

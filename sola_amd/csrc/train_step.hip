@@ -135,7 +135,9 @@ extern "C" int sola_train_step(SolaCtx* c, const float* obj, const float* lang, 
 // ---- clip + AdamW in one launch (optim.hip: mt_clip_adamw_kernel) --------------------------------------------------------------------
 // bind: the optimizer's state tensors by parameter name (torch.optim.AdamW keeps exp_avg / exp_avg_sq / step per parameter; with fused=True
 // the step is a device float).  The parameter and gradient pointers are the context's own bindings (sola_set_weight / sola_set_grad): the
-// update writes the CALLER's parameter storage in place.  Bind again whenever one of the pointers changes.
+// update writes the CALLER's parameter storage in place.  Bind again whenever one of the pointers changes: sola_set_weight / sola_set_grad
+// with a NEW pointer drop the table (sola_adamw_step then fails with "bind again" instead of writing through a stale pointer).  The table is
+// rewritten behind a device synchronisation, so an update still in flight on any stream never sees half of it.
 extern "C" int sola_adamw_bind(SolaCtx* c, const char* const* names, void* const* exp_avg, void* const* exp_avg_sq, void* const* step, int n) {
     SOLA_ARG(c && names && exp_avg && exp_avg_sq && n > 0 && n <= 128, "adamw_bind: bad argument");
     try {
@@ -153,9 +155,16 @@ extern "C" int sola_adamw_bind(SolaCtx* c, const char* const* names, void* const
             blocks += mt_adam_blocks(w.numel);
             bytes += 28.0 * (double)w.numel;  // p, g, m, v in; p, m, v out
         }
-        if (c->adam_tab && c->adam_n < n) { (void)hipFree(c->adam_tab); c->adam_tab = nullptr; }
-        if (!c->adam_tab) SOLA_HIP(hipMalloc(&c->adam_tab, (size_t)n * eb));
+        c->adam_n = 0;
+        SOLA_HIP(hipDeviceSynchronize());  // rare (once per optimizer / pointer change): no update may be reading the table
+        if (c->adam_tab && c->adam_cap < n) { (void)hipFree(c->adam_tab); c->adam_tab = nullptr; }
+        if (!c->adam_tab) { SOLA_HIP(hipMalloc(&c->adam_tab, (size_t)n * eb)); c->adam_cap = n; }
+        if (!c->adam_ticket) SOLA_HIP(hipMalloc(&c->adam_ticket, sizeof(int)));
+        SOLA_HIP(hipMemset(c->adam_ticket, 0, sizeof(int)));
         SOLA_HIP(hipMemcpy(c->adam_tab, host.data(), (size_t)n * eb, hipMemcpyHostToDevice));
+        bool has_steps = step != nullptr;
+        for (int i = 0; has_steps && i < n; ++i) has_steps = step[i] != nullptr;
+        c->adam_has_steps = has_steps;
         c->adam_n = n; c->adam_blocks = blocks; c->adam_bytes = bytes;
         return SOLA_OK;
     } catch (const std::exception& e) {
@@ -164,16 +173,20 @@ extern "C" int sola_adamw_bind(SolaCtx* c, const char* const* names, void* const
     }
 }
 
-// step = the update's number (1 for the first); dev_total_sq = the gradients' total sum of squares on the device (sola_train_step's
+// step = 0: the update's number is read from the bound step tensors on the device (number = counter + 1, counters advanced by the kernel -
+// what torch's own step() does, so the two can be mixed freely on one optimizer); step >= 1: an explicit number (1 for the first), written
+// into the step tensors if there are any.  dev_total_sq = the gradients' total sum of squares on the device (sola_train_step's
 // dev_grad_sq + n_groups) when max_grad_norm > 0, else ignored.  Invalidate derived weight copies afterwards (sola_weights_changed).
 // write_back_grads: 1 = an active clip leaves the scaled gradients in the gradient tensors (what clip_grad_norm_ leaves in .grad); 0 = they
 // keep the unclipped values (one eighth less traffic: train.py never reads .grad behind optimizer.step()) - parameters and moments the same
 extern "C" int sola_adamw_step(SolaCtx* c, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, const double* dev_total_sq,
                                float max_grad_norm, int write_back_grads, void* stream_) {
-    SOLA_ARG(c && c->adam_tab && c->adam_n > 0, "adamw_step: sola_adamw_bind has not been called on this context");
-    SOLA_ARG(step >= 1 && step < (1 << 24), "adamw_step: step %lld (a float counts it exactly up to 2^24)", (long long)step);
+    SOLA_ARG(c && c->adam_tab && c->adam_n > 0, "adamw_step: no optimizer bound to this context (sola_adamw_bind; bind again after sola_set_weight / sola_set_grad moved a pointer)");
+    SOLA_ARG(step >= 0, "adamw_step: step %lld", (long long)step);
+    SOLA_ARG(step >= 1 || c->adam_has_steps, "adamw_step: step 0 reads the optimizer's device step tensors, and none were bound");
+    if (step > (1 << 24)) step = 1 << 24;  // a float counter stays at 2^24, as torch's does
     SOLA_TRY(launch_mt_clip_adamw(c->adam_tab, c->adam_n, c->adam_blocks, c->adam_bytes, dev_total_sq, max_grad_norm, lr, beta1, beta2, eps, weight_decay, (float)step,
-                                  write_back_grads, as_stream(stream_)));
+                                  write_back_grads, c->adam_ticket, as_stream(stream_)));
     c->ws_dirty = true;
     c->lin16_dirty = true;
     return SOLA_OK;

@@ -207,6 +207,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             old = self._bound.get(key)
             if old is None or old[0] != rec[0]:
                 check(lib().sola_set_weight(self._ctx, key.encode(), ptr(t), t.numel()), f"sola_set_weight({key})")
+                self._adam_sig = None  # a moved pointer unbinds the optimizer in the library (sola_adamw_bind again)
                 changed = True
             elif old[1] != rec[1]:
                 changed = True
@@ -534,6 +535,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             g = self._grad_view(key)
             check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
         self._grad_bound = "arena"
+        self._adam_sig = None  # a moved gradient pointer unbinds the optimizer in the library
 
     def grad_buckets(self):
         """[(flat view of bucket k)] of the gradient arena, in completion order (valid after a backward)."""
@@ -565,6 +567,7 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
                 check(lib().sola_set_grad(self._ctx, key.encode(), ptr(g), g.numel()), f"sola_set_grad({key})")
                 grads.append(g)
             self._grad_bound = "fresh"
+            self._adam_sig = None
         else:
             if self._grad_bound != "arena":
                 self._bind_grad_arena()
@@ -660,9 +663,9 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         self._last_grad_sq = None
         if adam is not None:  # clip + AdamW in one launch; the kernel reads the total norm where the step left it
             g = optimizer.param_groups[0]
-            self._adam_step += 1
+            # step 0: the update's number comes from the optimizer's own device step tensors (torch's optimizer.step() may be mixed in)
             check(lib().sola_adamw_step(self._ctx, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                        self._adam_step, C.c_void_p(grad_sq.data_ptr() + 8 * n_groups), float(max_grad_norm), 1 if write_back_grads else 0,
+                                        0, C.c_void_p(grad_sq.data_ptr() + 8 * n_groups), float(max_grad_norm), 1 if write_back_grads else 0,
                                         current_stream(dev)), "sola_adamw_step")
         # every parameter's .grad = its slot of the arena (persistent views: nothing to do from the second step on)
         lo, hi = self._grad_arena.data_ptr(), self._grad_arena.data_ptr() + 4 * self._grad_arena.numel()
@@ -700,9 +703,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             sq = cached[0] if cached is not None and cached[1] == self._grad_tag(grads) else self._grad_sq_device()
             total = sq[-1:]
         g = optimizer.param_groups[0]
-        self._adam_step += 1
         check(lib().sola_adamw_step(self._ctx, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                    self._adam_step, ptr(total), float(max_grad_norm or 0.0), 1 if write_back_grads else 0, current_stream(dev)), "sola_adamw_step")
+                                    0, ptr(total), float(max_grad_norm or 0.0), 1 if write_back_grads else 0, current_stream(dev)), "sola_adamw_step")
         self._last_grad_sq = None
         self._weights_touched = True
 
@@ -728,14 +730,12 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
             steps = [opt.state[p]["step"] for _, p in named]
             if any(not s_.is_cuda or s_.dtype != torch.float32 for s_ in steps):
                 raise SolaError("train_step(optimizer=...): the optimizer's step counters must be device float32 scalars (torch.optim.AdamW(fused=True) or fresh state)")
-            first = float(steps[0].item())  # one host sync, at (re)binding only
             n = len(named)
             names = (C.c_char_p * n)(*[k.encode() for k, _ in named])
             vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
             check(lib().sola_adamw_bind(self._ctx, names, vp([opt.state[p]["exp_avg"] for _, p in named]), vp([opt.state[p]["exp_avg_sq"] for _, p in named]),
                                         vp(steps), n), "sola_adamw_bind")
             self._adam_sig = sig
-            self._adam_step = int(first)
         return True
 
     def step_grad_norm_dict(self):

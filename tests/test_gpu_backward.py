@@ -801,6 +801,72 @@ def test_fused_clip_adamw_equals_torch(max_norm):
             assert float(sa["step"]) == float(sb["step"]) == step + 1, (step, k)
 
 
+def test_fused_adamw_mixed_with_torch_steps_keeps_the_step_count():
+    """the update's number is read from the optimizer's DEVICE step tensors, so torch's own optimizer.step() interleaved with
+    module.train_step(optimizer=...) on the same optimizer - and a load_state_dict into it - cannot leave a stale count behind: model 1
+    alternates the two paths (fused, torch, fused, torch, fused), model 0 takes torch's step every time; parameters, moments and step
+    counters stay bit-identical, and a state dict loaded at step 5 (counters = 2) is continued from 2 by the fused path."""
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_inputs(cfg, 1, 16, 32, 16, 5).items()}
+    ms, opts = [], []
+    for _ in range(2):
+        m, _sd = build(cfg)
+        m.train(True)
+        m.precision = "f32"
+        ms.append(m)
+        opts.append(torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.05, fused=True))
+    saved = None
+    for step in range(5):
+        torch.manual_seed(91 + step)
+        ms[0].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0)
+        opts[0].step()
+        torch.manual_seed(91 + step)
+        if step % 2 == 0:
+            ms[1].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0, optimizer=opts[1])
+        else:
+            ms[1].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0)
+            opts[1].step()
+            ms[1].weights_changed()
+        torch.cuda.synchronize()
+        for (k, p), (_k, q) in zip(ms[0]._params(), ms[1]._params()):
+            assert torch.equal(p.detach(), q.detach()), (step, k, "parameter")
+            sa, sb = opts[0].state[p], opts[1].state[q]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (step, k, "moments")
+            assert float(sa["step"]) == float(sb["step"]) == step + 1, (step, k)
+        if step == 1:
+            import copy
+            saved = [copy.deepcopy(o.state_dict()) for o in opts], [copy.deepcopy(m.state_dict()) for m in ms]
+    # rewind both to step 2 through load_state_dict, then one more step each way
+    for m, o, osd, msd in zip(ms, opts, saved[0], saved[1]):
+        m.load_state_dict(msd)
+        o.load_state_dict(osd)
+    torch.manual_seed(5)
+    ms[0].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0)
+    opts[0].step()
+    torch.manual_seed(5)
+    ms[1].train_step(inp["object_tokens"], inp["lang_tokens"], inp["labels"], inp["pos_tokens"], POS_W, TEMP, ALIGN_W, max_grad_norm=1.0, optimizer=opts[1])
+    torch.cuda.synchronize()
+    for (k, p), (_k, q) in zip(ms[0]._params(), ms[1]._params()):
+        assert torch.equal(p.detach(), q.detach()), (k, "parameter after load_state_dict")
+        assert float(opts[0].state[p]["step"]) == float(opts[1].state[q]["step"]) == 3, k
+
+
+def test_grad_norm_groups_beyond_sixteen():
+    """the per-group fold takes 16 groups per launch; more (a configuration with > 14 layers) run as several launches - checked on
+    the multi-tensor entry point with 40 groups against float64 sums, the total in group order."""
+    torch.manual_seed(3)
+    tensors = [torch.randn(n, device="cuda") for n in (5, 4096, 4097, 70000) * 10]
+    gids = list(range(40))
+    m, _sd = build(synth.SMALL_MODEL_CFG)
+    sq = m._grad_sqnorms(tensors, gids, 40).cpu()
+    ref = torch.tensor([float((t.double() ** 2).sum()) for t in tensors], dtype=torch.float64)
+    assert torch.allclose(sq[:40], ref, rtol=1e-6)
+    tot = 0.0
+    for v in sq[:40].tolist():
+        tot += v
+    assert float(sq[40]) == tot
+
+
 def test_fused_clip_adamw_without_gradient_write_back():
     """sola_adamw_step(write_back_grads = 0) - what train.py and the bench's one-sample step pass: with the clip ACTIVE the parameters and
     both moments are bit-identical to the write-back form (and so to torch's), and .grad keeps the UNCLIPPED gradient."""
