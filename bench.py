@@ -377,6 +377,9 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
             m.precision = prec
             m.forward_ragged(objs, langs, differentiable=True)
             rag["train_forward_logit_err_vs_oracle"][prec] = row_errors(m.last_ragged[0].detach().cpu().numpy(), ref, m.last_ragged[3])
+            if reference_logits("rag_train.2024") is not None:
+                rag.setdefault("train_forward_logit_err_vs_reference", {})[prec] = row_errors(m.last_ragged[0].detach().cpu().numpy(),
+                                                                                              reference_logits("rag_train.2024"), m.last_ragged[3])
         m.train()
         del smp, objs, langs
     del m, opt
@@ -490,6 +493,10 @@ def stress_leg(cfg, m, dev, precision, steps):
            "gflop_per_sample": round(fl["total"] / 1e9, 2), "model_tflops": round(B / dt * fl["total"] / 1e12, 2),
            "roofline": gemm_roofline(prof, precision, dt, steps), "roofline_attention": attn_roofline(prof),
            "kernel_ms_per_step": kernel_ms(prof, steps)}
+    ref_gold = reference_logits("c4.77")
+    if ref_gold is not None:  # every row of this batch against the reference's own logits
+        with torch.no_grad():
+            out["logit_err_vs_reference"] = uniform_row_errors(m(c["object_tokens"], c["lang_tokens"])[0].cpu().numpy(), ref_gold)
     del c
     torch.cuda.empty_cache()
     return out
@@ -627,6 +634,16 @@ def ragged_leg(cfg, m, dev, steps, uniform_model_tflops, oracle_parity=None):
                 par[prec] = row_errors(m.last_ragged[0].cpu().numpy(), ref, m.last_ragged[3])
             m.precision = keep
             out[tag]["logit_err_vs_oracle"] = par
+        ref_gold = reference_logits("rag_infer." + tag)
+        if ref_gold is not None:  # the reference's own per-sample logits for this batch (no CPU work)
+            keep = m.precision
+            par = {}
+            for prec in (keep, "f32"):
+                m.precision = prec
+                m.forward_ragged(videos, texts, sample_video)
+                par[prec] = row_errors(m.last_ragged[0].cpu().numpy(), ref_gold, m.last_ragged[3])
+            m.precision = keep
+            out[tag]["logit_err_vs_reference"] = par
         del videos, texts
         torch.cuda.empty_cache()
     return out
@@ -642,6 +659,27 @@ def oracle_ragged_rows(cfg, tsd, bt):
         sm, _ = sola_oracle.forward(tsd, cfg, bt["videos"][v][None], bt["texts"][i][None])
         rows.append(np.asarray(sm)[0])
     return np.concatenate(rows)
+
+
+_REF_GOLD = None
+
+
+def reference_logits(key):
+    """The REFERENCE's own logits for a benched batch (tests/golden/bench_golden.npz, made by tests/golden/gen_golden.py bench from
+    module/module.py:130-162 called one sample per forward); None when the fixture or the key is absent.  A committed data file:
+    nothing of the reference is read at run time."""
+    global _REF_GOLD
+    if _REF_GOLD is None:
+        path = os.path.join(ROOT, "tests", "golden", "bench_golden.npz")
+        _REF_GOLD = dict(np.load(path)) if os.path.exists(path) else {}
+    return _REF_GOLD.get(key + ".score_map")
+
+
+def uniform_row_errors(got, ref_flat):
+    ref = ref_flat.reshape(got.shape).astype(np.float32)
+    e_rows = np.abs(got - ref).max(axis=1)
+    return {"max_abs_logit_err_vs_reference": float(e_rows.max()), "mean_row_max_err": float(e_rows.mean()), "rows_above_5e-4": int((e_rows > 5e-4).sum()),
+            "rows": int(got.shape[0]), "selections_equal": bool(np.array_equal(got > 0, ref > 0))}
 
 
 def row_errors(got, ref, counts):
@@ -766,7 +804,9 @@ _OPTIONAL = [("iou", "cpu_baseline", "sample"), ("training_step", "ragged", "f16
              ("f16_storage_mode", "ragged_four_expressions_per_video"), ("training_step", "ragged", "samples_per_step_128"),
              ("training_step", "ragged", "f16x3", "kernel_ms_per_step"), ("stress_T128_N128", "kernel_ms_per_step"), ("iou", "cpu_baseline"),
              ("f16_storage_mode", "C4_T128_N128", "roofline"), ("f16_storage_mode", "NS_T32_N64", "roofline")]
-_SHORT = {"max_abs_logit_err_vs_oracle": "max", "mean_row_max_err": "mean", "rows_above_5e-4": "gt5e-4", "samples_above_5e-4": "gt5e-4",
+_SHORT = {"max_abs_logit_err_vs_reference": "max", "max_abs_logit_err_vs_float64": "max_vs_f64", "reference_vs_float64": "ref_vs_f64",
+          "train_forward_logit_err_vs_reference": "train_fwd_err_vs_reference",
+          "max_abs_logit_err_vs_oracle": "max", "mean_row_max_err": "mean", "rows_above_5e-4": "gt5e-4", "samples_above_5e-4": "gt5e-4",
           "mean_sample_max": "mean", "selections_equal": "sel_eq", "max_abs_logit_diff_vs_f32_mode": "max_diff_f32",
           "rms_logit_diff_vs_f32_mode": "rms_diff_f32", "calls_repeated_in_f32": "f32_repeats", "max_abs_logit_diff_vs_split_mode": "max_diff_split",
           "rms_logit_diff_vs_split_mode": "rms_diff_split", "model_tflops_executed": "tflops_exec", "split_f16_mode_value": "split_value",
@@ -940,6 +980,7 @@ def main():
     # roofline entries, and the largest difference between the two modes' logits on this batch
     exact = None
     parity = None
+    parity_ref = None
     if args.precision == "f16x3" and world == 1:
         with torch.no_grad():
             sm_split, _ = m(obj, lang)
@@ -964,12 +1005,23 @@ def main():
                 err[tag] = {"max_abs_logit_err_vs_oracle": float(e_rows.max()), "mean_row_max_err": float(e_rows.mean()),
                             "rows_above_5e-4": int((e_rows > 5e-4).sum()), "rows": int(B),
                             "selections_equal": bool(np.array_equal(got.cpu().numpy() > 0, ref > 0))}
+        ref_gold = reference_logits(f"u256.{1000 + rank}") if (B, N, T, L) == (256, 64, 32, 16) else None
+        err_ref = None
+        if ref_gold is not None:  # every row against the REFERENCE's own logits (round 6); no CPU work: a 64 KB fixture
+            err_ref = {tag: uniform_row_errors(got.cpu().numpy(), ref_gold) for tag, got in (("f16x3", sm_split), ("f32", sm_f32))}
+            x64 = reference_logits("u256.1000.oracle_f64") if rank == 0 else None
+            if x64 is not None:  # distance from exact arithmetic (float64 evaluation), next to the reference's own
+                for tag, got in (("f16x3", sm_split), ("f32", sm_f32)):
+                    err_ref[tag]["max_abs_logit_err_vs_float64"] = float(np.abs(got.cpu().numpy() - x64.reshape(B, N)).max())
+                    err_ref[tag]["reference_vs_float64"] = float(np.abs(ref_gold.astype(np.float64) - x64).max())
         exact = {"value": round(B / dt32, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt32, 4), "steps": k, "dtype": "f32",
                  "roofline": gemm_roofline(prof32, "f32", dt32, k), "roofline_attention": attn_roofline(prof32),
                  "kernel_ms_per_step": kernel_ms(prof32, k),
                  "max_abs_logit_diff_vs_split_mode": float((sm_f32 - sm_split).abs().max()),
-                 **({"max_abs_logit_err_vs_oracle": err["f32"]} if err else {})}
+                 **({"max_abs_logit_err_vs_oracle": err["f32"]} if err else {}),
+                 **({"max_abs_logit_err_vs_reference": err_ref["f32"]} if err_ref else {})}
         parity = err["f16x3"] if err else None
+        parity_ref = err_ref["f16x3"] if err_ref else None
         m.precision = args.precision
 
     dist_res = None
@@ -1029,6 +1081,8 @@ def main():
             out["split_guard"] = {"enabled": bool(m.split_guard), "calls_repeated_in_f32": fallbacks, "guard_bits_last_call": guard_bits}
         if parity is not None:  # every row of the timed batch against the fp32 oracle (the headline mode; exact_f32_mode carries its own)
             out["max_abs_logit_err_vs_oracle"] = parity
+        if parity_ref is not None:  # ... and against the reference's own logits for this batch (tests/golden/bench_golden.npz)
+            out["max_abs_logit_err_vs_reference"] = parity_ref
         if exact is not None:
             out["exact_f32_mode"] = exact
         if world == 1 and args.extra_legs:

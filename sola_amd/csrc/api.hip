@@ -324,6 +324,7 @@ void sola_attn_set_ring_blocks(int v);
 void sola_attn_set_ring_remap(int v);
 void sola_attn_set_ring_ablate(int v);
 void sola_attn_set_simple_remap(int v);
+void sola_iou_set_shape(int v);
 void sola_attn_set_simple_db(int v);
 void sola_pack_set_resample_lds(int v);
 static int g_stage_split_math = 0;
@@ -415,6 +416,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_variant")) { sola_attn_set_variant(value); return SOLA_OK; }
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
     if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
+    if (!strcmp(key, "iou_shape")) { sola_iou_set_shape(value); return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }

@@ -307,159 +307,230 @@ __global__ __launch_bounds__(256) void mask_pair_kernel(const PairArgs a) {
 }
 
 // ---- one-launch path for the de-dup loop's real call sizes (generate_tokens_grid.py:266-278: P <= 4 new tracks against
-//      16-64 prompts, uint8 masks already at the comparison resolution) ---------------------------------------------------
-// The three-kernel path above costs five launches (two area memsets, two packs, one pair kernel): ~25 us of kernels inside
-// ~45 us of wall time for 10-35 MB of masks.  Here block (chunk, prompt group) packs its 8 KiB slice of the P track masks
-// to bits ONCE (registers), then streams the same slice of up to 16 prompts, eight in flight at a time, and counts
-// popc(A & B), |B| (and |A|) without ever writing a bit plane; per-block counts go to a small partial table and the last
-// block to finish (one atomic counter) folds them in index order and writes inter / union.  Every mask byte is read once
-// from HBM (the tracks again per prompt group, from L2).  One 64-byte memset + one kernel; integer sums, exact.
-struct FusedArgs {
+//      16-256 prompts, uint8 masks already at the comparison resolution) --------------------------------------------------
+// Round 6: ONE kernel and nothing else on the stream - no memset, no atomically accumulated table.
+//   * block (chunk, prompt group): 512 words (16 KiB of each mask) x G prompts; every 16-byte load of the block - the P
+//     track slices and the G prompt slices - is issued before the first use, each mask byte leaves HBM once (the tracks
+//     again per prompt group, from L2);
+//   * bits are packed in registers (never written), popc(A & B), |B|, |A| summed over the wave with DPP adds + two
+//     permlane swaps (integer sums: exact in any order), over the four waves through LDS, and the block's 5 G + 4 counts
+//     are STORED to its own row of a partial table;
+//   * the last block of a prompt group to finish (a ticket per group) adds the group's rows in chunk order and writes
+//     inter / union.  The tickets live in the library (g_iou_ticket: zero when the code object is loaded, put back to zero
+//     by the block that takes the last one), handed out as a ring range per launch - so a call leaves no state behind and
+//     needs no zeroed memory in front of it.  4096 tickets: launches on different streams overlap safely as long as fewer
+//     than 4096 prompt groups are in flight at once.
+// The grid is sized by the bytes read: 1 / 2 / 4 / 8 prompts per block for R <= 16 / <= 32 / <= 128 / more, two slices in flight per
+// batch (512-1024 blocks at 540 x 960; onepass_shape).
+struct OnepassArgs {
     const uint8_t *a, *b;
     long long hw, words;
-    int P, R, chunks, groups;
-    unsigned* acc;    // [R][5]: inter[p] (p < 4), |B_r| ; then [4]: |A_p|   (zeroed by the caller, with `done`)
-    unsigned* done;   // 1 counter
+    int P, R, chunks, groups, nb;
+    unsigned ticket_base;
+    unsigned* part;  // [groups][chunks][5 G + 4]: per prompt j of the group inter[p] (p < 4), |B_j|; then |A_p| (p < 4)
     long long *inter, *uni;
 };
 constexpr int FUSED_MAXP = 4;
-constexpr int FUSED_RG = 16;  // prompts per block
-constexpr int FUSED_RB = 8;   // prompts in flight
+constexpr int OP_WPT = 2;               // 32-pixel words per thread
+constexpr int OP_CHUNK = 256 * OP_WPT;  // words per block
+constexpr int OP_TICKETS = 4096;
+constexpr int OP_MAXV = 64;             // counts per block: 5 per prompt (at most 12 prompts) + 4
+constexpr int OP_MAX_CHUNKS = 128;      // the group's fold walks this many rows at most (masks of up to 2 M pixels)
+constexpr int OP_TICKET_PITCH = 32;    // a ticket per 128-byte line: agent-scope atomics on ONE line are serialised where they execute (~50 ns each:
+                                       // 512 blocks on 16 neighbouring words took 25 us); a line per prompt group leaves 32 of them in a row
+__device__ unsigned g_iou_ticket[OP_TICKETS * OP_TICKET_PITCH];
 
-// sum over the 64 lanes of two 16-bit counts packed in one word (each total < 2^16)
+// Integer sum over the 64 lanes, every lane gets it: DPP adds inside the 16-lane rows, v_permlane16_swap across the row pairs,
+// v_permlane32_swap across the halves (common.h: half_sum32 / wave_sum_dpp, on integers)
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    unsigned x = v, y = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    v = x + y;
+    x = v; y = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
 }
 
-__global__ __launch_bounds__(256) void mask_iou_fused_u8_kernel(const FusedArgs a) {
-    __shared__ unsigned red[4][FUSED_RB][3];
-    __shared__ unsigned reda[4][2];
+template <int G>
+__global__ __launch_bounds__(256) void mask_iou_onepass_kernel(const OnepassArgs a) {
+    __shared__ unsigned red[4][OP_MAXV];
+    __shared__ unsigned tot[4][OP_MAXV];
     __shared__ int is_last;
     const int chunk = blockIdx.x, grp = blockIdx.y;
-    const long long w = (long long)chunk * 256 + threadIdx.x;
-    const bool ok = w < a.words;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned wa[FUSED_MAXP];
+    const int GB = G * a.nb;         // prompts per block: nb batches of G (the G slices of a batch are all in flight at once)
+    const int NV = 5 * GB + 4;       // counts per block: per prompt inter[p] (p < 4) and |B|, then |A_p|
+    const int r0 = grp * GB;
+    // every load is unconditional (a predicated 16-byte load compiles to four predicated dword loads: 160 of them per thread made this
+    // kernel 2.5x slower): out-of-range words / absent tracks read a clamped address and their PACKED word is zeroed below
+    bool ok[OP_WPT];
+    long long wc[OP_WPT];
+    unsigned wa[OP_WPT][FUSED_MAXP];
+    {
+        uint4 la[FUSED_MAXP][OP_WPT][2];
 #pragma unroll
-    for (int p = 0; p < FUSED_MAXP; ++p) {
-        wa[p] = 0u;
-        if (p < a.P && ok) {
-            const uint4* src = reinterpret_cast<const uint4*>(a.a + (long long)p * a.hw);
-            wa[p] = pack16(src[2 * w]) | (pack16(src[2 * w + 1]) << 16);
+        for (int it = 0; it < OP_WPT; ++it) {
+            const long long w = (long long)chunk * OP_CHUNK + it * 256 + threadIdx.x;
+            ok[it] = w < a.words;
+            wc[it] = ok[it] ? w : a.words - 1;
+#pragma unroll
+            for (int p = 0; p < FUSED_MAXP; ++p) {
+                const uint4* src = reinterpret_cast<const uint4*>(a.a + (long long)min(p, a.P - 1) * a.hw) + 2 * wc[it];
+                la[p][it][0] = src[0];
+                la[p][it][1] = src[1];
+            }
         }
-    }
-    if (grp == 0) {  // |A_p| of this slice, once
-        const unsigned s01 = wave_sum_u32(__popc(wa[0]) | (__popc(wa[1]) << 16));
-        const unsigned s23 = wave_sum_u32(__popc(wa[2]) | (__popc(wa[3]) << 16));
-        if (lane == 0) { reda[wave][0] = s01; reda[wave][1] = s23; }
-    }
-    const int r0 = grp * FUSED_RG, r1 = min(a.R, r0 + FUSED_RG);
-    for (int rb = r0; rb < r1; rb += FUSED_RB) {
-        uint4 lo[FUSED_RB], hi[FUSED_RB];
+        uint4 lb[G][OP_WPT][2];
+        auto load_b = [&](int bt) {
 #pragma unroll
-        for (int j = 0; j < FUSED_RB; ++j) {
-            const int r = min(rb + j, a.R - 1);
-            const uint4* src = reinterpret_cast<const uint4*>(a.b + (long long)r * a.hw);
-            lo[j] = ok ? src[2 * w] : make_uint4(0u, 0u, 0u, 0u);
-            hi[j] = ok ? src[2 * w + 1] : make_uint4(0u, 0u, 0u, 0u);
-        }
-        __syncthreads();  // the previous batch's sums have been consumed
+            for (int it = 0; it < OP_WPT; ++it)
 #pragma unroll
-        for (int j = 0; j < FUSED_RB; ++j) {
-            const unsigned wb = pack16(lo[j]) | (pack16(hi[j]) << 16);
-            const unsigned s01 = wave_sum_u32(__popc(wa[0] & wb) | (__popc(wa[1] & wb) << 16));
-            const unsigned s23 = wave_sum_u32(__popc(wa[2] & wb) | (__popc(wa[3] & wb) << 16));
-            const unsigned sb = wave_sum_u32(__popc(wb));
-            if (lane == 0) { red[wave][j][0] = s01; red[wave][j][1] = s23; red[wave][j][2] = sb; }
-        }
-        __syncthreads();
-        if (threadIdx.x < FUSED_RB * 5) {
-            const int j = threadIdx.x / 5, q = threadIdx.x - j * 5;
-            const int r = rb + j;
-            if (r < r1 && (q < a.P || q == 4)) {
-                unsigned tot = 0;
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) {
-                    const unsigned v = q == 4 ? red[wv][j][2] : red[wv][j][q >> 1];
-                    tot += q == 4 ? v : ((q & 1) ? v >> 16 : v & 0xffffu);
+                for (int j = 0; j < G; ++j) {
+                    const uint4* src = reinterpret_cast<const uint4*>(a.b + (long long)min(r0 + bt * G + j, a.R - 1) * a.hw) + 2 * wc[it];
+                    lb[j][it][0] = src[0];
+                    lb[j][it][1] = src[1];
                 }
-                if (tot) atomicAdd(&a.acc[r * 5 + q], tot);
+        };
+        load_b(0);
+        // two 16-bit fields per word: a thread sees 64 pixels per mask, a wave 4096
+        unsigned ca[2] = {0u, 0u};
+#pragma unroll
+        for (int it = 0; it < OP_WPT; ++it) {
+#pragma unroll
+            for (int p = 0; p < FUSED_MAXP; ++p) wa[it][p] = (ok[it] && p < a.P) ? (pack16(la[p][it][0]) | (pack16(la[p][it][1]) << 16)) : 0u;
+            ca[0] += __popc(wa[it][0]) | (__popc(wa[it][1]) << 16);
+            ca[1] += __popc(wa[it][2]) | (__popc(wa[it][3]) << 16);
+        }
+        {
+            const unsigned a01 = wave_sum_u32(ca[0]), a23 = wave_sum_u32(ca[1]);
+            if (lane == 0) {
+                red[wave][5 * GB + 0] = a01 & 0xffffu; red[wave][5 * GB + 1] = a01 >> 16;
+                red[wave][5 * GB + 2] = a23 & 0xffffu; red[wave][5 * GB + 3] = a23 >> 16;
+            }
+        }
+        for (int bt = 0; bt < a.nb; ++bt) {
+            unsigned wb[G][OP_WPT];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int it = 0; it < OP_WPT; ++it) wb[j][it] = ok[it] ? (pack16(lb[j][it][0]) | (pack16(lb[j][it][1]) << 16)) : 0u;
+            if (bt + 1 < a.nb) load_b(bt + 1);  // the next batch's slices travel under this batch's counts
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                unsigned c01 = 0u, c23 = 0u, cb = 0u;
+#pragma unroll
+                for (int it = 0; it < OP_WPT; ++it) {
+                    c01 += __popc(wa[it][0] & wb[j][it]) | (__popc(wa[it][1] & wb[j][it]) << 16);
+                    c23 += __popc(wa[it][2] & wb[j][it]) | (__popc(wa[it][3] & wb[j][it]) << 16);
+                    cb += __popc(wb[j][it]);
+                }
+                const unsigned s01 = wave_sum_u32(c01), s23 = wave_sum_u32(c23), sb = wave_sum_u32(cb);
+                if (lane == 0) {
+                    unsigned* r = &red[wave][5 * (bt * G + j)];
+                    r[0] = s01 & 0xffffu; r[1] = s01 >> 16; r[2] = s23 & 0xffffu; r[3] = s23 >> 16; r[4] = sb;
+                }
             }
         }
     }
-    if (grp == 0) {
-        __syncthreads();
-        if (threadIdx.x < a.P) {
-            unsigned tot = 0;
-            for (int wv = 0; wv < 4; ++wv) {
-                const unsigned v = reda[wv][threadIdx.x >> 1];
-                tot += (threadIdx.x & 1) ? v >> 16 : v & 0xffffu;
-            }
-            if (tot) atomicAdd(&a.acc[a.R * 5 + threadIdx.x], tot);
-        }
-    }
-    // ---- the last block to finish writes the matrices (release: the adds above, then the counter; acquire on the other side)
-    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(a.done, 1u) == (unsigned)(a.chunks * a.groups - 1);
+    unsigned* const rows = a.part + (long long)grp * a.chunks * NV;
+    // ---- the group's last block folds.  No agent-scope FENCE: on gfx950 a __threadfence() is an L2 write-back + invalidate, and one per
+    //      block (512-2048 of them) serialised per XCD made this kernel 3-8x slower than its predecessor (51 / 120 / 285 us at R = 16 / 64 /
+    //      256, profiles/r06_iou.txt).  The row is written with agent-scope ATOMIC stores (performed at the level all XCDs share), the
+    //      storing lanes wait for their completion (workgroup-scope release = s_waitcnt), then the ticket; the folding block reads the
+    //      rows with agent-scope atomic loads behind the ticket it took.
+    if ((int)threadIdx.x < NV)
+        __hip_atomic_store(&rows[(long long)chunk * NV + threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    const unsigned slot = ((a.ticket_base + (unsigned)grp) & (OP_TICKETS - 1)) * OP_TICKET_PITCH;
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(&g_iou_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.chunks - 1);
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
-    for (int i = threadIdx.x; i < a.P * a.R; i += 256) {
-        const int p = i / a.R, r = i - p * a.R;
-        const long long in = __hip_atomic_load(&a.acc[r * 5 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long ab = __hip_atomic_load(&a.acc[r * 5 + 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long aa = __hip_atomic_load(&a.acc[a.R * 5 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.inter[i] = in;
-        a.uni[i] = aa + ab - in;  // sum(A + B) - inter (seg_utils.py:133-134)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    {   // four stripes of chunks x 64 value slots
+        const int v = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+        unsigned sum = 0;
+        if (v < NV)
+            for (int c = stripe; c < a.chunks; c += 4) sum += __hip_atomic_load(&rows[(long long)c * NV + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[stripe][v] = sum;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&g_iou_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if ((int)threadIdx.x < GB * FUSED_MAXP) {
+        const int j = threadIdx.x / FUSED_MAXP, p = threadIdx.x - j * FUSED_MAXP;
+        const int r = r0 + j;
+        if (r < a.R && p < a.P) {
+            long long in = 0, ab = 0, aa = 0;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) { in += tot[st][5 * j + p]; ab += tot[st][5 * j + 4]; aa += tot[st][5 * GB + p]; }
+            a.inter[(long long)p * a.R + r] = in;
+            a.uni[(long long)p * a.R + r] = aa + ab - in;  // sum(A + B) - inter (seg_utils.py:133-134)
+        }
     }
 }
 
 }  // namespace
 
+int g_iou_shape = 0;  // sola_tune "iou_shape": 0 = by R; else 16 * G + nb (G in {1, 2, 4} slices in flight, nb batches per block; G * nb <= 12)
+void sola_iou_set_shape(int v) { g_iou_shape = v; }
+static void onepass_shape(int R, int* G, int* nb) {
+    if (g_iou_shape > 0 && (g_iou_shape >> 4) * (g_iou_shape & 15) <= 12 && (g_iou_shape & 15) > 0 &&
+        ((g_iou_shape >> 4) == 1 || (g_iou_shape >> 4) == 2 || (g_iou_shape >> 4) == 4)) {
+        *G = g_iou_shape >> 4; *nb = g_iou_shape & 15;
+        return;
+    }
+    // measured (tools/iou_sweep.py, P = 4, 540 x 960; kernel us at (G, nb)): R = 16: 10.5-10.9 for every one- or two-prompt shape (the launch's
+    // latency chain: loads, row store + ticket, fold); R = 64: 20.4 (1,1) 14.8 (2,1) 13.5 (2,2); R = 256: 56.0 (1,1) 32.0 (4,1) 29.3 (2,2) 27.8 (2,4)
+    *G = R <= 16 ? 1 : 2;
+    *nb = R <= 32 ? 1 : (R <= 128 ? 2 : 4);
+}
 size_t mask_iou_fused_scratch_bytes(int P, int R, long long words) {
-    (void)P; (void)words;
-    return 64 + ((size_t)R * 5 + 4) * 4;
+    (void)P;
+    // an upper bound over every shape: one prompt per block
+    const size_t chunks = (size_t)((words + OP_CHUNK - 1) / OP_CHUNK);
+    return (size_t)R * chunks * 9 * sizeof(unsigned);
 }
 
 int g_iou_fused = 1;  // sola_tune "iou_fused": 0 forces the pack + pair path (A/B, tests)
 void sola_iou_set_fused(int v) { g_iou_fused = v; }
 
-// true if the call was served by the fused kernel
+// true if the call was served by the one-launch kernel
 bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P, int R, int H, int W, int h, int w, long long* inter,
                            long long* uni, void* scratch, size_t scratch_bytes, hipStream_t s, int* status) {
     *status = SOLA_OK;
     const long long hw = (long long)H * W;
-    // masks of up to 2^32 - 1 pixels keep every count inside 32 bits; a 256-word slice keeps the packed wave sums inside 16
-    // Measured (tools/iou_probe.py, P=4, 540x960): R=16 18.6 us per call fused vs 25.3 us pack + pair; R=64 30.6 vs 25.8; R=256
-    // 125 vs 40 (the per-block wave reductions grow with R while the pack + pair path amortises its launches).  Round 3: the pack +
-    // pair path packs BOTH mask sets in one launch behind one memset (launch_mask_pack_pair) - three stream operations instead of
-    // five - and takes 19.4 / 18.8 / 19.9 / 35.1 us at R = 16 / 32 / 64 / 256 against 21.7 / 21.8 / 30.0 / 127 fused
-    // (tools/iou_ab.py): fused up to 16 prompts only (g_iou_fused == 2 forces it for any R: tests).
-    if (!g_iou_fused || (R > 16 && g_iou_fused != 2) || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 ||
-        hw > 0xffffffffll || R > 16 * 65535 ||
+    // Round 3 measured the earlier fused kernel (atomics + memset, 16 prompts per block) against pack + pair: 21.7 / 30.0 / 127 us at
+    // R = 16 / 64 / 256 against 19.4 / 19.9 / 35.1 - its per-block reductions grew with R.  This one scales its grid with the bytes
+    // (profiles/r06_iou.txt); pack + pair keeps P > 4, resampled or float masks, masks beyond 2 M pixels and R > 4096.
+    int G, nb;
+    onepass_shape(R, &G, &nb);
+    const int GB = G * nb;
+    const long long groups = ((long long)R + GB - 1) / GB, chunks = (hw / 32 + OP_CHUNK - 1) / OP_CHUNK;
+    if (!g_iou_fused || elem_type != 0 || P > FUSED_MAXP || h != H || w != W || hw % 32 != 0 || chunks > OP_MAX_CHUNKS || groups > OP_TICKETS / 4 ||
         (reinterpret_cast<uintptr_t>(am) & 15) || (reinterpret_cast<uintptr_t>(bm) & 15) ||
         scratch_bytes < mask_iou_fused_scratch_bytes(P, R, hw / 32))
         return false;
-    FusedArgs a;
+    OnepassArgs a;
     a.a = static_cast<const uint8_t*>(am); a.b = static_cast<const uint8_t*>(bm);
     a.hw = hw; a.words = hw / 32; a.P = P; a.R = R;
-    a.chunks = (int)((a.words + 255) / 256);
-    a.groups = (R + FUSED_RG - 1) / FUSED_RG;
-    a.done = static_cast<unsigned*>(scratch);
-    a.acc = a.done + 16;
+    a.chunks = (int)chunks; a.groups = (int)groups; a.nb = nb;
+    static unsigned next_ticket = 0;  // ring position (per process; every device has its own g_iou_ticket, a range unused there stays zero)
+    a.ticket_base = __atomic_fetch_add(&next_ticket, (unsigned)groups, __ATOMIC_RELAXED);
+    a.part = static_cast<unsigned*>(scratch);
     a.inter = inter; a.uni = uni;
-    if (hipMemsetAsync(scratch, 0, mask_iou_fused_scratch_bytes(P, R, a.words), s) != hipSuccess) {
-        sola_set_error("mask_iou_matrix: hipMemsetAsync failed");
-        *status = SOLA_ERR_HIP;
-        return true;
-    }
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)(P + R) * hw);
-    hipLaunchKernelGGL(mask_iou_fused_u8_kernel, dim3(a.chunks, a.groups), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)chunks, (unsigned)groups);
+    if (G == 1) hipLaunchKernelGGL(mask_iou_onepass_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (G == 2) hipLaunchKernelGGL(mask_iou_onepass_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mask_iou_onepass_kernel<4>, grid, dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) {
-        sola_set_error("mask_iou_matrix: fused kernel launch failed");
+        sola_set_error("mask_iou_matrix: one-launch kernel failed to launch");
         *status = SOLA_ERR_HIP;
     }
     return true;

@@ -205,20 +205,20 @@ __global__ __launch_bounds__(256) void mt_clip_adamw_kernel(const AdamEntry* __r
             }
         }
     }
-    // every block has read its counter by now (its stores depend on it); the last one to arrive advances all of them
+    // every block has read its counter by now (its stores depend on it; the barrier below is behind every thread's use of it); the last
+    // one to arrive advances all of them.  A relaxed agent-scope atomic and NO fence: nothing another block wrote is read here - only the
+    // count matters - and a __threadfence() (L2 write-back + invalidate on gfx950) in each of the 8 052 blocks cost the one-sample step
+    // 0.4 ms (1.53 -> 1.98 ms)
     __shared__ int is_last;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
     if (is_last) {
         for (int i = threadIdx.x; i < n; i += 256) {
             float* sp = tab[i].step;
             if (sp) *sp = step_arg > 0.f ? step_arg : *sp + 1.f;
         }
-        if (threadIdx.x == 0) *ticket = 0;
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

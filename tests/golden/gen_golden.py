@@ -237,6 +237,67 @@ def gen_range_golden():
     print("range_golden.npz", os.path.getsize(os.path.join(HERE, "range_golden.npz")) / 1e6, "MB")
 
 
+def gen_bench_golden():
+    """The reference's OWN logits for every batch bench.py times and the every-row GPU tests check (those batches
+    were compared with the oracle only).  The reference is called the way its entry points call it - ONE sample per forward
+    (inference.py:58, evaluator.py:100, train.py:95 at configs/mevis/default.yaml:37), eval mode - and only score_map is stored
+    (float32; the selection sigmoid(score_map) > 0.5 of inference.py:59-60 as a bool array beside it):
+      u256.<seed>              256 samples at (T=32, N=64, L=16), seeds 1000 (bench.py's rank-0 batch), 1001, 1002
+      u256.1000.oracle_f64     the same samples through oracle/sola_oracle.py in float64 (the reference itself cannot run in double:
+                               module/module.py:120-125 builds its positional table in float32): how far the reference's own
+                               fp32 result sits from exact arithmetic, row by row
+      u256.1000.lin_div64      seed 1000 on weights whose first softmax is NOT saturated (synth variant "lin_div64")
+      c4.<seed>                BASELINE config C4 (T=128, N=128, L=16), 32 samples: seed 2000 (tests), 77 (bench.py's stress leg)
+      rag_infer.<tag>          synth.make_ragged_infer_batches(128, 2024): one / four expressions per video, logits concatenated
+      rag_train.<seed>         synth.make_ragged_samples(64, 2024) / (128, 2025): the ragged training batches (eval-mode forward)
+    """
+    cfg = synth.DEFAULT_MODEL_CFG
+    store = {}
+    m, _ = build_reference(cfg, seed=42)
+
+    def per_sample(mod, objs, langs, dtype=torch.float32):
+        out = []
+        with torch.no_grad():
+            for o, l in zip(objs, langs):
+                sm, _st = mod(torch.from_numpy(o)[None].to(dtype), torch.from_numpy(l)[None].to(dtype))
+                out.append(sm[0].numpy())
+        return out
+
+    def put(key, rows):
+        flat = np.concatenate(rows)
+        store[key + ".score_map"] = flat.astype(np.float32) if flat.dtype == np.float32 else flat
+        store[key + ".selected"] = (torch.sigmoid(torch.from_numpy(flat)) > 0.5).numpy()  # inference.py:59-60
+        print(key, flat.shape, "max|logit|", float(np.abs(flat).max()), flush=True)
+
+    B, N, T, L = 256, 64, 32, 16
+    for seed in (1000, 1001, 1002):
+        inp = synth.make_inputs(cfg, B, N, T, L, seed=seed)
+        put(f"u256.{seed}", per_sample(m, inp["object_tokens"], inp["lang_tokens"]))
+    inp = synth.make_inputs(cfg, B, N, T, L, seed=1000)
+    from oracle import sola_oracle
+    tsd = sola_oracle.to_torch_state(synth.make_state_dict(cfg, 42))
+    rows64 = [sola_oracle.forward(tsd, cfg, inp["object_tokens"][b:b + 8], inp["lang_tokens"][b:b + 8], dtype=torch.float64)[0].numpy().reshape(-1)
+              for b in range(0, B, 8)]
+    put("u256.1000.oracle_f64", rows64)
+    mv = LanguageAlignedTrackSelectionModule(cfg)
+    mv.load_state_dict({k: torch.from_numpy(a) for k, a in synth.make_state_dict_variant(cfg, 42, "lin_div64").items()}, strict=True)
+    put("u256.1000.lin_div64", per_sample(mv.eval(), inp["object_tokens"], inp["lang_tokens"]))
+    del mv
+    for seed in (2000, 77):
+        inp = synth.make_inputs(cfg, 32, 128, 128, 16, seed=seed)
+        put(f"c4.{seed}", per_sample(m, inp["object_tokens"], inp["lang_tokens"]))
+    for tag, bt in synth.make_ragged_infer_batches(cfg, 128, 2024).items():
+        objs = [bt["videos"][v] for v in bt["sample_video"]]
+        put(f"rag_infer.{tag}", per_sample(m, objs, bt["texts"]))
+        store[f"rag_infer.{tag}.counts"] = np.array([o.shape[0] for o in objs], dtype=np.int32)
+    for n, seed in ((64, 2024), (128, 2025)):
+        smp = synth.make_ragged_samples(cfg, n, seed)
+        put(f"rag_train.{seed}", per_sample(m, [x["obj"].numpy() for x in smp], [x["lang"].numpy() for x in smp]))
+        store[f"rag_train.{seed}.counts"] = np.array([int(x["obj"].shape[0]) for x in smp], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "bench_golden.npz"), **store)
+    print("bench_golden.npz", os.path.getsize(os.path.join(HERE, "bench_golden.npz")) / 1e6, "MB")
+
+
 def rect_masks(rng, n, H, W, base=None, jitter=0):
     out = np.zeros((n, H, W), dtype=np.uint8)
     boxes = []
@@ -344,3 +405,5 @@ if __name__ == "__main__":
         gen_range_golden()
     if which in ("all", "ragged_train"):
         gen_ragged_train_golden()
+    if which in ("all", "bench"):
+        gen_bench_golden()

@@ -109,10 +109,13 @@ def test_full_size_properties():
     assert inter[1, 1] == A[1].sum()  # A[1] is a subset of B[1]
 
 
-@pytest.mark.parametrize("P,R,H,W", [(4, 16, 540, 960), (1, 1, 540, 960), (3, 64, 540, 960), (4, 7, 64, 96), (2, 5, 960, 540), (4, 300, 128, 256)])
+@pytest.mark.parametrize("P,R,H,W", [(4, 16, 540, 960), (1, 1, 540, 960), (3, 64, 540, 960), (4, 7, 64, 96), (2, 5, 960, 540), (4, 300, 128, 256),
+                                     (4, 33, 1080, 1920), (2, 3, 8, 4), (4, 129, 36, 100)])
 def test_fused_one_launch_path_equals_pack_and_pair(P, R, H, W):
-    """uint8 masks at the comparison resolution with P <= 4 (the de-dup loop's calls) take the fused kernel; its counts are
-    the oracle's and the three-kernel path's, including empty masks and a mask equal to its partner."""
+    """uint8 masks at the comparison resolution with P <= 4 (the de-dup loop's calls) take the one-launch kernel (round 6: no memset,
+    per-block count rows + a ticket per prompt group, iou.hip); its counts are the oracle's and the three-kernel path's, including
+    empty masks, a mask equal to its partner, a last chunk that is mostly out of range (1080 x 1920: 127 chunks; 8 x 4: one word)
+    and prompt counts that leave the last group ragged."""
     from sola_amd import _lib
 
     rng = np.random.default_rng(P * 1000 + R)
@@ -132,10 +135,38 @@ def test_fused_one_launch_path_equals_pack_and_pair(P, R, H, W):
     for inter, union in outs:
         np.testing.assert_array_equal(inter, ri)
         np.testing.assert_array_equal(union, ru)
-    # repeated calls reuse the scratch: the self-zeroing must hold
+    # repeated calls reuse the scratch and the library's ticket ring: every ticket must be back at zero
     for _ in range(3):
         inter, union = seg_utils.mask_iou_matrix(cuda(A), cuda(B))
         np.testing.assert_array_equal(inter.cpu().numpy(), ri)
+
+
+def test_one_launch_kernel_on_two_streams_at_once():
+    """The one-launch kernel's tickets live in the library (a ring range per launch): calls in flight on two streams at the same
+    time take disjoint ranges - 200 interleaved calls of different sizes, every result equal to the pack + pair path's."""
+    from sola_amd import _lib
+
+    rng = np.random.default_rng(7)
+    sets = []
+    for R in (16, 70):
+        A = (rng.uniform(size=(4, 540, 960)) < 0.3).astype(np.uint8)
+        B = (rng.uniform(size=(R, 540, 960)) < 0.4).astype(np.uint8)
+        a, b = cuda(A), cuda(B)
+        _lib.check(_lib.lib().sola_tune(b"iou_fused", 0), "sola_tune")
+        ref = seg_utils.mask_iou_matrix(a, b)
+        _lib.check(_lib.lib().sola_tune(b"iou_fused", 1), "sola_tune")
+        sets.append((a, b, ref))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for _ in range(100):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i].append(seg_utils.mask_iou_matrix(sets[i][0], sets[i][1]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for inter, union in outs[i]:
+            assert torch.equal(inter, sets[i][2][0]) and torch.equal(union, sets[i][2][1])
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])

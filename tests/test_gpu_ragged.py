@@ -12,6 +12,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from conftest import _load  # noqa: E402
+
 from conftest import case_dict  # noqa: E402
 from sola_amd import SolaError, synth  # noqa: E402
 from sola_amd.loss import track_selection_losses, track_selection_losses_ragged  # noqa: E402
@@ -287,3 +289,12 @@ def test_benched_ragged_batch_every_logit_vs_oracle(full, tag):
     assert e.max() <= 1e-3
     if full.precision == "f16x3":
         assert full.split_fallbacks()[1] == 0  # the range guard did not trip: these are the split-f16 kernels' numbers
+    # round 6: the same logits against the REFERENCE's own (one module/module.py forward per sample; tests/golden/gen_golden.py bench)
+    gold = _load("bench_golden.npz")
+    rref = gold[f"rag_infer.{tag}.score_map"]
+    assert list(gold[f"rag_infer.{tag}.counts"]) == list(counts)
+    er = np.abs(got - rref)
+    perr = np.array([er[o:o + c].max() for o, c in zip(starts, counts)])
+    print(f"{tag} {full.precision} vs REFERENCE: worst logit error {er.max():.3e}, mean per-sample worst {perr.mean():.3e}, samples > 5e-4: {(perr > 5e-4).sum()}")
+    np.testing.assert_array_equal((torch.sigmoid(torch.from_numpy(got)) > 0.5).numpy(), gold[f"rag_infer.{tag}.selected"])
+    assert er.max() <= 1e-3

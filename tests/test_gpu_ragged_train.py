@@ -15,6 +15,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from conftest import _load  # noqa: E402
+
 from conftest import case_dict  # noqa: E402,F401
 from sola_amd import SolaError, _lib, synth  # noqa: E402
 from sola_amd.loss import track_selection_losses, track_selection_losses_ragged  # noqa: E402
@@ -500,3 +502,10 @@ def test_training_forward_of_the_benched_ragged_batch_every_logit_vs_oracle(full
     print(f"training forward {precision}: worst logit error {e.max():.3e}, mean per-sample worst {per.mean():.3e}, samples > 5e-4: {(per > 5e-4).sum()} of 64")
     np.testing.assert_array_equal(got > 0, ref > 0)
     assert e.max() <= 1e-3
+    # round 6: against the REFERENCE's own logits for this batch (tests/golden/gen_golden.py bench)
+    gold = _load("bench_golden.npz")
+    assert list(gold["rag_train.2024.counts"]) == list(counts)
+    er = np.abs(got - gold["rag_train.2024.score_map"])
+    print(f"training forward {precision} vs REFERENCE: worst logit error {er.max():.3e}, mean {er.mean():.3e}")
+    np.testing.assert_array_equal((torch.sigmoid(torch.from_numpy(got)) > 0.5).numpy(), gold["rag_train.2024.selected"])
+    assert er.max() <= 1e-3

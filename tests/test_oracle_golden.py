@@ -189,3 +189,34 @@ def test_accumulated_gradients_of_mixed_shape_samples_small():
         ref = g["small.gradsum." + k]
         err = float(np.abs(t.grad.numpy() - ref).max())
         assert err <= 1e-3 * float(np.abs(ref).max()) + 1e-6 * total, (k, err, float(np.abs(ref).max()))
+
+
+def test_benched_batches_vs_reference(full_sd):
+    """tests/golden/bench_golden.npz (gen_golden.py bench): the reference's own logits for the batches bench.py times.  The oracle on a
+    bounded sample of them (CPU time): the first 8 samples of the headline batch (seed 1000), base and "lin_div64" weights, in fp32 AND
+    float64 (the stored float64 row is the oracle's own: regenerated bit for bit within 1e-9), and the first 6 samples of the ragged
+    training batch - one per-sample forward each, as the reference is called (inference.py:58)."""
+    from conftest import _load
+
+    g = _load("bench_golden.npz")
+    cfg = synth.DEFAULT_MODEL_CFG
+    inp = synth.make_inputs(cfg, 256, 64, 32, 16, seed=1000)
+    tsd = sola_oracle.to_torch_state(full_sd)
+    sm, _ = sola_oracle.forward(tsd, cfg, inp["object_tokens"][:8], inp["lang_tokens"][:8])
+    ref = g["u256.1000.score_map"].reshape(256, 64)[:8]
+    assert float(np.abs(sm.numpy() - ref).max()) <= 1e-3
+    np.testing.assert_array_equal(sola_oracle.select(sm).numpy() > 0, g["u256.1000.selected"].reshape(256, 64)[:8])
+    sm64, _ = sola_oracle.forward(tsd, cfg, inp["object_tokens"][:8], inp["lang_tokens"][:8], dtype=torch.float64)
+    np.testing.assert_allclose(sm64.numpy(), g["u256.1000.oracle_f64.score_map"].reshape(256, 64)[:8], rtol=0, atol=1e-9)
+    assert float(np.abs(sm64.numpy() - ref).max()) <= 6e-4  # the reference's own fp32 distance from exact arithmetic on these rows
+    vsd = sola_oracle.to_torch_state(synth.make_state_dict_variant(cfg, 42, "lin_div64"))
+    smv, _ = sola_oracle.forward(vsd, cfg, inp["object_tokens"][:8], inp["lang_tokens"][:8])
+    assert float(np.abs(smv.numpy() - g["u256.1000.lin_div64.score_map"].reshape(256, 64)[:8]).max()) <= 1e-3
+    smp = synth.make_ragged_samples(cfg, 64, 2024)
+    counts = g["rag_train.2024.counts"]
+    off = 0
+    for i in range(6):
+        s1, _ = sola_oracle.forward(tsd, cfg, smp[i]["obj"].numpy()[None], smp[i]["lang"].numpy()[None])
+        assert int(counts[i]) == s1.shape[1]
+        assert float(np.abs(s1.numpy()[0] - g["rag_train.2024.score_map"][off:off + counts[i]]).max()) <= 1e-3, i
+        off += int(counts[i])
