@@ -972,6 +972,18 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # parity at N > 1 (round 6): every rank that owns a batch the reference's logits are committed for (seeds 1000-1002 = ranks 0-2 at the
+        # default batch) checks every row of ITS batch; the worst error over those ranks goes into the line (a 64 KB fixture, no CPU work)
+        rg = reference_logits(f"u256.{1000 + rank}") if (B, N, T, L) == (256, 64, 32, 16) else None
+        e = torch.tensor([-1.0, 0.0], device=dev, dtype=torch.float64)
+        if rg is not None:
+            with torch.no_grad():
+                ur = uniform_row_errors(m(obj, lang)[0].cpu().numpy(), rg)
+            e = torch.tensor([ur["max_abs_logit_err_vs_reference"] if ur["selections_equal"] else 1e9, 1.0], device=dev, dtype=torch.float64)
+        emax, ecnt = e[:1].clone(), e[1:].clone()
+        torch.distributed.all_reduce(emax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(ecnt, op=torch.distributed.ReduceOp.SUM)
+        dist_parity = {"max_abs_logit_err_vs_reference": float(emax.item()), "ranks_checked": int(ecnt.item())} if ecnt.item() > 0 else None
     total_samples = B * args.steps * world
     value = total_samples / elapsed
     sync = lambda: torch.cuda.synchronize(dev)
@@ -981,6 +993,8 @@ def main():
     exact = None
     parity = None
     parity_ref = None
+    if world == 1:
+        dist_parity = None
     if args.precision == "f16x3" and world == 1:
         with torch.no_grad():
             sm_split, _ = m(obj, lang)
@@ -1083,6 +1097,8 @@ def main():
             out["max_abs_logit_err_vs_oracle"] = parity
         if parity_ref is not None:  # ... and against the reference's own logits for this batch (tests/golden/bench_golden.npz)
             out["max_abs_logit_err_vs_reference"] = parity_ref
+        if world > 1 and dist_parity is not None:
+            out["max_abs_logit_err_vs_reference"] = dist_parity
         if exact is not None:
             out["exact_f32_mode"] = exact
         if world == 1 and args.extra_legs:

@@ -535,7 +535,7 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
  * transposing cast of a gradient matrix also writes its row-major cast; "bwd_fused_bf16_cast" 1 (default) = bf16 storage: the
  * statistics pass over a gradient matrix (bias sums) writes its bf16 cast as well - no max|x| pass, no scale; "attn_bwd_fused" 1 (default) = the one-pass attention
  * backward for units of <= 128 queries and keys and for chunked long query ranges, 0 = the two-pass kernels everywhere;
- * "attn_split_min_keys" (default 128) = units with more keys take the split-f16 attention on split q / k / v in precision 1;
+ * "attn_split_min_keys" (default 96) = units with more keys take the split-f16 attention on split q / k / v in precision 1;
  * "train_dw_f16" 1 (default) = weight-gradient products of the precision-1 training step on plain f16 operands;
  * "train_gn_cast" 1 (default) = in the 16-bit operand training modes a GroupNorm also writes the operand cast of the GEMM behind
  * it; "attn_spin" 1 (default) = the high-occupancy attention shape for split-f16 q / k / v; "gn_h8" /

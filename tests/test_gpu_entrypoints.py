@@ -97,6 +97,16 @@ def test_bench_two_ranks_code_path(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "samples/s"
     assert out["config"]["sharding"] == "per-sample x2" and "roofline" in out and "cpu_baseline" not in out
+    # the driver's contract at N > 1: every key of the line, the backend's own view of the job, the training leg
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in out, k
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True and out["vs_baseline"] is None and out["data"] == "synthetic"
+    assert out["metric"].startswith("track-selection forward+loss samples/sec at (T=32,N=64,d=256)")
+    assert out["config"]["world_size_reported_by_backend"] == 2 and out["config"]["collective_backend"] == "gloo"
+    assert out["config"]["batch_per_gpu"] == 4 and abs(out["value"] - 2 * 4 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]  # whole-job samples/s
+    if out["roofline"] is not None:
+        assert out["roofline"]["frac"] > 0 and out["roofline"]["bound"] == "mfma"
+    assert out["roofline_attention"]["bound"] == "hbm" and out["roofline_attention"]["frac"] > 0
     # the multi-rank training leg: the one collective of the path, with and without overlap, and the per-rank ragged inference leg
     td = out["training_step_dist"]
     assert td["world_size"] == 2 and td["backend"] == "gloo"
