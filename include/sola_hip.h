@@ -152,6 +152,24 @@ int sola_attention_f16(const void* dev_q, int ldq, const void* dev_k, int ldk, c
                        int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
                        int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, void* stream);
 
+/* Building blocks of the bf16 training step's 16-bit storage (precision 3, round 6), exposed for the parity tests.  BFLOAT16 matrices are
+ * rows of 2-byte values, pitches in values.
+ *   sola_gemm_nt_bf16: C = A W^T + bias (+ R) on bfloat16 A [M,K] / W [N,K], f32 accumulation; C and R f32 or (c_is_bf16 / r_is_bf16) bfloat16.
+ *   sola_attention_bf16: softmax(q k^T scale) v on bfloat16 q / k / v (sola_attention's addressing, more than 16 queries or keys); the
+ *     output as f32 rows (dev_o) and / or bfloat16 rows (dev_o_bf16), the log-sum-exp optional.
+ *   sola_attention_backward_bf16: sola_attention_backward_ws on bfloat16 q / k / v with the gradients written as bfloat16 rows; dev_dq_scratch
+ *     = an f32 [q rows, ld_dq] matrix (units of more keys than one key group accumulate dQ there).  One-pass kernel shapes only. */
+int sola_gemm_nt_bf16(const void* dev_a, int lda, const void* dev_w, const float* dev_bias, const void* dev_r, int ldr, int r_is_bf16,
+                      void* dev_c, int ldc, int c_is_bf16, int M, int N, int K, void* stream);
+int sola_attention_bf16(const void* dev_q, int ldq, const void* dev_k, int ldk, const void* dev_v, int ldv, float* dev_o, void* dev_o_bf16, int ldo,
+                        int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
+                        int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, float* dev_lse, void* stream);
+int sola_attention_backward_bf16(const void* dev_q, int ldq, const void* dev_k, int ldk, const void* dev_v, int ldv, const float* dev_o,
+                                 const float* dev_dout, int ldo, const float* dev_lse, void* dev_dq_bf16, void* dev_dk_bf16, void* dev_dv_bf16,
+                                 int ld_dq, int ld_dk, int ld_dv, float* dev_dq_scratch, float* dev_dvec, int G, int H, int head_dim, int Sq, int Sk,
+                                 int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride, int64_t k_outer, int64_t k_inner,
+                                 int64_t k_row_stride, float scale, int64_t q_rows, float* dev_scratch, size_t scratch_floats, void* stream);
+
 /* ---- forward: replaces LanguageAlignedTrackSelectionModule.forward (module/module.py:130-162) ------------------ */
 size_t sola_workspace_bytes(const SolaCtx* ctx, int B, int N, int T, int L);
 int sola_forward(SolaCtx* ctx,

@@ -325,6 +325,7 @@ void sola_attn_set_ring_remap(int v);
 void sola_attn_set_ring_ablate(int v);
 void sola_attn_set_simple_remap(int v);
 void sola_iou_set_shape(int v);
+extern int g_train_bf16_store;
 void sola_attn_set_simple_db(int v);
 void sola_pack_set_resample_lds(int v);
 static int g_stage_split_math = 0;
@@ -417,6 +418,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_target_blocks")) { sola_attn_set_target_blocks(value); return SOLA_OK; }
     if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
     if (!strcmp(key, "iou_shape")) { sola_iou_set_shape(value); return SOLA_OK; }
+    if (!strcmp(key, "train_bf16_store")) { g_train_bf16_store = value; return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }
@@ -550,6 +552,45 @@ extern "C" int sola_attention_f16(const void* q, int ldq, const void* k, int ldk
     AttnDesc d{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(o), ldq, ldk, ldv, ldo,
                G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, nullptr};
     return launch_attention_f16(d, as_stream(stream_));
+}
+
+// ---- building blocks of the bf16 training step's 16-bit storage (round 6), exposed for the parity tests --------------------------------
+extern "C" int sola_gemm_nt_bf16(const void* a_b, int lda, const void* w_b, const float* bias, const void* r, int ldr, int r_is_bf16, void* cmat, int ldc,
+                                 int c_is_bf16, int M, int N, int K, void* stream_) {
+    SOLA_ARG(a_b && w_b && cmat, "gemm_nt_bf16: null argument");
+    GemmDesc gd{};
+    gd.nprob = 1;
+    gd.p[0] = GemmProblem{static_cast<const float*>(a_b), static_cast<const float*>(w_b), bias, static_cast<const float*>(r), static_cast<float*>(cmat)};
+    gd.M = M; gd.N = N; gd.K = K; gd.lda = lda; gd.ldr = ldr; gd.ldc = ldc;
+    gd.arith = 2; gd.bf16 = 1; gd.out_scale = 1.f; gd.r_f16 = (r && r_is_bf16) ? 1 : 0; gd.c_f16 = c_is_bf16;
+    return launch_gemm(gd, as_stream(stream_));
+}
+extern "C" int sola_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, float* o, void* o_bf16, int ldo, int G, int H,
+                                   int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_rs,
+                                   int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, float* lse, void* stream_) {
+    SOLA_ARG(q && k && v && (o || o_bf16), "attention_bf16: null argument");
+    AttnDesc d{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), o, ldq, ldk, ldv, ldo,
+               G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale, lse};
+    d.drop = g_stage_drop;
+    d.in_bf16 = 1;
+    bool done = false;
+    if (o_bf16) { d.o_cast = o_bf16; d.o_cast_fmt = 3; d.o_cast_done = &done; }
+    SOLA_TRY(launch_attention(d, as_stream(stream_)));
+    SOLA_ARG(!o_bf16 || done, "attention_bf16: this shape does not write the bf16 output");
+    return SOLA_OK;
+}
+extern "C" int sola_attention_backward_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* o, const float* dout, int ldo,
+                                            const float* lse, void* dq16, void* dk16, void* dv16, int ld_dq, int ld_dk, int ld_dv, float* dq_scratch,
+                                            float* dvec, int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner,
+                                            int64_t q_rs, int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, int64_t q_rows, float* scratch,
+                                            size_t scratch_floats, void* stream_) {
+    SOLA_ARG(q && k && v && o && dout && lse && dq16 && dk16 && dv16 && dq_scratch && dvec, "attention_backward_bf16: null argument");
+    AttnBwdDesc d{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), o, dout, lse, dq_scratch, nullptr, nullptr, dvec,
+                  ldq, ldk, ldv, ldo, ld_dq, ld_dk, ld_dv, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale};
+    d.drop = g_stage_drop;
+    d.part = scratch; d.part_floats = scratch_floats; d.part_rows = q_rows;
+    d.io_bf16 = 1; d.dq16 = dq16; d.dk16 = dk16; d.dv16 = dv16;
+    return launch_attention_bwd(d, as_stream(stream_));
 }
 
 extern "C" int sola_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int K, float* scal, void* stream_) {

@@ -619,6 +619,7 @@ extern int g_attn_ring;
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
+    if (d.in_bf16) return launch_attention_simple(d, s);  // bf16 q / k / v (training step's 16-bit storage): one shape takes them, it checks
     if (d.k_private > 0) {  // shared trailing keys: one shape implements them
         SOLA_ARG(attention_shared_keys_supported(d), "attention: shared keys (k_private %d of %d) need the few-keys shape (f32 q/k/v, head_dim 128, <= 64 keys, >= 128 queries, no unit tables)", d.k_private, d.Sk);
         return launch_attention_res(d, s);

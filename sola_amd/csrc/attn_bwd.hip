@@ -35,7 +35,25 @@ struct AttnBwdArgs {
     // units of row stride 1 laid out in unit order); attn_bwd_part_reduce_kernel adds a unit's chunks in order
     int qc_tiles;
     float* part;
+    // round 6 (the training step's bf16 storage; one-pass kernel only - check attention_bwd_bf16_supported): q, k, v are BFLOAT16 rows
+    // (ldq / ldk / ldv in values) and dQ, dK, dV leave as bfloat16 rows dq16 / dk16 / dv16 (pitches ld_dq / ld_dk / ld_dv in values) - the
+    // operand of the dW / dX GEMMs behind this launch, no f32 copy and no cast pass.  dq (f32, same pitch) is scratch then: units of more
+    // keys than one key group holds accumulate their dQ there in f32 and only the last group writes the bf16 row.
+    // (dk / dv carry the bfloat16 key / value gradient pointers in this mode - two fewer kernel arguments: the four-wave shape has no scalar
+    // register to spare)
+    int io16;
+    unsigned short* dq16;
 };
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 w) {
+    return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 f32x4_to_bf16(float x, float y, float z, float w) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    bf4 b;
+    b[0] = (__bf16)x; b[1] = (__bf16)y; b[2] = (__bf16)z; b[3] = (__bf16)w;
+    return __builtin_bit_cast(uint2, b);
+}
 
 struct BwdGeo { long long q0, k0, q_rs, k_rs; int Sq, Sk; };
 __device__ __forceinline__ BwdGeo bwd_geo(const AttnBwdArgs& a, int grp) {
@@ -672,7 +690,10 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
 //     group adds to what the same thread wrote before.
 // D = dO . O and the log-sum-exp of the unit's queries sit in LDS.  Same arithmetic, masks and dropout counters as the two-pass
 // kernels.  q, k, v, o, dO are read once and dQ, dK, dV written once per (unit, head).
-template <int NWU>
+// IO16 (round 6): bf16 q / k / v in, bf16 dQ / dK / dV out (AttnBwdArgs::io16).  Only the loads and the stores differ: q rows are widened on
+// their way into the f32 LDS tile (four-wave shape: the next tile's q piece travels in four registers beside the DMA of dO and O), k / v
+// fragments are 8-byte loads, the gradients leave as 8-byte rows of four values.
+template <int NWU, bool IO16 = false>
 __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnBwdArgs a) {
     constexpr int DH = 128, NC = DH / 16, LD = DH + 4, F4 = DH / 4, NT = 64 * NWU;
     // NWU = 4: the next tile's q, dO and O rows travel straight into LDS (global_load_lds, no registers) under the current tile's
@@ -714,7 +735,9 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
             const int q = qt0 + r;
             const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
-            float4 qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
+            float4 qv;
+            if constexpr (IO16) qv = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.q) + row * a.ldq + h * DH + c4 * 4));
+            else qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
             float4 gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
             const float4 ov = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
             if (q >= geo.Sq) qv = gv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -731,14 +754,24 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
     // unit's queries re-read its first row (finite values; their probabilities are masked to zero).  (Two half-wave instructions
     // per pair under `if (lane < 32) ... else ...` do NOT work: the compiler merges the branches and reads the LDS base of the first
     // lane for the whole wave.)
+    // IO16, four waves: the next tile's q rows arrive by DMA as RAW bfloat16 rows at the start of the tile buffer's q image (16 x 256 bytes:
+    // wave w moves rows 4w..4w+3, lane l the eight values at 8 * (l & 15) of row 4w + (l >> 4) - lane-linear, so every thread's piece lands
+    // at 16 * tid); behind the wait each thread reads ITS OWN piece back (no barrier needed for that), and once every thread has (the
+    // barrier that follows anyway) widens it into the f32 image over the raw bytes.  No register lives across the tile's MFMAs.
     auto issue_tile = [&](int qt0, int buf) {
+        if constexpr (IO16) {
+            const int q = qt0 + (tid >> 4);
+            const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned short*>(a.q) + row * a.ldq + h * DH + (tid & 15) * 8),
+                                             (lptr_t)(Qs + buf * 16 * RP + wave * 256), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int pr2 = wave * 2 + i, r = pr2 * 2 + (lane >> 5), ch = lane & 31;
             const int q = qt0 + r;
             const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
             const int pc = buf * 16 * RP + pr2 * (2 * RP);  // floats
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.q + row * a.ldq + h * DH + ch * 4), (lptr_t)(Qs + pc), 16, 0, 0);
+            if constexpr (!IO16) __builtin_amdgcn_global_load_lds((gptr_t)(a.q + row * a.ldq + h * DH + ch * 4), (lptr_t)(Qs + pc), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + row * a.ldo + h * DH + ch * 4), (lptr_t)(Gs + pc), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(a.o + row * a.ldo + h * DH + ch * 4), (lptr_t)(Os + pr2 * (2 * RP)), 16, 0, 0);
         }
@@ -747,6 +780,12 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
             __builtin_amdgcn_global_load_lds((gptr_t)(a.lse + row * a.H + h), (lptr_t)(lsh + buf * 16), 4, 0, 0);
         }
+    };
+    auto load_qraw = [&](int buf) -> uint4 { return *reinterpret_cast<const uint4*>(Qs + buf * 16 * RP + tid * 4); };
+    auto store_q = [&](int buf, const uint4 w) {
+        const int r = tid >> 4, c8 = tid & 15;
+        *reinterpret_cast<float4*>(at(Qs, buf, r, 2 * c8)) = bf16x4_to_f32(make_uint2(w.x, w.y));
+        *reinterpret_cast<float4*>(at(Qs, buf, r, 2 * c8 + 1)) = bf16x4_to_f32(make_uint2(w.z, w.w));
     };
     auto dvec_from_lds = [&](int buf) {  // D of a landed tile: half a wave per row, two rows per wave and pass
 #pragma unroll
@@ -771,23 +810,33 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         {
             const float* kp = a.k + krow * a.ldk + h * DH + 4 * g4;
             const float* vp = a.v + krow * a.ldv + h * DH + 4 * g4;
+            const unsigned short* kp16 = reinterpret_cast<const unsigned short*>(a.k) + krow * a.ldk + h * DH + 4 * g4;
+            const unsigned short* vp16 = reinterpret_cast<const unsigned short*>(a.v) + krow * a.ldv + h * DH + 4 * g4;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float4 kl = *reinterpret_cast<const float4*>(kp + c * 16);  // clamped row, VALUE select (see attn_bwd_dkv_kernel)
+                float4 kl, vl;  // clamped row, VALUE select (see attn_bwd_dkv_kernel)
+                if constexpr (IO16) {
+                    kl = bf16x4_to_f32(*reinterpret_cast<const uint2*>(kp16 + c * 16));
+                    vl = bf16x4_to_f32(*reinterpret_cast<const uint2*>(vp16 + c * 16));
+                } else {
+                    kl = *reinterpret_cast<const float4*>(kp + c * 16);
+                    vl = *reinterpret_cast<const float4*>(vp + c * 16);
+                }
                 const float4 kv = k_ok ? kl : z;
                 kf[c] = make_float4(kv.x * a.scale, kv.y * a.scale, kv.z * a.scale, kv.w * a.scale);
-                const float4 vl = *reinterpret_cast<const float4*>(vp + c * 16);
                 vf[c] = k_ok ? vl : z;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // the same tile with the key on the contraction slots: K[key = 4*g4 + r][d = 16*c + c16]
                 const int kk = kt * 16 + 4 * g4 + r;
                 const bool okr = w_ok && kk < geo.Sk;
-                const float* kr = a.k + (geo.k0 + (long long)(okr ? kk : 0) * geo.k_rs) * a.ldk + h * DH + c16;
+                const long long ro = (geo.k0 + (long long)(okr ? kk : 0) * geo.k_rs) * a.ldk + h * DH + c16;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const float v = kr[c * 16];
+                    float v;
+                    if constexpr (IO16) v = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(a.k)[ro + c * 16] << 16);
+                    else v = a.k[ro + c * 16];
                     kT[c][r] = okr ? v * a.scale : 0.f;
                 }
             }
@@ -798,6 +847,11 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
 
         if constexpr (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (IO16) {
+                const uint4 w = load_qraw(0);
+                __syncthreads();  // every thread holds its raw piece
+                store_q(0, w);
+            }
             __syncthreads();  // tile 0 landed; also: the previous group's last reduction done
             dvec_from_lds(0);
             __syncthreads();
@@ -891,7 +945,14 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             }
             if constexpr (NWU > 1) {
                 if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed
-                __syncthreads();  // partial tiles complete (DMA: and the next tile visible)
+                uint4 qraw = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (DMA && IO16) {
+                    if (more && !(a.ntile & 2)) qraw = load_qraw(cur ^ 1);  // this thread's own DMA piece
+                }
+                __syncthreads();  // partial tiles complete (DMA: and the next tile visible; IO16: every raw q piece is in a register)
+                if constexpr (DMA && IO16) {
+                    if (more && !(a.ntile & 2)) store_q(cur ^ 1, qraw);  // nobody reads that buffer's q image before the iteration's closing barrier
+                }
                 const int nact = min(NWU, nkt - kg);
 #pragma unroll 1
                 for (int j = 0; j < PER; ++j) {
@@ -903,12 +964,18 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                     }
                     const int q = qt0 + r;
                     if (q < geo.Sq) {
-                        float* p = a.dq + (geo.q0 + (long long)q * geo.q_rs) * a.ld_dq + h * DH + c4 * 4;
+                        const long long eo = (geo.q0 + (long long)q * geo.q_rs) * a.ld_dq + h * DH + c4 * 4;
+                        float* p = a.dq + eo;
                         if (kg > 0) {  // written by this same thread in the previous key group
                             const float4 old = *reinterpret_cast<const float4*>(p);
                             acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
                         }
-                        *reinterpret_cast<float4*>(p) = acc;
+                        if constexpr (IO16) {  // the f32 row is scratch between key groups; the last group writes the bf16 row
+                            if (kg + NWU < nkt) *reinterpret_cast<float4*>(p) = acc;
+                            else *reinterpret_cast<uint2*>(a.dq16 + eo) = f32x4_to_bf16(acc.x, acc.y, acc.z, acc.w);
+                        } else {
+                            *reinterpret_cast<float4*>(p) = acc;
+                        }
                     }
                 }
                 if constexpr (DMA) {
@@ -920,7 +987,8 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             } else {
                 const int q = qt0 + c16;
                 if (q < geo.Sq) {  // one wave, one key tile: dqacc is the whole dQ tile
-                    float* p = a.dq + (geo.q0 + (long long)q * geo.q_rs) * a.ld_dq + h * DH + 4 * g4;
+                    const long long eo = (geo.q0 + (long long)q * geo.q_rs) * a.ld_dq + h * DH + 4 * g4;
+                    float* p = a.dq + eo;
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         float4 acc = make_float4(dqacc[c][0], dqacc[c][1], dqacc[c][2], dqacc[c][3]);
@@ -928,7 +996,12 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                             const float4 old = *reinterpret_cast<const float4*>(p + c * 16);
                             acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
                         }
-                        *reinterpret_cast<float4*>(p + c * 16) = acc;
+                        if constexpr (IO16) {
+                            if (kg + NWU < nkt) *reinterpret_cast<float4*>(p + c * 16) = acc;
+                            else *reinterpret_cast<uint2*>(a.dq16 + eo + c * 16) = f32x4_to_bf16(acc.x, acc.y, acc.z, acc.w);
+                        } else {
+                            *reinterpret_cast<float4*>(p + c * 16) = acc;
+                        }
                     }
                 }
                 __syncthreads();  // every lane is done with the tile
@@ -944,11 +1017,21 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 dkp = a.part + ((slot * a.H + h) * 2 * (16 * NWU) + kj) * DH + 4 * g4;
                 dvp = dkp + (16 * NWU) * DH;
             }
+            if (IO16 && !a.qc_tiles) {  // final rows: bf16
+                unsigned short* dk16 = reinterpret_cast<unsigned short*>(a.dk) + krow * a.ld_dk + h * DH + 4 * g4;
+                unsigned short* dv16 = reinterpret_cast<unsigned short*>(a.dv) + krow * a.ld_dv + h * DH + 4 * g4;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    *reinterpret_cast<uint2*>(dk16 + c * 16) = f32x4_to_bf16(dkacc[c][0] * a.scale, dkacc[c][1] * a.scale, dkacc[c][2] * a.scale, dkacc[c][3] * a.scale);
+                    *reinterpret_cast<uint2*>(dv16 + c * 16) = f32x4_to_bf16(dvacc[c][0], dvacc[c][1], dvacc[c][2], dvacc[c][3]);
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 *reinterpret_cast<float4*>(dkp + c * 16) = make_float4(dkacc[c][0] * a.scale, dkacc[c][1] * a.scale,
                                                                        dkacc[c][2] * a.scale, dkacc[c][3] * a.scale);
                 *reinterpret_cast<float4*>(dvp + c * 16) = make_float4(dvacc[c][0], dvacc[c][1], dvacc[c][2], dvacc[c][3]);
+            }
             }
         }
     }
@@ -972,6 +1055,11 @@ __global__ __launch_bounds__(256) void attn_bwd_part_reduce_kernel(const AttnBwd
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         const long long krow = geo.k0 + (long long)kj * geo.k_rs;
+        if (a.io16) {
+            unsigned short* p16 = (t ? reinterpret_cast<unsigned short*>(a.dv) + krow * a.ld_dv : reinterpret_cast<unsigned short*>(a.dk) + krow * a.ld_dk) + h * DH + c4 * 4;
+            *reinterpret_cast<uint2*>(p16) = f32x4_to_bf16(acc.x, acc.y, acc.z, acc.w);
+            continue;
+        }
         float* p = t ? a.dv + krow * a.ld_dv + h * DH + c4 * 4 : a.dk + krow * a.ld_dk + h * DH + c4 * 4;
         *reinterpret_cast<float4*>(p) = acc;
     }
@@ -985,7 +1073,7 @@ int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels f
 int g_attn_bwd_ablate = 0;  // measurement only (sola_tune "attn_bwd_ablate"): 1 = no tile arithmetic, 2 = only the first tile staged
 int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
 
-template <int NWU>
+template <int NWU, bool IO16>
 static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     constexpr int LD = 128 + 4;
     constexpr bool DMA = NWU == 4;  // as in the kernel
@@ -993,12 +1081,12 @@ static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const long long blocks = (long long)a.G * a.H;
     SOLA_ARG(blocks < (1ll << 31) && chunks < 65536, "attention backward: grid too large");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (a.qc_tiles) {
         // few (unit, head) pairs: the positions of a unit (at most 16 NWU keys x 64 float4) over several blocks
@@ -1027,9 +1115,14 @@ static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, long long part_rows, 
         a.qc_tiles = qc;
         chunks = ((a.Sq + 15) / 16 + qc - 1) / qc;
     }
-    if (a.Sk <= 16) return launch_bwd_fused_n<1>(a, chunks, s);
-    if (a.Sk <= 32) return launch_bwd_fused_n<2>(a, chunks, s);
-    return launch_bwd_fused_n<4>(a, chunks, s);
+    if (a.io16) {
+        if (a.Sk <= 16) return launch_bwd_fused_n<1, true>(a, chunks, s);
+        if (a.Sk <= 32) return launch_bwd_fused_n<2, true>(a, chunks, s);
+        return launch_bwd_fused_n<4, true>(a, chunks, s);
+    }
+    if (a.Sk <= 16) return launch_bwd_fused_n<1, false>(a, chunks, s);
+    if (a.Sk <= 32) return launch_bwd_fused_n<2, false>(a, chunks, s);
+    return launch_bwd_fused_n<4, false>(a, chunks, s);
 }
 
 static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
@@ -1137,6 +1230,14 @@ void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
 void sola_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
 void sola_attn_set_bwd_ablate(int v) { g_attn_bwd_ablate = v; }
 
+// bf16 q / k / v in and bf16 dQ / dK / dV out (AttnBwdDesc::io_bf16): the one-pass kernel's shapes, 8-value-aligned rows
+bool attention_bwd_bf16_supported(const AttnBwdDesc& d) {
+    if (!g_attn_bwd_fused || d.DH != 128 || d.Sk > 128 || (g_attn_bwd_small && d.Sq <= 4 && d.Sk <= 4)) return false;
+    if (d.ldq % 8 || d.ldk % 8 || d.ldv % 8 || d.ld_dq % 4 || d.ld_dk % 4 || d.ld_dv % 4) return false;
+    const bool can_chunk = d.part && d.Sk <= 64 && d.part_floats >= attention_bwd_part_floats(d.part_rows, d.G, d.H, d.Sk) && (d.q_units || (d.q_rs == 1 && d.inner == 1));
+    return d.Sq <= 128 || (d.Sk <= 64 && (d.Sq <= 16 * 16 || can_chunk));
+}
+
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention backward: bad sizes");
     AttnBwdArgs a;
@@ -1150,6 +1251,10 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.scale = d.scale;
     a.drop = d.drop;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    a.io16 = d.io_bf16 ? 1 : 0;
+    a.dq16 = static_cast<unsigned short*>(d.dq16);
+    if (d.io_bf16) { a.dk = static_cast<float*>(d.dk16); a.dv = static_cast<float*>(d.dv16); }
+    if (d.io_bf16) SOLA_ARG(attention_bwd_bf16_supported(d) && d.dq16 && d.dk16 && d.dv16 && d.dq, "attention backward: bf16 q / k / v and gradients need the one-pass kernel's shapes");
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN_BWD, s, 14.0 * elems * d.Sq * d.Sk, 4.0 * elems * (5.0 * d.Sq + 4.0 * d.Sk));
     if (g_attn_bwd_small && d.DH == 128 && d.Sq <= 4 && d.Sk <= 4) return launch_bwd_small(a, s);

@@ -22,6 +22,7 @@ struct AttnSArgs {
     long long k_outer, k_inner, k_rs;
     float scale;
     int o_sp16;
+    int in_bf16;  // q / k / v are bfloat16 rows (IN16 instantiation)
     int* guard;
     const int4 *q_units, *k_units;
     int xcd_remap;
@@ -30,7 +31,14 @@ struct AttnSArgs {
     void* o_cast;     // TR instantiation: AttnDesc::o_cast / o_side / o_cast_fmt
     void* o_side;
     int o_cast_fmt;
+    int o_skip_f32;   // TR + IN16: the f32 output is not written (the bf16 o_cast is the only copy: AttnDesc::in_bf16 with o == nullptr)
 };
+
+// four / eight bfloat16 values of one 8- / 16-byte load as floats (a bf16 is the upper half of an f32)
+__device__ __forceinline__ float4 bf16x4_f32(uint2 w) {
+    return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+}
 
 // DB: two LDS stages of TK keys; the next tile's K/V rows travel in registers while the current tile is multiplied and there
 // is ONE barrier per tile (the shape that took the attention backward from 460 to 299 us, attn_bwd.hip).
@@ -38,8 +46,11 @@ struct AttnSArgs {
 // takes this shape too (its q-blocks are independent blocks: units of very different lengths balance over the chip, where
 // attn.hip's shared mode walks a ragged unit's q-blocks inside one block).  A separate instantiation: the inference kernel's
 // registers (126 at four blocks per CU) are untouched.
-template <int DH, int TK, bool DB = false, bool TR = false>
+// IN16 (round 6, the training step's bf16 storage): q / k / v are BFLOAT16 rows (pitches in values) - 8-byte q loads, 16-byte K / V
+// prefetch pieces of eight values, widened on their way into the f32 LDS stages; everything behind the loads is the f32 kernel.
+template <int DH, int TK, bool DB = false, bool TR = false, bool IN16 = false>
 __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnSArgs a) {
+    static_assert(!IN16 || (DB && TR), "bf16 inputs: the double-buffered training instantiation");
     constexpr int NC = DH / 16;
     constexpr int LDK = DH + 4, LDV = DH + 4;
     constexpr int F4 = DH / 4;
@@ -68,7 +79,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
     const int qi = qb * 64 + wave * 16 + c16;
     const bool q_ok = qi < Sq;
     float4 qf[NC];
-    {
+    if constexpr (IN16) {
+        const unsigned short* qp = reinterpret_cast<const unsigned short*>(a.q) + (q0 + (long long)(q_ok ? qi : 0) * q_rs) * a.ldq + h * DH + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 v = bf16x4_f32(*reinterpret_cast<const uint2*>(qp + c * 16));
+            qf[c] = q_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
         const float* qp = a.q + (q0 + (long long)qi * q_rs) * a.ldq + h * DH + 4 * g4;
 #pragma unroll
         for (int c = 0; c < NC; ++c) qf[c] = q_ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -77,22 +95,25 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
 #pragma unroll
     for (int c = 0; c < NC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    constexpr int PT = DB ? 2 * TK * F4 / 256 : 1;  // float4 per thread and tile (K + V) of the prefetch
+    // pieces per thread and tile (K + V) of the prefetch: 16 bytes each - four f32 values, or eight bf16 ones (IN16)
+    constexpr int VPP = IN16 ? 8 : 4, PPR = DH / VPP;  // values per piece, pieces per row
+    constexpr int PT = DB ? 2 * TK * PPR / 256 : 1;
     float4 st[PT];
     // round 5: this kernel's time is its SIMD issue time - PMC: the f32 MFMA busy 50 % of the SIMD cycles and 1 066 VALU instructions per
     // wave, which do not overlap it on gfx950 (profiles/r05_attention_ring.txt) - so the prefetch keeps a pointer per piece and advances it
     // by the tile's stride (the 64-bit row products, quarter-rate multiplies, left the loop) and whole tiles load without the row test
-    const float* fp[PT];
+    const char* fp[PT];
     int fr[PT];
+    constexpr int ES = IN16 ? 2 : 4;  // bytes per stored value
     if constexpr (DB) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const int e = tid + 256 * j, which = e / (TK * F4), r = (e % (TK * F4)) / F4, c4 = e % F4;
+            const int e = tid + 256 * j, which = e / (TK * PPR), r = (e % (TK * PPR)) / PPR, cp = e % PPR;
             fr[j] = r;
-            fp[j] = which ? a.v + (k0 + (long long)r * k_rs) * a.ldv + h * DH + c4 * 4 : a.k + (k0 + (long long)r * k_rs) * a.ldk + h * DH + c4 * 4;
+            fp[j] = reinterpret_cast<const char*>(which ? a.v : a.k) + ((k0 + (long long)r * k_rs) * (which ? a.ldv : a.ldk) + h * DH + cp * VPP) * ES;
         }
     }
-    const long long fstep_k = (long long)TK * k_rs * a.ldk, fstep_v = (long long)TK * k_rs * a.ldv;  // wave-uniform
+    const long long fstep_k = (long long)TK * k_rs * a.ldk * ES, fstep_v = (long long)TK * k_rs * a.ldv * ES;  // wave-uniform, bytes
     auto fetch = [&](int kt0) {
         if (kt0 + TK <= Sk) {  // a whole tile (block-uniform)
 #pragma unroll
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
             }
         }
 #pragma unroll
-        for (int j = 0; j < PT; ++j) fp[j] += (tid + 256 * j) / (TK * F4) ? fstep_v : fstep_k;
+        for (int j = 0; j < PT; ++j) fp[j] += (tid + 256 * j) / (TK * PPR) ? fstep_v : fstep_k;
     };
     if (DB) fetch(0);
     int it = 0;
@@ -117,8 +138,15 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
             Vs = Ks + TK * LDK;
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
-                const int e = tid + 256 * j, which = e / (TK * F4), r = (e % (TK * F4)) / F4, c4 = e % F4;
-                *reinterpret_cast<float4*>(&(which ? Vs : Ks)[r * LDK + c4 * 4]) = st[j];
+                const int e = tid + 256 * j, which = e / (TK * PPR), r = (e % (TK * PPR)) / PPR, cp = e % PPR;
+                float* dst = &(which ? Vs : Ks)[r * LDK + cp * VPP];
+                if constexpr (IN16) {
+                    const uint4 w = __builtin_bit_cast(uint4, st[j]);
+                    *reinterpret_cast<float4*>(dst) = bf16x4_f32(make_uint2(w.x, w.y));
+                    *reinterpret_cast<float4*>(dst + 4) = bf16x4_f32(make_uint2(w.z, w.w));
+                } else {
+                    *reinterpret_cast<float4*>(dst) = st[j];
+                }
             }
             __syncthreads();
             if (kt0 + TK < Sk) fetch(kt0 + TK);
@@ -220,9 +248,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_f32_simple_kernel(const AttnS
     }
     float* op = a.o + (q0 + (long long)qi * q_rs) * a.ldo + h * DH;
     if (!a.o_sp16) {
+        if (!(TR && a.o_skip_f32)) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-            *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+            for (int c = 0; c < NC; ++c)
+                *reinterpret_cast<float4*>(op + 4 * g4 + c * 16) = make_float4(oacc[c][0] * inv, oacc[c][1] * inv, oacc[c][2] * inv, oacc[c][3] * inv);
+        }
         if constexpr (TR) {
             if (a.o_cast) {  // the out-projection's operand cast of the same values (uniform branch)
                 const long long eo = (q0 + (long long)qi * q_rs) * a.ldo + h * DH;  // element offset of this row's head slice
@@ -788,6 +818,12 @@ int launch_s(const AttnSArgs& a0, hipStream_t s) {
     const long long blocks = (long long)a.G * a.H * a.nqb;
     SOLA_ARG(blocks < (1ll << 31), "attention: grid too large");
     a.xcd_remap = (g_attn_simple_remap && blocks % 8 == 0) ? 1 : 0;
+    if (a.in_bf16) {  // training forward on bf16 q / k / v
+        const size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
+        hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, 16, true, true, true>), dim3((unsigned)blocks), dim3(256), lds2, s, a);
+        SOLA_LAUNCH_CHECK();
+        return SOLA_OK;
+    }
     if (a.lse || a.drop.enabled) {  // training forward
         const size_t lds2 = (size_t)2 * 2 * 16 * (DH + 4) * sizeof(float);
         hipLaunchKernelGGL((attn_fwd_f32_simple_kernel<DH, 16, true, true>), dim3((unsigned)blocks), dim3(256), lds2, s, a);
@@ -829,6 +865,7 @@ static AttnSArgs make_sargs(const AttnDesc& d) {
     a.lse = d.lse;
     a.drop = d.drop;
     a.o_cast = nullptr; a.o_side = nullptr; a.o_cast_fmt = 0;  // launch_attention_simple's training instantiation takes them
+    a.in_bf16 = 0; a.o_skip_f32 = 0;
     return a;
 }
 
@@ -852,13 +889,24 @@ bool attention_simple_supported(const AttnDesc& d) {
     if ((d.lse || d.drop.enabled) && (!g_attn_simple_train || d.o_sp16)) return false;
     return !d.in_sp16 && (d.Sq > 16 || d.Sk > 16) && (d.DH == 128 || d.DH == 64);
 }
+// bfloat16 q / k / v (AttnDesc::in_bf16): this file's training instantiation takes them - f32 output or bf16 cast only, 8-value-aligned rows
+bool attention_in_bf16_supported(const AttnDesc& d) {
+    return g_attn_simple_train && !d.o_sp16 && !d.in_sp16 && !d.k_private && (d.Sq > 16 || d.Sk > 16) && (d.DH == 128 || d.DH == 64) &&
+           d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0;
+}
 void sola_attn_set_simple_train(int v) { g_attn_simple_train = v; }
 
 int launch_attention_simple(const AttnDesc& d, hipStream_t s) {
     AttnSArgs a = make_sargs(d);
-    if (d.o_cast && d.o_cast_done && (d.lse || d.drop.enabled) && !d.o_sp16 && d.ldo % 8 == 0) {  // the TR instantiation runs (launch_s)
+    if (d.o_cast && d.o_cast_done && (d.lse || d.drop.enabled || d.in_bf16) && !d.o_sp16 && d.ldo % 8 == 0) {  // the TR instantiation runs (launch_s)
         a.o_cast = d.o_cast; a.o_side = d.o_cast_fmt == 1 ? d.o_side : nullptr; a.o_cast_fmt = d.o_cast_fmt;
         *d.o_cast_done = true;
+    }
+    a.in_bf16 = d.in_bf16;
+    if (d.in_bf16) {
+        SOLA_ARG(attention_in_bf16_supported(d), "attention: bf16 q / k / v need the high-occupancy training shape (more than 16 queries or keys, head_dim 64 / 128, pitches %% 8 == 0)");
+        a.o_skip_f32 = d.o == nullptr;
+        SOLA_ARG(d.o || a.o_cast, "attention: no output");
     }
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 4.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

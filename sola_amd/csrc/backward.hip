@@ -320,10 +320,32 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     const float* cast_src = nullptr;  // the matrix whose cast "dy_sp" holds (fused pass), its pitch and columns
     int cast_ld = 0, cast_cols = 0;
     const size_t dy_sp_halfs = split ? 2 * (size_t)std::max(M, BW) * 3 * D : 0;
-    auto stats = [&](const float* dY, int ld, int rows, int cols, int slot, float** sc_out, bool may_cast = true) -> int {
+    // round 6 (SolaCtx::qkv16): a site whose attention backward wrote dq / dk / dv as bfloat16 rows itself.  [M][3D] lands at the start of
+    // "dy_sp" - exactly where the fused statistics pass would have put its cast, so everything downstream of it is unchanged - and the
+    // object -> language site's [BW][2D] key / value gradients in the buffer's second half (kv_*: their own record, the dX GEMM of dq
+    // still reads the first half when they are consumed)
+    extern int g_train_bf16_store;
+    const bool gn16 = split && pure && bf && g_train_bf16_store && g_bwd_fused_bf16_cast && g_bwd_dual_cast && D % 8 == 0;  // norms write their bf16 dx
+    unsigned short* const dy16 = split ? reinterpret_cast<unsigned short*>(ar.get("dy_sp")) : nullptr;
+    unsigned short* const kv16 = split ? dy16 + dy_sp_halfs / 2 : nullptr;
+    const float* kv_src = nullptr;  // the [BW][2D] matrix whose bf16 rows kv16 holds
+    // ready16: the producer already wrote dY's bfloat16 rows (same pitch) there - only the slab column sums are taken, from the 2-byte rows
+    auto stats = [&](const float* dY, int ld, int rows, int cols, int slot, float** sc_out, bool may_cast = true, const void* ready16 = nullptr) -> int {
         *sc_out = nullptr;
         if (may_cast) cast_src = nullptr;
         if (!split || cols % 4 || ld % 4) return SOLA_OK;
+        if (ready16) {
+            (void)slot;
+            SOLA_ARG(16 + 2 * (stat_calls + 1) <= scal_floats, "backward: more gradient-statistics passes (%d) than scale slots", stat_calls + 1);
+            float* sc = ar.get("scal") + 16 + 2 * stat_calls++;
+            SOLA_TRY(launch_colsum_slabs_bf16(ready16, ld, rows, cols, sc, cpart, s));
+            if (ready16 == dy16) { cast_src = dY; cast_ld = ld; cast_cols = cols; }
+            else kv_src = dY;
+            cpart_cols = cols;
+            cpart_slabs = (rows + 63) / 64;
+            *sc_out = sc;
+            return SOLA_OK;
+        }
         // every call takes the next pair of the slots behind the 16 fixed ones: they were zeroed by ONE memset when the call began (a
         // memset of 8 bytes per gradient matrix was 20 launches of ~5 us per step)
         (void)slot;
@@ -366,6 +388,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (dy_rm_done && sc && g_bwd_dual_cast) {
                 d.a_rm = ar.get("dy_sp"); d.a_rm_ld = ldy;
                 d.a_rm_ready = cast_src && cast_src == g[0].dY && cast_ld == ldy && (g[n - 1].dY - g[0].dY) + n_out <= cast_cols;
+            }
+            if (kv_src && kv_src == g[0].dY && sc) {  // the attention backward's own bf16 rows of the key / value gradients
+                d.a_rm = reinterpret_cast<float*>(kv16); d.a_rm_ld = ldy; d.a_rm_ready = 1;
             }
             d.nprob = n; d.M = rows; d.N = n_out; d.K = k_in; d.lda = ldy; d.ldb = ldx;
             for (int j = 0; j < n; ++j) {
@@ -411,7 +436,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             // dY is cast with a data-dependent power-of-two scale (gradients sit mostly below the f16 normal range), the
             // transposed weights with the fixed 2^6; the epilogue undoes both
             float* scal = sc ? sc : ar.get("scal");
-            if (cast_done && sc) {
+            if (kv_src && kv_src == dY - col_off && sc) {
+                d.p[0].A = reinterpret_cast<const float*>(kv16 + col_off);
+                d.lda = ldy;
+            } else if (cast_done && sc) {
                 d.p[0].A = pure ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(ar.get("dy_sp")) + col_off) : ar.get("dy_sp") + col_off;
                 d.lda = ldy;
             } else {
@@ -443,12 +471,15 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     };
     ColsumPairGroupDesc gn_q{};
     float* gn_keep = (group && ar.off.count("gnkeep")) ? ar.get("gnkeep") : nullptr;
+    // dx16 (round 6, bf16 steps): the norm's input gradient once more as bfloat16 rows - the consumer GEMMs' operand, written here instead of
+    // by a statistics-and-cast pass that read the f32 matrix back (launch_cast_bf16_colsum); the f32 rows stay (residual stream)
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
-                      int leaky, const DropoutCfg* drop, const int4* units = nullptr) -> int {
+                      int leaky, const DropoutCfg* drop, const int4* units = nullptr, void* dx16 = nullptr) -> int {
         GroupNormBwdDesc d{};
         if (drop) d.drop = *drop;
         d.units = units;
+        d.dx16 = dx16;
         d.x = xpre; d.dy = dy; d.dy2 = dy2; d.gamma = W(wname + ".weight"); d.beta = W(wname + ".bias"); d.dx = dx;
         d.dgamma_part = ar.get("gpart"); d.dbeta_part = ar.get("bpart");
         d.n_inst = n_inst; d.inner = inner; d.outer_stride = outer; d.inner_stride = inner_stride; d.tok_stride = tok_stride;
@@ -515,7 +546,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         auto out_proj_bwd = [&](int a) -> int {
             const std::string an = lp + kAttnLong[a];
             float* sc;
-            SOLA_TRY(stats(dres, D, M, D, 2, &sc));
+            SOLA_TRY(stats(dres, D, M, D, 2, &sc, true, gn16 ? dy16 : nullptr));  // gn16: the norm's backward in front of this wrote the bf16 rows
             if (sc) SOLA_TRY(bias_from_stats(0, D, G(an + ".out_proj.bias")));
             const WG wo[1] = {{dres, ab(a, "attn"), G(an + ".out_proj.weight"), G(an + ".out_proj.bias")}};
             bool rm;
@@ -531,7 +562,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "object2lang_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); dlkv = keep((size_t)BW * 2 * D); }
             SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, max_rows_smp, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr));
             SOLA_TRY(out_proj_bwd(2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
@@ -542,17 +573,19 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             ad.part = ar.get("attn_part");
             ad.part_floats = attention_bwd_part_floats((long long)M, B, H, 64);
             ad.part_rows = (long long)M;
+            const bool s16 = split && (size_t)l * 3 + 2 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 2];
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = kv16; ad.dv16 = kv16 + D; kv_src = nullptr; cast_src = nullptr; }
             SOLA_TRY(wait_side(1));  // dqkv / dlkv: the previous sub-block's weight gradients have read them
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
             float *scq, *sckv;
-            SOLA_TRY(stats(dqkv, 3 * D, M, D, 4, &scq));
+            SOLA_TRY(stats(dqkv, 3 * D, M, D, 4, &scq, true, s16 ? dy16 : nullptr));
             if (scq) SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
             const WG wq[1] = {{dqkv, x_mot, G(an + ".q_proj.weight"), G(an + ".q_proj.bias")}};
             bool rmq;
             SOLA_TRY(dw_begin());
             SOLA_TRY(grad_w_many(wq, 1, 3 * D, D, M, D, D, scq, scq != nullptr, &rmq));
-            SOLA_TRY(stats(dlkv, 2 * D, BW, 2 * D, 6, &sckv, false));  // no fused cast: "dy_sp" holds dq's for the dX GEMM below
+            SOLA_TRY(stats(dlkv, 2 * D, BW, 2 * D, 6, &sckv, false, s16 ? kv16 : nullptr));  // no fused cast: "dy_sp" holds dq's for the dX GEMM below
             if (sckv) {
                 SOLA_TRY(bias_from_stats(0, D, G(an + ".k_proj.bias")));
                 SOLA_TRY(bias_from_stats(D, D, G(an + ".v_proj.bias")));
@@ -566,6 +599,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, 2 * D, D));
             SOLA_TRY(grad_x(dlkv, 2 * D, BW, 2 * D, D, dlang_init ? dlang : nullptr, dlang, sckv));  // accumulate over layers
+            kv_src = nullptr;
             dlang_init = true;
             cur = 1 - cur;
         }
@@ -574,19 +608,21 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "motion_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, R, 1, Tp, 0, 1, Tp, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr, gn16 ? dy16 : nullptr));
             SOLA_TRY(out_proj_bwd(1));
             AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
                            R, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
             if (rt) ad.q_units = rt->u_strk;
             ad.drop = c->attn_drop(l, 1);
+            const bool s16 = split && (size_t)l * 3 + 1 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 1];
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; }
             SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
             const float* x_obj = fb(ls + "_obj");
             float* sc3;
-            SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3));
+            SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3, true, s16 ? dy16 : nullptr));
             if (sc3) {
                 SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
                 SOLA_TRY(bias_from_stats(D, D, G(an + ".k_proj.bias")));
@@ -611,17 +647,19 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "obj_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr));
             SOLA_TRY(out_proj_bwd(0));
             AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
                            n_bt, H, DH, N, N, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
             if (rt) ad.q_units = rt->u_st;
             ad.drop = c->attn_drop(l, 0);
+            const bool s16 = split && (size_t)l * 3 + 0 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 0];
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; }
             SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             float* sc3;
-            SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3));
+            SOLA_TRY(stats(dqkv, 3 * D, M, 3 * D, 4, &sc3, true, s16 ? dy16 : nullptr));
             if (sc3) {
                 SOLA_TRY(bias_from_stats(0, D, G(an + ".q_proj.bias")));
                 SOLA_TRY(bias_from_stats(D, D, G(an + ".k_proj.bias")));
@@ -669,6 +707,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             o += (size_t)c->conv[i].cout * c->conv[i].cin * c->conv[i].k;
         }
     }
+    bool enc_dy16 = false;  // the current stage's dy also sits in "dy_sp" as bfloat16 rows (written by the norm backward that produced it)
     for (int i = 5; i >= 0; --i) {
         const ConvGeom& g = c->conv[i];
         const std::string cp = "short_motion_encoder." + std::to_string(kConvIdx[i]);
@@ -681,7 +720,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         float* scc = nullptr;  // scale slot of this layer's dY (shared by its dW and dX GEMMs)
         if (split && ar.off.count("tns") && gemm_tn_split_supported(rows, g.cout, g.k * g.cin) &&
             ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes(rows, g.cout, g.k * g.cin, 1)) {
-            SOLA_TRY(stats(dy, g.cout, rows, g.cout, 8, &scc));
+            SOLA_TRY(stats(dy, g.cout, rows, g.cout, 8, &scc, true, enc_dy16 ? dy16 : nullptr));
             GemmTnSplitDesc d{};
             d.scal = scc; d.pure = pure ? 1 + bf : (dw16 ? 1 : 0); d.rm_split = dw16 ? 1 : 0;
             d.nprob = 1; d.A[0] = dy; d.B[0] = i == 0 ? c->last_obj : x_in; d.C[0] = dwstd + ws_off[i];
@@ -780,8 +819,13 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         const std::string np = "short_motion_encoder." + std::to_string(kNormIdx[i - 1]);
         const DropoutCfg edrop = c->enc_drop(i - 1);
         if (group) enc[1] = keep((size_t)rows_in * g.cin);  // conv i-1's dY: read again by its deferred weight gradient
+        // the next stage's statistics pass finds the bf16 rows ready when they fit "dy_sp", the pitch is 16-byte aligned and that stage takes
+        // the 16-bit dW route (the conditions of the statistics call at the top of the loop)
+        enc_dy16 = gn16 && g.cin % 8 == 0 && (size_t)rows_in * g.cin <= dy_sp_halfs && ar.off.count("tns") &&
+                   gemm_tn_split_supported((int)rows_in, g.cin, c->conv[i - 1].k * c->conv[i - 1].cin) &&
+                   ar.total - ar.off.at("tns") >= gemm_tn_split_scratch_bytes((int)rows_in, g.cin, c->conv[i - 1].k * c->conv[i - 1].cin, 1);
         SOLA_TRY(gn_bwd(fb("conv" + std::to_string(i - 1)), dact, nullptr, np, enc[1], R, 1, t_in, 0, 1, t_in, g.cin,
-                        c->cfg.n_groups, 1, &edrop, rt ? rt->u_lvl[i] : nullptr));
+                        c->cfg.n_groups, 1, &edrop, rt ? rt->u_lvl[i] : nullptr, enc_dy16 ? dy16 : nullptr));
         dy = enc[1];  // dact (enc[0]) is consumed; the next stage's dX may overwrite it, its GN backward overwrites enc[1]
     }
     // weight-standardisation backward for all six convs

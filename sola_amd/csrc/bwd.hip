@@ -19,7 +19,17 @@ struct GnBwdArgs {
     int leaky;
     DropoutCfg drop;
     const int4* units;  // ragged batches: (first row, row stride, token count, -) per instance (GroupNormBwdDesc::units)
+    unsigned short* dx16;  // optional (round 6): dx once more as bfloat16 rows of the same pitch - the operand of the GEMMs that consume it
 };
+__device__ __forceinline__ void gn_store_dx(const GnBwdArgs& a, long long off, float4 o) {
+    *reinterpret_cast<float4*>(a.dx + off) = o;
+    if (a.dx16) {
+        typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+        bf4 b;
+        b[0] = (__bf16)o.x; b[1] = (__bf16)o.y; b[2] = (__bf16)o.z; b[3] = (__bf16)o.w;
+        *reinterpret_cast<bf4*>(a.dx16 + off) = b;
+    }
+}
 
 // token set of instance `inst` (norm.hip: gn_unit)
 struct GnBwdUnit { long long row0, tok_stride; int ntok; };
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
         o.y = rstd * (d.y * ga.y - m1 - xh.y * m2);
         o.z = rstd * (d.z * ga.z - m1 - xh.z * m2);
         o.w = rstd * (d.w * ga.w - m1 - xh.w * m2);
-        *reinterpret_cast<float4*>(a.dx + off) = o;
+        gn_store_dx(a, off, o);
     }
 }
 
@@ -285,8 +295,8 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
         const int t = tl + r * tpp;
         if (t < ntok) {
             const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-            *reinterpret_cast<float4*>(a.dx + off) = make_float4(rstd * (dv[r].x - m1 - xv[r].x * m2), rstd * (dv[r].y - m1 - xv[r].y * m2),
-                                                                 rstd * (dv[r].z - m1 - xv[r].z * m2), rstd * (dv[r].w - m1 - xv[r].w * m2));
+            gn_store_dx(a, off, make_float4(rstd * (dv[r].x - m1 - xv[r].x * m2), rstd * (dv[r].y - m1 - xv[r].y * m2),
+                                            rstd * (dv[r].z - m1 - xv[r].z * m2), rstd * (dv[r].w - m1 - xv[r].w * m2)));
         }
     }
 }
@@ -614,6 +624,7 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     a.x = d.x; a.dy = d.dy; a.dy2 = d.dy2; a.gamma = d.gamma; a.beta = d.beta; a.dx = d.dx; a.dgp = d.dgamma_part; a.dbp = d.dbeta_part;
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.units = d.units;
+    a.dx16 = static_cast<unsigned short*>(d.dx16);
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
     const int f4 = cg / 4;

@@ -120,6 +120,37 @@ __global__ __launch_bounds__(256) void cast_bf16_colsum_kernel(const float* __re
     *reinterpret_cast<float4*>(part + (slab * f4_per_row + c) * 4) = sum;
 }
 
+// Round 6 (bf16 storage of the step's gradients): the producer - the attention backward, a GroupNorm backward - has already written the
+// bfloat16 matrix; what is left of the statistics pass is the 64-row slab column sums (the bias gradients), read from the 2-byte rows: a
+// third of cast_bf16_colsum_kernel's bytes.  Same slabs and slot as that kernel; a lane owns eight columns (16 bytes per row).
+__global__ __launch_bounds__(256) void colsum_slabs_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ scal, float* __restrict__ part,
+                                                                long long rows, int c8_per_row, int ld_in) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const long long slab = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        scal[0] = 8192.f;
+        scal[1] = 1.f;
+    }
+    const long long r0 = slab * 64;
+    if (c >= c8_per_row || r0 >= rows) return;
+    const int nr = (int)min((long long)64, rows - r0);
+    const unsigned short* p = in + r0 * ld_in + (long long)c * 8;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int r = 0; r < nr; ++r, p += ld_in) {
+        const uint4 w = *reinterpret_cast<const uint4*>(p);
+        const unsigned u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sum[2 * j] += __builtin_bit_cast(float, u[j] << 16);
+            sum[2 * j + 1] += __builtin_bit_cast(float, u[j] & 0xffff0000u);
+        }
+    }
+    float* o = part + (slab * c8_per_row + c) * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+}
+
 // scale = 2^(13 - floor(log2(amax))): the largest magnitude lands in [2^13, 2^14), far from the f16 overflow at 65504
 __device__ __forceinline__ float auto_scale(unsigned amax_bits, int target = 13) {
     const int e = (int)(amax_bits >> 23) - 127;  // floor(log2(amax)) for normal floats
@@ -376,6 +407,16 @@ int launch_cast_bf16_colsum(const float* in, int ld_in, void* out, int ld_out, l
     const long long slabs = (rows + 63) / 64;
     hipLaunchKernelGGL(cast_bf16_colsum_kernel, dim3((unsigned)((K / 4 + 63) / 64), (unsigned)((slabs + 3) / 4)), dim3(256), 0, s, in,
                        reinterpret_cast<__bf16*>(out), scal, part, rows, K / 4, ld_in, ld_out);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
+int launch_colsum_slabs_bf16(const void* in, int ld_in, long long rows, int K, float* scal, float* part, hipStream_t s) {
+    SOLA_ARG(in && scal && part && rows > 0 && K > 0 && K % 8 == 0 && ld_in % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0, "colsum_slabs_bf16: K=%d ld_in=%d", K, ld_in);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 2.0 * rows * K);
+    const long long slabs = (rows + 63) / 64;
+    hipLaunchKernelGGL(colsum_slabs_bf16_kernel, dim3((unsigned)((K / 8 + 63) / 64), (unsigned)((slabs + 3) / 4)), dim3(256), 0, s,
+                       static_cast<const unsigned short*>(in), scal, part, rows, K / 8, ld_in);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

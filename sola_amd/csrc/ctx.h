@@ -75,6 +75,10 @@ struct SolaCtx {
     const float* last_obj = nullptr;  // input of the last training forward (conv0's weight gradient reads it)
     RagTables last_rag;               // last.rag: the unit tables that forward left in its workspace
     const void* last_ws = nullptr;    // workspace of the last forward (sola_backward_ragged checks it gets the same one)
+    // round 6, bf16 training step: attention site (layer * 3 + which) of the last training forward keeps its q / k / v as BFLOAT16 rows
+    // (written by the projection GEMM's epilogue, read by the attention forward and backward; the backward then writes dq / dk / dv as
+    // bfloat16 too - the dW / dX GEMMs' operand, no f32 copy, no cast pass).  Decided per site by the shapes the kernels take.
+    std::vector<char> qkv16;
     // inference precision: 0 = exact f32 MFMA; 1 = split-f16 operands, 3 x f16 MFMA with f32 accumulation (cast.hip).
     // ctx-owned split-f16 copies of the weights: standardised conv weights (same offsets as ws_buf) and the
     // 12 * n_layers linear weights pre-scaled by 64 (index (layer * 3 + attn) * 4 + proj, D*D floats each).

@@ -13,6 +13,7 @@ void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
 extern int g_train_dw_f16;
 int g_train_attn_cast = 1;  // sola_tune "train_attn_cast": 1 = f16 / bf16 operand steps: the training forward's attention kernels also write the out-projection's operand cast; 2 = the split-f16 step too
 void sola_train_set_attn_cast(int v) { g_train_attn_cast = v; }
+int g_train_bf16_store = 1;  // sola_tune "train_bf16_store": 1 = bf16 steps keep q / k / v (and the backward dq / dk / dv) as bfloat16 rows where the attention kernels take them (round 6)
 int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
@@ -301,8 +302,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
 
     // a5: alignment layers (module/module.py:22-52)
     const float scale = 1.0f / sqrtf((float)DH);
+    // c16: the outputs are written as BFLOAT16 rows (bf16 steps, sites whose attention kernels read them: site16 below)
     auto linear3 = [&](const float* a0, const float* a1, const float* a2, const std::string& attn, int nprob, int rows,
-                       float* o0, float* o1, float* o2, int first_proj, float* a_scal = nullptr) -> int {
+                       float* o0, float* o1, float* o2, int first_proj, float* a_scal = nullptr, bool c16 = false) -> int {
         static const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
         const float* as[3] = {a0, a1, a2};
         float* os[3] = {o0, o1, o2};
@@ -337,9 +339,33 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             }
             gd.arith = lowp_arith; gd.out_scale = 1.f; gd.bf16 = bf;
             if (a_scal) gd.out_scale_dev = a_scal + 1;
+            if (c16) gd.c_f16 = 1;
             pc_src[0] = pc_src[1] = nullptr;
         }
         return launch_gemm(gd, s);
+    };
+    // bf16 steps: does attention site `ad` keep q / k / v (forward) and dq / dk / dv (backward) as bfloat16 rows?  Both kernels must take
+    // the shape (attn_simple.hip's training instantiation; attn_bwd.hip's one-pass kernel)
+    c->qkv16.assign((size_t)c->cfg.n_layers * 3, 0);
+    auto site16 = [&](const AttnDesc& ad, bool o2l) -> bool {
+        if (!(train && split && pure && bf && g_train_bf16_store)) return false;
+        // the backward's dW products of these gradients must take the row-major 16-bit kernel (no f32 copy exists to transpose)
+        if (!gemm_tn_tr_supported(M, D, D, D, D) || (o2l && !gemm_tn_tr_supported((int)text_rows, D, D, D, D))) return false;
+        AttnDesc f = ad;
+        f.in_bf16 = 1;
+        if (!attention_in_bf16_supported(f)) return false;
+        AttnBwdDesc b{};
+        b.ldq = b.ldk = b.ldv = b.ldo = D;
+        b.ld_dq = 3 * D; b.ld_dk = b.ld_dv = o2l ? 2 * D : 3 * D;
+        b.G = ad.G; b.H = ad.H; b.DH = ad.DH; b.Sq = ad.Sq; b.Sk = ad.Sk; b.inner = ad.inner;
+        b.q_outer = ad.q_outer; b.q_inner = ad.q_inner; b.q_rs = ad.q_rs; b.k_outer = ad.k_outer; b.k_inner = ad.k_inner; b.k_rs = ad.k_rs;
+        b.q_units = ad.q_units; b.k_units = ad.k_units;
+        if (o2l) {  // what backward.hip hands the chunked launch
+            b.part = reinterpret_cast<float*>(1);
+            b.part_floats = attention_bwd_part_floats((long long)M, B, H, 64);
+            b.part_rows = (long long)M;
+        }
+        return attention_bwd_bf16_supported(b);
     };
     // The attention output's operand cast for the out-projection is written by the attention kernel itself where its shape can
     // (AttnDesc::o_cast, round 4; sola_tune "train_attn_cast" 0 = always the separate cast launch)
@@ -418,38 +444,47 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         float* x_mot = buf(ls + "_motion");
         float* x_o2l = buf(ls + "_o2l");
         // (i) inter-object attention over the N tracks of each (b, t'): module.py:31-35
-        SOLA_TRY(linear3(xin, xin, xin, lp + "obj_attn", 3, M, ab(0, "q"), ab(0, "k"), ab(0, "v"), 0));
         {
             AttnDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), D, D, D, D, B * Tp, H, DH, N, N, Tp,
                         (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale, lse(0)};
             if (rs) { ad.G = rt.sumTpS; ad.inner = 1; ad.q_units = rt.u_st; }
             if (train) ad.drop = c->attn_drop(l, 0);
+            const bool s16 = site16(ad, false);
+            SOLA_TRY(linear3(xin, xin, xin, lp + "obj_attn", 3, M, ab(0, "q"), ab(0, "k"), ab(0, "v"), 0, nullptr, s16));
+            ad.in_bf16 = s16 ? 1 : 0;
+            c->qkv16[(size_t)l * 3 + 0] = s16;
             SOLA_TRY(attention(ad));
         }
         SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
         if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st, x_pe, x_obj));
         else SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, nullptr, x_pe, x_obj));
         // (ii) motion attention over T' per track, PE on q and k only: module.py:38-43
-        SOLA_TRY(linear3(x_pe, x_pe, x_obj, lp + "motion_attn", 3, M, ab(1, "q"), ab(1, "k"), ab(1, "v"), 0));
         {
             AttnDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), D, D, D, D, B * N, H, DH, Tp, Tp, 1,
                         (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale, lse(1)};
             if (rs) { ad.G = rt.sumNS; ad.q_units = rt.u_strk; }
             if (train) ad.drop = c->attn_drop(l, 1);
+            const bool s16 = site16(ad, false);
+            SOLA_TRY(linear3(x_pe, x_pe, x_obj, lp + "motion_attn", 3, M, ab(1, "q"), ab(1, "k"), ab(1, "v"), 0, nullptr, s16));
+            ad.in_bf16 = s16 ? 1 : 0;
+            c->qkv16[(size_t)l * 3 + 1] = s16;
             SOLA_TRY(attention(ad));
         }
         SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
         if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk, x_mot));
         else SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp, nullptr, x_mot));
         // (iii) object -> language cross attention: module.py:46-50
-        SOLA_TRY(linear3(x_mot, nullptr, nullptr, lp + "object2lang_attn", 1, M, ab(2, "q"), nullptr, nullptr, 0));
-        SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, (int)text_rows, ab(2, "lk"), ab(2, "lv"), nullptr, 1,
-                         split ? c->scal_pair(1) : nullptr));
         {
             AttnDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
                         (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale, lse(2)};
             if (rs) { ad.Sq = rt.maxRowsSample; ad.q_units = rt.u_smp; ad.k_units = rt.u_langk; }
             if (train) ad.drop = c->attn_drop(l, 2);
+            const bool s16 = site16(ad, true);
+            SOLA_TRY(linear3(x_mot, nullptr, nullptr, lp + "object2lang_attn", 1, M, ab(2, "q"), nullptr, nullptr, 0, nullptr, s16));
+            SOLA_TRY(linear3(buf("lang"), buf("lang"), nullptr, lp + "object2lang_attn", 2, (int)text_rows, ab(2, "lk"), ab(2, "lv"), nullptr, 1,
+                             split ? c->scal_pair(1) : nullptr, s16));
+            ad.in_bf16 = s16 ? 1 : 0;
+            c->qkv16[(size_t)l * 3 + 2] = s16;
             SOLA_TRY(attention(ad));
         }
         SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));

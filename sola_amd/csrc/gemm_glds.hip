@@ -73,6 +73,26 @@ __device__ __forceinline__ void guard_sp16x4(int* guard, const float (&v)[4]) {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+// 16-bit outputs / residuals of the PURE kernels: _Float16, or bfloat16 when the operands are (GemmDesc::bf16 with c_f16 / r_f16: the bf16
+// STORAGE of the training step, round 6).  Four values as one 8-byte word.
+typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4 cvt16x4_out(const float (&v)[4], bool bf) {
+    if (bf) {
+        bf16x4g b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (__bf16)v[e];
+        return __builtin_bit_cast(half4, b);
+    }
+    half4 hh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+    return hh;
+}
+__device__ __forceinline__ float cvt16_in(_Float16 h, bool bf) {
+    if (bf) return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+    return (float)h;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -138,7 +158,7 @@ __device__ __forceinline__ void glds_tile_epilogue(const GldsArgs& a, const Gemm
                     const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < a.N) v[e] += (float)rb[e];
+                        if (n + e < a.N) v[e] += cvt16_in(rb[e], a.bf16 != 0);
                 } else if (a.r_sp16) {
                     // 4 consecutive columns sit in one 8-wide block: hi[4] and lo[4] are two aligned 8-byte loads
                     const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
@@ -162,11 +182,8 @@ __device__ __forceinline__ void glds_tile_epilogue(const GldsArgs& a, const Gemm
             }
             if (a.c_f16) {
                 if (n >= a.N) continue;  // N % 4 == 0: the four columns are in range together
-                half4 hh;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * a.ldc + n) = hh;
-                guard_sp16x4(a.guard, v);
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * a.ldc + n) = cvt16x4_out(v, a.bf16 != 0);
+                if (!a.bf16) guard_sp16x4(a.guard, v);
             } else if (a.c_sp16) {
                 if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
                 // 4 consecutive columns of one 8-wide block: hi[4] and lo[4] leave as two aligned 8-byte stores
@@ -1456,7 +1473,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                             if (RMODE == 3) {
                                 const half4 hh = __builtin_bit_cast(half4, float2{rv[0], rv[1]});
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)hh[e];
+                                for (int e = 0; e < 4; ++e) v[e] += cvt16_in(hh[e], PURE == 2);
                             } else if (RMODE == 2) {
                                 const half4 hh = __builtin_bit_cast(half4, float2{rv[0], rv[1]}), ll = __builtin_bit_cast(half4, float2{rv[2], rv[3]});
 #pragma unroll
@@ -1467,12 +1484,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                             }
                         }
                         if (CSP == 2) {
-                            half4 hh;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
+                            const half4 hh = cvt16x4_out(v, PURE == 2);
                             if (a.ablate & 8) asm volatile("" ::"v"(hh)); else
                             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = hh;
-                            note_range(v);
+                            if (PURE != 2) note_range(v);
                         } else if (CSP == 1) {
                             _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
                             half4 hh, ll;
@@ -1524,7 +1539,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                             const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R) + (long long)m * a.ldr + n;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (n + e < a.N) v[e] += (float)rb[e];
+                                if (n + e < a.N) v[e] += cvt16_in(rb[e], PURE == 2);
                         } else if (RMODE == 2) {
                             const _Float16* rb = reinterpret_cast<const _Float16*>(pr.R + (long long)m * a.ldr + (n & ~7)) + (n & 4);
                             if (n + 3 < a.N) {
@@ -1547,11 +1562,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
                     }
                     if (CSP == 2) {
                         if (n >= a.N) continue;  // N % 4 == 0: the four columns are in range together
-                        half4 hh;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hh[e] = (_Float16)v[e];
-                        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = hh;
-                        guard_sp16x4(a.guard, v);
+                        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(pr.C) + (long long)m * ldc + n) = cvt16x4_out(v, PURE == 2);
+                        if (PURE != 2) guard_sp16x4(a.guard, v);
                     } else if (CSP == 1) {
                         if (n >= a.N) continue;  // N % 8 == 0 and n % 4 == 0: the four columns are in range together
                         _Float16* cb = reinterpret_cast<_Float16*>(pr.C + (long long)m * ldc + (n & ~7)) + (n & 4);
@@ -2142,8 +2154,13 @@ static int launch_persist(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
 template <bool CONV>
 static int launch_persist_pure(GldsArgs& a, int M, int N, int nprob, hipStream_t s) {
     const bool has_r = a.p[0].R != nullptr;
-    if (a.bf16) {  // bf16 operands (training with bf16 GEMM operands, BASELINE config C2): f32 outputs / residuals only
+    if (a.bf16) {  // bf16 operands (training with bf16 GEMM operands, BASELINE config C2): f32 outputs / residuals, or - round 6, the
+        // step's 16-bit storage - bf16 outputs (with a bf16 residual)
         if (a.ksplit > 1) return launch_persist_t<CONV, 0, 0, 2>(a, M, N, nprob, s);
+        if (a.c_f16) {
+            if (CONV || !has_r) return launch_persist_t<CONV, 0, 2, 2>(a, M, N, nprob, s);
+            return launch_persist_t<false, 3, 2, 2>(a, M, N, nprob, s);
+        }
         if (has_r && !CONV) return launch_persist_t<false, 1, 0, 2>(a, M, N, nprob, s);
         return launch_persist_t<CONV, 0, 0, 2>(a, M, N, nprob, s);
     }
@@ -2213,7 +2230,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
         a.K = d.K / 2; a.lda = d.lda / 2; a.Cin = d.Cin / 2;
         a.r_f16 = d.r_f16; a.c_f16 = d.c_f16;
         a.bf16 = d.bf16 ? 1 : 0;
-        SOLA_ARG(!(a.bf16 && (a.r_f16 || a.c_f16)), "gemm: bf16 operands go with f32 outputs and residuals (training); the 16-bit STORAGE mode is f16");
+        SOLA_ARG(!(a.bf16 && a.r_f16 && !a.c_f16), "gemm: a bf16 residual goes with a bf16 output");
     }
     a.rowmap = d.conv == 1 ? d.rowmap : nullptr;
     a.out_scale = d.out_scale != 0.f ? d.out_scale : 1.f;

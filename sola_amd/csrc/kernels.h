@@ -188,6 +188,8 @@ struct AttnDesc {
     DropoutCfg drop;  // on the probabilities (tools/attention.py:71)
     int o_sp16;       // output as split-f16 pairs
     int in_sp16;      // q, k, v are split-f16 rows (written by a GEMM with c_sp16); not for sequences of <= 16 steps
+    int in_bf16 = 0;  // round 6: q, k, v are BFLOAT16 rows (ldq / ldk / ldv in values; a GEMM with bf16 + c_f16 wrote them) - the training
+                      // step's bf16 storage; check attention_in_bf16_supported().  o may then be null: only the o_cast copy is written
     int* guard;       // o_sp16, optional: range guard word (see GemmDesc::guard)
     // optional, ragged batches: group g attends q_units[g] = (first row, row stride, Sq_g, -) over k_units[g] = (first row,
     // row stride, Sk_g, -); Sq / Sk are then the LARGEST lengths (they select the kernel shape and size the LDS)
@@ -211,6 +213,7 @@ struct AttnDesc {
     bool* o_cast_done = nullptr;
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
+bool attention_in_bf16_supported(const AttnDesc& d);
 bool attention_shared_keys_supported(const AttnDesc& d);  // d.k_private / k_shared_row can be honoured (the launch then takes attn_res.hip's shape)
 
 struct AttnBwdDesc {
@@ -233,8 +236,14 @@ struct AttnBwdDesc {
     float* part = nullptr;
     size_t part_floats = 0;
     long long part_rows = 0;
+    // round 6, the training step's bf16 storage (check attention_bwd_bf16_supported): q, k, v are BFLOAT16 rows (ldq / ldk / ldv in values)
+    // and the gradients leave as bfloat16 rows dq16 / dk16 / dv16 (pitches ld_dq / ld_dk / ld_dv, in values); dq (f32, same pitch) is
+    // scratch for units whose keys exceed one key group
+    int io_bf16 = 0;
+    void *dq16 = nullptr, *dk16 = nullptr, *dv16 = nullptr;
 };
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);
+bool attention_bwd_bf16_supported(const AttnBwdDesc& d);
 size_t attention_bwd_part_floats(long long q_rows, int G, int H, int Sk);
 
 // ---- backward of the elementwise / reduction stages (bwd.hip) -------------------------------------------------
@@ -255,6 +264,7 @@ struct GroupNormBwdDesc {
     // optional, ragged batches: instance i covers units[i] = (first row, row stride, token count, -) (GroupNormDesc::units);
     // ntok is then the LARGEST token count (it selects the kernel shape)
     const int4* units;
+    void* dx16 = nullptr;  // optional (round 6, bf16 steps): dx once more as bfloat16 rows, same pitch (C values)
 };
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
 struct WsBwdLayer {
@@ -360,6 +370,8 @@ int launch_amax_accumulate(const float* in, int ld_in, long long rows, int K, fl
 int launch_amax_colsum(const float* in, int ld_in, long long rows, int K, float* scal, float* part, hipStream_t s);
 // bf16 mode: one read leaves the unscaled row-major bf16 cast [rows][ld_out] + amax_colsum's slab sums; scal <- {2^13, 1} (scale 1)
 int launch_cast_bf16_colsum(const float* in, int ld_in, void* out, int ld_out, long long rows, int K, float* scal, float* part, hipStream_t s);
+// the slab column sums alone, from a bfloat16 matrix its producer already wrote (round 6; same `part` layout and scale slot)
+int launch_colsum_slabs_bf16(const void* in, int ld_in, long long rows, int K, float* scal, float* part, hipStream_t s);
 // the cast half of launch_cast_sp16_auto: scal[0] already holds max|in|
 int launch_cast_sp16_scaled(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);
 int launch_cast_sp16_auto(const float* in, int ld_in, float* out, int ld_out, long long rows, int K, float* scal, hipStream_t s);

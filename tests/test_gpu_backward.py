@@ -521,13 +521,16 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_gradients_bit_for_
     """Round 5, bf16 storage: bfloat16 has f32's exponent range, so the backward's pass over a gradient matrix (bias sums) also writes
     its UNSCALED bf16 cast - no max|x| in front, no second read by the casts of the dW / dX GEMMs (sola_tune "bwd_fused_bf16_cast",
     default 1).  The two-pass path scales by a power of two before rounding and undoes it behind the f32 accumulation: the same
-    products, so every gradient must keep its bits with the switch off."""
+    products, so every gradient must keep its bits with the switch off.  (Round 6: with the step's bf16 STORAGE on, the producers write the
+    bfloat16 rows themselves and the bias sums are taken from those rounded rows - as autocast's grad_output.sum(0) is - so this A/B of
+    the pass runs with sola_tune "train_bf16_store" 0.)"""
     from sola_amd import _lib
     m, _ = full_model
     cfg = synth.DEFAULT_MODEL_CFG
     got = {}
     try:
         m.precision = "bf16"
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 0), "tune")
         for fused in (1, 0):
             _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", fused), "tune")
             _, l3, g = train_step_grads(m, cfg, 8, 40, 32, 10, 77)
@@ -535,6 +538,7 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_gradients_bit_for_
     finally:
         m.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad

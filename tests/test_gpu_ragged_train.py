@@ -248,11 +248,13 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
 def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_ragged_gradients_bit_for_bit(full):
     """Round 5 (tests/test_gpu_backward.py has the uniform-batch twin): in the bf16 step the pass over a gradient matrix that takes its
     bias sums writes its unscaled bf16 cast too (sola_tune "bwd_fused_bf16_cast" 1, the default) - against the two-pass path (max|x| +
-    sums, then power-of-two-scaled casts): the same loss, every gradient bit for bit, on a ragged batch."""
+    sums, then power-of-two-scaled casts): the same loss, every gradient bit for bit, on a ragged batch.  (With sola_tune
+    "train_bf16_store" 0: round 6's storage mode takes the bias sums from the producers' rounded bf16 rows.)"""
     cfg = synth.DEFAULT_MODEL_CFG
     full.precision = "bf16"
     got = {}
     try:
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 0), "tune")
         samples = [sample_inputs(cfg, N, T, L, 450 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
         for fused in (1, 0):
             _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", fused), "tune")
@@ -261,6 +263,7 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_ragged_gradients_b
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -305,6 +308,9 @@ def test_row_major_weight_gradient_route_equals_the_transposed_copy_route_on_a_r
     full.precision = precision
     got = {}
     try:
+        # (round 6: the bf16 step's q / k / v storage exists on the row-major route only - there is no f32 gradient to transpose - so it is
+        # switched off for this A/B of the two dW routes on the SAME operand values)
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 0), "tune")
         samples = [sample_inputs(cfg, N, T, L, 500 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
         for route in (1, 0):
             _lib.check(_lib.lib().sola_tune(b"train_tn_tr", route), "tune")
@@ -314,6 +320,7 @@ def test_row_major_weight_gradient_route_equals_the_transposed_copy_route_on_a_r
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
     worst = max((float((got[1][k].double() - got[0][k].double()).norm()) / (float(got[0][k].double().norm()) + 1e-30), k) for k in got[0])
     print("row-major vs transposed-copy dW route, worst tensor:", worst)
     assert worst[0] < 2e-5, worst
