@@ -326,7 +326,9 @@ int launch_cast_f16(const float* in, int ld_in, void* out, int ld_out, long long
     SolaProfScope prof(SOLA_PROF_MISC, s, 0, (scal ? 10.0 : 6.0) * rows * K);
     if (scal) {
         SOLA_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(float), s));
-        {
+        // bfloat16 has f32's exponent range: no max|x| pass - the zeroed slot reads as "scale 1" (auto_scale(0)), the same bits as any
+        // power-of-two scale would give, one read of the matrix less (round 6)
+        if (!bf16) {
             long long ar = rows; int ak = K, ald = ld_in;
             amax_shape(ar, ak, ald);
             hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((ak / 4 + 255) / 256), (unsigned)((ar + 63) / 64)), dim3(256), 0, s, in,
@@ -364,8 +366,10 @@ int launch_cast_f16_auto_multi(const float* const* in, void* const* out, int n, 
         const int nn = std::min(MULTI_MAX, n - i0);
         MultiArgs a;
         for (int i = 0; i < MULTI_MAX; ++i) { a.in[i] = i < nn ? in[i0 + i] : nullptr; a.out[i] = i < nn ? static_cast<float*>(out[i0 + i]) : nullptr; }
-        hipLaunchKernelGGL(amax_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, reinterpret_cast<unsigned*>(scal + 2 * i0), elems / 4);
-        SOLA_LAUNCH_CHECK();
+        if (!bf16) {  // bfloat16: scale 1 (the zeroed slots), no max|x| pass over the matrices
+            hipLaunchKernelGGL(amax_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, reinterpret_cast<unsigned*>(scal + 2 * i0), elems / 4);
+            SOLA_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(cast_f16_auto_multi_kernel, dim3(blocks, 1, nn), dim3(256), 0, s, a, scal + 2 * i0, elems / 8, bf16);
         SOLA_LAUNCH_CHECK();
     }
