@@ -499,66 +499,10 @@ enum { SOLA_PROF_GEMM = 0,      /* gemm_nt_f32_kernel<128,128> */
        SOLA_PROF_GEMM_SPLIT256 = 12, /* gemm_nt_split_glds_persist_kernel<*> (and the one-tile <4,2,4,*> kernel): 256x256 blocks, split-f16, 3 x f16 MFMA */
        SOLA_PROF_GEMM_SPLIT256_GN = 13, /* the same kernel with GroupNorm + LeakyReLU applied in the epilogue (encoder conv0-2): its time includes the norm */
        SOLA_PROF_NCAT = 14 };
-/* Kernel-schedule switches for within-process A/B measurements ("gemm_variant": 0 simple / 1 mid-tile staging;
- * "gemm_glds": split-f16 GEMM staging, 0 registers / 1 direct-to-LDS 128x128 blocks / 4 256x256 blocks / 3 auto;
- * "gemm_persist": 256x256 shape, 1 persistent kernel (default) / 0 one tile per block; "gemm_glds_force": tests only, take the
- * direct-to-LDS kernels for grids of any size; "gemm_splitk", "bilinear_staged";
- * "train_split_min_rows": precision 1 in training takes the split-f16 GEMMs from this many token rows (B*N*T') on, default 1024
- * (below that the step is launch-bound and the cast launches cost more than the GEMMs gain); tests set 0;
- * "gemm_ablate": measurement only (results are then WRONG), bits: 4 = no epilogue, 8 = interior epilogue without its global
- * stores, 16 = without its LDS transpose;
- * "gemm_nw4", "gemm_pp": experimental four-wave shapes of the persistent split-f16 GEMM (256x128 tiles, one wave per SIMD; gemm_pp with
- * two accumulator sets and the epilogue drained under the next tile), bit-identical to the default, 0 (default) = off;
- * "train_tn_tr": 1 (default) = weight gradients on 16-bit operands whose N and K are multiples of 256 read ROW-MAJOR casts and
- * transpose in the LDS read (no transposed copies), 0 = always the transposing casts + NT GEMM;
- * "train_x16_keep": 1 (default) = in the 16-bit operand training modes the forward keeps its fixed-scale operand casts (in the
- * arena the caller lends the context: sola_set_x16_arena) and the backward's weight-gradient products read them instead of casting the activations again
- * (the split-f16 step's operand casts write their hi halves once more as plain f16 rows for that purpose);
- * "infer_f32_rows": a precision-1 inference call (sola_forward / sola_forward_ragged) over at most this many object-token rows (default 4096:
- * one sample per call, the reference's inference batch size) runs the exact-f32 kernels - faster there since the few-row GEMM shape (no casts, no
- * guard read-back: 0.61 -> 0.45 ms per call at the headline shape) and exact; 0 = the split-f16 pass at every size;
- * "gemm_f32_nw8", "gemm_tn_nw8": 1 (default) = the exact-f32 128 x 128 GEMM / the exact-f32 weight-gradient kernels run eight waves of 32 x 64 per
- * block (four waves per SIMD instead of two; bit-identical outputs, bias gradients in another fixed summation order), 0 = four waves of 64 x 64;
- * "gemm_small_rows": exact-f32 GEMMs on plain rows of at most this many rows (default 2048: one sample per call or optimizer step) take the
- * 32 x 32 shape whose split over K happens inside the block (no partial sums in memory, no reduce launch); 0 = the 64 x 64 + split-K pair;
- * "gemm_splitk_max": most K ranges per tile of that pair (default 8; A/B);
- * "bwd_group_rows": an exact-f32 backward of at most this many token rows (default 2048) defers the weight-gradient products of its linear
- * layers and encoder convs into grouped launches and transposes the weights its dX GEMMs read in one launch (deterministic; not bit-identical
- * to the per-matrix slab form: another fixed summation order), 0 = per-matrix launches;
- * "train_attn_cast": 1 (default) = in the f16 / bf16 operand training steps the forward's attention kernels also write the operand cast of
- * their output that the out-projection GEMM takes (where the shape can; bit-identical to the separate cast launch: -0.5 % of the ragged step),
- * 2 = the split-f16 step too (pairs + the plain-f16 side copy: measured no gain), 0 = always the cast launch;
- * "gemm_k16": experimental one-tile-per-block shape of the split-f16 GEMM - 256x128 tiles, 16-deep k-tiles, two four-wave blocks per
- * CU (one block's epilogue under the other's k-loop); bit-identical to the default, 7-20 % slower, 0 = off;
- * "gemm_gn_fuse": 1 = encoder conv0-2 of the split-f16 forward apply their GroupNorm + LeakyReLU in the GEMM epilogue (batches whose
- * conv outputs fill 256-row tiles, 64 channels per group; ~2 % of the headline step), 0 (default since round 3: the epilogue had two
- * nondeterministic faults in development; round 4's ISA-level bisection - profiles/r04_gnf_fault.txt - shows packed-f32 code to be necessary
- * and no wait state inside the issuing wave to be sufficient, but names no instruction-level cause: contained - no packed-f32 instruction in
- * the built code object - and stress-tested, but opt-in) = separate GroupNorm launches;
- * "gemm_trace" / "gemm_stagger" / "gemm_order" / "gemm_ld" / "bwd_side_rows": round-4 measurement switches and experiments (in-kernel cycle
- * stamps of the persistent GEMM, start stagger, W-affine tile order, one wave of each SIMD pair issuing the whole DMA stream, the few-sample
- * backward's weight gradients on a side stream), all off by default, results bit-identical - DESIGN.md 5, profiles/r04_*.txt;
- * "iou_fused": sola_mask_iou_matrix with P <= 4 uint8 masks at the comparison resolution, 1 (default) = one fused kernel for
- * up to 32 prompts, 0 = always pack + pair, 2 = fused for any prompt count;
- * "pack_resample_lds": nearest-resampling mask pack, 1 (default) = source rows staged through LDS / 0 = per-pixel gather;
- * "gn_variant": 0 three-pass GroupNorm / 1 register-resident; "attn_variant": 0 baseline / 1 packed + q-block loop;
- * "attn_target_blocks";
- * attention forward shapes (round 2): "attn_reg" 0 / 1 (default: 5..16-step and 65..96-key units) / 2 (wherever it can run) =
- * register-only MFMA shape; "attn_res" 0 / 1 (default: >= 128 queries against <= 64 keys, uniform batches) / 2 (ragged batches
- * too) = resident-K/V shape, "attn_res_tiles", "attn_res_shape", "attn_res_splitm"; "attn_simple_db" 1 (default) = double-
- * buffered 16-key stages in the high-occupancy shape; "attn_simple_remap"; "attn_splitm", "attn_stage_split_math" (tests);
- * attention backward: "attn_bwd_small" 1 (default) = one-pass kernel for <= 4 steps, "attn_bwd_blk" 1 (default) = block-shared
- * double-buffered staging (bit-identical to 0); GroupNorm: "gn_wide" 1024-thread shape for 64-128 KiB units, "gn_slices"
- * two-launch sliced shape for larger units, "gn_bwd_reg" register-resident backward; "bwd_dual_cast" 1 (default) = the
- * transposing cast of a gradient matrix also writes its row-major cast; "bwd_fused_bf16_cast" 1 (default) = bf16 storage: the
- * statistics pass over a gradient matrix (bias sums) writes its bf16 cast as well - no max|x| pass, no scale; "attn_bwd_fused" 1 (default) = the one-pass attention
- * backward for units of <= 128 queries and keys and for chunked long query ranges, 0 = the two-pass kernels everywhere;
- * "attn_split_min_keys" (default 96) = units with more keys take the split-f16 attention on split q / k / v in precision 1;
- * "train_dw_f16" 1 (default) = weight-gradient products of the precision-1 training step on plain f16 operands;
- * "train_gn_cast" 1 (default) = in the 16-bit operand training modes a GroupNorm also writes the operand cast of the GEMM behind
- * it; "attn_spin" 1 (default) = the high-occupancy attention shape for split-f16 q / k / v; "gn_h8" /
- * "attn_f16_small" 1 (default) = the 16-byte-per-lane GroupNorm and the streaming short-sequence attention of precision 2).
- * Except under gemm_ablate / attn_bwd_ablate (measurement only), results are identical across variants up to f32 summation order. */
+/* Kernel-schedule switches for within-process A/B measurements and tests (e.g. "train_bf16_store", "iou_fused", "attn_split_min_keys",
+ * "infer_f32_rows", "train_split_min_rows").  Not part of the drop-in boundary: the defaults are the shipped path.  The catalogue of keys,
+ * values and what each was measured to do lives in docs/tune_keys.md; an unknown key returns SOLA_ERR_ARG.  Except under the *_ablate keys
+ * (measurement only), results are identical across variants up to f32 summation order. */
 int sola_tune(const char* key, int value);
 /* 1 when the library was built with EXPERIMENTS=1 (make -C sola_amd/csrc EXPERIMENTS=1): the closed experiments' kernels and their
  * sola_tune keys (gemm_pp, gemm_nw4, gemm_k16, gemm_stagger, gemm_order, gemm_trace, gemm_ld, gemm_gn_fuse, gemm_ablate, attn_bwd_ablate,
