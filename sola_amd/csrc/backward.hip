@@ -475,11 +475,12 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     // by a statistics-and-cast pass that read the f32 matrix back (launch_cast_bf16_colsum); the f32 rows stay (residual stream)
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
-                      int leaky, const DropoutCfg* drop, const int4* units = nullptr, void* dx16 = nullptr) -> int {
+                      int leaky, const DropoutCfg* drop, const int4* units = nullptr, void* dx16 = nullptr, bool x_bf16 = false) -> int {
         GroupNormBwdDesc d{};
         if (drop) d.drop = *drop;
         d.units = units;
         d.dx16 = dx16;
+        d.x_bf16 = x_bf16 ? 1 : 0;
         d.x = xpre; d.dy = dy; d.dy2 = dy2; d.gamma = W(wname + ".weight"); d.beta = W(wname + ".bias"); d.dx = dx;
         d.dgamma_part = ar.get("gpart"); d.dbeta_part = ar.get("bpart");
         d.n_inst = n_inst; d.inner = inner; d.outer_stride = outer; d.inner_stride = inner_stride; d.tok_stride = tok_stride;
@@ -562,7 +563,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "object2lang_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); dlkv = keep((size_t)BW * 2 * D); }
             SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, max_rows_smp, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 2 < c->res16.size() && c->res16[(size_t)l * 3 + 2]));
             SOLA_TRY(out_proj_bwd(2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
@@ -608,7 +609,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "motion_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, R, 1, Tp, 0, 1, Tp, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr, gn16 ? dy16 : nullptr));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 1 < c->res16.size() && c->res16[(size_t)l * 3 + 1]));
             SOLA_TRY(out_proj_bwd(1));
             AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
@@ -647,7 +648,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "obj_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 0 < c->res16.size() && c->res16[(size_t)l * 3 + 0]));
             SOLA_TRY(out_proj_bwd(0));
             AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,

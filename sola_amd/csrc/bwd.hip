@@ -20,7 +20,16 @@ struct GnBwdArgs {
     DropoutCfg drop;
     const int4* units;  // ragged batches: (first row, row stride, token count, -) per instance (GroupNormBwdDesc::units)
     unsigned short* dx16;  // optional (round 6): dx once more as bfloat16 rows of the same pitch - the operand of the GEMMs that consume it
+    int x_bf16;            // round 6: x (the saved pre-norm rows) is a bfloat16 matrix of the same pitch
 };
+__device__ __forceinline__ float4 gnb_load_x(const GnBwdArgs& a, long long off) {
+    if (a.x_bf16) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + off);
+        return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                           __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(a.x + off);
+}
 __device__ __forceinline__ void gn_store_dx(const GnBwdArgs& a, long long off, float4 o) {
     *reinterpret_cast<float4*>(a.dx + off) = o;
     if (a.dx16) {
@@ -82,14 +91,14 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
     float s = 0.f;
     if (active)
         for (int t = tl; t < ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
+            const float4 v = gnb_load_x(a, (row0 + (long long)t * tok_stride) * a.C + ch);
             s += (v.x + v.y) + (v.z + v.w);
         }
     const float mean = bwd_block_sum<NTHR>(s, red) / cnt;
     float q = 0.f;
     if (active)
         for (int t = tl; t < ntok; t += tpp) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x + (row0 + (long long)t * tok_stride) * a.C + ch);
+            const float4 v = gnb_load_x(a, (row0 + (long long)t * tok_stride) * a.C + ch);
             const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
     if (active)
         for (int t = tl; t < ntok; t += tpp) {
             const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-            const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+            const float4 v = gnb_load_x(a, off);
             const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
             const float4 d = grad_in(off, xh);
             dgam.x += d.x * xh.x; dgam.y += d.y * xh.y; dgam.z += d.z * xh.z; dgam.w += d.w * xh.w;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
     if (!active) return;
     for (int t = tl; t < ntok; t += tpp) {
         const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-        const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+        const float4 v = gnb_load_x(a, off);
         const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
         const float4 d = grad_in(off, xh);
         float4 o;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
         const int t = tl + r * tpp;
         const bool ok = t < ntok;
         const long long off = (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch;
-        const float4 xr = *reinterpret_cast<const float4*>(a.x + off);
+        const float4 xr = gnb_load_x(a, off);
         const float4 dr = *reinterpret_cast<const float4*>(a.dy + off);
         xv[r] = make_float4(ok ? xr.x : 0.f, ok ? xr.y : 0.f, ok ? xr.z : 0.f, ok ? xr.w : 0.f);
         dv[r] = make_float4(ok ? dr.x : 0.f, ok ? dr.y : 0.f, ok ? dr.z : 0.f, ok ? dr.w : 0.f);
@@ -625,6 +634,7 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     a.inner = d.inner; a.outer_stride = d.outer_stride; a.inner_stride = d.inner_stride; a.tok_stride = d.tok_stride;
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.units = d.units;
     a.dx16 = static_cast<unsigned short*>(d.dx16);
+    a.x_bf16 = d.x_bf16;
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
     const int f4 = cg / 4;

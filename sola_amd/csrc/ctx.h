@@ -79,6 +79,10 @@ struct SolaCtx {
     // (written by the projection GEMM's epilogue, read by the attention forward and backward; the backward then writes dq / dk / dv as
     // bfloat16 too - the dW / dX GEMMs' operand, no f32 copy, no cast pass).  Decided per site by the shapes the kernels take.
     std::vector<char> qkv16;
+    // ... and sub-block (layer * 3 + which) keeps its PRE-NORM rows (out-projection + residual, the GroupNorm's input) as bfloat16: the
+    // out-projection GEMM reads the residual from the sub-block input's bf16 operand copy and writes bf16, the GroupNorm forward and
+    // backward read bf16 (sola_tune "train_bf16_store" 2)
+    std::vector<char> res16;
     // inference precision: 0 = exact f32 MFMA; 1 = split-f16 operands, 3 x f16 MFMA with f32 accumulation (cast.hip).
     // ctx-owned split-f16 copies of the weights: standardised conv weights (same offsets as ws_buf) and the
     // 12 * n_layers linear weights pre-scaled by 64 (index (layer * 3 + attn) * 4 + proj, D*D floats each).

@@ -13,7 +13,8 @@ void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
 extern int g_train_dw_f16;
 int g_train_attn_cast = 1;  // sola_tune "train_attn_cast": 1 = f16 / bf16 operand steps: the training forward's attention kernels also write the out-projection's operand cast; 2 = the split-f16 step too
 void sola_train_set_attn_cast(int v) { g_train_attn_cast = v; }
-int g_train_bf16_store = 1;  // sola_tune "train_bf16_store": 1 = bf16 steps keep q / k / v (and the backward dq / dk / dv) as bfloat16 rows where the attention kernels take them (round 6)
+int g_train_bf16_store = 2;  // sola_tune "train_bf16_store" (round 6): 1 = bf16 steps keep q / k / v and the backward's gradient operands as bfloat16 rows where the kernels take
+                             // them; 2 (default) = also the pre-norm rows of the layers (out-projection + residual -> GroupNorm); 0 = f32 storage (the round-5 step)
 int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
@@ -386,12 +387,16 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         }
         return launch_attention(ad, s);
     };
-    auto out_proj = [&](const std::string& attn, const float* ao, const float* resid, float* res) -> int {
+    // r16 != null (bf16 steps, sola_tune "train_bf16_store" 2): the residual is read from the sub-block input's bfloat16 operand copy and
+    // the pre-norm rows are written as bfloat16 - 4 instead of 8 bytes per element through the epilogue of a K = 1024 GEMM that its f32
+    // epilogue traffic bounds (profiles/r06_train_ragged_bf16.txt)
+    auto out_proj = [&](const std::string& attn, const float* ao, const float* resid, float* res, const void* r16 = nullptr) -> int {
         GemmDesc gd{};
         gd.nprob = 1;
         gd.p[0] = GemmProblem{ao, W(attn + ".out_proj.weight"), W(attn + ".out_proj.bias"), resid, res};
         gd.M = M; gd.N = D; gd.K = D; gd.lda = D; gd.ldr = D; gd.ldc = D;
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
+        if (split && r16) { gd.p[0].R = static_cast<const float*>(r16); gd.r_f16 = 1; gd.c_f16 = 1; }
         if (split) {
             float* dst;
             if (ac_src == ao) {  // attention() reserved the operand's place; the attention kernel wrote it unless its shape cannot
@@ -411,8 +416,9 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     // that order): when one of them is this norm's y or y2, the norm writes the cast itself
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,
                   long long outer, long long inner_stride, long long tok_stride, int ntok, const int4* units = nullptr,
-                  const float* next_src0 = nullptr, const float* next_src1 = nullptr) -> int {
+                  const float* next_src0 = nullptr, const float* next_src1 = nullptr, bool res_bf16 = false) -> int {
         GroupNormDesc nd{};
+        nd.in_f16 = res_bf16 ? 2 : 0;
         if (gn_fmt) {
             const float* nxt[2] = {next_src0, next_src1};
             const long long y_rows = std::max<long long>(M, text_rows);  // the norm's token rows, bounded from above
@@ -432,6 +438,13 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0;
         nd.units = units;
         return launch_group_norm(nd, s);
+    };
+    c->res16.assign((size_t)c->cfg.n_layers * 3, 0);
+    // the bf16 operand copy of a sub-block's input, if it sits in the kept-operand arena (a shared cast buffer is overwritten before the
+    // out-projection runs) - then the sub-block's pre-norm rows are bfloat16 (out_proj / gn above)
+    auto resid16 = [&](const float* resid) -> const void* {
+        if (!(train && split && pure && bf && g_train_bf16_store >= 2 && keep16 && D % 8 == 0)) return nullptr;
+        return c->x16_find(resid, D, 1 + bf);
     };
     const float* xin = buf("conv5");
     for (int l = 0; l < c->cfg.n_layers; ++l) {
@@ -455,9 +468,11 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             c->qkv16[(size_t)l * 3 + 0] = s16;
             SOLA_TRY(attention(ad));
         }
-        SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res")));
-        if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st, x_pe, x_obj));
-        else SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, nullptr, x_pe, x_obj));
+        const void* r16_0 = resid16(xin);
+        c->res16[(size_t)l * 3 + 0] = r16_0 != nullptr;
+        SOLA_TRY(out_proj(lp + "obj_attn", ab(0, "attn"), xin, ab(0, "res"), r16_0));
+        if (rs) SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, rt.sumTpS, 1, 0, 0, 1, N, rt.u_st, x_pe, x_obj, r16_0 != nullptr));
+        else SOLA_TRY(gn(lp, 0, ab(0, "res"), x_obj, x_pe, B * Tp, Tp, (long long)N * Tp, 1, Tp, N, nullptr, x_pe, x_obj, r16_0 != nullptr));
         // (ii) motion attention over T' per track, PE on q and k only: module.py:38-43
         {
             AttnDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), D, D, D, D, B * N, H, DH, Tp, Tp, 1,
@@ -470,9 +485,11 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             c->qkv16[(size_t)l * 3 + 1] = s16;
             SOLA_TRY(attention(ad));
         }
-        SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res")));
-        if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk, x_mot));
-        else SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp, nullptr, x_mot));
+        const void* r16_1 = resid16(x_obj);
+        c->res16[(size_t)l * 3 + 1] = r16_1 != nullptr;
+        SOLA_TRY(out_proj(lp + "motion_attn", ab(1, "attn"), x_obj, ab(1, "res"), r16_1));
+        if (rs) SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, rt.sumNS, 1, 0, 0, 1, Tp, rt.u_strk, x_mot, nullptr, r16_1 != nullptr));
+        else SOLA_TRY(gn(lp, 1, ab(1, "res"), x_mot, nullptr, B * N, 1, Tp, 0, 1, Tp, nullptr, x_mot, nullptr, r16_1 != nullptr));
         // (iii) object -> language cross attention: module.py:46-50
         {
             AttnDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), D, D, D, D, B, H, DH, N * Tp, Wn, 1,
@@ -487,11 +504,13 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             c->qkv16[(size_t)l * 3 + 2] = s16;
             SOLA_TRY(attention(ad));
         }
-        SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res")));
+        const void* r16_2 = resid16(x_mot);
+        c->res16[(size_t)l * 3 + 2] = r16_2 != nullptr;
+        SOLA_TRY(out_proj(lp + "object2lang_attn", ab(2, "attn"), x_mot, ab(2, "res"), r16_2));
         // the next layer's q / k / v projections read x_o2l: its norm writes their operand (nothing reads it behind the last layer)
         const float* nxt_in = l + 1 < c->cfg.n_layers ? x_o2l : nullptr;
-        if (rs) SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, 0, 0, 1, rt.maxRowsSample, rt.u_smp, nxt_in));
-        else SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp, nullptr, nxt_in));
+        if (rs) SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, 0, 0, 1, rt.maxRowsSample, rt.u_smp, nxt_in, nullptr, r16_2 != nullptr));
+        else SOLA_TRY(gn(lp, 2, ab(2, "res"), x_o2l, nullptr, B, 1, (long long)N * Tp, 0, 1, N * Tp, nullptr, nxt_in, nullptr, r16_2 != nullptr));
         xin = x_o2l;
     }
 

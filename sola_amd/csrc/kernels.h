@@ -265,6 +265,7 @@ struct GroupNormBwdDesc {
     // ntok is then the LARGEST token count (it selects the kernel shape)
     const int4* units;
     void* dx16 = nullptr;  // optional (round 6, bf16 steps): dx once more as bfloat16 rows, same pitch (C values)
+    int x_bf16 = 0;        // round 6: x is a bfloat16 matrix (the bf16 step's pre-norm rows), same pitch
 };
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
 struct WsBwdLayer {
@@ -342,7 +343,7 @@ struct GroupNormDesc {
     // optional, ragged batches: instance i covers the tokens units[i] = (first row, row stride, token count, pe row) instead
     // of the strided pattern above; ntok is then the LARGEST token count (it selects the kernel shape)
     const int4* units;
-    int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices (statistics stay f32)
+    int in_f16, out_f16;  // 16-bit storage mode: x / (y, y2) are _Float16 matrices (statistics stay f32); in_f16 == 2: x is a BFLOAT16 matrix (round 6)
     const float* in_scale_dev;  // optional: x is multiplied by this device scalar while it is read (an input stored in scaled units)
     // optional scratch of the sliced shape (units beyond the register shapes): 8 bytes per (unit, 256-token slice); the forward
     // orchestrators pass a piece of the caller's workspace (concurrent calls on one device must not share it); null = a

@@ -91,7 +91,11 @@ typedef _Float16 half4n __attribute__((ext_vector_type(4)));
 // four consecutive channels starting at element offset `off` of x
 __device__ __forceinline__ float4 gn_load(const GnArgs& a, long long off) {
     float4 v;
-    if (a.in_f16) {
+    if (a.in_f16 == 2) {  // bfloat16 rows (round 6: the bf16 training step's pre-norm activations)
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + off);
+        v = make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                        __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+    } else if (a.in_f16) {
         const half4n h = *reinterpret_cast<const half4n*>(reinterpret_cast<const _Float16*>(a.x) + off);
         v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
     } else {
@@ -112,7 +116,21 @@ __device__ __forceinline__ float4 gn_load(const GnArgs& a, long long off) {
 template <int R>
 __device__ __forceinline__ void gn_load_slots(const GnArgs& a, float4 (&v)[R], long long row0, long long tok_stride, int ntok, int t_first, int tpp, int ch) {
     const float sc = a.in_scale_dev ? *a.in_scale_dev : 1.f;
-    if (a.in_f16) {
+    if (a.in_f16 == 2) {  // bfloat16 rows
+        const unsigned short* x = reinterpret_cast<const unsigned short*>(a.x);
+        uint2 h[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = t_first + r * tpp;
+            h[r] = *reinterpret_cast<const uint2*>(x + (row0 + (long long)(t < ntok ? t : 0) * tok_stride) * a.C + ch);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = t_first + r * tpp < ntok;
+            v[r] = make_float4(ok ? __builtin_bit_cast(float, h[r].x << 16) * sc : 0.f, ok ? __builtin_bit_cast(float, h[r].x & 0xffff0000u) * sc : 0.f,
+                               ok ? __builtin_bit_cast(float, h[r].y << 16) * sc : 0.f, ok ? __builtin_bit_cast(float, h[r].y & 0xffff0000u) * sc : 0.f);
+        }
+    } else if (a.in_f16) {
         const _Float16* x = reinterpret_cast<const _Float16*>(a.x);
         half4n h[R];
 #pragma unroll

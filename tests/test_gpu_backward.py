@@ -478,8 +478,11 @@ def test_kept_operand_casts_give_the_same_gradients_bit_for_bit(full_model, mode
     products' operands): the forward keeps its fixed-scale operand casts in a ctx-owned arena and the backward's weight-gradient
     products read them (sola_tune "train_x16_keep", default 1) instead of casting the same f32 activations again - the same 16-bit
     values either way, so every gradient must be bit-identical with the switch off.  The arena is sized from the previous step's
-    need: the SECOND step is the one that reuses the casts.  Dropout off (eval mode): the two runs see the same step."""
+    need: the SECOND step is the one that reuses the casts.  Dropout off (eval mode): the two runs see the same step.  (Round 6: the bf16
+    step's bfloat16 pre-norm rows read their residual from the kept casts, so that part of the storage mode - sola_tune "train_bf16_store" 2 -
+    exists only with the arena; this A/B of the arena runs at level 1.)"""
     from sola_amd import _lib
+    _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
     m, _ = full_model
     cfg = synth.DEFAULT_MODEL_CFG
     got = {}
@@ -512,6 +515,7 @@ def test_kept_operand_casts_give_the_same_gradients_bit_for_bit(full_model, mode
         m.eval()
         m.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -538,7 +542,7 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_gradients_bit_for_
     finally:
         m.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad

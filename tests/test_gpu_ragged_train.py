@@ -213,11 +213,14 @@ def test_mixed_batch_equals_one_sample_steps_full(full, precision):
 @pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
 def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, precision):
     """As tests/test_gpu_backward.py's test of the same name, on a mixed-shape ragged batch (conv taps through the row maps): the
-    backward reading the forward's kept operand casts (sola_tune "train_x16_keep" 1) against casting again (0)."""
+    backward reading the forward's kept operand casts (sola_tune "train_x16_keep" 1) against casting again (0).  (sola_tune
+    "train_bf16_store" 1: level 2's bfloat16 pre-norm rows exist only with the arena - a capped arena keeps some residual copies and not
+    others - so this A/B of the arena itself runs without them.)"""
     cfg = synth.DEFAULT_MODEL_CFG
     full.precision = precision
     got = {}
     try:
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
         samples = [sample_inputs(cfg, N, T, L, 400 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
         for keep in (1, 0):
             _lib.check(_lib.lib().sola_tune(b"train_x16_keep", keep), "tune")
@@ -240,6 +243,7 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -263,7 +267,7 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_ragged_gradients_b
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -320,7 +324,7 @@ def test_row_major_weight_gradient_route_equals_the_transposed_copy_route_on_a_r
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
     worst = max((float((got[1][k].double() - got[0][k].double()).norm()) / (float(got[0][k].double().norm()) + 1e-30), k) for k in got[0])
     print("row-major vs transposed-copy dW route, worst tensor:", worst)
     assert worst[0] < 2e-5, worst
