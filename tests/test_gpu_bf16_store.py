@@ -198,11 +198,12 @@ def test_ragged_bf16_step_with_bf16_q_k_v_storage(variant):
 
 
 def _oracle_step(sd, cfg, inp, B, autocast):
-    """one training-step gradient through the CPU oracle (checker): fp32, or under torch.autocast(bfloat16) - the textbook bf16 recipe"""
+    """one training-step gradient through the CPU oracle (checker): fp32 (autocast None), or under torch.autocast(<16-bit dtype>) - the
+    textbook mixed-precision recipe"""
     from oracle import sola_oracle  # checker only
 
     tsd = {k: torch.tensor(v, requires_grad=(k != "positional_encoding_gaussian_matrix")) for k, v in sd.items()}
-    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+    with torch.autocast("cpu", dtype=autocast or torch.bfloat16, enabled=autocast is not None):
         sm, st = sola_oracle.forward(tsd, cfg, inp["object_tokens"], inp["lang_tokens"])
     neg = tsd["negative_token.weight"].unsqueeze(0).repeat(B, 1, 1)
     ls = sola_oracle.losses(sm.float(), st.float(), inp["labels"], inp["pos_tokens"], neg, 1.5, 0.07, 0.3)
@@ -210,14 +211,15 @@ def _oracle_step(sd, cfg, inp, B, autocast):
     return float(ls["total"]), {k: v.grad.double() for k, v in tsd.items() if v.grad is not None}
 
 
-@pytest.mark.parametrize("variant", ["base", "lin_div64"])
-def test_bf16_step_against_the_oracle_under_torch_autocast(variant):
+@pytest.mark.parametrize("variant,mode", [("base", "bf16"), ("lin_div64", "bf16"), ("base", "f16")])  # (lin_div64, f16) measured 0.9995 / 0.9994 / 0.9995; a minute of CPU half-precision matmuls
+def test_16_bit_step_against_the_oracle_under_torch_autocast(variant, mode):
     """the bf16 step (bfloat16 GEMM operands, q / k / v and the gradient operands stored as bfloat16) against the ORACLE, not
     against the library's own f32 step: autograd through oracle/sola_oracle.py in fp32 and under torch.autocast("cpu", bfloat16), 8 samples
     of (N=40, T=32, L=10), dropout off.  The library's step must be at least as close to the fp32 oracle as autocast is (loss and gradient
     cosine; its activations, statistics, softmax and residuals stay f32, autocast's GroupNorm inputs and attention run in bf16), and on
     weights whose first softmax is not saturated ("lin_div64"), where two bf16 evaluations are comparable at all, it must agree with the
-    autocast gradient itself (cosine >= 0.985).  Measured: base - library 0.742 / autocast 0.550 against fp32 (library vs autocast 0.64:
+    autocast gradient itself (cosine >= 0.985).  The same for the f16-operand step (module.precision = "f16": f32 storage, per-tensor power-of-two
+    scales) against torch.autocast(float16): measured 0.985 library / 0.986 autocast at random init.  bf16, measured: base - library 0.742 / autocast 0.550 against fp32 (library vs autocast 0.64:
     two noisy evaluations of a saturated softmax), losses 8.497 / 8.480 against 8.464; lin_div64 - 0.9952 / 0.9947, library vs autocast 0.9954."""
     from sola_amd.loss import track_selection_losses
 
@@ -226,12 +228,12 @@ def test_bf16_step_against_the_oracle_under_torch_autocast(variant):
     sd = synth.make_state_dict_variant(cfg, 42, variant)
     inp = synth.make_inputs(cfg, B, N, T, L, 77)
     torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 32))
-    l32, g32 = _oracle_step(sd, cfg, inp, B, False)
-    l16, g16 = _oracle_step(sd, cfg, inp, B, True)
+    l32, g32 = _oracle_step(sd, cfg, inp, B, None)
+    l16, g16 = _oracle_step(sd, cfg, inp, B, torch.bfloat16 if mode == "bf16" else torch.float16)
     m = LanguageAlignedTrackSelectionModule(cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
     m = m.cuda().eval()
-    m.precision = "bf16"
+    m.precision = mode
     c = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
     for _ in range(2):  # the second step of a run has the kept-operand arena, i.e. the whole storage mode (bfloat16 pre-norm rows too)
         m.zero_grad(set_to_none=True)
@@ -244,7 +246,7 @@ def test_bf16_step_against_the_oracle_under_torch_autocast(variant):
     assert set(gh) == set(g32)
     lh = float(loss3[0])
     c_hip, c_auto, c_both = _cos(gh, g32), _cos(g16, g32), _cos(gh, g16)
-    print(f"{variant}: loss fp32 oracle {l32:.5f}, autocast oracle {l16:.5f}, library bf16 {lh:.5f}; gradient cosine vs fp32 oracle: library {c_hip:.4f}, "
+    print(f"{variant} {mode}: loss fp32 oracle {l32:.5f}, autocast oracle {l16:.5f}, library {lh:.5f}; gradient cosine vs fp32 oracle: library {c_hip:.4f}, "
           f"autocast {c_auto:.4f}; library vs autocast {c_both:.4f}")
     assert abs(lh / l32 - 1) <= max(2 * abs(l16 / l32 - 1), 5e-3)
     assert c_hip >= c_auto - 0.02
