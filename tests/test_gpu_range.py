@@ -229,6 +229,31 @@ def test_batch_256_on_unsaturated_weights_vs_reference(bench_gold, precision):
     assert r_rows.max() <= 1e-3 and r_rows.mean() <= 2.5e-4
 
 
+def test_16_bit_storage_mode_vs_reference(bench_gold):
+    """VERDICT r5 row g: the 16-bit STORAGE mode of inference (module.precision = "f16": every activation between two kernels a plain
+    _Float16) against the REFERENCE's own logits for the benched batch.  It is a reduced-precision mode with a stated tolerance, not a
+    parity mode: at random-init weights the first inter-object softmax is saturated (scores of rms ~100) and 2^-11 on q / k flips near-ties
+    (measured: worst 0.52, rms 0.032 on logits of magnitude ~10, 0.15 % of them beyond 0.25); on weights whose softmax is not saturated
+    ("lin_div64") what is left is the format's own rounding through 18 GEMM layers (measured: worst 0.034, rms 8.1e-3 = 8e-4 of the logits'
+    magnitude).  Bounds: 1.0 / 0.04 and 0.06 / 0.012; every selection whose logit is further than twice the worst error from 0 equal."""
+    B, N, T, L = 256, 64, 32, 16
+    inp = synth.make_inputs(CFG, B, N, T, L, seed=1000)
+    obj, lang = torch.from_numpy(inp["object_tokens"]).cuda(), torch.from_numpy(inp["lang_tokens"]).cuda()
+    for variant, key, worst_tol, rms_tol in (("base", "u256.1000", 1.0, 0.04), ("lin_div64", "u256.1000.lin_div64", 0.06, 0.012)):
+        m, _sd = build(variant, "f16")
+        with torch.no_grad():
+            sm, _st = m(obj, lang)
+        sm = sm.cpu().numpy()
+        ref = bench_gold[key + ".score_map"].reshape(sm.shape)
+        err = np.abs(sm - ref)
+        rms = float(np.sqrt((err.astype(np.float64) ** 2).mean()))
+        print(f"f16 storage, {variant} weights vs REFERENCE: worst {err.max():.3e} rms {rms:.3e} logits beyond 0.25: {(err > 0.25).mean():.4%}")
+        assert err.max() <= worst_tol and rms <= rms_tol
+        far = np.abs(ref) > 2 * max(err.max(), 1e-3)
+        np.testing.assert_array_equal((sm > 0)[far], (ref > 0)[far])
+        del m
+
+
 def test_stress_batch_every_row_vs_oracle(base_models, bench_gold):
     """BASELINE config C4 (T=128, N=128), 32 samples in one call, every row, both modes."""
     B, N, T, L = 32, 128, 128, 16
