@@ -798,11 +798,11 @@ _DROP = {"what", "tolerance", "shapes", "traffic_source", "traffic_kernel", "ker
          "executed_vs_uniform_batch_model_tflops", "pairs_per_s", "workload"}
 _DROP_NESTED = {"model_tflops", "gflop_per_sample", "achieved", "avg_launch_us", "launches", "share_of_step_time", "steps", "dtype"}  # below the top level and its two rooflines
 _KEEP_KERNEL_MS = {("kernel_ms_per_step",), ("training_step", "ragged", "f16x3", "kernel_ms_per_step"),
-                   ("training_step", "ragged", "f16", "kernel_ms_per_step"), ("training_step", "f16x3", "kernel_ms_per_step")}
+                   ("training_step", "ragged", "bf16", "kernel_ms_per_step"), ("training_step", "f16x3", "kernel_ms_per_step")}
 _CONTRACT_ROOFLINES = {("roofline",), ("roofline_attention",)}
-_OPTIONAL = [("iou", "cpu_baseline", "sample"), ("training_step", "ragged", "f16", "kernel_ms_per_step"), ("training_step", "f16x3", "kernel_ms_per_step"),
+_OPTIONAL = [("iou", "cpu_baseline", "sample"), ("training_step", "f16x3", "kernel_ms_per_step"),
              ("f16_storage_mode", "ragged_four_expressions_per_video"), ("training_step", "ragged", "samples_per_step_128"),
-             ("training_step", "ragged", "f16x3", "kernel_ms_per_step"), ("stress_T128_N128", "kernel_ms_per_step"), ("iou", "cpu_baseline"),
+             ("training_step", "ragged", "f16x3", "kernel_ms_per_step"), ("training_step", "ragged", "bf16", "kernel_ms_per_step"), ("stress_T128_N128", "kernel_ms_per_step"), ("iou", "cpu_baseline"),
              ("f16_storage_mode", "C4_T128_N128", "roofline"), ("f16_storage_mode", "NS_T32_N64", "roofline")]
 _SHORT = {"max_abs_logit_err_vs_reference": "max", "max_abs_logit_err_vs_float64": "max_vs_f64", "reference_vs_float64": "ref_vs_f64",
           "train_forward_logit_err_vs_reference": "train_fwd_err_vs_reference",
@@ -830,6 +830,10 @@ def compact(o, path=()):
         for k, v in o.items():
             p = path + (k,)
             if k in _DROP and p != ("config", "workload"):
+                continue
+            # nested legs: where every logit is compared with the REFERENCE's own (round 6), the same comparison with the oracle stays in the verbose file only
+            if len(path) > 0 and ((k == "logit_err_vs_oracle" and "logit_err_vs_reference" in o) or
+                                  (k == "train_forward_logit_err_vs_oracle" and "train_forward_logit_err_vs_reference" in o)):
                 continue
             if k in _DROP_NESTED and len(path) > 0 and path not in _CONTRACT_ROOFLINES:
                 continue
