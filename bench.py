@@ -1057,7 +1057,7 @@ def main():
         # HBM traffic cannot be read from inside the run (PMC needs rocprofv3); it is the committed per-launch PMC
         # measurement of this same command line (tools/profile_bench.sh -> profiles/r0X_traffic.json), used only when the
         # batch matches the profiled one, else null
-        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if not os.path.exists(tpath):
                 continue
