@@ -492,9 +492,9 @@ static void onepass_shape(int R, int* G, int* nb) {
 }
 size_t mask_iou_fused_scratch_bytes(int P, int R, long long words) {
     (void)P;
-    // an upper bound over every shape: one prompt per block
+    // an upper bound over every block shape: ceil(R / GB) groups x (5 GB + 4) counts <= 9 R + 64 for 1 <= GB <= 12
     const size_t chunks = (size_t)((words + OP_CHUNK - 1) / OP_CHUNK);
-    return (size_t)R * chunks * 9 * sizeof(unsigned);
+    return ((size_t)9 * R + 64) * chunks * sizeof(unsigned);
 }
 
 int g_iou_fused = 1;  // sola_tune "iou_fused": 0 forces the pack + pair path (A/B, tests)
