@@ -45,9 +45,10 @@ namespace {
 struct Arena {
     char* base;
     size_t total = 0;
-    std::unordered_map<std::string, size_t> off;
+    std::unordered_map<std::string, size_t> off, bytes;
     size_t add(const std::string& name, size_t floats) {
         off[name] = total;
+        bytes[name] = floats * sizeof(float);
         total += (floats * sizeof(float) + 255) & ~(size_t)255;
         return off[name];
     }
@@ -141,7 +142,11 @@ Arena make_arena(const SolaCtx* c, const BwdSizes& z) {
         {   // per-64-row-slab column sums of a gradient matrix (launch_amax_colsum): bias gradients without a second read
             size_t cp = std::max((M / 64 + 1) * 3 * D, (BW / 64 + 1) * 2 * D);
             for (int i = 0; i < 6; ++i) cp = std::max(cp, (z.rows[i + 1] / 64 + 1) * (size_t)c->conv[i].cout);
-            a.add("cpart", cp);
+            // round 6: every statistics pass of a step keeps its own slab table (the bias sums of a gradient bucket leave in one grouped
+            // launch, flush_bias): per layer 3 out-projection tables, two [.., 3D] and one [.., D] for the q / k / v gradients, one text table
+            size_t all = (size_t)c->cfg.n_layers * ((M / 64 + 1) * 10 * D + (BW / 64 + 1) * 2 * D + 7 * 64);
+            for (int i = 0; i < 6; ++i) all += (z.rows[i + 1] / 64 + 1) * (size_t)c->conv[i].cout + 64;
+            a.add("cpart", std::max(cp, all));
         }
         // split-f16 weight gradients of the projections (gemm_tn_split.hip): transposed operands + partial sums
         if (gemm_tn_split_supported((int)M, (int)D, (int)D)) {
@@ -310,8 +315,11 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     // path (gemm_tn_split.hip) + the bias gradients as column sums, or the f32 kernel per problem
     // Split mode reads every gradient matrix ONCE for its scale (max|dY|, shared by the dW and dX GEMMs that consume it) and
     // its bias gradients (per-slab column sums, folded by a tiny second pass): stats() -> scale slot, bias_from_stats().
-    float* cpart = split ? ar.get("cpart") : nullptr;
+    float* cpart = split ? ar.get("cpart") : nullptr;  // the CURRENT statistics pass's slab table (bumped per pass: they all stay until flush_bias)
+    float* cpart_next = cpart;
+    const size_t cpart_bytes = split ? ar.bytes.at("cpart") : 0;
     int cpart_cols = 0, cpart_slabs = 0;
+    ColsumJobsDesc bias_q{};  // deferred bias gradients of the current bucket
     int stat_calls = 0;
     const int scal_floats = split ? (int)(16 + 2 * (6 + 8 * (size_t)c->cfg.n_layers)) : 0;
     if (split) SOLA_HIP(hipMemsetAsync(ar.get("scal"), 0, scal_floats * sizeof(float), s));
@@ -334,6 +342,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         *sc_out = nullptr;
         if (may_cast) cast_src = nullptr;
         if (!split || cols % 4 || ld % 4) return SOLA_OK;
+        cpart = cpart_next;  // this pass's own table
+        cpart_next += (((size_t)((rows + 63) / 64) * cols) + 63) & ~(size_t)63;
+        SOLA_ARG((size_t)(cpart_next - ar.get("cpart")) * sizeof(float) <= cpart_bytes, "backward: the slab tables of the step's statistics passes exceed their arena");
         if (ready16) {
             (void)slot;
             SOLA_ARG(16 + 2 * (stat_calls + 1) <= scal_floats, "backward: more gradient-statistics passes (%d) than scale slots", stat_calls + 1);
@@ -362,8 +373,19 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         *sc_out = sc;
         return SOLA_OK;
     };
+    auto flush_bias = [&]() -> int {
+        if (bias_q.n == 0) return SOLA_OK;
+        SOLA_TRY(launch_colsum_jobs(bias_q, s));
+        bias_q.n = 0;
+        return SOLA_OK;
+    };
+    // deferred (round 6): the sums of a bucket's bias gradients leave in ONE launch in front of the bucket's event (flush_bias) - the same
+    // per-column arithmetic as the per-gradient launch_colsum they replace
     auto bias_from_stats = [&](int col_off, int ncols, float* db) -> int {
-        return launch_colsum(cpart + col_off, db, 1, cpart_slabs, ncols, cpart_cols, 1.f, 0, nullptr, 0, s);
+        if (bias_q.n == 48) SOLA_TRY(flush_bias());
+        const int e = bias_q.n++;
+        bias_q.in[e] = cpart + col_off; bias_q.out[e] = db; bias_q.rows[e] = cpart_slabs; bias_q.cols[e] = ncols; bias_q.ld[e] = cpart_cols;
+        return SOLA_OK;
     };
     struct WG { const float* dY; const float* X; float* dW; float* db; };
     // sc: scale slot from stats() over a matrix containing every dY of the call; db_done: the bias gradients were taken from it
@@ -681,6 +703,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         }
         if (l > 0) {
             SOLA_TRY(join_side());
+            SOLA_TRY(flush_bias());  // the layer's deferred bias sums
             if (!group) SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1 - l], s));  // layer l's 30 gradients are final
         }
     }
@@ -694,6 +717,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     SOLA_TRY(launch_neg_token_grad(dlang, ar.get("dlbar"), nullptr, G("negative_token.weight"), B, L, c->cfg.n_negative, D, s,
                                    rt ? rt->u_lang : nullptr));
     SOLA_TRY(join_side());
+    SOLA_TRY(flush_bias());
     SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers - 1], s));  // layer 0 + negative tokens
 
     // ---- encoder ----------------------------------------------------------------------------------------------
@@ -841,6 +865,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         }
         SOLA_TRY(launch_ws_backward(layers, 6, s));
     }
+    SOLA_TRY(flush_bias());
     SOLA_HIP(hipEventRecord(c->bucket_ev[c->cfg.n_layers], s));  // encoder
     c->bucket_recorded = true;
     return SOLA_OK;

@@ -373,7 +373,64 @@ __global__ __launch_bounds__(256) void colsum_pair_group_kernel(const ColsumGrou
     }
 }
 
+// Up to 48 single column sums in ONE launch (round 6: the ~30 bias gradients of a reduced-precision training step were one ~9-us launch each
+// over the slab sums their statistics pass left; every statistics pass keeps its slab table now and a bucket's bias sums leave together).
+// Per-column arithmetic = colsum_kernel with one chunk (eight partial sums per row lane, four row lanes combined in a fixed order): the same bits.
+constexpr int CSJ_MAX = 48;
+struct ColsumJobsArgs {
+    const float* in[CSJ_MAX];
+    float* out[CSJ_MAX];
+    int rows[CSJ_MAX], cols[CSJ_MAX], ld[CSJ_MAX], first_block[CSJ_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void colsum_jobs_kernel(const ColsumJobsArgs a) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int e = lo;
+    const int c = ((int)blockIdx.x - a.first_block[e]) * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int cols = a.cols[e], ld = a.ld[e], r_end = a.rows[e];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    if (c < cols) {
+        const float* p = a.in[e] + c;
+        int r = rl;
+        for (; r + 28 < r_end; r += 32) {
+            s0 += p[(long long)r * ld]; s1 += p[(long long)(r + 4) * ld]; s2 += p[(long long)(r + 8) * ld]; s3 += p[(long long)(r + 12) * ld];
+            s4 += p[(long long)(r + 16) * ld]; s5 += p[(long long)(r + 20) * ld]; s6 += p[(long long)(r + 24) * ld]; s7 += p[(long long)(r + 28) * ld];
+        }
+        for (; r < r_end; r += 4) s0 += p[(long long)r * ld];
+    }
+    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) a.out[e][c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * 1.0f;
+}
+
 }  // namespace
+
+int launch_colsum_jobs(const ColsumJobsDesc& d, hipStream_t s) {
+    SOLA_ARG(d.n >= 1 && d.n <= CSJ_MAX, "colsum_jobs: %d jobs", d.n);
+    ColsumJobsArgs a;
+    a.n = d.n;
+    int blocks = 0;
+    double bytes = 0;
+    for (int e = 0; e < d.n; ++e) {
+        SOLA_ARG(d.in[e] && d.out[e] && d.rows[e] > 0 && d.cols[e] > 0 && d.ld[e] >= d.cols[e], "colsum_jobs: job %d", e);
+        a.in[e] = d.in[e]; a.out[e] = d.out[e]; a.rows[e] = d.rows[e]; a.cols[e] = d.cols[e]; a.ld[e] = d.ld[e];
+        a.first_block[e] = blocks;
+        blocks += (d.cols[e] + 63) / 64;
+        bytes += 4.0 * d.rows[e] * d.cols[e];
+    }
+    a.first_block[d.n] = blocks;
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, bytes);
+    hipLaunchKernelGGL(colsum_jobs_kernel, dim3(blocks), dim3(256), 0, s, a);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
 
 int g_gemm_tn_nw8 = 1;  // sola_tune "gemm_tn_nw8": the exact-f32 weight-gradient kernels with eight waves per block (0 = four; A/B)
 void sola_gemm_tn_set_nw8(int v) { g_gemm_tn_nw8 = v; }

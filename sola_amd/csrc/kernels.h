@@ -174,6 +174,14 @@ struct ColsumPairGroupDesc {
     int n;
 };
 int launch_colsum_pair_group(const ColsumPairGroupDesc& d, hipStream_t s);
+// up to 48 single column sums out[j][c] = sum_r in[j][r * ld + c] in one launch (the arithmetic of launch_colsum without scratch: same bits)
+struct ColsumJobsDesc {
+    const float* in[48];
+    float* out[48];
+    int rows[48], cols[48], ld[48];
+    int n;
+};
+int launch_colsum_jobs(const ColsumJobsDesc& d, hipStream_t s);
 
 // ---- attention core (attn.hip) ---------------------------------------------------------------------------------
 struct AttnDesc {
