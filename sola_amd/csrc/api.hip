@@ -326,6 +326,7 @@ void sola_attn_set_ring_ablate(int v);
 void sola_attn_set_simple_remap(int v);
 void sola_iou_set_shape(int v);
 extern int g_train_bf16_store;
+void sola_attn_set_bf16_mfma(int v);
 void sola_attn_set_simple_db(int v);
 void sola_pack_set_resample_lds(int v);
 static int g_stage_split_math = 0;
@@ -419,6 +420,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "iou_fused")) { sola_iou_set_fused(value); return SOLA_OK; }
     if (!strcmp(key, "iou_shape")) { sola_iou_set_shape(value); return SOLA_OK; }
     if (!strcmp(key, "train_bf16_store")) { g_train_bf16_store = value; return SOLA_OK; }
+    if (!strcmp(key, "attn_bf16_mfma")) { sola_attn_set_bf16_mfma(value); return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }

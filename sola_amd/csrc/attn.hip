@@ -608,6 +608,8 @@ bool attention_res_supported(const AttnDesc& d);
 int launch_attention_res(const AttnDesc& d, hipStream_t s);
 extern int g_attn_splitm;
 
+bool attention_bf16_mfma_supported(const AttnDesc& d);
+int launch_attention_bf16_train(const AttnDesc& d, hipStream_t s);
 bool attention_spin_supported(const AttnDesc& d);
 int launch_attention_spin(const AttnDesc& d, hipStream_t s);
 #ifdef SOLA_EXPERIMENTS  // closed experiment (lab/attn_ring.hip): EXPERIMENTS=1 builds with sola_tune "attn_ring" only
@@ -619,7 +621,10 @@ extern int g_attn_ring;
 int launch_attention(const AttnDesc& d, hipStream_t s) {
     SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0, "attention: bad sizes");
     SOLA_ARG(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0, "attention: strides must be multiples of 4");
-    if (d.in_bf16) return launch_attention_simple(d, s);  // bf16 q / k / v (training step's 16-bit storage): one shape takes them, it checks
+    if (d.in_bf16) {  // bf16 q / k / v (training step's 16-bit storage)
+        if (attention_bf16_mfma_supported(d)) return launch_attention_bf16_train(d, s);  // bf16 MFMA products, half the bytes per load (attn_f16.hip)
+        return launch_attention_simple(d, s);                                            // f32 MFMA on the widened values (attn_simple.hip; it checks)
+    }
     if (d.k_private > 0) {  // shared trailing keys: one shape implements them
         SOLA_ARG(attention_shared_keys_supported(d), "attention: shared keys (k_private %d of %d) need the few-keys shape (f32 q/k/v, head_dim 128, <= 64 keys, >= 128 queries, no unit tables)", d.k_private, d.Sk);
         return launch_attention_res(d, s);

@@ -35,7 +35,24 @@ struct AttnHArgs {
     int* guard;
     const int4 *q_units, *k_units;
     int qpb;  // consecutive 64-query blocks of a unit per thread block (> 1 only where the unit's keys fit one tile: K / V staged once)
+    // TR instantiation (round 6: the bf16 training forward on bfloat16 q / k / v, AttnDesc::in_bf16): f32 output rows (optional), the
+    // bfloat16 copy the out-projection takes as its operand (optional), the log-sum-exp of the scaled scores, dropout on the probabilities
+    float* o32;
+    float* lse;
+    DropoutCfg drop;
 };
+typedef short short4v __attribute__((ext_vector_type(4)));
+// one 16x16x16 product on f16 or - BF - bfloat16 operands (the 16-bit values travel as _Float16-typed bit patterns either way)
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma_16x16x16(const half4v a, const half4v b, const f32x4 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a), __builtin_bit_cast(short4v, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ _Float16 cvt_16(float x) {
+    if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)x);
+    else return (_Float16)x;
+}
 
 int g_attn_f16_small = 1;
 int g_attn_f16_qpb = 4;  // sola_tune "attn_f16_qpb": q-blocks per block against <= 64 keys, at most (1 = every q-block stages the unit's K / V itself; < 0: exactly -v, tests)  // sola_tune "attn_f16_small": 0 = the MFMA shape for sequences of <= 4 steps too (A/B)
@@ -58,7 +75,9 @@ __device__ __forceinline__ GeoH geo_h(const AttnHArgs& a, int grp) {
 // WPU = wave per unit (sequences of <= 16 steps): the block's four waves serve four different (group, head) units
 // (Round 5, measured and removed: two 32-key LDS stages with the next tile's rows prefetched in registers, attn_fwd_f32_simple_kernel's DB
 // shape - 161 vs 151 us at the 128-key inter-object site, equal at 64 keys: at four blocks per CU the other blocks already cover a tile's load.)
-template <int DH, bool WPU>
+// BF: bfloat16 operands (v_mfma_f32_16x16x16_bf16).  TR: the training forward - the log-sum-exp of every query row, dropout on the
+// probabilities (the row sum stays undropped, as in attn_simple.hip), the output as f32 rows and / or as the 16-bit rows the out-projection reads.
+template <int DH, bool WPU, bool BF = false, bool TR = false>
 __global__ __launch_bounds__(256, WPU ? 2 : 4) void attn_fwd_f16_kernel(const AttnHArgs a) {
     constexpr int NC = DH / 16;        // 16-wide head-dim chunks
     constexpr bool PAIR = NC % 2 == 0; // chunk pairs with 16-byte accesses (head_dim 16: the 8-byte fragment shapes)
@@ -156,15 +175,15 @@ __global__ __launch_bounds__(256, WPU ? 2 : 4) void attn_fwd_f16_kernel(const At
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
                             const half4v kf = *reinterpret_cast<const half4v*>(kp + c * 16);
-                            if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc1, 0, 0, 0);
-                            else acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[c], acc0, 0, 0, 0);
+                            if (c & 1) acc1 = mfma_16x16x16<BF>(kf, qf[c], acc1);
+                            else acc0 = mfma_16x16x16<BF>(kf, qf[c], acc0);
                         }
                     }
 #pragma unroll
                     for (int cp = 0; cp < NC / 2; ++cp) {
                         const half8v k8 = *reinterpret_cast<const half8v*>(kp + cp * 32);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(half4v{k8[0], k8[1], k8[2], k8[3]}, qf[2 * cp], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(half4v{k8[4], k8[5], k8[6], k8[7]}, qf[2 * cp + 1], acc1, 0, 0, 0);
+                        acc0 = mfma_16x16x16<BF>(half4v{k8[0], k8[1], k8[2], k8[3]}, qf[2 * cp], acc0);
+                        acc1 = mfma_16x16x16<BF>(half4v{k8[4], k8[5], k8[6], k8[7]}, qf[2 * cp + 1], acc1);
                     }
                     const int key0 = kt0 + t * 16 + 4 * g4;
 #pragma unroll
@@ -197,13 +216,23 @@ __global__ __launch_bounds__(256, WPU ? 2 : 4) void attn_fwd_f16_kernel(const At
             m_run = m_new;
 #pragma unroll
             for (int c = 0; c < NC; ++c) oacc[c] *= alpha;
+            if constexpr (TR) {
+                if (a.drop.enabled) {  // dropout acts on the normalised probabilities: the row sum above stays undropped (attn.hip)
+                    const unsigned long long rbase = ((unsigned long long)(grp * a.H + h) * g.Sq + qi) * g.Sk;
+#pragma unroll
+                    for (int t = 0; t < TROWS / 16; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            sc[t][r] = dropout_keep(a.drop, rbase + kt0 + t * 16 + 4 * g4 + r) ? sc[t][r] * a.drop.scale : 0.f;
+                }
+            }
             // O^T += V^T P^T
 #pragma unroll
             for (int t = 0; t < TROWS / 16; ++t) {
                 if (t < ntile) {
                     half4v pf;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pf[r] = (_Float16)sc[t][r];
+                    for (int r = 0; r < 4; ++r) pf[r] = cvt_16<BF>(sc[t][r]);
                     // MFMA row m = c16 -> element 32 cp + 8 (m >> 2) + (m & 3) [+ 4] (PAIR), else 16 c + m
                     const _Float16* vp = &Vs[(t * 16 + 4 * g4) * LD + (PAIR ? 8 * (c16 >> 2) + (c16 & 3) : c16)];
 #pragma unroll
@@ -211,10 +240,36 @@ __global__ __launch_bounds__(256, WPU ? 2 : 4) void attn_fwd_f16_kernel(const At
                         half4v vf;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) vf[j] = vp[j * LD + (PAIR ? (c >> 1) * 32 + (c & 1) * 4 : c * 16)];
-                        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, oacc[c], 0, 0, 0);
+                        oacc[c] = mfma_16x16x16<BF>(vf, pf, oacc[c]);
                     }
                 }
             }
+        }
+        if constexpr (TR) {
+            static_assert(!TR || PAIR, "training instantiation: head_dim a multiple of 32");
+            if (q_ok) {
+                const float inv = 1.f / l_run;
+                const long long row = g.q0 + (long long)qi * g.q_rs;
+                if (a.lse && g4 == 0) a.lse[row * a.H + h] = m_run + logf(l_run);
+                const long long eo = row * a.ldo + h * DH + 8 * g4;
+#pragma unroll
+                for (int cp = 0; cp < NC / 2; ++cp) {
+                    float v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v8[j] = oacc[2 * cp + (j >> 2)][j & 3] * inv;
+                    if (a.o32) {
+                        *reinterpret_cast<float4*>(a.o32 + eo + cp * 32) = make_float4(v8[0], v8[1], v8[2], v8[3]);
+                        *reinterpret_cast<float4*>(a.o32 + eo + cp * 32 + 4) = make_float4(v8[4], v8[5], v8[6], v8[7]);
+                    }
+                    if (a.o) {
+                        half8v o8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o8[j] = cvt_16<BF>(v8[j]);
+                        *reinterpret_cast<half8v*>(a.o + eo + cp * 32) = o8;
+                    }
+                }
+            }
+            continue;
         }
         if (q_ok) {
             const float inv = 1.f / l_run;
@@ -378,7 +433,56 @@ int launch_h(const AttnHArgs& a0, hipStream_t s) {
     return SOLA_OK;
 }
 
+// training forward on bfloat16 q / k / v (head_dim 128 / 64): one wave per unit for sequences of <= 16 steps, else 64-query blocks
+template <int DH>
+int launch_h_bf16_train(const AttnHArgs& a0, hipStream_t s) {
+    AttnHArgs a = a0;
+    constexpr int LD = DH + 8;
+    const long long units = (long long)a.G * a.H;
+    if (a.Sq <= 16 && a.Sk <= 16) {
+        a.nqb = 1; a.qpb = 1;
+        const size_t lds = (size_t)4 * 2 * 16 * LD * sizeof(_Float16);
+        hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, true, true, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, s, a);
+    } else {
+        a.nqb = (a.Sq + 63) / 64;
+        a.qpb = 1;
+        if (a.Sk <= 64 && g_attn_f16_qpb > 1)
+            while (a.qpb < g_attn_f16_qpb && a.qpb * 2 <= a.nqb && units * ((a.nqb + 2 * a.qpb - 1) / (2 * a.qpb)) >= 8ll * sola_cu_count()) a.qpb *= 2;
+        const long long blocks = units * ((a.nqb + a.qpb - 1) / a.qpb);
+        SOLA_ARG(blocks < (1ll << 31), "attention (bf16): grid too large");
+        const size_t lds = (size_t)2 * 64 * LD * sizeof(_Float16);
+        hipLaunchKernelGGL((attn_fwd_f16_kernel<DH, false, true, true>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    }
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 }  // namespace
+
+int g_attn_bf16_mfma = 1;  // sola_tune "attn_bf16_mfma": 1 = bf16 training forward on the bf16 MFMA (this file); 0 = the f32-MFMA kernel on widened values (attn_simple.hip)
+void sola_attn_set_bf16_mfma(int v) { g_attn_bf16_mfma = v; }
+// AttnDesc::in_bf16 launches this kernel takes: head_dim 128 / 64, 16-byte aligned rows, no shared keys, f32 and / or bf16 (o_cast_fmt 3) output
+bool attention_bf16_mfma_supported(const AttnDesc& d) {
+    return g_attn_bf16_mfma && d.in_bf16 && !d.o_sp16 && !d.in_sp16 && !d.k_private && (d.DH == 128 || d.DH == 64) && d.ldq % 8 == 0 && d.ldk % 8 == 0 &&
+           d.ldv % 8 == 0 && d.ldo % 8 == 0 && (!d.o_cast || d.o_cast_fmt == 3) && (d.o || d.o_cast);
+}
+int launch_attention_bf16_train(const AttnDesc& d, hipStream_t s) {
+    SOLA_ARG(d.G > 0 && d.H > 0 && d.Sq > 0 && d.Sk > 0 && d.inner > 0 && attention_bf16_mfma_supported(d), "attention (bf16): unsupported launch");
+    AttnHArgs a;
+    a.q = reinterpret_cast<const _Float16*>(d.q); a.k = reinterpret_cast<const _Float16*>(d.k);
+    a.v = reinterpret_cast<const _Float16*>(d.v); a.o = reinterpret_cast<_Float16*>(d.o_cast);
+    a.o32 = d.o; a.lse = d.lse; a.drop = d.drop;
+    a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+    a.G = d.G; a.H = d.H; a.Sq = d.Sq; a.Sk = d.Sk; a.inner = d.inner; a.nqb = 1;
+    a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
+    a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
+    a.scale = d.scale; a.guard = nullptr; a.qpb = 1;
+    a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
+    if (d.o_cast && d.o_cast_done) *d.o_cast_done = true;
+    const double elems = (double)d.G * d.H * d.DH;
+    SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, elems * (2.0 * (d.Sq + 2.0 * d.Sk) + (d.o ? 4.0 : 0.0) * d.Sq + (d.o_cast ? 2.0 : 0.0) * d.Sq));
+    return d.DH == 128 ? launch_h_bf16_train<128>(a, s) : launch_h_bf16_train<64>(a, s);
+}
 
 void sola_attn_set_f16_small(int v) { g_attn_f16_small = v; }
 void sola_attn_set_f16_qpb(int v) { g_attn_f16_qpb = v == 0 ? 1 : v; }
@@ -396,6 +500,7 @@ int launch_attention_f16(const AttnDesc& d, hipStream_t s) {
     a.q_outer = d.q_outer; a.q_inner = d.q_inner; a.q_rs = d.q_rs;
     a.k_outer = d.k_outer; a.k_inner = d.k_inner; a.k_rs = d.k_rs;
     a.scale = d.scale; a.guard = d.guard; a.qpb = 1;
+    a.o32 = nullptr; a.lse = nullptr; a.drop = DropoutCfg{};
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     const double elems = (double)d.G * d.H * d.DH;
     SolaProfScope prof(SOLA_PROF_ATTN, s, 4.0 * elems * d.Sq * d.Sk, 2.0 * elems * (2.0 * d.Sq + 2.0 * d.Sk));

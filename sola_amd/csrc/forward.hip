@@ -354,7 +354,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         if (!gemm_tn_tr_supported(M, D, D, D, D) || (o2l && !gemm_tn_tr_supported((int)text_rows, D, D, D, D))) return false;
         AttnDesc f = ad;
         f.in_bf16 = 1;
-        if (!attention_in_bf16_supported(f)) return false;
+        f.o_cast = reinterpret_cast<void*>(1); f.o_cast_fmt = 3;  // (what attention() below hands the launch)
+        if (!attention_in_bf16_supported(f) && !attention_bf16_mfma_supported(f)) return false;
         AttnBwdDesc b{};
         b.ldq = b.ldk = b.ldv = b.ldo = D;
         b.ld_dq = 3 * D; b.ld_dk = b.ld_dv = o2l ? 2 * D : 3 * D;

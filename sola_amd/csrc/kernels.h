@@ -221,7 +221,8 @@ struct AttnDesc {
     bool* o_cast_done = nullptr;
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
-bool attention_in_bf16_supported(const AttnDesc& d);
+bool attention_in_bf16_supported(const AttnDesc& d);   // attn_simple.hip's f32-MFMA kernel on bfloat16 rows
+bool attention_bf16_mfma_supported(const AttnDesc& d);  // attn_f16.hip's bf16-MFMA training kernel (the default where it applies)
 bool attention_shared_keys_supported(const AttnDesc& d);  // d.k_private / k_shared_row can be honoured (the launch then takes attn_res.hip's shape)
 
 struct AttnBwdDesc {

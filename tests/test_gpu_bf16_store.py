@@ -79,8 +79,54 @@ def _attn_case(name):
 ATTN_CASES = ["inter_object", "inter_object_80", "motion_24", "motion_17x12", "object_to_language"]
 
 
+@pytest.mark.parametrize("case", ATTN_CASES + ["motion_12"])
+def test_attention_forward_on_the_bf16_mfma(case):
+    """The shipped bf16 training forward (attn_f16.hip's kernel on v_mfma_f32_16x16x16_bf16, sola_tune "attn_bf16_mfma" 1): q k^T products of
+    bfloat16 values are exact in f32, so the scores and the log-sum-exp carry f32 accumulation error only (1e-5); the probabilities enter the
+    P V product rounded to bfloat16 (what every 16-bit flash attention does), so the output is within 2^-8 of float64 attention on the widened
+    values, relative to the largest |v| a row can see; the bf16 copy is the rounding of the f32 rows."""
+    H = 8
+    if case == "motion_12":  # one wave per unit: sequences of <= 16 steps
+        G, Sq, Sk, inner, qa, ka, qrows, krows = 50, 12, 12, 1, (12, 0, 1), (12, 0, 1), 600, 600
+    else:
+        G, H, Sq, Sk, inner, qa, ka, qrows, krows = _attn_case(case)
+    D = H * 128
+    torch.manual_seed(3 + len(case))
+    q16, k16, v16 = (bf(torch.randn(n, D, device="cuda") * sc) for n, sc in ((qrows, 1.0), (krows, 1.0), (krows, 1.0)))
+    o = torch.zeros(qrows, D, device="cuda")
+    o16 = torch.zeros(qrows, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(qrows, H, device="cuda")
+    scale = 1.0 / math.sqrt(128)
+    check(lib().sola_attention_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o), ptr(o16), D, G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2],
+                                    ka[0], ka[1], ka[2], scale, ptr(lse), current_stream(q16.device)), "attention_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(o16, o.to(torch.bfloat16))
+    qd, kd, vd = q16.double().cpu(), k16.double().cpu(), v16.double().cpu()
+    worst_o = worst_l = 0.0
+    for g in (0, G // 2, G - 1):
+        qr = [(g // inner) * qa[0] + (g % inner) * qa[1] + i * qa[2] for i in range(Sq)]
+        kr = [(g // inner) * ka[0] + (g % inner) * ka[1] + i * ka[2] for i in range(Sk)]
+        for h in (0, H - 1):
+            sl = slice(h * 128, (h + 1) * 128)
+            sc = qd[qr][:, sl] @ kd[kr][:, sl].t() * scale
+            ref = torch.softmax(sc, dim=-1) @ vd[kr][:, sl]
+            worst_o = max(worst_o, float((o.cpu().double()[qr][:, sl] - ref).abs().max()) / float(vd[kr][:, sl].abs().max()))
+            worst_l = max(worst_l, float((lse.cpu().double()[qr][:, h] - torch.logsumexp(sc, dim=-1)).abs().max()))
+    print(f"{case}: bf16-MFMA attention vs float64: output {worst_o:.2e} of max|v|, log-sum-exp {worst_l:.2e}")
+    assert worst_o <= 2.0 ** -8 and worst_l <= 2e-5
+
+
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_attention_forward_on_bf16_rows_equals_the_f32_kernel_on_the_widened_values(case):
+    """(sola_tune "attn_bf16_mfma" 0: the f32-MFMA kernel of attn_simple.hip on bfloat16 rows - the shapes the bf16-MFMA kernel does not take)"""
+    check(lib().sola_tune(b"attn_bf16_mfma", 0), "tune")
+    try:
+        _forward_f32_mfma_case(case)
+    finally:
+        check(lib().sola_tune(b"attn_bf16_mfma", 1), "tune")
+
+
+def _forward_f32_mfma_case(case):
     G, H, Sq, Sk, inner, qa, ka, qrows, krows = _attn_case(case)
     D = H * 128
     torch.manual_seed(len(case))
