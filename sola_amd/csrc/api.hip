@@ -296,6 +296,7 @@ void sola_iou_set_fused(int v);
 void sola_attn_set_split_min_keys(int v);
 void sola_attn_set_bwd_fused(int v);
 void sola_attn_set_bwd_ablate(int v);
+void sola_attn_set_bwd_bf16_mfma(int v);
 void sola_attn_set_f16_small(int v);
 void sola_gn_set_h8(int v);
 void sola_attn_set_spin(int v);
@@ -421,6 +422,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "iou_shape")) { sola_iou_set_shape(value); return SOLA_OK; }
     if (!strcmp(key, "train_bf16_store")) { g_train_bf16_store = value; return SOLA_OK; }
     if (!strcmp(key, "attn_bf16_mfma")) { sola_attn_set_bf16_mfma(value); return SOLA_OK; }
+    if (!strcmp(key, "attn_bwd_bf16_mfma")) { sola_attn_set_bwd_bf16_mfma(value); return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }

@@ -693,8 +693,18 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
 // IO16 (round 6): bf16 q / k / v in, bf16 dQ / dK / dV out (AttnBwdArgs::io16).  Only the loads and the stores differ: q rows are widened on
 // their way into the f32 LDS tile (four-wave shape: the next tile's q piece travels in four registers beside the DMA of dO and O), k / v
 // fragments are 8-byte loads, the gradients leave as 8-byte rows of four values.
-template <int NWU, bool IO16 = false>
+// MF (round 6, with IO16; sola_tune "attn_bwd_bf16_mfma"): the five products run on v_mfma_f32_16x16x16_bf16 - every group of four f32
+// MFMAs over the register slots (.x .y .z .w of a row chunk, or r = 0..3 of a C-layout tile) is ONE bf16 MFMA whose operand is those four
+// values packed: q / k / v are bfloat16 already (exact), dO, the probabilities and dS are rounded to bfloat16 (nearest even) - the operand
+// precision torch's autocast backward has; accumulation, the softmax terms, D = dO . O and the output sums stay f32.  K is NOT pre-scaled
+// here (scale * k is not a bfloat16): S and dQ take the scale behind their products.  160 -> 40 matrix instructions per (query tile, key
+// tile) at 8x the rate: the f32 matrix time was a third of the kernel on ragged batches.
+template <int NWU, bool IO16 = false, bool MF = false>
 __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnBwdArgs a) {
+    static_assert(!MF || IO16, "the bf16 products take bf16 q / k / v");
+    typedef short short4m __attribute__((ext_vector_type(4)));
+    auto pk4 = [](float x, float y, float z, float w) -> short4m { return __builtin_bit_cast(short4m, f32x4_to_bf16(x, y, z, w)); };
+    auto mf16 = [](const short4m x, const short4m y, const f32x4 c) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c, 0, 0, 0); };
     constexpr int DH = 128, NC = DH / 16, LD = DH + 4, F4 = DH / 4, NT = 64 * NWU;
     // NWU = 4: the next tile's q, dO and O rows travel straight into LDS (global_load_lds, no registers) under the current tile's
     // MFMAs - two tile buffers.  The LDS side of the instruction is lane-linear (base + 16 * lane = two 512-byte rows back to back),
@@ -807,7 +817,32 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         if constexpr (DMA) issue_tile(qt_begin * 16, 0);  // under the K / V loads
         float4 kf[NC], vf[NC];
         float kT[NC][4];
-        {
+        short4m kfh[NC], vfh[NC], kTh[NC];  // MF: the same three fragment sets as bfloat16 operands - the raw values, no widening
+        if constexpr (MF) {
+            const unsigned short* kp16 = reinterpret_cast<const unsigned short*>(a.k) + krow * a.ldk + h * DH + 4 * g4;
+            const unsigned short* vp16 = reinterpret_cast<const unsigned short*>(a.v) + krow * a.ldv + h * DH + 4 * g4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const uint2 kl = *reinterpret_cast<const uint2*>(kp16 + c * 16), vl = *reinterpret_cast<const uint2*>(vp16 + c * 16);
+                kfh[c] = __builtin_bit_cast(short4m, make_uint2(k_ok ? kl.x : 0u, k_ok ? kl.y : 0u));
+                vfh[c] = __builtin_bit_cast(short4m, make_uint2(k_ok ? vl.x : 0u, k_ok ? vl.y : 0u));
+            }
+            unsigned short kr[NC][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = kt * 16 + 4 * g4 + r;
+                const bool okr = w_ok && kk < geo.Sk;
+                const long long ro = (geo.k0 + (long long)(okr ? kk : 0) * geo.k_rs) * a.ldk + h * DH + c16;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const unsigned short v = reinterpret_cast<const unsigned short*>(a.k)[ro + c * 16];
+                    kr[c][r] = okr ? v : (unsigned short)0;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                kTh[c] = __builtin_bit_cast(short4m, make_uint2((unsigned)kr[c][0] | ((unsigned)kr[c][1] << 16), (unsigned)kr[c][2] | ((unsigned)kr[c][3] << 16)));
+        } else {
             const float* kp = a.k + krow * a.ldk + h * DH + 4 * g4;
             const float* vp = a.v + krow * a.ldv + h * DH + 4 * g4;
             const unsigned short* kp16 = reinterpret_cast<const unsigned short*>(a.k) + krow * a.ldk + h * DH + 4 * g4;
@@ -875,7 +910,11 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 for (int c = 0; c < NC; ++c) {
                     const float4 qv = *reinterpret_cast<const float4*>(at(Qs, cur, c16, c * 4 + g4));
                     const float4 gv = *reinterpret_cast<const float4*>(at(Gs, cur, c16, c * 4 + g4));
-                    if (c & 1) {
+                    if constexpr (MF) {
+                        const short4m qh = pk4(qv.x, qv.y, qv.z, qv.w), gh = pk4(gv.x, gv.y, gv.z, gv.w);
+                        if (c & 1) { s1 = mf16(qh, kfh[c], s1); p1 = mf16(gh, vfh[c], p1); }
+                        else { s0 = mf16(qh, kfh[c], s0); p0 = mf16(gh, vfh[c], p0); }
+                    } else if (c & 1) {
                         s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[c].x, s1, 0, 0, 0);
                         p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[c].x, p1, 0, 0, 0);
                         s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[c].y, s1, 0, 0, 0);
@@ -903,7 +942,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 for (int r = 0; r < 4; ++r) {
                     const int q = qt0 + 4 * g4 + r;
                     const bool ok = k_ok && q < geo.Sq;
-                    pr[r] = ok ? __expf((s0[r] + s1[r]) - lse_r[r]) : 0.f;
+                    pr[r] = ok ? __expf((s0[r] + s1[r]) * (MF ? a.scale : 1.f) - lse_r[r]) : 0.f;
                     const float dp = p0[r] + p1[r];
                     float keep = 1.f;
                     if (a.drop.enabled)
@@ -912,6 +951,17 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                     pr[r] *= keep;  // dV uses the dropped probabilities
                 }
                 // dV^T[d][key] += sum_q dO[q][d] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+                if constexpr (MF) {
+                    const short4m prh = pk4(pr[0], pr[1], pr[2], pr[3]), dsh4 = pk4(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const int ch = c * 4 + (c16 >> 2), e = c16 & 3, R0 = 4 * g4;
+                        const float g0 = at(Gs, cur, R0, ch)[e], g1 = at(Gs, cur, R0 + 1, ch)[e], g2 = at(Gs, cur, R0 + 2, ch)[e], g3 = at(Gs, cur, R0 + 3, ch)[e];
+                        const float q0 = at(Qs, cur, R0, ch)[e], q1 = at(Qs, cur, R0 + 1, ch)[e], q2 = at(Qs, cur, R0 + 2, ch)[e], q3 = at(Qs, cur, R0 + 3, ch)[e];
+                        dvacc[c] = mf16(pk4(g0, g1, g2, g3), prh, dvacc[c]);
+                        dkacc[c] = mf16(pk4(q0, q1, q2, q3), dsh4, dkacc[c]);
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int R = 4 * g4 + r;
@@ -923,6 +973,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                         dkacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qcol, ds[r], dkacc[c], 0, 0, 0);
                     }
                 }
+                }
                 // dS with the KEY on the contraction slots: through the wave's own 16 x 17 words of LDS
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tsc[(4 * g4 + r) * 17 + c16] = ds[r];
@@ -932,10 +983,19 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 for (int r = 0; r < 4; ++r) dst[r] = tsc[c16 * 17 + 4 * g4 + r];  // dS[q = c16][key = 4*g4 + r]
                 stage_sync<true>();  // the next tile's writes stay behind these reads
                 // dQ^T[d][q] += sum_key K[key][d] * dS[q][key]   (K pre-scaled)
+                if constexpr (MF) {
+                    const short4m dsth = pk4(dst[0], dst[1], dst[2], dst[3]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        dqacc[c] = mf16(kTh[c], dsth, dqacc[c]);
+                        dqacc[c] *= a.scale;  // K was not pre-scaled
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int c = 0; c < NC; ++c) dqacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kT[c][r], dst[r], dqacc[c], 0, 0, 0);
+                }
                 if constexpr (NWU > 1) {
                     float* sl = slots + wave * 16 * LD + c16 * LD + 4 * g4;
 #pragma unroll
@@ -1073,7 +1133,8 @@ int g_attn_bwd_small = 1;  // sola_tune "attn_bwd_small": 0 = two-pass kernels f
 int g_attn_bwd_ablate = 0;  // measurement only (sola_tune "attn_bwd_ablate"): 1 = no tile arithmetic, 2 = only the first tile staged
 int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
 
-template <int NWU, bool IO16>
+int g_attn_bwd_bf16_mfma = 1;  // sola_tune "attn_bwd_bf16_mfma": 0 = the bf16-row launches keep the f32 products (bit-identical to the f32 kernel on the widened values)
+template <int NWU, bool IO16, bool MF = false>
 static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     constexpr int LD = 128 + 4;
     constexpr bool DMA = NWU == 4;  // as in the kernel
@@ -1081,12 +1142,12 @@ static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const long long blocks = (long long)a.G * a.H;
     SOLA_ARG(blocks < (1ll << 31) && chunks < 65536, "attention backward: grid too large");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16, MF>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (a.qc_tiles) {
         // few (unit, head) pairs: the positions of a unit (at most 16 NWU keys x 64 float4) over several blocks
@@ -1114,6 +1175,11 @@ static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, long long part_rows, 
     if (a.Sq > 16 * qc && can_chunk) {
         a.qc_tiles = qc;
         chunks = ((a.Sq + 15) / 16 + qc - 1) / qc;
+    }
+    if (a.io16 && g_attn_bwd_bf16_mfma) {
+        if (a.Sk <= 16) return launch_bwd_fused_n<1, true, true>(a, chunks, s);
+        if (a.Sk <= 32) return launch_bwd_fused_n<2, true, true>(a, chunks, s);
+        return launch_bwd_fused_n<4, true, true>(a, chunks, s);
     }
     if (a.io16) {
         if (a.Sk <= 16) return launch_bwd_fused_n<1, true>(a, chunks, s);
@@ -1229,6 +1295,7 @@ void sola_attn_set_bwd_blk(int v) { g_attn_bwd_blk = v; }
 void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
 void sola_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
 void sola_attn_set_bwd_ablate(int v) { g_attn_bwd_ablate = v; }
+void sola_attn_set_bwd_bf16_mfma(int v) { g_attn_bwd_bf16_mfma = v; }
 
 // bf16 q / k / v in and bf16 dQ / dK / dV out (AttnBwdDesc::io_bf16): the one-pass kernel's shapes, 8-value-aligned rows
 bool attention_bwd_bf16_supported(const AttnBwdDesc& d) {

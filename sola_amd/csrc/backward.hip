@@ -753,7 +753,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.conv = g.k > 1 ? 1 : 0; d.T_in = t_in; d.T_out = p.Tl[i]; d.stride = g.stride; d.pad = g.pad; d.Cin = g.cin;
             d.rowmap = rowmap; d.B_rows = rows_in;
             if (cast_src == dy && cast_ld == g.cout && cast_cols == g.cout) { d.a_rm = ar.get("dy_sp"); d.a_rm_ld = g.cout; d.a_rm_ready = 1; }
-            if ((pure || dw16) && i > 0) d.B16[0] = c->x16_find(x_in, g.cin, pure ? 1 + bf : 1);
+            if ((pure || dw16) && (i > 0 || (pure && bf))) d.B16[0] = c->x16_find(i == 0 ? c->last_obj : x_in, g.cin, pure ? 1 + bf : 1);
             d.scratch = ar.get("tns"); d.scratch_bytes = ar.total - ar.off.at("tns");
             SOLA_TRY(launch_gemm_tn_split(d, s));
             if (scc) SOLA_TRY(bias_from_stats(0, g.cout, G(cp + ".bias")));

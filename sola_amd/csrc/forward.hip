@@ -257,7 +257,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         if (rs && gd.conv) { gd.rowmap = rt.rowmap[i]; gd.T_in = 1; gd.T_out = 1; }
         gd.splitk_ws = splitk_ws; gd.splitk_bytes = splitk_bytes;
         if (split && g.cin % (pure ? 64 : 32) == 0) {
-            if (i == 0) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip)
+            if (i == 0 && !(pure && bf)) {  // the caller's tokens: data-dependent power-of-two scale (forward_fast.hip); bfloat16 has f32's range -
+                                            // its cast is the fixed-scale one below, kept for the backward's dW product like every other operand
                 SOLA_TRY(cast_auto(x, g.cin, sp_a, level_rows(i), g.cin, c->scal_pair(0)));
                 gd.out_scale_dev = c->scal_pair(0) + 1;
                 gd.p[0].A = sp_a;

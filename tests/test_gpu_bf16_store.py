@@ -158,6 +158,23 @@ def _forward_f32_mfma_case(case):
 
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_attention_backward_on_bf16_rows_equals_the_f32_kernel_and_writes_the_rounded_gradients(case):
+    """(sola_tune "attn_bwd_bf16_mfma" 0: the f32 products on bfloat16 rows - bit-identical to the f32 kernel on the widened values)"""
+    check(lib().sola_tune(b"attn_bwd_bf16_mfma", 0), "tune")
+    try:
+        _backward_case(case, exact=True)
+    finally:
+        check(lib().sola_tune(b"attn_bwd_bf16_mfma", 1), "tune")
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_backward_on_the_bf16_mfma(case):
+    """The shipped bf16 backward (attn_bwd_fused_kernel<.., true, true>: the five products on v_mfma_f32_16x16x16_bf16 with dO, the probabilities
+    and dS rounded to bfloat16, f32 accumulation and softmax terms) against the f32 kernel on the same bfloat16 q / k / v: the operand roundings
+    are 2^-9 relative per factor, so every gradient row is within 2^-6 of the largest entry of its matrix (measured: ~2^-8)."""
+    _backward_case(case, exact=False)
+
+
+def _backward_case(case, exact):
     G, H, Sq, Sk, inner, qa, ka, qrows, krows = _attn_case(case)
     D = H * 128
     torch.manual_seed(100 + len(case))
@@ -179,9 +196,16 @@ def test_attention_backward_on_bf16_rows_equals_the_f32_kernel_and_writes_the_ro
                                              3 * D, 3 * D, 3 * D, ptr(dq_scr), ptr(dvec), G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2], ka[0], ka[1], ka[2],
                                              1.0 / math.sqrt(128), qrows, ptr(scr) if n_scr else None, n_scr, current_stream(q16.device)), "attention_backward_bf16")
     torch.cuda.synchronize()
-    assert torch.equal(g16[:, :D], dq.to(torch.bfloat16))
-    assert torch.equal(gk16[:, D:2 * D], dk.to(torch.bfloat16))
-    assert torch.equal(gk16[:, 2 * D:], dv.to(torch.bfloat16))
+    if exact:
+        assert torch.equal(g16[:, :D], dq.to(torch.bfloat16))
+        assert torch.equal(gk16[:, D:2 * D], dk.to(torch.bfloat16))
+        assert torch.equal(gk16[:, 2 * D:], dv.to(torch.bfloat16))
+    else:
+        for name, got, ref in (("dq", g16[:, :D], dq), ("dk", gk16[:, D:2 * D], dk), ("dv", gk16[:, 2 * D:], dv)):
+            err = float((got.float() - ref).abs().max()) / float(ref.abs().max())
+            cos = float((got.float() * ref).sum() / (got.float().norm() * ref.norm()))
+            print(f"{case} {name}: max err / max|ref| {err:.2e}, cosine {cos:.6f}")
+            assert err <= 2.0 ** -6 and cos >= 0.9995, (name, err, cos)
     if krows != qrows:
         assert torch.all(g16[:, D:] == 7.0)  # nothing outside the addressed slices
 
