@@ -497,8 +497,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     // by a statistics-and-cast pass that read the f32 matrix back (launch_cast_bf16_colsum); the f32 rows stay (residual stream)
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
-                      int leaky, const DropoutCfg* drop, const int4* units = nullptr, void* dx16 = nullptr, bool x_bf16 = false) -> int {
+                      int leaky, const DropoutCfg* drop, const int4* units = nullptr, void* dx16 = nullptr, bool x_bf16 = false,
+                      const void* stats_in = nullptr) -> int {
         GroupNormBwdDesc d{};
+        d.stats_in = stats_in;
         if (drop) d.drop = *drop;
         d.units = units;
         d.dx16 = dx16;
@@ -585,7 +587,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "object2lang_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); dlkv = keep((size_t)BW * 2 * D); }
             SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, max_rows_smp, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 2 < c->res16.size() && c->res16[(size_t)l * 3 + 2]));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 2 < c->res16.size() && c->res16[(size_t)l * 3 + 2],
+                            ((size_t)l < c->gn2_stats.size() && c->gn2_stats[l]) ? fb("l" + std::to_string(l) + "_gn2st") : nullptr));
             SOLA_TRY(out_proj_bwd(2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,

@@ -21,6 +21,7 @@ struct GnBwdArgs {
     const int4* units;  // ragged batches: (first row, row stride, token count, -) per instance (GroupNormBwdDesc::units)
     unsigned short* dx16;  // optional (round 6): dx once more as bfloat16 rows of the same pitch - the operand of the GEMMs that consume it
     int x_bf16;            // round 6: x (the saved pre-norm rows) is a bfloat16 matrix of the same pitch
+    const float2* stats;   // round 6, three-pass kernel: the forward's (mean, rstd) per (instance, group) - no statistics walks (GroupNormBwdDesc::stats_in)
 };
 __device__ __forceinline__ float4 gnb_load_x(const GnBwdArgs& a, long long off) {
     if (a.x_bf16) {
@@ -88,22 +89,28 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
     const bool active = tl < tpp;
     const float cnt = (float)ntok * (float)a.cg;
 
-    float s = 0.f;
-    if (active)
-        for (int t = tl; t < ntok; t += tpp) {
-            const float4 v = gnb_load_x(a, (row0 + (long long)t * tok_stride) * a.C + ch);
-            s += (v.x + v.y) + (v.z + v.w);
-        }
-    const float mean = bwd_block_sum<NTHR>(s, red) / cnt;
-    float q = 0.f;
-    if (active)
-        for (int t = tl; t < ntok; t += tpp) {
-            const float4 v = gnb_load_x(a, (row0 + (long long)t * tok_stride) * a.C + ch);
-            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-    const float var = bwd_block_sum<NTHR>(q, red) / cnt;
-    const float rstd = 1.0f / sqrtf(var + a.eps);
+    float mean, rstd;
+    if (a.stats) {  // block-uniform: the forward's statistics of this unit (two of the four walks over x are gone)
+        const float2 st = a.stats[blockIdx.x];
+        mean = st.x; rstd = st.y;
+    } else {
+        float s = 0.f;
+        if (active)
+            for (int t = tl; t < ntok; t += tpp) {
+                const float4 v = gnb_load_x(a, (row0 + (long long)t * tok_stride) * a.C + ch);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        mean = bwd_block_sum<NTHR>(s, red) / cnt;
+        float q = 0.f;
+        if (active)
+            for (int t = tl; t < ntok; t += tpp) {
+                const float4 v = gnb_load_x(a, (row0 + (long long)t * tok_stride) * a.C + ch);
+                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        const float var = bwd_block_sum<NTHR>(q, red) / cnt;
+        rstd = 1.0f / sqrtf(var + a.eps);
+    }
 
     float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), be = ga;
     if (active) {
@@ -635,6 +642,7 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.units = d.units;
     a.dx16 = static_cast<unsigned short*>(d.dx16);
     a.x_bf16 = d.x_bf16;
+    a.stats = static_cast<const float2*>(d.stats_in);
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
     const int f4 = cg / 4;

@@ -15,6 +15,8 @@ int g_train_attn_cast = 1;  // sola_tune "train_attn_cast": 1 = f16 / bf16 opera
 void sola_train_set_attn_cast(int v) { g_train_attn_cast = v; }
 int g_train_bf16_store = 2;  // sola_tune "train_bf16_store" (round 6): 1 = bf16 steps keep q / k / v and the backward's gradient operands as bfloat16 rows where the kernels take
                              // them; 2 (default) = also the pre-norm rows of the layers (out-projection + residual -> GroupNorm); 0 = f32 storage (the round-5 step)
+int g_train_gn_stats = 1;  // sola_tune "train_gn_stats": 1 = the training forward keeps the sliced GroupNorm shape's (mean, rstd) for the backward (A/B)
+void sola_train_set_gn_stats(int v) { g_train_gn_stats = v; }
 int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)
 int g_train_split_min_rows = 1024;  // sola_tune "train_split_min_rows": training takes the split-f16 GEMMs from this many token rows on
 void sola_set_train_split_min_rows(int v) { g_train_split_min_rows = v; }
@@ -74,6 +76,9 @@ void plan_fill(Plan& p, const SolaCtx* c, const PlanSizes& z, bool train) {
             }
         }
     for (int l = 0; l < c->cfg.n_layers; ++l) {
+        // training: (mean, rstd) of the object->language norm's (sample, group) units where the sliced shape computes them - the backward's
+        // three-pass kernel of those units then walks x twice instead of four times (GroupNormDesc::stats_out)
+        if (train) p.add("l" + std::to_string(l) + "_gn2st", z.S * c->cfg.n_groups_module, 2);
         p.add("l" + std::to_string(l) + "_obj", z.M, D);
         p.add("l" + std::to_string(l) + "_xpe", z.M, D);
         p.add("l" + std::to_string(l) + "_motion", z.M, D);
@@ -416,6 +421,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     };
     // next_src0 / next_src1: the FIRST / SECOND distinct input of the projection launch that follows (linear3 casts them into sp_a / sp_b in
     // that order): when one of them is this norm's y or y2, the norm writes the cast itself
+    int gn_layer = 0;  // the layer whose norms the loop below is launching
     auto gn = [&](const std::string& lp, int idx, const float* res, float* y, float* y2, int n_inst, int inner,
                   long long outer, long long inner_stride, long long tok_stride, int ntok, const int4* units = nullptr,
                   const float* next_src0 = nullptr, const float* next_src1 = nullptr, bool res_bf16 = false) -> int {
@@ -439,8 +445,18 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
         nd.tok_stride = tok_stride; nd.ntok = ntok; nd.C = D; nd.groups = c->cfg.n_groups_module;
         nd.eps = 1e-5f; nd.slope = 0.f; nd.leaky = 0;
         nd.units = units;
+        if (train && idx == 2 && g_train_gn_stats) {
+            const int l = gn_layer;
+            int wrote = 0;
+            nd.stats_out = buf("l" + std::to_string(l) + "_gn2st");
+            nd.stats_written = &wrote;
+            SOLA_TRY(launch_group_norm(nd, s));
+            if ((size_t)l < c->gn2_stats.size()) c->gn2_stats[l] = (char)wrote;
+            return SOLA_OK;
+        }
         return launch_group_norm(nd, s);
     };
+    c->gn2_stats.assign((size_t)c->cfg.n_layers, 0);
     c->res16.assign((size_t)c->cfg.n_layers * 3, 0);
     // the bf16 operand copy of a sub-block's input, if it sits in the kept-operand arena (a shared cast buffer is overwritten before the
     // out-projection runs) - then the sub-block's pre-norm rows are bfloat16 (out_proj / gn above)
@@ -451,6 +467,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     const float* xin = buf("conv5");
     for (int l = 0; l < c->cfg.n_layers; ++l) {
         const std::string lp = "object_lang_align_layers." + std::to_string(l) + ".";
+        gn_layer = l;
         const std::string ls = "l" + std::to_string(l);
         auto ab = [&](int a, const char* what) { return buf(abuf(train, l, kAttnShort[a], what)); };
         auto lse = [&](int a) -> float* { return train ? ab(a, "lse") : nullptr; };

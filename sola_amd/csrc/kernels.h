@@ -275,6 +275,9 @@ struct GroupNormBwdDesc {
     const int4* units;
     void* dx16 = nullptr;  // optional (round 6, bf16 steps): dx once more as bfloat16 rows, same pitch (C values)
     int x_bf16 = 0;        // round 6: x is a bfloat16 matrix (the bf16 step's pre-norm rows), same pitch
+    // optional (round 6): (mean, rstd) of every (instance, group) unit as the forward computed them (GroupNormDesc::stats_out) - the
+    // three-pass kernel of the largest units then skips its two statistics walks over x (the register shapes recompute: x is in registers)
+    const void* stats_in = nullptr;
 };
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
 struct WsBwdLayer {
@@ -366,6 +369,11 @@ struct GroupNormDesc {
     void* y_cast = nullptr;
     void* y2_cast = nullptr;
     int cast_fmt = 0;
+    // optional (round 6, training forward of the largest units): where the sliced shape leaves (mean, rstd) of every (instance, group) unit
+    // - [n_inst * groups] pairs - for the backward (GroupNormBwdDesc::stats_in); *stats_written (host) is set to 1 when the launch took
+    // that shape and wrote them, left alone otherwise
+    void* stats_out = nullptr;
+    int* stats_written = nullptr;
 };
 int launch_group_norm(const GroupNormDesc& d, hipStream_t s);
 // side16 (optional): also the plain f16 cast of the same values, contiguous [rows][K] halfs (= the hi halves)

@@ -85,6 +85,7 @@ struct GnArgs {
     const float* in_scale_dev;  // optional multiplier applied to x while reading (GroupNormDesc::in_scale_dev)
     void *y_cast, *y2_cast;     // f32 outputs: also their casts for the next GEMM (GroupNormDesc::y_cast)
     int cast_fmt;               // 2 f16, 3 bf16
+    float2* stats_out;          // sliced shape only: (mean, rstd) per unit for the backward (GroupNormDesc::stats_out)
 };
 
 typedef _Float16 half4n __attribute__((ext_vector_type(4)));
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(256) void group_norm_slice_apply_kernel(const GnArg
         }
     }
     const float rstd = 1.0f / sqrtf(m2 / ntot + a.eps);  // biased variance, as nn.GroupNorm
+    if (a.stats_out && q.sl == 0 && threadIdx.x == 0) a.stats_out[unit] = make_float2(mean, rstd);
     const int ch = q.g * a.cg + q.c4 * 4;
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
@@ -746,6 +748,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
     a.ntok = d.ntok; a.C = d.C; a.cg = cg; a.groups = d.groups; a.eps = d.eps; a.slope = d.slope; a.leaky = d.leaky; a.drop = d.drop; a.out_sp16 = d.out_sp16; a.guard = (d.out_sp16 || d.out_f16) ? d.guard : nullptr; a.units = d.units;
     a.in_f16 = d.in_f16; a.out_f16 = d.out_f16; a.in_scale_dev = d.in_scale_dev;
     a.y_cast = d.y_cast; a.y2_cast = d.y2_cast; a.cast_fmt = (d.y_cast || d.y2_cast) ? d.cast_fmt : 0;
+    a.stats_out = static_cast<float2*>(d.stats_out);
     SOLA_ARG(a.cast_fmt == 0 || (!d.out_sp16 && !d.out_f16 && a.cast_fmt >= 2 && a.cast_fmt <= 3 && (!d.y2_cast || d.y2)),
              "group_norm: operand casts go with f32 outputs (format 2 = f16, 3 = bf16)");
     SOLA_ARG(!(d.out_f16 && d.out_sp16), "group_norm: one output format at a time");
@@ -800,6 +803,7 @@ int launch_group_norm(const GroupNormDesc& d, hipStream_t s) {
             hipLaunchKernelGGL(group_norm_slice_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, S, slots);
             SOLA_LAUNCH_CHECK();
             hipLaunchKernelGGL(group_norm_slice_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, S, slots);
+            if (d.stats_out && d.stats_written) *d.stats_written = 1;
         } else {
             hipLaunchKernelGGL(group_norm_kernel, dim3((unsigned)n_units), dim3(256), 0, s, a);
         }
