@@ -1,6 +1,7 @@
 // Backward of the HBM-bound stages (autograd of module/module.py:76-92,34-49,152-160, module/ws.py:9-13,
 // train.py:98-113, tools/loss.py:29-56).  Same decomposition and deterministic reductions as the forward kernels.
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -117,12 +118,8 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
         ga = *reinterpret_cast<const float4*>(a.gamma + ch);
         be = *reinterpret_cast<const float4*>(a.beta + ch);
     }
-    auto grad_in = [&](long long off, const float4& xh) {
-        float4 d = *reinterpret_cast<const float4*>(a.dy + off);
-        if (a.dy2) {
-            const float4 e = *reinterpret_cast<const float4*>(a.dy2 + off);
-            d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
-        }
+    // dy' of one element quad from the loaded gradient: dropout mask and LeakyReLU slope as the forward applied them
+    auto grad_post = [&](long long off, const float4& xh, float4 d) {
         if (a.drop.enabled) {  // y = dropout(lrelu(gn(x))): the mask is regenerated from the element index
             d.x = dropout_keep(a.drop, (unsigned long long)off) ? d.x * a.drop.scale : 0.f;
             d.y = dropout_keep(a.drop, (unsigned long long)off + 1) ? d.y * a.drop.scale : 0.f;
@@ -137,20 +134,55 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
         }
         return d;
     };
+    // One walk over the unit's (x, dy) pairs, FOUR token slots per trip: their eight loads go out back to back (slots past the unit re-read
+    // the thread's first token and are skipped), the format of x is decided once around the walk.  One slot per trip was a dependent
+    // memory round trip per token: a 600-token unit took twenty of them per walk (round 6).
+    auto walk = [&](auto xb, auto&& body) {
+        constexpr bool XB = decltype(xb)::value;
+        constexpr int U = 4;
+        for (int t0 = tl; t0 < ntok; t0 += U * tpp) {
+            float4 xr[U], dr[U];
+            long long offs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * tpp;
+                offs[u] = (row0 + (long long)(t < ntok ? t : tl) * tok_stride) * a.C + ch;
+                if constexpr (XB) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + offs[u]);
+                    xr[u] = make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                                        __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+                } else {
+                    xr[u] = *reinterpret_cast<const float4*>(a.x + offs[u]);
+                }
+                dr[u] = *reinterpret_cast<const float4*>(a.dy + offs[u]);
+            }
+            if (a.dy2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 e = *reinterpret_cast<const float4*>(a.dy2 + offs[u]);
+                    dr[u].x += e.x; dr[u].y += e.y; dr[u].z += e.z; dr[u].w += e.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u * tpp < ntok) body(offs[u], xr[u], dr[u]);
+        }
+    };
     float s1 = 0.f, s2 = 0.f;
     float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
-    if (active)
-        for (int t = tl; t < ntok; t += tpp) {
-            const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-            const float4 v = gnb_load_x(a, off);
-            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-            const float4 d = grad_in(off, xh);
-            dgam.x += d.x * xh.x; dgam.y += d.y * xh.y; dgam.z += d.z * xh.z; dgam.w += d.w * xh.w;
-            dbet.x += d.x; dbet.y += d.y; dbet.z += d.z; dbet.w += d.w;
-            const float g0 = d.x * ga.x, g1 = d.y * ga.y, g2 = d.z * ga.z, g3 = d.w * ga.w;
-            s1 += (g0 + g1) + (g2 + g3);
-            s2 += (g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w);
-        }
+    auto sums = [&](long long off, const float4& v, const float4& dl) {
+        const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+        const float4 d = grad_post(off, xh, dl);
+        dgam.x += d.x * xh.x; dgam.y += d.y * xh.y; dgam.z += d.z * xh.z; dgam.w += d.w * xh.w;
+        dbet.x += d.x; dbet.y += d.y; dbet.z += d.z; dbet.w += d.w;
+        const float g0 = d.x * ga.x, g1 = d.y * ga.y, g2 = d.z * ga.z, g3 = d.w * ga.w;
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += (g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w);
+    };
+    if (active) {
+        if (a.x_bf16) walk(std::true_type{}, sums);
+        else walk(std::false_type{}, sums);
+    }
     const float m1 = bwd_block_sum<NTHR>(s1, red) / cnt;
     const float m2 = bwd_block_sum<NTHR>(s2, red) / cnt;
     // per-channel partials: reduce the token slots that share a channel quad
@@ -170,18 +202,18 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
         *reinterpret_cast<float4*>(a.dbp + o) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     if (!active) return;
-    for (int t = tl; t < ntok; t += tpp) {
-        const long long off = (row0 + (long long)t * tok_stride) * a.C + ch;
-        const float4 v = gnb_load_x(a, off);
+    auto apply = [&](long long off, const float4& v, const float4& dl) {
         const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-        const float4 d = grad_in(off, xh);
+        const float4 d = grad_post(off, xh, dl);
         float4 o;
         o.x = rstd * (d.x * ga.x - m1 - xh.x * m2);
         o.y = rstd * (d.y * ga.y - m1 - xh.y * m2);
         o.z = rstd * (d.z * ga.z - m1 - xh.z * m2);
         o.w = rstd * (d.w * ga.w - m1 - xh.w * m2);
         gn_store_dx(a, off, o);
-    }
+    };
+    if (a.x_bf16) walk(std::true_type{}, apply);
+    else walk(std::false_type{}, apply);
 }
 
 // Register-resident shape (as norm.hip's group_norm_reg_kernel): x and dy of the whole unit are read ONCE into 2 R float4 per
@@ -214,17 +246,33 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArg
     // Token slots beyond the unit load token 0 (always there) and are zeroed by a select: written as `t < ntok ? *(float4*)p : z` each
     // load became FOUR predicated 4-byte loads in an exec-mask region of its own, and the dy2 term a load + wait per slot (round 4,
     // tools/co_loads.py: 64 dword loads at R = 8; the inter-object norm's backward ran at half the speed its traffic allows).
+    // The format of x is decided ONCE around the whole batch of loads: with the test inside gnb_load_x every slot's load sat in a basic block
+    // of its own and the bfloat16 side waited for each 8-byte load before issuing the next (round 6, tools/co_dis.py: four dependent round
+    // trips at R = 4 - the bf16 steps' norms ran slower on 2-byte rows than on 4-byte ones).
+    auto load_all = [&](auto xb) {
+        constexpr bool XB = decltype(xb)::value;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int t = tl + r * tpp;
-        const bool ok = t < ntok;
-        const long long off = (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch;
-        const float4 xr = gnb_load_x(a, off);
-        const float4 dr = *reinterpret_cast<const float4*>(a.dy + off);
-        xv[r] = make_float4(ok ? xr.x : 0.f, ok ? xr.y : 0.f, ok ? xr.z : 0.f, ok ? xr.w : 0.f);
-        dv[r] = make_float4(ok ? dr.x : 0.f, ok ? dr.y : 0.f, ok ? dr.z : 0.f, ok ? dr.w : 0.f);
-        s += (xv[r].x + xv[r].y) + (xv[r].z + xv[r].w);
-    }
+        for (int r = 0; r < R; ++r) {
+            const int t = tl + r * tpp;
+            const bool ok = t < ntok;
+            const long long off = (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch;
+            float4 xr;
+            if constexpr (XB) {
+                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + off);
+                xr = make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                                 __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+            } else {
+                xr = *reinterpret_cast<const float4*>(a.x + off);
+            }
+            const float4 dr = *reinterpret_cast<const float4*>(a.dy + off);
+            xv[r] = make_float4(ok ? xr.x : 0.f, ok ? xr.y : 0.f, ok ? xr.z : 0.f, ok ? xr.w : 0.f);
+            dv[r] = make_float4(ok ? dr.x : 0.f, ok ? dr.y : 0.f, ok ? dr.z : 0.f, ok ? dr.w : 0.f);
+        }
+    };
+    if (a.x_bf16) load_all(std::true_type{});
+    else load_all(std::false_type{});
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += (xv[r].x + xv[r].y) + (xv[r].z + xv[r].w);
     if (a.dy2) {  // block-uniform: the second gradient of the inter-object norm (x_obj feeds x_obj + pe too)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
