@@ -738,26 +738,47 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
     auto at = [&](float* base, int buf, int r, int ch) -> float* {
         return DMA ? base + buf * 16 * RP + (r >> 1) * (2 * RP) + (r & 1) * DH + (ch << 2) : base + (buf * 16 + r) * RP + (ch << 2);
     };
-    // registers path: a tile's q and dO rows -> LDS; a row is the 32 float4 of half a wave, which also sums D = dO . O for it
+    // registers path: a tile's q and dO rows -> LDS; a row is the 32 float4 of half a wave, which also sums D = dO . O for it.
+    // SB row pieces per batch: their loads (q, dO, O and the row's log-sum-exp - every lane of the row fetches it, one address) go out back to
+    // back, then the batch is summed and stored.  MF shapes have the registers for whole batches of four (the two-wave shape's tile in ONE
+    // round trip); the f32-product shapes keep one / two pieces per trip (they spill otherwise).  Round 6: the rolled loop of the two-wave
+    // shape was 4 pieces x 2 dependent round trips (the log-sum-exp load sat in a branch of its own behind the others) per 16-query tile.
+    constexpr int SBW = MF ? (NWU == 2 ? 2 : 4) : STAGE_UNROLL;  // (four pieces in the two-wave MF shape: 256 registers and four spills)
+    constexpr int SB = SBW < PER ? SBW : PER;
+    static_assert(PER % SB == 0, "whole batches");
     auto stage_direct = [&](int qt0) {
-#pragma unroll STAGE_UNROLL
-        for (int j = 0; j < PER; ++j) {
-            const int idx = tid + j * NT, r = idx / F4, c4 = idx - r * F4;
-            const int q = qt0 + r;
-            const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
-            float4 qv;
-            if constexpr (IO16) qv = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.q) + row * a.ldq + h * DH + c4 * 4));
-            else qv = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
-            float4 gv = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
-            const float4 ov = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
-            if (q >= geo.Sq) qv = gv = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float d = half_sum32((ov.x * gv.x + ov.y * gv.y) + (ov.z * gv.z + ov.w * gv.w));
-            if (c4 == 0) {
-                dsh[r] = d;
-                lsh[r] = a.lse[row * a.H + h];
+#pragma unroll 1
+        for (int j0 = 0; j0 < PER; j0 += SB) {
+            float4 qf[IO16 ? 1 : SB], gv[SB], ov[SB];
+            uint2 qr[IO16 ? SB : 1];  // bf16 rows stay raw until they are stored (two registers a piece instead of four)
+            float ls[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = tid + (j0 + u) * NT, r = idx / F4, c4 = idx - r * F4;
+                const int q = qt0 + r;
+                const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
+                if constexpr (IO16) qr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.q) + row * a.ldq + h * DH + c4 * 4);
+                else qf[u] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
+                gv[u] = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
+                ov[u] = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
+                ls[u] = a.lse[row * a.H + h];
             }
-            *reinterpret_cast<float4*>(at(Qs, 0, r, c4)) = qv;
-            *reinterpret_cast<float4*>(at(Gs, 0, r, c4)) = gv;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = tid + (j0 + u) * NT, r = idx / F4, c4 = idx - r * F4;
+                const bool in = qt0 + r < geo.Sq;
+                float4 qv;
+                if constexpr (IO16) qv = bf16x4_to_f32(in ? qr[u] : make_uint2(0u, 0u));
+                else qv = in ? qf[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!in) gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float d = half_sum32((ov[u].x * gv[u].x + ov[u].y * gv[u].y) + (ov[u].z * gv[u].z + ov[u].w * gv[u].w));
+                if (c4 == 0) {
+                    dsh[r] = d;
+                    lsh[r] = ls[u];
+                }
+                *reinterpret_cast<float4*>(at(Qs, 0, r, c4)) = qv;
+                *reinterpret_cast<float4*>(at(Gs, 0, r, c4)) = gv[u];
+            }
         }
     };
     // DMA path: wave w moves row pairs 2w and 2w+1 of each of the three tensors, one pair (1 KB) per instruction; rows past the
