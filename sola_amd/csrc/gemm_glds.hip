@@ -60,6 +60,11 @@ struct GldsArgs {
     float gn_eps, gn_slope, gn_icnt;  // gn_icnt = 1 / (gn_tokens * 64)
     // persistent kernel, measurement (sola_tune "gemm_stagger" / "gemm_order" / "gemm_trace"; all 0 in production)
     int stagger;  // > 0: block b sleeps ((b >> 3) % 4) * stagger * 64 clocks before its first tile (de-synchronises the CUs' epilogues)
+    // round 6, 16-bit launches whose tiles are not whole rounds of the CUs: the blocks that get one tile FEWER than the others start late, at
+    // phases spread over most of a tile's time (slack * 64 clocks per k-tile at phase 1; 0 = off).  Their delay is free - they would idle at
+    // the end instead - and their epilogues (and k-loops) no longer coincide with those of the full-count blocks: the HBM bursts of the
+    // synchronised epilogues had every CU's matrix pipe waiting at once (sola_tune "gemm_slack_stagger"; profiles/r06_train_ragged_bf16.txt)
+    int slack;
     int order;    // tile order variant (decode())
     unsigned long long* trace;  // TRACE instantiation: per (block, wave) record, see gemm_trace_words
 };
@@ -1173,6 +1178,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         const int ph = (blockIdx.x >> 3) & 3;
         for (int q = 0; q < ph * a.stagger; ++q) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
     }
+    if (a.slack > 0) {
+        const int grid = (int)gridDim.x, first = total % grid;  // blocks first.. have one tile fewer (first == 0: whole rounds, nobody has slack)
+        if (first != 0 && (int)blockIdx.x >= first) {
+            const int nsl = grid - first, idx = (int)blockIdx.x - first;
+            const int n = (int)((long long)idx * a.slack * nk * 7 / (8LL * nsl));  // phases 0 .. 7/8 of a tile's time
+            for (int q = 0; q < n; ++q) __builtin_amdgcn_s_sleep(1);
+        }
+    }
     // TRACE: cycles this wave spent at the k-tile wait + barrier, in the k-loops and in the epilogues; per tile the real-time stamps
     // (100 MHz, low 32 bits) of the end of its k-loop and of its epilogue, lane t of two registers = tile t of this block
     unsigned long long tr_wait = 0, tr_loop = 0, tr_epi = 0, tr_t0 = 0, tr_t1 = 0, tr_first = 0;
@@ -2024,6 +2037,9 @@ int g_gemm_persist = 1;  // 256x256 shape: 1 = persistent kernel (one block per 
 void sola_gemm_set_persist(int v) { g_gemm_persist = v; }
 // measurement switches of the persistent kernel (sola_tune "gemm_stagger" / "gemm_order" / "gemm_trace"), all off in production
 int g_gemm_stagger = 0, g_gemm_order = 0, g_gemm_trace = 0, g_gemm_ld = 0;
+int g_gemm_slack_stagger = 40;  // sola_tune "gemm_slack_stagger": s_sleep(1) periods per k-tile at phase 1 for the blocks with a tile of slack (16-bit launches; 0 = off;
+                                // A/B on one box, ragged bf16 step: 0 -> 17.64-17.73 ms, 40 -> 17.46-17.51, 75 -> 17.54)
+void sola_gemm_set_slack_stagger(int v) { g_gemm_slack_stagger = v; }
 static unsigned long long* g_trace_buf = nullptr;  // [1024 blocks][8 waves][gemm_trace_words], allocated on first use
 constexpr size_t TRACE_BYTES = (size_t)1024 * 8 * gemm_trace_words * 8;
 // copies the trace of the LAST traced launch to the host (synchronises the device); returns the number of bytes written, < 0 on error
@@ -2240,6 +2256,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
     a.stagger = g_gemm_stagger; a.order = g_gemm_order; a.trace = nullptr;
+    a.slack = d.arith == 2 ? g_gemm_slack_stagger : 0;
     a.guard = (d.c_sp16 || d.c_f16) ? d.guard : nullptr;
     a.gn_gamma = d.gn_gamma; a.gn_beta = d.gn_beta; a.gn_tokens = d.gn_tokens; a.gn_eps = d.gn_eps; a.gn_slope = d.gn_slope;
     a.gn_icnt = d.gn_tokens > 0 ? 1.0f / (64.0f * (float)d.gn_tokens) : 0.f;
