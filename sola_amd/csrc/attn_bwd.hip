@@ -594,7 +594,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
 // float4 chunk c of every row, the TT x TT scores S = q k^T, dP = dO v^T and D = dO . o are per-lane partial dot products
 // all-reduced over the 32 lanes (DPP, common.h), P is recomputed from the saved log-sum-exp, dS = P o (dP - D), and dQ, dK, dV
 // are TT x TT combinations of the rows in registers.  Dropout on P as in the forward (same counter-based mask).
-template <int TT>
+// IO16 (round 6): bf16 q / k / v rows in, bf16 dQ / dK / dV rows out (AttnBwdArgs::io16) - the loads and the stores differ, the arithmetic
+// does not (f32 on the widened values: bit-identical to the f32 instantiation on them, gradients rounded once).
+template <int TT, bool IO16 = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a) {
     constexpr int DH = 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -619,11 +621,21 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             const float4 v = *reinterpret_cast<const float4*>(p);
             return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         };
-        qv[t] = ld(a.q + qr * a.ldq + h * DH + 4 * c, t < Sq);
+        auto ld16 = [&](const float* base, long long off, bool ok) {  // four bfloat16 values of a bf16 matrix
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+            return bf16x4_to_f32(make_uint2(ok ? w.x : 0u, ok ? w.y : 0u));
+        };
+        if constexpr (IO16) {
+            qv[t] = ld16(a.q, qr * a.ldq + h * DH + 4 * c, t < Sq);
+            kv[t] = ld16(a.k, kr * a.ldk + h * DH + 4 * c, t < Sk);
+            vv[t] = ld16(a.v, kr * a.ldv + h * DH + 4 * c, t < Sk);
+        } else {
+            qv[t] = ld(a.q + qr * a.ldq + h * DH + 4 * c, t < Sq);
+            kv[t] = ld(a.k + kr * a.ldk + h * DH + 4 * c, t < Sk);
+            vv[t] = ld(a.v + kr * a.ldv + h * DH + 4 * c, t < Sk);
+        }
         gv[t] = ld(a.dout + qr * a.ldo + h * DH + 4 * c, t < Sq);
         const float4 ov = ld(a.o + qr * a.ldo + h * DH + 4 * c, t < Sq);
-        kv[t] = ld(a.k + kr * a.ldk + h * DH + 4 * c, t < Sk);
-        vv[t] = ld(a.v + kr * a.ldv + h * DH + 4 * c, t < Sk);
         lse[t] = t < Sq ? a.lse[qr * a.H + h] : 0.f;
         dsum[t] = half_sum32((ov.x * gv[t].x + ov.y * gv[t].y) + (ov.z * gv[t].z + ov.w * gv[t].w));  // D[i] = dO[i] . O[i]
         if (t < Sq && c == 0) a.dvec[qr * a.H + h] = dsum[t];
@@ -657,7 +669,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             const float w = ds[i][j] * a.scale;
             dq.x += w * kv[j].x; dq.y += w * kv[j].y; dq.z += w * kv[j].z; dq.w += w * kv[j].w;
         }
-        *reinterpret_cast<float4*>(a.dq + (q0 + (long long)i * geo.q_rs) * a.ld_dq + h * DH + 4 * c) = dq;
+        const long long eo = (q0 + (long long)i * geo.q_rs) * a.ld_dq + h * DH + 4 * c;
+        if constexpr (IO16) *reinterpret_cast<uint2*>(a.dq16 + eo) = f32x4_to_bf16(dq.x, dq.y, dq.z, dq.w);
+        else *reinterpret_cast<float4*>(a.dq + eo) = dq;
     }
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
@@ -670,8 +684,13 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             dv.x += pw * gv[i].x; dv.y += pw * gv[i].y; dv.z += pw * gv[i].z; dv.w += pw * gv[i].w;
         }
         const long long kr = k0 + (long long)j * geo.k_rs;
-        *reinterpret_cast<float4*>(a.dk + kr * a.ld_dk + h * DH + 4 * c) = dk;
-        *reinterpret_cast<float4*>(a.dv + kr * a.ld_dv + h * DH + 4 * c) = dv;
+        if constexpr (IO16) {  // (a.dk / a.dv hold the bf16 matrices: launch_attention_bwd)
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dk) + kr * a.ld_dk + h * DH + 4 * c) = f32x4_to_bf16(dk.x, dk.y, dk.z, dk.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dv) + kr * a.ld_dv + h * DH + 4 * c) = f32x4_to_bf16(dv.x, dv.y, dv.z, dv.w);
+        } else {
+            *reinterpret_cast<float4*>(a.dk + kr * a.ld_dk + h * DH + 4 * c) = dk;
+            *reinterpret_cast<float4*>(a.dv + kr * a.ld_dv + h * DH + 4 * c) = dv;
+        }
     }
 }
 
@@ -1216,7 +1235,11 @@ static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
     const long long units = (long long)a.G * a.H;
     const unsigned blocks = (unsigned)((units + 7) / 8);
     const int need = a.Sq > a.Sk ? a.Sq : a.Sk;
-    if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.io16) {
+        if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2, true>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_small_kernel<4, true>), dim3(blocks), dim3(256), 0, s, a);
+    } else if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
     else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_bwd_small_kernel<4>), dim3(blocks), dim3(256), 0, s, a);
     SOLA_LAUNCH_CHECK();
@@ -1320,8 +1343,9 @@ void sola_attn_set_bwd_bf16_mfma(int v) { g_attn_bwd_bf16_mfma = v; }
 
 // bf16 q / k / v in and bf16 dQ / dK / dV out (AttnBwdDesc::io_bf16): the one-pass kernel's shapes, 8-value-aligned rows
 bool attention_bwd_bf16_supported(const AttnBwdDesc& d) {
-    if (!g_attn_bwd_fused || d.DH != 128 || d.Sk > 128 || (g_attn_bwd_small && d.Sq <= 4 && d.Sk <= 4)) return false;
-    if (d.ldq % 8 || d.ldk % 8 || d.ldv % 8 || d.ld_dq % 4 || d.ld_dk % 4 || d.ld_dv % 4) return false;
+    if (d.DH != 128 || d.ldq % 8 || d.ldk % 8 || d.ldv % 8 || d.ld_dq % 4 || d.ld_dk % 4 || d.ld_dv % 4) return false;
+    if (g_attn_bwd_small && d.Sq <= 4 && d.Sk <= 4) return true;  // the register kernel of sequences of <= 4 steps
+    if (!g_attn_bwd_fused || d.Sk > 128) return false;
     const bool can_chunk = d.part && d.Sk <= 64 && d.part_floats >= attention_bwd_part_floats(d.part_rows, d.G, d.H, d.Sk) && (d.q_units || (d.q_rs == 1 && d.inner == 1));
     return d.Sq <= 128 || (d.Sk <= 64 && (d.Sq <= 16 * 16 || can_chunk));
 }

@@ -70,6 +70,12 @@ def _attn_case(name):
     if name == "motion_17x12":  # 17 queries against 12 keys: one-wave backward
         R = 33
         return R, H, 17, 12, 1, (17, 0, 1), (12, 0, 1), R * 17, R * 12
+    if name == "motion_4":  # the headline shape's motion attention: T' = 4 (register kernel of <= 4 steps in the backward)
+        R, Tp = 130, 4
+        return R, H, Tp, Tp, 1, (Tp, 0, 1), (Tp, 0, 1), R * Tp, R * Tp
+    if name == "motion_3x2":
+        R = 37
+        return R, H, 3, 2, 1, (3, 0, 1), (2, 0, 1), R * 3, R * 2
     if name == "object_to_language":  # 512 queries per sample against 48 text ++ negative rows: the chunked backward
         B, M1, W = 3, 512, 48
         return B, H, M1, W, 1, (M1, 0, 1), (W, 0, 1), B * M1, B * W
@@ -79,7 +85,7 @@ def _attn_case(name):
 ATTN_CASES = ["inter_object", "inter_object_80", "motion_24", "motion_17x12", "object_to_language"]
 
 
-@pytest.mark.parametrize("case", ATTN_CASES + ["motion_12"])
+@pytest.mark.parametrize("case", ATTN_CASES + ["motion_12", "motion_4"])
 def test_attention_forward_on_the_bf16_mfma(case):
     """The shipped bf16 training forward (attn_f16.hip's kernel on v_mfma_f32_16x16x16_bf16, sola_tune "attn_bf16_mfma" 1): q k^T products of
     bfloat16 values are exact in f32, so the scores and the log-sum-exp carry f32 accumulation error only (1e-5); the probabilities enter the
@@ -156,7 +162,7 @@ def _forward_f32_mfma_case(case):
     assert float((o.cpu().double()[qr][:, sl] - p @ vd[kr][:, sl]).abs().max()) <= 2e-5
 
 
-@pytest.mark.parametrize("case", ATTN_CASES)
+@pytest.mark.parametrize("case", ATTN_CASES + ["motion_4", "motion_3x2"])
 def test_attention_backward_on_bf16_rows_equals_the_f32_kernel_and_writes_the_rounded_gradients(case):
     """(sola_tune "attn_bwd_bf16_mfma" 0: the f32 products on bfloat16 rows - bit-identical to the f32 kernel on the widened values)"""
     check(lib().sola_tune(b"attn_bwd_bf16_mfma", 0), "tune")
@@ -196,7 +202,14 @@ def _backward_case(case, exact):
                                              3 * D, 3 * D, 3 * D, ptr(dq_scr), ptr(dvec), G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2], ka[0], ka[1], ka[2],
                                              1.0 / math.sqrt(128), qrows, ptr(scr) if n_scr else None, n_scr, current_stream(q16.device)), "attention_backward_bf16")
     torch.cuda.synchronize()
-    if exact:
+    if exact and max(Sq, Sk) <= 4:
+        # the register kernel of <= 4 steps is plain f32 VALU code: its two instantiations may contract their multiply-adds differently, so
+        # the f32 gradients agree to an ulp and their bfloat16 roundings to one bfloat16 ulp (2^-8 relative)
+        for got, ref in ((g16[:, :D], dq), (gk16[:, D:2 * D], dk), (gk16[:, 2 * D:], dv)):
+            r16 = ref.to(torch.bfloat16).float()
+            assert float(((got.float() - r16).abs() - 2.0 ** -7 * r16.abs()).max()) <= 1e-12
+            assert float((got.float() != r16).float().mean()) <= 1e-3  # ... and only where the f32 value sits on a rounding boundary
+    elif exact:
         assert torch.equal(g16[:, :D], dq.to(torch.bfloat16))
         assert torch.equal(gk16[:, D:2 * D], dk.to(torch.bfloat16))
         assert torch.equal(gk16[:, 2 * D:], dv.to(torch.bfloat16))
