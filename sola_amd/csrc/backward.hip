@@ -785,9 +785,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         // d act_{i-1}[(r, ti)][ci] = sum_{kk, co} dY[(r, to)][co] w_std[co][kk][ci]: the NT kernel with the transposed-conv
         // gather over dY and the weights re-laid-out to [cin][kk*cout + co]
         float* dact = enc[0];
-        auto col2im = [&](const float* zc) -> int {
-            if (rt) return launch_col2im_ragged(zc, dact, rows_in, rt->imap[i - 1], g.cin, g.k, g.stride, g.pad, s);
-            return launch_col2im(zc, dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s);
+        auto col2im = [&](const float* zc, int z16 = 0) -> int {
+            if (rt) return launch_col2im_ragged(zc, dact, rows_in, rt->imap[i - 1], g.cin, g.k, g.stride, g.pad, s, z16);
+            return launch_col2im(zc, dact, R, t_in, p.Tl[i], g.cin, g.k, g.stride, g.pad, s, z16);
         };
         // few-sample exact-f32 backward: z = dY W over the OUTPUT rows with the standardised weights read where the forward left them
         // ([cout][k*cin] row-major = the few-row kernel's NN form: no transposed copy), then the taps are gathered - uniform batches too
@@ -816,8 +816,12 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             d.p[0] = GemmProblem{ar.get("dy_sp"), ar.get("wt_sp"), nullptr, nullptr, g.k > 1 ? ar.get("zcol") : dact};
             d.M = rows; d.N = g.k * g.cin; d.K = g.cout; d.lda = g.cout; d.ldc = g.k * g.cin;
             d.arith = lowp_arith; d.bf16 = bf; d.out_scale = 1.f; d.out_scale_dev = scal + 1;
+            // bf16 steps (train_bf16_store): the per-tap contributions leave the GEMM as bfloat16 rows - the input gradient of a bf16 conv as
+            // autocast computes it - and the gather sums the taps in f32: half the bytes written and read between the two launches
+            const int z16 = (pure && bf && g_train_bf16_store >= 3 && g.k > 1 && (g.k * g.cin) % 8 == 0) ? 1 : 0;
+            d.c_f16 = z16;
             SOLA_TRY(launch_gemm(d, s));
-            if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol")));
+            if (g.k > 1) SOLA_TRY(col2im(ar.get("zcol"), z16));
         } else if (rt) {
             // ragged, exact f32: the same decomposition - z = dY W over the OUTPUT rows (a plain GEMM on the concatenated rows, half
             // the products of the gather form for the stride-2 convs), then the taps are gathered per sequence

@@ -13,8 +13,9 @@ void sola_train_set_gn_cast(int v) { g_train_gn_cast = v; }
 extern int g_train_dw_f16;
 int g_train_attn_cast = 1;  // sola_tune "train_attn_cast": 1 = f16 / bf16 operand steps: the training forward's attention kernels also write the out-projection's operand cast; 2 = the split-f16 step too
 void sola_train_set_attn_cast(int v) { g_train_attn_cast = v; }
-int g_train_bf16_store = 2;  // sola_tune "train_bf16_store" (round 6): 1 = bf16 steps keep q / k / v and the backward's gradient operands as bfloat16 rows where the kernels take
-                             // them; 2 (default) = also the pre-norm rows of the layers (out-projection + residual -> GroupNorm); 0 = f32 storage (the round-5 step)
+int g_train_bf16_store = 3;  // sola_tune "train_bf16_store" (round 6): 1 = bf16 steps keep q / k / v and the backward's gradient operands as bfloat16 rows where the kernels take
+                             // them; 2 = also the pre-norm rows of the layers (out-projection + residual -> GroupNorm); 3 (default) = also the conv input gradients' per-tap
+                             // contributions between their GEMM and the gather; 0 = f32 storage (the round-5 step)
 int g_train_gn_stats = 1;  // sola_tune "train_gn_stats": 1 = the training forward keeps the sliced GroupNorm shape's (mean, rstd) for the backward (A/B)
 void sola_train_set_gn_stats(int v) { g_train_gn_stats = v; }
 int g_train_x16_keep = 1;  // sola_tune "train_x16_keep": 1 = 16-bit operand modes keep the forward's operand casts for the backward's dW products (ctx.h)

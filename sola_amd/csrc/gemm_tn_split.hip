@@ -136,6 +136,16 @@ __global__ __launch_bounds__(256) void cast_sp16_t_kernel(const float* __restric
 // Transposed-conv scatter as a gather: z [R*T_out][k*cin] holds, for every output step, its contribution to each of the k
 // input steps it touches (z = dY W, one GEMM); dx[(r, ti)][ci] = sum over the taps kk with (ti + pad - kk) = to * stride,
 // 0 <= to < T_out, of z[(r, to)][kk*cin + ci].  One thread per float4 of dx; fixed tap order.
+// ZB (round 6, bf16 steps): z is a bfloat16 matrix of the same shape (the GEMM that produced it wrote bfloat16 rows); the taps are summed in f32
+__device__ __forceinline__ float4 c2i_load(const float* z, long long off, bool zb) {
+    if (zb) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(z) + off);
+        return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                           __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(z + off);
+}
+template <bool ZB>
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z, float* __restrict__ dx, long long n4, int T_in, int T_out,
                                                      int cin4, int k, int stride, int pad) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -150,13 +160,14 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ z
         if (u < 0 || u % stride) continue;
         const int to = u / stride;
         if (to >= T_out) continue;
-        const float4 v = *reinterpret_cast<const float4*>(z + ((r * T_out + to) * k + kk) * (long long)(cin4 * 4) + c4 * 4);
+        const float4 v = c2i_load(z, ((r * T_out + to) * k + kk) * (long long)(cin4 * 4) + c4 * 4, ZB);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     *reinterpret_cast<float4*>(dx + i * 4) = acc;
 }
 
 // ragged batches: input row i of the conv has imap[i] = (first output row of its sequence, T_out, step ti, -)
+template <bool ZB>
 __global__ __launch_bounds__(256) void col2im_ragged_kernel(const float* __restrict__ z, float* __restrict__ dx, long long n4,
                                                             const int4* __restrict__ imap, int cin4, int k, int stride, int pad) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void col2im_ragged_kernel(const float* __restr
         if (u < 0 || u % stride) continue;
         const int to = u / stride;
         if (to >= im.y) continue;
-        const float4 v = *reinterpret_cast<const float4*>(z + (((long long)im.x + to) * k + kk) * (long long)(cin4 * 4) + c4 * 4);
+        const float4 v = c2i_load(z, (((long long)im.x + to) * k + kk) * (long long)(cin4 * 4) + c4 * 4, ZB);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     *reinterpret_cast<float4*>(dx + i * 4) = acc;
@@ -208,20 +219,22 @@ int launch_cast_f16_t(const float* in, int ld_in, void* out, long long ld_out, i
     return cast_t(bf16 ? 2 : 1, in, ld_in, static_cast<float*>(out), ld_out, rows, cols, scal, s);
 }
 
-int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s) {
+int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s, int z_bf16) {
     SOLA_ARG(z && dx && cin % 4 == 0 && k >= 1 && stride >= 1, "col2im: cin=%d k=%d stride=%d", cin, k, stride);
     const long long n4 = R * T_in * (cin / 4);
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (R * T_out * (double)k * cin + R * T_in * (double)cin));
-    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, T_in, T_out, cin / 4, k, stride, pad);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (z_bf16 ? 2.0 : 4.0) * R * T_out * (double)k * cin + 4.0 * R * T_in * (double)cin);
+    if (z_bf16) hipLaunchKernelGGL(col2im_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, T_in, T_out, cin / 4, k, stride, pad);
+    else hipLaunchKernelGGL(col2im_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, T_in, T_out, cin / 4, k, stride, pad);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }
 
-int launch_col2im_ragged(const float* z, float* dx, long long rows_in, const int4* imap, int cin, int k, int stride, int pad, hipStream_t s) {
+int launch_col2im_ragged(const float* z, float* dx, long long rows_in, const int4* imap, int cin, int k, int stride, int pad, hipStream_t s, int z_bf16) {
     SOLA_ARG(z && dx && imap && cin % 4 == 0 && k >= 1 && stride >= 1 && rows_in > 0, "col2im_ragged: cin=%d k=%d stride=%d", cin, k, stride);
     const long long n4 = rows_in * (cin / 4);
-    SolaProfScope prof(SOLA_PROF_MISC, s, 0, 4.0 * (rows_in * (double)k * cin / stride + rows_in * (double)cin));
-    hipLaunchKernelGGL(col2im_ragged_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, imap, cin / 4, k, stride, pad);
+    SolaProfScope prof(SOLA_PROF_MISC, s, 0, (z_bf16 ? 2.0 : 4.0) * rows_in * (double)k * cin / stride + 4.0 * rows_in * (double)cin);
+    if (z_bf16) hipLaunchKernelGGL(col2im_ragged_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, imap, cin / 4, k, stride, pad);
+    else hipLaunchKernelGGL(col2im_ragged_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, dx, n4, imap, cin / 4, k, stride, pad);
     SOLA_LAUNCH_CHECK();
     return SOLA_OK;
 }

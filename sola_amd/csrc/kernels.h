@@ -122,9 +122,9 @@ struct GemmTnSplitDesc {
 // device pair as for launch_cast_sp16_auto with scal[0] = max|in| already there
 int launch_cast_sp16_t(const float* in, int ld_in, float* out, long long ld_out, int rows, int cols, float* scal, hipStream_t s);
 // dx[(r, ti)][ci] = sum over taps of z[(r, to)][kk*cin + ci] (the scatter of a transposed conv, as a gather)
-int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s);
+int launch_col2im(const float* z, float* dx, long long R, int T_in, int T_out, int cin, int k, int stride, int pad, hipStream_t s, int z_bf16 = 0);  // z_bf16: z is a bfloat16 matrix (round 6)
 // ragged batches: input row i has imap[i] = (first output row of its sequence, T_out, step ti inside the sequence, -)
-int launch_col2im_ragged(const float* z, float* dx, long long rows_in, const int4* imap, int cin, int k, int stride, int pad, hipStream_t s);
+int launch_col2im_ragged(const float* z, float* dx, long long rows_in, const int4* imap, int cin, int k, int stride, int pad, hipStream_t s, int z_bf16 = 0);
 bool gemm_tn_split_supported(int M, int N, int K);
 bool gemm_tn_split_writes_rm(const GemmTnSplitDesc& d);
 size_t gemm_tn_split_scratch_bytes(int M, int N, int K, int nprob);

@@ -515,7 +515,7 @@ def test_kept_operand_casts_give_the_same_gradients_bit_for_bit(full_model, mode
         m.eval()
         m.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -542,7 +542,7 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_gradients_bit_for_
     finally:
         m.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad

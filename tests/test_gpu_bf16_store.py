@@ -257,7 +257,7 @@ def test_ragged_bf16_step_with_bf16_q_k_v_storage(variant):
     m = m.cuda().train()
     smp = synth.make_ragged_samples(cfg, 24, 2024, "cuda")
     res = {}
-    for tag, prec, store in (("f32", "f32", 2), ("operands", "bf16", 0), ("stored", "bf16", 2)):
+    for tag, prec, store in (("f32", "f32", 3), ("operands", "bf16", 0), ("stored", "bf16", 3)):
         m.precision = prec
         check(lib().sola_tune(b"train_bf16_store", store), "tune")
         try:
@@ -265,7 +265,7 @@ def test_ragged_bf16_step_with_bf16_q_k_v_storage(variant):
                 _ragged_step(m, smp, 98)  # previous step's need: the second step of a run is the first with the whole storage mode on
             res[tag] = _ragged_step(m, smp, 99)
         finally:
-            check(lib().sola_tune(b"train_bf16_store", 2), "tune")
+            check(lib().sola_tune(b"train_bf16_store", 3), "tune")
     m.precision = "f32"
     l32, g32, _ = res["f32"]
     out = {}

@@ -243,7 +243,7 @@ def test_kept_operand_casts_give_the_same_ragged_gradients_bit_for_bit(full, pre
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_x16_keep", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -267,7 +267,7 @@ def test_bf16_statistics_pass_that_is_the_cast_gives_the_same_ragged_gradients_b
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"bwd_fused_bf16_cast", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
     assert torch.equal(got[1][1], got[0][1])
     bad = [k for k in got[1][0] if not torch.equal(got[1][0][k], got[0][0][k])]
     assert not bad, bad
@@ -324,7 +324,7 @@ def test_row_major_weight_gradient_route_equals_the_transposed_copy_route_on_a_r
     finally:
         full.precision = "f32"
         _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
-        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
     worst = max((float((got[1][k].double() - got[0][k].double()).norm()) / (float(got[0][k].double().norm()) + 1e-30), k) for k in got[0])
     print("row-major vs transposed-copy dW route, worst tensor:", worst)
     assert worst[0] < 2e-5, worst
