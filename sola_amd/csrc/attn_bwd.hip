@@ -43,6 +43,9 @@ struct AttnBwdArgs {
     // register to spare)
     int io16;
     unsigned short* dq16;
+    // round 6 (with io16 and the bf16 products): dout is a BFLOAT16 matrix too (pitch ldo in values) - the out-projection's input-gradient
+    // GEMM wrote bfloat16 rows (what autocast's linear backward returns); the products take the same rounded values either way
+    int g16;
 };
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 w) {
     return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
 // are TT x TT combinations of the rows in registers.  Dropout on P as in the forward (same counter-based mask).
 // IO16 (round 6): bf16 q / k / v rows in, bf16 dQ / dK / dV rows out (AttnBwdArgs::io16) - the loads and the stores differ, the arithmetic
 // does not (f32 on the widened values: bit-identical to the f32 instantiation on them, gradients rounded once).
-template <int TT, bool IO16 = false>
+template <int TT, bool IO16 = false, bool G16 = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a) {
     constexpr int DH = 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -634,7 +637,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
             kv[t] = ld(a.k + kr * a.ldk + h * DH + 4 * c, t < Sk);
             vv[t] = ld(a.v + kr * a.ldv + h * DH + 4 * c, t < Sk);
         }
-        gv[t] = ld(a.dout + qr * a.ldo + h * DH + 4 * c, t < Sq);
+        if constexpr (G16) gv[t] = ld16(a.dout, qr * a.ldo + h * DH + 4 * c, t < Sq);
+        else gv[t] = ld(a.dout + qr * a.ldo + h * DH + 4 * c, t < Sq);
         const float4 ov = ld(a.o + qr * a.ldo + h * DH + 4 * c, t < Sq);
         lse[t] = t < Sq ? a.lse[qr * a.H + h] : 0.f;
         dsum[t] = half_sum32((ov.x * gv[t].x + ov.y * gv[t].y) + (ov.z * gv[t].z + ov.w * gv[t].w));  // D[i] = dO[i] . O[i]
@@ -718,9 +722,12 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
 // precision torch's autocast backward has; accumulation, the softmax terms, D = dO . O and the output sums stay f32.  K is NOT pre-scaled
 // here (scale * k is not a bfloat16): S and dQ take the scale behind their products.  160 -> 40 matrix instructions per (query tile, key
 // tile) at 8x the rate: the f32 matrix time was a third of the kernel on ragged batches.
-template <int NWU, bool IO16 = false, bool MF = false>
+// G16 (with MF): dO arrives as bfloat16 rows too (AttnBwdArgs::g16) - staged like q: widened into the f32 tile image (register shapes: on the
+// way in; four-wave shape: raw DMA, each thread widens its own piece and sums D = dO . O for its row with the fifteen lanes beside it).
+template <int NWU, bool IO16 = false, bool MF = false, bool G16 = false>
 __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnBwdArgs a) {
     static_assert(!MF || IO16, "the bf16 products take bf16 q / k / v");
+    static_assert(!G16 || MF, "bf16 dO goes with the bf16 products");
     typedef short short4m __attribute__((ext_vector_type(4)));
     auto pk4 = [](float x, float y, float z, float w) -> short4m { return __builtin_bit_cast(short4m, f32x4_to_bf16(x, y, z, w)); };
     auto mf16 = [](const short4m x, const short4m y, const f32x4 c) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c, 0, 0, 0); };
@@ -778,7 +785,8 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
                 if constexpr (IO16) qr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.q) + row * a.ldq + h * DH + c4 * 4);
                 else qf[u] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
-                gv[u] = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
+                if constexpr (G16) gv[u] = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.dout) + row * a.ldo + h * DH + c4 * 4));
+                else gv[u] = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
                 ov[u] = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
                 ls[u] = a.lse[row * a.H + h];
             }
@@ -814,6 +822,9 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
             __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned short*>(a.q) + row * a.ldq + h * DH + (tid & 15) * 8),
                                              (lptr_t)(Qs + buf * 16 * RP + wave * 256), 16, 0, 0);
+            if constexpr (G16)
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned short*>(a.dout) + row * a.ldo + h * DH + (tid & 15) * 8),
+                                                 (lptr_t)(Gs + buf * 16 * RP + wave * 256), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const long long row = geo.q0 + (long long)(q < geo.Sq ? q : 0) * geo.q_rs;
             const int pc = buf * 16 * RP + pr2 * (2 * RP);  // floats
             if constexpr (!IO16) __builtin_amdgcn_global_load_lds((gptr_t)(a.q + row * a.ldq + h * DH + ch * 4), (lptr_t)(Qs + pc), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + row * a.ldo + h * DH + ch * 4), (lptr_t)(Gs + pc), 16, 0, 0);
+            if constexpr (!G16) __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + row * a.ldo + h * DH + ch * 4), (lptr_t)(Gs + pc), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(a.o + row * a.ldo + h * DH + ch * 4), (lptr_t)(Os + pr2 * (2 * RP)), 16, 0, 0);
         }
         if (tid < 16) {  // the rows' log-sum-exp: 4 bytes per lane, straight into the tile's slots
@@ -836,6 +847,22 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         const int r = tid >> 4, c8 = tid & 15;
         *reinterpret_cast<float4*>(at(Qs, buf, r, 2 * c8)) = bf16x4_to_f32(make_uint2(w.x, w.y));
         *reinterpret_cast<float4*>(at(Qs, buf, r, 2 * c8 + 1)) = bf16x4_to_f32(make_uint2(w.z, w.w));
+    };
+    auto load_graw = [&](int buf) -> uint4 { return *reinterpret_cast<const uint4*>(Gs + buf * 16 * RP + tid * 4); };
+    // G16: this thread's eight dO values of row tid >> 4 into the f32 image, and the row's D = dO . O from them and the O rows the DMA landed
+    // (sixteen lanes a row: the sum closes with four exchanges inside the 16-lane group)
+    auto store_g = [&](int buf, const uint4 w) {
+        const int r = tid >> 4, c8 = tid & 15;
+        const float4 g0 = bf16x4_to_f32(make_uint2(w.x, w.y)), g1 = bf16x4_to_f32(make_uint2(w.z, w.w));
+        *reinterpret_cast<float4*>(at(Gs, buf, r, 2 * c8)) = g0;
+        *reinterpret_cast<float4*>(at(Gs, buf, r, 2 * c8 + 1)) = g1;
+        const float4 o0 = *reinterpret_cast<const float4*>(at(Os, 0, r, 2 * c8)), o1 = *reinterpret_cast<const float4*>(at(Os, 0, r, 2 * c8 + 1));
+        float d = ((o0.x * g0.x + o0.y * g0.y) + (o0.z * g0.z + o0.w * g0.w)) + ((o1.x * g1.x + o1.y * g1.y) + (o1.z * g1.z + o1.w * g1.w));
+        d += __shfl_xor(d, 8, 16);
+        d += __shfl_xor(d, 4, 16);
+        d += __shfl_xor(d, 2, 16);
+        d += __shfl_xor(d, 1, 16);
+        if (c8 == 0) dsh[buf * 16 + r] = d;
     };
     auto dvec_from_lds = [&](int buf) {  // D of a landed tile: half a wave per row, two rows per wave and pass
 #pragma unroll
@@ -924,11 +951,14 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (IO16) {
                 const uint4 w = load_qraw(0);
-                __syncthreads();  // every thread holds its raw piece
+                uint4 wg = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (G16) wg = load_graw(0);
+                __syncthreads();  // every thread holds its raw piece(s); the O rows are visible
                 store_q(0, w);
+                if constexpr (G16) store_g(0, wg);
             }
             __syncthreads();  // tile 0 landed; also: the previous group's last reduction done
-            dvec_from_lds(0);
+            if constexpr (!G16) dvec_from_lds(0);
             __syncthreads();
         } else {
             stage_direct(qt_begin * 16);
@@ -1045,13 +1075,19 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             }
             if constexpr (NWU > 1) {
                 if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed
-                uint4 qraw = make_uint4(0u, 0u, 0u, 0u);
+                uint4 qraw = make_uint4(0u, 0u, 0u, 0u), graw = qraw;
                 if constexpr (DMA && IO16) {
-                    if (more && !(a.ntile & 2)) qraw = load_qraw(cur ^ 1);  // this thread's own DMA piece
+                    if (more && !(a.ntile & 2)) {
+                        qraw = load_qraw(cur ^ 1);  // this thread's own DMA piece
+                        if constexpr (G16) graw = load_graw(cur ^ 1);
+                    }
                 }
                 __syncthreads();  // partial tiles complete (DMA: and the next tile visible; IO16: every raw q piece is in a register)
                 if constexpr (DMA && IO16) {
-                    if (more && !(a.ntile & 2)) store_q(cur ^ 1, qraw);  // nobody reads that buffer's q image before the iteration's closing barrier
+                    if (more && !(a.ntile & 2)) {
+                        store_q(cur ^ 1, qraw);  // nobody reads that buffer's q image before the iteration's closing barrier
+                        if constexpr (G16) store_g(cur ^ 1, graw);  // ... nor its dO image / D slots
+                    }
                 }
                 const int nact = min(NWU, nkt - kg);
 #pragma unroll 1
@@ -1079,7 +1115,9 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                     }
                 }
                 if constexpr (DMA) {
-                    if (more && !(a.ntile & 2)) dvec_from_lds(cur ^ 1);
+                    if constexpr (!G16) {
+                        if (more && !(a.ntile & 2)) dvec_from_lds(cur ^ 1);
+                    }
                 } else {
                     if (more && !(a.ntile & 2)) stage_direct(qt0 + 16);
                 }
@@ -1174,7 +1212,7 @@ int g_attn_bwd_ablate = 0;  // measurement only (sola_tune "attn_bwd_ablate"): 1
 int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
 
 int g_attn_bwd_bf16_mfma = 1;  // sola_tune "attn_bwd_bf16_mfma": 0 = the bf16-row launches keep the f32 products (bit-identical to the f32 kernel on the widened values)
-template <int NWU, bool IO16, bool MF = false>
+template <int NWU, bool IO16, bool MF = false, bool G16 = false>
 static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     constexpr int LD = 128 + 4;
     constexpr bool DMA = NWU == 4;  // as in the kernel
@@ -1182,12 +1220,12 @@ static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16, MF, G16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const long long blocks = (long long)a.G * a.H;
     SOLA_ARG(blocks < (1ll << 31) && chunks < 65536, "attention backward: grid too large");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16, MF>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16, MF, G16>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (a.qc_tiles) {
         // few (unit, head) pairs: the positions of a unit (at most 16 NWU keys x 64 float4) over several blocks
@@ -1216,6 +1254,11 @@ static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, long long part_rows, 
         a.qc_tiles = qc;
         chunks = ((a.Sq + 15) / 16 + qc - 1) / qc;
     }
+    if (a.io16 && a.g16) {  // (launch_attention_bwd: only with the bf16 products on)
+        if (a.Sk <= 16) return launch_bwd_fused_n<1, true, true, true>(a, chunks, s);
+        if (a.Sk <= 32) return launch_bwd_fused_n<2, true, true, true>(a, chunks, s);
+        return launch_bwd_fused_n<4, true, true, true>(a, chunks, s);
+    }
     if (a.io16 && g_attn_bwd_bf16_mfma) {
         if (a.Sk <= 16) return launch_bwd_fused_n<1, true, true>(a, chunks, s);
         if (a.Sk <= 32) return launch_bwd_fused_n<2, true, true>(a, chunks, s);
@@ -1235,7 +1278,11 @@ static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
     const long long units = (long long)a.G * a.H;
     const unsigned blocks = (unsigned)((units + 7) / 8);
     const int need = a.Sq > a.Sk ? a.Sq : a.Sk;
-    if (a.io16) {
+    if (a.io16 && a.g16) {
+        if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_small_kernel<4, true, true>), dim3(blocks), dim3(256), 0, s, a);
+    } else if (a.io16) {
         if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1, true>), dim3(blocks), dim3(256), 0, s, a);
         else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2, true>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_bwd_small_kernel<4, true>), dim3(blocks), dim3(256), 0, s, a);
@@ -1340,6 +1387,7 @@ void sola_attn_set_bwd_rag_wave(int v) { g_attn_bwd_rag_wave = v; }
 void sola_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
 void sola_attn_set_bwd_ablate(int v) { g_attn_bwd_ablate = v; }
 void sola_attn_set_bwd_bf16_mfma(int v) { g_attn_bwd_bf16_mfma = v; }
+bool attention_bwd_dout_bf16_enabled() { return g_attn_bwd_bf16_mfma != 0; }
 
 // bf16 q / k / v in and bf16 dQ / dK / dV out (AttnBwdDesc::io_bf16): the one-pass kernel's shapes, 8-value-aligned rows
 bool attention_bwd_bf16_supported(const AttnBwdDesc& d) {
@@ -1364,6 +1412,8 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.drop = d.drop;
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     a.io16 = d.io_bf16 ? 1 : 0;
+    a.g16 = d.dout_bf16 ? 1 : 0;
+    SOLA_ARG(!d.dout_bf16 || (d.io_bf16 && g_attn_bwd_bf16_mfma && d.ldo % 8 == 0), "attention backward: a bf16 dO goes with bf16 q / k / v and the bf16 products");
     a.dq16 = static_cast<unsigned short*>(d.dq16);
     if (d.io_bf16) { a.dk = static_cast<float*>(d.dk16); a.dv = static_cast<float*>(d.dv16); }
     if (d.io_bf16) SOLA_ARG(attention_bwd_bf16_supported(d) && d.dq16 && d.dk16 && d.dv16 && d.dq, "attention backward: bf16 q / k / v and gradients need the one-pass kernel's shapes");

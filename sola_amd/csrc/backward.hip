@@ -437,7 +437,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     // dX[rows, k_in] = dY[rows, n_cat] * Wcat (+ R), where wt holds Wcat^T as [k_in][n_cat]
     // cast_done: "dy_sp" already holds the row-major cast of the [rows][ldy] matrix that dY - col_off starts (grad_w_many)
     auto grad_x = [&](const float* dY, int ldy, int rows, int n_cat, int k_in, const float* Radd, float* dX, float* sc = nullptr,
-                      bool cast_done = false, int col_off = 0) -> int {
+                      bool cast_done = false, int col_off = 0, bool c16 = false) -> int {
         GemmDesc d{};
         d.nprob = 1;
         d.p[0] = GemmProblem{dY, wt, nullptr, Radd, dX};
@@ -475,6 +475,9 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             wt_sp_ready = false;
             d.p[0].W = ar.get("wt_sp");
             d.arith = lowp_arith; d.bf16 = bf; d.out_scale = 1.f / kLinScale; d.out_scale_dev = scal + 1;
+            if (c16) d.c_f16 = 1;  // dX as bfloat16 rows (pitch k_in values)
+        } else {
+            SOLA_ARG(!c16, "backward: a bf16 input gradient needs the 16-bit GEMM");
         }
         return launch_gemm(d, s);
     };
@@ -568,7 +571,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
         auto ab = [&](int a, const char* what) { return fb(abuf(true, l, kAttnShort[a], what)); };
         const float* xin = l == 0 ? fb("conv5") : fb("l" + std::to_string(l - 1) + "_o2l");
         // common tail of every sub-block: out_proj backward  (res = resid + attn * Wo^T + bo)
-        auto out_proj_bwd = [&](int a) -> int {
+        // g16 (bf16 steps, train_bf16_store 3): d(attention output) leaves the GEMM as bfloat16 rows - the attention backward reads them
+        auto out_proj_bwd = [&](int a, bool g16 = false) -> int {
             const std::string an = lp + kAttnLong[a];
             float* sc;
             SOLA_TRY(stats(dres, D, M, D, 2, &sc, true, gn16 ? dy16 : nullptr));  // gn16: the norm's backward in front of this wrote the bf16 rows
@@ -579,7 +583,11 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(grad_w_many(wo, 1, D, D, M, D, D, sc, sc != nullptr, &rm));
             SOLA_TRY(dw_end(0));
             SOLA_TRY(transpose_into(W(an + ".out_proj.weight"), D, D, D, 0));
-            return grad_x(dres, D, M, D, D, nullptr, dattn, sc, rm);
+            return grad_x(dres, D, M, D, D, nullptr, dattn, sc, rm, 0, g16);
+        };
+        auto site_g16 = [&](int a) -> bool {  // the site's q / k / v are bf16 rows, its backward kernels take a bf16 dO, and the GEMM can write it
+            return split && pure && bf && g_train_bf16_store >= 3 && (size_t)l * 3 + a < c->qkv16.size() && c->qkv16[(size_t)l * 3 + a] &&
+                   attention_bwd_dout_bf16_enabled() && D % 8 == 0 && D % (pure ? 64 : 32) == 0;
         };
 
         // (iii) object -> language: x_o2l = GN2(x_mot + attn(q(x_mot), k(lang), v(lang)) Wo)
@@ -589,7 +597,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(gn_bwd(ab(2, "res"), gbuf[cur], nullptr, lp + "norm.2", dres, B, 1, (long long)N * Tp, 0, 1, max_rows_smp, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 2 < c->res16.size() && c->res16[(size_t)l * 3 + 2],
                             ((size_t)l < c->gn2_stats.size() && c->gn2_stats[l]) ? fb("l" + std::to_string(l) + "_gn2st") : nullptr));
-            SOLA_TRY(out_proj_bwd(2));
+            const bool g16_2 = site_g16(2);
+            SOLA_TRY(out_proj_bwd(2, g16_2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
                            B, H, DH, max_rows_smp, Wn, 1, (long long)N * Tp, 0, 1, (long long)Wn, 0, 1, scale};
@@ -600,7 +609,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             ad.part_floats = attention_bwd_part_floats((long long)M, B, H, 64);
             ad.part_rows = (long long)M;
             const bool s16 = split && (size_t)l * 3 + 2 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 2];
-            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = kv16; ad.dv16 = kv16 + D; kv_src = nullptr; cast_src = nullptr; }
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = kv16; ad.dv16 = kv16 + D; kv_src = nullptr; cast_src = nullptr; ad.dout_bf16 = g16_2 ? 1 : 0; }
             SOLA_TRY(wait_side(1));  // dqkv / dlkv: the previous sub-block's weight gradients have read them
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
@@ -635,14 +644,15 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, R, 1, Tp, 0, 1, Tp, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 1 < c->res16.size() && c->res16[(size_t)l * 3 + 1]));
-            SOLA_TRY(out_proj_bwd(1));
+            const bool g16_1 = site_g16(1);
+            SOLA_TRY(out_proj_bwd(1, g16_1));
             AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
                            R, H, DH, Tp, Tp, 1, (long long)Tp, 0, 1, (long long)Tp, 0, 1, scale};
             if (rt) ad.q_units = rt->u_strk;
             ad.drop = c->attn_drop(l, 1);
             const bool s16 = split && (size_t)l * 3 + 1 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 1];
-            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; }
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; ad.dout_bf16 = g16_1 ? 1 : 0; }
             SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
@@ -674,14 +684,15 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 0 < c->res16.size() && c->res16[(size_t)l * 3 + 0]));
-            SOLA_TRY(out_proj_bwd(0));
+            const bool g16_0 = site_g16(0);
+            SOLA_TRY(out_proj_bwd(0, g16_0));
             AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
                            n_bt, H, DH, N, N, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, (long long)N * Tp, 1, Tp, scale};
             if (rt) ad.q_units = rt->u_st;
             ad.drop = c->attn_drop(l, 0);
             const bool s16 = split && (size_t)l * 3 + 0 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 0];
-            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; }
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; ad.dout_bf16 = g16_0 ? 1 : 0; }
             SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             float* sc3;

@@ -64,7 +64,7 @@ struct GldsArgs {
     // phases spread over most of a tile's time (slack * 64 clocks per k-tile at phase 1; 0 = off).  Their delay is free - they would idle at
     // the end instead - and their epilogues (and k-loops) no longer coincide with those of the full-count blocks: the HBM bursts of the
     // synchronised epilogues had every CU's matrix pipe waiting at once (sola_tune "gemm_slack_stagger"; profiles/r06_train_ragged_bf16.txt)
-    int slack;
+    // (carried as a NEGATIVE `stagger`: one more kernel argument cost the f16 conv instantiation a spilled register)
     int order;    // tile order variant (decode())
     unsigned long long* trace;  // TRACE instantiation: per (block, wave) record, see gemm_trace_words
 };
@@ -1178,11 +1178,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_split_glds_persist_kernel(con
         const int ph = (blockIdx.x >> 3) & 3;
         for (int q = 0; q < ph * a.stagger; ++q) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
     }
-    if (a.slack > 0) {
+    if constexpr (PURE == 2)  // bf16 instantiations only (the training step's): the conv instantiations of the other modes have no register left for it
+    if (a.stagger < 0) {
+        const int slack = -a.stagger;
         const int grid = (int)gridDim.x, first = total % grid;  // blocks first.. have one tile fewer (first == 0: whole rounds, nobody has slack)
         if (first != 0 && (int)blockIdx.x >= first) {
             const int nsl = grid - first, idx = (int)blockIdx.x - first;
-            const int n = (int)((long long)idx * a.slack * nk * 7 / (8LL * nsl));  // phases 0 .. 7/8 of a tile's time
+            const int n = (int)((long long)idx * slack * nk * 7 / (8LL * nsl));  // phases 0 .. 7/8 of a tile's time
             for (int q = 0; q < n; ++q) __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -2256,7 +2258,7 @@ int launch_gemm_split_glds(const GemmDesc& d, hipStream_t s) {
     a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
     a.stagger = g_gemm_stagger; a.order = g_gemm_order; a.trace = nullptr;
-    a.slack = d.arith == 2 ? g_gemm_slack_stagger : 0;
+    if (a.stagger == 0 && d.arith == 2 && d.bf16 && g_gemm_slack_stagger > 0) a.stagger = -g_gemm_slack_stagger;
     a.guard = (d.c_sp16 || d.c_f16) ? d.guard : nullptr;
     a.gn_gamma = d.gn_gamma; a.gn_beta = d.gn_beta; a.gn_tokens = d.gn_tokens; a.gn_eps = d.gn_eps; a.gn_slope = d.gn_slope;
     a.gn_icnt = d.gn_tokens > 0 ? 1.0f / (64.0f * (float)d.gn_tokens) : 0.f;

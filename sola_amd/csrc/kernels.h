@@ -250,7 +250,11 @@ struct AttnBwdDesc {
     // scratch for units whose keys exceed one key group
     int io_bf16 = 0;
     void *dq16 = nullptr, *dk16 = nullptr, *dv16 = nullptr;
+    // ... and dout is a BFLOAT16 matrix (pitch ldo, in values; ldo % 8 == 0): with io_bf16 and the bf16 products only
+    // (attention_bwd_dout_bf16_enabled())
+    int dout_bf16 = 0;
 };
+bool attention_bwd_dout_bf16_enabled();
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);
 bool attention_bwd_bf16_supported(const AttnBwdDesc& d);
 size_t attention_bwd_part_floats(long long q_rows, int G, int H, int Sk);

@@ -180,7 +180,15 @@ def test_attention_backward_on_the_bf16_mfma(case):
     _backward_case(case, exact=False)
 
 
-def _backward_case(case, exact):
+@pytest.mark.parametrize("case", ATTN_CASES + ["motion_4"])
+def test_attention_backward_with_a_bf16_output_gradient(case):
+    """dO as bfloat16 rows (the out-projection's input-gradient GEMM writes them in the bf16 step, train_bf16_store 3): the kernels widen the
+    rows where they widened q - the gradients of the f32-dO launch on the rounded values (the bf16 products round dO to bfloat16 anyway;
+    D = dO . O sees the rounded rows in both), and within the bf16-product bound of the f32 kernel."""
+    _backward_case(case, exact=False, dout_bf16=True)
+
+
+def _backward_case(case, exact, dout_bf16=False):
     G, H, Sq, Sk, inner, qa, ka, qrows, krows = _attn_case(case)
     D = H * 128
     torch.manual_seed(100 + len(case))
@@ -188,6 +196,9 @@ def _backward_case(case, exact):
     qf, kf, vf = q16.float(), k16.float(), v16.float()
     o, lse = ops.attention(qf, kf, vf, G, H, Sq, Sk, inner, qa, ka, return_lse=True)
     dout = torch.randn(qrows, D, device="cuda") * 1e-3
+    dout16 = bf(dout)
+    if dout_bf16:
+        dout = dout16.float()  # the reference launches see the rounded rows
     dq, dk, dv = ops.attention_backward(qf, kf, vf, o, dout, lse, G, H, Sq, Sk, inner, qa, ka)
     # gradients into column slices of wider matrices, as backward.hip lays them out ([rows][3D])
     g16 = torch.full((qrows, 3 * D), 7.0, device="cuda", dtype=torch.bfloat16)
@@ -197,11 +208,27 @@ def _backward_case(case, exact):
     n_scr = int(lib().sola_attention_backward_scratch_floats(qrows, G, H, Sk))
     scr = torch.empty(max(n_scr, 1), device="cuda")
     e2 = 2  # bytes per value
-    check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o), ptr(dout), D, ptr(lse),
+    dout_arg = dout16 if dout_bf16 else dout
+    check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o), C.c_void_p(dout_arg.data_ptr()), 1 if dout_bf16 else 0, D, ptr(lse),
                                              C.c_void_p(g16.data_ptr()), C.c_void_p(gk16.data_ptr() + D * e2), C.c_void_p(gk16.data_ptr() + 2 * D * e2),
                                              3 * D, 3 * D, 3 * D, ptr(dq_scr), ptr(dvec), G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2], ka[0], ka[1], ka[2],
                                              1.0 / math.sqrt(128), qrows, ptr(scr) if n_scr else None, n_scr, current_stream(q16.device)), "attention_backward_bf16")
     torch.cuda.synchronize()
+    if dout_bf16:  # the same launch with the (rounded) rows handed over as f32: identical bits
+        h16 = torch.full_like(g16, 7.0)
+        hk16 = h16 if krows == qrows else torch.full_like(gk16, 7.0)
+        check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o), C.c_void_p(dout.data_ptr()), 0, D, ptr(lse),
+                                                 C.c_void_p(h16.data_ptr()), C.c_void_p(hk16.data_ptr() + D * e2), C.c_void_p(hk16.data_ptr() + 2 * D * e2),
+                                                 3 * D, 3 * D, 3 * D, ptr(dq_scr), ptr(dvec), G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2], ka[0], ka[1], ka[2],
+                                                 1.0 / math.sqrt(128), qrows, ptr(scr) if n_scr else None, n_scr, current_stream(q16.device)), "attention_backward_bf16")
+        torch.cuda.synchronize()
+        # the four-wave shape sums D = dO . O in another order on the raw rows (sixteen lanes a row), the register kernel may contract its
+        # multiply-adds differently: f32 differences of an ulp, visible only where a gradient sits on a bfloat16 rounding boundary
+        for x, y in ((h16, g16), (hk16, gk16)):
+            assert float((x.float() - y.float()).abs().max()) <= 2.0 ** -7 * float(y.float().abs().max())
+            assert float((x != y).float().mean()) <= 5e-3
+        if case in ("motion_24", "motion_17x12"):  # register-staged shapes: the same arithmetic in the same order
+            assert torch.equal(h16, g16) and torch.equal(hk16, gk16)
     if exact and max(Sq, Sk) <= 4:
         # the register kernel of <= 4 steps is plain f32 VALU code: its two instantiations may contract their multiply-adds differently, so
         # the f32 gradients agree to an ulp and their bfloat16 roundings to one bfloat16 ulp (2^-8 relative)
