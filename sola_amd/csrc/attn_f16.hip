@@ -234,13 +234,27 @@ __global__ __launch_bounds__(256, WPU ? 2 : 4) void attn_fwd_f16_kernel(const At
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pf[r] = cvt_16<BF>(sc[t][r]);
                     // MFMA row m = c16 -> element 32 cp + 8 (m >> 2) + (m & 3) [+ 4] (PAIR), else 16 c + m
-                    const _Float16* vp = &Vs[(t * 16 + 4 * g4) * LD + (PAIR ? 8 * (c16 >> 2) + (c16 & 3) : c16)];
+                    if constexpr (PAIR) {
+                        // V^T fragment = four KEYS' values of one head-dim element per lane: gfx950's transposing LDS read hands a 16-lane group the
+                        // 4 x 16 block whose sixteen 8-byte pieces its lanes address - lane i names piece (key 4 g4 + (i >> 2), elements 8 (i & 3) ..
+                        // + 3 of the chunk) and receives, as lane m, the four keys' values of element 8 (m >> 2) + (m & 3): ONE read where four
+                        // 2-byte reads stood (128 -> 32 LDS instructions per 64-key tile and wave; tools/micro/tr_read.hip pins the lane map)
+                        const _Float16* vt = &Vs[(t * 16 + 4 * g4 + (c16 >> 2)) * LD + 8 * (c16 & 3)];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        half4v vf;
+                        for (int c = 0; c < NC; ++c) {
+                            const short4v vr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) short4v*)(vt + (c >> 1) * 32 + (c & 1) * 4));
+                            oacc[c] = mfma_16x16x16<BF>(__builtin_bit_cast(half4v, vr), pf, oacc[c]);
+                        }
+                    } else {
+                        const _Float16* vp = &Vs[(t * 16 + 4 * g4) * LD + c16];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) vf[j] = vp[j * LD + (PAIR ? (c >> 1) * 32 + (c & 1) * 4 : c * 16)];
-                        oacc[c] = mfma_16x16x16<BF>(vf, pf, oacc[c]);
+                        for (int c = 0; c < NC; ++c) {
+                            half4v vf;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) vf[j] = vp[j * LD + c * 16];
+                            oacc[c] = mfma_16x16x16<BF>(vf, pf, oacc[c]);
+                        }
                     }
                 }
             }
