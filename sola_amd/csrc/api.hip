@@ -299,6 +299,7 @@ void sola_attn_set_bwd_ablate(int v);
 void sola_attn_set_bwd_bf16_mfma(int v);
 void sola_train_set_gn_stats(int v);
 void sola_gemm_set_slack_stagger(int v);
+void sola_iou_set_packed(int v);
 void sola_attn_set_f16_small(int v);
 void sola_gn_set_h8(int v);
 void sola_attn_set_spin(int v);
@@ -427,6 +428,7 @@ extern "C" int sola_tune(const char* key, int value) {
     if (!strcmp(key, "attn_bwd_bf16_mfma")) { sola_attn_set_bwd_bf16_mfma(value); return SOLA_OK; }
     if (!strcmp(key, "train_gn_stats")) { sola_train_set_gn_stats(value); return SOLA_OK; }
     if (!strcmp(key, "gemm_slack_stagger")) { sola_gemm_set_slack_stagger(value); return SOLA_OK; }
+    if (!strcmp(key, "iou_packed")) { sola_iou_set_packed(value); return SOLA_OK; }
     if (!strcmp(key, "attn_split_min_keys")) { sola_attn_set_split_min_keys(value); return SOLA_OK; }
     if (!strcmp(key, "attn_splitm")) { sola_attn_set_splitm(value); return SOLA_OK; }
     if (!strcmp(key, "attn_reg")) { sola_attn_set_reg(value); return SOLA_OK; }

@@ -327,6 +327,7 @@ struct OnepassArgs {
     long long hw, words;
     int P, R, chunks, groups, nb;
     unsigned ticket_base;
+    unsigned acc_base;  // PK: first line of this call's pair words in g_iou_acc (pair (prompt r, track p) at acc_base + 4 r + p)
     unsigned* part;  // [groups][chunks][5 G + 4]: per prompt j of the group inter[p] (p < 4), |B_j|; then |A_p| (p < 4)
     long long *inter, *uni;
 };
@@ -339,6 +340,13 @@ constexpr int OP_MAX_CHUNKS = 128;      // the group's fold walks this many rows
 constexpr int OP_TICKET_PITCH = 32;    // a ticket per 128-byte line: agent-scope atomics on ONE line are serialised where they execute (~50 ns each:
                                        // 512 blocks on 16 neighbouring words took 25 us); a line per prompt group leaves 32 of them in a row
 __device__ unsigned g_iou_ticket[OP_TICKETS * OP_TICKET_PITCH];
+// PK (round 6): masks of fewer than 2^19 pixels (540 x 960 = 518 400) - one 64-bit word per (track, prompt) pair holds
+// [arrivals:7 | |A_p|:19 | |B_r|:19 | inter:19]; every block ADDS its partial counts and a 1 to it with an agent-scope atomic that returns the
+// old value, and the lane that sees chunks - 1 arrivals owns the totals: it writes inter / union and puts the word back to zero.  One memory
+// round trip behind the loads where the ticket form has three (row store, ticket, fold loads).  A word per 128-byte line, as the tickets.
+constexpr int OP_ACC_LINES = 16384;  // ring of pair words (2 MB); a call takes 4 R of them
+constexpr int OP_ACC_PITCH = 16;     // 64-bit words per line
+__device__ unsigned long long g_iou_acc[(size_t)OP_ACC_LINES * OP_ACC_PITCH];
 
 // Integer sum over the 64 lanes, every lane gets it: DPP adds inside the 16-lane rows, v_permlane16_swap across the row pairs,
 // v_permlane32_swap across the halves (common.h: half_sum32 / wave_sum_dpp, on integers)
@@ -355,7 +363,7 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
     return x + y;
 }
 
-template <int G>
+template <int G, bool PK = false>
 __global__ __launch_bounds__(256) void mask_iou_onepass_kernel(const OnepassArgs a) {
     __shared__ unsigned red[4][OP_MAXV];
     __shared__ unsigned tot[4][OP_MAXV];
@@ -437,6 +445,28 @@ __global__ __launch_bounds__(256) void mask_iou_onepass_kernel(const OnepassArgs
         }
     }
     __syncthreads();
+    if constexpr (PK) {
+        if ((int)threadIdx.x < GB * FUSED_MAXP) {
+            const int j = threadIdx.x / FUSED_MAXP, p = threadIdx.x - j * FUSED_MAXP;
+            const int r = r0 + j;
+            if (r < a.R && p < a.P) {
+                const unsigned long long in = (red[0][5 * j + p] + red[1][5 * j + p]) + (red[2][5 * j + p] + red[3][5 * j + p]);
+                const unsigned long long nb_ = (red[0][5 * j + 4] + red[1][5 * j + 4]) + (red[2][5 * j + 4] + red[3][5 * j + 4]);
+                const unsigned long long na = (red[0][5 * GB + p] + red[1][5 * GB + p]) + (red[2][5 * GB + p] + red[3][5 * GB + p]);
+                const unsigned long long mine = in | (nb_ << 19) | (na << 38) | (1ull << 57);
+                unsigned long long* w = &g_iou_acc[(size_t)((a.acc_base + 4u * (unsigned)r + (unsigned)p) & (OP_ACC_LINES - 1)) * OP_ACC_PITCH];
+                const unsigned long long old = __hip_atomic_fetch_add(w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(old >> 57) == a.chunks - 1) {  // every other block of this group has added its counts
+                    const unsigned long long t = old + mine;
+                    const long long ti = (long long)(t & 0x7ffffull), tb = (long long)((t >> 19) & 0x7ffffull), ta = (long long)((t >> 38) & 0x7ffffull);
+                    a.inter[(long long)p * a.R + r] = ti;
+                    a.uni[(long long)p * a.R + r] = ta + tb - ti;  // sum(A + B) - inter (seg_utils.py:133-134)
+                    __hip_atomic_store(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        return;
+    }
     unsigned* const rows = a.part + (long long)grp * a.chunks * NV;
     // ---- the group's last block folds.  No agent-scope FENCE: on gfx950 a __threadfence() is an L2 write-back + invalidate, and one per
     //      block (512-2048 of them) serialised per XCD made this kernel 3-8x slower than its predecessor (51 / 120 / 285 us at R = 16 / 64 /
@@ -497,6 +527,8 @@ size_t mask_iou_fused_scratch_bytes(int P, int R, long long words) {
     return ((size_t)9 * R + 64) * chunks * sizeof(unsigned);
 }
 
+int g_iou_packed = 1;  // sola_tune "iou_packed": 0 = the ticket form for every mask size (A/B, tests)
+void sola_iou_set_packed(int v) { g_iou_packed = v; }
 int g_iou_fused = 1;  // sola_tune "iou_fused": 0 forces the pack + pair path (A/B, tests)
 void sola_iou_set_fused(int v) { g_iou_fused = v; }
 
@@ -522,11 +554,18 @@ bool launch_mask_iou_fused(const void* am, const void* bm, int elem_type, int P,
     a.chunks = (int)chunks; a.groups = (int)groups; a.nb = nb;
     static unsigned next_ticket = 0;  // ring position (per process; every device has its own g_iou_ticket, a range unused there stays zero)
     a.ticket_base = __atomic_fetch_add(&next_ticket, (unsigned)groups, __ATOMIC_RELAXED);
+    const bool pk = g_iou_packed && hw < (1ll << 19) && chunks <= 126 && R <= OP_ACC_LINES / 16;
+    static unsigned next_acc = 0;
+    a.acc_base = pk ? __atomic_fetch_add(&next_acc, 4u * (unsigned)R, __ATOMIC_RELAXED) : 0u;
     a.part = static_cast<unsigned*>(scratch);
     a.inter = inter; a.uni = uni;
     SolaProfScope prof(SOLA_PROF_IOU_PACK, s, 0, (double)(P + R) * hw);
     const dim3 grid((unsigned)chunks, (unsigned)groups);
-    if (G == 1) hipLaunchKernelGGL(mask_iou_onepass_kernel<1>, grid, dim3(256), 0, s, a);
+    if (pk) {
+        if (G == 1) hipLaunchKernelGGL((mask_iou_onepass_kernel<1, true>), grid, dim3(256), 0, s, a);
+        else if (G == 2) hipLaunchKernelGGL((mask_iou_onepass_kernel<2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((mask_iou_onepass_kernel<4, true>), grid, dim3(256), 0, s, a);
+    } else if (G == 1) hipLaunchKernelGGL(mask_iou_onepass_kernel<1>, grid, dim3(256), 0, s, a);
     else if (G == 2) hipLaunchKernelGGL(mask_iou_onepass_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mask_iou_onepass_kernel<4>, grid, dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) {

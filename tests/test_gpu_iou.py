@@ -141,6 +141,34 @@ def test_fused_one_launch_path_equals_pack_and_pair(P, R, H, W):
         np.testing.assert_array_equal(inter.cpu().numpy(), ri)
 
 
+@pytest.mark.parametrize("R", [1, 16, 70, 300])
+def test_packed_pair_words_at_the_largest_counts(R):
+    """Round 6: masks of fewer than 2^19 pixels accumulate [arrivals | |A| | |B| | inter] per (track, prompt) pair in ONE 64-bit word (19-bit
+    fields, an atomic add that returns the old word; sola_tune "iou_packed" 0 = the ticket form).  540 x 960 = 518 400 pixels is 1.1 % below
+    the field's range: all-ones masks put every field at its largest value; and the two forms agree on random masks, call after call (the
+    words go back to zero)."""
+    from sola_amd import _lib
+
+    H, W = 540, 960
+    rng = np.random.default_rng(R)
+    A = np.ones((4, H, W), np.uint8)
+    B = np.ones((R, H, W), np.uint8)
+    if R > 2:
+        B[1] = (rng.uniform(size=(H, W)) < 0.5)
+        A[2] = (rng.uniform(size=(H, W)) < 0.9)
+    ri, ru = iou_oracle.iou_matrix(A, B)
+    assert ri.max() == H * W
+    for packed in (1, 0, 1):
+        _lib.check(_lib.lib().sola_tune(b"iou_packed", packed), "sola_tune")
+        try:
+            for _ in range(3):
+                inter, union = seg_utils.mask_iou_matrix(cuda(A), cuda(B))
+                np.testing.assert_array_equal(inter.cpu().numpy(), ri)
+                np.testing.assert_array_equal(union.cpu().numpy(), ru)
+        finally:
+            _lib.check(_lib.lib().sola_tune(b"iou_packed", 1), "sola_tune")
+
+
 def test_one_launch_kernel_on_two_streams_at_once():
     """The one-launch kernel's tickets live in the library (a ring range per launch): calls in flight on two streams at the same
     time take disjoint ranges - 200 interleaved calls of different sizes, every result equal to the pack + pair path's."""
