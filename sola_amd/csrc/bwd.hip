@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
 //   WAVE = false: one block per unit (the inter-object norm: 32 KiB, R = 8).
 //   NTHR = 1024 (block shape only): the 128 KiB object->language units at 8 float4 per lane and tensor (norm.hip's wide shape).
 template <int R, bool WAVE, int NTHR = 256>
-__global__ __launch_bounds__(NTHR) void group_norm_bwd_reg_kernel(const GnBwdArgs a, long long n_units, int groups) {
+__global__ __launch_bounds__(NTHR, (NTHR == 256 && !WAVE) ? (R <= 2 ? 8 : (R == 4 ? 6 : 1)) : 1) void group_norm_bwd_reg_kernel(const GnBwdArgs a, long long n_units, int groups) {
     __shared__ float red[NTHR / 64];
     __shared__ float part[WAVE ? 1 : NTHR * 8];
     const int f4 = a.cg >> 2;
