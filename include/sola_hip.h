@@ -159,13 +159,14 @@ int sola_attention_f16(const void* dev_q, int ldq, const void* dev_k, int ldk, c
  *     output as f32 rows (dev_o) and / or bfloat16 rows (dev_o_bf16), the log-sum-exp optional.
  *   sola_attention_backward_bf16: sola_attention_backward_ws on bfloat16 q / k / v with the gradients written as bfloat16 rows; dev_dq_scratch
  *     = an f32 [q rows, ld_dq] matrix (units of more keys than one key group accumulate dQ there).  One-pass kernel shapes and sequences
- *     of <= 4 steps.  dev_dout: f32 rows, or (dout_is_bf16, with the bf16 products on: sola_tune "attn_bwd_bf16_mfma") bfloat16 rows of pitch ldo. */
+ *     of <= 4 steps.  dev_dout: f32 rows, or (dout_is_bf16, with the bf16 products on: sola_tune "attn_bwd_bf16_mfma") bfloat16 rows of pitch ldo;
+ *     dev_o likewise (o_is_bf16, only together with dout_is_bf16). */
 int sola_gemm_nt_bf16(const void* dev_a, int lda, const void* dev_w, const float* dev_bias, const void* dev_r, int ldr, int r_is_bf16,
                       void* dev_c, int ldc, int c_is_bf16, int M, int N, int K, void* stream);
 int sola_attention_bf16(const void* dev_q, int ldq, const void* dev_k, int ldk, const void* dev_v, int ldv, float* dev_o, void* dev_o_bf16, int ldo,
                         int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride,
                         int64_t k_outer, int64_t k_inner, int64_t k_row_stride, float scale, float* dev_lse, void* stream);
-int sola_attention_backward_bf16(const void* dev_q, int ldq, const void* dev_k, int ldk, const void* dev_v, int ldv, const float* dev_o,
+int sola_attention_backward_bf16(const void* dev_q, int ldq, const void* dev_k, int ldk, const void* dev_v, int ldv, const void* dev_o, int o_is_bf16,
                                  const void* dev_dout, int dout_is_bf16, int ldo, const float* dev_lse, void* dev_dq_bf16, void* dev_dk_bf16, void* dev_dv_bf16,
                                  int ld_dq, int ld_dk, int ld_dv, float* dev_dq_scratch, float* dev_dvec, int G, int H, int head_dim, int Sq, int Sk,
                                  int inner, int64_t q_outer, int64_t q_inner, int64_t q_row_stride, int64_t k_outer, int64_t k_inner,

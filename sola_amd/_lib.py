@@ -70,7 +70,7 @@ SIGNATURES = {
     "sola_gemm_nn": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "sola_gemm_nt_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sola_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp, _vp]),
-    "sola_attention_backward_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
+    "sola_attention_backward_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                           _i64, _i64, _i64, _i64, _i64, _i64, _f, _i64, _vp, _sz, _vp]),
     "sola_attention_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "sola_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

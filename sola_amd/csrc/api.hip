@@ -589,18 +589,19 @@ extern "C" int sola_attention_bf16(const void* q, int ldq, const void* k, int ld
     SOLA_ARG(!o_bf16 || done, "attention_bf16: this shape does not write the bf16 output");
     return SOLA_OK;
 }
-extern "C" int sola_attention_backward_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* o, const void* dout, int dout_bf16, int ldo,
+extern "C" int sola_attention_backward_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int o_bf16, const void* dout, int dout_bf16, int ldo,
                                             const float* lse, void* dq16, void* dk16, void* dv16, int ld_dq, int ld_dk, int ld_dv, float* dq_scratch,
                                             float* dvec, int G, int H, int head_dim, int Sq, int Sk, int inner, int64_t q_outer, int64_t q_inner,
                                             int64_t q_rs, int64_t k_outer, int64_t k_inner, int64_t k_rs, float scale, int64_t q_rows, float* scratch,
                                             size_t scratch_floats, void* stream_) {
     SOLA_ARG(q && k && v && o && dout && lse && dq16 && dk16 && dv16 && dq_scratch && dvec, "attention_backward_bf16: null argument");
-    AttnBwdDesc d{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), o, static_cast<const float*>(dout), lse, dq_scratch, nullptr, nullptr, dvec,
+    AttnBwdDesc d{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), static_cast<const float*>(o), static_cast<const float*>(dout), lse, dq_scratch, nullptr, nullptr, dvec,
                   ldq, ldk, ldv, ldo, ld_dq, ld_dk, ld_dv, G, H, head_dim, Sq, Sk, inner, q_outer, q_inner, q_rs, k_outer, k_inner, k_rs, scale};
     d.drop = g_stage_drop;
     d.part = scratch; d.part_floats = scratch_floats; d.part_rows = q_rows;
     d.io_bf16 = 1; d.dq16 = dq16; d.dk16 = dk16; d.dv16 = dv16;
     d.dout_bf16 = dout_bf16 ? 1 : 0;
+    d.o_bf16 = o_bf16 ? 1 : 0;
     return launch_attention_bwd(d, as_stream(stream_));
 }
 

@@ -46,6 +46,7 @@ struct AttnBwdArgs {
     // round 6 (with io16 and the bf16 products): dout is a BFLOAT16 matrix too (pitch ldo in values) - the out-projection's input-gradient
     // GEMM wrote bfloat16 rows (what autocast's linear backward returns); the products take the same rounded values either way
     int g16;
+    int o16;  // ... and o too (pitch ldo in values): the forward kept only the bfloat16 rows the out-projection reads (with g16)
 };
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 w) {
     return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_blk_kernel(const AttnBwdA
 // are TT x TT combinations of the rows in registers.  Dropout on P as in the forward (same counter-based mask).
 // IO16 (round 6): bf16 q / k / v rows in, bf16 dQ / dK / dV rows out (AttnBwdArgs::io16) - the loads and the stores differ, the arithmetic
 // does not (f32 on the widened values: bit-identical to the f32 instantiation on them, gradients rounded once).
-template <int TT, bool IO16 = false, bool G16 = false>
+template <int TT, bool IO16 = false, bool G16 = false, bool O16 = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a) {
     constexpr int DH = 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -639,7 +640,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
         }
         if constexpr (G16) gv[t] = ld16(a.dout, qr * a.ldo + h * DH + 4 * c, t < Sq);
         else gv[t] = ld(a.dout + qr * a.ldo + h * DH + 4 * c, t < Sq);
-        const float4 ov = ld(a.o + qr * a.ldo + h * DH + 4 * c, t < Sq);
+        float4 ov;
+        if constexpr (O16) ov = ld16(a.o, qr * a.ldo + h * DH + 4 * c, t < Sq);
+        else ov = ld(a.o + qr * a.ldo + h * DH + 4 * c, t < Sq);
         lse[t] = t < Sq ? a.lse[qr * a.H + h] : 0.f;
         dsum[t] = half_sum32((ov.x * gv[t].x + ov.y * gv[t].y) + (ov.z * gv[t].z + ov.w * gv[t].w));  // D[i] = dO[i] . O[i]
         if (t < Sq && c == 0) a.dvec[qr * a.H + h] = dsum[t];
@@ -724,10 +727,13 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnBwdArgs a
 // tile) at 8x the rate: the f32 matrix time was a third of the kernel on ragged batches.
 // G16 (with MF): dO arrives as bfloat16 rows too (AttnBwdArgs::g16) - staged like q: widened into the f32 tile image (register shapes: on the
 // way in; four-wave shape: raw DMA, each thread widens its own piece and sums D = dO . O for its row with the fifteen lanes beside it).
-template <int NWU, bool IO16 = false, bool MF = false, bool G16 = false>
+// O16 (with G16): O is a bfloat16 matrix as well (AttnBwdArgs::o16): it only enters D = dO . O - register shapes widen it on the way in, the
+// four-wave shape fetches it as a raw DMA beside dO's and each thread multiplies its own eight values of the two.
+template <int NWU, bool IO16 = false, bool MF = false, bool G16 = false, bool O16 = false>
 __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnBwdArgs a) {
     static_assert(!MF || IO16, "the bf16 products take bf16 q / k / v");
     static_assert(!G16 || MF, "bf16 dO goes with the bf16 products");
+    static_assert(!O16 || G16, "bf16 O goes with bf16 dO");
     typedef short short4m __attribute__((ext_vector_type(4)));
     auto pk4 = [](float x, float y, float z, float w) -> short4m { return __builtin_bit_cast(short4m, f32x4_to_bf16(x, y, z, w)); };
     auto mf16 = [](const short4m x, const short4m y, const f32x4 c) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c, 0, 0, 0); };
@@ -787,7 +793,8 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
                 else qf[u] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * DH + c4 * 4);
                 if constexpr (G16) gv[u] = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.dout) + row * a.ldo + h * DH + c4 * 4));
                 else gv[u] = *reinterpret_cast<const float4*>(a.dout + row * a.ldo + h * DH + c4 * 4);
-                ov[u] = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
+                if constexpr (O16) ov[u] = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.o) + row * a.ldo + h * DH + c4 * 4));
+                else ov[u] = *reinterpret_cast<const float4*>(a.o + row * a.ldo + h * DH + c4 * 4);
                 ls[u] = a.lse[row * a.H + h];
             }
 #pragma unroll
@@ -825,6 +832,9 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             if constexpr (G16)
                 __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned short*>(a.dout) + row * a.ldo + h * DH + (tid & 15) * 8),
                                                  (lptr_t)(Gs + buf * 16 * RP + wave * 256), 16, 0, 0);
+            if constexpr (O16)
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned short*>(a.o) + row * a.ldo + h * DH + (tid & 15) * 8),
+                                                 (lptr_t)(Os + wave * 256), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
             const int pc = buf * 16 * RP + pr2 * (2 * RP);  // floats
             if constexpr (!IO16) __builtin_amdgcn_global_load_lds((gptr_t)(a.q + row * a.ldq + h * DH + ch * 4), (lptr_t)(Qs + pc), 16, 0, 0);
             if constexpr (!G16) __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + row * a.ldo + h * DH + ch * 4), (lptr_t)(Gs + pc), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.o + row * a.ldo + h * DH + ch * 4), (lptr_t)(Os + pr2 * (2 * RP)), 16, 0, 0);
+            if constexpr (!O16) __builtin_amdgcn_global_load_lds((gptr_t)(a.o + row * a.ldo + h * DH + ch * 4), (lptr_t)(Os + pr2 * (2 * RP)), 16, 0, 0);
         }
         if (tid < 16) {  // the rows' log-sum-exp: 4 bytes per lane, straight into the tile's slots
             const int q = qt0 + tid;
@@ -856,7 +866,13 @@ __global__ __launch_bounds__(64 * NWU, 2) void attn_bwd_fused_kernel(const AttnB
         const float4 g0 = bf16x4_to_f32(make_uint2(w.x, w.y)), g1 = bf16x4_to_f32(make_uint2(w.z, w.w));
         *reinterpret_cast<float4*>(at(Gs, buf, r, 2 * c8)) = g0;
         *reinterpret_cast<float4*>(at(Gs, buf, r, 2 * c8 + 1)) = g1;
-        const float4 o0 = *reinterpret_cast<const float4*>(at(Os, 0, r, 2 * c8)), o1 = *reinterpret_cast<const float4*>(at(Os, 0, r, 2 * c8 + 1));
+        float4 o0, o1;
+        if constexpr (O16) {  // this thread's own raw piece of the O rows (same lane-linear place as its dO piece)
+            const uint4 wo = *reinterpret_cast<const uint4*>(Os + tid * 4);
+            o0 = bf16x4_to_f32(make_uint2(wo.x, wo.y)); o1 = bf16x4_to_f32(make_uint2(wo.z, wo.w));
+        } else {
+            o0 = *reinterpret_cast<const float4*>(at(Os, 0, r, 2 * c8)); o1 = *reinterpret_cast<const float4*>(at(Os, 0, r, 2 * c8 + 1));
+        }
         float d = ((o0.x * g0.x + o0.y * g0.y) + (o0.z * g0.z + o0.w * g0.w)) + ((o1.x * g1.x + o1.y * g1.y) + (o1.z * g1.z + o1.w * g1.w));
         d += __shfl_xor(d, 8, 16);
         d += __shfl_xor(d, 4, 16);
@@ -1212,7 +1228,7 @@ int g_attn_bwd_ablate = 0;  // measurement only (sola_tune "attn_bwd_ablate"): 1
 int g_attn_bwd_fused = 1;  // sola_tune "attn_bwd_fused": 0 = two-pass kernels for the units of <= 128 queries and keys too (A/B)
 
 int g_attn_bwd_bf16_mfma = 1;  // sola_tune "attn_bwd_bf16_mfma": 0 = the bf16-row launches keep the f32 products (bit-identical to the f32 kernel on the widened values)
-template <int NWU, bool IO16, bool MF = false, bool G16 = false>
+template <int NWU, bool IO16, bool MF = false, bool G16 = false, bool O16 = false>
 static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     constexpr int LD = 128 + 4;
     constexpr bool DMA = NWU == 4;  // as in the kernel
@@ -1220,12 +1236,12 @@ static int launch_bwd_fused_n(const AttnBwdArgs& a, int chunks, hipStream_t s) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16, MF, G16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SOLA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NWU, IO16, MF, G16, O16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.done(dev);
     }
     const long long blocks = (long long)a.G * a.H;
     SOLA_ARG(blocks < (1ll << 31) && chunks < 65536, "attention backward: grid too large");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16, MF, G16>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NWU, IO16, MF, G16, O16>), dim3((unsigned)blocks, (unsigned)chunks), dim3(64 * NWU), lds, s, a);
     SOLA_LAUNCH_CHECK();
     if (a.qc_tiles) {
         // few (unit, head) pairs: the positions of a unit (at most 16 NWU keys x 64 float4) over several blocks
@@ -1254,6 +1270,11 @@ static int launch_bwd_fused(AttnBwdArgs a, bool can_chunk, long long part_rows, 
         a.qc_tiles = qc;
         chunks = ((a.Sq + 15) / 16 + qc - 1) / qc;
     }
+    if (a.io16 && a.g16 && a.o16) {
+        if (a.Sk <= 16) return launch_bwd_fused_n<1, true, true, true, true>(a, chunks, s);
+        if (a.Sk <= 32) return launch_bwd_fused_n<2, true, true, true, true>(a, chunks, s);
+        return launch_bwd_fused_n<4, true, true, true, true>(a, chunks, s);
+    }
     if (a.io16 && a.g16) {  // (launch_attention_bwd: only with the bf16 products on)
         if (a.Sk <= 16) return launch_bwd_fused_n<1, true, true, true>(a, chunks, s);
         if (a.Sk <= 32) return launch_bwd_fused_n<2, true, true, true>(a, chunks, s);
@@ -1278,7 +1299,11 @@ static int launch_bwd_small(const AttnBwdArgs& a, hipStream_t s) {
     const long long units = (long long)a.G * a.H;
     const unsigned blocks = (unsigned)((units + 7) / 8);
     const int need = a.Sq > a.Sk ? a.Sq : a.Sk;
-    if (a.io16 && a.g16) {
+    if (a.io16 && a.g16 && a.o16) {
+        if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1, true, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2, true, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_small_kernel<4, true, true, true>), dim3(blocks), dim3(256), 0, s, a);
+    } else if (a.io16 && a.g16) {
         if (need <= 1) hipLaunchKernelGGL((attn_bwd_small_kernel<1, true, true>), dim3(blocks), dim3(256), 0, s, a);
         else if (need <= 2) hipLaunchKernelGGL((attn_bwd_small_kernel<2, true, true>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_bwd_small_kernel<4, true, true>), dim3(blocks), dim3(256), 0, s, a);
@@ -1413,6 +1438,8 @@ int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s) {
     a.q_units = d.q_units; a.k_units = d.q_units ? (d.k_units ? d.k_units : d.q_units) : nullptr;
     a.io16 = d.io_bf16 ? 1 : 0;
     a.g16 = d.dout_bf16 ? 1 : 0;
+    a.o16 = d.o_bf16 ? 1 : 0;
+    SOLA_ARG(!d.o_bf16 || d.dout_bf16, "attention backward: a bf16 O goes with a bf16 dO");
     SOLA_ARG(!d.dout_bf16 || (d.io_bf16 && g_attn_bwd_bf16_mfma && d.ldo % 8 == 0), "attention backward: a bf16 dO goes with bf16 q / k / v and the bf16 products");
     a.dq16 = static_cast<unsigned short*>(d.dq16);
     if (d.io_bf16) { a.dk = static_cast<float*>(d.dk16); a.dv = static_cast<float*>(d.dv16); }

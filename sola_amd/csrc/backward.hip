@@ -598,6 +598,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_smp : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 2 < c->res16.size() && c->res16[(size_t)l * 3 + 2],
                             ((size_t)l < c->gn2_stats.size() && c->gn2_stats[l]) ? fb("l" + std::to_string(l) + "_gn2st") : nullptr));
             const bool g16_2 = site_g16(2);
+            SOLA_ARG(g16_2 || !((size_t)l * 3 + 2 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 2]),
+                     "backward: attention output %d of layer %d exists as bf16 rows only, but this backward takes the f32 rows (a switch changed between the forward and the backward)", 2, l);
             SOLA_TRY(out_proj_bwd(2, g16_2));
             AttnBwdDesc ad{ab(2, "q"), ab(2, "lk"), ab(2, "lv"), ab(2, "attn"), dattn, ab(2, "lse"),
                            dqkv, dlkv, dlkv + D, dvec, D, D, D, D, 3 * D, 2 * D, 2 * D,
@@ -609,7 +611,12 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             ad.part_floats = attention_bwd_part_floats((long long)M, B, H, 64);
             ad.part_rows = (long long)M;
             const bool s16 = split && (size_t)l * 3 + 2 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 2];
-            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = kv16; ad.dv16 = kv16 + D; kv_src = nullptr; cast_src = nullptr; ad.dout_bf16 = g16_2 ? 1 : 0; }
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = kv16; ad.dv16 = kv16 + D; kv_src = nullptr; cast_src = nullptr; ad.dout_bf16 = g16_2 ? 1 : 0;
+                if (g16_2 && (size_t)l * 3 + 2 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 2]) {
+                    ad.o = static_cast<const float*>(c->x16_find(ab(2, "attn"), D, 2));
+                    ad.o_bf16 = 1;
+                    SOLA_ARG(ad.o, "backward: the forward kept only the bf16 rows of attention output %d of layer %d, and they are not in the arena", 2, l);
+                } }
             SOLA_TRY(wait_side(1));  // dqkv / dlkv: the previous sub-block's weight gradients have read them
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_mot = fb(ls + "_motion");
@@ -645,6 +652,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(gn_bwd(ab(1, "res"), gbuf[cur], nullptr, lp + "norm.1", dres, R, 1, Tp, 0, 1, Tp, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_strk : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 1 < c->res16.size() && c->res16[(size_t)l * 3 + 1]));
             const bool g16_1 = site_g16(1);
+            SOLA_ARG(g16_1 || !((size_t)l * 3 + 1 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 1]),
+                     "backward: attention output %d of layer %d exists as bf16 rows only, but this backward takes the f32 rows (a switch changed between the forward and the backward)", 1, l);
             SOLA_TRY(out_proj_bwd(1, g16_1));
             AttnBwdDesc ad{ab(1, "q"), ab(1, "k"), ab(1, "v"), ab(1, "attn"), dattn, ab(1, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
@@ -652,7 +661,12 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (rt) ad.q_units = rt->u_strk;
             ad.drop = c->attn_drop(l, 1);
             const bool s16 = split && (size_t)l * 3 + 1 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 1];
-            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; ad.dout_bf16 = g16_1 ? 1 : 0; }
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; ad.dout_bf16 = g16_1 ? 1 : 0;
+                if (g16_1 && (size_t)l * 3 + 1 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 1]) {
+                    ad.o = static_cast<const float*>(c->x16_find(ab(1, "attn"), D, 2));
+                    ad.o_bf16 = 1;
+                    SOLA_ARG(ad.o, "backward: the forward kept only the bf16 rows of attention output %d of layer %d, and they are not in the arena", 1, l);
+                } }
             SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             const float* x_pe = fb(ls + "_xpe");
@@ -685,6 +699,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
                             c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 0 < c->res16.size() && c->res16[(size_t)l * 3 + 0]));
             const bool g16_0 = site_g16(0);
+            SOLA_ARG(g16_0 || !((size_t)l * 3 + 0 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 0]),
+                     "backward: attention output %d of layer %d exists as bf16 rows only, but this backward takes the f32 rows (a switch changed between the forward and the backward)", 0, l);
             SOLA_TRY(out_proj_bwd(0, g16_0));
             AttnBwdDesc ad{ab(0, "q"), ab(0, "k"), ab(0, "v"), ab(0, "attn"), dattn, ab(0, "lse"),
                            dqkv, dqkv + D, dqkv + 2 * D, dvec, D, D, D, D, 3 * D, 3 * D, 3 * D,
@@ -692,7 +708,12 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             if (rt) ad.q_units = rt->u_st;
             ad.drop = c->attn_drop(l, 0);
             const bool s16 = split && (size_t)l * 3 + 0 < c->qkv16.size() && c->qkv16[(size_t)l * 3 + 0];
-            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; ad.dout_bf16 = g16_0 ? 1 : 0; }
+            if (s16) { ad.io_bf16 = 1; ad.dq16 = dy16; ad.dk16 = dy16 + D; ad.dv16 = dy16 + 2 * D; cast_src = nullptr; ad.dout_bf16 = g16_0 ? 1 : 0;
+                if (g16_0 && (size_t)l * 3 + 0 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 0]) {
+                    ad.o = static_cast<const float*>(c->x16_find(ab(0, "attn"), D, 2));
+                    ad.o_bf16 = 1;
+                    SOLA_ARG(ad.o, "backward: the forward kept only the bf16 rows of attention output %d of layer %d, and they are not in the arena", 0, l);
+                } }
             SOLA_TRY(wait_side(1));
             SOLA_TRY(launch_attention_bwd(ad, s));
             float* sc3;

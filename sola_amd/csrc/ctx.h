@@ -83,6 +83,7 @@ struct SolaCtx {
     // out-projection GEMM reads the residual from the sub-block input's bf16 operand copy and writes bf16, the GroupNorm forward and
     // backward read bf16 (sola_tune "train_bf16_store" 2)
     std::vector<char> res16;
+    std::vector<char> attn_o16;   // per (layer, site): the last training forward wrote that attention's output as bfloat16 rows ONLY (arena slot keyed by the f32 buffer)
     std::vector<char> gn2_stats;  // per layer: the last training forward left the object->language norm's (mean, rstd) in "l<l>_gn2st" (forward.hip)
     // inference precision: 0 = exact f32 MFMA; 1 = split-f16 operands, 3 x f16 MFMA with f32 accumulation (cast.hip).
     // ctx-owned split-f16 copies of the weights: standardised conv weights (same offsets as ws_buf) and the

@@ -382,6 +382,8 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
     float* ac_dst = nullptr;
     void* ac_side = nullptr;
     bool ac_done = false;
+    int o16_site = -1;  // set by the layer loop in front of a site's attention() call: index l * 3 + a of c->attn_o16
+    c->attn_o16.assign((size_t)c->cfg.n_layers * 3, 0);
     auto attention = [&](AttnDesc& ad) -> int {
         ac_src = nullptr; ac_done = false;
         // measured on the 64-sample ragged mix (same box): f16 operands 22.67 -> 22.55 ms per step (attention +0.10 ms, cast launches -0.26 ms);
@@ -392,7 +394,16 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             ac_dst = slot16(0, ad.o, M, D);
             ac_side = side16(ad.o, M, D);
             ad.o_cast = ac_dst; ad.o_side = ac_side; ad.o_cast_fmt = pure ? 2 + bf : 1; ad.o_cast_done = &ac_done;
+            // bf16 steps (train_bf16_store 3): where the bf16-MFMA kernel writes the out-projection's operand rows itself and they have an arena
+            // slot of their own, the f32 rows are not written at all - the out-projection, its weight gradient and the attention backward
+            // (D = dO . O) read the bfloat16 rows (4 of the launch's 12 bytes per element)
+            if (o16_site >= 0 && ad.in_bf16 && g_train_bf16_store >= 3 && ac_dst != sp_a && ac_dst != sp_b && ad.o_cast_fmt == 3 &&
+                attention_bf16_mfma_supported(ad) && attention_bwd_dout_bf16_enabled()) {
+                ad.o = nullptr;
+                c->attn_o16[(size_t)o16_site] = 1;
+            }
         }
+        o16_site = -1;
         return launch_attention(ad, s);
     };
     // r16 != null (bf16 steps, sola_tune "train_bf16_store" 2): the residual is read from the sub-block input's bfloat16 operand copy and
@@ -486,6 +497,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             SOLA_TRY(linear3(xin, xin, xin, lp + "obj_attn", 3, M, ab(0, "q"), ab(0, "k"), ab(0, "v"), 0, nullptr, s16));
             ad.in_bf16 = s16 ? 1 : 0;
             c->qkv16[(size_t)l * 3 + 0] = s16;
+            o16_site = l * 3 + 0;
             SOLA_TRY(attention(ad));
         }
         const void* r16_0 = resid16(xin);
@@ -503,6 +515,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
             SOLA_TRY(linear3(x_pe, x_pe, x_obj, lp + "motion_attn", 3, M, ab(1, "q"), ab(1, "k"), ab(1, "v"), 0, nullptr, s16));
             ad.in_bf16 = s16 ? 1 : 0;
             c->qkv16[(size_t)l * 3 + 1] = s16;
+            o16_site = l * 3 + 1;
             SOLA_TRY(attention(ad));
         }
         const void* r16_1 = resid16(x_obj);
@@ -522,6 +535,7 @@ int sola_forward_impl(SolaCtx* c, const float* obj, const float* lang, int B, in
                              split ? c->scal_pair(1) : nullptr, s16));
             ad.in_bf16 = s16 ? 1 : 0;
             c->qkv16[(size_t)l * 3 + 2] = s16;
+            o16_site = l * 3 + 2;
             SOLA_TRY(attention(ad));
         }
         const void* r16_2 = resid16(x_mot);

@@ -253,6 +253,7 @@ struct AttnBwdDesc {
     // ... and dout is a BFLOAT16 matrix (pitch ldo, in values; ldo % 8 == 0): with io_bf16 and the bf16 products only
     // (attention_bwd_dout_bf16_enabled())
     int dout_bf16 = 0;
+    int o_bf16 = 0;  // ... and o as well (with dout_bf16): the forward kept only the bfloat16 output rows
 };
 bool attention_bwd_dout_bf16_enabled();
 int launch_attention_bwd(const AttnBwdDesc& d, hipStream_t s);

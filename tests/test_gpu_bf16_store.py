@@ -188,7 +188,14 @@ def test_attention_backward_with_a_bf16_output_gradient(case):
     _backward_case(case, exact=False, dout_bf16=True)
 
 
-def _backward_case(case, exact, dout_bf16=False):
+@pytest.mark.parametrize("case", ATTN_CASES + ["motion_4"])
+def test_attention_backward_with_bf16_output_rows_too(case):
+    """... and O as bfloat16 rows (the forward of the bf16 step keeps only the rows the out-projection reads): O enters D = dO . O only; the
+    launch equals the f32-O launch on the rounded rows (as above), and stays within the bf16-product bound of the f32 kernel on the f32 O."""
+    _backward_case(case, exact=False, dout_bf16=True, o_bf16=True)
+
+
+def _backward_case(case, exact, dout_bf16=False, o_bf16=False):
     G, H, Sq, Sk, inner, qa, ka, qrows, krows = _attn_case(case)
     D = H * 128
     torch.manual_seed(100 + len(case))
@@ -209,7 +216,9 @@ def _backward_case(case, exact, dout_bf16=False):
     scr = torch.empty(max(n_scr, 1), device="cuda")
     e2 = 2  # bytes per value
     dout_arg = dout16 if dout_bf16 else dout
-    check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o), C.c_void_p(dout_arg.data_ptr()), 1 if dout_bf16 else 0, D, ptr(lse),
+    o_arg = bf(o) if o_bf16 else o
+    check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, C.c_void_p(o_arg.data_ptr()), 1 if o_bf16 else 0,
+                                             C.c_void_p(dout_arg.data_ptr()), 1 if dout_bf16 else 0, D, ptr(lse),
                                              C.c_void_p(g16.data_ptr()), C.c_void_p(gk16.data_ptr() + D * e2), C.c_void_p(gk16.data_ptr() + 2 * D * e2),
                                              3 * D, 3 * D, 3 * D, ptr(dq_scr), ptr(dvec), G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2], ka[0], ka[1], ka[2],
                                              1.0 / math.sqrt(128), qrows, ptr(scr) if n_scr else None, n_scr, current_stream(q16.device)), "attention_backward_bf16")
@@ -217,7 +226,8 @@ def _backward_case(case, exact, dout_bf16=False):
     if dout_bf16:  # the same launch with the (rounded) rows handed over as f32: identical bits
         h16 = torch.full_like(g16, 7.0)
         hk16 = h16 if krows == qrows else torch.full_like(gk16, 7.0)
-        check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o), C.c_void_p(dout.data_ptr()), 0, D, ptr(lse),
+        o_ref = bf(o).float() if o_bf16 else o  # (a bf16 O: the reference launch sees the rounded rows)
+        check(lib().sola_attention_backward_bf16(ptr(q16), D, ptr(k16), D, ptr(v16), D, ptr(o_ref), 0, C.c_void_p(dout.data_ptr()), 0, D, ptr(lse),
                                                  C.c_void_p(h16.data_ptr()), C.c_void_p(hk16.data_ptr() + D * e2), C.c_void_p(hk16.data_ptr() + 2 * D * e2),
                                                  3 * D, 3 * D, 3 * D, ptr(dq_scr), ptr(dvec), G, H, 128, Sq, Sk, inner, qa[0], qa[1], qa[2], ka[0], ka[1], ka[2],
                                                  1.0 / math.sqrt(128), qrows, ptr(scr) if n_scr else None, n_scr, current_stream(q16.device)), "attention_backward_bf16")

@@ -286,6 +286,9 @@ def test_attention_written_operand_casts_give_the_same_ragged_step_bit_for_bit(f
     full.train(train)
     got = {}
     try:
+        # (bf16, train_bf16_store 3: where the attention kernel writes the bf16 rows itself it writes ONLY them, and D = dO . O sees the rounded
+        # rows - a different, equally valid step; this A/B is about the cast's route, so it runs at level 2)
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
         samples = [sample_inputs(cfg, N, T, L, 450 + i) for i, (N, T, L) in enumerate(FULL_SHAPES)]
         for fold in (2, 0):  # 2: the split-f16 step too (1, the default, covers the f16 / bf16 operand steps only)
             _lib.check(_lib.lib().sola_tune(b"train_attn_cast", fold), "tune")
@@ -297,6 +300,7 @@ def test_attention_written_operand_casts_give_the_same_ragged_step_bit_for_bit(f
         full.precision = "f32"
         full.train(was_training)
         _lib.check(_lib.lib().sola_tune(b"train_attn_cast", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
     assert torch.equal(got[2][1], got[0][1])
     bad = [k for k in got[2][0] if not torch.equal(got[2][0][k], got[0][0][k])]
     assert not bad, bad

@@ -213,7 +213,7 @@ def test_one_pass_attention_backward_code_object():
     import re
     dis, notes = _code_object_text("attn_bwd.o")
     names = re.findall(r"^[0-9a-f]+ <(\S*attn_bwd_fused_kernel\S*)>:", dis, re.M)
-    assert len(names) == 12, names  # one / two / four waves x (f32 q, k, v and gradients | bfloat16 ones, f32 products | bf16 products | bf16 products and bf16 dO: round 6)
+    assert len(names) == 15, names  # one / two / four waves x (f32 q, k, v and gradients | bfloat16 ones, f32 products | bf16 products | + bf16 dO | + bf16 O: round 6)
     for nm in names:
         body = dis[dis.index(f"<{nm}>:"):]
         body = body[:body.index("s_endpgm")]
@@ -232,7 +232,7 @@ def test_one_pass_attention_backward_code_object():
         else:
             assert body.count("v_mfma_f32_16x16x4") >= 160, (nm, body.count("v_mfma_f32_16x16x4"))
     four = [nm for nm in names if "ILi4E" in nm]
-    assert len(four) == 4
+    assert len(four) == 5
     for nm in four:
         body4 = dis[dis.index(f"<{nm}>:"):]
         assert "global_load_lds_dwordx4" in body4[:body4.index("s_endpgm")]
@@ -380,7 +380,7 @@ def test_no_kernel_outside_the_known_experiments_has_a_scratch_segment():
     known = [  # (demangled-name pattern, most spilled VGPRs, largest scratch segment in bytes)
         (r"attn_fwd_f32_kernel<128, false, [48], (true|false), 2>", 8, 32),            # round-1 shared-staging attention (the uniform training forward's motion / object->language launches): 5-6 values
         (r"attn_fwd_f32_simple_kernel<128, 16, true, true(, false)?>", 1, 8),           # training forward: one value
-        (r"attn_bwd_fused_kernel<4, true, false, false>", 2, 12),                                     # round 6, bf16 q / k / v: one pair parked in the prologue, fetched behind the tile loop
+        (r"attn_bwd_fused_kernel<4, true, false, false, false>", 2, 12),                                     # round 6, bf16 q / k / v: one pair parked in the prologue, fetched behind the tile loop
         (r"group_norm_reg_kernel<32, false, 256>", 0, 528),                             # gn_wide = 0 only
         (r"group_norm_bwd_reg_kernel<8, false, 1024>", 14, 60),                         # 128 registers at 16 waves per block
         (r"gemm_nt_split_glds_kernel<4, 2, 4, true, [012]>", 21, 56),                   # non-persistent conv shape (gemm_persist = 0)
