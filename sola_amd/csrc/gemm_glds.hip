@@ -891,8 +891,30 @@ __global__ __launch_bounds__(512) void gemm_tn_tr_kernel(const TnTrArgs t) {
     __syncthreads();
 
     GemmProblem pr{};
-    pr.C = a.part + ((long long)blockIdx.z * a.ksplit + range) * a.M * a.N;
+    const long long slab = ((long long)blockIdx.z * a.ksplit + range) * a.M * a.N;
+    // (c_f16: the partial sums leave as 16-bit rows - bfloat16 in the bf16 step: GemmTnTrDesc::part_bf16)
+    pr.C = a.c_f16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.part) + slab) : a.part + slab;
     glds_tile_epilogue<MI, WAVES_N>(a, pr, acc, lds, wave, lane, wr, wc, m0, n0);
+}
+
+// the ordered reduce of bfloat16 partial sums: C = scales * (sum over the slabs, in index order), four columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const unsigned short* __restrict__ part, int ksplit, long long mn, int N, int ldc,
+                                                                 float* c0, float* c1, float* c2, const float* __restrict__ s0,
+                                                                 const float* __restrict__ s1) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // quad index within one problem
+    if (i * 4 >= mn) return;
+    const int z = blockIdx.z;
+    const unsigned short* p = part + (long long)z * ksplit * mn + i * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ksplit; ++k) {
+        const uint2 w = *reinterpret_cast<const uint2*>(p + (long long)k * mn);
+        acc.x += __builtin_bit_cast(float, w.x << 16); acc.y += __builtin_bit_cast(float, w.x & 0xffff0000u);
+        acc.z += __builtin_bit_cast(float, w.y << 16); acc.w += __builtin_bit_cast(float, w.y & 0xffff0000u);
+    }
+    const float osc = (s0 ? *s0 : 1.f) * (s1 ? *s1 : 1.f);
+    float* c = z == 0 ? c0 : (z == 1 ? c1 : c2);
+    const long long e = i * 4, m = e / N, n = e - m * N;
+    *reinterpret_cast<float4*>(c + m * ldc + n) = make_float4(acc.x * osc, acc.y * osc, acc.z * osc, acc.w * osc);
 }
 
 
@@ -2295,6 +2317,16 @@ void gemm_tn_tr_geometry(int M, int N, int K, int nprob, int max_ranges, int& ks
     kper = (nkt + ks - 1) / ks;
     ksplit = (nkt + kper - 1) / kper;  // no empty range
 }
+int launch_splitk_reduce_bf16(const void* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
+                              const float* scale_dev, hipStream_t s) {
+    SOLA_ARG(part && ksplit >= 1 && nprob >= 1 && nprob <= 3 && N % 4 == 0 && ldc % 4 == 0, "splitk_reduce_bf16: ksplit %d nprob %d N %d", ksplit, nprob, N);
+    const long long mn = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((mn / 4 + 255) / 256), 1, nprob), dim3(256), 0, s, static_cast<const unsigned short*>(part),
+                       ksplit, mn, N, ldc, C[0], C[nprob > 1 ? 1 : 0], C[nprob > 2 ? 2 : 0], out_scale_dev, scale_dev);
+    SOLA_LAUNCH_CHECK();
+    return SOLA_OK;
+}
+
 int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s) {
     SOLA_ARG(d.nprob >= 1 && d.nprob <= 3 && d.part && d.ksplit >= 1 && d.kper >= 1, "gemm_tn_tr: nprob %d ksplit %d", d.nprob, d.ksplit);
     SOLA_ARG(gemm_tn_tr_supported(d.M, d.N, d.K, d.lda, d.ldb), "gemm_tn_tr: M=%d N=%d K=%d", d.M, d.N, d.K);
@@ -2307,6 +2339,7 @@ int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s) {
     a.out_scale = 1.f;
     a.ksplit = d.ksplit; a.part = d.part; a.nprob = d.nprob;
     a.ablate = g_gemm_ablate;
+    if (d.part_bf16) { SOLA_ARG(d.bf16 && d.K % 4 == 0, "gemm_tn_tr: bfloat16 partial sums go with bfloat16 operands"); a.c_f16 = 1; a.bf16 = 1; }
     for (int j = 0; j < 3; ++j) {
         t.A[j] = static_cast<const char*>(d.A[j < d.nprob ? j : 0]);
         t.B[j] = static_cast<const char*>(d.B[j < d.nprob ? j : 0]);

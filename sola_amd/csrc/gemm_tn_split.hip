@@ -329,7 +329,12 @@ int launch_gemm_tn_split(const GemmTnSplitDesc& d, hipStream_t s) {
         t.conv = d.conv; t.Cin = d.Cin; t.T_in = d.T_in; t.T_out = d.T_out; t.stride = d.stride; t.pad = d.pad; t.rowmap = d.rowmap;
         gemm_tn_tr_geometry(d.M, d.N, d.K, d.nprob, ks, t.ksplit, t.kper);
         t.part = slabs;
+        // bf16 steps (train_bf16_store 3): the partial sums of the k ranges leave as bfloat16 slabs (half the bytes written by the 256 blocks
+        // at once and read back by the fold); sixteen of them are summed in f32 - autocast's linear backward rounds the whole dW to bfloat16 once
+        extern int g_train_bf16_store;
+        t.part_bf16 = (bf && g_train_bf16_store >= 3 && d.K % 4 == 0) ? 1 : 0;
         SOLA_TRY(launch_gemm_tn_tr(t, s));
+        if (t.part_bf16) return launch_splitk_reduce_bf16(slabs, t.ksplit, d.nprob, d.C, d.N, d.K, d.K, scal + 1, d.scal_b ? d.scal_b + 1 : nullptr, s);
         return launch_splitk_reduce(slabs, t.ksplit, d.nprob, d.C, d.N, d.K, d.K, scal + 1, d.scal_b ? d.scal_b + 1 : nullptr, s);
     }
     const float* xt_of[3] = {nullptr, nullptr, nullptr};

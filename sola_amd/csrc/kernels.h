@@ -147,7 +147,10 @@ struct GemmTnTrDesc {
     // geometry or the ragged rowmap as in GemmDesc
     int conv, Cin, T_in, T_out, stride, pad;
     const int2* rowmap;
+    int part_bf16 = 0;  // round 6 (bf16 operands): the split-K partial sums are written as bfloat16 slabs (same element order) - launch_splitk_reduce_bf16 folds them
 };
+int launch_splitk_reduce_bf16(const void* part, int ksplit, int nprob, float* const* C, int M, int N, int ldc, const float* out_scale_dev,
+                              const float* scale_dev, hipStream_t s);
 bool gemm_tn_tr_supported(int M, int N, int K, long long lda, long long ldb);
 void gemm_tn_tr_geometry(int M, int N, int K, int nprob, int max_ranges, int& ksplit, int& kper);
 int launch_gemm_tn_tr(const GemmTnTrDesc& d, hipStream_t s);
