@@ -420,13 +420,23 @@ def test_weight_gradient_gemm_on_row_major_16bit_operands(shape, bf16):
     sc = 2.0 ** (13 - int(torch.floor(torch.log2(a.abs().max())).item()))  # cast.hip's data-dependent power-of-two scale
     ref = ((a * sc).to(dt).double().t() @ b.to(dt).double()) / sc
     try:
+        # (bf16, sola_tune "train_bf16_store" 3 - the default: the row-major kernel's split-K partial sums leave as bfloat16 slabs, folded in
+        # f32; checked below.  The f32-accumulation statement is made at level 2.)
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 2), "tune")
         for route in (1, 0):
             _lib.check(_lib.lib().sola_tune(b"train_tn_tr", route), "tune")
             out = ops.gemm_tn_f16(a, b, bf16)
             err = float((out.double() - ref).abs().max() / ref.abs().max())
             assert err < 5e-6, (route, err)
+        _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
+        if bf16:  # each of the (at most 16) partial sums rounded to bfloat16: 2^-9 of its own size, summed in f32
+            out = ops.gemm_tn_f16(a, b, bf16)
+            err = float((out.double() - ref).abs().max() / ref.abs().max())
+            assert err < 2.0 ** -7, err
     finally:
         _lib.check(_lib.lib().sola_tune(b"train_tn_tr", 1), "tune")
+        _lib.check(_lib.lib().sola_tune(b"train_bf16_store", 3), "tune")
 
 
 @pytest.mark.parametrize("geom", [(512, 32, 256, 512, 3, 2, 1), (300, 16, 512, 512, 3, 2, 1), (1024, 4, 512, 1024, 3, 1, 1), (77, 9, 256, 256, 5, 1, 2)])
