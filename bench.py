@@ -242,7 +242,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
     sola_backward + gradient norms / clip + AdamW) at up to 64 samples: exact f32, split-f16 GEMMs, f16-operand GEMMs."""
     from sola_amd import synth
     from sola_amd.loss import track_selection_losses
-    from sola_amd.module import LanguageAlignedTrackSelectionModule
+    from sola_amd.module import LanguageAlignedTrackSelectionModule, collate_ragged
 
     m = LanguageAlignedTrackSelectionModule(cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
@@ -314,7 +314,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
 
     S = 64
     smp = synth.make_ragged_samples(cfg, S, 2024, dev)
-    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    objs, langs = collate_ragged([x["obj"] for x in smp]), collate_ragged([x["lang"] for x in smp])  # as a collate function hands them over: views of one buffer
     rlabels = torch.cat([x["labels"] for x in smp])
     rpos = torch.stack([x["pos"] for x in smp])
     rflops = sum(synth.flops_per_sample(cfg, int(o.shape[0]), int(o.shape[1]), int(t.shape[0]))["total"] for o, t in zip(objs, langs))
@@ -343,7 +343,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
     # optimizer, the weight-side casts) are halved per sample
     S2 = 128
     smp = synth.make_ragged_samples(cfg, S2, 2025, dev)
-    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    objs, langs = collate_ragged([x["obj"] for x in smp]), collate_ragged([x["lang"] for x in smp])  # as a collate function hands them over: views of one buffer
     rlabels = torch.cat([x["labels"] for x in smp])
     rpos = torch.stack([x["pos"] for x in smp])
     rflops2 = sum(synth.flops_per_sample(cfg, int(o.shape[0]), int(o.shape[1]), int(t.shape[0]))["total"] for o, t in zip(objs, langs))
@@ -369,7 +369,7 @@ def training_leg(cfg, sd, dev, B, N, T, L, steps, oracle_parity=None):
         m.weights_changed()
         m.eval()
         smp = synth.make_ragged_samples(cfg, S, 2024, dev)
-        objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+        objs, langs = collate_ragged([x["obj"] for x in smp]), collate_ragged([x["lang"] for x in smp])  # as a collate function hands them over: views of one buffer
         bt = {"sample_video": list(range(S)), "videos": [o.cpu().numpy() for o in objs], "texts": [t.cpu().numpy() for t in langs]}
         ref = oracle_ragged_rows(cfg, oracle_parity, bt)
         rag["train_forward_logit_err_vs_oracle"] = {}
@@ -396,7 +396,7 @@ def dist_legs(cfg, sd, dev, world, rank, steps):
     from sola_amd import dist as sdist
     from sola_amd import synth
     from sola_amd.loss import track_selection_losses, track_selection_losses_ragged
-    from sola_amd.module import LanguageAlignedTrackSelectionModule
+    from sola_amd.module import LanguageAlignedTrackSelectionModule, collate_ragged  # noqa: F401
 
     def max_over_ranks(x):
         t = torch.tensor([x], device=dev, dtype=torch.float64)
@@ -454,7 +454,7 @@ def dist_legs(cfg, sd, dev, world, rank, steps):
     m.eval()
     S = 64
     smp = synth.make_ragged_samples(cfg, S, 3000 + rank, dev)
-    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    objs, langs = collate_ragged([x["obj"] for x in smp]), collate_ragged([x["lang"] for x in smp])  # as a collate function hands them over: views of one buffer
     labels = torch.cat([x["labels"] for x in smp]); pos = torch.stack([x["pos"] for x in smp])
 
     def rstep():
@@ -549,6 +549,7 @@ def f16_storage_leg(cfg, m, dev, steps):
     # the ragged path under the same mode (round 3: inference.py / eval.py call only this path): the MeViS-like mix, four
     # expressions per video, against the same call in the default split-f16 mode
     from sola_amd.loss import track_selection_losses_ragged
+    from sola_amd.module import collate_ragged
 
     rng = np.random.Generator(np.random.PCG64(2024))
     S, per_video = 128, 4
@@ -556,8 +557,8 @@ def f16_storage_leg(cfg, m, dev, steps):
     shapes = [(int(rng.integers(8, 81)), int(rng.integers(20, 201))) for _ in range(S // per_video)]
     lens = [int(rng.integers(4, 25)) for _ in range(S)]
     sample_video = [i // per_video for i in range(S)]
-    videos = [torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)).to(dev) for n, t in shapes]
-    texts = [torch.from_numpy(rng.standard_normal((ln, D)).astype(np.float32)).to(dev) for ln in lens]
+    videos = collate_ragged([torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)) for n, t in shapes], dev)
+    texts = collate_ragged([torch.from_numpy(rng.standard_normal((ln, D)).astype(np.float32)) for ln in lens], dev)
     labels = torch.cat([torch.from_numpy((rng.uniform(size=shapes[v][0]) < 0.2).astype(np.float32)) for v in sample_video]).to(dev)
     pos = torch.stack([t.mean(0) for t in texts], 0)
 
@@ -591,6 +592,7 @@ def ragged_leg(cfg, m, dev, steps, uniform_model_tflops, oracle_parity=None):
     library's sola_forward), `executed` = with the text-independent half computed once per video."""
     from sola_amd import ops, synth
     from sola_amd.loss import track_selection_losses_ragged
+    from sola_amd.module import collate_ragged
 
     S = 128
     out = {"samples_per_launch": S, "shapes": "N~U[8,80], T~U[20,200], L~U[4,24], seed 2024"}
@@ -598,8 +600,8 @@ def ragged_leg(cfg, m, dev, steps, uniform_model_tflops, oracle_parity=None):
     for tag, bt in batches.items():
         per_video, shapes, lens, sample_video = bt["per_video"], bt["shapes"], bt["lens"], bt["sample_video"]
         V = S // per_video
-        videos = [torch.from_numpy(v).to(dev) for v in bt["videos"]]
-        texts = [torch.from_numpy(t).to(dev) for t in bt["texts"]]
+        videos = collate_ragged([torch.from_numpy(v) for v in bt["videos"]], dev)  # views of one buffer (a collated batch)
+        texts = collate_ragged([torch.from_numpy(t) for t in bt["texts"]], dev)
         labels = torch.cat([torch.from_numpy(l) for l in bt["labels"]]).to(dev)
         pos = torch.stack([t.mean(0) for t in texts], 0)
 
@@ -695,7 +697,7 @@ def call_pattern_leg(cfg, sd, dev, steps):
     the headline one (C0 (T=8, N=8), C1 (T=32, N=16) and (T=32, N=80)), each in both arithmetic modes.  S=1: wall time per call
     incl. the host side (forward + selection, the output left on the device).  Uniform shapes: samples/s at a batch of ~16 K layer tokens."""
     from sola_amd import ops, synth
-    from sola_amd.module import LanguageAlignedTrackSelectionModule
+    from sola_amd.module import LanguageAlignedTrackSelectionModule, collate_ragged  # noqa: F401
 
     m = LanguageAlignedTrackSelectionModule(cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
@@ -911,7 +913,7 @@ def main():
 
     from sola_amd import _lib, ops, synth
     from sola_amd.loss import track_selection_losses
-    from sola_amd.module import LanguageAlignedTrackSelectionModule
+    from sola_amd.module import LanguageAlignedTrackSelectionModule, collate_ragged  # noqa: F401
 
     for kv in args.tune:  # A/B measurements only; the line says so (config.tune)
         key, val = kv.split("=")

@@ -52,6 +52,38 @@ class ObjectLanguageAlignmentLayer(nn.Module):
         raise SolaError("parameter holder: the layer runs inside libsola_hip (sola_forward)")
 
 
+def _rows_of(tensors, cols):
+    """The tensors of a ragged batch as ONE [rows, cols] f32 matrix.  Tensors that already lie back to back in one buffer (a collated batch:
+    ``collate_ragged``) are taken as they are - no copy; anything else is concatenated (torch.cat: a pass over the batch's bytes)."""
+    t0 = tensors[0]
+    ok = all(t.dtype == torch.float32 and t.is_contiguous() and t.device == t0.device for t in tensors)
+    if ok:
+        end = t0.data_ptr()
+        for t in tensors:
+            if t.data_ptr() != end or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr():
+                ok = False
+                break
+            end += t.numel() * 4
+    if ok:
+        rows = sum(int(t.numel()) for t in tensors) // cols
+        return torch.as_strided(t0, (rows, cols), (cols, 1), t0.storage_offset())
+    return torch.cat([t.reshape(-1, cols) for t in tensors], 0).to(torch.float32).contiguous()
+
+
+def collate_ragged(tensors, device=None):
+    """Views of ONE contiguous buffer holding the given per-sample tensors back to back (what a collate function hands the training loop):
+    ``forward_ragged`` / ``train_step_ragged`` then read the buffer where it lies instead of concatenating the batch on the device."""
+    flat = torch.cat([t.reshape(-1) for t in tensors]).to(torch.float32)
+    if device is not None:
+        flat = flat.to(device)
+    out, o = [], 0
+    for t in tensors:
+        n = int(t.numel())
+        out.append(flat[o:o + n].view(t.shape))
+        o += n
+    return out
+
+
 class LanguageAlignedTrackSelectionModule(nn.Module):
     """``m(object_tokens [B,N,T,d], lang_tokens [B,L,D]) -> (score_map [B,N], score_tokens [B,N,D])``
     (module/module.py:54-162)."""
@@ -352,8 +384,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         S = len(lang_tokens)
         d, D = self.object_token_dim, self.lang_token_dim
         dev = object_tokens[0].device
-        obj = torch.cat([t.reshape(-1, d) for t in object_tokens], 0).to(torch.float32).contiguous()
-        lang = torch.cat(list(lang_tokens), 0).to(torch.float32).contiguous()
+        obj = _rows_of(object_tokens, d)
+        lang = _rows_of(list(lang_tokens), D)
         batch = self._ragged_batch_struct(object_tokens, lang_tokens, sample_video)
         self._ensure_ctx(dev)
         self._bind_weights()
@@ -456,8 +488,8 @@ class LanguageAlignedTrackSelectionModule(nn.Module):
         S = len(lang_tokens)
         d, D = self.object_token_dim, self.lang_token_dim
         dev = object_tokens[0].device
-        obj = torch.cat([t.detach().reshape(-1, d) for t in object_tokens], 0).to(torch.float32).contiguous()
-        lang = torch.cat([t.detach() for t in lang_tokens], 0).to(torch.float32).contiguous()
+        obj = _rows_of([t.detach() for t in object_tokens], d)
+        lang = _rows_of([t.detach() for t in lang_tokens], D)
         batch = self._ragged_batch_struct(object_tokens, lang_tokens, list(range(S)))
         self._ensure_ctx(dev)
         self._bind_weights(train=True)

@@ -298,3 +298,23 @@ def test_benched_ragged_batch_every_logit_vs_oracle(full, tag):
     print(f"{tag} {full.precision} vs REFERENCE: worst logit error {er.max():.3e}, mean per-sample worst {perr.mean():.3e}, samples > 5e-4: {(perr > 5e-4).sum()}")
     np.testing.assert_array_equal((torch.sigmoid(torch.from_numpy(got)) > 0.5).numpy(), gold[f"rag_infer.{tag}.selected"])
     assert er.max() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_collated_batch_gives_the_same_ragged_forward_bit_for_bit():
+    """A batch handed over as views of one buffer (module.collate_ragged) is read where it lies - the same call on the same values as the
+    list of separate tensors that forward_ragged concatenates."""
+    import torch
+    from sola_amd import synth
+    from sola_amd.module import LanguageAlignedTrackSelectionModule, collate_ragged
+
+    cfg = synth.DEFAULT_MODEL_CFG
+    m = LanguageAlignedTrackSelectionModule(cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, 42).items()}, strict=True)
+    m = m.cuda().eval()
+    smp = synth.make_ragged_samples(cfg, 6, 77, "cuda", n_range=(3, 12), t_range=(9, 40))
+    objs, langs = [x["obj"] for x in smp], [x["lang"] for x in smp]
+    with torch.no_grad():
+        a_map, a_tok = m.forward_ragged(objs, langs)
+        b_map, b_tok = m.forward_ragged(collate_ragged(objs), collate_ragged(langs))
+    assert all(torch.equal(x, y) for x, y in zip(a_map, b_map)) and all(torch.equal(x, y) for x, y in zip(a_tok, b_tok))

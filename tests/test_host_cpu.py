@@ -454,3 +454,23 @@ def test_default_precision_is_the_range_guarded_split_mode(monkeypatch):
     assert m2.precision == "f32" and m2.train_precision == "f32"
     monkeypatch.setenv("SOLA_TRAIN_PRECISION", "f16x3")
     assert LanguageAlignedTrackSelectionModule(synth.SMALL_MODEL_CFG).train_precision == "f16x3"
+
+
+def test_collated_ragged_batches_are_read_where_they_lie():
+    """module.collate_ragged hands back views of ONE buffer; module._rows_of (what forward_ragged / the ragged training step pass to the C
+    ABI) takes such a batch without a copy and concatenates anything else."""
+    import torch
+    from sola_amd.module import _rows_of, collate_ragged
+
+    a = [torch.randn(3, 5, 4), torch.randn(2, 7, 4), torch.randn(1, 1, 4)]
+    v = collate_ragged(a)
+    assert all(torch.equal(x, y) for x, y in zip(a, v))
+    r = _rows_of(v, 4)
+    assert r.data_ptr() == v[0].data_ptr() and r.shape == (3 * 5 + 2 * 7 + 1, 4)
+    assert torch.equal(r, torch.cat([t.reshape(-1, 4) for t in a]))
+    assert torch.equal(_rows_of(a, 4), r)                     # separate tensors: concatenated
+    gap = _rows_of([v[0], v[2]], 4)                           # views with a gap between them: concatenated
+    assert gap.shape == (16, 4) and gap.data_ptr() != v[0].data_ptr()
+    assert _rows_of([v[1], v[0]], 4).data_ptr() != v[1].data_ptr()  # out of order
+    half = [t.double() for t in v]
+    assert _rows_of(half, 4).dtype == torch.float32

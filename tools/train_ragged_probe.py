@@ -13,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sola_amd import _lib, synth  # noqa: E402
 from sola_amd.loss import track_selection_losses_ragged  # noqa: E402
-from sola_amd.module import LanguageAlignedTrackSelectionModule  # noqa: E402
+from sola_amd.module import LanguageAlignedTrackSelectionModule, collate_ragged  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f32", "f16x3", "f16"]
@@ -26,7 +26,7 @@ m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_di
 m = m.cuda().train()
 opt = torch.optim.AdamW(m.parameters(), lr=1e-5, fused=True)
 samples = synth.make_ragged_samples(cfg, S, 2024, "cuda")
-objs, langs = [s["obj"] for s in samples], [s["lang"] for s in samples]
+objs, langs = collate_ragged([s["obj"] for s in samples]), collate_ragged([s["lang"] for s in samples])  # views of one buffer, as a collate function hands them over
 labels = torch.cat([s["labels"] for s in samples])
 pos = torch.stack([s["pos"] for s in samples])
 rows = sum(int(o.shape[0] * o.shape[1]) for o in objs)
