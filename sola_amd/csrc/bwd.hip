@@ -241,6 +241,13 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && !WAVE) ? (R <= 2 ? 8 : (R == 
     const int ch = g * a.cg + c4 * 4;
     const float cnt = (float)ntok * (float)a.cg;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (R <= 4: the affine parameters beside the unit's rows, not behind the two reductions - one memory round trip less on the block's
+    // critical path; the 8-slot shapes have no register to carry them across the reductions)
+    float4 ga = z, be = z;
+    if constexpr (R <= 4) {
+        ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+        be = *reinterpret_cast<const float4*>(a.beta + ch);
+    }
     float4 xv[R], dv[R];
     float s = 0.f;
     // Token slots beyond the unit load token 0 (always there) and are zeroed by a select: written as `t < ntok ? *(float4*)p : z` each
@@ -293,8 +300,10 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && !WAVE) ? (R <= 2 ? 8 : (R == 
         }
     const float var = (WAVE ? wave_sum(q) : bwd_block_sum<NTHR>(q, red)) / cnt;
     const float rstd = 1.0f / sqrtf(var + a.eps);
-    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
-    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    if constexpr (R > 4) {
+        ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+        be = *reinterpret_cast<const float4*>(a.beta + ch);
+    }
     float s1 = 0.f, s2 = 0.f;
     float4 dgam = z, dbet = z;
 #pragma unroll

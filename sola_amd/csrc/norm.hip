@@ -335,6 +335,12 @@ __global__ __launch_bounds__(NTHR) void group_norm_reg_kernel(const GnArgs a, lo
     const int ntok = un.ntok;
     const int ch = g * a.cg + c4 * 4;
     const float cnt = (float)ntok * (float)a.cg;
+    // the affine parameters (and the positional row) are fetched HERE, beside the unit's rows: behind the two reductions - where they are
+    // first used, and where the block barriers pin them - they were one more memory round trip on every block's critical path (round 6)
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch);
     float4 v[R];
     gn_load_slots<R>(a, v, row0, tok_stride, ntok, tl, tpp, ch);
     float s = 0.f;
@@ -351,10 +357,6 @@ __global__ __launch_bounds__(NTHR) void group_norm_reg_kernel(const GnArgs a, lo
     }
     const float var = (WAVE ? wave_sum(q) : block_sum_n<NTHR>(q, red)) / cnt;  // biased, as nn.GroupNorm
     const float rstd = 1.0f / sqrtf(var + a.eps);
-    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + ch);
-    const float4 be = *reinterpret_cast<const float4*>(a.beta + ch);
-    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.y2) pe = *reinterpret_cast<const float4*>(a.pe + (long long)un.pe_row * a.C + ch);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tl + r * tpp;
