@@ -501,9 +501,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     auto gn_bwd = [&](const float* xpre, const float* dy, const float* dy2, const std::string& wname, float* dx, int n_inst,
                       int inner, long long outer, long long inner_stride, long long tok_stride, int ntok, int C, int groups,
                       int leaky, const DropoutCfg* drop, const int4* units = nullptr, void* dx16 = nullptr, bool x_bf16 = false,
-                      const void* stats_in = nullptr) -> int {
+                      const void* stats_in = nullptr, bool dy2_16 = false) -> int {
         GroupNormBwdDesc d{};
         d.stats_in = stats_in;
+        d.dy2_bf16 = dy2_16 ? 1 : 0;
         if (drop) d.drop = *drop;
         d.units = units;
         d.dx16 = dx16;
@@ -563,6 +564,7 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
     float* dlang = ar.get("dlang");
     float* dvec = ar.get("dvec");
     float* egrad = ar.get("e");
+    bool egrad_bf16 = false;  // the motion sub-block's backward left d(x_obj + pe) in `egrad` as bfloat16 rows (bf16 steps)
     bool dlang_init = false;
 
     for (int l = c->cfg.n_layers - 1; l >= 0; --l) {
@@ -687,7 +689,10 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             SOLA_TRY(dw_end(1));
             SOLA_TRY(transpose_into(W(an + ".q_proj.weight"), D, D, 2 * D, 0));
             SOLA_TRY(transpose_into(W(an + ".k_proj.weight"), D, D, 2 * D, D));
-            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad, sc3, rm3, 0));  // d(x_obj + pe) = dq Wq + dk Wk
+            // (bf16 steps, train_bf16_store 3: this branch gradient leaves its GEMM as bfloat16 rows; the inter-object norm's backward adds it as dy2)
+            const bool e16 = split && pure && bf && g_train_bf16_store >= 3 && D % 8 == 0 && group_norm_bwd_dy2_bf16_supported(N, D, c->cfg.n_groups_module);
+            egrad_bf16 = e16;
+            SOLA_TRY(grad_x(dqkv, 3 * D, M, 2 * D, D, nullptr, egrad, sc3, rm3, 0, e16));  // d(x_obj + pe) = dq Wq + dk Wk
             SOLA_TRY(transpose_into(W(an + ".v_proj.weight"), D, D, D, 0));
             SOLA_TRY(grad_x(dqkv + 2 * D, 3 * D, M, D, D, dres, gbuf[1 - cur], sc3, rm3, 2 * D));  // d x_obj (direct) = dres + dv Wv
             cur = 1 - cur;
@@ -697,7 +702,8 @@ static int backward_impl(SolaCtx* c, const float* d_score_map, const float* d_sc
             const std::string an = lp + "obj_attn";
             if (group) { dres = keep((size_t)M * D); dqkv = keep((size_t)M * 3 * D); }
             SOLA_TRY(gn_bwd(ab(0, "res"), gbuf[cur], egrad, lp + "norm.0", dres, n_bt, rt ? 1 : Tp, (long long)N * Tp, 1, Tp, N, D,
-                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 0 < c->res16.size() && c->res16[(size_t)l * 3 + 0]));
+                            c->cfg.n_groups_module, 0, nullptr, rt ? rt->u_st : nullptr, gn16 ? dy16 : nullptr, (size_t)l * 3 + 0 < c->res16.size() && c->res16[(size_t)l * 3 + 0],
+                            nullptr, egrad_bf16));
             const bool g16_0 = site_g16(0);
             SOLA_ARG(g16_0 || !((size_t)l * 3 + 0 < c->attn_o16.size() && c->attn_o16[(size_t)l * 3 + 0]),
                      "backward: attention output %d of layer %d exists as bf16 rows only, but this backward takes the f32 rows (a switch changed between the forward and the backward)", 0, l);

@@ -23,7 +23,12 @@ struct GnBwdArgs {
     unsigned short* dx16;  // optional (round 6): dx once more as bfloat16 rows of the same pitch - the operand of the GEMMs that consume it
     int x_bf16;            // round 6: x (the saved pre-norm rows) is a bfloat16 matrix of the same pitch
     const float2* stats;   // round 6, three-pass kernel: the forward's (mean, rstd) per (instance, group) - no statistics walks (GroupNormBwdDesc::stats_in)
+    int dy2_bf16;          // round 6: dy2 is a bfloat16 matrix of the same pitch (a branch gradient written by its GEMM as bfloat16 rows)
 };
+__device__ __forceinline__ float4 gnb_widen(const uint2 w) {
+    return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+}
 __device__ __forceinline__ float4 gnb_load_x(const GnBwdArgs& a, long long off) {
     if (a.x_bf16) {
         const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + off);
@@ -156,7 +161,13 @@ __global__ __launch_bounds__(NTHR) void group_norm_bwd_kernel(const GnBwdArgs a)
                 }
                 dr[u] = *reinterpret_cast<const float4*>(a.dy + offs[u]);
             }
-            if (a.dy2) {
+            if (a.dy2 && a.dy2_bf16) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 e = gnb_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.dy2) + offs[u]));
+                    dr[u].x += e.x; dr[u].y += e.y; dr[u].z += e.z; dr[u].w += e.w;
+                }
+            } else if (a.dy2) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float4 e = *reinterpret_cast<const float4*>(a.dy2 + offs[u]);
@@ -280,7 +291,17 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && !WAVE) ? (R <= 2 ? 8 : (R == 
     else load_all(std::false_type{});
 #pragma unroll
     for (int r = 0; r < R; ++r) s += (xv[r].x + xv[r].y) + (xv[r].z + xv[r].w);
-    if (a.dy2) {  // block-uniform: the second gradient of the inter-object norm (x_obj feeds x_obj + pe too)
+    if (NTHR != 1024 && a.dy2 && a.dy2_bf16) {  // (the format decided around the batch of loads, as for x; the 1024-thread shape - the
+                                                  // object->language norm's - never has a second gradient and no register for the code)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = tl + r * tpp;
+            const bool ok = t < ntok;
+            const long long off = (row0 + (long long)(ok ? t : 0) * tok_stride) * a.C + ch;
+            const float4 e = gnb_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.dy2) + off));
+            dv[r].x += ok ? e.x : 0.f; dv[r].y += ok ? e.y : 0.f; dv[r].z += ok ? e.z : 0.f; dv[r].w += ok ? e.w : 0.f;
+        }
+    } else if (a.dy2) {  // block-uniform: the second gradient of the inter-object norm (x_obj feeds x_obj + pe too)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int t = tl + r * tpp;
@@ -688,6 +709,22 @@ int launch_segsum_rows(const float* in, float* out, const int32_t* off, int segm
 int g_gn_bwd_reg = 1;  // sola_tune "gn_bwd_reg": 0 = three-pass kernel for every shape (A/B)
 void sola_gn_set_bwd_reg(int v) { g_gn_bwd_reg = v; }
 
+// which kernel launch_group_norm_bwd picks for units of at most `ntok` tokens: the 1024-thread register shape (17..32 float4 per lane of a
+// 256-thread block) has no bfloat16-dy2 code
+static bool gn_bwd_takes_reg1024(int ntok, int cg) {
+    const int f4 = cg / 4;
+    const bool pow2 = (f4 & (f4 - 1)) == 0;
+    if (!g_gn_bwd_reg || !pow2 || f4 > 256) return false;
+    const int rw = f4 <= 64 ? (ntok + 64 / f4 - 1) / (64 / f4) : 1 << 30;
+    const int rb = (ntok + 256 / f4 - 1) / (256 / f4);
+    if (rw <= 4 || rb <= 8) return false;
+    if (rb <= 16 && 512 % f4 == 0) return false;
+    return rb <= 32 && 1024 % f4 == 0;
+}
+bool group_norm_bwd_dy2_bf16_supported(int ntok, int C, int groups) {
+    return groups > 0 && C % groups == 0 && (C / groups) % 4 == 0 && !gn_bwd_takes_reg1024(ntok, C / groups);
+}
+
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     SOLA_ARG(d.groups > 0 && d.C % d.groups == 0, "group_norm_bwd: C=%d groups=%d", d.C, d.groups);
     const int cg = d.C / d.groups;
@@ -700,6 +737,8 @@ int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s) {
     a.dx16 = static_cast<unsigned short*>(d.dx16);
     a.x_bf16 = d.x_bf16;
     a.stats = static_cast<const float2*>(d.stats_in);
+    a.dy2_bf16 = (d.dy2 && d.dy2_bf16) ? 1 : 0;
+    SOLA_ARG(!a.dy2_bf16 || group_norm_bwd_dy2_bf16_supported(d.ntok, d.C, d.groups), "group_norm_bwd: a bfloat16 dy2 is not read by this shape's kernel");
     const double elems = (double)d.n_inst * d.ntok * d.C;
     SolaProfScope prof(SOLA_PROF_NORM, s, 20.0 * elems, (d.dy2 ? 16.0 : 12.0) * elems);
     const int f4 = cg / 4;

@@ -286,8 +286,10 @@ struct GroupNormBwdDesc {
     // optional (round 6): (mean, rstd) of every (instance, group) unit as the forward computed them (GroupNormDesc::stats_out) - the
     // three-pass kernel of the largest units then skips its two statistics walks over x (the register shapes recompute: x is in registers)
     const void* stats_in = nullptr;
+    int dy2_bf16 = 0;  // round 6: dy2 is a bfloat16 matrix (same pitch)
 };
 int launch_group_norm_bwd(const GroupNormBwdDesc& d, hipStream_t s);
+bool group_norm_bwd_dy2_bf16_supported(int ntok, int C, int groups);  // the shapes whose kernels read a bfloat16 dy2 (all but the 1024-thread register shape)
 struct WsBwdLayer {
     const float* w;      // [cout, cin, k] original weights
     const float* dwstd;  // [cout, k*cin] gradient wrt the standardised weights (GEMM layout)
